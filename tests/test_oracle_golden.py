@@ -1,0 +1,156 @@
+"""Pin the CPU oracle (oracle/hotpath.py) against golden vectors produced by the reference
+itself (tools/gen_golden.py, float64).  Tolerances are float64 round-off class."""
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, relerr
+from oracle import hotpath as O
+
+TOL = 1e-11
+
+
+@pytest.mark.parametrize("name", golden_names("fft_"))
+def test_transforms(name):
+    meta, a = load_golden(name)
+    nfft, norm, db = meta["nfft"], meta["norm"], meta["alias_decay_db"]
+    x = a["x"].clone().requires_grad_(True)
+    X = O.rfft(x, nfft, norm, db)
+    assert relerr(X, a["X"]) < TOL
+    (gx,) = torch.autograd.grad(torch.sum(torch.real(X * torch.conj(a["C"]))), [x])
+    assert relerr(gx, a["gx"]) < TOL
+    Z = a["Z"].clone().requires_grad_(True)
+    y = O.irfft(Z, nfft, norm, db)
+    assert relerr(y, a["y"]) < TOL
+    (gZ,) = torch.autograd.grad(torch.sum(y * a["c"]), [Z])
+    assert relerr(gZ, a["gZ"]) < TOL
+
+
+def _module_response(meta, a, param):
+    """Oracle frequency response (or constant matrix) for a golden module case."""
+    cls, kw = meta["cls"], meta["kwargs"]
+    nfft, db = meta["nfft"], meta["alias_decay_db"]
+    g = O.gamma_of(db, nfft, torch.float64)
+    if cls in ("Gain", "parallelGain"):
+        return O.to_complex(param), "const"
+    if cls == "Matrix":
+        return O.to_complex(O.orthogonal(param)), "const"
+    if cls in ("Filter", "parallelFilter"):
+        return O.fir_response(param, nfft, g), "bin"
+    if cls in ("Biquad", "parallelBiquad"):
+        return O.biquad_response(param, kw["filter_type"], nfft, 48000, g), "bin"
+    if cls in ("GEQ", "parallelGEQ"):
+        return O.geq_response(param, nfft, g).to(torch.complex128), "bin"
+    if cls in ("Delay", "parallelDelay"):
+        p = torch.nn.functional.softplus(param) if kw.get("requires_grad") else param
+        m = O.delay_samples(p, 48000, 100, kw["isint"])
+        return O.delay_response(m, nfft, g), "bin"
+    raise KeyError(cls)
+
+
+_MODULE_CASES = [n for n in golden_names() if load_golden(n)[0].get("cls")]
+
+
+@pytest.mark.parametrize("name", _MODULE_CASES)
+def test_modules(name):
+    meta, a = load_golden(name)
+    cls = meta["cls"]
+    diag = cls.startswith("parallel")
+    param = a["param"].clone().requires_grad_(True)
+    H, kind = _module_response(meta, a, param)
+    if "freq_response" in a and kind == "bin":
+        assert relerr(H, a["freq_response"]) < 1e-10
+    X = a["X"].clone().requires_grad_(True)
+    fn = {("const", False): O.mimo_const, ("const", True): O.mimo_const_diag,
+          ("bin", False): O.mimo_full, ("bin", True): O.mimo_diag}[(kind, diag)]
+    Y = fn(H, X)
+    assert relerr(Y, a["Y"]) < 1e-10
+    wrt = [X] + ([param] if "gparam" in a else [])
+    g = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(a["C"]))), wrt)
+    assert relerr(g[0], a["gX"]) < 1e-10
+    if "gparam" in a:
+        # GEQ coefficients are float32 in the reference: float32-class tolerance there
+        tol = 2e-5 if "GEQ" in cls else 1e-9
+        assert relerr(g[1], a["gparam"]) < tol
+    if "X4" in a:
+        assert relerr(fn(H.detach(), a["X4"]), a["Y4"]) < 1e-10
+    if cls in ("Delay", "parallelDelay") and meta["kwargs"]["isint"]:
+        m = O.delay_samples(a["param"], 48000, 100, True)
+        He = O.delay_response_exact(m, meta["nfft"], O.gamma_of(meta["alias_decay_db"], meta["nfft"]))
+        assert relerr(He, a["freq_response"]) < 1e-12
+
+
+def test_geq_quirk_float32_coefficients():
+    meta, a = load_golden("geq_quirk")
+    nfft = meta["nfft"]
+    g = O.gamma_of(meta["alias_decay_db"], nfft)
+    gain_db = 20 * torch.log10(torch.abs(a["param"]))
+    b, aa = O.geq_sos(gain_db, a["center_freq"], a["shelving"])
+    assert b.dtype == torch.float32 and aa.dtype == torch.float32
+    H = O.sos_response(b, aa, nfft, g)
+    assert relerr(H, a["H"]) < 5e-7  # float32 coefficient arithmetic, op-order differences
+    cf, sc = O.eq_freqs(1)
+    assert torch.equal(cf, a["center_freq"]) and torch.allclose(sc, a["shelving"])
+
+
+@pytest.mark.parametrize("name", golden_names("config2"))
+def test_config2(name):
+    meta, a = load_golden(name)
+    x = a["x"].clone().requires_grad_(True)
+    W = a["W"].clone().requires_grad_(True)
+    G = a["geq_param"].clone().requires_grad_(True)
+    y = O.config2_forward(x, W, G, meta["nfft"], meta["alias_decay_db"])
+    assert relerr(y, a["y"]) < 1e-6      # float32 GEQ coefficients inside
+    gx, gW, gG = torch.autograd.grad((y ** 2).mean(), [x, W, G])
+    assert relerr(gx, a["gx"]) < 1e-6
+    assert relerr(gW, a["gW"]) < 1e-6
+    assert relerr(gG, a["gG"]) < 2e-5
+    assert meta["state_keys"] == ["_Shell__core.mix.param", "_Shell__core.eq.param"]
+
+
+@pytest.mark.parametrize("name", ["fdn4", "fdn6", "fdn6_db0", "fdn16"])
+def test_fdn(name):
+    meta, a = load_golden(name)
+    nfft, db, attn = meta["nfft"], meta["alias_decay_db"], meta["attn"]
+    amap = (lambda p: 20 * torch.log10(torch.sigmoid(p)))
+    leaves = {k: a[k].clone().requires_grad_(True) for k in ["x", "in_gain", "out_gain", "U_param"]}
+    ap = a["attn_param"].clone().requires_grad_(True) if attn else None
+    y = O.fdn_forward(leaves["x"], leaves["in_gain"], leaves["out_gain"], leaves["U_param"], a["delays_s"],
+                      nfft, db, attn_param=ap, attn_map=amap)
+    tol = 2e-6 if attn else 1e-9          # float32 GEQ coefficients when attenuation is present
+    assert relerr(y, a["y"]) < tol
+    wrt = list(leaves.values()) + ([ap] if attn else [])
+    g = torch.autograd.grad(torch.sum(y * a["c"]), wrt)
+    for got, key in zip(g, ["gx", "g_in_gain", "g_out_gain", "g_U_param"] + (["g_attn_param"] if attn else [])):
+        assert relerr(got, a[key]) < (5e-5 if key == "g_attn_param" else max(tol, 1e-8)), key
+    # frequency-domain core on a complex spectrum
+    Yf = O.fdn_forward(a["x"], a["in_gain"], a["out_gain"], a["U_param"], a["delays_s"], nfft, db,
+                       attn_param=a.get("attn_param"), attn_map=amap, output="freq")
+    assert Yf.shape == a["Yf"].shape
+    # the model is linear: check the core against the stored complex-spectrum run
+    g_ = O.gamma_of(db, nfft)
+    m = O.delay_samples(a["delays_s"], 48000, 100, True)
+    D = O.delay_response(m, nfft, g_)
+    U = O.to_complex(O.orthogonal(a["U_param"]))
+    Bk = U.unsqueeze(0).expand(nfft // 2 + 1, *U.shape)
+    if attn:
+        Bk = O.geq_response(a["attn_param"], nfft, g_, map_fn=amap).to(torch.complex128).unsqueeze(-1) * Bk
+    F = torch.diag_embed(D)
+    Xin = O.mimo_const(O.to_complex(a["in_gain"]), a["Xf"])
+    Yc = O.mimo_const(O.to_complex(a["out_gain"]), O.recursion(F, Bk, Xin))
+    assert relerr(Yc, a["Yf"]) < tol
+    # closed-loop matrices on selected bins
+    A = torch.eye(meta["N"], dtype=torch.complex128) - F @ Bk
+    assert relerr(A[a["A_bins"].long()], a["A_sel"]) < tol
+    if "Xm" in a:
+        assert relerr(O.recursion(F, Bk, a["Xm"]), a["Ym"]) < tol
+    # analytic probe (examples/e10_probe.py): H(z_k) == core response to a unit spectrum
+    ones = torch.ones(1, nfft // 2 + 1, 1, dtype=torch.complex128)
+    Hc = O.mimo_const(O.to_complex(a["out_gain"]),
+                      O.recursion(F, Bk, O.mimo_const(O.to_complex(a["in_gain"]), ones))).reshape(-1)
+    if not attn:  # GEQ inherits Filter.probe (FIR formula, dsp.py:945-962), which is not its SOS response
+        assert relerr(Hc[a["probe_bins"].long()], a["probe"].reshape(-1)) < 1e-8
+    # responses: ir = irfft(core(rfft(impulse))) * gamma^-n ; fr = rfft(ir)
+    assert relerr(torch.fft.rfft(a["ir"], n=nfft, dim=1), a["fr"]) < 1e-9
+    env = O.alias_envelope(db, nfft)
+    ir = torch.fft.irfft(Hc.view(1, -1, 1), n=nfft, dim=1) * env.view(1, -1, 1)
+    assert relerr(ir, a["ir"]) < max(tol, 1e-8)

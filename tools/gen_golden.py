@@ -1,0 +1,292 @@
+"""Generate golden vectors by running the REFERENCE (float64, CPU) in this container.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+
+The reference never travels to the GPU box; these small fixtures do.  Each .npz holds the
+inputs, parameters (as assigned), reference outputs and reference gradients of one case,
+plus a JSON ``meta`` string describing how to rebuild the same module with the drop-in API.
+Gradients are those of  L = sum(Re(Y * conj(C)))  (complex Y) or  L = sum(y * c)  (real y) for
+a stored random cotangent C, i.e. autograd's vector-Jacobian product with cotangent C.
+"""
+import json
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import refimport  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+F64 = torch.float64
+C128 = torch.complex128
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, meta, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    arrays = {k: (npy(v) if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), **arrays)
+    sz = os.path.getsize(os.path.join(OUT, name + ".npz"))
+    print(f"{name:40s} {sz/1024:8.1f} KiB")
+
+
+def crandn(*shape):
+    return torch.complex(torch.randn(*shape, dtype=F64), torch.randn(*shape, dtype=F64))
+
+
+def vjp_complex(Y, C, wrt):
+    L = torch.sum(torch.real(Y * torch.conj(C)))
+    return torch.autograd.grad(L, wrt, allow_unused=True)
+
+
+# ----------------------------------------------------------------------------- transforms
+def gen_transforms(dsp):
+    cases = [
+        # nfft, T, norm, alias_db, channels-shape
+        (96, 96, "backward", None, (3,)),
+        (96, 49, "ortho", None, (3,)),
+        (96, 96, "forward", 30.0, (3,)),
+        (96, 103, "forward", None, (3,)),
+        (250, 250, "backward", 30.0, (2,)),
+        (250, 126, "backward", None, (2,)),
+        (960, 960, "backward", None, (1,)),
+        (960, 960, "backward", 30.0, (1,)),
+        (1500, 1500, "ortho", 30.0, (1,)),
+        (64, 64, "backward", None, (2, 2)),   # trailing dims (identity-probe shape)
+        (2048, 2048, "backward", 60.0, (1,)),
+    ]
+    for i, (nfft, T, norm, db, ch) in enumerate(cases):
+        torch.manual_seed(1000 + i)
+        x = torch.randn(2 if nfft < 900 else 1, T, *ch, dtype=F64, requires_grad=True)
+        if db is None:
+            f, g = dsp.FFT(nfft, norm=norm, dtype=F64), dsp.iFFT(nfft, norm=norm, dtype=F64)
+        else:
+            f = dsp.FFTAntiAlias(nfft, norm=norm, alias_decay_db=db, dtype=F64)
+            g = dsp.iFFTAntiAlias(nfft, norm=norm, alias_decay_db=db, dtype=F64)
+        X = f(x)
+        C = crandn(*X.shape)
+        (gx,) = vjp_complex(X, C, [x])
+        # inverse on an arbitrary (non-Hermitian-consistent) spectrum, like a processed one
+        Z = crandn(*X.shape).requires_grad_(True)
+        y = g(Z)
+        c = torch.randn(*y.shape, dtype=F64)
+        (gZ,) = torch.autograd.grad(torch.sum(y * c), [Z])
+        save(f"fft_{i:02d}", dict(kind="transform", nfft=nfft, T=T, norm=norm, alias_decay_db=db),
+             x=x, X=X, C=C, gx=gx, Z=Z, y=y, c=c, gZ=gZ)
+
+
+# ----------------------------------------------------------------------------- single modules
+def module_case(name, mod, meta, nin, nfft, extra_identity=True):
+    """Run a module on a vector signal (2,M,nin) and a matrix signal (1,M,nin,nin)."""
+    M = nfft // 2 + 1
+    arrays = dict(param=mod.param.detach().clone())
+    try:
+        Hresp = mod.freq_response(mod.param)
+        if isinstance(Hresp, torch.Tensor):
+            arrays["freq_response"] = Hresp
+    except Exception:
+        pass
+    X = crandn(2, M, nin).requires_grad_(True)
+    Y = mod(X)
+    C = crandn(*Y.shape)
+    wrt = [X] + ([mod.param] if mod.param.requires_grad else [])
+    g = vjp_complex(Y, C, wrt)
+    arrays.update(X=X, Y=Y, C=C, gX=g[0])
+    if mod.param.requires_grad and g[1] is not None:
+        arrays["gparam"] = g[1]
+    if extra_identity:
+        X4 = crandn(1, M, nin, nin)
+        arrays.update(X4=X4, Y4=mod(X4))
+    save(name, meta, **arrays)
+
+
+def gen_modules(dsp):
+    nfft = 96
+    for db in (0.0, 30.0):
+        tag = f"db{int(db)}"
+        kw = dict(nfft=nfft, alias_decay_db=db, dtype=F64)
+        torch.manual_seed(2000 + int(db))
+        module_case(f"gain_{tag}", dsp.Gain(size=(3, 2), requires_grad=True, **kw),
+                    dict(cls="Gain", kwargs=dict(size=[3, 2], requires_grad=True), nfft=nfft, alias_decay_db=db), 2, nfft)
+        module_case(f"pgain_{tag}", dsp.parallelGain(size=(3,), requires_grad=True, **kw),
+                    dict(cls="parallelGain", kwargs=dict(size=[3], requires_grad=True), nfft=nfft, alias_decay_db=db), 3, nfft)
+        module_case(f"matrix_orth_{tag}", dsp.Matrix(size=(4, 4), matrix_type="orthogonal", requires_grad=True, **kw),
+                    dict(cls="Matrix", kwargs=dict(size=[4, 4], matrix_type="orthogonal", requires_grad=True), nfft=nfft, alias_decay_db=db), 4, nfft)
+        module_case(f"filter_{tag}", dsp.Filter(size=(5, 3, 2), requires_grad=True, **kw),
+                    dict(cls="Filter", kwargs=dict(size=[5, 3, 2], requires_grad=True), nfft=nfft, alias_decay_db=db), 2, nfft)
+        module_case(f"pfilter_{tag}", dsp.parallelFilter(size=(4, 3), requires_grad=True, **kw),
+                    dict(cls="parallelFilter", kwargs=dict(size=[4, 3], requires_grad=True), nfft=nfft, alias_decay_db=db), 3, nfft)
+        for ft in ("lowpass", "highpass", "bandpass"):
+            module_case(f"biquad_{ft}_{tag}",
+                        dsp.Biquad(size=(3, 2), n_sections=2, filter_type=ft, requires_grad=True, **kw),
+                        dict(cls="Biquad", kwargs=dict(size=[3, 2], n_sections=2, filter_type=ft, requires_grad=True),
+                             nfft=nfft, alias_decay_db=db), 2, nfft)
+        module_case(f"pbiquad_{tag}",
+                    dsp.parallelBiquad(size=(3,), n_sections=2, filter_type="highpass", requires_grad=True, **kw),
+                    dict(cls="parallelBiquad", kwargs=dict(size=[3], n_sections=2, filter_type="highpass", requires_grad=True),
+                         nfft=nfft, alias_decay_db=db), 3, nfft)
+        module_case(f"geq_{tag}", dsp.GEQ(size=(2, 2), requires_grad=True, **kw),
+                    dict(cls="GEQ", kwargs=dict(size=[2, 2], requires_grad=True), nfft=nfft, alias_decay_db=db), 2, nfft)
+        module_case(f"pgeq_{tag}", dsp.parallelGEQ(size=(3,), requires_grad=True, **kw),
+                    dict(cls="parallelGEQ", kwargs=dict(size=[3], requires_grad=True), nfft=nfft, alias_decay_db=db), 3, nfft)
+        for isint in (True, False):
+            it = "int" if isint else "frac"
+            module_case(f"delay_{it}_{tag}", dsp.Delay(size=(3, 2), max_len=40, isint=isint, **kw),
+                        dict(cls="Delay", kwargs=dict(size=[3, 2], max_len=40, isint=isint), nfft=nfft, alias_decay_db=db), 2, nfft)
+            module_case(f"pdelay_{it}_{tag}", dsp.parallelDelay(size=(3,), max_len=40, isint=isint, **kw),
+                        dict(cls="parallelDelay", kwargs=dict(size=[3], max_len=40, isint=isint), nfft=nfft, alias_decay_db=db), 3, nfft)
+        # learnable fractional delay (softplus map, dsp.py:3418-3419)
+        module_case(f"delay_learn_{tag}", dsp.Delay(size=(2, 2), max_len=30, isint=False, requires_grad=True, **kw),
+                    dict(cls="Delay", kwargs=dict(size=[2, 2], max_len=30, isint=False, requires_grad=True),
+                         nfft=nfft, alias_decay_db=db), 2, nfft)
+
+    # float32-mode GEQ coefficients quirk (F8): record the float64-mode SOS arrays themselves
+    torch.manual_seed(2100)
+    geq = dsp.GEQ(size=(2, 2), nfft=nfft, alias_decay_db=30.0, dtype=F64)
+    H, Bf, Af = geq.get_poly_coeff(geq.map(geq.param))
+    save("geq_quirk", dict(kind="geq_quirk", nfft=nfft, alias_decay_db=30.0),
+         param=geq.param.detach(), H=H, B=Bf, A=Af, center_freq=geq.center_freq, shelving=geq.shelving_crossover)
+
+
+# ----------------------------------------------------------------------------- config-2 miniature
+def gen_config2(dsp, system):
+    for db, nfft, B in ((0.0, 240, 2), (30.0, 250, 2)):
+        torch.manual_seed(3000 + int(db))
+        N = 8
+        kw = dict(nfft=nfft, alias_decay_db=db, dtype=F64)
+        mat = dsp.Matrix(size=(N, N), matrix_type="random", requires_grad=True, **kw)
+        geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+        core = system.Series(OrderedDict({"mix": mat, "eq": geq}))
+        model = system.Shell(core=core, input_layer=dsp.FFT(nfft, dtype=F64), output_layer=dsp.iFFT(nfft, dtype=F64))
+        x = torch.randn(B, nfft, N, dtype=F64, requires_grad=True)
+        y = model(x)
+        loss = (y ** 2).mean()
+        gx, gW, gG = torch.autograd.grad(loss, [x, mat.param, geq.param])
+        keys = list(model.state_dict().keys())
+        save(f"config2_db{int(db)}", dict(kind="config2", nfft=nfft, alias_decay_db=db, N=N, B=B, state_keys=keys),
+             x=x, W=mat.param, geq_param=geq.param, y=y, loss=loss, gx=gx, gW=gW, gG=gG)
+
+
+# ----------------------------------------------------------------------------- FDN / Recursion
+def build_fdn(dsp, system, N, nfft, db, delays, with_attn, dtype=F64, out_layer="ifft_aa"):
+    kw = dict(nfft=nfft, alias_decay_db=db, dtype=dtype)
+    input_gain = dsp.Gain(size=(N, 1), requires_grad=True, **kw)
+    output_gain = dsp.Gain(size=(1, N), requires_grad=True, **kw)
+    dl = dsp.parallelDelay(size=(N,), max_len=int(max(delays)), isint=True, requires_grad=False, **kw)
+    dl.assign_value(dl.sample2s(torch.tensor(delays, dtype=dtype)))
+    mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+    if with_attn:
+        att = dsp.parallelGEQ(size=(N,), octave_interval=1, fs=48000, requires_grad=True, **kw)
+        att.map = lambda x: 20 * torch.log10(torch.sigmoid(x))
+        fb = system.Series(OrderedDict({"mixing_matrix": mix, "attenuation": att}))
+    else:
+        att = None
+        fb = mix
+    rec = system.Recursion(fF=dl, fB=fb)
+    core = system.Series(OrderedDict({"input_gain": input_gain, "feedback_loop": rec, "output_gain": output_gain}))
+    if out_layer == "ifft_aa":
+        ol = dsp.iFFTAntiAlias(nfft=nfft, alias_decay_db=db, dtype=dtype)
+    else:
+        ol = dsp.Transform(lambda x: torch.abs(x))
+    model = system.Shell(core=core, input_layer=dsp.FFT(nfft, dtype=dtype), output_layer=ol)
+    return model, dict(input_gain=input_gain, output_gain=output_gain, delays=dl, mix=mix, att=att, rec=rec)
+
+
+def gen_fdn(dsp, system):
+    specs = [
+        # name, N, nfft, db, delays, attenuation, B, signal
+        ("fdn4", 4, 512, 30.0, [101, 157, 211, 263], False, 1, "impulse"),
+        ("fdn6", 6, 480, 30.0, [59, 97, 131, 151, 163, 169], True, 2, "wgn"),
+        ("fdn6_db0", 6, 480, 0.0, [59, 97, 131, 151, 163, 169], True, 1, "impulse"),
+        ("fdn16", 16, 1500, 30.0, [53, 61, 71, 79, 89, 97, 103, 109, 127, 137, 149, 157, 167, 179, 191, 199], True, 1, "impulse"),
+    ]
+    for name, N, nfft, db, delays, attn, B, sig in specs:
+        torch.manual_seed(4000 + N + int(db))
+        model, p = build_fdn(dsp, system, N, nfft, db, delays, attn)
+        with torch.no_grad():  # keep the loop well inside the unit circle
+            if attn:
+                p["att"].param.copy_(torch.randn_like(p["att"].param) * 0.3 + 2.0)
+        if sig == "impulse":
+            x = torch.zeros(B, nfft, 1, dtype=F64)
+            x[:, 0, :] = 1
+        else:
+            x = torch.randn(B, nfft, 1, dtype=F64)
+        x.requires_grad_(True)
+        y = model(x)
+        c = torch.randn(*y.shape, dtype=F64)
+        plist = [p["input_gain"].param, p["output_gain"].param, p["mix"].param] + ([p["att"].param] if attn else [])
+        grads = torch.autograd.grad(torch.sum(y * c), [x] + plist)
+        arrays = dict(x=x, y=y, c=c, gx=grads[0], in_gain=plist[0], out_gain=plist[1], U_param=plist[2],
+                      g_in_gain=grads[1], g_out_gain=grads[2], g_U_param=grads[3],
+                      delays_s=p["delays"].param.detach())
+        if attn:
+            arrays.update(attn_param=plist[3], g_attn_param=grads[4])
+        # frequency-domain core output for a complex spectrum (vector RHS) and the closed-loop
+        # matrices of a few bins (A as the reference builds it)
+        core = model.get_core()
+        M = nfft // 2 + 1
+        with torch.no_grad():
+            Xf = crandn(B, M, 1)
+            arrays.update(Xf=Xf, Yf=core(Xf))
+            rec = p["rec"]
+            I = rec.I.unsqueeze(0)
+            A = I - rec.feedforward(rec.feedback(I))
+            sel = [0, 1, M // 3, M - 1]
+            arrays.update(A_bins=np.array(sel), A_sel=A[0, sel])
+            # matrix RHS (identity path) through the recursion alone
+            Xm = crandn(1, M, N, N)
+            if N <= 4:
+                arrays.update(Xm=Xm, Ym=rec(Xm))
+            # responses
+            arrays.update(ir=model.get_time_response(identity=False), fr=model.get_freq_response(identity=False))
+            # analytic probe on 16 bins (examples/e10_probe.py) -- independent of the FFT
+            ks = np.linspace(0, M - 1, 16).astype(int)
+            pr = []
+            for k in ks:
+                z = torch.tensor(np.exp(2j * np.pi * k / nfft), dtype=C128)
+                pr.append(model.probe(z).reshape(-1))
+            arrays.update(probe_bins=ks, probe=torch.stack(pr))
+        keys = list(model.state_dict().keys())
+        save(name, dict(kind="fdn", N=N, nfft=nfft, alias_decay_db=db, delays=delays, attn=attn, B=B, state_keys=keys),
+             **arrays)
+
+    # identity responses of a 2-in/2-out recursion-bearing system (get_*_response(identity=True))
+    torch.manual_seed(4500)
+    nfft, N, db = 480, 3, 30.0
+    kw = dict(nfft=nfft, alias_decay_db=db, dtype=F64)
+    dl = dsp.parallelDelay(size=(N,), max_len=60, isint=True, **kw)
+    dl.assign_value(dl.sample2s(torch.tensor([23.0, 41.0, 59.0], dtype=F64)))
+    mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", **kw)
+    att = dsp.parallelGain(size=(N,), **kw)
+    att.assign_value(torch.tensor([0.9, 0.85, 0.8], dtype=F64))
+    rec = system.Recursion(fF=dl, fB=system.Series(OrderedDict({"mix": mix, "att": att})))
+    model = system.Shell(core=rec)
+    with torch.no_grad():
+        save("rec3_identity", dict(kind="rec_identity", N=N, nfft=nfft, alias_decay_db=db, delays=[23, 41, 59]),
+             U_param=mix.param, att=att.param,
+             ir=model.get_time_response(identity=True), fr=model.get_freq_response(identity=True),
+             ir_vec=model.get_time_response(identity=False))
+
+
+def main():
+    torch.set_default_dtype(torch.float32)
+    dsp, system = refimport.load()
+    import warnings
+
+    warnings.filterwarnings("ignore")
+    gen_transforms(dsp)
+    gen_modules(dsp)
+    gen_config2(dsp, system)
+    gen_fdn(dsp, system)
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
+    print(f"total {total/1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
