@@ -1,0 +1,165 @@
+#!/usr/bin/env python
+"""Benchmark of the flamo hot path on MI355X (contract: see the task statement).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+  Shell(FFT(96000) -> Series(Matrix(8,8,"random"), GEQ((8,8))) -> iFFT(96000)), batch 32 per GPU,
+  float32, synthetic white-noise input resident in HBM, forward + backward of loss=(y**2).mean()
+  with gradients for every learnable parameter (Matrix and GEQ gains), as in the reference's
+  training step (flamo/optimize/trainer.py:172-191; the data tensor does not require grad).
+Metric: frequency-bin x channel products per second =
+  (sum over per-bin MIMO modules of B*M*N_out*N_in) / time(fwd+bwd), whole job over all GPUs.
+Multi-GPU: batch data parallel (bins are independent but so are batch items, and config 2's
+parameters are a few KB): each rank owns 32 signals, parameter gradients are all-reduced over
+RCCL each step; "weak" scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+from collections import OrderedDict
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NFFT, NCH, BATCH = 96000, 8, 32
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def build_model(dev, dtype):
+    from flamo_amd.processor import dsp, system
+    kw = dict(nfft=NFFT, alias_decay_db=0.0, device=dev, dtype=dtype)
+    mat = dsp.Matrix(size=(NCH, NCH), matrix_type="random", requires_grad=True, **kw)
+    geq = dsp.GEQ(size=(NCH, NCH), requires_grad=True, **kw)
+    core = system.Series(OrderedDict(mix=mat, eq=geq))
+    return system.Shell(core, dsp.FFT(NFFT, dtype=dtype), dsp.iFFT(NFFT, dtype=dtype)), [mat.param, geq.param]
+
+
+def cpu_baseline(W, G, max_seconds=25.0):
+    """The same graph on the host cores through the CPU oracle (a port of the reference's torch
+    ops), float32 like the reference's default module dtype.  Bounded sample: the full config-2
+    batch, as many steps as fit in ~max_seconds (at least 1 after a warm-up)."""
+    from oracle import hotpath as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = torch.randn(BATCH, NFFT, NCH, dtype=torch.float32)
+    Wc = W.detach().cpu().float().requires_grad_(True)
+    Gc = G.detach().cpu().float().requires_grad_(True)
+
+    def step():
+        y = O.config2_forward(x, Wc, Gc, NFFT)
+        torch.autograd.grad((y ** 2).mean(), [Wc, Gc])
+
+    t0 = time.perf_counter()
+    step()
+    first = time.perf_counter() - t0
+    n = max(1, min(3, int((max_seconds - first) / max(first, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    dt = (time.perf_counter() - t0) / n
+    M = NFFT // 2 + 1
+    return {"value": 2 * BATCH * M * NCH * NCH / dt, "unit": "products/s", "cores": cores, "kind": "port",
+            "sample": f"config 2 full size (B={BATCH}, nfft={NFFT}, {NCH}x{NCH}, float32), {n} timed step(s) "
+                      f"after 1 warm-up, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    args = ap.parse_args()
+    warnings.simplefilter("ignore")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+
+    from flamo_amd import ops
+    torch.manual_seed(130709)          # same parameters on every rank (replicated)
+    model, params = build_model(dev, dtype)
+    torch.manual_seed(130709 + 1 + rank)
+    x = torch.randn(BATCH, NFFT, NCH, device=dev, dtype=dtype)   # resident in HBM before timing
+
+    def step():
+        for p in params:
+            p.grad = None
+        y = model(x)
+        loss = (y ** 2).mean()
+        loss.backward()
+        if dist_on:
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)                       # RCCL; < 4 KB of parameter gradients
+        return loss
+
+    def fence():
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.kernel_timer.reset(enabled=(rank == 0))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ops.kernel_timer.enabled = False
+    if dist_on:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    M = NFFT // 2 + 1
+    products_per_step = 2 * BATCH * M * NCH * NCH * world   # two per-bin MIMO modules (Matrix, GEQ)
+    ms = elapsed / args.steps * 1e3
+    if rank == 0:
+        esz = 8 if dtype == torch.float32 else 16
+        timers = ops.kernel_timer.summary()
+        roof = None
+        if "mimo_bin_fwd" in timers:
+            n, mean_ms = timers["mimo_bin_fwd"]
+            alg_bytes = esz * (BATCH * M * NCH + BATCH * M * NCH) + esz * M * NCH * NCH   # X + Y + H per launch
+            achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "mimo_full_kernel (GEQ einsum fmn,bfn->bfm, forward)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "algorithmic_bytes": alg_bytes, "launch_ms": mean_ms, "launches": n}
+        out = {"metric": "freq-bin*channel products/sec (fwd+bwd), nfft=96000 8x8ch", "value": products_per_step / (ms * 1e-3),
+               "unit": "products/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[1]: Shell(FFT -> Series(Matrix 8x8, GEQ 8x8) -> iFFT), nfft=96000, "
+                                      "batch 32 per GPU, fwd+bwd of (y**2).mean(), parameter grads",
+                          "nfft": NFFT, "channels": NCH, "batch_per_gpu": BATCH, "parallelism": f"dp{world} (batch)",
+                          "input_grad": False},
+               "roofline": roof,
+               "kernel_ms": {k: round(v[1], 4) for k, v in timers.items()}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(params[0], params[1])
+        print(json.dumps(out))
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

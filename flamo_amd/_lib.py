@@ -1,0 +1,94 @@
+"""ctypes binding of libflamo_hip.so (C ABI declared in include/flamo_hip.h).
+
+The shared library is built in-tree (``flamo_amd/libflamo_hip.so``) by ``build()`` /
+``make -C flamo_amd/csrc``.  There is NO fallback: if the library is missing or a tensor is
+not on a ROCm device the ops raise -- the product path never routes through torch.fft,
+torch.einsum, torch.linalg or any CPU code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflamo_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lock = threading.Lock()
+_lib = None
+
+_vp, _i, _l, _d, _sz = C.c_void_p, C.c_int, C.c_long, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/flamo_hip.h one to one
+_SIGNATURES = {
+    "fl_version": (_i, []),
+    "fl_last_error": (C.c_char_p, []),
+    "fl_twiddle_fill_f32": (_i, [_vp, _i, _vp]),
+    "fl_twiddle_fill_f64": (_i, [_vp, _i, _vp]),
+    "fl_fft_plan": (_i, [_i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    "fl_fft_scratch_elems": (_sz, [_i, _i, _i]),
+    "fl_debug_set_fft_max_single": (_i, [_i]),
+    "fl_rfft_f32": (_i, [_vp, _l, _i, _vp, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
+    "fl_rfft_f64": (_i, [_vp, _l, _i, _vp, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
+    "fl_irfft_f32": (_i, [_vp, _vp, _l, _i, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
+    "fl_irfft_f64": (_i, [_vp, _vp, _l, _i, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
+    "fl_transpose": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "fl_mimo_c64": (_i, [_vp, _l, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_c128": (_i, [_vp, _l, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_diag_c64": (_i, [_vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
+    "fl_mimo_diag_c128": (_i, [_vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradh_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _d, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradh_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _d, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradh_diag_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradh_diag_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _vp]),
+    "fl_delay_response_c64": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_delay_response_c128": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_sos_response_f32": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_sos_response_f64": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_sos_bwd_blocks": (_i, [_i]),
+    "fl_sos_response_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_sos_response_bwd_f64": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_solve_c64": (_i, [_vp, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
+    "fl_solve_c128": (_i, [_vp, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def build(force: bool = False) -> str:
+    """Compile every HIP source for gfx950 into flamo_amd/libflamo_hip.so (hipcc cross-compiles
+    without a GPU).  Returns the library path."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libflamo_hip.so failed:\n" + r.stdout[-4000:] + r.stderr[-8000:])
+    return LIB_PATH
+
+
+def lib() -> C.CDLL:
+    """The loaded library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} not found: the HIP extension is required (run "
+                        "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C flamo_amd/csrc`)."
+                    )
+                handle = C.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGNATURES.items():
+                    fn = getattr(handle, name)  # AttributeError if the symbol is missing
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().fl_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libflamo_hip {what} failed (code {rc}): {msg}")

@@ -1,0 +1,608 @@
+// Batched real FFT / inverse real FFT for gfx950 (MI355X), mixed radix 2/3/4/5 (+7/11/13).
+//
+// A real transform of length n is computed as a complex FFT of the packed half-length
+// sequence z[j] = x[2j] + i x[2j+1] (L = n/2) plus a split step.  The complex FFT is a
+// "four-step" factorisation L = L1*L2 when L does not fit in LDS:
+//
+//   pass 1 (fft_cols): for a tile of CT adjacent columns c, Stockham FFT of length L1 over
+//                      z[t1*L2 + c] in LDS, multiply by W_L^(c*k1), store A[k1*L2 + c].
+//   pass 2 (fft_rows): for a tile of rows k1 (contiguous L2 elements), Stockham FFT of length
+//                      L2 in LDS, then the epilogue writes natural order k = k1 + L1*k2.
+//
+// Forward (rfft): pass 2's epilogue is the real-FFT split step, which couples bins k and
+// L-k; a workgroup therefore owns rows {r, L1-r} together and emits both bins.  Inverse
+// (irfft): the Hermitian pre-step is fused into pass 1's loader (reads X[j] and X[L-j]) and
+// the envelope/scale/real-pair store into pass 2's epilogue.  All global traffic is in
+// >= 64-byte contiguous segments; one read + one write of the data per pass.
+//
+// The anti-alias envelope gamma^-t of FFTAntiAlias / iFFTAntiAlias (dsp.py:158-162,201-205)
+// is applied in the loader / epilogue (no separate pass).
+#include "common.h"
+
+namespace fl {
+
+enum { LOAD_PACK = 0, LOAD_IRFFT_PRE = 1, LOAD_SCRATCH = 2 };
+enum { EPI_RFFT_POST = 0, EPI_IRFFT_STORE = 1 };
+
+struct Rad {
+    int n;
+    int r[24];
+};
+
+template <typename T>
+struct FftArgs {
+    const T* xr;        // LOAD_PACK source (real, signal-planar)
+    long xr_stride;
+    int t_in;
+    const cx<T>* Xc;    // LOAD_IRFFT_PRE source (half spectrum, L+1 bins per signal)
+    cx<T>* Xout;        // EPI_RFFT_POST destination
+    T* yr;              // EPI_IRFFT_STORE destination
+    long yr_stride;
+    int t_out;
+    cx<T>* scratch;
+    const cx<T>* W;     // W_n^j, j in [0,n)
+    int n, L, L1, L2, L1P, L2P, CT, RT, ntiles;
+    int per;            // LDS slots per primary row in pass 2 (2 when mirror rows are held)
+    T scale;
+    double env_log2;
+    int interior;       // rfft: double interior bins; irfft: halve interior bins
+    Rad rad1, rad2;
+};
+
+// ---------------------------------------------------------------- radix butterflies (in registers)
+template <typename T, int R, bool INV>
+struct Bfly;
+
+template <typename T, bool INV>
+struct Bfly<T, 2, INV> {
+    static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
+        cx<T> a = v[0], b = v[1];
+        v[0] = a + b;
+        v[1] = a - b;
+    }
+};
+
+template <typename T, bool INV>
+struct Bfly<T, 4, INV> {
+    static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
+        cx<T> t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
+        cx<T> t3 = INV ? mul_i(d) : mul_mi(d);
+        v[0] = t0 + t2;
+        v[1] = t1 + t3;
+        v[2] = t0 - t2;
+        v[3] = t1 - t3;
+    }
+};
+
+template <typename T, bool INV>
+struct Bfly<T, 3, INV> {
+    static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
+        const T h = (T)0.86602540378443864676;  // sin(2pi/3)
+        cx<T> t = v[1] + v[2];
+        cx<T> u = cx<T>(v[0].x - (T)0.5 * t.x, v[0].y - (T)0.5 * t.y);
+        cx<T> d = v[1] - v[2];
+        cx<T> w = INV ? mul_i(d) : mul_mi(d);
+        w = cx<T>(h * w.x, h * w.y);
+        v[0] = v[0] + t;
+        v[1] = u + w;
+        v[2] = u - w;
+    }
+};
+
+template <typename T, bool INV>
+struct Bfly<T, 5, INV> {
+    static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
+        const T c1 = (T)0.30901699437494742410;   // cos(2pi/5)
+        const T c2 = (T)-0.80901699437494742410;  // cos(4pi/5)
+        const T s1 = (T)0.95105651629515357212;   // sin(2pi/5)
+        const T s2 = (T)0.58778525229247312917;   // sin(4pi/5)
+        cx<T> a1 = v[1] + v[4], a2 = v[2] + v[3], d1 = v[1] - v[4], d2 = v[2] - v[3];
+        cx<T> m1 = cx<T>(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
+        cx<T> m2 = cx<T>(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
+        cx<T> e1 = cx<T>(s1 * d1.x + s2 * d2.x, s1 * d1.y + s2 * d2.y);
+        cx<T> e2 = cx<T>(s2 * d1.x - s1 * d2.x, s2 * d1.y - s1 * d2.y);
+        cx<T> j1 = INV ? mul_i(e1) : mul_mi(e1);
+        cx<T> j2 = INV ? mul_i(e2) : mul_mi(e2);
+        v[0] = v[0] + a1 + a2;
+        v[1] = m1 + j1;
+        v[4] = m1 - j1;
+        v[2] = m2 + j2;
+        v[3] = m2 - j2;
+    }
+};
+
+// generic odd prime radix: direct O(R^2) DFT with w_R^j = tw[j * step] (forward table)
+template <typename T, int R, bool INV>
+struct Bfly {
+    static __device__ inline void run(cx<T>* v, const cx<T>* tw, int step) {
+        cx<T> o[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            cx<T> acc = v[0];
+#pragma unroll
+            for (int j = 1; j < R; ++j) {
+                cx<T> w = tw[((j * k) % R) * step];
+                if (INV) w = conj(w);
+                fma_cx(acc, v[j], w);
+            }
+            o[k] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = o[k];
+    }
+};
+
+// One Stockham (decimation-in-frequency, autosort) stage of radix R on nseq sequences of
+// length len stored at stride lenP in LDS:  y[q + s(Rp + k)] = w_p^k sum_j x[q + s(p + m j)] w_R^{jk}
+template <typename T, int R, bool INV>
+__device__ void stockham_stage(const cx<T>* __restrict__ a, cx<T>* __restrict__ b, const cx<T>* __restrict__ tw,
+                               int nseq, int len, int lenP, int s) {
+    const int nb = len / R;
+    const int m = nb / s;
+    for (int idx = threadIdx.x; idx < nseq * nb; idx += blockDim.x) {
+        const int seq = idx / nb, w = idx - seq * nb;
+        const int p = w / s, q = w - p * s;
+        const cx<T>* x = a + seq * lenP;
+        cx<T>* y = b + seq * lenP;
+        cx<T> v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = x[q + s * (p + m * j)];
+        Bfly<T, R, INV>::run(v, tw, nb);
+        y[q + s * (R * p)] = v[0];
+#pragma unroll
+        for (int k = 1; k < R; ++k) {
+            cx<T> t = tw[p * k * s];
+            if (INV) t = conj(t);
+            y[q + s * (R * p + k)] = v[k] * t;
+        }
+    }
+}
+
+// Full in-LDS FFT of nseq sequences; returns the buffer holding the result.
+template <typename T, bool INV>
+__device__ cx<T>* lds_fft(cx<T>* a, cx<T>* b, const cx<T>* tw, int nseq, int len, int lenP, const Rad& rad) {
+    int s = 1;
+    for (int i = 0; i < rad.n; ++i) {
+        const int r = rad.r[i];
+        switch (r) {
+            case 2: stockham_stage<T, 2, INV>(a, b, tw, nseq, len, lenP, s); break;
+            case 3: stockham_stage<T, 3, INV>(a, b, tw, nseq, len, lenP, s); break;
+            case 4: stockham_stage<T, 4, INV>(a, b, tw, nseq, len, lenP, s); break;
+            case 5: stockham_stage<T, 5, INV>(a, b, tw, nseq, len, lenP, s); break;
+            case 7: stockham_stage<T, 7, INV>(a, b, tw, nseq, len, lenP, s); break;
+            case 11: stockham_stage<T, 11, INV>(a, b, tw, nseq, len, lenP, s); break;
+            default: stockham_stage<T, 13, INV>(a, b, tw, nseq, len, lenP, s); break;
+        }
+        __syncthreads();
+        cx<T>* t = a;
+        a = b;
+        b = t;
+        s *= r;
+    }
+    return a;
+}
+
+// ---------------------------------------------------------------- loaders
+template <typename T>
+__device__ inline T envelope(double env_log2, int t) {
+    return (T)exp2((T)(env_log2 * (double)t));
+}
+template <>
+__device__ inline float envelope<float>(double env_log2, int t) {
+    return exp2f((float)(env_log2 * (double)t));
+}
+
+// packed half-length sequence of a real signal: z[j] = x[2j] e(2j) + i x[2j+1] e(2j+1)
+template <typename T>
+__device__ inline cx<T> load_pack(const FftArgs<T>& a, int sig, int j) {
+    const T* x = a.xr + (size_t)sig * a.xr_stride;
+    const int t = 2 * j;
+    T re = (t < a.t_in) ? x[t] : (T)0;
+    T im = (t + 1 < a.t_in) ? x[t + 1] : (T)0;
+    if (a.env_log2 != 0.0) {
+        re *= envelope<T>(a.env_log2, t);
+        im *= envelope<T>(a.env_log2, t + 1);
+    }
+    return cx<T>(re, im);
+}
+
+// Hermitian pre-step of the inverse real FFT:
+//   Zf[j] = (X[j] + conj X[L-j]) + i conj(W_n^j) (X[j] - conj X[L-j])
+template <typename T>
+__device__ inline cx<T> load_irfft_pre(const FftArgs<T>& a, int sig, int j) {
+    const cx<T>* X = a.Xc + (size_t)sig * (a.L + 1);
+    cx<T> xa = X[j], xb = X[a.L - j];
+    if (j == 0) {  // DC and Nyquist: imaginary parts are ignored (C2R semantics)
+        xa.y = 0;
+        xb.y = 0;
+    } else if (a.interior) {
+        xa = (T)0.5 * xa;
+        xb = (T)0.5 * xb;
+    }
+    xb = conj(xb);
+    cx<T> sum = xa + xb, dif = xa - xb;
+    cx<T> w = conj(a.W[j]);
+    return sum + mul_i(w * dif);
+}
+
+template <typename T, int LOAD>
+__device__ inline cx<T> load_any(const FftArgs<T>& a, int sig, int j) {
+    if (LOAD == LOAD_PACK) return load_pack<T>(a, sig, j);
+    if (LOAD == LOAD_IRFFT_PRE) return load_irfft_pre<T>(a, sig, j);
+    return a.scratch[(size_t)sig * a.L + j];
+}
+
+// ---------------------------------------------------------------- pass 1: column FFTs
+template <typename T, int LOAD, bool INV>
+__global__ void __launch_bounds__(256) fft_cols(FftArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cx<T>* buf0 = reinterpret_cast<cx<T>*>(smem);
+    cx<T>* buf1 = buf0 + a.CT * a.L1P;
+    cx<T>* tw = buf1 + a.CT * a.L1P;
+    const int tile = blockIdx.x % a.ntiles, sig = blockIdx.x / a.ntiles;
+    const int c0 = tile * a.CT;
+    const int nc = min(a.CT, a.L2 - c0);
+    const int twstep = a.n / a.L1;
+    for (int j = threadIdx.x; j < a.L1; j += blockDim.x) tw[j] = a.W[j * twstep];
+    for (int e = threadIdx.x; e < nc * a.L1; e += blockDim.x) {
+        const int t1 = e / nc, c = e - t1 * nc;
+        buf0[c * a.L1P + t1] = load_any<T, LOAD>(a, sig, t1 * a.L2 + c0 + c);
+    }
+    __syncthreads();
+    cx<T>* res = lds_fft<T, INV>(buf0, buf1, tw, nc, a.L1, a.L1P, a.rad1);
+    cx<T>* out = a.scratch + (size_t)sig * a.L;
+    for (int e = threadIdx.x; e < nc * a.L1; e += blockDim.x) {
+        const int k1 = e / nc, c = e - k1 * nc;
+        cx<T> w = a.W[2 * (c0 + c) * k1];  // W_L^(c k1) = W_n^(2 c k1), index < n
+        if (INV) w = conj(w);
+        out[k1 * a.L2 + c0 + c] = res[c * a.L1P + k1] * w;
+    }
+}
+
+// ---------------------------------------------------------------- pass 2: row FFTs + epilogue
+template <typename T, int LOAD, int EPI, bool INV>
+__global__ void __launch_bounds__(256) fft_rows(FftArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile = blockIdx.x % a.ntiles, sig = blockIdx.x / a.ntiles;
+    const int P = (EPI == EPI_RFFT_POST) ? (a.L1 / 2 + 1) : a.L1;  // primary rows
+    const int r0 = tile * a.RT;
+    const int nr = min(a.RT, P - r0);
+    const int nslots = a.per * nr;
+    const int maxslots = a.per * a.RT;
+    cx<T>* buf0 = reinterpret_cast<cx<T>*>(smem);
+    cx<T>* buf1 = buf0 + maxslots * a.L2P;
+    cx<T>* tw = buf1 + maxslots * a.L2P;
+    const int twstep = a.n / a.L2;
+    for (int j = threadIdx.x; j < a.L2; j += blockDim.x) tw[j] = a.W[j * twstep];
+    for (int e = threadIdx.x; e < nslots * a.L2; e += blockDim.x) {
+        const int sl = e / a.L2, t2 = e - sl * a.L2;
+        int row;
+        bool valid = true;
+        if (a.per == 2) {
+            const int r = r0 + (sl >> 1);
+            if (sl & 1) {
+                row = (a.L1 - r) % a.L1;
+                valid = (row != r);
+            } else {
+                row = r;
+            }
+        } else {
+            row = r0 + sl;
+        }
+        cx<T> v(0, 0);
+        if (valid) v = load_any<T, LOAD>(a, sig, row * a.L2 + t2);
+        buf0[sl * a.L2P + t2] = v;
+    }
+    __syncthreads();
+    cx<T>* res = lds_fft<T, INV>(buf0, buf1, tw, nslots, a.L2, a.L2P, a.rad2);
+
+    if (EPI == EPI_RFFT_POST) {
+        // X[k] = 1/2 [ (Z[k] + conj Z[L-k]) - i W_n^k (Z[k] - conj Z[L-k]) ],  Z[L] := Z[0]
+        cx<T>* X = a.Xout + (size_t)sig * (a.L + 1);
+        const T hs = (T)0.5 * a.scale;
+        const T wi = a.interior ? (T)2 : (T)1;
+        for (int e = threadIdx.x; e < nr * a.L2; e += blockDim.x) {
+            const int k2 = e / nr, i = e - k2 * nr;
+            const int r = r0 + i;
+            const int k = r + a.L1 * k2;
+            const int km = (k == 0) ? 0 : a.L - k;
+            const int rowm = km % a.L1, colm = km / a.L1;
+            const int slm = (rowm == r) ? a.per * i : a.per * i + 1;
+            const cx<T> zk = res[(a.per * i) * a.L2P + k2];
+            const cx<T> zm = res[slm * a.L2P + colm];
+            {
+                const cx<T> p = zk + conj(zm), d = zk - conj(zm);
+                const cx<T> o = p + mul_mi(a.W[k] * d);
+                const T sc = (k == 0) ? hs : hs * wi;
+                X[k] = cx<T>(sc * o.x, sc * o.y);
+                if (k == 0) {  // Nyquist bin k = L: W_n^L = -1
+                    const cx<T> o2 = p + mul_i(d);
+                    X[a.L] = cx<T>(hs * o2.x, hs * o2.y);
+                }
+            }
+            if (k != 0 && rowm != r) {  // partner bin L-k lives in a row only this workgroup holds
+                const cx<T> p = zm + conj(zk), d = zm - conj(zk);
+                const cx<T> o = p + mul_mi(a.W[km] * d);
+                const T sc = hs * wi;
+                X[km] = cx<T>(sc * o.x, sc * o.y);
+            }
+        }
+    } else {
+        // y[2j] = scale e(2j) Re z[j],  y[2j+1] = scale e(2j+1) Im z[j],  j = k1 + L1 k2
+        T* y = a.yr + (size_t)sig * a.yr_stride;
+        for (int e = threadIdx.x; e < nr * a.L2; e += blockDim.x) {
+            const int k2 = e / nr, i = e - k2 * nr;
+            const int j = (r0 + i) + a.L1 * k2;
+            const cx<T> z = res[i * a.L2P + k2];
+            const int t = 2 * j;
+            T re = a.scale * z.x, im = a.scale * z.y;
+            if (a.env_log2 != 0.0) {
+                re *= envelope<T>(a.env_log2, t);
+                im *= envelope<T>(a.env_log2, t + 1);
+            }
+            if (t < a.t_out) y[t] = re;
+            if (t + 1 < a.t_out) y[t + 1] = im;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- twiddles, transpose
+template <typename T>
+__global__ void twiddle_fill(cx<T>* W, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) {
+        double s, c;
+        sincospi(2.0 * (double)j / (double)n, &s, &c);
+        W[j] = cx<T>((T)c, (T)(-s));
+    }
+}
+
+template <typename E>
+__global__ void __launch_bounds__(256) transpose_kernel(const E* __restrict__ src, E* __restrict__ dst, int rows, int cols) {
+    __shared__ E tile[32][33];
+    const size_t base = (size_t)blockIdx.z * rows * cols;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        if (r < rows && c < cols) tile[i][tx] = src[base + (size_t)r * cols + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < rows && c < cols) dst[base + (size_t)c * rows + r] = tile[tx][i];
+    }
+}
+
+// ---------------------------------------------------------------- host-side planning
+static int g_max_single = 0;
+
+static bool factorize(int n, Rad& rad) {
+    rad.n = 0;
+    const int cand[] = {4, 2, 3, 5, 7, 11, 13};
+    for (int r : cand)
+        while (n % r == 0 && rad.n < 24) {
+            rad.r[rad.n++] = r;
+            n /= r;
+        }
+    return n == 1;
+}
+
+struct Plan {
+    int n, L, L1, L2;
+    Rad rad1, rad2;
+};
+
+static const int LDS_BUDGET = 64 * 1024;
+
+static int max_single(bool f64) {
+    if (g_max_single > 0) return g_max_single;
+    return f64 ? 1024 : 2048;
+}
+
+static int make_plan(int nfft, bool f64, Plan& p) {
+    if (nfft < 2 || (nfft & 1)) {
+        set_error("nfft=%d: only even transform lengths are supported", nfft);
+        return FL_ERR_UNSUPPORTED;
+    }
+    p.n = nfft;
+    p.L = nfft / 2;
+    const int ms = max_single(f64);
+    const int maxrow = f64 ? 512 : 1024;
+    if (p.L <= ms) {
+        p.L1 = 1;
+        p.L2 = p.L;
+    } else {
+        p.L1 = 0;
+        for (int d = (int)floor(sqrt((double)p.L)); d >= 2; --d) {
+            if (p.L % d == 0) {
+                if (p.L / d <= maxrow) {
+                    p.L1 = d;
+                    p.L2 = p.L / d;
+                } else if (p.L / d <= 2 * maxrow) {  // long columns, short rows
+                    p.L1 = p.L / d;
+                    p.L2 = d;
+                }
+                break;
+            }
+        }
+        if (!p.L1) {
+            set_error("nfft=%d: no two-pass factorisation with row length <= %d", nfft, maxrow);
+            return FL_ERR_UNSUPPORTED;
+        }
+    }
+    if (!factorize(p.L1, p.rad1) || !factorize(p.L2, p.rad2)) {
+        set_error("nfft=%d: half-length %d has a prime factor > 13", nfft, p.L);
+        return FL_ERR_UNSUPPORTED;
+    }
+    return FL_OK;
+}
+
+template <typename T>
+static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipStream_t st) {
+    const int esz = (int)sizeof(cx<T>);
+    const int budget = LDS_BUDGET / esz;  // complex elements of LDS
+    a.n = p.n; a.L = p.L; a.L1 = p.L1; a.L2 = p.L2;
+    a.L1P = p.L1 | 1; a.L2P = p.L2 | 1;
+    a.rad1 = p.rad1; a.rad2 = p.rad2;
+    if (nsig <= 0) return FL_OK;
+    if (p.L1 > 1) {
+        FL_REQUIRE(a.scratch != nullptr, "two-pass FFT (nfft=%d) needs a scratch buffer", p.n);
+        int ct = (budget - p.L1) / (2 * a.L1P);
+        if (ct > 32) ct = 32;
+        FL_REQUIRE(ct >= 1, "column pass does not fit in LDS (L1=%d)", p.L1);
+        a.CT = ct;
+        a.ntiles = cdiv_i(p.L2, ct);
+        const size_t lds = (size_t)(2 * ct * a.L1P + p.L1) * esz;
+        const size_t nblk = (size_t)a.ntiles * nsig;
+        FL_REQUIRE(nblk < (1ull << 31), "grid too large");
+        if (inverse)
+            hipLaunchKernelGGL((fft_cols<T, LOAD_IRFFT_PRE, true>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+        else
+            hipLaunchKernelGGL((fft_cols<T, LOAD_PACK, false>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+        FL_CHECK_LAUNCH("fft_cols");
+    }
+    {
+        const int per = (inverse || p.L1 == 1) ? 1 : 2;  // slots per primary row
+        a.per = per;
+        int rt = (budget - p.L2) / (2 * per * a.L2P);
+        if (rt > 32) rt = 32;
+        FL_REQUIRE(rt >= 1, "row pass does not fit in LDS (L2=%d)", p.L2);
+        const int P = inverse ? p.L1 : (p.L1 / 2 + 1);
+        if (rt > P) rt = P;
+        a.RT = rt;
+        a.ntiles = cdiv_i(P, rt);
+        const size_t lds = (size_t)(2 * per * rt * a.L2P + p.L2) * esz;
+        const size_t nblk = (size_t)a.ntiles * nsig;
+        FL_REQUIRE(nblk < (1ull << 31), "grid too large");
+        if (!inverse) {
+            if (p.L1 > 1)
+                hipLaunchKernelGGL((fft_rows<T, LOAD_SCRATCH, EPI_RFFT_POST, false>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            else
+                hipLaunchKernelGGL((fft_rows<T, LOAD_PACK, EPI_RFFT_POST, false>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+        } else {
+            if (p.L1 > 1)
+                hipLaunchKernelGGL((fft_rows<T, LOAD_SCRATCH, EPI_IRFFT_STORE, true>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            else
+                hipLaunchKernelGGL((fft_rows<T, LOAD_IRFFT_PRE, EPI_IRFFT_STORE, true>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+        }
+        FL_CHECK_LAUNCH("fft_rows");
+    }
+    return FL_OK;
+}
+
+template <typename T>
+static int rfft_impl(const void* x, long x_sig_stride, int t_in, void* X, void* scratch, const void* W, int nsig,
+                     int nfft, double scale, double env_log2, int interior_x2, void* stream) {
+    Plan p;
+    int rc = make_plan(nfft, sizeof(T) == 8, p);
+    if (rc) return rc;
+    FL_REQUIRE(x && X && W, "rfft: null pointer");
+    FL_REQUIRE(t_in >= 0 && nsig >= 0, "rfft: bad sizes");
+    FftArgs<T> a = {};
+    a.xr = (const T*)x;
+    a.xr_stride = x_sig_stride;
+    a.t_in = t_in < nfft ? t_in : nfft;
+    a.Xout = (cx<T>*)X;
+    a.scratch = (cx<T>*)scratch;
+    a.W = (const cx<T>*)W;
+    a.scale = (T)scale;
+    a.env_log2 = env_log2;
+    a.interior = interior_x2;
+    return launch_fft<T>(false, a, p, nsig, (hipStream_t)stream);
+}
+
+template <typename T>
+static int irfft_impl(const void* X, void* y, long y_sig_stride, int t_out, void* scratch, const void* W, int nsig,
+                      int nfft, double scale, double env_log2, int interior_half, void* stream) {
+    Plan p;
+    int rc = make_plan(nfft, sizeof(T) == 8, p);
+    if (rc) return rc;
+    FL_REQUIRE(X && y && W, "irfft: null pointer");
+    FL_REQUIRE(t_out >= 0 && t_out <= nfft && nsig >= 0, "irfft: t_out must be in [0, nfft]");
+    FftArgs<T> a = {};
+    a.Xc = (const cx<T>*)X;
+    a.yr = (T*)y;
+    a.yr_stride = y_sig_stride;
+    a.t_out = t_out;
+    a.scratch = (cx<T>*)scratch;
+    a.W = (const cx<T>*)W;
+    a.scale = (T)scale;
+    a.env_log2 = env_log2;
+    a.interior = interior_half;
+    return launch_fft<T>(true, a, p, nsig, (hipStream_t)stream);
+}
+
+template <typename T>
+static int twiddle_impl(void* W, int nfft, void* stream) {
+    FL_REQUIRE(W && nfft > 0, "twiddle: bad arguments");
+    hipLaunchKernelGGL((twiddle_fill<T>), dim3(cdiv_i(nfft, 256)), dim3(256), 0, (hipStream_t)stream, (cx<T>*)W, nfft);
+    FL_CHECK_LAUNCH("twiddle_fill");
+    return FL_OK;
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+extern "C" {
+
+int fl_twiddle_fill_f32(void* W, int nfft, void* stream) { return twiddle_impl<float>(W, nfft, stream); }
+int fl_twiddle_fill_f64(void* W, int nfft, void* stream) { return twiddle_impl<double>(W, nfft, stream); }
+
+int fl_fft_plan(int nfft, int is_f64, int* L1, int* L2) {
+    Plan p;
+    int rc = make_plan(nfft, is_f64 != 0, p);
+    if (rc) return rc;
+    if (L1) *L1 = p.L1;
+    if (L2) *L2 = p.L2;
+    return FL_OK;
+}
+
+size_t fl_fft_scratch_elems(int nfft, int is_f64, int nsig) {
+    Plan p;
+    if (make_plan(nfft, is_f64 != 0, p) != FL_OK) return 0;
+    if (p.L1 == 1 || nsig <= 0) return 0;
+    return (size_t)p.L * (size_t)nsig;
+}
+
+int fl_debug_set_fft_max_single(int max_half_len) {
+    g_max_single = max_half_len > 0 ? max_half_len : 0;
+    return FL_OK;
+}
+
+int fl_rfft_f32(const void* x, long xs, int t_in, void* X, void* scratch, const void* W, int nsig, int nfft,
+                double scale, double env_log2, int interior_x2, void* stream) {
+    return rfft_impl<float>(x, xs, t_in, X, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
+}
+int fl_rfft_f64(const void* x, long xs, int t_in, void* X, void* scratch, const void* W, int nsig, int nfft,
+                double scale, double env_log2, int interior_x2, void* stream) {
+    return rfft_impl<double>(x, xs, t_in, X, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
+}
+int fl_irfft_f32(const void* X, void* y, long ys, int t_out, void* scratch, const void* W, int nsig, int nfft,
+                 double scale, double env_log2, int interior_half, void* stream) {
+    return irfft_impl<float>(X, y, ys, t_out, scratch, W, nsig, nfft, scale, env_log2, interior_half, stream);
+}
+int fl_irfft_f64(const void* X, void* y, long ys, int t_out, void* scratch, const void* W, int nsig, int nfft,
+                 double scale, double env_log2, int interior_half, void* stream) {
+    return irfft_impl<double>(X, y, ys, t_out, scratch, W, nsig, nfft, scale, env_log2, interior_half, stream);
+}
+
+int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, int elem_bytes, void* stream) {
+    FL_REQUIRE(src && dst, "transpose: null pointer");
+    FL_REQUIRE(nbatch >= 0 && rows >= 0 && cols >= 0, "transpose: bad sizes");
+    if (nbatch == 0 || rows == 0 || cols == 0) return FL_OK;
+    FL_REQUIRE(nbatch <= 65535 && cdiv_i(rows, 32) <= 65535, "transpose: batch/rows too large");
+    dim3 grid(cdiv_i(cols, 32), cdiv_i(rows, 32), nbatch);
+    hipStream_t st = (hipStream_t)stream;
+    switch (elem_bytes) {
+        case 4: hipLaunchKernelGGL((transpose_kernel<uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, rows, cols); break;
+        case 8: hipLaunchKernelGGL((transpose_kernel<uint64_t>), grid, dim3(256), 0, st, (const uint64_t*)src, (uint64_t*)dst, rows, cols); break;
+        case 16: hipLaunchKernelGGL((transpose_kernel<uint4>), grid, dim3(256), 0, st, (const uint4*)src, (uint4*)dst, rows, cols); break;
+        default: set_error("transpose: elem_bytes must be 4, 8 or 16"); return FL_ERR_BAD_ARG;
+    }
+    FL_CHECK_LAUNCH("transpose");
+    return FL_OK;
+}
+
+}  // extern "C"

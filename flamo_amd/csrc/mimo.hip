@@ -1,0 +1,272 @@
+// Per-frequency-bin complex MIMO products for gfx950 (MI355X).
+//
+//   Y[b,m,k,f] = sum_n H[f,m,n] X[b,n,k,f]            (flamo "fmn,bfn...->bfm...", dsp.py:922-924)
+//
+// All tensors are bin-planar (the bin axis f is contiguous), so a wavefront of 64 lanes owns
+// 64 adjacent bins and every global access is a fully coalesced 512 B (c64) / 1 KiB (c128)
+// segment.  The op is HBM-bound (N/2 flop per byte at N channels, far below the CDNA4 ridge),
+// so the kernels are plain VALU FMA streams: no LDS, no MFMA -- the (No x Ni) contraction per
+// bin is far too small for a 16x16/32x32 MFMA tile and reshaping bins into a GEMM would only
+// add traffic.  Each lane keeps an (MT x BT) accumulator tile: MT output channels x BT
+// batch/trailing columns, so one H element loaded is reused BT times and one X element MT
+// times from registers.
+#include "common.h"
+
+namespace fl {
+
+template <typename T, int MT, int BT>
+__global__ void __launch_bounds__(256) mimo_full_kernel(
+    const cx<T>* __restrict__ H, long hs_f, long hs_m, long hs_n, int conj_h,
+    const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
+    cx<T>* __restrict__ Y, long ys_b, long ys_m, long ys_k,
+    int B, int M, int No, int Ni, int K) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= M) return;
+    const int col0 = blockIdx.y * BT;
+    const int m0 = blockIdx.z * MT;
+    const int ncols = B * K;
+    long xoff[BT], yoff[BT];
+    bool cv[BT];
+#pragma unroll
+    for (int c = 0; c < BT; ++c) {
+        const int col = col0 + c;
+        cv[c] = col < ncols;
+        const int b = cv[c] ? col / K : 0, k = cv[c] ? col - b * K : 0;
+        xoff[c] = (long)b * xs_b + (long)k * xs_k + f;
+        yoff[c] = (long)b * ys_b + (long)k * ys_k + f;
+    }
+    cx<T> acc[BT][MT];
+#pragma unroll
+    for (int c = 0; c < BT; ++c)
+#pragma unroll
+        for (int mm = 0; mm < MT; ++mm) acc[c][mm] = cx<T>(0, 0);
+    const cx<T>* Hf = H + (long)f * hs_f;
+    for (int n = 0; n < Ni; ++n) {
+        cx<T> h[MT], x[BT];
+#pragma unroll
+        for (int mm = 0; mm < MT; ++mm) {
+            const int m = m0 + mm;
+            h[mm] = (m < No) ? Hf[(long)m * hs_m + (long)n * hs_n] : cx<T>(0, 0);
+            if (conj_h) h[mm].y = -h[mm].y;
+        }
+#pragma unroll
+        for (int c = 0; c < BT; ++c) x[c] = cv[c] ? X[xoff[c] + (long)n * xs_n] : cx<T>(0, 0);
+#pragma unroll
+        for (int c = 0; c < BT; ++c)
+#pragma unroll
+            for (int mm = 0; mm < MT; ++mm) fma_cx(acc[c][mm], h[mm], x[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < BT; ++c) {
+        if (!cv[c]) continue;
+#pragma unroll
+        for (int mm = 0; mm < MT; ++mm) {
+            const int m = m0 + mm;
+            if (m < No) Y[yoff[c] + (long)m * ys_m] = acc[c][mm];
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) mimo_diag_kernel(
+    const cx<T>* __restrict__ h, long hs_f, long hs_n, int conj_h,
+    const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
+    cx<T>* __restrict__ Y, long ys_b, long ys_n, long ys_k, int B, int M, int N, int K) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= M) return;
+    const int n = blockIdx.y;
+    cx<T> hv = h[(long)f * hs_f + (long)n * hs_n];
+    if (conj_h) hv.y = -hv.y;
+    const int ncols = B * K;
+    for (int col = blockIdx.z; col < ncols; col += gridDim.z) {
+        const int b = col / K, k = col - b * K;
+        Y[(long)b * ys_b + (long)n * ys_n + (long)k * ys_k + f] =
+            hv * X[(long)b * xs_b + (long)n * xs_n + (long)k * xs_k + f];
+    }
+}
+
+// dH[m,n,f] = scale * sum_{b,k} G[b,m,k,f] conj(X[b,n,k,f])
+template <typename T, int MT, int NT>
+__global__ void __launch_bounds__(256) mimo_gradh_kernel(
+    const cx<T>* __restrict__ G, long gs_b, long gs_m, long gs_k,
+    const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
+    cx<T>* __restrict__ dH, T scale, int B, int M, int No, int Ni, int K) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= M) return;
+    const int m0 = blockIdx.y * MT, n0 = blockIdx.z * NT;
+    cx<T> acc[MT][NT];
+#pragma unroll
+    for (int mm = 0; mm < MT; ++mm)
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) acc[mm][nn] = cx<T>(0, 0);
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < K; ++k) {
+            const cx<T>* g = G + (long)b * gs_b + (long)k * gs_k + f;
+            const cx<T>* x = X + (long)b * xs_b + (long)k * xs_k + f;
+            cx<T> gv[MT], xv[NT];
+#pragma unroll
+            for (int mm = 0; mm < MT; ++mm) gv[mm] = (m0 + mm < No) ? g[(long)(m0 + mm) * gs_m] : cx<T>(0, 0);
+#pragma unroll
+            for (int nn = 0; nn < NT; ++nn) xv[nn] = (n0 + nn < Ni) ? x[(long)(n0 + nn) * xs_n] : cx<T>(0, 0);
+#pragma unroll
+            for (int mm = 0; mm < MT; ++mm)
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) fma_cxc(acc[mm][nn], gv[mm], xv[nn]);
+        }
+#pragma unroll
+    for (int mm = 0; mm < MT; ++mm)
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+            const int m = m0 + mm, n = n0 + nn;
+            if (m < No && n < Ni) dH[((long)m * Ni + n) * M + f] = cx<T>(scale * acc[mm][nn].x, scale * acc[mm][nn].y);
+        }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) mimo_gradh_diag_kernel(
+    const cx<T>* __restrict__ G, long gs_b, long gs_n, long gs_k,
+    const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
+    cx<T>* __restrict__ dh, int B, int M, int N, int K) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= M) return;
+    const int n = blockIdx.y;
+    cx<T> acc(0, 0);
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < K; ++k)
+            fma_cxc(acc, G[(long)b * gs_b + (long)n * gs_n + (long)k * gs_k + f],
+                    X[(long)b * xs_b + (long)n * xs_n + (long)k * xs_k + f]);
+    dh[(long)n * M + f] = acc;
+}
+
+// ---------------------------------------------------------------- host dispatch
+template <typename T, int MT>
+static int launch_full_bt(int bt, dim3 grid, hipStream_t st, const cx<T>* H, long hs_f, long hs_m, long hs_n, int conj_h,
+                          const cx<T>* X, long xs_b, long xs_n, long xs_k, cx<T>* Y, long ys_b, long ys_m, long ys_k,
+                          int B, int M, int No, int Ni, int K) {
+    if (bt == 4)
+        hipLaunchKernelGGL((mimo_full_kernel<T, MT, 4>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
+                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+    else if (bt == 2)
+        hipLaunchKernelGGL((mimo_full_kernel<T, MT, 2>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
+                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+    else
+        hipLaunchKernelGGL((mimo_full_kernel<T, MT, 1>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
+                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+    FL_CHECK_LAUNCH("mimo_full");
+    return FL_OK;
+}
+
+template <typename T>
+static int mimo_impl(const void* H, long hs_f, long hs_m, long hs_n, int conj_h, const void* X, long xs_b, long xs_n,
+                     long xs_k, void* Y, long ys_b, long ys_m, long ys_k, int B, int M, int No, int Ni, int K,
+                     void* stream) {
+    FL_REQUIRE(H && X && Y, "mimo: null pointer");
+    FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo: bad sizes");
+    if (B == 0 || M == 0) return FL_OK;
+    const int ncols = B * K;
+    const int bt = ncols >= 4 ? 4 : (ncols >= 2 ? 2 : 1);
+    const int mt = No >= 8 ? 8 : (No >= 4 ? 4 : (No >= 2 ? 2 : 1));
+    dim3 grid(cdiv_i(M, 256), cdiv_i(ncols, bt), cdiv_i(No, mt));
+    FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo: too many batch columns / channels for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    const cx<T>* h = (const cx<T>*)H;
+    const cx<T>* x = (const cx<T>*)X;
+    cx<T>* y = (cx<T>*)Y;
+    switch (mt) {
+        case 8: return launch_full_bt<T, 8>(bt, grid, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+        case 4: return launch_full_bt<T, 4>(bt, grid, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+        case 2: return launch_full_bt<T, 2>(bt, grid, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+        default: return launch_full_bt<T, 1>(bt, grid, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+    }
+}
+
+template <typename T>
+static int mimo_diag_impl(const void* h, long hs_f, long hs_n, int conj_h, const void* X, long xs_b, long xs_n, long xs_k,
+                          void* Y, long ys_b, long ys_n, long ys_k, int B, int M, int N, int K, void* stream) {
+    FL_REQUIRE(h && X && Y, "mimo_diag: null pointer");
+    FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0 && N <= 65535, "mimo_diag: bad sizes");
+    if (B == 0 || M == 0) return FL_OK;
+    int gz = B * K;
+    if (gz > 1024) gz = 1024;
+    dim3 grid(cdiv_i(M, 256), N, gz);
+    hipLaunchKernelGGL((mimo_diag_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)h, hs_f, hs_n, conj_h,
+                       (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)Y, ys_b, ys_n, ys_k, B, M, N, K);
+    FL_CHECK_LAUNCH("mimo_diag");
+    return FL_OK;
+}
+
+template <typename T>
+static int gradh_impl(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                      void* dH, double scale, int B, int M, int No, int Ni, int K, void* stream) {
+    FL_REQUIRE(G && X && dH, "mimo_gradh: null pointer");
+    FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo_gradh: bad sizes");
+    if (M == 0) return FL_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (No >= 4 && Ni >= 4) {
+        dim3 grid(cdiv_i(M, 256), cdiv_i(No, 4), cdiv_i(Ni, 4));
+        FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradh: too many channels");
+        hipLaunchKernelGGL((mimo_gradh_kernel<T, 4, 4>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
+                           (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, (T)scale, B, M, No, Ni, K);
+    } else {
+        dim3 grid(cdiv_i(M, 256), No, Ni);
+        FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradh: too many channels");
+        hipLaunchKernelGGL((mimo_gradh_kernel<T, 1, 1>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
+                           (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, (T)scale, B, M, No, Ni, K);
+    }
+    FL_CHECK_LAUNCH("mimo_gradh");
+    return FL_OK;
+}
+
+template <typename T>
+static int gradh_diag_impl(const void* G, long gs_b, long gs_n, long gs_k, const void* X, long xs_b, long xs_n,
+                           long xs_k, void* dh, int B, int M, int N, int K, void* stream) {
+    FL_REQUIRE(G && X && dh, "mimo_gradh_diag: null pointer");
+    FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0 && N <= 65535, "mimo_gradh_diag: bad sizes");
+    if (M == 0) return FL_OK;
+    dim3 grid(cdiv_i(M, 256), N);
+    hipLaunchKernelGGL((mimo_gradh_diag_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)G, gs_b, gs_n,
+                       gs_k, (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dh, B, M, N, K);
+    FL_CHECK_LAUNCH("mimo_gradh_diag");
+    return FL_OK;
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+extern "C" {
+
+int fl_mimo_c64(const void* H, long hs_f, long hs_m, long hs_n, int conj_h, const void* X, long xs_b, long xs_n, long xs_k,
+                void* Y, long ys_b, long ys_m, long ys_k, int B, int M, int No, int Ni, int K, void* stream) {
+    return mimo_impl<float>(H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n, xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, stream);
+}
+int fl_mimo_c128(const void* H, long hs_f, long hs_m, long hs_n, int conj_h, const void* X, long xs_b, long xs_n, long xs_k,
+                 void* Y, long ys_b, long ys_m, long ys_k, int B, int M, int No, int Ni, int K, void* stream) {
+    return mimo_impl<double>(H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n, xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, stream);
+}
+int fl_mimo_diag_c64(const void* h, long hs_f, long hs_n, int conj_h, const void* X, long xs_b, long xs_n, long xs_k,
+                     void* Y, long ys_b, long ys_n, long ys_k, int B, int M, int N, int K, void* stream) {
+    return mimo_diag_impl<float>(h, hs_f, hs_n, conj_h, X, xs_b, xs_n, xs_k, Y, ys_b, ys_n, ys_k, B, M, N, K, stream);
+}
+int fl_mimo_diag_c128(const void* h, long hs_f, long hs_n, int conj_h, const void* X, long xs_b, long xs_n, long xs_k,
+                      void* Y, long ys_b, long ys_n, long ys_k, int B, int M, int N, int K, void* stream) {
+    return mimo_diag_impl<double>(h, hs_f, hs_n, conj_h, X, xs_b, xs_n, xs_k, Y, ys_b, ys_n, ys_k, B, M, N, K, stream);
+}
+int fl_mimo_gradh_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                      void* dH, double scale, int B, int M, int No, int Ni, int K, void* stream) {
+    return gradh_impl<float>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, dH, scale, B, M, No, Ni, K, stream);
+}
+int fl_mimo_gradh_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                       void* dH, double scale, int B, int M, int No, int Ni, int K, void* stream) {
+    return gradh_impl<double>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, dH, scale, B, M, No, Ni, K, stream);
+}
+int fl_mimo_gradh_diag_c64(const void* G, long gs_b, long gs_n, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                           void* dh, int B, int M, int N, int K, void* stream) {
+    return gradh_diag_impl<float>(G, gs_b, gs_n, gs_k, X, xs_b, xs_n, xs_k, dh, B, M, N, K, stream);
+}
+int fl_mimo_gradh_diag_c128(const void* G, long gs_b, long gs_n, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                            void* dh, int B, int M, int N, int K, void* stream) {
+    return gradh_diag_impl<double>(G, gs_b, gs_n, gs_k, X, xs_b, xs_n, xs_k, dh, B, M, N, K, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,221 @@
+// Frequency-response generators evaluated directly per bin (gfx950 / MI355X).
+//
+//  * integer delay lines: H[c,k] = amp[c] * W_n^((k*m_c) mod n)  -- exact integer phase index
+//    (Delay/parallelDelay with isint=True, flamo/processor/dsp.py:3356-3365, 3512-3521);
+//  * second-order-section cascades: H[c,k] = prod_s B_s(k) / prod_s A_s(k) with
+//    B_s(k) = b0 + b1 g w + b2 g^2 w^2, w = W_n^k -- what the reference obtains from
+//    rfft(3 taps, nfft) per section followed by prod/prod (dsp.py:1520-1526, 2587-2593),
+//    without ever materialising the (M, sections, N_out, N_in) tensors; plus its backward.
+#include "common.h"
+
+namespace fl {
+
+template <typename T>
+__global__ void __launch_bounds__(256) delay_response_kernel(const int32_t* __restrict__ m, const T* __restrict__ amp,
+                                                            const cx<T>* __restrict__ W, int nfft, int bin0,
+                                                            int m_local, cx<T>* __restrict__ H) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= m_local) return;
+    const int c = blockIdx.y;
+    const long long k = bin0 + f;
+    long long idx = (k * (long long)m[c]) % nfft;
+    if (idx < 0) idx += nfft;
+    const cx<T> w = W[idx];
+    const T a = amp[c];
+    H[(size_t)c * m_local + f] = cx<T>(a * w.x, a * w.y);
+}
+
+template <typename T>
+struct SosEval {
+    cx<T> z1, z2;  // g*w, g^2*w^2
+    __device__ inline cx<T> poly(const T* co, int S, int C, int s, int c) const {
+        const T c0 = co[((size_t)0 * S + s) * C + c];
+        const T c1 = co[((size_t)1 * S + s) * C + c];
+        const T c2 = co[((size_t)2 * S + s) * C + c];
+        return cx<T>(c0 + c1 * z1.x + c2 * z2.x, c1 * z1.y + c2 * z2.y);
+    }
+};
+
+template <typename T>
+__device__ inline SosEval<T> sos_point(const cx<T>* W, int nfft, int k, T g) {
+    SosEval<T> e;
+    const cx<T> w1 = W[k % nfft];
+    const cx<T> w2 = W[(2 * (long long)k) % nfft];
+    e.z1 = cx<T>(g * w1.x, g * w1.y);
+    e.z2 = cx<T>(g * g * w2.x, g * g * w2.y);
+    return e;
+}
+
+template <typename T> __device__ inline T eps_of();
+template <> __device__ inline float eps_of<float>() { return 1.1920928955078125e-07f; }
+template <> __device__ inline double eps_of<double>() { return 2.220446049250313e-16; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) sos_response_kernel(const T* __restrict__ b, const T* __restrict__ a, int S, int C,
+                                                          T g, const cx<T>* __restrict__ W, int nfft, int bin0,
+                                                          int m_local, cx<T>* __restrict__ H) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= m_local) return;
+    const int c = blockIdx.y;
+    const SosEval<T> e = sos_point<T>(W, nfft, bin0 + f, g);
+    cx<T> Bp(1, 0), Ap(1, 0);
+    for (int s = 0; s < S; ++s) {
+        Bp = Bp * e.poly(b, S, C, s, c);
+        Ap = Ap * e.poly(a, S, C, s, c);
+    }
+    cx<T> h = (Ap.x != 0 || Ap.y != 0) ? cdiv(Bp, Ap) : cx<T>(eps_of<T>(), 0);
+    H[(size_t)c * m_local + f] = h;
+}
+
+// Backward: dL/db[p,s,c] = sum_k Re(conj(gH) * H/B_s * z_p),  dL/da[p,s,c] = -sum_k Re(conj(gH) * H/A_s * z_p)
+// Sections are processed in chunks of 4 (blockIdx.z) so the 24 running sums stay in registers.
+template <typename T>
+__global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __restrict__ gH, const T* __restrict__ b,
+                                                              const T* __restrict__ a, int S, int C, T g,
+                                                              const cx<T>* __restrict__ W, int nfft, int bin0,
+                                                              int m_local, T* __restrict__ part) {
+    const int c = blockIdx.y;
+    const int s0 = blockIdx.z * 4;
+    T acc[2][3][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][p][q] = 0;
+
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < m_local; f += gridDim.x * 256) {
+        const SosEval<T> e = sos_point<T>(W, nfft, bin0 + f, g);
+        cx<T> Bp(1, 0), Ap(1, 0);
+        for (int s = 0; s < S; ++s) {
+            Bp = Bp * e.poly(b, S, C, s, c);
+            Ap = Ap * e.poly(a, S, C, s, c);
+        }
+        if (Ap.x == 0 && Ap.y == 0) continue;  // guarded bins are the constant eps: zero gradient
+        const cx<T> h = cdiv(Bp, Ap);
+        const cx<T> gc = conj(gH[(size_t)c * m_local + f]);
+        const cx<T> zp[3] = {cx<T>(1, 0), e.z1, e.z2};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = s0 + q;
+            if (s >= S) break;
+            const cx<T> Bs = e.poly(b, S, C, s, c), As = e.poly(a, S, C, s, c);
+            cx<T> qb;
+            if (Bs.x != 0 || Bs.y != 0) {
+                qb = cdiv(h, Bs);
+            } else {  // numerator section vanishes at this bin: product of the others
+                cx<T> o(1, 0);
+                for (int t = 0; t < S; ++t)
+                    if (t != s) o = o * e.poly(b, S, C, t, c);
+                qb = cdiv(o, Ap);
+            }
+            const cx<T> qa = cdiv(h, As);
+            const cx<T> tb = gc * qb, ta = gc * qa;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                acc[0][p][q] += tb.x * zp[p].x - tb.y * zp[p].y;     // Re(tb * z_p)
+                acc[1][p][q] -= ta.x * zp[p].x - ta.y * zp[p].y;
+            }
+        }
+    }
+    // block reduction: wavefront shuffles, then 4 partials through LDS
+    __shared__ T red[4][24];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                T v = acc[i][p][q];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (lane == 0) red[wave][(i * 3 + p) * 4 + q] = v;
+            }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        const int i = threadIdx.x / 12, p = (threadIdx.x / 4) % 3, q = threadIdx.x % 4;
+        const int s = s0 + q;
+        if (s < S) {
+            const T v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            part[((((size_t)blockIdx.x * 2 + i) * 3 + p) * S + s) * C + c] = v;
+        }
+    }
+}
+
+static int sos_blocks(int m_local) {
+    int nb = cdiv_i(m_local, 256);
+    if (nb > 32) nb = 32;
+    if (nb < 1) nb = 1;
+    return nb;
+}
+
+template <typename T>
+static int delay_impl(const int32_t* m, const void* amp, int C, const void* W, int nfft, int bin0, int m_local, void* H,
+                      void* stream) {
+    FL_REQUIRE(m && amp && W && H, "delay_response: null pointer");
+    FL_REQUIRE(C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local >= 0, "delay_response: bad sizes");
+    if (m_local == 0) return FL_OK;
+    dim3 grid(cdiv_i(m_local, 256), C);
+    hipLaunchKernelGGL((delay_response_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, m, (const T*)amp,
+                       (const cx<T>*)W, nfft, bin0, m_local, (cx<T>*)H);
+    FL_CHECK_LAUNCH("delay_response");
+    return FL_OK;
+}
+
+template <typename T>
+static int sos_impl(const void* b, const void* a, int S, int C, double gamma, const void* W, int nfft, int bin0,
+                    int m_local, void* H, void* stream) {
+    FL_REQUIRE(b && a && W && H, "sos_response: null pointer");
+    FL_REQUIRE(S > 0 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local >= 0, "sos_response: bad sizes");
+    if (m_local == 0) return FL_OK;
+    dim3 grid(cdiv_i(m_local, 256), C);
+    hipLaunchKernelGGL((sos_response_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)b, (const T*)a, S, C,
+                       (T)gamma, (const cx<T>*)W, nfft, bin0, m_local, (cx<T>*)H);
+    FL_CHECK_LAUNCH("sos_response");
+    return FL_OK;
+}
+
+template <typename T>
+static int sos_bwd_impl(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* W, int nfft,
+                        int bin0, int m_local, void* part, void* stream) {
+    FL_REQUIRE(gH && b && a && W && part, "sos_response_bwd: null pointer");
+    FL_REQUIRE(S > 0 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local > 0, "sos_response_bwd: bad sizes");
+    dim3 grid(sos_blocks(m_local), C, cdiv_i(S, 4));
+    hipLaunchKernelGGL((sos_response_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)gH,
+                       (const T*)b, (const T*)a, S, C, (T)gamma, (const cx<T>*)W, nfft, bin0, m_local, (T*)part);
+    FL_CHECK_LAUNCH("sos_response_bwd");
+    return FL_OK;
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+extern "C" {
+int fl_delay_response_c64(const int32_t* m, const void* amp, int C, const void* W, int nfft, int bin0, int m_local,
+                          void* H, void* stream) {
+    return delay_impl<float>(m, amp, C, W, nfft, bin0, m_local, H, stream);
+}
+int fl_delay_response_c128(const int32_t* m, const void* amp, int C, const void* W, int nfft, int bin0, int m_local,
+                           void* H, void* stream) {
+    return delay_impl<double>(m, amp, C, W, nfft, bin0, m_local, H, stream);
+}
+int fl_sos_response_f32(const void* b, const void* a, int S, int C, double gamma, const void* W, int nfft, int bin0,
+                        int m_local, void* H, void* stream) {
+    return sos_impl<float>(b, a, S, C, gamma, W, nfft, bin0, m_local, H, stream);
+}
+int fl_sos_response_f64(const void* b, const void* a, int S, int C, double gamma, const void* W, int nfft, int bin0,
+                        int m_local, void* H, void* stream) {
+    return sos_impl<double>(b, a, S, C, gamma, W, nfft, bin0, m_local, H, stream);
+}
+int fl_sos_bwd_blocks(int m_local) { return sos_blocks(m_local); }
+int fl_sos_response_bwd_f32(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* W,
+                            int nfft, int bin0, int m_local, void* part, void* stream) {
+    return sos_bwd_impl<float>(gH, b, a, S, C, gamma, W, nfft, bin0, m_local, part, stream);
+}
+int fl_sos_response_bwd_f64(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* W,
+                            int nfft, int bin0, int m_local, void* part, void* stream) {
+    return sos_bwd_impl<double>(gH, b, a, S, C, gamma, W, nfft, bin0, m_local, part, stream);
+}
+}

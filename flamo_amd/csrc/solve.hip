@@ -1,0 +1,162 @@
+// Bin-parallel closed-loop solve for system.Recursion (gfx950 / MI355X).
+//
+//   per bin f:  A_f = I - P[:,:,f]  (or P, or the conjugate transpose of either)
+//               OUT[b,:,k,f] = A_f^{-1} R[b,:,k,f]   for every batch b and trailing column k
+//
+// replacing torch.linalg.solve(A, B) at flamo/processor/system.py:425.  The reference expands
+// the SAME (M,N,N) matrix stack to the batch and LAPACK factors it B times; here each bin is
+// factored once (LU, partial pivoting by |re|+|im| like LAPACK's icamax) and the factors are
+// applied to all B*K right-hand sides.
+//
+// Mapping: NMAX = next power of two >= N lanes cooperate on one bin, one matrix ROW per lane
+// held in registers (2*NMAX VGPRs for c64), so a 64-wide wavefront factors 64/NMAX bins at
+// once.  Row exchanges are implicit (each lane remembers at which step its row was the
+// pivot); the pivot row is broadcast with cross-lane shuffles -- no LDS, no atomics.  The
+// kernel is vector-ALU bound (8/3 N^3 flop per bin vs ~8 N^2 bytes), the N x N update is a
+// rank-1 update per step, not a dense tile contraction, so MFMA does not apply.
+#include "common.h"
+
+namespace fl {
+
+template <typename T>
+__device__ inline cx<T> shfl_cx(cx<T> v, int src, int width) {
+    return cx<T>(__shfl(v.x, src, width), __shfl(v.y, src, width));
+}
+
+template <typename T, int NMAX>
+__global__ void __launch_bounds__(256) solve_kernel(
+    const cx<T>* __restrict__ P, int one_minus, int adjoint,
+    const cx<T>* __restrict__ R, long rs_b, long rs_n, long rs_k,
+    cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
+    int B, int M, int N, int K) {
+    constexpr int BPB = 256 / NMAX;
+    const int gi = threadIdx.x % NMAX;
+    const int f = blockIdx.x * BPB + threadIdx.x / NMAX;
+    if (f >= M) return;  // whole lane group leaves together
+
+    // ---- load this lane's row of A
+    cx<T> row[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+        cx<T> v(0, 0);
+        if (gi < N && j < N) {
+            v = adjoint ? conj(P[((long)j * N + gi) * M + f]) : P[((long)gi * N + j) * M + f];
+            if (one_minus) v = cx<T>(-v.x, -v.y);
+        }
+        if (one_minus ? (j == gi) : (j == gi && gi >= N)) v.x += (T)1;
+        row[j] = v;
+    }
+
+    // ---- LU with implicit partial pivoting
+    int my_step = (gi < N) ? -1 : NMAX + gi;  // step at which this lane's row became the pivot
+    int pl[NMAX];                              // pivot lane of each step (uniform in the group)
+    cx<T> dinv(0, 0);                          // reciprocal of this lane's pivot
+#pragma unroll
+    for (int k = 0; k < NMAX; ++k) {
+        pl[k] = 0;
+        if (k < N) {
+            T bm = (my_step < 0) ? (fabs(row[k].x) + fabs(row[k].y)) : (T)-1;
+            int best = gi;
+#pragma unroll
+            for (int off = NMAX / 2; off >= 1; off >>= 1) {
+                const T om = __shfl_xor(bm, off, NMAX);
+                const int ob = __shfl_xor(best, off, NMAX);
+                if (om > bm || (om == bm && ob < best)) {
+                    bm = om;
+                    best = ob;
+                }
+            }
+            pl[k] = best;
+            const cx<T> piv = shfl_cx(row[k], best, NMAX);
+            const cx<T> inv = cdiv(cx<T>(1, 0), piv);
+            const bool elim = (my_step < 0) && (gi != best);
+            const cx<T> l = elim ? row[k] * inv : cx<T>(0, 0);
+#pragma unroll
+            for (int j = k + 1; j < NMAX; ++j) {
+                if (j < N) {
+                    const cx<T> pr = shfl_cx(row[j], best, NMAX);
+                    row[j] = row[j] - l * pr;
+                }
+            }
+            if (elim) row[k] = l;
+            if (gi == best) {
+                my_step = k;
+                dinv = inv;
+            }
+        }
+    }
+
+    // ---- apply to every right-hand side
+    const int ncols = B * K;
+    for (int col = 0; col < ncols; ++col) {
+        const int b = col / K, kk = col - b * K;
+        cx<T> y(0, 0);
+        if (gi < N) y = R[(long)b * rs_b + (long)gi * rs_n + (long)kk * rs_k + f];
+        // forward substitution with the stored multipliers
+#pragma unroll
+        for (int k = 0; k < NMAX; ++k) {
+            if (k < N) {
+                const cx<T> yp = shfl_cx(y, pl[k], NMAX);
+                if (my_step > k && my_step < NMAX) y = y - row[k] * yp;
+            }
+        }
+        // back substitution: lane pl[k] finishes x_k, the earlier pivots subtract U[.,k] x_k
+#pragma unroll
+        for (int k = NMAX - 1; k >= 0; --k) {
+            if (k < N) {
+                if (my_step == k) y = y * dinv;
+                const cx<T> xk = shfl_cx(y, pl[k], NMAX);
+                if (my_step < k) y = y - row[k] * xk;
+            }
+        }
+        if (gi < N) OUT[(long)b * os_b + (long)my_step * os_n + (long)kk * os_k + f] = y;
+    }
+}
+
+template <typename T, int NMAX>
+static int launch_solve(const void* P, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
+                        void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, hipStream_t st) {
+    constexpr int BPB = 256 / NMAX;
+    dim3 grid(cdiv_i(M, BPB));
+    hipLaunchKernelGGL((solve_kernel<T, NMAX>), grid, dim3(256), 0, st, (const cx<T>*)P, one_minus, adjoint,
+                       (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);
+    FL_CHECK_LAUNCH("solve");
+    return FL_OK;
+}
+
+template <typename T>
+static int solve_impl(const void* P, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
+                      void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+    FL_REQUIRE(P && R && OUT, "solve: null pointer");
+    FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0, "solve: bad sizes");
+    const int nmax_lim = sizeof(T) == 8 ? 32 : 64;
+    if (N > nmax_lim) {
+        set_error("solve: N=%d exceeds the register-resident limit (%d) for this precision", N, nmax_lim);
+        return FL_ERR_UNSUPPORTED;
+    }
+    if (B == 0 || M == 0) return FL_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define FL_SOLVE(NM) return launch_solve<T, NM>(P, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, st)
+    if (N <= 4) FL_SOLVE(4);
+    if (N <= 8) FL_SOLVE(8);
+    if (N <= 16) FL_SOLVE(16);
+    if (N <= 32) FL_SOLVE(32);
+    if constexpr (sizeof(T) == 4) FL_SOLVE(64);
+#undef FL_SOLVE
+    return FL_ERR_UNSUPPORTED;
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+extern "C" {
+int fl_solve_c64(const void* P, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+                 long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+    return solve_impl<float>(P, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+int fl_solve_c128(const void* P, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+                  long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+    return solve_impl<double>(P, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+}

@@ -1,0 +1,518 @@
+"""Autograd operators of the hot path, each a thin host wrapper over one C-ABI entry point.
+
+Layout.  Frequency-domain tensors keep flamo's logical shape ``(B, M, N, ...)`` but are stored
+*bin-planar*: memory order ``(B, N, ..., M)`` with the bin axis contiguous, exposed through a
+``movedim`` view -- the same memory order ``torch.fft.rfft(dim=1)`` itself returns for a
+contiguous ``(B, T, N)`` input, so user code written against the reference sees identical
+shapes.  Time-domain tensors produced here are signal-planar ``(B, N, ..., T)`` likewise.
+Tensors that arrive in another layout are converted once with the LDS transpose kernel.
+
+PyTorch is used for device memory, streams and autograd bookkeeping only; every arithmetic
+pass over (B, M, ...) data is one of the HIP kernels.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+__all__ = ["rfft", "irfft", "mimo", "solve", "delay_response", "sos_response", "to_planar", "set_bin_shard",
+           "bin_shard"]
+
+
+# ----------------------------------------------------------------------------- plumbing
+def _require_gpu(*ts: torch.Tensor) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "flamo_amd: tensors must live on a ROCm device (got %s); the HIP path has no CPU fallback" % t.device
+            )
+        dev = t.device if dev is None else dev
+        if t.device != dev:
+            raise RuntimeError("flamo_amd: tensors on different devices")
+    return dev
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rdtype(t: torch.Tensor) -> torch.dtype:
+    if t.dtype in (torch.complex64, torch.float32):
+        return torch.float32
+    if t.dtype in (torch.complex128, torch.float64):
+        return torch.float64
+    raise TypeError(f"flamo_amd: unsupported dtype {t.dtype} (float32/float64 and their complex types only)")
+
+
+def _cdtype(real: torch.dtype) -> torch.dtype:
+    return torch.complex64 if real == torch.float32 else torch.complex128
+
+
+def _sfx(real: torch.dtype, cplx: bool) -> str:
+    if cplx:
+        return "c64" if real == torch.float32 else "c128"
+    return "f32" if real == torch.float32 else "f64"
+
+
+def _prod(xs) -> int:
+    p = 1
+    for v in xs:
+        p *= int(v)
+    return p
+
+
+_twiddles = {}
+
+
+def twiddles(nfft: int, real: torch.dtype, device: torch.device) -> torch.Tensor:
+    """Master table W[j] = exp(-2 pi i j / nfft), cached per (nfft, precision, device)."""
+    key = (int(nfft), real, device.index if device.index is not None else torch.cuda.current_device())
+    W = _twiddles.get(key)
+    if W is None:
+        W = torch.empty(nfft, dtype=_cdtype(real), device=device)
+        L = _lib.lib()
+        fn = L.fl_twiddle_fill_f32 if real == torch.float32 else L.fl_twiddle_fill_f64
+        _lib.check(fn(W.data_ptr(), nfft, _stream()), "twiddle_fill")
+        _twiddles[key] = W
+    return W
+
+
+def _transpose(src: torch.Tensor, nbatch: int, rows: int, cols: int) -> torch.Tensor:
+    """src: contiguous memory (nbatch, rows, cols) -> new contiguous (nbatch, cols, rows)."""
+    dst = torch.empty(nbatch * cols * rows, dtype=src.dtype, device=src.device)
+    if dst.numel():
+        _lib.check(_lib.lib().fl_transpose(src.data_ptr(), dst.data_ptr(), nbatch, rows, cols, src.element_size(),
+                                           _stream()), "transpose")
+    return dst
+
+
+def _is_planar(x: torch.Tensor) -> bool:
+    """memory order (B, rest..., axis1) contiguous"""
+    return x.movedim(1, -1).is_contiguous()
+
+
+def to_planar(x: torch.Tensor) -> torch.Tensor:
+    """Same logical tensor (B, A, rest...) stored with axis 1 contiguous (memory (B, rest..., A))."""
+    if x.dim() < 2:
+        raise ValueError("expected at least 2 dims")
+    if _is_planar(x):
+        return x
+    B, A = x.shape[0], x.shape[1]
+    rest = tuple(x.shape[2:])
+    xc = x.contiguous()  # no-op for the usual channel-innermost layout
+    out = _transpose(xc, B, A, _prod(rest))
+    return out.view(B, *rest, A).movedim(-1, 1)
+
+
+def _empty_planar(shape: Tuple[int, ...], dtype, device) -> torch.Tensor:
+    B, A = shape[0], shape[1]
+    rest = tuple(shape[2:])
+    return torch.empty((B, *rest, A), dtype=dtype, device=device).movedim(-1, 1)
+
+
+def _bnk(x: torch.Tensor):
+    """(B, M, N, K) sizes and element strides (s_b, s_n, s_k) of a planar tensor (B, M, N, rest...)."""
+    B, M, N = x.shape[0], x.shape[1], x.shape[2]
+    K = _prod(x.shape[3:])
+    mem = x.movedim(1, -1)  # (B, N, rest..., M) contiguous
+    s_b = mem.stride(0)
+    s_n = mem.stride(1)
+    s_k = M  # trailing dims are contiguous just above the bin axis
+    return B, M, N, K, s_b, s_n, s_k
+
+
+# ----------------------------------------------------------------------------- kernel timing (bench.py)
+class KernelTimer:
+    """HIP-event timing of individual kernel launches on the stream they are launched on
+    (bench.py's roofline leg).  Disabled by default: zero overhead on the hot path."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def reset(self, enabled: bool):
+        self.enabled = enabled
+        self.records = {}
+
+    def span(self, name):
+        timer = self
+
+        class _Span:
+            def __enter__(self_):
+                if timer.enabled:
+                    self_.a = torch.cuda.Event(enable_timing=True)
+                    self_.b = torch.cuda.Event(enable_timing=True)
+                    self_.a.record(torch.cuda.current_stream())
+                return self_
+
+            def __exit__(self_, *exc):
+                if timer.enabled:
+                    self_.b.record(torch.cuda.current_stream())
+                    timer.records.setdefault(name, []).append((self_.a, self_.b))
+                return False
+
+        return _Span()
+
+    def summary(self):
+        """name -> (launches, mean milliseconds); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), sum(ms) / max(len(ms), 1))
+        return out
+
+
+kernel_timer = KernelTimer()
+
+
+# ----------------------------------------------------------------------------- bin sharding (multi-GPU)
+_shard = {"bin0": 0, "m_local": None}
+
+
+def set_bin_shard(bin0: int = 0, m_local: Optional[int] = None) -> None:
+    """Restrict the response generators to bins [bin0, bin0+m_local) (flamo_amd.dist sets this
+    per rank; default: all nfft//2+1 bins)."""
+    _shard["bin0"] = int(bin0)
+    _shard["m_local"] = None if m_local is None else int(m_local)
+
+
+def bin_shard(nfft: int) -> Tuple[int, int]:
+    M = nfft // 2 + 1
+    if _shard["m_local"] is None:
+        return 0, M
+    return _shard["bin0"], _shard["m_local"]
+
+
+# ----------------------------------------------------------------------------- transforms
+_NORM_FWD = {"backward": lambda n: 1.0, "ortho": lambda n: 1.0 / math.sqrt(n), "forward": lambda n: 1.0 / n}
+_NORM_INV = {"backward": lambda n: 1.0 / n, "ortho": lambda n: 1.0 / math.sqrt(n), "forward": lambda n: 1.0}
+
+
+def _rfft_launch(xp: torch.Tensor, t_in: int, nfft: int, scale: float, env_log2: float, interior_x2: int):
+    """xp: signal-planar real, logical (B, T, rest...), memory (B, rest..., T).  Returns planar X."""
+    real = _rdtype(xp)
+    dev = xp.device
+    B = xp.shape[0]
+    rest = tuple(xp.shape[2:])
+    nsig = B * _prod(rest)
+    M = nfft // 2 + 1
+    X = torch.empty((B, *rest, M), dtype=_cdtype(real), device=dev)
+    L = _lib.lib()
+    f64 = int(real == torch.float64)
+    n_scr = L.fl_fft_scratch_elems(nfft, f64, nsig)
+    scratch = torch.empty(max(n_scr, 1), dtype=_cdtype(real), device=dev)
+    fn = L.fl_rfft_f64 if f64 else L.fl_rfft_f32
+    _lib.check(fn(xp.movedim(1, -1).data_ptr(), xp.shape[1], t_in, X.data_ptr(), scratch.data_ptr(),
+                  twiddles(nfft, real, dev).data_ptr(), nsig, nfft, scale, env_log2, interior_x2, _stream()), "rfft")
+    return X.movedim(-1, 1)
+
+
+def _irfft_launch(Xp: torch.Tensor, nfft: int, t_out: int, t_alloc: int, scale: float, env_log2: float,
+                  interior_half: int):
+    """Xp: bin-planar complex (B, M, rest...).  Returns signal-planar real (B, t_alloc, rest...)."""
+    real = _rdtype(Xp)
+    dev = Xp.device
+    B = Xp.shape[0]
+    rest = tuple(Xp.shape[2:])
+    nsig = B * _prod(rest)
+    alloc = torch.zeros if t_alloc > t_out else torch.empty
+    y = alloc((B, *rest, t_alloc), dtype=real, device=dev)
+    L = _lib.lib()
+    f64 = int(real == torch.float64)
+    n_scr = L.fl_fft_scratch_elems(nfft, f64, nsig)
+    scratch = torch.empty(max(n_scr, 1), dtype=_cdtype(real), device=dev)
+    fn = L.fl_irfft_f64 if f64 else L.fl_irfft_f32
+    _lib.check(fn(Xp.movedim(1, -1).data_ptr(), y.data_ptr(), t_alloc, t_out, scratch.data_ptr(),
+                  twiddles(nfft, real, dev).data_ptr(), nsig, nfft, scale, env_log2, interior_half, _stream()), "irfft")
+    return y.movedim(-1, 1)
+
+
+class _Rfft(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, nfft, scale, env_log2):
+        _require_gpu(x)
+        if x.is_complex():
+            raise TypeError("rfft expects a real tensor")
+        ctx.meta = (nfft, scale, env_log2, x.shape[1])
+        xp = to_planar(x)
+        return _rfft_launch(xp, min(x.shape[1], nfft), nfft, scale, env_log2, 0)
+
+    @staticmethod
+    def backward(ctx, gX):
+        nfft, scale, env_log2, T = ctx.meta
+        # g_x[t] = scale e(t) Re sum_k g_X[k] exp(+j w_k t): an inverse real FFT with the
+        # interior bins halved (undoing the C2R doubling), cropped / zero-extended to T
+        g = _irfft_launch(to_planar(gX.resolve_conj()), nfft, min(T, nfft), T, scale, env_log2, 1)
+        return g, None, None, None
+
+
+class _Irfft(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, nfft, scale, env_log2):
+        _require_gpu(X)
+        if not X.is_complex():
+            raise TypeError("irfft expects a complex tensor")
+        if X.shape[1] != nfft // 2 + 1:
+            raise ValueError(f"irfft: expected {nfft // 2 + 1} bins along dim 1, got {X.shape[1]}")
+        ctx.meta = (nfft, scale, env_log2)
+        return _irfft_launch(to_planar(X.resolve_conj()), nfft, nfft, nfft, scale, env_log2, 0)
+
+    @staticmethod
+    def backward(ctx, gy):
+        nfft, scale, env_log2 = ctx.meta
+        # g_X[k] = w_k scale sum_t g_y[t] e(t) exp(-j w_k t), w_k = 2 on interior bins
+        g = _rfft_launch(to_planar(gy), nfft, nfft, scale, env_log2, 1)
+        return g, None, None, None
+
+
+def env_log2_of(alias_decay_db: float, nfft: int) -> float:
+    """log2 of the per-sample growth of the envelope gamma^-t, gamma = 10^(-|dB|/(20 nfft))
+    (dsp.py:153-160), derived in float64 on the host."""
+    return abs(float(alias_decay_db)) / (20.0 * nfft) * math.log2(10.0)
+
+
+def rfft(x: torch.Tensor, nfft: int, norm: str = "backward", alias_decay_db: Optional[float] = None) -> torch.Tensor:
+    """torch.fft.rfft(x [* gamma^-t], n=nfft, dim=1, norm=norm) on the HIP path."""
+    if norm not in _NORM_FWD:
+        raise ValueError(f"Invalid normalization mode: {norm}")
+    env = 0.0 if not alias_decay_db else env_log2_of(alias_decay_db, nfft)
+    return _Rfft.apply(x, int(nfft), _NORM_FWD[norm](nfft), env)
+
+
+def irfft(X: torch.Tensor, nfft: int, norm: str = "backward", alias_decay_db: Optional[float] = None) -> torch.Tensor:
+    """torch.fft.irfft(X, n=nfft, dim=1, norm=norm) [* gamma^-t] on the HIP path."""
+    if norm not in _NORM_INV:
+        raise ValueError(f"Invalid normalization mode: {norm}")
+    env = 0.0 if not alias_decay_db else env_log2_of(alias_decay_db, nfft)
+    return _Irfft.apply(X, int(nfft), _NORM_INV[norm](nfft), env)
+
+
+# ----------------------------------------------------------------------------- per-bin MIMO product
+def _h_planar(H: torch.Tensor, per_bin: bool) -> torch.Tensor:
+    """Per-bin responses (M, ...) are used with the bin axis contiguous."""
+    if not per_bin:
+        return H.contiguous()
+    if H.movedim(0, -1).is_contiguous():
+        return H
+    M = H.shape[0]
+    rest = tuple(H.shape[1:])
+    out = _transpose(H.contiguous(), 1, M, _prod(rest))
+    return out.view(*rest, M).movedim(-1, 0)
+
+
+def _mimo_launch(H, per_bin, diag, conj_t, X):
+    """Y = op(H) X.  conj_t: use H^H (swap m/n, conjugate)."""
+    real = _rdtype(X)
+    B, M, Nx, K, xs_b, xs_n, xs_k = _bnk(X)
+    L = _lib.lib()
+    if diag:
+        N = H.shape[-1]
+        hs_f, hs_n = (1, M) if per_bin else (0, 1)
+        Y = _empty_planar(X.shape, X.dtype, X.device)
+        _, _, _, _, ys_b, ys_n, ys_k = _bnk(Y)
+        fn = L.fl_mimo_diag_c64 if real == torch.float32 else L.fl_mimo_diag_c128
+        _lib.check(fn(H.data_ptr(), hs_f, hs_n, int(conj_t), X.data_ptr(), xs_b, xs_n, xs_k, Y.data_ptr(), ys_b, ys_n,
+                      ys_k, B, M, N, K, _stream()), "mimo_diag")
+        return Y
+    No_h, Ni_h = H.shape[-2], H.shape[-1]
+    if per_bin:
+        hs_f, hs_m, hs_n = 1, Ni_h * M, M
+    else:
+        hs_f, hs_m, hs_n = 0, Ni_h, 1
+    if conj_t:
+        No, Ni, hs_m, hs_n = Ni_h, No_h, hs_n, hs_m
+    else:
+        No, Ni = No_h, Ni_h
+    Y = _empty_planar((B, M, No, *X.shape[3:]), X.dtype, X.device)
+    _, _, _, _, ys_b, ys_m, ys_k = _bnk(Y)
+    fn = L.fl_mimo_c64 if real == torch.float32 else L.fl_mimo_c128
+    tag = ("mimo_bin" if per_bin else "mimo_const") + ("_adj" if conj_t else "_fwd")
+    with kernel_timer.span(tag):
+        _lib.check(fn(H.data_ptr(), hs_f, hs_m, hs_n, int(conj_t), X.data_ptr(), xs_b, xs_n, xs_k, Y.data_ptr(), ys_b,
+                      ys_m, ys_k, B, M, No, Ni, K, _stream()), "mimo")
+    return Y
+
+
+def _gradh_launch(G, X, diag, scale=1.0):
+    """sum over batch/trailing dims of G x conj(X): planar (No, Ni, M) [full] or (N, M) [diag]."""
+    real = _rdtype(X)
+    B, M, Ni, K, xs_b, xs_n, xs_k = _bnk(X)
+    _, _, No, _, gs_b, gs_m, gs_k = _bnk(G)
+    L = _lib.lib()
+    if diag:
+        dh = torch.empty((Ni, M), dtype=X.dtype, device=X.device)
+        fn = L.fl_mimo_gradh_diag_c64 if real == torch.float32 else L.fl_mimo_gradh_diag_c128
+        _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dh.data_ptr(), B, M, Ni, K,
+                      _stream()), "mimo_gradh_diag")
+        return dh if scale == 1.0 else dh * scale
+    dH = torch.empty((No, Ni, M), dtype=X.dtype, device=X.device)
+    fn = L.fl_mimo_gradh_c64 if real == torch.float32 else L.fl_mimo_gradh_c128
+    _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dH.data_ptr(), float(scale), B, M,
+                  No, Ni, K, _stream()), "mimo_gradh")
+    return dH
+
+
+class _Mimo(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, H, X, diag):
+        _require_gpu(H, X)
+        if not X.is_complex():
+            raise TypeError("the per-bin product expects a complex (frequency-domain) signal")
+        per_bin = H.dim() == (2 if diag else 3)
+        if H.dim() not in ((1, 2) if diag else (2, 3)):
+            raise ValueError(f"bad response rank {H.dim()}")
+        M = X.shape[1]
+        if per_bin and H.shape[0] != M:
+            raise ValueError(f"response has {H.shape[0]} bins, signal has {M}")
+        if H.shape[-1] != X.shape[2]:
+            raise ValueError(f"response expects {H.shape[-1]} input channels, signal has {X.shape[2]}")
+        Hp = _h_planar(H.resolve_conj(), per_bin)
+        Xp = to_planar(X.resolve_conj())
+        ctx.save_for_backward(Hp, Xp)
+        ctx.cfg = (per_bin, bool(diag))
+        return _mimo_launch(Hp, per_bin, diag, False, Xp)
+
+    @staticmethod
+    def backward(ctx, gY):
+        Hp, Xp = ctx.saved_tensors
+        per_bin, diag = ctx.cfg
+        gY = to_planar(gY.resolve_conj())
+        gH = gX = None
+        if ctx.needs_input_grad[1]:
+            gX = _mimo_launch(Hp, per_bin, diag, True, gY)
+        if ctx.needs_input_grad[0]:
+            g = _gradh_launch(gY, Xp, diag)  # planar (.., M)
+            gH = g.movedim(-1, 0) if per_bin else g.sum(dim=-1)
+        return gH, gX, None
+
+
+def mimo(H: torch.Tensor, X: torch.Tensor, diag: bool = False) -> torch.Tensor:
+    """Per-bin complex product.  ``H``: (M,No,Ni) | (No,Ni) for ``diag=False``; (M,N) | (N,) for
+    ``diag=True``.  ``X``: (B, M, Ni, ...).  Implements the four flamo einsum patterns
+    "fmn,bfn...->bfm...", "mn,bfn...->bfm...", "fn,bfn...->bfn...", "n,bfn...->bfn..."."""
+    if H.dtype != X.dtype:
+        H = H.to(X.dtype)  # differentiable cast (real -> complex, or precision)
+    return _Mimo.apply(H, X, bool(diag))
+
+
+# ----------------------------------------------------------------------------- closed-loop solve
+def _solve_launch(Pp, one_minus, adjoint, R):
+    real = _rdtype(R)
+    B, M, N, K, rs_b, rs_n, rs_k = _bnk(R)
+    OUT = _empty_planar(R.shape, R.dtype, R.device)
+    _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
+    L = _lib.lib()
+    fn = L.fl_solve_c64 if real == torch.float32 else L.fl_solve_c128
+    _lib.check(fn(Pp.data_ptr(), int(one_minus), int(adjoint), R.data_ptr(), rs_b, rs_n, rs_k, OUT.data_ptr(), os_b,
+                  os_n, os_k, B, M, N, K, _stream()), "solve")
+    return OUT
+
+
+class _Solve(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, P, R, one_minus):
+        _require_gpu(P, R)
+        # P: (1, M, N, N) or (M, N, N) logical; stored planar (N, N, M)
+        P3 = P[0] if P.dim() == 4 else P
+        if P.dim() == 4 and P.shape[0] != 1:
+            raise ValueError("solve: the system matrix must not be batched (it is batch-independent)")
+        M, N = P3.shape[0], P3.shape[1]
+        if P3.shape[2] != N or R.shape[1] != M or R.shape[2] != N:
+            raise ValueError(f"solve: incompatible shapes {tuple(P.shape)} and {tuple(R.shape)}")
+        Pp = _h_planar(P3.resolve_conj(), True)
+        Rp = to_planar(R.resolve_conj())
+        OUT = _solve_launch(Pp, one_minus, False, Rp)
+        ctx.save_for_backward(Pp, OUT)
+        ctx.cfg = (bool(one_minus), P.dim())
+        return OUT
+
+    @staticmethod
+    def backward(ctx, gOUT):
+        Pp, OUT = ctx.saved_tensors
+        one_minus, pdim = ctx.cfg
+        gR = _solve_launch(Pp, one_minus, True, to_planar(gOUT.resolve_conj()))  # A^-H g
+        gP = None
+        if ctx.needs_input_grad[0]:
+            # dA = -gR out^H ;  dP = -dA when A = I - P
+            gP = _gradh_launch(gR, OUT, False, scale=(1.0 if one_minus else -1.0)).movedim(-1, 0)
+            if pdim == 4:
+                gP = gP.unsqueeze(0)
+        return gP, (gR if ctx.needs_input_grad[1] else None), None
+
+
+def solve(P: torch.Tensor, R: torch.Tensor, one_minus: bool = True) -> torch.Tensor:
+    """Per bin: (I - P[f])^-1 R[:, f] (``one_minus``) or P[f]^-1 R[:, f]; R: (B, M, N[, K...])."""
+    if P.dtype != R.dtype:
+        P = P.to(R.dtype)
+    return _Solve.apply(P, R, bool(one_minus))
+
+
+# ----------------------------------------------------------------------------- responses
+def delay_response(m_int: torch.Tensor, amp: torch.Tensor, nfft: int) -> torch.Tensor:
+    """Integer-delay response H[k, ...] = amp[...] * exp(-2 pi i ((k * m[...]) mod nfft) / nfft)
+    for the local bin range.  m_int: integer tensor (any shape); amp: real, same shape."""
+    dev = _require_gpu(m_int, amp)
+    real = _rdtype(amp)
+    bin0, m_local = bin_shard(nfft)
+    shape = tuple(m_int.shape)
+    C_ = max(_prod(shape), 1)
+    m32 = m_int.to(torch.int32).contiguous()
+    amp = amp.contiguous()
+    H = torch.empty((*shape, m_local), dtype=_cdtype(real), device=dev)
+    L = _lib.lib()
+    fn = L.fl_delay_response_c64 if real == torch.float32 else L.fl_delay_response_c128
+    _lib.check(fn(m32.data_ptr(), amp.data_ptr(), C_, twiddles(nfft, real, dev).data_ptr(), nfft, bin0, m_local,
+                  H.data_ptr(), _stream()), "delay_response")
+    return H.movedim(-1, 0)
+
+
+class _Sos(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, b, a, gamma, nfft):
+        dev = _require_gpu(b, a)
+        real = _rdtype(b)
+        if b.shape != a.shape or b.shape[0] != 3 or b.dim() < 2:
+            raise ValueError("sos_response: b and a must both be (3, n_sections, ...)")
+        bc, ac = b.contiguous(), a.contiguous()
+        S = b.shape[1]
+        chan = tuple(b.shape[2:])
+        C_ = max(_prod(chan), 1)
+        bin0, m_local = bin_shard(nfft)
+        H = torch.empty((*chan, m_local), dtype=_cdtype(real), device=dev)
+        L = _lib.lib()
+        fn = L.fl_sos_response_f32 if real == torch.float32 else L.fl_sos_response_f64
+        _lib.check(fn(bc.data_ptr(), ac.data_ptr(), S, C_, float(gamma), twiddles(nfft, real, dev).data_ptr(), nfft,
+                      bin0, m_local, H.data_ptr(), _stream()), "sos_response")
+        ctx.save_for_backward(bc, ac)
+        ctx.cfg = (float(gamma), nfft, S, C_, bin0, m_local)
+        return H.movedim(-1, 0)
+
+    @staticmethod
+    def backward(ctx, gH):
+        bc, ac = ctx.saved_tensors
+        gamma, nfft, S, C_, bin0, m_local = ctx.cfg
+        real = _rdtype(bc)
+        dev = bc.device
+        g = gH.resolve_conj()
+        g = g if g.movedim(0, -1).is_contiguous() else _h_planar(g, True)
+        L = _lib.lib()
+        nblk = L.fl_sos_bwd_blocks(m_local)
+        part = torch.zeros((nblk, 2, 3, S, C_), dtype=real, device=dev)
+        fn = L.fl_sos_response_bwd_f32 if real == torch.float32 else L.fl_sos_response_bwd_f64
+        _lib.check(fn(g.data_ptr(), bc.data_ptr(), ac.data_ptr(), S, C_, gamma, twiddles(nfft, real, dev).data_ptr(),
+                      nfft, bin0, m_local, part.data_ptr(), _stream()), "sos_response_bwd")
+        tot = part.sum(dim=0)
+        return tot[0].view(bc.shape), tot[1].view(ac.shape), None, None
+
+
+def sos_response(b: torch.Tensor, a: torch.Tensor, gamma: float, nfft: int) -> torch.Tensor:
+    """H[k, ...] = prod_s B_s(k) / prod_s A_s(k) of a cascade of second-order sections with
+    coefficients b, a: (3, n_sections, ...) real (anti-alias radius gamma applied to the taps)."""
+    return _Sos.apply(b, a, float(gamma), int(nfft))

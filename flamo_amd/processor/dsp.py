@@ -1,0 +1,644 @@
+"""Drop-in counterparts of ``flamo.processor.dsp`` for the frequency-sampling hot path, executed
+by hand-written HIP kernels on MI355X (``flamo_amd.ops``).
+
+Same class names, constructor signatures, attributes (``param``, ``map``, ``gamma``, ``nfft``,
+``alias_decay_db``, ``freq_response``, ``freq_convolve``, ``input_channels``/``output_channels``),
+tensor conventions (time ``(B, T, N, ...)``, frequency ``(B, M, N, ...)`` with ``M = nfft//2+1``)
+and error behaviour as the reference (gdalsanto/flamo v0.2.13; citations are to its
+``flamo/processor/dsp.py``).  What differs is where the arithmetic runs:
+
+* ``FFT``/``iFFT``/``*AntiAlias``     -> ``ops.rfft`` / ``ops.irfft``   (torch.fft.rfft/irfft, dsp.py:88,114,161,204)
+* every ``freq_convolve``            -> ``ops.mimo``                   (the four einsum patterns, dsp.py:466,552,922,1021)
+* SOS-type responses (Biquad, GEQ)   -> ``ops.sos_response``           (rfft(3 taps)+prod/prod, dsp.py:1520-1526)
+* integer delays                     -> ``ops.delay_response``         (exp(-j w m), dsp.py:3356-3374)
+
+Parameter maps (matrix_exp, log10, softplus, RBJ / shelving formulas) stay in PyTorch: they act
+on a few hundred scalars and autograd differentiates them for free.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..functional import (GEQDesign, HadamardMatrix, RotationMatrix, bandpass_filter, eq_freqs, highpass_filter,
+                          lowpass_filter, rad2hertz, skew_matrix)
+from ..utils import to_complex
+
+_identity = lambda x: x  # noqa: E731
+
+
+def _gamma(alias_decay_db, nfft, device=None, dtype=torch.float32) -> torch.Tensor:
+    db = torch.as_tensor(alias_decay_db, device=device, dtype=dtype)
+    return 10 ** (-torch.abs(db) / nfft / 20)
+
+
+# ============================================================================ transforms
+class Transform(nn.Module):
+    """Wraps a callable as a layer (dsp.py:27-66)."""
+
+    def __init__(self, transform: callable = _identity, device: Optional[str] = None,
+                 dtype: torch.dtype = torch.float32):
+        super().__init__()
+        self.transform = transform
+        self.device = device
+        self.dtype = dtype
+
+    def forward(self, x: torch.Tensor):
+        return self.transform(x)
+
+    def probe(self, z: torch.Tensor):
+        return None
+
+
+class FFT(Transform):
+    """Real FFT along dim 1, ``(B, T, N, ...) -> (B, nfft//2+1, N, ...)`` (dsp.py:69-93)."""
+
+    def __init__(self, nfft: int = 2 ** 11, norm: str = "backward", dtype: torch.dtype = torch.float32):
+        self.nfft, self.norm = nfft, norm
+        super().__init__(transform=lambda x: ops.rfft(x, self.nfft, self.norm), dtype=dtype)
+
+
+class iFFT(Transform):
+    """Inverse real FFT along dim 1 (dsp.py:96-119)."""
+
+    def __init__(self, nfft: int = 2 ** 11, norm: str = "backward", dtype: torch.dtype = torch.float32):
+        self.nfft, self.norm = nfft, norm
+        super().__init__(transform=lambda x: ops.irfft(x, self.nfft, self.norm), dtype=dtype)
+
+
+class _AntiAliasMixin:
+    def _setup(self, nfft, norm, alias_decay_db, device, dtype):
+        self.nfft, self.norm = nfft, norm
+        self._alias_db = float(alias_decay_db)
+        gamma = _gamma(alias_decay_db, nfft, device, dtype)
+        # kept for API parity; the kernels regenerate gamma^-t in registers from log2(gamma)
+        self.alias_envelope = gamma ** torch.arange(0, -nfft, -1, device=device, dtype=dtype)
+
+    def _check(self, x):
+        # the reference applies the envelope with einsum("btm,t->btm"): 3-D input, T == nfft
+        if x.dim() != 3 or x.shape[1] != self.nfft:
+            raise RuntimeError(
+                f"anti-alias transform expects a (B, {self.nfft}, N) tensor, got {tuple(x.shape)}")
+
+
+class FFTAntiAlias(Transform, _AntiAliasMixin):
+    """rfft(x * gamma^-t) -- the envelope is the *rising* one, as coded in dsp.py:153-162."""
+
+    def __init__(self, nfft: int = 2 ** 11, norm: str = "backward", alias_decay_db: float = 0.0,
+                 device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        self._setup(nfft, norm, alias_decay_db, device, dtype)
+
+        def transform(x):
+            self._check(x)
+            return ops.rfft(x, self.nfft, self.norm, self._alias_db)
+
+        super().__init__(transform=transform, device=device, dtype=dtype)
+
+
+class iFFTAntiAlias(Transform, _AntiAliasMixin):
+    """irfft(X) * gamma^-t (dsp.py:166-206)."""
+
+    def __init__(self, nfft: int = 2 ** 11, norm: str = "backward", alias_decay_db: float = 0.0,
+                 device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        self._setup(nfft, norm, alias_decay_db, device, dtype)
+
+        def transform(x):
+            if x.dim() != 3:
+                raise RuntimeError(f"anti-alias transform expects a (B, M, N) tensor, got {tuple(x.shape)}")
+            return ops.irfft(x, self.nfft, self.norm, self._alias_db)
+
+        super().__init__(transform=transform, device=device, dtype=dtype)
+
+
+# ============================================================================ core base class
+class DSP(nn.Module):
+    """Learnable LTI block: raw ``param`` -> ``map`` -> frequency response -> product with the
+    input spectrum (dsp.py:212-352)."""
+
+    def __init__(self, size: tuple, nfft: int = 2 ** 11, map: callable = _identity, requires_grad: bool = False,
+                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        super().__init__()
+        assert isinstance(size, tuple), "Size must be a tuple."
+        self.size = size
+        self.nfft = nfft
+        self.map = map
+        self.new_value = 0
+        self.requires_grad = requires_grad
+        self.device = device
+        self.dtype = dtype
+        self.param = nn.Parameter(torch.empty(self.size, device=device, dtype=dtype), requires_grad=requires_grad)
+        # transforms along dim 0 (taps -> response), on the same HIP FFT as the signal path
+        self.fft = lambda x: ops.rfft(x.unsqueeze(0), self.nfft)[0]
+        self.ifft = lambda x: ops.irfft(x.unsqueeze(0), self.nfft)[0]
+        self.alias_decay_db = torch.tensor(alias_decay_db, device=device, dtype=dtype)
+        self.init_param()
+        self.get_gamma()
+
+    def forward(self, x, **kwargs):
+        warnings.warn("Forward method not implemented. Input is returned.", UserWarning)
+        return x
+
+    def init_param(self):
+        torch.nn.init.normal_(self.param)
+
+    def get_gamma(self):
+        self.gamma = 10 ** (-torch.abs(self.alias_decay_db) / self.nfft / 20)
+        # float64 host copy used by the kernels: gamma is raised to powers up to nfft, so the
+        # float32-rounded tensor above (kept for API parity) would cost 1e-4 of accuracy
+        self._gamma_f = 10.0 ** (-abs(float(self.alias_decay_db)) / self.nfft / 20.0)
+
+    def assign_value(self, new_value: torch.Tensor, indx: tuple = tuple([slice(None)])):
+        assert (
+            self.param[indx].shape == new_value.shape
+        ), f"New values shape {new_value.shape} is not compatible with the parameter shape {self.param[indx].shape}."
+        with torch.no_grad():
+            self.param[indx].copy_(new_value)
+            self.new_value = 1
+
+    def probe(self, z: torch.Tensor):
+        raise NotImplementedError(f"probe() not implemented for {self.__class__.__name__}")
+
+    def probe_w(self, w: torch.Tensor):
+        return self.probe(1 / w)
+
+    # ---- shared by all subclasses
+    def _run(self, x, ext_param):
+        self.check_input_shape(x)
+        if ext_param is None:
+            return self.freq_convolve(x, self.param)
+        with torch.no_grad():
+            self.assign_value(ext_param)
+        return self.freq_convolve(x, ext_param)
+
+    def _gamma_on(self, t: torch.Tensor) -> torch.Tensor:
+        return self.gamma.to(device=t.device)
+
+
+# ============================================================================ gains / matrices
+class Gain(DSP):
+    """Frequency-independent gain matrix, param (N_out, N_in) (dsp.py:357-496)."""
+
+    _diag = False
+
+    def __init__(self, size: tuple = (1, 1), nfft: int = 2 ** 11, map: callable = _identity,
+                 requires_grad: bool = False, alias_decay_db: float = 0.0, device: Optional[str] = None,
+                 dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, nfft=nfft, map=map, requires_grad=requires_grad, alias_decay_db=alias_decay_db,
+                         device=device, dtype=dtype)
+        self.initialize_class()
+
+    def forward(self, x, ext_param=None):
+        return self._run(x, ext_param)
+
+    def check_input_shape(self, x):
+        if self.input_channels != x.shape[2]:
+            raise ValueError(f"parameter shape = {self.size} not compatible with input signal of shape = ({x.shape}).")
+
+    def check_param_shape(self):
+        assert len(self.size) == 2, "gains must be 2D. For 1D (parallel) gains use parallelGain module."
+
+    def get_freq_convolve(self):
+        self.freq_convolve = lambda x, param: ops.mimo(to_complex(self.map(param)), x, diag=self._diag)
+
+    def initialize_class(self):
+        self.check_param_shape()
+        self.get_io()
+        self.get_freq_convolve()
+
+    def get_io(self):
+        self.input_channels = self.size[-1]
+        self.output_channels = self.size[-2]
+
+    def probe(self, z: torch.Tensor):
+        return to_complex(self.map(self.param))
+
+
+class parallelGain(Gain):
+    """Per-channel gains, param (N,) (dsp.py:499-573)."""
+
+    _diag = True
+
+    def __init__(self, size: tuple = (1,), nfft: int = 2 ** 11, map: callable = _identity,
+                 requires_grad: bool = False, alias_decay_db: float = 0.0, device: Optional[str] = None,
+                 dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, nfft=nfft, map=map, requires_grad=requires_grad, alias_decay_db=alias_decay_db,
+                         device=device, dtype=dtype)
+
+    def check_param_shape(self):
+        assert len(self.size) == 1, "gains must be 1D, for 2D gains use Gain module."
+
+    def get_io(self):
+        self.input_channels = self.output_channels = self.size[-1]
+
+    def probe(self, z: torch.Tensor):
+        return torch.diag(to_complex(self.map(self.param)))
+
+
+class Matrix(Gain):
+    """Gain matrix with a structural map: random | orthogonal | hadamard | rotation (dsp.py:579-676)."""
+
+    def __init__(self, size: tuple = (1, 1), nfft: int = 2 ** 11, map: callable = _identity,
+                 matrix_type: str = "random", iter: int = 1, requires_grad: bool = False,
+                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        self.matrix_type = matrix_type
+        self.iter = iter
+        super().__init__(size=size, nfft=nfft, map=map, requires_grad=requires_grad, alias_decay_db=alias_decay_db,
+                         device=device, dtype=dtype)
+
+    def matrix_gallery(self):
+        N = self.size[0]
+        kind = self.matrix_type
+        if kind == "random":
+            self.map = _identity
+        elif kind == "orthogonal":
+            assert N == self.size[1], "Matrix must be square to be orthogonal"
+            self.map = lambda x: torch.matrix_exp(skew_matrix(x))
+        elif kind == "hadamard":
+            assert N == self.size[1], "Matrix must be square to be Hadamard"
+            assert N % 2 == 0, "Matrix must have even dimensions to be Hadamard"
+            self.map = lambda x: HadamardMatrix(self.size[0], device=x.device, dtype=self.dtype)(x)
+        elif kind == "rotation":
+            assert N == self.size[1], "Matrix must be square to be a rotation matrix"
+            assert N % 2 == 0, "Matrix must have even dimensions to be a rotation matrix"
+            self.map = lambda x: RotationMatrix(self.size[0], self.iter, device=x.device, dtype=self.dtype)([x[0][0]])
+
+    def initialize_class(self):
+        self.check_param_shape()
+        self.get_io()
+        self.matrix_gallery()
+        self.get_freq_convolve()
+
+
+class HouseholderMatrix(Gain):
+    """U = I - 2 u u^T applied as two rank-1 products (dsp.py:679-782)."""
+
+    def __init__(self, size: tuple = (1, 1), nfft: int = 2 ** 11, requires_grad: bool = False,
+                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        assert size[0] == size[1], "Matrix must be square"
+        unit = lambda x: to_complex(x) / torch.norm(x, dim=0, keepdim=True)  # noqa: E731
+        super().__init__(size=(size[0], 1), nfft=nfft, map=unit, requires_grad=requires_grad,
+                         alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def forward(self, x, ext_param=None):
+        self.check_input_shape(x)
+        if ext_param is None:
+            u = self.map(self.param)
+        else:
+            with torch.no_grad():
+                self.assign_value(ext_param)
+            u = self.map(ext_param)
+        uTx = ops.mimo(u.transpose(1, 0), x)       # (B, M, 1, ...)
+        return x - 2 * ops.mimo(u, uTx)
+
+    def check_input_shape(self, x):
+        if self.size[0] != x.shape[2]:
+            raise ValueError(f"parameter shape = {self.size} not compatible with input signal of shape = ({x.shape}).")
+
+    def get_io(self):
+        self.input_channels = self.output_channels = self.size[0]
+
+
+# ============================================================================ filters
+class Filter(DSP):
+    """FIR filter matrix, param (taps, N_out, N_in) (dsp.py:788-962)."""
+
+    _diag = False
+
+    def __init__(self, size: tuple = (1, 1, 1), nfft: int = 2 ** 11, map: callable = _identity,
+                 requires_grad: bool = False, alias_decay_db: float = 0.0, device: Optional[str] = None,
+                 dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, nfft=nfft, map=map, requires_grad=requires_grad, alias_decay_db=alias_decay_db,
+                         device=device, dtype=dtype)
+        self.initialize_class()
+
+    def forward(self, x, ext_param=None):
+        return self._run(x, ext_param)
+
+    def check_input_shape(self, x):
+        if (int(self.nfft / 2 + 1), self.input_channels) != (x.shape[1], x.shape[2]):
+            raise ValueError(f"parameter shape not compatible with input signal of shape = ({x.shape}).")
+
+    def check_param_shape(self):
+        assert len(self.size) == 3, "Filter must be 3D, for 2D (parallel) filters use ParallelFilter module."
+
+    def get_freq_response(self):
+        """taps * gamma^n  ->  rfft(nfft) along the tap axis (dsp.py:893-908)."""
+        self.ir = lambda x: self.map(x)
+
+        def response(param):
+            h = self.ir(param)
+            n = torch.arange(0, h.shape[0], device=h.device, dtype=torch.float64)
+            env = (self._gamma_f ** n).to(h.dtype).view(-1, *([1] * (h.dim() - 1)))
+            return self.fft(h * env)
+
+        self.freq_response = response
+
+    def get_freq_convolve(self):
+        self.freq_convolve = lambda x, param: ops.mimo(self.freq_response(param), x, diag=self._diag)
+
+    def initialize_class(self):
+        self.check_param_shape()
+        self.get_io()
+        self.get_freq_response()
+        self.get_freq_convolve()
+
+    def get_io(self):
+        if self._diag:
+            self.input_channels = self.output_channels = self.size[-1]
+        else:
+            self.input_channels = self.size[-1]
+            self.output_channels = self.size[-2]
+
+    def _probe_fir(self, z):
+        coeff = self.map(self.param)
+        k = torch.arange(coeff.shape[0], device=coeff.device, dtype=coeff.dtype)
+        w = (self.gamma ** k) * z ** (-k)
+        return (to_complex(coeff) * w.view(-1, *([1] * (coeff.dim() - 1)))).sum(dim=0)
+
+    def probe(self, z: torch.Tensor):
+        return self._probe_fir(z)
+
+
+class parallelFilter(Filter):
+    """Per-channel FIR filters, param (taps, N) (dsp.py:965-1049)."""
+
+    _diag = True
+
+    def __init__(self, size: tuple = (1, 1), nfft: int = 2 ** 11, map: callable = _identity,
+                 requires_grad: bool = False, alias_decay_db: float = 0.0, device: Optional[str] = None,
+                 dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, nfft=nfft, map=map, requires_grad=requires_grad, alias_decay_db=alias_decay_db,
+                         device=device, dtype=dtype)
+
+    def check_param_shape(self):
+        assert len(self.size) == 2, "Filter must be 1D, for 2D filters use Filter module."
+
+    def probe(self, z: torch.Tensor):
+        return torch.diag(self._probe_fir(z))
+
+
+class _SOSMixin:
+    """Second-order-section cascades share one tail: weight the 3 taps by gamma^[0,1,2] and
+    evaluate prod B / prod A per bin (dsp.py:1520-1526) -- here directly in ``ops.sos_response``,
+    without building the (M, sections, ...) tensors."""
+
+    def _sos_to_response(self, b, a):
+        return ops.sos_response(b.to(self.dtype), a.to(self.dtype), self._gamma_f, self.nfft)
+
+    def _sections_spectra(self, b, a):
+        """B, A as the reference returns them from get_poly_coeff: rfft of the weighted taps."""
+        env = self.alias_envelope_dcy.to(b.device).view(3, *([1] * (b.dim() - 1)))
+        return self.fft(b.to(self.dtype) * env), self.fft(a.to(self.dtype) * env)
+
+    def get_freq_response(self):
+        self.freq_response = lambda param: self._sos_to_response(*self._sos_coeffs(self.map(param)))
+
+    def get_poly_coeff(self, param):
+        """(H, B, A) for *mapped* parameters, as in the reference.  H comes from the fused kernel;
+        B and A (per-section spectra) are only materialised by this inspection method."""
+        b, a = self._sos_coeffs(param)
+        B, A = self._sections_spectra(b, a)
+        return self._sos_to_response(b, a), B, A
+
+
+class Biquad(_SOSMixin, Filter):
+    """Cascaded RBJ biquads, param (n_sections, 2|3, N_out, N_in): (fc/nyquist[, fc2], gain)
+    (dsp.py:1353-1603)."""
+
+    def __init__(self, size: tuple = (1, 1), n_sections: int = 1, filter_type: str = "lowpass",
+                 nfft: int = 2 ** 11, fs: int = 48000, requires_grad: bool = False, alias_decay_db: float = 0.0,
+                 device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        assert filter_type in ["lowpass", "highpass", "bandpass"], "Invalid filter type"
+        self.n_sections = n_sections
+        self.filter_type = filter_type
+        self.fs = fs
+        self.device = device
+        self.dtype = dtype
+        self.get_map()
+        self.alias_envelope_dcy = _gamma(alias_decay_db, nfft, device, dtype) ** torch.arange(0, 3, 1, device=device,
+                                                                                             dtype=dtype)
+        super().__init__(size=(n_sections, *self.get_size(), *size), nfft=nfft, map=self.map,
+                         requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def get_size(self):
+        return (3,) if self.filter_type == "bandpass" else (2,)
+
+    def get_map(self):
+        """(fc, gain) -> clamp(stack(fc, 20 log10|gain|), [0,-60], [1,60]) (dsp.py:1528-1563)."""
+        bp = self.filter_type == "bandpass"
+
+        def mapping(x):
+            dt, dev = x.dtype, x.device
+            gain_db = 20 * torch.log10(torch.abs(x[:, -1]))
+            if bp:
+                e = torch.finfo(dt).eps
+                y = torch.stack((x[:, 0], x[:, 1], gain_db), dim=1)
+                lo = torch.tensor([0 + e, 0 + e, -60], device=dev, dtype=dt)
+                hi = torch.tensor([1 - e, 1 - e, 60], device=dev, dtype=dt)
+            else:
+                y = torch.stack((x[:, 0], gain_db), dim=1)
+                lo = torch.tensor([0, -60], device=dev, dtype=dt)
+                hi = torch.tensor([1, 60], device=dev, dtype=dt)
+            shp = [1, -1] + [1] * (x.dim() - 2)
+            return torch.clamp(y, min=lo.view(shp).expand_as(y), max=hi.view(shp).expand_as(y))
+
+        self.map = mapping
+
+    def _sos_coeffs(self, p):
+        """mapped params -> RBJ (b, a), each (3, n_sections, ...) (dsp.py:1494-1519)."""
+        hz = lambda r: rad2hertz(r * torch.pi, fs=self.fs)  # noqa: E731
+        kw = dict(fs=self.fs, device=p.device, dtype=p.dtype)
+        if self.filter_type == "lowpass":
+            return lowpass_filter(fc=hz(p[:, 0]), gain=p[:, 1], **kw)
+        if self.filter_type == "highpass":
+            return highpass_filter(fc=hz(p[:, 0]), gain=p[:, 1], **kw)
+        return bandpass_filter(fc1=hz(p[:, 0]), fc2=hz(p[:, 1]), gain=p[:, 2], **kw)
+
+    def init_param(self):
+        torch.nn.init.uniform_(self.param[:, 0], a=0, b=0.5)
+        if self.filter_type == "bandpass":
+            torch.nn.init.uniform_(self.param[:, 1], a=self.param[:, 0].max().item(), b=1)
+        torch.nn.init.uniform_(self.param[:, -1], a=-1, b=1)
+
+    def check_param_shape(self):
+        assert len(self.size) == 4, "Parameter size must be 4D, for 3D (parallel) biquads use parallelBiquad module."
+
+
+class parallelBiquad(Biquad):
+    """Per-channel biquad cascades, param (n_sections, 2|3, N) (dsp.py:1607-1764)."""
+
+    _diag = True
+
+    def __init__(self, size: tuple = (1,), n_sections: int = 1, filter_type: str = "lowpass", nfft: int = 2 ** 11,
+                 fs: int = 48000, requires_grad: bool = False, alias_decay_db: float = 0.0,
+                 device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, n_sections=n_sections, filter_type=filter_type, nfft=nfft, fs=fs,
+                         requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def check_param_shape(self):
+        assert len(self.size) == 3, "Parameter size must be 3D, for 3D sapce use Biquad module."
+
+
+class GEQ(_SOSMixin, Filter):
+    """Graphic equaliser: param (n_bands+3 command gains, N_out, N_in), default map 20 log10|x|
+    (dsp.py:2467-2611).  Sections: flat gain, low shelf, octave peaks (R = 2.7), high shelf."""
+
+    def __init__(self, size: tuple = (1, 1), octave_interval: int = 1, nfft: int = 2 ** 11, fs: int = 48000,
+                 map: callable = lambda x: 20 * torch.log10(torch.abs(x)), requires_grad: bool = False,
+                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        self.octave_interval = octave_interval
+        self.fs = fs
+        self.center_freq, self.shelving_crossover = eq_freqs(interval=octave_interval)
+        self.n_gains = len(self.center_freq) + 3
+        self._design = GEQDesign(self.center_freq, self.shelving_crossover, fs=fs, R=2.7)
+        self.alias_envelope_dcy = _gamma(alias_decay_db, nfft, device, dtype) ** torch.arange(0, 3, 1, device=device,
+                                                                                             dtype=dtype)
+        super().__init__(size=(self.n_gains, *size), nfft=nfft, map=map, requires_grad=requires_grad,
+                         alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def init_param(self):
+        torch.nn.init.uniform_(self.param, a=10 ** (-6 / 20), b=10 ** (6 / 20))
+
+    def check_param_shape(self):
+        assert len(self.size) == 3, "Filter must be 3D, for 2D (parallel) filters use ParallelGEQ module."
+
+    def _sos_coeffs(self, gain_db):
+        """command gains in dB -> float32 SOS (b, a) for every channel pair at once; the
+        reference loops over pairs in Python calling eq.geq (dsp.py:2573-2585)."""
+        return self._design.sections(gain_db)
+
+
+class parallelGEQ(GEQ):
+    """Per-channel graphic equaliser, param (n_bands+3, N) (dsp.py:2614-2692)."""
+
+    _diag = True
+
+    def __init__(self, size: tuple = (1,), octave_interval: int = 1, nfft: int = 2 ** 11, fs: int = 48000,
+                 map: callable = lambda x: 20 * torch.log10(torch.abs(x)), requires_grad: bool = False,
+                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, octave_interval=octave_interval, nfft=nfft, fs=fs, map=map,
+                         requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def check_param_shape(self):
+        assert len(self.size) == 2, "Filter must be 2D, for 3D filters use GEQ module."
+
+
+# ============================================================================ delays
+class Delay(DSP):
+    """Delay matrix, param (N_out, N_in) in units of ``unit/fs`` seconds (dsp.py:3226-3450).
+
+    ``isint=True``: the delay in samples is rounded (half to even) and the response
+    gamma^m exp(-j 2 pi k m / nfft) is generated with the phase index (k*m) mod nfft reduced in
+    integer arithmetic -- exact, where the reference evaluates exp(-j*omega*m) in floating point."""
+
+    _diag = False
+
+    def __init__(self, size: tuple = (1, 1), max_len: int = 2000, isint: bool = False, unit: int = 100,
+                 nfft: int = 2 ** 11, fs: int = 48000, requires_grad: bool = False, alias_decay_db: float = 0.0,
+                 device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        self.fs = fs
+        self.max_len = max_len
+        self.unit = unit
+        self.isint = isint
+        super().__init__(size=size, nfft=nfft, requires_grad=requires_grad, alias_decay_db=alias_decay_db,
+                         device=device, dtype=dtype)
+        self.initialize_class()
+
+    def forward(self, x, ext_param=None):
+        return self._run(x, ext_param)
+
+    def init_param(self):
+        if self.isint:
+            delay_len = torch.randint(1, self.max_len, self.size, device=self.device)
+        else:
+            delay_len = torch.rand(self.size, device=self.device) * self.max_len
+        self.assign_value(self.sample2s(delay_len))
+        self.order = delay_len.max() + 1
+
+    def s2sample(self, delay):
+        return delay * self.fs / self.unit
+
+    def sample2s(self, delay: torch.Tensor):
+        return delay / self.fs * self.unit
+
+    def get_delays(self):
+        return lambda param: self.s2sample(self.map(param))
+
+    def get_freq_response(self):
+        m = self.get_delays()
+
+        def response(param):
+            mm = m(param)
+            if self.isint:
+                mi = mm.round()
+                amp = (self._gamma_f ** mi.to(torch.float64)).to(self.dtype)
+                return ops.delay_response(mi.to(torch.int64), amp, self.nfft)
+            g = self._gamma_on(mm)
+            # fractional (learnable) delays: phase = frac(k m / nfft) in float64, then exp.
+            bin0, m_local = ops.bin_shard(self.nfft)
+            k = torch.arange(bin0, bin0 + m_local, device=mm.device, dtype=torch.float64)
+            k = k.view(-1, *([1] * mm.dim()))
+            turns = torch.remainder(k * mm.to(torch.float64).unsqueeze(0) / self.nfft, 1.0)
+            ang = (-2 * torch.pi * turns).to(mm.dtype)
+            return torch.polar((g ** mm).unsqueeze(0).expand_as(ang).contiguous(), ang)
+
+        self.freq_response = response
+
+    def check_input_shape(self, x):
+        if (int(self.nfft / 2 + 1), self.input_channels) != (x.shape[1], x.shape[2]):
+            raise ValueError(
+                f"parameter shape = {self.param.shape} not compatible with input signal of shape = ({x.shape}).")
+
+    def check_param_shape(self):
+        assert len(self.size) == 2, "delay must be 2D, for 1D (parallel) delay use parallelDelay module."
+
+    def get_freq_convolve(self):
+        self.freq_convolve = lambda x, param: ops.mimo(self.freq_response(param), x, diag=self._diag)
+
+    def initialize_class(self):
+        self.check_param_shape()
+        self.get_io()
+        if self.requires_grad:
+            self.map = lambda x: nn.functional.softplus(x)
+        self.omega = (2 * torch.pi * torch.arange(0, self.nfft // 2 + 1, device=self.device, dtype=self.dtype)
+                      / self.nfft).unsqueeze(1)
+        self.get_freq_response()
+        self.get_freq_convolve()
+
+    def get_io(self):
+        if self._diag:
+            self.input_channels = self.output_channels = self.size[-1]
+        else:
+            self.input_channels = self.size[-1]
+            self.output_channels = self.size[-2]
+
+    def _probe_delay(self, z):
+        m = self.s2sample(self.map(self.param))
+        if self.isint:
+            m = m.round()
+        return (self.gamma ** m) * (1.0 / z) ** m
+
+    def probe(self, z: torch.Tensor):
+        return self._probe_delay(z)
+
+
+class parallelDelay(Delay):
+    """Per-channel delays, param (N,) (dsp.py:3453-3551)."""
+
+    _diag = True
+
+    def __init__(self, size: tuple = (1,), max_len: int = 2000, unit: int = 100, isint: bool = False,
+                 nfft=2 ** 11, fs: int = 48000, requires_grad: bool = False, alias_decay_db: float = 0.0,
+                 device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, max_len=max_len, isint=isint, unit=unit, nfft=nfft, fs=fs,
+                         requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def check_param_shape(self):
+        assert len(self.size) == 1, "delays must be 1D, for 2D delays use Delay module."
+
+    def probe(self, z: torch.Tensor):
+        return torch.diag_embed(self._probe_delay(z))

@@ -1,0 +1,426 @@
+"""Drop-in counterparts of ``flamo.processor.system``: ``Series``, ``Recursion``, ``Parallel`` and
+``Shell`` (citations: the reference's ``flamo/processor/system.py``).
+
+The containers keep the reference's behaviour (key rules, nfft / alias_decay_db / dtype
+coherence checks, I/O channel checks, ``ext_param`` routing, state_dict naming) and hand the
+arithmetic to the HIP path.  ``Recursion`` differs in how it gets to the same numbers: the
+closed-loop matrix ``A = I - F(B(I))`` is identical for every batch element (the reference
+expands the identity to the batch and factors the same matrices B times, system.py:420-425);
+here the identity is pushed through the two paths ONCE with batch 1 and the bin-parallel LU
+kernel (``ops.solve``) factors each bin once and back-substitutes all B right-hand sides.
+"""
+from __future__ import annotations
+
+import warnings
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..functional import signal_gallery
+from .dsp import FFT, Transform, iFFT
+
+
+def _common_attribute(modules, attr, what="Series"):
+    """Value of `attr` shared by all modules that have it (None + warning if nobody has it)."""
+    value = None
+    for m in modules:
+        if hasattr(m, attr):
+            value = getattr(m, attr)
+            break
+    if value is None:
+        warnings.warn(f"Attribute {attr} not found in any of the modules.")
+        return None
+    for i, m in enumerate(modules):
+        if hasattr(m, attr) and getattr(m, attr) != value:
+            raise ValueError(
+                f"All modules must have the same {attr} value. Module {m.__class__.__name__} at index {i} "
+                f"is incoherent with the part of the {what} preceding it.")
+    return value
+
+
+# ============================================================================ Series
+class Series(nn.Sequential):
+    """Cascade of DSP modules (system.py:11-329)."""
+
+    def __init__(self, *args):
+        super().__init__(self.__unpack_modules(modules=args, current_keys=[]))
+        self.__refresh()
+
+    def __refresh(self):
+        mods = list(self)
+        self.nfft = _common_attribute(mods, "nfft")
+        self.alias_decay_db = _common_attribute(mods, "alias_decay_db")
+        self.dtype = _common_attribute(mods, "dtype")
+        self.input_channels, self.output_channels = self.__check_io()
+
+    def prepend(self, new_module) -> "Series":
+        return self.insert(index=0, new_module=new_module)
+
+    def append(self, new_module) -> "Series":
+        for k, v in self.__unpack_modules((new_module,), [*self._modules.keys()]).items():
+            self.add_module(k, v)
+        self.__refresh()
+        return self
+
+    def insert(self, index: int, new_module) -> "Series":
+        n = len(self._modules)
+        if not (-n <= index <= n):
+            raise IndexError("Index out of range.")
+        if index < 0:
+            index += n
+        new_items = list(self.__unpack_modules((new_module,), [*self._modules.keys()]).items())
+        items = list(self._modules.items())
+        items[index:index] = new_items
+        self._modules.clear()
+        self._modules.update(items)
+        self.__refresh()
+        return self
+
+    def __unpack_modules(self, modules: tuple, current_keys: list) -> OrderedDict:
+        """Flatten nested Sequential / dict containers into one ordered {key: leaf module} map.
+        Key rules (system.py:127-209): a unique custom key is kept; a duplicate custom key is an
+        error; a missing key, or one that parses as an integer, becomes the position index."""
+        out = OrderedDict()
+
+        def taken():
+            return [*current_keys, *out.keys()]
+
+        for module in modules:
+            if isinstance(module, nn.Sequential):
+                out.update(self.__unpack_modules((module._modules,), taken()))
+            elif isinstance(module, (OrderedDict, dict)):
+                for k, v in module.items():
+                    if isinstance(v, nn.Sequential):
+                        out.update(self.__unpack_modules((v._modules,), taken()))
+                    elif isinstance(v, (OrderedDict, dict)):
+                        out.update(self.__unpack_modules((v,), taken()))
+                    else:
+                        numeric = True
+                        try:
+                            int(k)
+                        except (TypeError, ValueError):
+                            numeric = False
+                        if numeric:
+                            new_key = str(len(out) + len(current_keys))
+                            out[new_key] = v
+                            if k != new_key:
+                                warnings.warn(f"Key {k} is an integer, it will be overwritten.")
+                        else:
+                            if k in taken():
+                                raise ValueError(f"Key {k} is already present in the Series.")
+                            out[k] = v
+            elif isinstance(module, nn.Module):
+                out[str(len(out) + len(current_keys))] = module
+            else:
+                raise ValueError("Modules must be nn.Module, nn.Sequential, or OrderedDict.")
+        return out
+
+    def __check_io(self):
+        mods = [(i, m) for i, m in enumerate(self) if hasattr(m, "input_channels")]
+        if not mods:
+            return None, None
+        first_i, first = mods[0]
+        prev_name, prev_pos, prev_out = first.__class__.__name__, first_i, first.output_channels
+        for j, m in mods[1:]:
+            assert m.input_channels == prev_out, (
+                f"Module {prev_name} at index {prev_pos} has {prev_out} output channels, but module "
+                f"{m.__class__.__name__} at index {j} has {m.input_channels} input_channels.")
+            prev_name, prev_pos, prev_out = m.__class__.__name__, j, getattr(m, "output_channels", None)
+        return first.input_channels, prev_out
+
+    def forward(self, input, ext_param=None):
+        if ext_param is None:
+            for module in self:
+                input = module(input)
+            return input
+        for key, module in self._modules.items():
+            input = module(input, ext_param[key]) if key in ext_param else module(input)
+        return input
+
+    def probe(self, z: torch.Tensor):
+        H = None
+        for module in self:
+            Hi = module.probe(z)
+            H = Hi if H is None else Hi @ H
+        return H
+
+    def probe_w(self, w: torch.Tensor):
+        H = None
+        for module in self:
+            Hi = module.probe_w(w)
+            H = Hi if H is None else Hi @ H
+        return H
+
+
+# ============================================================================ Recursion
+class Recursion(nn.Module):
+    """Closed loop  Y = (I - F B)^-1 F X  per frequency bin (system.py:335-565)."""
+
+    def __init__(self, fF, fB):
+        nn.Module.__init__(self)
+        self.feedforward = self.__as_series(fF, "Feedforward")
+        self.feedback = self.__as_series(fB, "Feedback")
+        self.nfft = self.__check_attribute("nfft")
+        self.alias_decay_db = self.__check_attribute("alias_decay_db")
+        self.dtype = self.__check_attribute("dtype")
+        self.input_channels, self.output_channels = self.__check_io()
+
+    @staticmethod
+    def __as_series(path, name):
+        if isinstance(path, (nn.Sequential, OrderedDict)) and not isinstance(path, Series):
+            warnings.warn(f"{name} path has been converted to a Series class instance.")
+            return Series(path)
+        return path
+
+    def forward(self, X: torch.Tensor, ext_param: dict = None):
+        ext_fb = ext_ff = None
+        if ext_param is not None:
+            for key, param in ext_param.items():
+                if "feedback" in key:
+                    ext_fb = param
+                elif "feedforward" in key:
+                    ext_ff = param
+        R = self.feedforward(X, ext_ff)
+        # loop matrix P = F(B(I)) for ONE batch element (it does not depend on the batch)
+        I = self.__identity_like(R)
+        P = self.feedforward(self.feedback(I, ext_fb), ext_ff)
+        return ops.solve(P, R, one_minus=True)
+
+    def __identity_like(self, R: torch.Tensor) -> torch.Tensor:
+        """(1, M_local, N, N) identity spectrum, bin-planar, cached per (device, dtype, bins)."""
+        N, M = self.output_channels, R.shape[1]
+        key = (R.device, R.dtype, M)
+        cache = self.__dict__.setdefault("_I_cache", {})
+        if key not in cache:
+            eye = torch.eye(N, dtype=R.dtype, device=R.device)
+            cache[key] = eye.unsqueeze(-1).expand(N, N, M).contiguous().movedim(-1, 0).unsqueeze(0)
+        return cache[key]
+
+    @property
+    def I(self) -> torch.Tensor:  # noqa: E743
+        """(M, N, N) complex identity, the attribute the reference builds eagerly in __init__
+        (system.py:427-438).  Built on first access only: the forward pass never needs the
+        M*N*N copy (1.5 GB at nfft=384000, N=32)."""
+        if "_I_full" not in self.__dict__:
+            N, M = self.output_channels, self.nfft // 2 + 1
+            cd = torch.complex128 if self.dtype == torch.float64 else torch.complex64
+            dev = self.alias_decay_db.device if isinstance(self.alias_decay_db, torch.Tensor) else None
+            self.__dict__["_I_full"] = torch.eye(N, dtype=cd, device=dev).unsqueeze(0).repeat(M, 1, 1)
+        return self.__dict__["_I_full"]
+
+    def __check_attribute(self, attr: str):
+        ff, fb = getattr(self.feedforward, attr, None), getattr(self.feedback, attr, None)
+        if ff is None:
+            warnings.warn(f"The feedforward pass does not possess the attribute {attr}.")
+        if fb is None:
+            warnings.warn(f"The feedback pass does not possess the attribute {attr}.")
+        if ff is not None and fb is not None:
+            assert ff == fb, (f"The feedforward pass has {attr} = {ff} and feedback pass has {attr} = {fb}. "
+                              "They must have the same value.")
+        return ff if ff is not None else fb
+
+    def __check_io(self) -> tuple:
+        chans = {}
+        for path, label in ((self.feedforward, "feedforward"), (self.feedback, "feedback")):
+            for end in ("input_channels", "output_channels"):
+                v = getattr(path, end, None)
+                if v is None:
+                    raise ValueError(f"The {label} pass does not possess the attribute {end}.")
+                chans[(label, end)] = v
+        ff_in, ff_out = chans[("feedforward", "input_channels")], chans[("feedforward", "output_channels")]
+        fb_in, fb_out = chans[("feedback", "input_channels")], chans[("feedback", "output_channels")]
+        assert ff_out == fb_in, (f"Feedforward pass has {ff_out} output channels, but feedback pass has {fb_in} "
+                                 "input channels. They must be the same.")
+        assert fb_out == ff_in, (f"Feedforward pass {ff_in} input channels, but the feedback pass has {fb_out} "
+                                 "output channels. They must be the same.")
+        return ff_in, ff_out
+
+    def probe(self, z: torch.Tensor):
+        F, B = self.feedforward.probe(z), self.feedback.probe(z)
+        A = torch.eye(F.shape[-1], dtype=F.dtype, device=F.device) - F @ B
+        return torch.linalg.solve(A, F)
+
+    def probe_recursion(self, z: torch.Tensor, include_shell_io: bool = False, **kwargs):
+        F, B = self.feedforward.probe(z), self.feedback.probe(z)
+        return torch.eye(F.shape[0], dtype=F.dtype, device=F.device) - F @ B
+
+    def probe_recursion_w(self, w: torch.Tensor):
+        F, B = self.feedforward.probe_w(w), self.feedback.probe_w(w)
+        return torch.eye(F.shape[0], dtype=F.dtype, device=F.device) - F @ B
+
+
+# ============================================================================ Parallel
+class Parallel(nn.Module):
+    """Two branches on the same input, summed or concatenated along channels (system.py:570-772)."""
+
+    def __init__(self, brA, brB, sum_output: bool = True):
+        nn.Module.__init__(self)
+        self.branchA = Series(brA) if isinstance(brA, (nn.Sequential, OrderedDict)) and not isinstance(brA, Series) else brA
+        self.branchB = Series(brB) if isinstance(brB, (nn.Sequential, OrderedDict)) and not isinstance(brB, Series) else brB
+        self.sum_output = sum_output
+        self.nfft = self.__shared("nfft")
+        self.alias_decay_db = self.__shared("alias_decay_db")
+        self.dtype = self.__shared("dtype")
+        self.input_channels, self.output_channels = self.__check_io()
+
+    def __shared(self, attr):
+        a, b = getattr(self.branchA, attr, None), getattr(self.branchB, attr, None)
+        if a is None:
+            warnings.warn(f"The branch A does not possess the attribute {attr}.")
+        if b is None:
+            warnings.warn(f"The branch B does not possess the attribute {attr}.")
+        if a is not None and b is not None:
+            assert a == b, f"The branch A has {attr} = {a} and branch B has {attr} = {b}. They must have the same value."
+        return a if a is not None else b
+
+    def __check_io(self):
+        a_in, a_out = getattr(self.branchA, "input_channels", None), getattr(self.branchA, "output_channels", None)
+        b_in, b_out = getattr(self.branchB, "input_channels", None), getattr(self.branchB, "output_channels", None)
+        for v, name in ((a_in, "branch A input"), (a_out, "branch A output"), (b_in, "branch B input"),
+                        (b_out, "branch B output")):
+            if v is None:
+                raise ValueError(f"The {name} channels attribute is missing.")
+        assert a_in == b_in, f"Branch A has {a_in} input channels, but branch B has {b_in} input channels."
+        if self.sum_output:
+            assert a_out == b_out, f"Branch A has {a_out} output channels, but branch B has {b_out}."
+            return a_in, a_out
+        return a_in, a_out + b_out
+
+    def forward(self, X, ext_param: dict = None):
+        ya = self.branchA(X) if ext_param is None else self.branchA(X, ext_param)
+        yb = self.branchB(X) if ext_param is None else self.branchB(X, ext_param)
+        return ya + yb if self.sum_output else torch.cat((ya, yb), dim=2)
+
+
+# ============================================================================ Shell
+class Shell(nn.Module):
+    """input_layer -> core -> output_layer, plus impulse/frequency response helpers
+    (system.py:776-1153)."""
+
+    def __init__(self, core, input_layer=nn.Identity(), output_layer=nn.Identity()):
+        nn.Module.__init__(self)
+        self.__core = self.__wrap(core, "Core")
+        self.__input_layer = self.__wrap(input_layer, "Input layer")
+        self.__output_layer = self.__wrap(output_layer, "Output layer")
+        self.nfft = self.__check_attribute("nfft")
+        self.alias_decay_db = self.__check_attribute("alias_decay_db")
+        self.dtype = self.__check_attribute("dtype")
+        self.input_channels, self.output_channels = self.__check_io()
+
+    @staticmethod
+    def __wrap(layer, name):
+        if isinstance(layer, (nn.Sequential, OrderedDict)) and not isinstance(layer, Series):
+            warnings.warn(f"{name} has been converted to a Series class instance.")
+            return Series(layer)
+        return layer
+
+    def forward(self, x: torch.Tensor, ext_param: dict = None) -> torch.Tensor:
+        x = self.__input_layer(x)
+        x = self.__core(x, ext_param) if ext_param is not None else self.__core(x)
+        return self.__output_layer(x)
+
+    # ---- accessors
+    def get_inputLayer(self):
+        return self.__input_layer
+
+    def set_inputLayer(self, input_layer: nn.Module = None) -> None:
+        self.__input_layer = input_layer
+
+    def get_outputLayer(self):
+        return self.__output_layer
+
+    def set_outputLayer(self, output_layer: nn.Module = None) -> None:
+        self.__output_layer = output_layer
+
+    def get_core(self):
+        return self.__core
+
+    def set_core(self, core: nn.Module) -> None:
+        self.__core = core
+
+    # ---- checks
+    def __check_attribute(self, attr: str):
+        core_v = getattr(self.__core, attr, None)
+        if core_v is None:
+            raise ValueError(f"The core does not possess the attribute {attr}.")
+        in_v = getattr(self.__input_layer, attr, None)
+        if in_v is not None:
+            assert core_v == in_v, (f"The input layer has {attr} = {in_v} and the core has {attr} = {core_v}. "
+                                    "They must have the same value.")
+        out_v = getattr(self.__output_layer, attr, None)
+        if out_v is not None:
+            assert core_v == out_v, (f"The core has {attr} = {core_v} and the output layer has {attr} = {out_v}. "
+                                     "They must have the same value.")
+        return core_v
+
+    def __check_io(self) -> tuple:
+        core_in = getattr(self.__core, "input_channels", None)
+        core_out = getattr(self.__core, "output_channels", None)
+        if core_in is None:
+            raise ValueError("The core does not possess the attribute input_channels.")
+        il_out = getattr(self.__input_layer, "output_channels", None)
+        if il_out is not None:
+            assert core_in == il_out, (f"The core should receive {core_in} input channels, but {il_out} channels "
+                                       "arrive from the input layer.")
+        if core_out is None:
+            raise ValueError("The core does not possess the attribute output_channels.")
+        ol_in = getattr(self.__output_layer, "input_channels", None)
+        if ol_in is not None:
+            assert core_out == ol_in, (f"The core sends {core_out} output channels, but the output layer can only "
+                                       f"receive {ol_in} channels.")
+        il_in = getattr(self.__input_layer, "input_channels", None)
+        ol_out = getattr(self.__output_layer, "output_channels", None)
+        return (il_in if il_in is not None else core_in), (ol_out if ol_out is not None else core_out)
+
+    def probe(self, z: torch.Tensor, include_shell_io: bool = False):
+        H = self.__core.probe(z)
+        if include_shell_io:
+            for layer, left in ((self.__input_layer, False), (self.__output_layer, True)):
+                Hl = layer.probe(z) if hasattr(layer, "probe") else None
+                if Hl is None:
+                    continue
+                H = Hl if H is None else (Hl @ H if left else H @ Hl)
+        return H
+
+    # ---- responses
+    def __device(self):
+        for p in self.parameters():
+            return p.device
+        return self.alias_decay_db.device
+
+    def __probe_signal(self, fs, identity):
+        x = signal_gallery(batch_size=1, n_samples=self.nfft, n=self.input_channels, signal_type="impulse", fs=fs,
+                           device=self.__device(), dtype=self.dtype)
+        return x.diag_embed() if (identity and self.input_channels > 1) else x
+
+    def __with_layers(self, input_layer, output_layer, x):
+        saved = (self.get_inputLayer(), self.get_outputLayer())
+        self.set_inputLayer(input_layer)
+        self.set_outputLayer(output_layer)
+        try:
+            with torch.no_grad():
+                return self.forward(x)
+        finally:
+            self.set_inputLayer(saved[0])
+            self.set_outputLayer(saved[1])
+
+    def __anti_alias_db(self) -> float:
+        return abs(float(self.alias_decay_db))
+
+    def get_time_response(self, fs: int = 48000, identity: bool = False) -> torch.Tensor:
+        """Impulse response irfft(core(rfft(delta))) * gamma^-t (system.py:1012-1079); with
+        ``identity`` the input is diag_embed'ed so the full N_out x N_in response matrix comes out.
+        The envelope is fused into the inverse-FFT epilogue."""
+        db = self.__anti_alias_db()
+        out = Transform(lambda X: ops.irfft(X, self.nfft, "backward", db if db else None))
+        return self.__with_layers(FFT(self.nfft, dtype=self.dtype), out, self.__probe_signal(fs, identity))
+
+    def get_freq_response(self, fs: int = 48000, identity: bool = False) -> torch.Tensor:
+        """rfft(irfft(core(rfft(delta))) * gamma^-t) (system.py:1081-1153): the time-domain
+        round trip is what moves the response from the circle |z| = 1/gamma back to the unit
+        circle; both transforms and the envelope run as two fused HIP FFT calls."""
+        db = self.__anti_alias_db()
+        out = Transform(lambda X: ops.rfft(ops.irfft(X, self.nfft, "backward", db if db else None), self.nfft))
+        return self.__with_layers(FFT(self.nfft, dtype=self.dtype), out, self.__probe_signal(fs, identity))

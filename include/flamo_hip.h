@@ -1,0 +1,183 @@
+/*
+ * flamo_hip.h -- C ABI of libflamo_hip.so, the MI355X (gfx950) kernels behind the
+ * flamo.processor.dsp / flamo.processor.system operator API.
+ *
+ * The reference (gdalsanto/flamo v0.2.13) has no FFI layer of its own: its hot path is three
+ * torch primitives called from Python.  Every entry point below names the reference call
+ * site(s) it replaces (paths relative to the reference checkout).  The library is bound with
+ * ctypes from flamo_amd/_lib.py (see INTEGRATION.md for the stub a maintainer would add to
+ * the reference).
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers owned by the caller (PyTorch's caching allocator),
+ *    including scratch.  The library allocates nothing and never synchronises the device;
+ *    every launch goes to `stream` (a hipStream_t passed as void*).
+ *  - Return value: FL_OK (0) or a negative FL_ERR_* code; fl_last_error() returns a
+ *    thread-local message for the last failure on the calling thread.  No C++ exception
+ *    crosses the ABI.  Functions are re-entrant.
+ *  - Layout ("bin-planar"): a frequency-domain tensor with logical shape (B, M, N, K) is
+ *    stored with the bin axis contiguous: address = b*s_b + n*s_n + k*s_k + f.  A time-domain
+ *    tensor (B, T, N) is stored signal-planar: address = sig*stride + t, sig = b*N + n.
+ *    Complex numbers are interleaved (re, im) pairs of the real type (f32 -> "c64",
+ *    f64 -> "c128").  Strides are in ELEMENTS of the array's own element type.
+ *  - Suffixes: _f32/_c64 single precision, _f64/_c128 double precision.
+ */
+#ifndef FLAMO_HIP_H
+#define FLAMO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FL_OK 0
+#define FL_ERR_BAD_ARG (-1)
+#define FL_ERR_UNSUPPORTED (-2)
+#define FL_ERR_HIP (-3)
+
+#define FL_ABI_VERSION 1
+
+int fl_version(void);
+const char* fl_last_error(void);
+
+/* ------------------------------------------------------------------ transforms
+ * Replace torch.fft.rfft / torch.fft.irfft along dim=1 in dsp.FFT (flamo/processor/dsp.py:88),
+ * dsp.iFFT (dsp.py:114), dsp.FFTAntiAlias (dsp.py:161-162), dsp.iFFTAntiAlias (dsp.py:204-205)
+ * and Shell.get_time_response / get_freq_response (flamo/processor/system.py:1050-1052,
+ * 1119-1128), and the autograd backward of both (rfft' is an irfft with halved interior
+ * bins, irfft' is an rfft with doubled interior bins).
+ */
+
+/* W[j] = exp(-2*pi*i*j/nfft), j in [0, nfft): master twiddle table shared by the FFT passes,
+ * the real-FFT split step, the integer-delay response and the SOS response. */
+int fl_twiddle_fill_f32(void* W, int nfft, void* stream);
+int fl_twiddle_fill_f64(void* W, int nfft, void* stream);
+
+/* Plan query: nfft must be even with nfft/2 = 2^a 3^b 5^c 7^d 11^e 13^f.  L1*L2 = nfft/2;
+ * L1 == 1 means a single in-LDS pass.  Returns FL_ERR_UNSUPPORTED otherwise. */
+int fl_fft_plan(int nfft, int is_f64, int* L1, int* L2);
+/* complex elements of scratch needed for nsig signals (0 for single-pass plans) */
+size_t fl_fft_scratch_elems(int nfft, int is_f64, int nsig);
+/* test hook: largest half-length handled in one pass (0 restores the default) */
+int fl_debug_set_fft_max_single(int max_half_len);
+
+/* X[sig, k] = scale * w_k * sum_t x[sig, t] * e(t) * exp(-2 pi i k t / nfft),  k in [0, nfft/2]
+ *   x: real, signal `sig` starts at x + sig*x_sig_stride and has t_in valid samples (zero
+ *      padded / truncated to nfft as torch.fft.rfft(n=nfft) does);
+ *   e(t) = 2^(env_log2 * t) (anti-alias envelope gamma^-t; env_log2 = 0 disables it);
+ *   w_k = 1, or (interior_x2 != 0) 2 for 0 < k < nfft/2 (used by irfft's backward);
+ *   X: complex, signal `sig` at X + sig*(nfft/2+1). */
+int fl_rfft_f32(const void* x, long x_sig_stride, int t_in, void* X, void* scratch, const void* W,
+                int nsig, int nfft, double scale, double env_log2, int interior_x2, void* stream);
+int fl_rfft_f64(const void* x, long x_sig_stride, int t_in, void* X, void* scratch, const void* W,
+                int nsig, int nfft, double scale, double env_log2, int interior_x2, void* stream);
+
+/* y[sig, t] = scale * e(t) * sum_k w_k' Re(v_k X[sig,k] exp(+2 pi i k t / nfft)),  t in [0, t_out)
+ *   C2R semantics of torch.fft.irfft: w_k' = 1 for k in {0, nfft/2} (imaginary part ignored),
+ *   2 otherwise; v_k = 1, or (interior_half != 0) 1/2 for interior bins (rfft's backward);
+ *   t_out <= nfft samples are written per signal at y + sig*y_sig_stride. */
+int fl_irfft_f32(const void* X, void* y, long y_sig_stride, int t_out, void* scratch, const void* W,
+                 int nsig, int nfft, double scale, double env_log2, int interior_half, void* stream);
+int fl_irfft_f64(const void* X, void* y, long y_sig_stride, int t_out, void* scratch, const void* W,
+                 int nsig, int nfft, double scale, double env_log2, int interior_half, void* stream);
+
+/* dst[b][c][r] = src[b][r][c]  (batched 2-D transpose through LDS; elem_bytes in {4, 8, 16}).
+ * Converts the reference's channel-innermost (B, T, N) / (B, M, N) tensors to the planar layout
+ * and back. */
+int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, int elem_bytes, void* stream);
+
+/* ------------------------------------------------------------------ per-bin complex MIMO product
+ * Replace torch.einsum("fmn,bfn...->bfm...") (dsp.py:922-924, 3406-3408 and every Filter
+ * subclass), einsum("mn,bfn...->bfm...") (Gain/Matrix, dsp.py:466-468) with hs_f = 0,
+ * einsum("fn,bfn...->bfn...") (parallel*, dsp.py:1021-1023, 3504-3506) and
+ * einsum("n,bfn...->bfn...") (parallelGain, dsp.py:552-554) with hs_f = 0, plus their
+ * autograd backward.
+ *
+ * Y[b,m,k,f] = sum_n op(H[f,m,n]) X[b,n,k,f];  op = conj if conj_h.
+ * H element address: f*hs_f + m*hs_m + n*hs_n (hs_f = 0: frequency-independent matrix).
+ * X/Y addresses: b*s_b + ch*s_n + k*s_k + f. */
+int fl_mimo_c64(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
+                const void* X, long xs_b, long xs_n, long xs_k,
+                void* Y, long ys_b, long ys_m, long ys_k,
+                int B, int M, int No, int Ni, int K, void* stream);
+int fl_mimo_c128(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
+                 const void* X, long xs_b, long xs_n, long xs_k,
+                 void* Y, long ys_b, long ys_m, long ys_k,
+                 int B, int M, int No, int Ni, int K, void* stream);
+
+/* Y[b,n,k,f] = op(h[f,n]) X[b,n,k,f];  h address f*hs_f + n*hs_n */
+int fl_mimo_diag_c64(const void* h, long hs_f, long hs_n, int conj_h,
+                     const void* X, long xs_b, long xs_n, long xs_k,
+                     void* Y, long ys_b, long ys_n, long ys_k,
+                     int B, int M, int N, int K, void* stream);
+int fl_mimo_diag_c128(const void* h, long hs_f, long hs_n, int conj_h,
+                      const void* X, long xs_b, long xs_n, long xs_k,
+                      void* Y, long ys_b, long ys_n, long ys_k,
+                      int B, int M, int N, int K, void* stream);
+
+/* dH[m,n,f] = scale * sum_{b,k} G[b,m,k,f] * conj(X[b,n,k,f])   (planar dH: (m*Ni+n)*M + f).
+ * The gradient of the product w.r.t. H (torch complex convention), and -scale = the
+ * Recursion's dA = -dR out^H. */
+int fl_mimo_gradh_c64(const void* G, long gs_b, long gs_m, long gs_k,
+                      const void* X, long xs_b, long xs_n, long xs_k,
+                      void* dH, double scale, int B, int M, int No, int Ni, int K, void* stream);
+int fl_mimo_gradh_c128(const void* G, long gs_b, long gs_m, long gs_k,
+                       const void* X, long xs_b, long xs_n, long xs_k,
+                       void* dH, double scale, int B, int M, int No, int Ni, int K, void* stream);
+/* dh[n,f] = sum_{b,k} G[b,n,k,f] * conj(X[b,n,k,f])   (planar dh: n*M + f) */
+int fl_mimo_gradh_diag_c64(const void* G, long gs_b, long gs_n, long gs_k,
+                           const void* X, long xs_b, long xs_n, long xs_k,
+                           void* dh, int B, int M, int N, int K, void* stream);
+int fl_mimo_gradh_diag_c128(const void* G, long gs_b, long gs_n, long gs_k,
+                            const void* X, long xs_b, long xs_n, long xs_k,
+                            void* dh, int B, int M, int N, int K, void* stream);
+
+/* ------------------------------------------------------------------ frequency responses
+ * Integer delay lines, Delay/parallelDelay.get_freq_response with isint=True
+ * (dsp.py:3356-3365, 3512-3521):  H[c, f] = amp[c] * exp(-2 pi i ((bin0+f) * m[c] mod nfft) / nfft)
+ * -- the phase index is reduced in 64-bit integer arithmetic and looked up in W (bit-exact
+ * indexing; the reference evaluates exp(-j*omega*m) in floating point).  amp[c] = gamma^m[c]
+ * is supplied by the caller (real, same precision as H). H planar: c*m_local + f. */
+int fl_delay_response_c64(const int32_t* m, const void* amp, int C, const void* W, int nfft,
+                          int bin0, int m_local, void* H, void* stream);
+int fl_delay_response_c128(const int32_t* m, const void* amp, int C, const void* W, int nfft,
+                           int bin0, int m_local, void* H, void* stream);
+
+/* Second-order-section cascades, the tail shared by Biquad/SVF/GEQ/PEQ.get_poly_coeff
+ * (dsp.py:1520-1526, 2587-2593):  per channel c and bin k,
+ *   B_s = b[0,s,c] + b[1,s,c] g w + b[2,s,c] g^2 w^2,  A_s likewise,  w = exp(-2 pi i k/nfft),
+ *   H[c,k] = prod_s B_s / prod_s A_s, or eps where |prod A| == 0.
+ * b, a: real (3, S, C) contiguous.  Evaluated directly (no (M,S,C) tensor is ever built). */
+int fl_sos_response_f32(const void* b, const void* a, int S, int C, double gamma, const void* W,
+                        int nfft, int bin0, int m_local, void* H, void* stream);
+int fl_sos_response_f64(const void* b, const void* a, int S, int C, double gamma, const void* W,
+                        int nfft, int bin0, int m_local, void* H, void* stream);
+/* Backward: partial sums over bins of dL/db, dL/da.  part: real (nblk, 2, 3, S, C) where
+ * nblk = fl_sos_bwd_blocks(m_local); the caller sums over nblk. */
+int fl_sos_bwd_blocks(int m_local);
+int fl_sos_response_bwd_f32(const void* gH, const void* b, const void* a, int S, int C, double gamma,
+                            const void* W, int nfft, int bin0, int m_local, void* part, void* stream);
+int fl_sos_response_bwd_f64(const void* gH, const void* b, const void* a, int S, int C, double gamma,
+                            const void* W, int nfft, int bin0, int m_local, void* part, void* stream);
+
+/* ------------------------------------------------------------------ closed loop
+ * Replace torch.linalg.solve(A, B) in system.Recursion.forward (system.py:420-425).
+ * Per bin f:  A_f = (one_minus ? I - P[:,:,f] : P[:,:,f]);  if adjoint, A_f := A_f^H;
+ *             OUT[b,:,k,f] = A_f^{-1} R[b,:,k,f]
+ * LU with partial pivoting, factored ONCE per bin and applied to all B*K right-hand sides
+ * (the reference factors the same matrix B times).  P planar: (i*N + j)*M + f.  N <= 64. */
+int fl_solve_c64(const void* P, int one_minus, int adjoint,
+                 const void* R, long rs_b, long rs_n, long rs_k,
+                 void* OUT, long os_b, long os_n, long os_k,
+                 int B, int M, int N, int K, void* stream);
+int fl_solve_c128(const void* P, int one_minus, int adjoint,
+                  const void* R, long rs_b, long rs_n, long rs_k,
+                  void* OUT, long os_b, long os_n, long os_k,
+                  int B, int M, int N, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLAMO_HIP_H */

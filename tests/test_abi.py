@@ -1,0 +1,102 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports every
+symbol include/flamo_hip.h declares; host logic of the operator API (no GPU compute)."""
+import ctypes
+import os
+import re
+import warnings
+from collections import OrderedDict
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "flamo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from flamo_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 29
+    for s in syms:
+        assert hasattr(handle, s), f"{s} declared in include/flamo_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == syms          # the ctypes table binds exactly the header
+    L = _lib.lib()
+    assert L.fl_version() == 1
+
+
+def test_plan_queries_and_errors():
+    from flamo_amd import _lib
+    L = _lib.lib()
+    l1, l2 = ctypes.c_int(), ctypes.c_int()
+    for nfft, f64 in ((96000, 0), (192000, 0), (384000, 0), (96000, 1), (2048, 0), (1500, 1)):
+        assert L.fl_fft_plan(nfft, f64, ctypes.byref(l1), ctypes.byref(l2)) == 0
+        assert l1.value * l2.value == nfft // 2
+    assert L.fl_fft_plan(95, 0, None, None) == -2 and b"even" in L.fl_last_error()
+    assert L.fl_fft_plan(2 * 17, 0, None, None) == -2 and b"prime factor" in L.fl_last_error()
+    assert L.fl_fft_scratch_elems(96000, 0, 256) == 48000 * 256
+    assert L.fl_fft_scratch_elems(2048, 0, 256) == 0
+    assert L.fl_rfft_f32(None, 0, 0, None, None, None, 1, 96000, 1.0, 0.0, 0, None) == -1   # null pointers rejected
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    from flamo_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.rfft(torch.zeros(1, 8, 1), 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.mimo(torch.zeros(2, 2, dtype=torch.complex64), torch.zeros(1, 5, 2, dtype=torch.complex64))
+
+
+def test_operator_api_host_logic():
+    from flamo_amd.processor import dsp, system
+    warnings.simplefilter("ignore")
+    nfft = 512
+    kw = dict(nfft=nfft, alias_decay_db=30.0)
+    g1, g2 = dsp.Gain(size=(4, 1), **kw), dsp.Gain(size=(1, 4), **kw)
+    dl = dsp.parallelDelay(size=(4,), max_len=100, isint=True, **kw)
+    mx = dsp.Matrix(size=(4, 4), matrix_type="orthogonal", **kw)
+    rec = system.Recursion(fF=dl, fB=mx)
+    core = system.Series(OrderedDict({"input_gain": g1, "feedback_loop": rec, "output_gain": g2}))
+    model = system.Shell(core, dsp.FFT(nfft), dsp.iFFTAntiAlias(nfft, alias_decay_db=30.0))
+    assert list(model.state_dict()) == ["_Shell__core.input_gain.param", "_Shell__core.feedback_loop.feedforward.param",
+                                        "_Shell__core.feedback_loop.feedback.param", "_Shell__core.output_gain.param"]
+    assert (model.input_channels, model.output_channels, model.nfft) == (1, 1, nfft)
+    assert rec.I.shape == (nfft // 2 + 1, 4, 4)
+    # key rules of Series (system.py:127-209)
+    s = system.Series(dsp.Gain(size=(2, 2)), OrderedDict({"a": dsp.Gain(size=(2, 2)), "7": dsp.Gain(size=(3, 2))}))
+    assert list(s._modules) == ["0", "a", "2"] and (s.input_channels, s.output_channels) == (2, 3)
+    s.prepend(dsp.Gain(size=(2, 5)))
+    assert s.input_channels == 5 and len(s) == 4
+    with pytest.raises(ValueError):
+        system.Series(OrderedDict({"a": dsp.Gain()}), OrderedDict({"a": dsp.Gain()}))
+    with pytest.raises(AssertionError):
+        system.Series(dsp.Gain(size=(3, 2)), dsp.Gain(size=(2, 2)))          # channel mismatch
+    with pytest.raises(ValueError):
+        system.Series(dsp.Gain(size=(2, 2), nfft=64), dsp.Gain(size=(2, 2), nfft=128))
+    with pytest.raises(AssertionError):
+        dsp.Gain(size=(3,))
+    with pytest.raises(AssertionError):
+        dsp.DSP(size=[1, 2])
+    with pytest.raises(AssertionError):
+        system.Recursion(fF=dsp.Gain(size=(2, 3)), fB=dsp.Gain(size=(2, 2)))
+    d = dsp.Delay(size=(2, 2), max_len=50, isint=True, nfft=64)
+    d.assign_value(d.sample2s(torch.tensor([[1.0, 2.0], [3.0, 4.0]])))
+    assert torch.allclose(d.s2sample(d.param), torch.tensor([[1.0, 2.0], [3.0, 4.0]])) and d.new_value == 1
+    # parameter maps (host side) agree with the oracle's restatement
+    from oracle import hotpath as O
+    p = torch.randn(5, 5, dtype=torch.float64)
+    m = dsp.Matrix(size=(5, 5), matrix_type="orthogonal", dtype=torch.float64)
+    assert torch.allclose(m.map(p), O.orthogonal(p))
+    bq = dsp.Biquad(size=(2, 2), n_sections=2, filter_type="bandpass", dtype=torch.float64)
+    assert torch.allclose(bq.map(bq.param), O.biquad_map(bq.param.detach(), "bandpass"))
+    geq = dsp.GEQ(size=(2, 2), dtype=torch.float64)
+    b, a = geq._sos_coeffs(geq.map(geq.param))
+    bo, ao = O.geq_sos(geq.map(geq.param), geq.center_freq, geq.shelving_crossover)
+    assert b.dtype == torch.float32 and torch.equal(b, bo) and torch.equal(a, ao)

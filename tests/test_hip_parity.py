@@ -1,0 +1,344 @@
+"""GPU parity tests: the HIP path (through the C ABI) against
+  * the golden vectors produced by the reference itself (float64), and
+  * the CPU oracle on seeded inputs, plus size-independent properties at BASELINE sizes.
+
+Tolerances (relative l2 error against the float64 reference):
+  float64 kernels 1e-10, float32 kernels 1e-5 (BASELINE.json north_star: <= 1e-5).
+"""
+import ctypes
+
+import pytest
+import torch
+
+from conftest import golden_names, load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float64: 1e-10, torch.float32: 1e-5}
+CD = {torch.float64: torch.complex128, torch.float32: torch.complex64}
+
+
+def _dev(t, dev, dt):
+    if t.is_complex():
+        return t.to(device=dev, dtype=CD[dt])
+    return t.to(device=dev, dtype=dt)
+
+
+@pytest.fixture(params=[torch.float64, torch.float32], ids=["f64", "f32"])
+def dt(request):
+    return request.param
+
+
+@pytest.fixture(params=[0, 8], ids=["plan-default", "plan-two-pass"])
+def plan(request):
+    """Force the two-pass (four-step) FFT on small goldens so that path is covered too."""
+    from flamo_amd import _lib
+    _lib.lib().fl_debug_set_fft_max_single(request.param)
+    yield request.param
+    _lib.lib().fl_debug_set_fft_max_single(0)
+
+
+# ----------------------------------------------------------------------------- transforms
+@pytest.mark.parametrize("name", golden_names("fft_"))
+def test_transforms_golden(gpu, dt, plan, name):
+    from flamo_amd import ops
+    meta, a = load_golden(name)
+    nfft, norm, db = meta["nfft"], meta["norm"], meta["alias_decay_db"]
+    x = _dev(a["x"], gpu, dt).requires_grad_(True)
+    X = ops.rfft(x, nfft, norm, db)
+    assert X.shape == a["X"].shape
+    assert relerr(X.cpu(), a["X"]) < TOL[dt]
+    (gx,) = torch.autograd.grad(torch.sum(torch.real(X * torch.conj(_dev(a["C"], gpu, dt)))), [x])
+    assert relerr(gx.cpu(), a["gx"]) < TOL[dt]
+    Z = _dev(a["Z"], gpu, dt).requires_grad_(True)
+    y = ops.irfft(Z, nfft, norm, db)
+    assert y.shape == a["y"].shape
+    assert relerr(y.cpu(), a["y"]) < TOL[dt]
+    (gZ,) = torch.autograd.grad(torch.sum(y * _dev(a["c"], gpu, dt)), [Z])
+    assert relerr(gZ.cpu(), a["gZ"]) < TOL[dt]
+
+
+@pytest.mark.parametrize("nfft", [96000, 192000, 384000, 2 * 7 * 11 * 13 * 4])
+def test_fft_full_size_properties(gpu, nfft):
+    """BASELINE sizes: oracle comparison, round trip, linearity and Parseval."""
+    from flamo_amd import ops
+    from oracle import hotpath as O
+    torch.manual_seed(nfft)
+    for dt_, tol in ((torch.float32, 1e-5), (torch.float64, 1e-10)):
+        x = torch.randn(2, nfft, 3, dtype=dt_, device=gpu)
+        X = ops.rfft(x, nfft)
+        assert relerr(X.cpu(), O.rfft(x.cpu().double(), nfft)) < tol
+        y = ops.irfft(X, nfft)
+        assert relerr(y, x) < tol                                   # round trip
+        x2 = torch.randn_like(x)
+        lin = ops.rfft(2.5 * x - x2, nfft) - (2.5 * X - ops.rfft(x2, nfft))
+        assert (lin.abs().max() / X.abs().max()).item() < (1e-5 if dt_ == torch.float32 else 1e-12)
+        # Parseval with Hermitian weights
+        w = torch.full((nfft // 2 + 1,), 2.0, device=gpu, dtype=dt_)
+        w[0] = 1
+        w[-1] = 1
+        e_f = (X.abs() ** 2 * w.view(1, -1, 1)).sum() / nfft
+        assert abs((e_f / (x ** 2).sum()).item() - 1) < (1e-4 if dt_ == torch.float32 else 1e-11)
+        # anti-alias pair undoes itself up to gamma^-2t: irfft_aa(rfft_aa(x)) = x * gamma^-2t
+        ya = ops.irfft(ops.rfft(x, nfft, "backward", 30.0), nfft, "backward", 30.0)
+        env2 = O.alias_envelope(30.0, nfft).to(gpu) ** 2
+        assert relerr(ya.double(), x.double() * env2.view(1, -1, 1)) < tol
+
+
+def test_fft_ragged_and_layouts(gpu):
+    from flamo_amd import ops
+    from oracle import hotpath as O
+    nfft = 1500
+    for T in (1, 7, 751, 1500, 1777):
+        x = torch.randn(3, T, 2, dtype=torch.float64, device=gpu, requires_grad=True)
+        X = ops.rfft(x, nfft, "ortho")
+        xr = x.detach().cpu().requires_grad_(True)
+        Xr = O.rfft(xr, nfft, "ortho")
+        assert relerr(X.cpu(), Xr) < 1e-10
+        C = torch.randn_like(Xr)
+        (g,) = torch.autograd.grad(torch.sum(torch.real(X * torch.conj(C.to(gpu)))), [x])
+        (gr,) = torch.autograd.grad(torch.sum(torch.real(Xr * torch.conj(C))), [xr])
+        assert g.shape == x.shape and relerr(g.cpu(), gr) < 1e-10
+    # planar input (time axis contiguous) and empty batch
+    xp = torch.randn(2, 3, nfft, dtype=torch.float64, device=gpu).movedim(-1, 1)
+    assert relerr(ops.rfft(xp, nfft).cpu(), O.rfft(xp.cpu(), nfft)) < 1e-10
+    assert ops.rfft(torch.zeros(0, nfft, 2, dtype=torch.float32, device=gpu), nfft).shape == (0, nfft // 2 + 1, 2)
+    with pytest.raises(RuntimeError):
+        ops.rfft(torch.zeros(1, 34, 1, device=gpu), 34)      # half-length 17: unsupported radix, fails loudly
+
+
+# ----------------------------------------------------------------------------- modules
+_MODULE_CASES = [n for n in golden_names() if load_golden(n)[0].get("cls")]
+
+
+def _build_module(meta, a, dev, dt):
+    from flamo_amd.processor import dsp
+    kw = dict(meta["kwargs"])
+    kw["size"] = tuple(kw["size"])
+    mod = getattr(dsp, meta["cls"])(nfft=meta["nfft"], alias_decay_db=meta["alias_decay_db"], device=dev, dtype=dt,
+                                    **kw)
+    mod.assign_value(_dev(a["param"], dev, dt))
+    return mod
+
+
+@pytest.mark.parametrize("name", _MODULE_CASES)
+def test_modules_golden(gpu, dt, name):
+    meta, a = load_golden(name)
+    mod = _build_module(meta, a, gpu, dt)
+    tol = TOL[dt]
+    if "freq_response" in a:
+        H = mod.freq_response(mod.param)
+        assert H.shape == a["freq_response"].shape
+        assert relerr(H.detach().cpu(), a["freq_response"]) < tol
+    X = _dev(a["X"], gpu, dt).requires_grad_(True)
+    Y = mod(X)
+    assert Y.shape == a["Y"].shape
+    assert relerr(Y.detach().cpu(), a["Y"]) < tol
+    wrt = [X] + ([mod.param] if "gparam" in a else [])
+    g = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(_dev(a["C"], gpu, dt)))), wrt)
+    assert relerr(g[0].cpu(), a["gX"]) < tol
+    if "gparam" in a:
+        # float32 GEQ coefficients inside the reference: gradient agrees to float32 class
+        gtol = max(tol, 5e-5) if "GEQ" in meta["cls"] else max(tol, 1e-9)
+        assert relerr(g[1].cpu(), a["gparam"]) < gtol
+    # matrix-valued signal (B, M, N, N): the identity-probe path
+    Y4 = mod(_dev(a["X4"], gpu, dt))
+    assert relerr(Y4.detach().cpu(), a["Y4"]) < tol
+    # channel-innermost (reference-contiguous) input gives the same result as planar input
+    Yc = mod(_dev(a["X"], gpu, dt).contiguous())
+    assert relerr(Yc.detach().cpu(), a["Y"]) < tol
+    with pytest.raises(ValueError):
+        mod(torch.zeros(1, meta["nfft"] // 2 + 1, a["X"].shape[2] + 1, dtype=CD[dt], device=gpu))
+
+
+def test_integer_delay_phase_is_exact(gpu):
+    """bit-exact integer delay indexing: the f32 response equals the correctly rounded f64 one."""
+    from flamo_amd.processor import dsp
+    from oracle import hotpath as O
+    nfft = 192000
+    m = torch.tensor([503.0, 997.0, 1499.0, 2713.0])
+    d32 = dsp.parallelDelay(size=(4,), max_len=3000, isint=True, nfft=nfft, alias_decay_db=30.0, device=gpu)
+    d32.assign_value(d32.sample2s(m.to(gpu)))
+    H32 = d32.freq_response(d32.param).cpu()
+    He = O.delay_response_exact(m.to(torch.int64), nfft, O.gamma_of(30.0, nfft))
+    assert relerr(H32, He) < 2e-7          # float32 rounding only; the reference's own f32 run is 1e-3 off
+    assert relerr(H32, O.delay_response(m.double(), nfft, O.gamma_of(30.0, nfft))) < 2e-7
+
+
+# ----------------------------------------------------------------------------- composed systems
+def _config2_model(dsp, system, meta, a, dev, dt):
+    from collections import OrderedDict
+    nfft, db, N = meta["nfft"], meta["alias_decay_db"], meta["N"]
+    kw = dict(nfft=nfft, alias_decay_db=db, device=dev, dtype=dt)
+    mat = dsp.Matrix(size=(N, N), matrix_type="random", requires_grad=True, **kw)
+    geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+    mat.assign_value(_dev(a["W"], dev, dt))
+    geq.assign_value(_dev(a["geq_param"], dev, dt))
+    core = system.Series(OrderedDict({"mix": mat, "eq": geq}))
+    return system.Shell(core, dsp.FFT(nfft, dtype=dt), dsp.iFFT(nfft, dtype=dt)), mat, geq
+
+
+@pytest.mark.parametrize("name", golden_names("config2"))
+def test_config2_golden(gpu, dt, plan, name):
+    from flamo_amd.processor import dsp, system
+    meta, a = load_golden(name)
+    model, mat, geq = _config2_model(dsp, system, meta, a, gpu, dt)
+    assert list(model.state_dict().keys()) == meta["state_keys"]
+    x = _dev(a["x"], gpu, dt).requires_grad_(True)
+    y = model(x)
+    assert relerr(y.detach().cpu(), a["y"]) < max(TOL[dt], 1e-9)
+    gx, gW, gG = torch.autograd.grad((y ** 2).mean(), [x, mat.param, geq.param])
+    tol = max(TOL[dt], 1e-9)
+    assert relerr(gx.cpu(), a["gx"]) < tol
+    assert relerr(gW.cpu(), a["gW"]) < tol
+    assert relerr(gG.cpu(), a["gG"]) < max(tol, 5e-5)
+
+
+def _fdn_model(dsp, system, meta, a, dev, dt):
+    from collections import OrderedDict
+    N, nfft, db = meta["N"], meta["nfft"], meta["alias_decay_db"]
+    kw = dict(nfft=nfft, alias_decay_db=db, device=dev, dtype=dt)
+    ig = dsp.Gain(size=(N, 1), requires_grad=True, **kw)
+    og = dsp.Gain(size=(1, N), requires_grad=True, **kw)
+    dl = dsp.parallelDelay(size=(N,), max_len=max(meta["delays"]), isint=True, **kw)
+    mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+    ig.assign_value(_dev(a["in_gain"], dev, dt))
+    og.assign_value(_dev(a["out_gain"], dev, dt))
+    dl.assign_value(_dev(a["delays_s"], dev, dt))
+    mix.assign_value(_dev(a["U_param"], dev, dt))
+    att = None
+    if meta["attn"]:
+        att = dsp.parallelGEQ(size=(N,), requires_grad=True, **kw)
+        att.map = lambda x: 20 * torch.log10(torch.sigmoid(x))
+        att.assign_value(_dev(a["attn_param"], dev, dt))
+        fb = system.Series(OrderedDict({"mixing_matrix": mix, "attenuation": att}))
+    else:
+        fb = mix
+    rec = system.Recursion(fF=dl, fB=fb)
+    core = system.Series(OrderedDict({"input_gain": ig, "feedback_loop": rec, "output_gain": og}))
+    model = system.Shell(core, dsp.FFT(nfft, dtype=dt), dsp.iFFTAntiAlias(nfft, alias_decay_db=db, device=dev, dtype=dt))
+    return model, dict(ig=ig, og=og, mix=mix, att=att, rec=rec)
+
+
+@pytest.mark.parametrize("name", ["fdn4", "fdn6", "fdn6_db0", "fdn16"])
+def test_fdn_golden(gpu, dt, name):
+    from flamo_amd.processor import dsp, system
+    meta, a = load_golden(name)
+    if dt == torch.float32 and meta["alias_decay_db"] == 0.0:
+        pytest.skip("undamped loop (alias_decay_db=0): resonant bins are conditioned ~1e6, float32 parity not claimed")
+    model, p = _fdn_model(dsp, system, meta, a, gpu, dt)
+    assert list(model.state_dict().keys()) == meta["state_keys"]
+    tol = max(TOL[dt], 1e-8)
+    x = _dev(a["x"], gpu, dt).requires_grad_(True)
+    y = model(x)
+    assert relerr(y.detach().cpu(), a["y"]) < tol
+    plist = [p["ig"].param, p["og"].param, p["mix"].param] + ([p["att"].param] if meta["attn"] else [])
+    g = torch.autograd.grad(torch.sum(y * _dev(a["c"], gpu, dt)), [x] + plist)
+    keys = ["gx", "g_in_gain", "g_out_gain", "g_U_param"] + (["g_attn_param"] if meta["attn"] else [])
+    for got, key in zip(g, keys):
+        assert relerr(got.cpu(), a[key]) < (max(tol, 1e-4) if key == "g_attn_param" else 5 * tol), key
+    core = model.get_core()
+    with torch.no_grad():
+        assert relerr(core(_dev(a["Xf"], gpu, dt)).cpu(), a["Yf"]) < tol
+        if "Xm" in a:
+            assert relerr(p["rec"](_dev(a["Xm"], gpu, dt)).cpu(), a["Ym"]) < tol
+        ir = model.get_time_response(identity=False)
+        fr = model.get_freq_response(identity=False)
+        assert ir.shape == a["ir"].shape and fr.shape == a["fr"].shape
+        assert relerr(ir.cpu(), a["ir"]) < tol and relerr(fr.cpu(), a["fr"]) < tol
+        if not meta["attn"]:   # analytic probe identity of examples/e10_probe.py (assert max diff < 5e-3 there)
+            ones = torch.ones(1, meta["nfft"] // 2 + 1, 1, dtype=CD[dt], device=gpu)
+            Hc = core(ones).reshape(-1).cpu()
+            assert relerr(Hc[a["probe_bins"].long()], a["probe"].reshape(-1)) < tol
+
+
+def test_identity_responses_golden(gpu, dt):
+    from collections import OrderedDict
+    from flamo_amd.processor import dsp, system
+    meta, a = load_golden("rec3_identity")
+    N, nfft, db = meta["N"], meta["nfft"], meta["alias_decay_db"]
+    kw = dict(nfft=nfft, alias_decay_db=db, device=gpu, dtype=dt)
+    dl = dsp.parallelDelay(size=(N,), max_len=60, isint=True, **kw)
+    dl.assign_value(dl.sample2s(torch.tensor(meta["delays"], dtype=dt, device=gpu)))
+    mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", **kw)
+    mix.assign_value(_dev(a["U_param"], gpu, dt))
+    att = dsp.parallelGain(size=(N,), **kw)
+    att.assign_value(_dev(a["att"], gpu, dt))
+    model = system.Shell(core=system.Recursion(fF=dl, fB=system.Series(OrderedDict({"mix": mix, "att": att}))))
+    tol = max(TOL[dt], 1e-9)
+    assert relerr(model.get_time_response(identity=True).cpu(), a["ir"]) < tol
+    assert relerr(model.get_freq_response(identity=True).cpu(), a["fr"]) < tol
+    assert relerr(model.get_time_response(identity=False).cpu(), a["ir_vec"]) < tol
+
+
+def test_fdn16_full_size_against_oracle(gpu):
+    """BASELINE config 3: 16-channel FDN at nfft=192000, float64 and float32 vs the float64 oracle."""
+    from flamo_amd.processor import dsp, system
+    from oracle import hotpath as O
+    torch.manual_seed(130709)
+    N, nfft, db = 16, 192000, 30.0
+    delays = [503, 593, 701, 811, 919, 1031, 1151, 1259, 1381, 1493, 1613, 1741, 1873, 2003, 2381, 2713]
+    meta = dict(N=N, nfft=nfft, alias_decay_db=db, delays=delays, attn=True)
+    a = dict(in_gain=torch.randn(N, 1, dtype=torch.float64), out_gain=torch.randn(1, N, dtype=torch.float64),
+             U_param=torch.randn(N, N, dtype=torch.float64), attn_param=torch.randn(12, N, dtype=torch.float64) * 0.3 + 2,
+             delays_s=torch.tensor(delays, dtype=torch.float64) / 48000 * 100)
+    x = torch.zeros(1, nfft, 1, dtype=torch.float64)
+    x[:, 0] = 1
+    amap = lambda p: 20 * torch.log10(torch.sigmoid(p))
+    yref = O.fdn_forward(x, a["in_gain"], a["out_gain"], a["U_param"], a["delays_s"], nfft, db,
+                         attn_param=a["attn_param"], attn_map=amap)
+    for dt_, tol in ((torch.float64, 1e-8), (torch.float32, 1e-5)):
+        model, _ = _fdn_model(dsp, system, meta, a, gpu, dt_)
+        with torch.no_grad():
+            y = model(x.to(gpu, dt_))
+        assert relerr(y.cpu(), yref) < tol, dt_
+
+
+def test_solve_properties(gpu):
+    """A x = b residual and adjoint consistency for every supported N (padding paths included)."""
+    from flamo_amd import ops
+    torch.manual_seed(0)
+    M = 301
+    for N in (1, 2, 3, 4, 6, 8, 13, 16, 24, 32):
+        P = (torch.randn(M, N, N, dtype=torch.complex128, device=gpu) * (0.4 / N ** 0.5))
+        R = torch.randn(3, M, N, 2, dtype=torch.complex128, device=gpu)
+        X = ops.solve(P, R, one_minus=True)
+        A = torch.eye(N, dtype=torch.complex128, device=gpu) - P
+        res = torch.einsum("fmn,bfnk->bfmk", A, X) - R
+        assert (res.abs().max() / R.abs().max()).item() < 1e-12, N
+        Xd = ops.solve(A, R, one_minus=False)
+        assert relerr(Xd, X) < 1e-12
+        X32 = ops.solve(P.to(torch.complex64), R.to(torch.complex64), one_minus=True)
+        assert relerr(X32.to(torch.complex128), X) < 1e-5
+    # a matrix that needs row exchanges (zero leading pivot)
+    Pm = torch.tensor([[0.0, 1.0], [1.0, 0.0]], dtype=torch.complex128, device=gpu).expand(5, 2, 2).contiguous()
+    R = torch.randn(1, 5, 2, dtype=torch.complex128, device=gpu)
+    X = ops.solve(Pm, R, one_minus=False)
+    assert relerr(X[..., 0], R[..., 1]) < 1e-14 and relerr(X[..., 1], R[..., 0]) < 1e-14
+    with pytest.raises(RuntimeError):
+        ops.solve(torch.zeros(4, 65, 65, dtype=torch.complex64, device=gpu),
+                  torch.zeros(1, 4, 65, dtype=torch.complex64, device=gpu))
+
+
+def test_config2_full_size(gpu):
+    """BASELINE config 2 (the metric's configuration): Series(Matrix 8x8, GEQ 8x8), nfft=96000, B=32,
+    float32 on the GPU against the float64 oracle; forward and all gradients."""
+    from flamo_amd.processor import dsp, system
+    from oracle import hotpath as O
+    torch.manual_seed(130709)
+    N, nfft, B = 8, 96000, 8          # B=8 keeps the CPU oracle to a few seconds
+    a = dict(W=torch.randn(N, N, dtype=torch.float64),
+             geq_param=torch.empty(12, N, N, dtype=torch.float64).uniform_(10 ** (-6 / 20), 10 ** (6 / 20)))
+    x = torch.randn(B, nfft, N, dtype=torch.float64)
+    leaves = [t.clone().requires_grad_(True) for t in (x, a["W"], a["geq_param"])]
+    yref = O.config2_forward(leaves[0], leaves[1], leaves[2], nfft)
+    gref = torch.autograd.grad((yref ** 2).mean(), leaves)
+    meta = dict(nfft=nfft, alias_decay_db=0.0, N=N)
+    model, mat, geq = _config2_model(dsp, system, meta, a, gpu, torch.float32)
+    xg = x.to(gpu, torch.float32).requires_grad_(True)
+    y = model(xg)
+    assert relerr(y.detach().cpu(), yref.detach()) < 1e-5
+    g = torch.autograd.grad((y ** 2).mean(), [xg, mat.param, geq.param])
+    assert relerr(g[0].cpu(), gref[0]) < 1e-5
+    assert relerr(g[1].cpu(), gref[1]) < 1e-5
+    assert relerr(g[2].cpu(), gref[2]) < 1e-4
