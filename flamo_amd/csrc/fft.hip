@@ -497,6 +497,7 @@ static int rfft_impl(const void* x, long x_sig_stride, int t_in, void* X, void* 
     Plan p;
     int rc = make_plan(nfft, sizeof(T) == 8, p);
     if (rc) return rc;
+    if (nsig == 0) return FL_OK;
     FL_REQUIRE(x && X && W, "rfft: null pointer");
     FL_REQUIRE(t_in >= 0 && nsig >= 0, "rfft: bad sizes");
     FftArgs<T> a = {};
@@ -518,6 +519,7 @@ static int irfft_impl(const void* X, void* y, long y_sig_stride, int t_out, void
     Plan p;
     int rc = make_plan(nfft, sizeof(T) == 8, p);
     if (rc) return rc;
+    if (nsig == 0) return FL_OK;
     FL_REQUIRE(X && y && W, "irfft: null pointer");
     FL_REQUIRE(t_out >= 0 && t_out <= nfft && nsig >= 0, "irfft: t_out must be in [0, nfft]");
     FftArgs<T> a = {};

@@ -25,24 +25,27 @@ __global__ void __launch_bounds__(256) delay_response_kernel(const int32_t* __re
     H[(size_t)c * m_local + f] = cx<T>(a * w.x, a * w.y);
 }
 
-template <typename T>
+// The section polynomials are evaluated in DOUBLE precision whatever the storage type T: at low
+// frequencies b0 + b1 w + b2 w^2 cancels to ~1e-5 of its terms (shelving sections at 44 Hz), so
+// float32 evaluation -- what the reference's float32 mode does -- loses 3 digits there.  The
+// point w = exp(-2 pi i k / n) is generated with sincospi in double, not read from a table.
 struct SosEval {
-    cx<T> z1, z2;  // g*w, g^2*w^2
-    __device__ inline cx<T> poly(const T* co, int S, int C, int s, int c) const {
-        const T c0 = co[((size_t)0 * S + s) * C + c];
-        const T c1 = co[((size_t)1 * S + s) * C + c];
-        const T c2 = co[((size_t)2 * S + s) * C + c];
-        return cx<T>(c0 + c1 * z1.x + c2 * z2.x, c1 * z1.y + c2 * z2.y);
+    cx<double> z1, z2;  // g*w, g^2*w^2
+    __device__ inline cx<double> poly(const double* co, int S, int C, int s, int c) const {
+        const double c0 = co[((size_t)0 * S + s) * C + c];
+        const double c1 = co[((size_t)1 * S + s) * C + c];
+        const double c2 = co[((size_t)2 * S + s) * C + c];
+        return cx<double>(c0 + c1 * z1.x + c2 * z2.x, c1 * z1.y + c2 * z2.y);
     }
 };
 
-template <typename T>
-__device__ inline SosEval<T> sos_point(const cx<T>* W, int nfft, int k, T g) {
-    SosEval<T> e;
-    const cx<T> w1 = W[k % nfft];
-    const cx<T> w2 = W[(2 * (long long)k) % nfft];
-    e.z1 = cx<T>(g * w1.x, g * w1.y);
-    e.z2 = cx<T>(g * g * w2.x, g * g * w2.y);
+__device__ inline SosEval sos_point(int nfft, int k, double g) {
+    SosEval e;
+    double s1, c1, s2, c2;
+    sincospi(2.0 * (double)k / (double)nfft, &s1, &c1);
+    sincospi(4.0 * (double)k / (double)nfft, &s2, &c2);
+    e.z1 = cx<double>(g * c1, -g * s1);
+    e.z2 = cx<double>(g * g * c2, -g * g * s2);
     return e;
 }
 
@@ -51,32 +54,32 @@ template <> __device__ inline float eps_of<float>() { return 1.1920928955078125e
 template <> __device__ inline double eps_of<double>() { return 2.220446049250313e-16; }
 
 template <typename T>
-__global__ void __launch_bounds__(256) sos_response_kernel(const T* __restrict__ b, const T* __restrict__ a, int S, int C,
-                                                          T g, const cx<T>* __restrict__ W, int nfft, int bin0,
+__global__ void __launch_bounds__(256) sos_response_kernel(const double* __restrict__ b, const double* __restrict__ a, int S, int C,
+                                                          double g, int nfft, int bin0,
                                                           int m_local, cx<T>* __restrict__ H) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= m_local) return;
     const int c = blockIdx.y;
-    const SosEval<T> e = sos_point<T>(W, nfft, bin0 + f, g);
-    cx<T> Bp(1, 0), Ap(1, 0);
+    const SosEval e = sos_point(nfft, bin0 + f, g);
+    cx<double> Bp(1, 0), Ap(1, 0);
     for (int s = 0; s < S; ++s) {
         Bp = Bp * e.poly(b, S, C, s, c);
         Ap = Ap * e.poly(a, S, C, s, c);
     }
-    cx<T> h = (Ap.x != 0 || Ap.y != 0) ? cdiv(Bp, Ap) : cx<T>(eps_of<T>(), 0);
-    H[(size_t)c * m_local + f] = h;
+    cx<double> h = (Ap.x != 0 || Ap.y != 0) ? cdiv(Bp, Ap) : cx<double>((double)eps_of<T>(), 0);
+    H[(size_t)c * m_local + f] = cx<T>((T)h.x, (T)h.y);
 }
 
 // Backward: dL/db[p,s,c] = sum_k Re(conj(gH) * H/B_s * z_p),  dL/da[p,s,c] = -sum_k Re(conj(gH) * H/A_s * z_p)
 // Sections are processed in chunks of 4 (blockIdx.z) so the 24 running sums stay in registers.
 template <typename T>
-__global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __restrict__ gH, const T* __restrict__ b,
-                                                              const T* __restrict__ a, int S, int C, T g,
-                                                              const cx<T>* __restrict__ W, int nfft, int bin0,
-                                                              int m_local, T* __restrict__ part) {
+__global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __restrict__ gH, const double* __restrict__ b,
+                                                              const double* __restrict__ a, int S, int C, double g,
+                                                              int nfft, int bin0,
+                                                              int m_local, double* __restrict__ part) {
     const int c = blockIdx.y;
     const int s0 = blockIdx.z * 4;
-    T acc[2][3][4];
+    double acc[2][3][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -85,32 +88,33 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
             for (int q = 0; q < 4; ++q) acc[i][p][q] = 0;
 
     for (int f = blockIdx.x * 256 + threadIdx.x; f < m_local; f += gridDim.x * 256) {
-        const SosEval<T> e = sos_point<T>(W, nfft, bin0 + f, g);
-        cx<T> Bp(1, 0), Ap(1, 0);
+        const SosEval e = sos_point(nfft, bin0 + f, g);
+        cx<double> Bp(1, 0), Ap(1, 0);
         for (int s = 0; s < S; ++s) {
             Bp = Bp * e.poly(b, S, C, s, c);
             Ap = Ap * e.poly(a, S, C, s, c);
         }
         if (Ap.x == 0 && Ap.y == 0) continue;  // guarded bins are the constant eps: zero gradient
-        const cx<T> h = cdiv(Bp, Ap);
-        const cx<T> gc = conj(gH[(size_t)c * m_local + f]);
-        const cx<T> zp[3] = {cx<T>(1, 0), e.z1, e.z2};
+        const cx<double> h = cdiv(Bp, Ap);
+        const cx<T> gin = gH[(size_t)c * m_local + f];
+        const cx<double> gc((double)gin.x, -(double)gin.y);
+        const cx<double> zp[3] = {cx<double>(1, 0), e.z1, e.z2};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int s = s0 + q;
             if (s >= S) break;
-            const cx<T> Bs = e.poly(b, S, C, s, c), As = e.poly(a, S, C, s, c);
-            cx<T> qb;
+            const cx<double> Bs = e.poly(b, S, C, s, c), As = e.poly(a, S, C, s, c);
+            cx<double> qb;
             if (Bs.x != 0 || Bs.y != 0) {
                 qb = cdiv(h, Bs);
             } else {  // numerator section vanishes at this bin: product of the others
-                cx<T> o(1, 0);
+                cx<double> o(1, 0);
                 for (int t = 0; t < S; ++t)
                     if (t != s) o = o * e.poly(b, S, C, t, c);
                 qb = cdiv(o, Ap);
             }
-            const cx<T> qa = cdiv(h, As);
-            const cx<T> tb = gc * qb, ta = gc * qa;
+            const cx<double> qa = cdiv(h, As);
+            const cx<double> tb = gc * qb, ta = gc * qa;
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 acc[0][p][q] += tb.x * zp[p].x - tb.y * zp[p].y;     // Re(tb * z_p)
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
         }
     }
     // block reduction: wavefront shuffles, then 4 partials through LDS
-    __shared__ T red[4][24];
+    __shared__ double red[4][24];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -127,7 +131,7 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                T v = acc[i][p][q];
+                double v = acc[i][p][q];
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
                 if (lane == 0) red[wave][(i * 3 + p) * 4 + q] = v;
@@ -137,7 +141,7 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
         const int i = threadIdx.x / 12, p = (threadIdx.x / 4) % 3, q = threadIdx.x % 4;
         const int s = s0 + q;
         if (s < S) {
-            const T v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
             part[((((size_t)blockIdx.x * 2 + i) * 3 + p) * S + s) * C + c] = v;
         }
     }
@@ -164,26 +168,26 @@ static int delay_impl(const int32_t* m, const void* amp, int C, const void* W, i
 }
 
 template <typename T>
-static int sos_impl(const void* b, const void* a, int S, int C, double gamma, const void* W, int nfft, int bin0,
+static int sos_impl(const void* b, const void* a, int S, int C, double gamma, int nfft, int bin0,
                     int m_local, void* H, void* stream) {
-    FL_REQUIRE(b && a && W && H, "sos_response: null pointer");
+    FL_REQUIRE(b && a && H, "sos_response: null pointer");
     FL_REQUIRE(S > 0 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local >= 0, "sos_response: bad sizes");
     if (m_local == 0) return FL_OK;
     dim3 grid(cdiv_i(m_local, 256), C);
-    hipLaunchKernelGGL((sos_response_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)b, (const T*)a, S, C,
-                       (T)gamma, (const cx<T>*)W, nfft, bin0, m_local, (cx<T>*)H);
+    hipLaunchKernelGGL((sos_response_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const double*)b, (const double*)a, S, C,
+                       gamma, nfft, bin0, m_local, (cx<T>*)H);
     FL_CHECK_LAUNCH("sos_response");
     return FL_OK;
 }
 
 template <typename T>
-static int sos_bwd_impl(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* W, int nfft,
+static int sos_bwd_impl(const void* gH, const void* b, const void* a, int S, int C, double gamma, int nfft,
                         int bin0, int m_local, void* part, void* stream) {
-    FL_REQUIRE(gH && b && a && W && part, "sos_response_bwd: null pointer");
+    FL_REQUIRE(gH && b && a && part, "sos_response_bwd: null pointer");
     FL_REQUIRE(S > 0 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local > 0, "sos_response_bwd: bad sizes");
     dim3 grid(sos_blocks(m_local), C, cdiv_i(S, 4));
     hipLaunchKernelGGL((sos_response_bwd_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)gH,
-                       (const T*)b, (const T*)a, S, C, (T)gamma, (const cx<T>*)W, nfft, bin0, m_local, (T*)part);
+                       (const double*)b, (const double*)a, S, C, gamma, nfft, bin0, m_local, (double*)part);
     FL_CHECK_LAUNCH("sos_response_bwd");
     return FL_OK;
 }
@@ -201,21 +205,21 @@ int fl_delay_response_c128(const int32_t* m, const void* amp, int C, const void*
                            void* H, void* stream) {
     return delay_impl<double>(m, amp, C, W, nfft, bin0, m_local, H, stream);
 }
-int fl_sos_response_f32(const void* b, const void* a, int S, int C, double gamma, const void* W, int nfft, int bin0,
+int fl_sos_response_c64(const void* b, const void* a, int S, int C, double gamma, int nfft, int bin0,
                         int m_local, void* H, void* stream) {
-    return sos_impl<float>(b, a, S, C, gamma, W, nfft, bin0, m_local, H, stream);
+    return sos_impl<float>(b, a, S, C, gamma, nfft, bin0, m_local, H, stream);
 }
-int fl_sos_response_f64(const void* b, const void* a, int S, int C, double gamma, const void* W, int nfft, int bin0,
+int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamma, int nfft, int bin0,
                         int m_local, void* H, void* stream) {
-    return sos_impl<double>(b, a, S, C, gamma, W, nfft, bin0, m_local, H, stream);
+    return sos_impl<double>(b, a, S, C, gamma, nfft, bin0, m_local, H, stream);
 }
 int fl_sos_bwd_blocks(int m_local) { return sos_blocks(m_local); }
-int fl_sos_response_bwd_f32(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* W,
+int fl_sos_response_bwd_c64(const void* gH, const void* b, const void* a, int S, int C, double gamma,
                             int nfft, int bin0, int m_local, void* part, void* stream) {
-    return sos_bwd_impl<float>(gH, b, a, S, C, gamma, W, nfft, bin0, m_local, part, stream);
+    return sos_bwd_impl<float>(gH, b, a, S, C, gamma, nfft, bin0, m_local, part, stream);
 }
-int fl_sos_response_bwd_f64(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* W,
+int fl_sos_response_bwd_c128(const void* gH, const void* b, const void* a, int S, int C, double gamma,
                             int nfft, int bin0, int m_local, void* part, void* stream) {
-    return sos_bwd_impl<double>(gH, b, a, S, C, gamma, W, nfft, bin0, m_local, part, stream);
+    return sos_bwd_impl<double>(gH, b, a, S, C, gamma, nfft, bin0, m_local, part, stream);
 }
 }

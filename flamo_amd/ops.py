@@ -475,11 +475,12 @@ def delay_response(m_int: torch.Tensor, amp: torch.Tensor, nfft: int) -> torch.T
 
 class _Sos(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, b, a, gamma, nfft):
+    def forward(ctx, b, a, gamma, nfft, real):
         dev = _require_gpu(b, a)
-        real = _rdtype(b)
         if b.shape != a.shape or b.shape[0] != 3 or b.dim() < 2:
             raise ValueError("sos_response: b and a must both be (3, n_sections, ...)")
+        if b.dtype != torch.float64 or a.dtype != torch.float64:
+            raise TypeError("sos_response: coefficients are passed in float64")
         bc, ac = b.contiguous(), a.contiguous()
         S = b.shape[1]
         chan = tuple(b.shape[2:])
@@ -487,32 +488,33 @@ class _Sos(torch.autograd.Function):
         bin0, m_local = bin_shard(nfft)
         H = torch.empty((*chan, m_local), dtype=_cdtype(real), device=dev)
         L = _lib.lib()
-        fn = L.fl_sos_response_f32 if real == torch.float32 else L.fl_sos_response_f64
-        _lib.check(fn(bc.data_ptr(), ac.data_ptr(), S, C_, float(gamma), twiddles(nfft, real, dev).data_ptr(), nfft,
-                      bin0, m_local, H.data_ptr(), _stream()), "sos_response")
+        fn = L.fl_sos_response_c64 if real == torch.float32 else L.fl_sos_response_c128
+        _lib.check(fn(bc.data_ptr(), ac.data_ptr(), S, C_, float(gamma), nfft, bin0, m_local, H.data_ptr(), _stream()),
+                   "sos_response")
         ctx.save_for_backward(bc, ac)
-        ctx.cfg = (float(gamma), nfft, S, C_, bin0, m_local)
+        ctx.cfg = (float(gamma), nfft, S, C_, bin0, m_local, real)
         return H.movedim(-1, 0)
 
     @staticmethod
     def backward(ctx, gH):
         bc, ac = ctx.saved_tensors
-        gamma, nfft, S, C_, bin0, m_local = ctx.cfg
-        real = _rdtype(bc)
+        gamma, nfft, S, C_, bin0, m_local, real = ctx.cfg
         dev = bc.device
         g = gH.resolve_conj()
         g = g if g.movedim(0, -1).is_contiguous() else _h_planar(g, True)
         L = _lib.lib()
         nblk = L.fl_sos_bwd_blocks(m_local)
-        part = torch.zeros((nblk, 2, 3, S, C_), dtype=real, device=dev)
-        fn = L.fl_sos_response_bwd_f32 if real == torch.float32 else L.fl_sos_response_bwd_f64
-        _lib.check(fn(g.data_ptr(), bc.data_ptr(), ac.data_ptr(), S, C_, gamma, twiddles(nfft, real, dev).data_ptr(),
-                      nfft, bin0, m_local, part.data_ptr(), _stream()), "sos_response_bwd")
+        part = torch.zeros((nblk, 2, 3, S, C_), dtype=torch.float64, device=dev)
+        fn = L.fl_sos_response_bwd_c64 if real == torch.float32 else L.fl_sos_response_bwd_c128
+        _lib.check(fn(g.data_ptr(), bc.data_ptr(), ac.data_ptr(), S, C_, gamma, nfft, bin0, m_local, part.data_ptr(),
+                      _stream()), "sos_response_bwd")
         tot = part.sum(dim=0)
-        return tot[0].view(bc.shape), tot[1].view(ac.shape), None, None
+        return tot[0].view(bc.shape), tot[1].view(ac.shape), None, None, None
 
 
-def sos_response(b: torch.Tensor, a: torch.Tensor, gamma: float, nfft: int) -> torch.Tensor:
+def sos_response(b: torch.Tensor, a: torch.Tensor, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
     """H[k, ...] = prod_s B_s(k) / prod_s A_s(k) of a cascade of second-order sections with
-    coefficients b, a: (3, n_sections, ...) real (anti-alias radius gamma applied to the taps)."""
-    return _Sos.apply(b, a, float(gamma), int(nfft))
+    coefficients b, a: (3, n_sections, ...) real (anti-alias radius gamma applied to the taps).
+    The cascade is evaluated in float64 (coefficients are promoted); ``dtype`` (float32 |
+    float64) selects the precision H is stored in."""
+    return _Sos.apply(b.to(torch.float64), a.to(torch.float64), float(gamma), int(nfft), dtype)

@@ -387,7 +387,7 @@ class _SOSMixin:
     without building the (M, sections, ...) tensors."""
 
     def _sos_to_response(self, b, a):
-        return ops.sos_response(b.to(self.dtype), a.to(self.dtype), self._gamma_f, self.nfft)
+        return ops.sos_response(b, a, self._gamma_f, self.nfft, dtype=self.dtype)
 
     def _sections_spectra(self, b, a):
         """B, A as the reference returns them from get_poly_coeff: rfft of the weighted taps."""
@@ -395,7 +395,10 @@ class _SOSMixin:
         return self.fft(b.to(self.dtype) * env), self.fft(a.to(self.dtype) * env)
 
     def get_freq_response(self):
-        self.freq_response = lambda param: self._sos_to_response(*self._sos_coeffs(self.map(param)))
+        # the few hundred parameter scalars are mapped to coefficients in float64 whatever the
+        # module dtype: the cascade is ill-conditioned in its coefficients at low frequency and
+        # the float64 reference is the parity target
+        self.freq_response = lambda param: self._sos_to_response(*self._sos_coeffs(self.map(param.double())))
 
     def get_poly_coeff(self, param):
         """(H, B, A) for *mapped* parameters, as in the reference.  H comes from the fused kernel;
@@ -572,19 +575,18 @@ class Delay(DSP):
         m = self.get_delays()
 
         def response(param):
-            mm = m(param)
+            md = m(param.double())          # seconds -> samples in float64 whatever the module dtype
             if self.isint:
-                mi = mm.round()
-                amp = (self._gamma_f ** mi.to(torch.float64)).to(self.dtype)
+                mi = md.round()             # half-to-even, as torch.round in the reference
+                amp = (self._gamma_f ** mi).to(self.dtype)
                 return ops.delay_response(mi.to(torch.int64), amp, self.nfft)
-            g = self._gamma_on(mm)
-            # fractional (learnable) delays: phase = frac(k m / nfft) in float64, then exp.
+            # fractional (learnable) delays: phase = frac(k m / nfft) and gamma^m in float64
             bin0, m_local = ops.bin_shard(self.nfft)
-            k = torch.arange(bin0, bin0 + m_local, device=mm.device, dtype=torch.float64)
-            k = k.view(-1, *([1] * mm.dim()))
-            turns = torch.remainder(k * mm.to(torch.float64).unsqueeze(0) / self.nfft, 1.0)
-            ang = (-2 * torch.pi * turns).to(mm.dtype)
-            return torch.polar((g ** mm).unsqueeze(0).expand_as(ang).contiguous(), ang)
+            k = torch.arange(bin0, bin0 + m_local, device=md.device, dtype=torch.float64)
+            k = k.view(-1, *([1] * md.dim()))
+            ang = -2 * torch.pi * torch.remainder(k * md.unsqueeze(0) / self.nfft, 1.0)
+            H = torch.polar((self._gamma_f ** md).unsqueeze(0).expand_as(ang).contiguous(), ang)
+            return H.to(torch.complex64 if self.dtype == torch.float32 else torch.complex128)
 
         self.freq_response = response
 

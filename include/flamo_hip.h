@@ -149,18 +149,20 @@ int fl_delay_response_c128(const int32_t* m, const void* amp, int C, const void*
  * (dsp.py:1520-1526, 2587-2593):  per channel c and bin k,
  *   B_s = b[0,s,c] + b[1,s,c] g w + b[2,s,c] g^2 w^2,  A_s likewise,  w = exp(-2 pi i k/nfft),
  *   H[c,k] = prod_s B_s / prod_s A_s, or eps where |prod A| == 0.
- * b, a: real (3, S, C) contiguous.  Evaluated directly (no (M,S,C) tensor is ever built). */
-int fl_sos_response_f32(const void* b, const void* a, int S, int C, double gamma, const void* W,
+ * b, a: DOUBLE (3, S, C) contiguous whatever the precision of H (_c64 / _c128).  Evaluated directly (no (M,S,C) tensor is ever built), in
+ * double precision whatever the storage type: the shelving sections cancel to ~1e-5 of their
+ * terms at low frequency, which float32 evaluation (the reference's float32 mode) cannot hold. */
+int fl_sos_response_c64(const void* b, const void* a, int S, int C, double gamma,
                         int nfft, int bin0, int m_local, void* H, void* stream);
-int fl_sos_response_f64(const void* b, const void* a, int S, int C, double gamma, const void* W,
+int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamma,
                         int nfft, int bin0, int m_local, void* H, void* stream);
-/* Backward: partial sums over bins of dL/db, dL/da.  part: real (nblk, 2, 3, S, C) where
+/* Backward: partial sums over bins of dL/db, dL/da.  part: double (nblk, 2, 3, S, C) where
  * nblk = fl_sos_bwd_blocks(m_local); the caller sums over nblk. */
 int fl_sos_bwd_blocks(int m_local);
-int fl_sos_response_bwd_f32(const void* gH, const void* b, const void* a, int S, int C, double gamma,
-                            const void* W, int nfft, int bin0, int m_local, void* part, void* stream);
-int fl_sos_response_bwd_f64(const void* gH, const void* b, const void* a, int S, int C, double gamma,
-                            const void* W, int nfft, int bin0, int m_local, void* part, void* stream);
+int fl_sos_response_bwd_c64(const void* gH, const void* b, const void* a, int S, int C, double gamma,
+                            int nfft, int bin0, int m_local, void* part, void* stream);
+int fl_sos_response_bwd_c128(const void* gH, const void* b, const void* a, int S, int C, double gamma,
+                            int nfft, int bin0, int m_local, void* part, void* stream);
 
 /* ------------------------------------------------------------------ closed loop
  * Replace torch.linalg.solve(A, B) in system.Recursion.forward (system.py:420-425).
