@@ -43,33 +43,50 @@ def build_model(dev, dtype):
     return system.Shell(core, dsp.FFT(NFFT, dtype=dtype), dsp.iFFT(NFFT, dtype=dtype)), [mat.param, geq.param]
 
 
-def cpu_baseline(W, G, max_seconds=25.0):
+def cpu_baseline(W, G, budget_s=20.0):
     """The same graph on the host cores through the CPU oracle (a port of the reference's torch
-    ops), float32 like the reference's default module dtype.  Bounded sample: the full config-2
-    batch, as many steps as fit in ~max_seconds (at least 1 after a warm-up)."""
+    ops), float32 like the reference's default module dtype.  Bounded sample: a probe step at
+    batch 1 sizes the largest batch (<= 32) whose timed steps fit in ~budget_s; throughput is
+    reported on that sample (the work is linear in the batch apart from the response build)."""
     from oracle import hotpath as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    x = torch.randn(BATCH, NFFT, NCH, dtype=torch.float32)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
     Wc = W.detach().cpu().float().requires_grad_(True)
     Gc = G.detach().cpu().float().requires_grad_(True)
 
-    def step():
+    def step(x):
         y = O.config2_forward(x, Wc, Gc, NFFT)
         torch.autograd.grad((y ** 2).mean(), [Wc, Gc])
 
-    t0 = time.perf_counter()
-    step()
-    first = time.perf_counter() - t0
-    n = max(1, min(3, int((max_seconds - first) / max(first, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    dt = (time.perf_counter() - t0) / n
+    def timed(b, n):
+        x = torch.randn(b, NFFT, NCH, dtype=torch.float32)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step(x)
+        return (time.perf_counter() - t0) / n
+
+    # torch's CPU ops do not scale to hundreds of SMT threads on these shapes: probe a few thread
+    # counts at batch 1 and keep the fastest (the count actually used is reported as "cores")
+    best = None
+    for cores in sorted({min(avail, c) for c in (16, 64, avail)}):
+        torch.set_num_threads(cores)
+        timed(1, 1)                  # warm-up (thread pools, FFT plans)
+        t = timed(1, 1)
+        if best is None or t < best[0]:
+            best = (t, cores)
+        if t > budget_s / 3:
+            break
+    t1, cores = best
+    torch.set_num_threads(cores)
+    b = int(max(1, min(BATCH, budget_s / 2 / max(t1, 1e-3))))
+    n = 2 if b < BATCH or t1 * BATCH * 2 < budget_s else 1
+    dt = timed(b, n)
     M = NFFT // 2 + 1
-    return {"value": 2 * BATCH * M * NCH * NCH / dt, "unit": "products/s", "cores": cores, "kind": "port",
-            "sample": f"config 2 full size (B={BATCH}, nfft={NFFT}, {NCH}x{NCH}, float32), {n} timed step(s) "
-                      f"after 1 warm-up, {dt:.2f} s/step"}
+    return {"value": 2 * b * M * NCH * NCH / dt, "unit": "products/s", "cores": cores, "kind": "port",
+            "sample": f"config 2 graph (nfft={NFFT}, {NCH}x{NCH}, float32) at batch {b} of {BATCH}, {n} timed step(s) "
+                      f"after warm-up, {dt:.2f} s/step, torch {torch.__version__} CPU ops"}
 
 
 def main():
