@@ -346,6 +346,354 @@ __global__ void __launch_bounds__(256) fft_rows(FftArgs<T> a) {
     }
 }
 
+
+// ================================================================ fast path: two register stages
+// For the production lengths (nfft/2 = L1*L2 with L1, L2 in {200, 240, 300, 320, 400, 480, ...})
+// each sub-FFT of length len = A*B is done as TWO in-register stages with ONE LDS exchange:
+//   stage 1: B work items per sequence, each an A-point FFT over the stride-B samples, loaded
+//            straight from global memory, multiplied by W_len^(tb*ka), written to LDS;
+//   stage 2: A work items per sequence, each a B-point FFT read from LDS; results leave for
+//            global memory (pass 1) or go back to LDS in natural order for the epilogue (pass 2).
+// The A- and B-point FFTs are fully unrolled mixed-radix networks on registers whose twiddles
+// are compile-time constants.  Compared with the generic Stockham path (one LDS round trip per
+// radix-2..5 stage) this does a quarter of the LDS traffic and a third of the barriers.
+
+constexpr double kPi = 3.141592653589793238462643383279502884;
+
+constexpr double c_sin_small(double x) {  // |x| <= pi/4
+    double x2 = x * x, term = x, sum = x;
+    for (int k = 1; k < 14; ++k) {
+        term *= -x2 / ((2 * k) * (2 * k + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double c_cos_small(double x) {
+    double x2 = x * x, term = 1, sum = 1;
+    for (int k = 1; k < 14; ++k) {
+        term *= -x2 / ((2 * k - 1) * (2 * k));
+        sum += term;
+    }
+    return sum;
+}
+// cos / sin of 2*pi*m/R with exact octant reduction
+constexpr double c_cos2pi(int m, int R) {
+    m %= R;
+    if (m < 0) m += R;
+    // fold to [0, R/2]: cos(2pi m/R) = cos(2pi (R-m)/R)
+    if (2 * m > R) m = R - m;
+    // now angle in [0, pi]; cos(pi - x) = -cos x
+    bool neg = false;
+    if (4 * m > R) { m = R - 2 * m; neg = true; /* angle' = pi - angle = pi*(R-2m)/R -> use half-angle form below */
+        // angle' = pi * m' / R with m' = R - 2m_old ; handle by separate formula
+        double x = kPi * (double)m / (double)R;           // in [0, pi/2)
+        double v = (x <= kPi / 4) ? c_cos_small(x) : c_sin_small(kPi / 2 - x);
+        return -v;
+    }
+    (void)neg;
+    double x = 2 * kPi * (double)m / (double)R;           // in [0, pi/2]
+    return (x <= kPi / 4) ? c_cos_small(x) : c_sin_small(kPi / 2 - x);
+}
+constexpr double c_sin2pi(int m, int R) {
+    m %= R;
+    if (m < 0) m += R;
+    bool neg = false;
+    if (2 * m > R) { m = R - m; neg = true; }              // sin(2pi - x) = -sin x
+    double v = 0;
+    if (4 * m > R) {                                       // angle in (pi/2, pi]: sin(pi - x)
+        double x = kPi * (double)(R - 2 * m) / (double)R;  // pi - angle, in [0, pi/2)
+        v = (x <= kPi / 4) ? c_sin_small(x) : c_cos_small(kPi / 2 - x);
+    } else {
+        double x = 2 * kPi * (double)m / (double)R;
+        v = (x <= kPi / 4) ? c_sin_small(x) : c_cos_small(kPi / 2 - x);
+    }
+    return neg ? -v : v;
+}
+
+template <int R>
+struct TwTab {
+    double re[R], im[R];  // W_R^m = exp(-2 pi i m / R)
+    constexpr TwTab() : re{}, im{} {
+        for (int m = 0; m < R; ++m) {
+            re[m] = c_cos2pi(m, R);
+            im[m] = -c_sin2pi(m, R);
+        }
+    }
+};
+
+constexpr bool is_base_radix(int R) { return R == 2 || R == 3 || R == 4 || R == 5 || R == 7 || R == 11 || R == 13; }
+constexpr int first_factor(int R) {
+    if (R % 4 == 0) return 4;
+    if (R % 2 == 0) return 2;
+    if (R % 3 == 0) return 3;
+    if (R % 5 == 0) return 5;
+    if (R % 7 == 0) return 7;
+    if (R % 11 == 0) return 11;
+    return 13;
+}
+
+// Natural-order in-register FFT of size R: v[k] <- sum_t v[t] W_R^(+-tk)
+template <typename T, int R, bool INV>
+struct RegFFT {
+    static __device__ __forceinline__ void run(cx<T> (&v)[R]) {
+        if constexpr (R == 1) {
+            return;
+        } else if constexpr (R == 7 || R == 11 || R == 13) {
+            constexpr TwTab<R> tw = TwTab<R>();
+            cx<T> o[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                cx<T> acc = v[0];
+#pragma unroll
+                for (int j = 1; j < R; ++j) {
+                    const int m = (j * k) % R;
+                    const cx<T> w((T)tw.re[m], INV ? (T)(-tw.im[m]) : (T)tw.im[m]);
+                    fma_cx(acc, v[j], w);
+                }
+                o[k] = acc;
+            }
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[k] = o[k];
+        } else if constexpr (is_base_radix(R)) {
+            Bfly<T, R, INV>::run(v, nullptr, 0);
+        } else {
+            constexpr int R1 = first_factor(R), R2 = R / R1;
+            constexpr TwTab<R> tw = TwTab<R>();
+            cx<T> w[R];
+#pragma unroll
+            for (int t2 = 0; t2 < R2; ++t2) {
+                cx<T> sub[R1];
+#pragma unroll
+                for (int t1 = 0; t1 < R1; ++t1) sub[t1] = v[t1 * R2 + t2];
+                RegFFT<T, R1, INV>::run(sub);
+#pragma unroll
+                for (int k1 = 0; k1 < R1; ++k1) {
+                    const int m = (t2 * k1) % R;
+                    if (m == 0) {
+                        w[k1 * R2 + t2] = sub[k1];
+                    } else {
+                        const cx<T> tf((T)tw.re[m], INV ? (T)(-tw.im[m]) : (T)tw.im[m]);
+                        w[k1 * R2 + t2] = sub[k1] * tf;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k1 = 0; k1 < R1; ++k1) {
+                cx<T> sub[R2];
+#pragma unroll
+                for (int t2 = 0; t2 < R2; ++t2) sub[t2] = w[k1 * R2 + t2];
+                RegFFT<T, R2, INV>::run(sub);
+#pragma unroll
+                for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = sub[k2];
+            }
+        }
+    }
+};
+
+constexpr int FAST_CT = 16;  // columns per workgroup in pass 1 (16 x 8 B = 128-byte segments)
+
+template <typename T, int A, int B, int LOAD, bool INV>
+__global__ void __launch_bounds__(256) fft_cols_fast(FftArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LEN = A * B, LENP = LEN | 1;
+    cx<T>* U = reinterpret_cast<cx<T>*>(smem);   // [FAST_CT][LENP]
+    cx<T>* tw = U + FAST_CT * LENP;               // W_LEN^m
+    const int tile = blockIdx.x % a.ntiles, sig = blockIdx.x / a.ntiles;
+    const int c0 = tile * FAST_CT;
+    const int nc = min(FAST_CT, a.L2 - c0);
+    const int twstep = a.n / LEN;
+    for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[j * twstep];
+    __syncthreads();
+    // stage 1: A-point FFTs over t_a for every (t_b, column)
+    for (int item = threadIdx.x; item < B * FAST_CT; item += 256) {
+        const int tb = item / FAST_CT, c = item % FAST_CT;
+        if (c < nc) {
+            cx<T> v[A];
+#pragma unroll
+            for (int ta = 0; ta < A; ++ta) v[ta] = load_any<T, LOAD>(a, sig, (ta * B + tb) * a.L2 + c0 + c);
+            RegFFT<T, A, INV>::run(v);
+            cx<T>* u = U + c * LENP + tb;
+            u[0] = v[0];
+#pragma unroll
+            for (int ka = 1; ka < A; ++ka) {
+                cx<T> t = tw[ka * tb];
+                if (INV) t = conj(t);
+                u[ka * B] = v[ka] * t;
+            }
+        }
+    }
+    __syncthreads();
+    // stage 2: B-point FFTs over t_b for every (k_a, column); inter-pass twiddle; store
+    cx<T>* out = a.scratch + (size_t)sig * a.L;
+    for (int item = threadIdx.x; item < A * FAST_CT; item += 256) {
+        const int ka = item / FAST_CT, c = item % FAST_CT;
+        if (c < nc) {
+            cx<T> v[B];
+            const cx<T>* u = U + c * LENP + ka * B;
+#pragma unroll
+            for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
+            RegFFT<T, B, INV>::run(v);
+#pragma unroll
+            for (int kb = 0; kb < B; ++kb) {
+                const int k1 = ka + A * kb;
+                cx<T> w = a.W[2 * (c0 + c) * k1];
+                if (INV) w = conj(w);
+                out[(size_t)k1 * a.L2 + c0 + c] = v[kb] * w;
+            }
+        }
+    }
+}
+
+// pass 2 fast: rows of length LEN = A*B; nslots*A <= 256 so every thread owns at most one
+// stage-2 item and the natural-order result can be written back into the same LDS buffer.
+template <typename T, int A, int B, int LOAD, int EPI, bool INV>
+__global__ void __launch_bounds__(256) fft_rows_fast(FftArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LEN = A * B, LENP = LEN | 1;
+    const int tile = blockIdx.x % a.ntiles, sig = blockIdx.x / a.ntiles;
+    const int P = (EPI == EPI_RFFT_POST) ? (a.L1 / 2 + 1) : a.L1;
+    const int r0 = tile * a.RT;
+    const int nr = min(a.RT, P - r0);
+    const int nslots = a.per * nr;
+    cx<T>* U = reinterpret_cast<cx<T>*>(smem);    // [per*RT][LENP]
+    cx<T>* tw = U + a.per * a.RT * LENP;
+    const int twstep = a.n / LEN;
+    for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[j * twstep];
+    __syncthreads();
+    for (int item = threadIdx.x; item < nslots * B; item += 256) {
+        const int sl = item / B, tb = item % B;
+        int row;
+        bool valid = true;
+        if (a.per == 2) {
+            const int r = r0 + (sl >> 1);
+            if (sl & 1) {
+                row = (a.L1 - r) % a.L1;
+                valid = (row != r);
+            } else {
+                row = r;
+            }
+        } else {
+            row = r0 + sl;
+        }
+        cx<T> v[A];
+#pragma unroll
+        for (int ta = 0; ta < A; ++ta)
+            v[ta] = valid ? load_any<T, LOAD>(a, sig, row * LEN + ta * B + tb) : cx<T>(0, 0);
+        RegFFT<T, A, INV>::run(v);
+        cx<T>* u = U + sl * LENP + tb;
+        u[0] = v[0];
+#pragma unroll
+        for (int ka = 1; ka < A; ++ka) {
+            cx<T> t = tw[ka * tb];
+            if (INV) t = conj(t);
+            u[ka * B] = v[ka] * t;
+        }
+    }
+    __syncthreads();
+    {
+        const int item = threadIdx.x;
+        const bool act = item < nslots * A;
+        const int sl = item / A, ka = item % A;
+        cx<T> v[B];
+        if (act) {
+            const cx<T>* u = U + sl * LENP + ka * B;
+#pragma unroll
+            for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
+            RegFFT<T, B, INV>::run(v);
+        }
+        __syncthreads();
+        if (act) {
+            cx<T>* z = U + sl * LENP + ka;
+#pragma unroll
+            for (int kb = 0; kb < B; ++kb) z[A * kb] = v[kb];
+        }
+        __syncthreads();
+    }
+    const cx<T>* res = U;
+    if (EPI == EPI_RFFT_POST) {
+        cx<T>* X = a.Xout + (size_t)sig * (a.L + 1);
+        const T hs = (T)0.5 * a.scale;
+        const T wi = a.interior ? (T)2 : (T)1;
+        for (int e = threadIdx.x; e < nr * LEN; e += 256) {
+            const int k2 = e / nr, i = e - k2 * nr;
+            const int r = r0 + i;
+            const int k = r + a.L1 * k2;
+            const int km = (k == 0) ? 0 : a.L - k;
+            const int rowm = km % a.L1, colm = km / a.L1;
+            const int slm = (rowm == r) ? a.per * i : a.per * i + 1;
+            const cx<T> zk = res[(a.per * i) * LENP + k2];
+            const cx<T> zm = res[slm * LENP + colm];
+            {
+                const cx<T> p = zk + conj(zm), d = zk - conj(zm);
+                const cx<T> o = p + mul_mi(a.W[k] * d);
+                const T sc = (k == 0) ? hs : hs * wi;
+                X[k] = cx<T>(sc * o.x, sc * o.y);
+                if (k == 0) {
+                    const cx<T> o2 = p + mul_i(d);
+                    X[a.L] = cx<T>(hs * o2.x, hs * o2.y);
+                }
+            }
+            if (k != 0 && rowm != r) {
+                const cx<T> p = zm + conj(zk), d = zm - conj(zk);
+                const cx<T> o = p + mul_mi(a.W[km] * d);
+                const T sc = hs * wi;
+                X[km] = cx<T>(sc * o.x, sc * o.y);
+            }
+        }
+    } else {
+        T* y = a.yr + (size_t)sig * a.yr_stride;
+        for (int e = threadIdx.x; e < nr * LEN; e += 256) {
+            const int k2 = e / nr, i = e - k2 * nr;
+            const int j = (r0 + i) + a.L1 * k2;
+            const cx<T> z = res[i * LENP + k2];
+            const int t = 2 * j;
+            T re = a.scale * z.x, im = a.scale * z.y;
+            if (a.env_log2 != 0.0) {
+                re *= envelope<T>(a.env_log2, t);
+                im *= envelope<T>(a.env_log2, t + 1);
+            }
+            if (t < a.t_out) y[t] = re;
+            if (t + 1 < a.t_out) y[t + 1] = im;
+        }
+    }
+}
+
+// (A, B) split of a sub-FFT length handled by the fast path; 0 = not supported
+struct FastSplit { int len, A, B; };
+static const FastSplit kFastSplits[] = {{200, 8, 25}, {240, 16, 15}, {300, 12, 25}, {320, 16, 20},
+                                        {400, 16, 25}, {480, 32, 15}};
+static const FastSplit* fast_split(int len) {
+    for (const FastSplit& f : kFastSplits)
+        if (f.len == len) return &f;
+    return nullptr;
+}
+
+template <typename T, int A, int B>
+static void launch_cols_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, size_t lds, hipStream_t st) {
+    if (inverse)
+        hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_IRFFT_PRE, true>), dim3(nblk), dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_PACK, false>), dim3(nblk), dim3(256), lds, st, a);
+}
+template <typename T, int A, int B>
+static void launch_rows_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, size_t lds, hipStream_t st) {
+    if (inverse)
+        hipLaunchKernelGGL((fft_rows_fast<T, A, B, LOAD_SCRATCH, EPI_IRFFT_STORE, true>), dim3(nblk), dim3(256), lds, st, a);
+    else
+        hipLaunchKernelGGL((fft_rows_fast<T, A, B, LOAD_SCRATCH, EPI_RFFT_POST, false>), dim3(nblk), dim3(256), lds, st, a);
+}
+
+#define FL_FAST_DISPATCH(FN, len, ...)                                   \
+    switch (len) {                                                       \
+        case 200: FN<T, 8, 25>(__VA_ARGS__); break;                      \
+        case 240: FN<T, 16, 15>(__VA_ARGS__); break;                     \
+        case 300: FN<T, 12, 25>(__VA_ARGS__); break;                     \
+        case 320: FN<T, 16, 20>(__VA_ARGS__); break;                     \
+        case 400: FN<T, 16, 25>(__VA_ARGS__); break;                     \
+        case 480: FN<T, 32, 15>(__VA_ARGS__); break;                     \
+        default: break;                                                  \
+    }
+
 // ---------------------------------------------------------------- twiddles, transpose
 template <typename T>
 __global__ void twiddle_fill(cx<T>* W, int n) {
@@ -374,8 +722,48 @@ __global__ void __launch_bounds__(256) transpose_kernel(const E* __restrict__ sr
     }
 }
 
+// Tall-and-narrow case (rows >> cols, cols <= 64): the channel-innermost (T, N) -> planar (N, T)
+// conversion.  A workgroup moves TR consecutive rows: one fully contiguous TR*cols read, cols
+// contiguous TR-element writes.  TALL=false is the mirror image (planar -> channel-innermost).
+template <typename E, bool TALL>
+__global__ void __launch_bounds__(256) transpose_narrow_kernel(const E* __restrict__ src, E* __restrict__ dst,
+                                                              int nlong, int nshort, int TR) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    E* tile = reinterpret_cast<E*>(smem);  // [TR][nshort + 1]
+    const size_t base = (size_t)blockIdx.y * nlong * nshort;
+    const int l0 = blockIdx.x * TR;
+    const int nl = min(TR, nlong - l0);
+    const int pitch = nshort + 1;
+    if (TALL) {
+        // src[(l0 + i) * nshort + c] contiguous in (i, c); dst[c * nlong + l0 + i]
+        const E* s = src + base + (size_t)l0 * nshort;
+        for (int e = threadIdx.x; e < nl * nshort; e += 256) {
+            const int i = e / nshort, c = e - i * nshort;
+            tile[i * pitch + c] = s[e];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nl * nshort; e += 256) {
+            const int c = e / nl, i = e - c * nl;
+            dst[base + (size_t)c * nlong + l0 + i] = tile[i * pitch + c];
+        }
+    } else {
+        // src[c * nlong + l0 + i]; dst[(l0 + i) * nshort + c] contiguous in (i, c)
+        for (int e = threadIdx.x; e < nl * nshort; e += 256) {
+            const int c = e / nl, i = e - c * nl;
+            tile[i * pitch + c] = src[base + (size_t)c * nlong + l0 + i];
+        }
+        __syncthreads();
+        E* d = dst + base + (size_t)l0 * nshort;
+        for (int e = threadIdx.x; e < nl * nshort; e += 256) {
+            const int i = e / nshort, c = e - i * nshort;
+            d[e] = tile[i * pitch + c];
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host-side planning
 static int g_max_single = 0;
+static int g_fast_enabled = 1;
 
 static bool factorize(int n, Rad& rad) {
     rad.n = 0;
@@ -446,23 +834,48 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
     a.L1P = p.L1 | 1; a.L2P = p.L2 | 1;
     a.rad1 = p.rad1; a.rad2 = p.rad2;
     if (nsig <= 0) return FL_OK;
+    const bool use_fast = g_fast_enabled && p.L1 > 1 && fast_split(p.L1) && fast_split(p.L2);
     if (p.L1 > 1) {
         FL_REQUIRE(a.scratch != nullptr, "two-pass FFT (nfft=%d) needs a scratch buffer", p.n);
-        int ct = (budget - p.L1) / (2 * a.L1P);
-        if (ct > 32) ct = 32;
-        FL_REQUIRE(ct >= 1, "column pass does not fit in LDS (L1=%d)", p.L1);
-        a.CT = ct;
-        a.ntiles = cdiv_i(p.L2, ct);
-        const size_t lds = (size_t)(2 * ct * a.L1P + p.L1) * esz;
+        if (use_fast) {
+            a.CT = FAST_CT;
+            a.ntiles = cdiv_i(p.L2, FAST_CT);
+            const size_t lds = (size_t)(FAST_CT * a.L1P + p.L1) * esz;
+            const size_t nblk = (size_t)a.ntiles * nsig;
+            FL_REQUIRE(nblk < (1ull << 31), "grid too large");
+            FL_FAST_DISPATCH(launch_cols_fast, p.L1, inverse, a, (unsigned)nblk, lds, st)
+            FL_CHECK_LAUNCH("fft_cols_fast");
+        } else {
+            int ct = (budget - p.L1) / (2 * a.L1P);
+            if (ct > 32) ct = 32;
+            FL_REQUIRE(ct >= 1, "column pass does not fit in LDS (L1=%d)", p.L1);
+            a.CT = ct;
+            a.ntiles = cdiv_i(p.L2, ct);
+            const size_t lds = (size_t)(2 * ct * a.L1P + p.L1) * esz;
+            const size_t nblk = (size_t)a.ntiles * nsig;
+            FL_REQUIRE(nblk < (1ull << 31), "grid too large");
+            if (inverse)
+                hipLaunchKernelGGL((fft_cols<T, LOAD_IRFFT_PRE, true>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            else
+                hipLaunchKernelGGL((fft_cols<T, LOAD_PACK, false>), dim3((unsigned)nblk), dim3(256), lds, st, a);
+            FL_CHECK_LAUNCH("fft_cols");
+        }
+    }
+    if (use_fast) {
+        const FastSplit* fs = fast_split(p.L2);
+        const int per = inverse ? 1 : 2;
+        a.per = per;
+        int rt = 256 / (per * fs->A);               // every stage-2 item gets its own thread
+        const int P = inverse ? p.L1 : (p.L1 / 2 + 1);
+        if (rt > P) rt = P;
+        a.RT = rt;
+        a.ntiles = cdiv_i(P, rt);
+        const size_t lds = (size_t)(per * rt * a.L2P + p.L2) * esz;
         const size_t nblk = (size_t)a.ntiles * nsig;
         FL_REQUIRE(nblk < (1ull << 31), "grid too large");
-        if (inverse)
-            hipLaunchKernelGGL((fft_cols<T, LOAD_IRFFT_PRE, true>), dim3((unsigned)nblk), dim3(256), lds, st, a);
-        else
-            hipLaunchKernelGGL((fft_cols<T, LOAD_PACK, false>), dim3((unsigned)nblk), dim3(256), lds, st, a);
-        FL_CHECK_LAUNCH("fft_cols");
-    }
-    {
+        FL_FAST_DISPATCH(launch_rows_fast, p.L2, inverse, a, (unsigned)nblk, lds, st)
+        FL_CHECK_LAUNCH("fft_rows_fast");
+    } else {
         const int per = (inverse || p.L1 == 1) ? 1 : 2;  // slots per primary row
         a.per = per;
         int rt = (budget - p.L2) / (2 * per * a.L2P);
@@ -573,6 +986,11 @@ int fl_debug_set_fft_max_single(int max_half_len) {
     return FL_OK;
 }
 
+int fl_debug_set_fft_fast(int enabled) {
+    g_fast_enabled = enabled != 0;
+    return FL_OK;
+}
+
 int fl_rfft_f32(const void* x, long xs, int t_in, void* X, void* scratch, const void* W, int nsig, int nfft,
                 double scale, double env_log2, int interior_x2, void* stream) {
     return rfft_impl<float>(x, xs, t_in, X, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
@@ -594,9 +1012,32 @@ int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, int
     FL_REQUIRE(src && dst, "transpose: null pointer");
     FL_REQUIRE(nbatch >= 0 && rows >= 0 && cols >= 0, "transpose: bad sizes");
     if (nbatch == 0 || rows == 0 || cols == 0) return FL_OK;
-    FL_REQUIRE(nbatch <= 65535 && cdiv_i(rows, 32) <= 65535, "transpose: batch/rows too large");
-    dim3 grid(cdiv_i(cols, 32), cdiv_i(rows, 32), nbatch);
+    FL_REQUIRE(nbatch <= 65535, "transpose: batch too large");
     hipStream_t st = (hipStream_t)stream;
+    const bool tall = cols <= 64 && rows >= 4 * cols, wide = rows <= 64 && cols >= 4 * rows;
+    if (tall || wide) {
+        const int nshort = tall ? cols : rows, nlong = tall ? rows : cols;
+        int TR = (32 * 1024) / ((nshort + 1) * elem_bytes);   // ~32 KB of LDS
+        if (TR > 2048) TR = 2048;
+        TR = (TR / 64) * 64;
+        if (TR < 64) TR = 64;
+        dim3 g2(cdiv_i(nlong, TR), nbatch);
+        const size_t lds = (size_t)TR * (nshort + 1) * elem_bytes;
+#define FL_TN(E) \
+        if (tall) hipLaunchKernelGGL((transpose_narrow_kernel<E, true>), g2, dim3(256), lds, st, (const E*)src, (E*)dst, nlong, nshort, TR); \
+        else hipLaunchKernelGGL((transpose_narrow_kernel<E, false>), g2, dim3(256), lds, st, (const E*)src, (E*)dst, nlong, nshort, TR)
+        switch (elem_bytes) {
+            case 4: FL_TN(uint32_t); break;
+            case 8: FL_TN(uint64_t); break;
+            case 16: FL_TN(uint4); break;
+            default: set_error("transpose: elem_bytes must be 4, 8 or 16"); return FL_ERR_BAD_ARG;
+        }
+#undef FL_TN
+        FL_CHECK_LAUNCH("transpose_narrow");
+        return FL_OK;
+    }
+    FL_REQUIRE(cdiv_i(rows, 32) <= 65535, "transpose: too many rows");
+    dim3 grid(cdiv_i(cols, 32), cdiv_i(rows, 32), nbatch);
     switch (elem_bytes) {
         case 4: hipLaunchKernelGGL((transpose_kernel<uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, rows, cols); break;
         case 8: hipLaunchKernelGGL((transpose_kernel<uint64_t>), grid, dim3(256), 0, st, (const uint64_t*)src, (uint64_t*)dst, rows, cols); break;

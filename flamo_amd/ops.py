@@ -489,8 +489,9 @@ class _Sos(torch.autograd.Function):
         H = torch.empty((*chan, m_local), dtype=_cdtype(real), device=dev)
         L = _lib.lib()
         fn = L.fl_sos_response_c64 if real == torch.float32 else L.fl_sos_response_c128
-        _lib.check(fn(bc.data_ptr(), ac.data_ptr(), S, C_, float(gamma), nfft, bin0, m_local, H.data_ptr(), _stream()),
-                   "sos_response")
+        Wd = twiddles(nfft, torch.float64, dev)
+        _lib.check(fn(bc.data_ptr(), ac.data_ptr(), S, C_, float(gamma), Wd.data_ptr(), nfft, bin0, m_local,
+                      H.data_ptr(), _stream()), "sos_response")
         ctx.save_for_backward(bc, ac)
         ctx.cfg = (float(gamma), nfft, S, C_, bin0, m_local, real)
         return H.movedim(-1, 0)
@@ -506,8 +507,9 @@ class _Sos(torch.autograd.Function):
         nblk = L.fl_sos_bwd_blocks(m_local)
         part = torch.zeros((nblk, 2, 3, S, C_), dtype=torch.float64, device=dev)
         fn = L.fl_sos_response_bwd_c64 if real == torch.float32 else L.fl_sos_response_bwd_c128
-        _lib.check(fn(g.data_ptr(), bc.data_ptr(), ac.data_ptr(), S, C_, gamma, nfft, bin0, m_local, part.data_ptr(),
-                      _stream()), "sos_response_bwd")
+        Wd = twiddles(nfft, torch.float64, dev)
+        _lib.check(fn(g.data_ptr(), bc.data_ptr(), ac.data_ptr(), S, C_, gamma, Wd.data_ptr(), nfft, bin0, m_local,
+                      part.data_ptr(), _stream()), "sos_response_bwd")
         tot = part.sum(dim=0)
         return tot[0].view(bc.shape), tot[1].view(ac.shape), None, None, None
 

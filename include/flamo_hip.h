@@ -62,6 +62,9 @@ int fl_fft_plan(int nfft, int is_f64, int* L1, int* L2);
 size_t fl_fft_scratch_elems(int nfft, int is_f64, int nsig);
 /* test hook: largest half-length handled in one pass (0 restores the default) */
 int fl_debug_set_fft_max_single(int max_half_len);
+/* test hook: 0 forces the generic Stockham kernels where the two-register-stage fast kernels
+ * would be chosen (default 1) */
+int fl_debug_set_fft_fast(int enabled);
 
 /* X[sig, k] = scale * w_k * sum_t x[sig, t] * e(t) * exp(-2 pi i k t / nfft),  k in [0, nfft/2]
  *   x: real, signal `sig` starts at x + sig*x_sig_stride and has t_in valid samples (zero
@@ -149,20 +152,21 @@ int fl_delay_response_c128(const int32_t* m, const void* amp, int C, const void*
  * (dsp.py:1520-1526, 2587-2593):  per channel c and bin k,
  *   B_s = b[0,s,c] + b[1,s,c] g w + b[2,s,c] g^2 w^2,  A_s likewise,  w = exp(-2 pi i k/nfft),
  *   H[c,k] = prod_s B_s / prod_s A_s, or eps where |prod A| == 0.
- * b, a: DOUBLE (3, S, C) contiguous whatever the precision of H (_c64 / _c128).  Evaluated directly (no (M,S,C) tensor is ever built), in
+ * b, a: DOUBLE (3, S, C) contiguous and Wd the FLOAT64 twiddle table (fl_twiddle_fill_f64)
+ * whatever the precision of H (_c64 / _c128).  Evaluated directly (no (M,S,C) tensor is ever built), in
  * double precision whatever the storage type: the shelving sections cancel to ~1e-5 of their
  * terms at low frequency, which float32 evaluation (the reference's float32 mode) cannot hold. */
-int fl_sos_response_c64(const void* b, const void* a, int S, int C, double gamma,
+int fl_sos_response_c64(const void* b, const void* a, int S, int C, double gamma, const void* Wd,
                         int nfft, int bin0, int m_local, void* H, void* stream);
-int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamma,
-                        int nfft, int bin0, int m_local, void* H, void* stream);
+int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamma, const void* Wd,
+                         int nfft, int bin0, int m_local, void* H, void* stream);
 /* Backward: partial sums over bins of dL/db, dL/da.  part: double (nblk, 2, 3, S, C) where
  * nblk = fl_sos_bwd_blocks(m_local); the caller sums over nblk. */
 int fl_sos_bwd_blocks(int m_local);
 int fl_sos_response_bwd_c64(const void* gH, const void* b, const void* a, int S, int C, double gamma,
-                            int nfft, int bin0, int m_local, void* part, void* stream);
+                            const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
 int fl_sos_response_bwd_c128(const void* gH, const void* b, const void* a, int S, int C, double gamma,
-                            int nfft, int bin0, int m_local, void* part, void* stream);
+                             const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
 
 /* ------------------------------------------------------------------ closed loop
  * Replace torch.linalg.solve(A, B) in system.Recursion.forward (system.py:420-425).
