@@ -29,20 +29,33 @@ __global__ void __launch_bounds__(256) delay_response_kernel(const int32_t* __re
 // frequencies b0 + b1 w + b2 w^2 cancels to ~1e-5 of its terms (shelving sections at 44 Hz), so
 // float32 evaluation -- what the reference's float32 mode does -- loses 3 digits there.  The
 // point w = exp(-2 pi i k / n) comes from the float64 master twiddle table.
+// stage the (3, S) taps of channel c of b and a into LDS: lb = [3][S], la = [3][S]
+__device__ inline void stage_taps(const double* __restrict__ b, const double* __restrict__ a, int S, int C, int c,
+                                  double* lb, double* la) {
+    for (int i = threadIdx.x; i < 3 * S; i += blockDim.x) {
+        lb[i] = b[(size_t)i * C + c];
+        la[i] = a[(size_t)i * C + c];
+    }
+    __syncthreads();
+}
+
 struct SosEval {
     cx<double> z1, z2;  // g*w, g^2*w^2
-    __device__ inline cx<double> poly(const double* co, int S, int C, int s, int c) const {
-        const double c0 = co[((size_t)0 * S + s) * C + c];
-        const double c1 = co[((size_t)1 * S + s) * C + c];
-        const double c2 = co[((size_t)2 * S + s) * C + c];
+    // co: this channel's taps staged in LDS as [3][S] (broadcast reads, no scalar-load latency)
+    __device__ inline cx<double> poly(const double* co, int S, int s) const {
+        const double c0 = co[s];
+        const double c1 = co[S + s];
+        const double c2 = co[2 * S + s];
         return cx<double>(c0 + c1 * z1.x + c2 * z2.x, c1 * z1.y + c2 * z2.y);
     }
 };
 
 __device__ inline SosEval sos_point(const cx<double>* __restrict__ Wd, int nfft, int k, double g) {
     SosEval e;
-    const cx<double> w1 = Wd[k % nfft];
-    const cx<double> w2 = Wd[(2 * (long long)k) % nfft];
+    // 0 <= k <= nfft/2 on this path, so the two indices reduce with a compare instead of a modulo
+    const int k2 = 2 * k;
+    const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
+    const cx<double> w2 = Wd[k2 < nfft ? k2 : k2 - nfft];
     e.z1 = cx<double>(g * w1.x, g * w1.y);
     e.z2 = cx<double>(g * g * w2.x, g * g * w2.y);
     return e;
@@ -56,14 +69,18 @@ template <typename T>
 __global__ void __launch_bounds__(256) sos_response_kernel(const double* __restrict__ b, const double* __restrict__ a, int S, int C,
                                                           double g, const cx<double>* __restrict__ Wd, int nfft,
                                                           int bin0, int m_local, cx<T>* __restrict__ H) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lb = reinterpret_cast<double*>(smem);
+    double* la = lb + 3 * S;
+    const int c = blockIdx.y;
+    stage_taps(b, a, S, C, c, lb, la);
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= m_local) return;
-    const int c = blockIdx.y;
     const SosEval e = sos_point(Wd, nfft, bin0 + f, g);
     cx<double> Bp(1, 0), Ap(1, 0);
     for (int s = 0; s < S; ++s) {
-        Bp = Bp * e.poly(b, S, C, s, c);
-        Ap = Ap * e.poly(a, S, C, s, c);
+        Bp = Bp * e.poly(lb, S, s);
+        Ap = Ap * e.poly(la, S, s);
     }
     cx<double> h = (Ap.x != 0 || Ap.y != 0) ? cdiv(Bp, Ap) : cx<double>((double)eps_of<T>(), 0);
     H[(size_t)c * m_local + f] = cx<T>((T)h.x, (T)h.y);
@@ -93,7 +110,11 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
                                                               const double* __restrict__ a, int S, int C, double g,
                                                               const cx<double>* __restrict__ Wd, int nfft, int bin0,
                                                               int m_local, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lb = reinterpret_cast<double*>(smem);
+    double* la = lb + 3 * S;
     const int c = blockIdx.y;
+    stage_taps(b, a, S, C, c, lb, la);
     const int s0 = blockIdx.z * SCH;
     double acc[2][3][SCH];
 #pragma unroll
@@ -107,8 +128,8 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
         const SosEval e = sos_point(Wd, nfft, bin0 + f, g);
         cx<double> Bp(1, 0), Ap(1, 0);
         for (int s = 0; s < S; ++s) {
-            Bp = Bp * e.poly(b, S, C, s, c);
-            Ap = Ap * e.poly(a, S, C, s, c);
+            Bp = Bp * e.poly(lb, S, s);
+            Ap = Ap * e.poly(la, S, s);
         }
         if (Ap.x == 0 && Ap.y == 0) continue;  // guarded bins are the constant eps: zero gradient
         const cx<double> h = cdiv_fast(Bp, Ap);
@@ -119,14 +140,14 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
         for (int q = 0; q < SCH; ++q) {
             const int s = s0 + q;
             if (s < S) {
-                const cx<double> Bs = e.poly(b, S, C, s, c), As = e.poly(a, S, C, s, c);
+                const cx<double> Bs = e.poly(lb, S, s), As = e.poly(la, S, s);
                 cx<double> tb;
                 if (Bs.x != 0 || Bs.y != 0) {
                     tb = cdiv_fast(gh, Bs);
                 } else {  // numerator section vanishes at this bin: product of the others
                     cx<double> o(1, 0);
                     for (int t = 0; t < S; ++t)
-                        if (t != s) o = o * e.poly(b, S, C, t, c);
+                        if (t != s) o = o * e.poly(lb, S, t);
                     tb = gc * cdiv_fast(o, Ap);
                 }
                 const cx<double> ta = cdiv_fast(gh, As);
@@ -164,9 +185,100 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
     }
 }
 
+// ---------------------------------------------------------------- graphic-equaliser design
+// Command gains (dB) -> second-order sections of the GEQ, all channel pairs at once, and the
+// backward of that map.  Restates flamo/auxiliary/eq.py:57-111 (geq) with
+// flamo/functional.py:555-675 (shelving_filter, peak_filter): band 0 flat gain, band 1 low
+// shelf, bands 2..nb-2 peaking (R = 2.7), band nb-1 high shelf.  The reference stores the
+// sections in float32 buffers even in float64 mode (dsp.py:2573-2585), so every coefficient is
+// rounded to float32 exactly where the reference rounds it; the band constants (tan/cos of the
+// float32 band frequencies) are supplied by the host.  consts layout (double):
+//   [t_lo, t_hi, t2_lo, t2_hi, st_lo, st_hi, pk_t[nb-3], pk_c[nb-3]]
+// One thread per (band, channel): ~1 KB of work replaces ~150 tiny elementwise launches per step.
+__device__ inline double f32r(double x) { return (double)(float)x; }
+
+__global__ void __launch_bounds__(256) geq_sections_kernel(const double* __restrict__ gain_db, int nb, int C,
+                                                          const double* __restrict__ k, double* __restrict__ b,
+                                                          double* __restrict__ a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nb * C) return;
+    const int band = idx / C;
+    const int st = nb * C;
+    const double g = pow(10.0, gain_db[idx] / 20.0);
+    double b0, b1, b2, a0, a1, a2;
+    if (band == 0) {
+        b0 = f32r(g); b1 = 0; b2 = 0; a0 = 1; a1 = 0; a2 = 0;
+    } else if (band == 1 || band == nb - 1) {
+        const int i = (band == 1) ? 0 : 1;
+        const double t2 = k[2 + i], stq = k[4 + i];
+        const double u = sqrt(g), q = pow(g, 0.25);
+        const double p0 = f32r(u * t2 + stq * q + 1), p1 = f32r(2 * u * t2 - 2), p2 = f32r(u * t2 - stq * q + 1);
+        const double d0 = f32r(u + stq * q + t2), d1 = f32r(2 * t2 - 2 * u), d2 = f32r(u - stq * q + t2);
+        const float uf = (float)u, gf = (float)g;
+        const float s0 = uf * (float)p0, s1 = uf * (float)p1, s2 = uf * (float)p2;   // float32 products
+        if (band == 1) {
+            b0 = s0; b1 = s1; b2 = s2; a0 = d0; a1 = d1; a2 = d2;
+        } else {
+            b0 = (float)d0 * gf; b1 = (float)d1 * gf; b2 = (float)d2 * gf; a0 = s0; a1 = s1; a2 = s2;
+        }
+    } else {
+        const int np = nb - 3;
+        const double t = k[6 + band - 2], c = k[6 + np + band - 2];
+        const double sg = sqrt(g);
+        b0 = f32r(sg + g * t); b1 = f32r(-2 * sg * c); b2 = f32r(sg - g * t);
+        a0 = f32r(sg + t); a1 = b1; a2 = f32r(sg - t);
+    }
+    b[idx] = b0; b[idx + st] = b1; b[idx + 2 * st] = b2;
+    a[idx] = a0; a[idx + st] = a1; a[idx + 2 * st] = a2;
+}
+
+__global__ void __launch_bounds__(256) geq_sections_bwd_kernel(const double* __restrict__ gain_db,
+                                                              const double* __restrict__ gb,
+                                                              const double* __restrict__ ga, int nb, int C,
+                                                              const double* __restrict__ k,
+                                                              double* __restrict__ ggain) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nb * C) return;
+    const int band = idx / C;
+    const int st = nb * C;
+    const double g = pow(10.0, gain_db[idx] / 20.0);
+    const double B0 = gb[idx], B1 = gb[idx + st], B2 = gb[idx + 2 * st];
+    const double A0 = ga[idx], A1 = ga[idx + st], A2 = ga[idx + 2 * st];
+    double dg;  // dL/dg
+    if (band == 0) {
+        dg = B0;
+    } else if (band == 1 || band == nb - 1) {
+        const int i = (band == 1) ? 0 : 1;
+        const double t2 = k[2 + i], stq = k[4 + i];
+        const double u = sqrt(g), q = pow(g, 0.25);
+        const double du = 0.5 / u, dq = 0.25 * q / g;
+        const double p0 = u * t2 + stq * q + 1, p1 = 2 * u * t2 - 2, p2 = u * t2 - stq * q + 1;
+        const double d0 = u + stq * q + t2, d1 = 2 * t2 - 2 * u, d2 = u - stq * q + t2;
+        const double dp0 = t2 * du + stq * dq, dp1 = 2 * t2 * du, dp2 = t2 * du - stq * dq;
+        const double dd0 = du + stq * dq, dd1 = -2 * du, dd2 = du - stq * dq;
+        // s = u * p (scaled numerator-form), d = denominator-form
+        const double ds0 = du * p0 + u * dp0, ds1 = du * p1 + u * dp1, ds2 = du * p2 + u * dp2;
+        if (band == 1) {
+            dg = B0 * ds0 + B1 * ds1 + B2 * ds2 + A0 * dd0 + A1 * dd1 + A2 * dd2;
+        } else {   // b = d * g, a = s
+            dg = B0 * (d0 + g * dd0) + B1 * (d1 + g * dd1) + B2 * (d2 + g * dd2) + A0 * ds0 + A1 * ds1 + A2 * ds2;
+        }
+    } else {
+        const int np = nb - 3;
+        const double t = k[6 + band - 2], c = k[6 + np + band - 2];
+        const double dsg = 0.5 / sqrt(g);
+        dg = B0 * (dsg + t) + B1 * (-2 * c * dsg) + B2 * (dsg - t) + A0 * dsg + A1 * (-2 * c * dsg) + A2 * dsg;
+    }
+    ggain[idx] = dg * g * (2.302585092994045684 / 20.0);   // dg/dgain_db = g ln(10) / 20
+}
+
+static int g_sos_chunk = 0;
+static int g_sos_blocks = 0;
+
 static int sos_blocks(int m_local) {
     int nb = cdiv_i(m_local, 256);
-    if (nb > 64) nb = 64;
+    const int cap = g_sos_blocks > 0 ? g_sos_blocks : 16;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return nb;
 }
@@ -188,10 +300,10 @@ template <typename T>
 static int sos_impl(const void* b, const void* a, int S, int C, double gamma, const void* Wd, int nfft, int bin0,
                     int m_local, void* H, void* stream) {
     FL_REQUIRE(b && a && H && Wd, "sos_response: null pointer");
-    FL_REQUIRE(S > 0 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local >= 0, "sos_response: bad sizes");
+    FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local >= 0, "sos_response: bad sizes");
     if (m_local == 0) return FL_OK;
     dim3 grid(cdiv_i(m_local, 256), C);
-    hipLaunchKernelGGL((sos_response_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const double*)b, (const double*)a, S, C,
+    hipLaunchKernelGGL((sos_response_kernel<T>), grid, dim3(256), (size_t)6 * S * sizeof(double), (hipStream_t)stream, (const double*)b, (const double*)a, S, C,
                        gamma, (const cx<double>*)Wd, nfft, bin0, m_local, (cx<T>*)H);
     FL_CHECK_LAUNCH("sos_response");
     return FL_OK;
@@ -201,15 +313,22 @@ template <typename T>
 static int sos_bwd_impl(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* Wd,
                         int nfft, int bin0, int m_local, void* part, void* stream) {
     FL_REQUIRE(gH && b && a && part && Wd, "sos_response_bwd: null pointer");
-    FL_REQUIRE(S > 0 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local > 0, "sos_response_bwd: bad sizes");
-    if (S > 4) {
-        dim3 grid(sos_blocks(m_local), C, cdiv_i(S, 12));
-        hipLaunchKernelGGL((sos_response_bwd_kernel<T, 12>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)gH,
-                           (const double*)b, (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0, m_local,
-                           (double*)part);
-    } else {
+    FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local > 0, "sos_response_bwd: bad sizes");
+    const int sch = g_sos_chunk > 0 ? g_sos_chunk : 6;
+#define FL_SOS_BWD(SC)                                                                                              \
+    {                                                                                                               \
+        dim3 grid(sos_blocks(m_local), C, cdiv_i(S, SC));                                                           \
+        hipLaunchKernelGGL((sos_response_bwd_kernel<T, SC>), grid, dim3(256), (size_t)6 * S * sizeof(double),      \
+                           (hipStream_t)stream, (const cx<T>*)gH, (const double*)b, (const double*)a, S, C, gamma, \
+                           (const cx<double>*)Wd, nfft, bin0, m_local, (double*)part);                              \
+    }
+    if (S > 4 && sch == 12) FL_SOS_BWD(12)
+    else if (S > 4 && sch == 6) FL_SOS_BWD(6)
+    else if (S > 4 && sch == 3) FL_SOS_BWD(3)
+    else if (S > 4) FL_SOS_BWD(4)
+    else {
         dim3 grid(sos_blocks(m_local), C, 1);
-        hipLaunchKernelGGL((sos_response_bwd_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)gH,
+        hipLaunchKernelGGL((sos_response_bwd_kernel<T, 4>), grid, dim3(256), (size_t)6 * S * sizeof(double), (hipStream_t)stream, (const cx<T>*)gH,
                            (const double*)b, (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0, m_local,
                            (double*)part);
     }
@@ -239,6 +358,31 @@ int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamm
     return sos_impl<double>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, stream);
 }
 int fl_sos_bwd_blocks(int m_local) { return sos_blocks(m_local); }
+int fl_debug_set_sos_chunk(int sections_per_thread) {
+    g_sos_blocks = sections_per_thread / 100;      // hundreds digit(s): blocks per channel (0 = default)
+    sections_per_thread %= 100;
+    g_sos_chunk = sections_per_thread;
+    return FL_OK;
+}
+
+int fl_geq_sections(const void* gain_db, int nb, int C, const void* consts, void* b, void* a, void* stream) {
+    FL_REQUIRE(gain_db && consts && b && a, "geq_sections: null pointer");
+    FL_REQUIRE(nb >= 4 && C > 0, "geq_sections: need >= 4 bands (gain, two shelves, one peak) and C > 0");
+    hipLaunchKernelGGL(geq_sections_kernel, dim3(cdiv_i((long)nb * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)gain_db, nb, C, (const double*)consts, (double*)b, (double*)a);
+    FL_CHECK_LAUNCH("geq_sections");
+    return FL_OK;
+}
+int fl_geq_sections_bwd(const void* gain_db, const void* gb, const void* ga, int nb, int C, const void* consts,
+                        void* ggain, void* stream) {
+    FL_REQUIRE(gain_db && gb && ga && consts && ggain, "geq_sections_bwd: null pointer");
+    FL_REQUIRE(nb >= 4 && C > 0, "geq_sections_bwd: bad sizes");
+    hipLaunchKernelGGL(geq_sections_bwd_kernel, dim3(cdiv_i((long)nb * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const double*)gain_db, (const double*)gb, (const double*)ga, nb, C, (const double*)consts,
+                       (double*)ggain);
+    FL_CHECK_LAUNCH("geq_sections_bwd");
+    return FL_OK;
+}
 int fl_sos_response_bwd_c64(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* Wd,
                             int nfft, int bin0, int m_local, void* part, void* stream) {
     return sos_bwd_impl<float>(gH, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);

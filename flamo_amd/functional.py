@@ -184,6 +184,14 @@ class GEQDesign:
         self.pk_c = torch.cos(wc).double()
         self._dev = {}
 
+    def device_consts(self, device) -> torch.Tensor:
+        """[t_lo, t_hi, t2_lo, t2_hi, st_lo, st_hi, pk_t..., pk_c...] as one float64 device tensor
+        (argument of the fused HIP kernel ``ops.geq_sections``)."""
+        key = ("flat", str(device))
+        if key not in self._dev:
+            self._dev[key] = torch.cat([self.sh_t, self.sh_t2, self.sh_st, self.pk_t, self.pk_c]).to(device)
+        return self._dev[key]
+
     def _consts(self, device):
         key = str(device)
         if key not in self._dev:

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["rfft", "irfft", "mimo", "solve", "delay_response", "sos_response", "to_planar", "set_bin_shard",
+__all__ = ["rfft", "irfft", "mimo", "solve", "delay_response", "sos_response", "geq_sections", "to_planar", "set_bin_shard",
            "bin_shard"]
 
 
@@ -333,7 +333,7 @@ def _mimo_launch(H, per_bin, diag, conj_t, X):
     Y = _empty_planar((B, M, No, *X.shape[3:]), X.dtype, X.device)
     _, _, _, _, ys_b, ys_m, ys_k = _bnk(Y)
     fn = L.fl_mimo_c64 if real == torch.float32 else L.fl_mimo_c128
-    tag = ("mimo_bin" if per_bin else "mimo_const") + ("_adj" if conj_t else "_fwd")
+    tag = ("mimo_bin" if per_bin else "mimo_const") + ("_adj" if conj_t else "_fwd") + f"[cols={B * K},{No}x{Ni}]"
     with kernel_timer.span(tag):
         _lib.check(fn(H.data_ptr(), hs_f, hs_m, hs_n, int(conj_t), X.data_ptr(), xs_b, xs_n, xs_k, Y.data_ptr(), ys_b,
                       ys_m, ys_k, B, M, No, Ni, K, _stream()), "mimo")
@@ -512,6 +512,41 @@ class _Sos(torch.autograd.Function):
                       part.data_ptr(), _stream()), "sos_response_bwd")
         tot = part.sum(dim=0)
         return tot[0].view(bc.shape), tot[1].view(ac.shape), None, None, None
+
+
+class _GeqSections(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gain_db, consts):
+        dev = _require_gpu(gain_db, consts)
+        gd = gain_db.to(torch.float64).contiguous()
+        nb = gd.shape[0]
+        chan = tuple(gd.shape[1:])
+        C_ = max(_prod(chan), 1)
+        b = torch.empty((3, nb, *chan), dtype=torch.float64, device=dev)
+        a = torch.empty_like(b)
+        _lib.check(_lib.lib().fl_geq_sections(gd.data_ptr(), nb, C_, consts.data_ptr(), b.data_ptr(), a.data_ptr(),
+                                              _stream()), "geq_sections")
+        ctx.save_for_backward(gd, consts)
+        ctx.in_dtype = gain_db.dtype
+        return b, a
+
+    @staticmethod
+    def backward(ctx, gb, ga):
+        gd, consts = ctx.saved_tensors
+        nb = gd.shape[0]
+        C_ = max(_prod(gd.shape[1:]), 1)
+        out = torch.empty_like(gd)
+        gb = torch.zeros_like(gd.new_empty((3, *gd.shape))) if gb is None else gb.to(torch.float64).contiguous()
+        ga = torch.zeros_like(gb) if ga is None else ga.to(torch.float64).contiguous()
+        _lib.check(_lib.lib().fl_geq_sections_bwd(gd.data_ptr(), gb.data_ptr(), ga.data_ptr(), nb, C_, consts.data_ptr(),
+                                                  out.data_ptr(), _stream()), "geq_sections_bwd")
+        return out.to(ctx.in_dtype), None
+
+
+def geq_sections(gain_db: torch.Tensor, consts: torch.Tensor):
+    """Command gains in dB (n_bands, ...) -> (b, a), each (3, n_bands, ...) float64 tensors holding
+    the float32-rounded sections of the graphic equaliser (one fused kernel each way)."""
+    return _GeqSections.apply(gain_db, consts)
 
 
 def sos_response(b: torch.Tensor, a: torch.Tensor, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:

@@ -177,6 +177,26 @@ class DSP(nn.Module):
     def _gamma_on(self, t: torch.Tensor) -> torch.Tensor:
         return self.gamma.to(device=t.device)
 
+    # ---- protocol used by system.Series to fold adjacent per-bin modules into one pass
+    def _bin_response(self, param):
+        """(H, diag) such that forward(x) == ops.mimo(H, x, diag), or None if this module is not a
+        plain per-bin product (or its freq_convolve was replaced by the user)."""
+        return None
+
+    def _fusable(self) -> bool:
+        return getattr(self, "_own_convolve", None) is not None and self.freq_convolve is self._own_convolve
+
+    def _response_for_fusion(self, shape, ext_param):
+        """Same checks and side effects as forward() (shape check, ext_param logging), but returns
+        the response instead of applying it."""
+        from types import SimpleNamespace
+        self.check_input_shape(SimpleNamespace(shape=tuple(shape)))
+        if ext_param is None:
+            return self._bin_response(self.param)
+        with torch.no_grad():
+            self.assign_value(ext_param)
+        return self._bin_response(ext_param)
+
 
 # ============================================================================ gains / matrices
 class Gain(DSP):
@@ -203,6 +223,10 @@ class Gain(DSP):
 
     def get_freq_convolve(self):
         self.freq_convolve = lambda x, param: ops.mimo(to_complex(self.map(param)), x, diag=self._diag)
+        self._own_convolve = self.freq_convolve
+
+    def _bin_response(self, param):
+        return to_complex(self.map(param)), self._diag
 
     def initialize_class(self):
         self.check_param_shape()
@@ -283,6 +307,12 @@ class HouseholderMatrix(Gain):
         super().__init__(size=(size[0], 1), nfft=nfft, map=unit, requires_grad=requires_grad,
                          alias_decay_db=alias_decay_db, device=device, dtype=dtype)
 
+    def _bin_response(self, param):
+        return None
+
+    def _fusable(self) -> bool:
+        return False
+
     def forward(self, x, ext_param=None):
         self.check_input_shape(x)
         if ext_param is None:
@@ -339,6 +369,10 @@ class Filter(DSP):
 
     def get_freq_convolve(self):
         self.freq_convolve = lambda x, param: ops.mimo(self.freq_response(param), x, diag=self._diag)
+        self._own_convolve = self.freq_convolve
+
+    def _bin_response(self, param):
+        return self.freq_response(param), self._diag
 
     def initialize_class(self):
         self.check_param_shape()
@@ -512,7 +546,9 @@ class GEQ(_SOSMixin, Filter):
     def _sos_coeffs(self, gain_db):
         """command gains in dB -> float32 SOS (b, a) for every channel pair at once; the
         reference loops over pairs in Python calling eq.geq (dsp.py:2573-2585)."""
-        return self._design.sections(gain_db)
+        if gain_db.is_cuda:
+            return ops.geq_sections(gain_db, self._design.device_consts(gain_db.device))
+        return self._design.sections(gain_db)      # host-side evaluation (inspection on CPU tensors)
 
 
 class parallelGEQ(GEQ):
@@ -600,6 +636,10 @@ class Delay(DSP):
 
     def get_freq_convolve(self):
         self.freq_convolve = lambda x, param: ops.mimo(self.freq_response(param), x, diag=self._diag)
+        self._own_convolve = self.freq_convolve
+
+    def _bin_response(self, param):
+        return self.freq_response(param), self._diag
 
     def initialize_class(self):
         self.check_param_shape()

@@ -22,6 +22,39 @@ from ..functional import signal_gallery
 from .dsp import FFT, Transform, iFFT
 
 
+# Series-level fusion: adjacent per-bin products H_k ... H_2 H_1 X are evaluated as (H_k ... H_1) X --
+# the small (N_out x N_in) responses are multiplied per bin ONCE, then the (B, M, N) signal makes a
+# single pass through HBM instead of one per module (and one gradient pass instead of two per
+# module on the way back).  Results are identical up to floating-point reassociation.
+FUSE_SERIES = True
+FUSE_MIN_COLUMNS = 4   # batch x trailing columns below which folding does not pay
+
+
+def _as_signal(H: torch.Tensor, diag: bool, M: int) -> torch.Tensor:
+    """Response (const or per-bin, diagonal or full) -> matrix-valued signal (1, M, N_out, N_in)."""
+    if diag:
+        H = torch.diag_embed(H)
+    if H.dim() == 2:
+        H = H.unsqueeze(0).expand(M, *H.shape)
+    return H.unsqueeze(0)
+
+
+def _compose(acc, nxt, M: int):
+    """(H2, diag2) after (H1, diag1): the response of the cascade."""
+    H1, d1 = acc
+    H2, d2 = nxt
+    if H1.dtype != H2.dtype:
+        cd = torch.promote_types(H1.dtype, H2.dtype)
+        H1, H2 = H1.to(cd), H2.to(cd)
+    if d1 and d2:
+        return H2 * H1, True                      # (M,N)*(N,), (N,)*(N,), ... broadcast
+    if H1.dim() == (1 if d1 else 2) and H2.dim() == (1 if d2 else 2):   # both frequency independent
+        A = torch.diag_embed(H2) if d2 else H2
+        Bm = torch.diag_embed(H1) if d1 else H1
+        return A @ Bm, False
+    return ops.mimo(H2, _as_signal(H1, d1, M), diag=d2)[0], False
+
+
 def _common_attribute(modules, attr, what="Series"):
     """Value of `attr` shared by all modules that have it (None + warning if nobody has it)."""
     value = None
@@ -131,13 +164,41 @@ class Series(nn.Sequential):
         return first.input_channels, prev_out
 
     def forward(self, input, ext_param=None):
-        if ext_param is None:
-            for module in self:
+        items = list(self._modules.items())
+        i = 0
+        while i < len(items):
+            key, module = items[i]
+            j = i
+            if FUSE_SERIES and torch.is_tensor(input) and input.is_complex() and input.is_cuda and input.dim() >= 3:
+                cols = input.shape[0]
+                for d in input.shape[3:]:
+                    cols *= d
+                if cols >= FUSE_MIN_COLUMNS:
+                    while j < len(items) and hasattr(items[j][1], "_fusable") and items[j][1]._fusable():
+                        j += 1
+            if j - i >= 2:
+                input = self.__fused(items[i:j], input, ext_param)
+                i = j
+                continue
+            if ext_param is not None and key in ext_param:
+                input = module(input, ext_param[key])
+            else:
                 input = module(input)
-            return input
-        for key, module in self._modules.items():
-            input = module(input, ext_param[key]) if key in ext_param else module(input)
+            i += 1
         return input
+
+    @staticmethod
+    def __fused(run, x, ext_param):
+        """Apply a run of per-bin modules as one product with the cascade's response."""
+        M = x.shape[1]
+        shape = list(x.shape)
+        acc = None
+        for key, module in run:
+            ext = ext_param[key] if (ext_param is not None and key in ext_param) else None
+            resp = module._response_for_fusion(shape, ext)
+            shape[2] = module.output_channels
+            acc = resp if acc is None else _compose(acc, resp, M)
+        return ops.mimo(acc[0], x, diag=acc[1])
 
     def probe(self, z: torch.Tensor):
         H = None

@@ -163,10 +163,22 @@ int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamm
 /* Backward: partial sums over bins of dL/db, dL/da.  part: double (nblk, 2, 3, S, C) where
  * nblk = fl_sos_bwd_blocks(m_local); the caller sums over nblk. */
 int fl_sos_bwd_blocks(int m_local);
+/* tuning hook: sections whose sums one thread keeps in registers (12, 6, 4 or 3; 0 = default) */
+int fl_debug_set_sos_chunk(int sections_per_thread);
 int fl_sos_response_bwd_c64(const void* gH, const void* b, const void* a, int S, int C, double gamma,
                             const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
 int fl_sos_response_bwd_c128(const void* gH, const void* b, const void* a, int S, int C, double gamma,
                              const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
+
+/* Graphic-equaliser design: command gains in dB -> the float32-rounded second-order sections of
+ * GEQ / parallelGEQ for all C channel pairs at once (replaces the Python double loop over
+ * flamo/auxiliary/eq.py:57-111 `geq` in dsp.py:2573-2585, 2661-2672), and its backward.
+ *   gain_db: double (nb, C);  b, a: double (3, nb, C) holding float32-representable values;
+ *   consts: double [t_lo, t_hi, t2_lo, t2_hi, st_lo, st_hi, pk_t[nb-3], pk_c[nb-3]] -- tan/cos of
+ *   the float32 band frequencies as the host evaluates them (flamo/functional.py:555-675). */
+int fl_geq_sections(const void* gain_db, int nb, int C, const void* consts, void* b, void* a, void* stream);
+int fl_geq_sections_bwd(const void* gain_db, const void* gb, const void* ga, int nb, int C, const void* consts,
+                        void* ggain, void* stream);
 
 /* ------------------------------------------------------------------ closed loop
  * Replace torch.linalg.solve(A, B) in system.Recursion.forward (system.py:420-425).

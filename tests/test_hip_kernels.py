@@ -45,3 +45,68 @@ def test_mimo_shapes_against_einsum(gpu, No, Ni, K, B):
             h = torch.randn(M, Ni, dtype=cd, device=gpu)
             Yd = ops.mimo(h, X, diag=True)
             assert relerr(Yd.cpu(), torch.einsum("fn,bfn...->bfn...", h.cpu(), X.cpu())) < tol
+
+
+def test_geq_design_kernel_matches_host_formulas(gpu):
+    """Fused GEQ design kernel vs the vectorised host restatement (bit-exact up to pow() ulps) and
+    its analytic backward vs autograd."""
+    from flamo_amd import functional as F, ops
+    torch.manual_seed(5)
+    cf, sc = F.eq_freqs(1)
+    des = F.GEQDesign(cf, sc)
+    gdb = (torch.rand(12, 8, 8, dtype=torch.float64) * 24 - 12).requires_grad_(True)
+    b_ref, a_ref = des.sections(gdb)
+    gd = gdb.detach().to(gpu).requires_grad_(True)
+    b, a = ops.geq_sections(gd, des.device_consts(gpu))
+    assert b.shape == b_ref.shape and b.dtype == torch.float64
+    # float32-representable outputs, identical to the host evaluation except where a 1-ulp pow()
+    # difference flips a float32 rounding (rare)
+    assert torch.equal(b.float().double(), b) and torch.equal(a.float().double(), a)
+    mism = ((b.cpu() != b_ref.double()) | (a.cpu() != a_ref.double())).float().mean().item()
+    assert mism < 0.01
+    assert relerr(b.cpu(), b_ref.double()) < 2e-7 and relerr(a.cpu(), a_ref.double()) < 2e-7
+    cb, ca = torch.randn_like(b_ref, dtype=torch.float64), torch.randn_like(a_ref, dtype=torch.float64)
+    (g_ref,) = torch.autograd.grad((b_ref.double() * cb).sum() + (a_ref.double() * ca).sum(), [gdb])
+    (g,) = torch.autograd.grad((b * cb.to(gpu)).sum() + (a * ca.to(gpu)).sum(), [gd])
+    assert relerr(g.cpu(), g_ref) < 1e-6
+
+
+def test_series_fusion_matches_module_by_module(gpu):
+    """Folding adjacent per-bin modules into one pass (system.FUSE_SERIES) changes nothing but the
+    floating-point association: outputs and every gradient agree with the unfused evaluation."""
+    from collections import OrderedDict
+    from flamo_amd.processor import dsp, system
+    torch.manual_seed(3)
+    nfft, N, B = 480, 4, 6
+    for dt, tol in ((torch.float64, 1e-12), (torch.float32, 5e-6)):
+        kw = dict(nfft=nfft, alias_decay_db=30.0, device=gpu, dtype=dt)
+        mods = OrderedDict(
+            g=dsp.parallelGain(size=(N,), requires_grad=True, **kw),
+            d=dsp.parallelDelay(size=(N,), max_len=50, isint=True, **kw),
+            mix=dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw),
+            eq=dsp.GEQ(size=(3, N), requires_grad=True, **kw),
+            fir=dsp.parallelFilter(size=(5, 3), requires_grad=True, **kw),
+            out=dsp.Gain(size=(2, 3), requires_grad=True, **kw))
+        core = system.Series(mods)
+        model = system.Shell(core, dsp.FFT(nfft, dtype=dt), dsp.iFFTAntiAlias(nfft, alias_decay_db=30.0, device=gpu, dtype=dt))
+        x = torch.randn(B, nfft, N, device=gpu, dtype=dt, requires_grad=True)
+        params = [m.param for m in mods.values() if m.param.requires_grad]
+        res = {}
+        for fuse in (True, False):
+            system.FUSE_SERIES = fuse
+            try:
+                y = model(x)
+                res[fuse] = [y.detach()] + list(torch.autograd.grad((y ** 2).mean(), [x] + params))
+            finally:
+                system.FUSE_SERIES = True
+        for a, b in zip(res[True], res[False]):
+            assert relerr(a, b) < tol
+        # ext_param routing through a fused run still logs the external values into the module
+        ext = {"mix": torch.randn(N, N, device=gpu, dtype=dt)}
+        y1 = core(torch.randn(B, nfft // 2 + 1, N, device=gpu, dtype=CDT[dt]), ext)
+        assert torch.equal(mods["mix"].param.detach(), ext["mix"]) and y1.shape[2] == 2
+        with pytest.raises(ValueError):
+            core(torch.zeros(B, nfft // 2 + 1, N + 1, device=gpu, dtype=CDT[dt]))
+
+
+CDT = {torch.float64: torch.complex128, torch.float32: torch.complex64}
