@@ -349,7 +349,7 @@ class Filter(DSP):
         return self._run(x, ext_param)
 
     def check_input_shape(self, x):
-        if (int(self.nfft / 2 + 1), self.input_channels) != (x.shape[1], x.shape[2]):
+        if (ops.bin_shard(self.nfft)[1], self.input_channels) != (x.shape[1], x.shape[2]):
             raise ValueError(f"parameter shape not compatible with input signal of shape = ({x.shape}).")
 
     def check_param_shape(self):
@@ -363,7 +363,9 @@ class Filter(DSP):
             h = self.ir(param)
             n = torch.arange(0, h.shape[0], device=h.device, dtype=torch.float64)
             env = (self._gamma_f ** n).to(h.dtype).view(-1, *([1] * (h.dim() - 1)))
-            return self.fft(h * env)
+            H = self.fft(h * env)
+            bin0, m_local = ops.bin_shard(self.nfft)      # bin-sharded execution keeps the local range
+            return H if m_local == H.shape[0] else H[bin0:bin0 + m_local]
 
         self.freq_response = response
 
@@ -627,7 +629,7 @@ class Delay(DSP):
         self.freq_response = response
 
     def check_input_shape(self, x):
-        if (int(self.nfft / 2 + 1), self.input_channels) != (x.shape[1], x.shape[2]):
+        if (ops.bin_shard(self.nfft)[1], self.input_channels) != (x.shape[1], x.shape[2]):
             raise ValueError(
                 f"parameter shape = {self.param.shape} not compatible with input signal of shape = ({x.shape}).")
 
