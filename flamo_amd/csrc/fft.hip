@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(256) fft_cols_fast(FftArgs<T> a) {
 // pass 2 fast: rows of length LEN = A*B; nslots*A <= 256 so every thread owns at most one
 // stage-2 item and the natural-order result can be written back into the same LDS buffer.
 template <typename T, int A, int B, int LOAD, int EPI, bool INV>
-__global__ void __launch_bounds__(256) fft_rows_fast(FftArgs<T> a) {
+__global__ void __launch_bounds__(512) fft_rows_fast(FftArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LEN = A * B, LENP = LEN | 1;
     const int tile = blockIdx.x % a.ntiles, sig = blockIdx.x / a.ntiles;
@@ -558,9 +558,9 @@ __global__ void __launch_bounds__(256) fft_rows_fast(FftArgs<T> a) {
     cx<T>* U = reinterpret_cast<cx<T>*>(smem);    // [per*RT][LENP]
     cx<T>* tw = U + a.per * a.RT * LENP;
     const int twstep = a.n / LEN;
-    for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[j * twstep];
+    for (int j = threadIdx.x; j < LEN; j += blockDim.x) tw[j] = a.W[j * twstep];
     __syncthreads();
-    for (int item = threadIdx.x; item < nslots * B; item += 256) {
+    for (int item = threadIdx.x; item < nslots * B; item += blockDim.x) {
         const int sl = item / B, tb = item % B;
         int row;
         bool valid = true;
@@ -614,7 +614,7 @@ __global__ void __launch_bounds__(256) fft_rows_fast(FftArgs<T> a) {
         cx<T>* X = a.Xout + (size_t)sig * (a.L + 1);
         const T hs = (T)0.5 * a.scale;
         const T wi = a.interior ? (T)2 : (T)1;
-        for (int e = threadIdx.x; e < nr * LEN; e += 256) {
+        for (int e = threadIdx.x; e < nr * LEN; e += blockDim.x) {
             const int k2 = e / nr, i = e - k2 * nr;
             const int r = r0 + i;
             const int k = r + a.L1 * k2;
@@ -642,7 +642,7 @@ __global__ void __launch_bounds__(256) fft_rows_fast(FftArgs<T> a) {
         }
     } else {
         T* y = a.yr + (size_t)sig * a.yr_stride;
-        for (int e = threadIdx.x; e < nr * LEN; e += 256) {
+        for (int e = threadIdx.x; e < nr * LEN; e += blockDim.x) {
             const int k2 = e / nr, i = e - k2 * nr;
             const int j = (r0 + i) + a.L1 * k2;
             const cx<T> z = res[i * LENP + k2];
@@ -676,11 +676,11 @@ static void launch_cols_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, s
         hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_PACK, false>), dim3(nblk), dim3(256), lds, st, a);
 }
 template <typename T, int A, int B>
-static void launch_rows_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, size_t lds, hipStream_t st) {
+static void launch_rows_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, size_t lds, int nthreads, hipStream_t st) {
     if (inverse)
-        hipLaunchKernelGGL((fft_rows_fast<T, A, B, LOAD_SCRATCH, EPI_IRFFT_STORE, true>), dim3(nblk), dim3(256), lds, st, a);
+        hipLaunchKernelGGL((fft_rows_fast<T, A, B, LOAD_SCRATCH, EPI_IRFFT_STORE, true>), dim3(nblk), dim3(nthreads), lds, st, a);
     else
-        hipLaunchKernelGGL((fft_rows_fast<T, A, B, LOAD_SCRATCH, EPI_RFFT_POST, false>), dim3(nblk), dim3(256), lds, st, a);
+        hipLaunchKernelGGL((fft_rows_fast<T, A, B, LOAD_SCRATCH, EPI_RFFT_POST, false>), dim3(nblk), dim3(nthreads), lds, st, a);
 }
 
 #define FL_FAST_DISPATCH(FN, len, ...)                                   \
@@ -865,15 +865,22 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
         const FastSplit* fs = fast_split(p.L2);
         const int per = inverse ? 1 : 2;
         a.per = per;
-        int rt = 256 / (per * fs->A);               // every stage-2 item gets its own thread
+        // rows per workgroup: 16 (128-byte output segments in c64) if LDS allows, every stage-2
+        // item (slot, k_a) on its own thread of a 256- or 512-thread workgroup
         const int P = inverse ? p.L1 : (p.L1 / 2 + 1);
+        int rt = 512 / (per * fs->A);
+        const int lds_rows = (LDS_BUDGET / esz - p.L2) / (per * a.L2P);
+        if (rt > lds_rows) rt = lds_rows;
+        if (rt > 16) rt = 16;
         if (rt > P) rt = P;
+        FL_REQUIRE(rt >= 1, "row pass does not fit (L2=%d)", p.L2);
+        const int nthreads = (per * rt * fs->A > 256) ? 512 : 256;
         a.RT = rt;
         a.ntiles = cdiv_i(P, rt);
         const size_t lds = (size_t)(per * rt * a.L2P + p.L2) * esz;
         const size_t nblk = (size_t)a.ntiles * nsig;
         FL_REQUIRE(nblk < (1ull << 31), "grid too large");
-        FL_FAST_DISPATCH(launch_rows_fast, p.L2, inverse, a, (unsigned)nblk, lds, st)
+        FL_FAST_DISPATCH(launch_rows_fast, p.L2, inverse, a, (unsigned)nblk, lds, nthreads, st)
         FL_CHECK_LAUNCH("fft_rows_fast");
     } else {
         const int per = (inverse || p.L1 == 1) ? 1 : 2;  // slots per primary row

@@ -19,11 +19,18 @@ __global__ void __launch_bounds__(256) mimo_full_kernel(
     const cx<T>* __restrict__ H, long hs_f, long hs_m, long hs_n, int conj_h,
     const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
     cx<T>* __restrict__ Y, long ys_b, long ys_m, long ys_k,
-    int B, int M, int No, int Ni, int K) {
-    const int f = blockIdx.x * 256 + threadIdx.x;
+    int B, int M, int No, int Ni, int K, int nct, int nmt) {
+    // XCD-aware block order (block q runs on XCD q % 8, each XCD has its own L2): the blocks that
+    // share one bin tile -- all batch-column tiles and channel tiles, which re-read the same H[f]
+    // -- get consecutive slots on the SAME XCD, so H comes from HBM once and from that L2 after
+    // (measured: 369 MB -> 232 MB of fabric traffic per launch at config 2, algorithmic 221 MB).
+    const int inner = nct * nmt;
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int ft = (r / inner) * 8 + xcd, rem = r % inner;
+    const int f = ft * 256 + threadIdx.x;
     if (f >= M) return;
-    const int col0 = blockIdx.y * BT;
-    const int m0 = blockIdx.z * MT;
+    const int col0 = (rem % nct) * BT;
+    const int m0 = (rem / nct) * MT;
     const int ncols = B * K;
     long xoff[BT], yoff[BT];
     bool cv[BT];
@@ -140,18 +147,18 @@ __global__ void __launch_bounds__(256) mimo_gradh_diag_kernel(
 
 // ---------------------------------------------------------------- host dispatch
 template <typename T, int MT>
-static int launch_full_bt(int bt, dim3 grid, hipStream_t st, const cx<T>* H, long hs_f, long hs_m, long hs_n, int conj_h,
+static int launch_full_bt(int bt, dim3 grid, int nct, int nmt, hipStream_t st, const cx<T>* H, long hs_f, long hs_m, long hs_n, int conj_h,
                           const cx<T>* X, long xs_b, long xs_n, long xs_k, cx<T>* Y, long ys_b, long ys_m, long ys_k,
                           int B, int M, int No, int Ni, int K) {
     if (bt == 4)
         hipLaunchKernelGGL((mimo_full_kernel<T, MT, 4>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
-                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
     else if (bt == 2)
         hipLaunchKernelGGL((mimo_full_kernel<T, MT, 2>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
-                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
     else
         hipLaunchKernelGGL((mimo_full_kernel<T, MT, 1>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
-                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
     FL_CHECK_LAUNCH("mimo_full");
     return FL_OK;
 }
@@ -166,17 +173,19 @@ static int mimo_impl(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
     const int ncols = B * K;
     const int bt = ncols >= 4 ? 4 : (ncols >= 2 ? 2 : 1);
     const int mt = No >= 8 ? 8 : (No >= 4 ? 4 : (No >= 2 ? 2 : 1));
-    dim3 grid(cdiv_i(M, 256), cdiv_i(ncols, bt), cdiv_i(No, mt));
-    FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo: too many batch columns / channels for one launch");
+    const int nct = cdiv_i(ncols, bt), nmt = cdiv_i(No, mt);
+    const size_t nblk = (size_t)cdiv_i(cdiv_i(M, 256), 8) * 8 * nct * nmt;
+    FL_REQUIRE(nblk < (1ull << 31), "mimo: grid too large");
+    dim3 grid((unsigned)nblk);
     hipStream_t st = (hipStream_t)stream;
     const cx<T>* h = (const cx<T>*)H;
     const cx<T>* x = (const cx<T>*)X;
     cx<T>* y = (cx<T>*)Y;
     switch (mt) {
-        case 8: return launch_full_bt<T, 8>(bt, grid, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
-        case 4: return launch_full_bt<T, 4>(bt, grid, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
-        case 2: return launch_full_bt<T, 2>(bt, grid, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
-        default: return launch_full_bt<T, 1>(bt, grid, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+        case 8: return launch_full_bt<T, 8>(bt, grid, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+        case 4: return launch_full_bt<T, 4>(bt, grid, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+        case 2: return launch_full_bt<T, 2>(bt, grid, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+        default: return launch_full_bt<T, 1>(bt, grid, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
     }
 }
 
