@@ -31,31 +31,31 @@ _SIGNATURES = {
     "fl_fft_scratch_elems": (_sz, [_i, _i, _i]),
     "fl_debug_set_fft_max_single": (_i, [_i]),
     "fl_debug_set_fft_fast": (_i, [_i]),
-    "fl_rfft_f32": (_i, [_vp, _l, _i, _vp, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
-    "fl_rfft_f64": (_i, [_vp, _l, _i, _vp, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
-    "fl_irfft_f32": (_i, [_vp, _vp, _l, _i, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
-    "fl_irfft_f64": (_i, [_vp, _vp, _l, _i, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
-    "fl_transpose": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "fl_rfft_f32": (_i, [_vp, _l, _i, _vp, _l, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
+    "fl_rfft_f64": (_i, [_vp, _l, _i, _vp, _l, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
+    "fl_irfft_f32": (_i, [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
+    "fl_irfft_f64": (_i, [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
+    "fl_transpose": (_i, [_vp, _vp, _i, _i, _i, _l, _i, _vp]),
     "fl_mimo_c64": (_i, [_vp, _l, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _i, _vp]),
     "fl_mimo_c128": (_i, [_vp, _l, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _i, _vp]),
     "fl_mimo_diag_c64": (_i, [_vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_mimo_diag_c128": (_i, [_vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
-    "fl_mimo_gradh_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _d, _i, _i, _i, _i, _i, _vp]),
-    "fl_mimo_gradh_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _d, _i, _i, _i, _i, _i, _vp]),
-    "fl_mimo_gradh_diag_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _vp]),
-    "fl_mimo_gradh_diag_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _vp]),
-    "fl_delay_response_c64": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
-    "fl_delay_response_c128": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
-    "fl_sos_response_c64": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
-    "fl_sos_response_c128": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_mimo_gradh_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _d, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradh_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _d, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradh_diag_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradh_diag_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _i, _i, _i, _i, _vp]),
+    "fl_delay_response_c64": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _l, _vp]),
+    "fl_delay_response_c128": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _l, _vp]),
+    "fl_sos_response_c64": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _l, _vp]),
+    "fl_sos_response_c128": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _l, _vp]),
     "fl_sos_bwd_blocks": (_i, [_i]),
     "fl_debug_set_sos_chunk": (_i, [_i]),
-    "fl_sos_response_bwd_c64": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
-    "fl_sos_response_bwd_c128": (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_sos_response_bwd_c64": (_i, [_vp, _l, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_sos_response_bwd_c128": (_i, [_vp, _l, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
     "fl_geq_sections": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "fl_geq_sections_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
-    "fl_solve_c64": (_i, [_vp, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
-    "fl_solve_c128": (_i, [_vp, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
+    "fl_solve_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
+    "fl_solve_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -39,6 +39,7 @@ struct FftArgs {
     T* yr;              // EPI_IRFFT_STORE destination
     long yr_stride;
     int t_out;
+    long xc_stride;     // elements between consecutive signals of Xc / Xout (>= L+1)
     cx<T>* scratch;
     const cx<T>* W;     // W_n^j, j in [0,n)
     int n, L, L1, L2, L1P, L2P, CT, RT, ntiles;
@@ -210,7 +211,7 @@ __device__ inline cx<T> load_pack(const FftArgs<T>& a, int sig, int j) {
 //   Zf[j] = (X[j] + conj X[L-j]) + i conj(W_n^j) (X[j] - conj X[L-j])
 template <typename T>
 __device__ inline cx<T> load_irfft_pre(const FftArgs<T>& a, int sig, int j) {
-    const cx<T>* X = a.Xc + (size_t)sig * (a.L + 1);
+    const cx<T>* X = a.Xc + (size_t)sig * a.xc_stride;
     cx<T> xa = X[j], xb = X[a.L - j];
     if (j == 0) {  // DC and Nyquist: imaginary parts are ignored (C2R semantics)
         xa.y = 0;
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(256) fft_rows(FftArgs<T> a) {
 
     if (EPI == EPI_RFFT_POST) {
         // X[k] = 1/2 [ (Z[k] + conj Z[L-k]) - i W_n^k (Z[k] - conj Z[L-k]) ],  Z[L] := Z[0]
-        cx<T>* X = a.Xout + (size_t)sig * (a.L + 1);
+        cx<T>* X = a.Xout + (size_t)sig * a.xc_stride;
         const T hs = (T)0.5 * a.scale;
         const T wi = a.interior ? (T)2 : (T)1;
         for (int e = threadIdx.x; e < nr * a.L2; e += blockDim.x) {
@@ -611,7 +612,7 @@ __global__ void __launch_bounds__(512) fft_rows_fast(FftArgs<T> a) {
     }
     const cx<T>* res = U;
     if (EPI == EPI_RFFT_POST) {
-        cx<T>* X = a.Xout + (size_t)sig * (a.L + 1);
+        cx<T>* X = a.Xout + (size_t)sig * a.xc_stride;
         const T hs = (T)0.5 * a.scale;
         const T wi = a.interior ? (T)2 : (T)1;
         for (int e = threadIdx.x; e < nr * LEN; e += blockDim.x) {
@@ -706,9 +707,11 @@ __global__ void twiddle_fill(cx<T>* W, int n) {
 }
 
 template <typename E>
-__global__ void __launch_bounds__(256) transpose_kernel(const E* __restrict__ src, E* __restrict__ dst, int rows, int cols) {
+__global__ void __launch_bounds__(256) transpose_kernel(const E* __restrict__ src, E* __restrict__ dst, int rows, int cols,
+                                                        long pitch) {
     __shared__ E tile[32][33];
     const size_t base = (size_t)blockIdx.z * rows * cols;
+    const size_t dbase = (size_t)blockIdx.z * cols * pitch;
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int i = ty; i < 32; i += 8) {
@@ -718,7 +721,7 @@ __global__ void __launch_bounds__(256) transpose_kernel(const E* __restrict__ sr
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
-        if (r < rows && c < cols) dst[base + (size_t)c * rows + r] = tile[tx][i];
+        if (r < rows && c < cols) dst[dbase + (size_t)c * pitch + r] = tile[tx][i];
     }
 }
 
@@ -727,36 +730,36 @@ __global__ void __launch_bounds__(256) transpose_kernel(const E* __restrict__ sr
 // contiguous TR-element writes.  TALL=false is the mirror image (planar -> channel-innermost).
 template <typename E, bool TALL>
 __global__ void __launch_bounds__(256) transpose_narrow_kernel(const E* __restrict__ src, E* __restrict__ dst,
-                                                              int nlong, int nshort, int TR) {
+                                                              int nlong, int nshort, int TR, long pitch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     E* tile = reinterpret_cast<E*>(smem);  // [TR][nshort + 1]
     const size_t base = (size_t)blockIdx.y * nlong * nshort;
     const int l0 = blockIdx.x * TR;
     const int nl = min(TR, nlong - l0);
-    const int pitch = nshort + 1;
+    const int tpitch = nshort + 1;
     if (TALL) {
         // src[(l0 + i) * nshort + c] contiguous in (i, c); dst[c * nlong + l0 + i]
         const E* s = src + base + (size_t)l0 * nshort;
         for (int e = threadIdx.x; e < nl * nshort; e += 256) {
             const int i = e / nshort, c = e - i * nshort;
-            tile[i * pitch + c] = s[e];
+            tile[i * tpitch + c] = s[e];
         }
         __syncthreads();
         for (int e = threadIdx.x; e < nl * nshort; e += 256) {
             const int c = e / nl, i = e - c * nl;
-            dst[base + (size_t)c * nlong + l0 + i] = tile[i * pitch + c];
+            dst[(size_t)blockIdx.y * nshort * pitch + (size_t)c * pitch + l0 + i] = tile[i * tpitch + c];
         }
     } else {
         // src[c * nlong + l0 + i]; dst[(l0 + i) * nshort + c] contiguous in (i, c)
         for (int e = threadIdx.x; e < nl * nshort; e += 256) {
             const int c = e / nl, i = e - c * nl;
-            tile[i * pitch + c] = src[base + (size_t)c * nlong + l0 + i];
+            tile[i * tpitch + c] = src[base + (size_t)c * nlong + l0 + i];
         }
         __syncthreads();
         E* d = dst + base + (size_t)l0 * nshort;
         for (int e = threadIdx.x; e < nl * nshort; e += 256) {
             const int i = e / nshort, c = e - i * nshort;
-            d[e] = tile[i * pitch + c];
+            d[e] = tile[i * tpitch + c];
         }
     }
 }
@@ -912,8 +915,8 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
 }
 
 template <typename T>
-static int rfft_impl(const void* x, long x_sig_stride, int t_in, void* X, void* scratch, const void* W, int nsig,
-                     int nfft, double scale, double env_log2, int interior_x2, void* stream) {
+static int rfft_impl(const void* x, long x_sig_stride, int t_in, void* X, long X_sig_stride, void* scratch, const void* W,
+                     int nsig, int nfft, double scale, double env_log2, int interior_x2, void* stream) {
     Plan p;
     int rc = make_plan(nfft, sizeof(T) == 8, p);
     if (rc) return rc;
@@ -925,6 +928,8 @@ static int rfft_impl(const void* x, long x_sig_stride, int t_in, void* X, void* 
     a.xr_stride = x_sig_stride;
     a.t_in = t_in < nfft ? t_in : nfft;
     a.Xout = (cx<T>*)X;
+    FL_REQUIRE(X_sig_stride >= nfft / 2 + 1, "rfft: X_sig_stride must be >= nfft/2+1");
+    a.xc_stride = X_sig_stride;
     a.scratch = (cx<T>*)scratch;
     a.W = (const cx<T>*)W;
     a.scale = (T)scale;
@@ -934,8 +939,8 @@ static int rfft_impl(const void* x, long x_sig_stride, int t_in, void* X, void* 
 }
 
 template <typename T>
-static int irfft_impl(const void* X, void* y, long y_sig_stride, int t_out, void* scratch, const void* W, int nsig,
-                      int nfft, double scale, double env_log2, int interior_half, void* stream) {
+static int irfft_impl(const void* X, long X_sig_stride, void* y, long y_sig_stride, int t_out, void* scratch, const void* W,
+                      int nsig, int nfft, double scale, double env_log2, int interior_half, void* stream) {
     Plan p;
     int rc = make_plan(nfft, sizeof(T) == 8, p);
     if (rc) return rc;
@@ -944,6 +949,8 @@ static int irfft_impl(const void* X, void* y, long y_sig_stride, int t_out, void
     FL_REQUIRE(t_out >= 0 && t_out <= nfft && nsig >= 0, "irfft: t_out must be in [0, nfft]");
     FftArgs<T> a = {};
     a.Xc = (const cx<T>*)X;
+    FL_REQUIRE(X_sig_stride >= nfft / 2 + 1, "irfft: X_sig_stride must be >= nfft/2+1");
+    a.xc_stride = X_sig_stride;
     a.yr = (T*)y;
     a.yr_stride = y_sig_stride;
     a.t_out = t_out;
@@ -998,30 +1005,30 @@ int fl_debug_set_fft_fast(int enabled) {
     return FL_OK;
 }
 
-int fl_rfft_f32(const void* x, long xs, int t_in, void* X, void* scratch, const void* W, int nsig, int nfft,
+int fl_rfft_f32(const void* x, long xs, int t_in, void* X, long Xs, void* scratch, const void* W, int nsig, int nfft,
                 double scale, double env_log2, int interior_x2, void* stream) {
-    return rfft_impl<float>(x, xs, t_in, X, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
+    return rfft_impl<float>(x, xs, t_in, X, Xs, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
 }
-int fl_rfft_f64(const void* x, long xs, int t_in, void* X, void* scratch, const void* W, int nsig, int nfft,
+int fl_rfft_f64(const void* x, long xs, int t_in, void* X, long Xs, void* scratch, const void* W, int nsig, int nfft,
                 double scale, double env_log2, int interior_x2, void* stream) {
-    return rfft_impl<double>(x, xs, t_in, X, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
+    return rfft_impl<double>(x, xs, t_in, X, Xs, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
 }
-int fl_irfft_f32(const void* X, void* y, long ys, int t_out, void* scratch, const void* W, int nsig, int nfft,
+int fl_irfft_f32(const void* X, long Xs, void* y, long ys, int t_out, void* scratch, const void* W, int nsig, int nfft,
                  double scale, double env_log2, int interior_half, void* stream) {
-    return irfft_impl<float>(X, y, ys, t_out, scratch, W, nsig, nfft, scale, env_log2, interior_half, stream);
+    return irfft_impl<float>(X, Xs, y, ys, t_out, scratch, W, nsig, nfft, scale, env_log2, interior_half, stream);
 }
-int fl_irfft_f64(const void* X, void* y, long ys, int t_out, void* scratch, const void* W, int nsig, int nfft,
+int fl_irfft_f64(const void* X, long Xs, void* y, long ys, int t_out, void* scratch, const void* W, int nsig, int nfft,
                  double scale, double env_log2, int interior_half, void* stream) {
-    return irfft_impl<double>(X, y, ys, t_out, scratch, W, nsig, nfft, scale, env_log2, interior_half, stream);
+    return irfft_impl<double>(X, Xs, y, ys, t_out, scratch, W, nsig, nfft, scale, env_log2, interior_half, stream);
 }
 
-int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, int elem_bytes, void* stream) {
+int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, long dst_pitch, int elem_bytes, void* stream) {
     FL_REQUIRE(src && dst, "transpose: null pointer");
-    FL_REQUIRE(nbatch >= 0 && rows >= 0 && cols >= 0, "transpose: bad sizes");
+    FL_REQUIRE(nbatch >= 0 && rows >= 0 && cols >= 0 && dst_pitch >= rows, "transpose: bad sizes (dst_pitch >= rows)");
     if (nbatch == 0 || rows == 0 || cols == 0) return FL_OK;
     FL_REQUIRE(nbatch <= 65535, "transpose: batch too large");
     hipStream_t st = (hipStream_t)stream;
-    const bool tall = cols <= 64 && rows >= 4 * cols, wide = rows <= 64 && cols >= 4 * rows;
+    const bool tall = cols <= 64 && rows >= 4 * cols, wide = rows <= 64 && cols >= 4 * rows && dst_pitch == rows;
     if (tall || wide) {
         const int nshort = tall ? cols : rows, nlong = tall ? rows : cols;
         int TR = (32 * 1024) / ((nshort + 1) * elem_bytes);   // ~32 KB of LDS
@@ -1031,8 +1038,8 @@ int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, int
         dim3 g2(cdiv_i(nlong, TR), nbatch);
         const size_t lds = (size_t)TR * (nshort + 1) * elem_bytes;
 #define FL_TN(E) \
-        if (tall) hipLaunchKernelGGL((transpose_narrow_kernel<E, true>), g2, dim3(256), lds, st, (const E*)src, (E*)dst, nlong, nshort, TR); \
-        else hipLaunchKernelGGL((transpose_narrow_kernel<E, false>), g2, dim3(256), lds, st, (const E*)src, (E*)dst, nlong, nshort, TR)
+        if (tall) hipLaunchKernelGGL((transpose_narrow_kernel<E, true>), g2, dim3(256), lds, st, (const E*)src, (E*)dst, nlong, nshort, TR, dst_pitch); \
+        else hipLaunchKernelGGL((transpose_narrow_kernel<E, false>), g2, dim3(256), lds, st, (const E*)src, (E*)dst, nlong, nshort, TR, dst_pitch)
         switch (elem_bytes) {
             case 4: FL_TN(uint32_t); break;
             case 8: FL_TN(uint64_t); break;
@@ -1046,9 +1053,9 @@ int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, int
     FL_REQUIRE(cdiv_i(rows, 32) <= 65535, "transpose: too many rows");
     dim3 grid(cdiv_i(cols, 32), cdiv_i(rows, 32), nbatch);
     switch (elem_bytes) {
-        case 4: hipLaunchKernelGGL((transpose_kernel<uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, rows, cols); break;
-        case 8: hipLaunchKernelGGL((transpose_kernel<uint64_t>), grid, dim3(256), 0, st, (const uint64_t*)src, (uint64_t*)dst, rows, cols); break;
-        case 16: hipLaunchKernelGGL((transpose_kernel<uint4>), grid, dim3(256), 0, st, (const uint4*)src, (uint4*)dst, rows, cols); break;
+        case 4: hipLaunchKernelGGL((transpose_kernel<uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, rows, cols, dst_pitch); break;
+        case 8: hipLaunchKernelGGL((transpose_kernel<uint64_t>), grid, dim3(256), 0, st, (const uint64_t*)src, (uint64_t*)dst, rows, cols, dst_pitch); break;
+        case 16: hipLaunchKernelGGL((transpose_kernel<uint4>), grid, dim3(256), 0, st, (const uint4*)src, (uint4*)dst, rows, cols, dst_pitch); break;
         default: set_error("transpose: elem_bytes must be 4, 8 or 16"); return FL_ERR_BAD_ARG;
     }
     FL_CHECK_LAUNCH("transpose");

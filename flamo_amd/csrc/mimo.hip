@@ -97,7 +97,7 @@ template <typename T, int MT, int NT>
 __global__ void __launch_bounds__(256) mimo_gradh_kernel(
     const cx<T>* __restrict__ G, long gs_b, long gs_m, long gs_k,
     const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
-    cx<T>* __restrict__ dH, T scale, int B, int M, int No, int Ni, int K) {
+    cx<T>* __restrict__ dH, long dh_pitch, T scale, int B, int M, int No, int Ni, int K) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= M) return;
     const int m0 = blockIdx.y * MT, n0 = blockIdx.z * NT;
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) mimo_gradh_kernel(
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) {
             const int m = m0 + mm, n = n0 + nn;
-            if (m < No && n < Ni) dH[((long)m * Ni + n) * M + f] = cx<T>(scale * acc[mm][nn].x, scale * acc[mm][nn].y);
+            if (m < No && n < Ni) dH[((long)m * Ni + n) * dh_pitch + f] = cx<T>(scale * acc[mm][nn].x, scale * acc[mm][nn].y);
         }
 }
 
@@ -133,7 +133,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) mimo_gradh_diag_kernel(
     const cx<T>* __restrict__ G, long gs_b, long gs_n, long gs_k,
     const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
-    cx<T>* __restrict__ dh, int B, int M, int N, int K) {
+    cx<T>* __restrict__ dh, long dh_pitch, int B, int M, int N, int K) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= M) return;
     const int n = blockIdx.y;
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) mimo_gradh_diag_kernel(
         for (int k = 0; k < K; ++k)
             fma_cxc(acc, G[(long)b * gs_b + (long)n * gs_n + (long)k * gs_k + f],
                     X[(long)b * xs_b + (long)n * xs_n + (long)k * xs_k + f]);
-    dh[(long)n * M + f] = acc;
+    dh[(long)n * dh_pitch + f] = acc;
 }
 
 // ---------------------------------------------------------------- host dispatch
@@ -206,8 +206,9 @@ static int mimo_diag_impl(const void* h, long hs_f, long hs_n, int conj_h, const
 
 template <typename T>
 static int gradh_impl(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                      void* dH, double scale, int B, int M, int No, int Ni, int K, void* stream) {
+                      void* dH, long dh_pitch, double scale, int B, int M, int No, int Ni, int K, void* stream) {
     FL_REQUIRE(G && X && dH, "mimo_gradh: null pointer");
+    FL_REQUIRE(dh_pitch >= M, "mimo_gradh: dh_pitch must be >= M");
     FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo_gradh: bad sizes");
     if (M == 0) return FL_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -215,12 +216,12 @@ static int gradh_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
         dim3 grid(cdiv_i(M, 256), cdiv_i(No, 4), cdiv_i(Ni, 4));
         FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradh: too many channels");
         hipLaunchKernelGGL((mimo_gradh_kernel<T, 4, 4>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
-                           (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, (T)scale, B, M, No, Ni, K);
+                           (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K);
     } else {
         dim3 grid(cdiv_i(M, 256), No, Ni);
         FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradh: too many channels");
         hipLaunchKernelGGL((mimo_gradh_kernel<T, 1, 1>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
-                           (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, (T)scale, B, M, No, Ni, K);
+                           (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K);
     }
     FL_CHECK_LAUNCH("mimo_gradh");
     return FL_OK;
@@ -228,13 +229,14 @@ static int gradh_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
 
 template <typename T>
 static int gradh_diag_impl(const void* G, long gs_b, long gs_n, long gs_k, const void* X, long xs_b, long xs_n,
-                           long xs_k, void* dh, int B, int M, int N, int K, void* stream) {
+                           long xs_k, void* dh, long dh_pitch, int B, int M, int N, int K, void* stream) {
     FL_REQUIRE(G && X && dh, "mimo_gradh_diag: null pointer");
+    FL_REQUIRE(dh_pitch >= M, "mimo_gradh_diag: dh_pitch must be >= M");
     FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0 && N <= 65535, "mimo_gradh_diag: bad sizes");
     if (M == 0) return FL_OK;
     dim3 grid(cdiv_i(M, 256), N);
     hipLaunchKernelGGL((mimo_gradh_diag_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)G, gs_b, gs_n,
-                       gs_k, (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dh, B, M, N, K);
+                       gs_k, (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dh, dh_pitch, B, M, N, K);
     FL_CHECK_LAUNCH("mimo_gradh_diag");
     return FL_OK;
 }
@@ -262,20 +264,20 @@ int fl_mimo_diag_c128(const void* h, long hs_f, long hs_n, int conj_h, const voi
     return mimo_diag_impl<double>(h, hs_f, hs_n, conj_h, X, xs_b, xs_n, xs_k, Y, ys_b, ys_n, ys_k, B, M, N, K, stream);
 }
 int fl_mimo_gradh_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                      void* dH, double scale, int B, int M, int No, int Ni, int K, void* stream) {
-    return gradh_impl<float>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, dH, scale, B, M, No, Ni, K, stream);
+                      void* dH, long dh_pitch, double scale, int B, int M, int No, int Ni, int K, void* stream) {
+    return gradh_impl<float>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, dH, dh_pitch, scale, B, M, No, Ni, K, stream);
 }
 int fl_mimo_gradh_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                       void* dH, double scale, int B, int M, int No, int Ni, int K, void* stream) {
-    return gradh_impl<double>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, dH, scale, B, M, No, Ni, K, stream);
+                       void* dH, long dh_pitch, double scale, int B, int M, int No, int Ni, int K, void* stream) {
+    return gradh_impl<double>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, dH, dh_pitch, scale, B, M, No, Ni, K, stream);
 }
 int fl_mimo_gradh_diag_c64(const void* G, long gs_b, long gs_n, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                           void* dh, int B, int M, int N, int K, void* stream) {
-    return gradh_diag_impl<float>(G, gs_b, gs_n, gs_k, X, xs_b, xs_n, xs_k, dh, B, M, N, K, stream);
+                           void* dh, long dh_pitch, int B, int M, int N, int K, void* stream) {
+    return gradh_diag_impl<float>(G, gs_b, gs_n, gs_k, X, xs_b, xs_n, xs_k, dh, dh_pitch, B, M, N, K, stream);
 }
 int fl_mimo_gradh_diag_c128(const void* G, long gs_b, long gs_n, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                            void* dh, int B, int M, int N, int K, void* stream) {
-    return gradh_diag_impl<double>(G, gs_b, gs_n, gs_k, X, xs_b, xs_n, xs_k, dh, B, M, N, K, stream);
+                            void* dh, long dh_pitch, int B, int M, int N, int K, void* stream) {
+    return gradh_diag_impl<double>(G, gs_b, gs_n, gs_k, X, xs_b, xs_n, xs_k, dh, dh_pitch, B, M, N, K, stream);
 }
 
 }  // extern "C"

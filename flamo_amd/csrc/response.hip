@@ -13,7 +13,7 @@ namespace fl {
 template <typename T>
 __global__ void __launch_bounds__(256) delay_response_kernel(const int32_t* __restrict__ m, const T* __restrict__ amp,
                                                             const cx<T>* __restrict__ W, int nfft, int bin0,
-                                                            int m_local, cx<T>* __restrict__ H) {
+                                                            int m_local, cx<T>* __restrict__ H, long h_pitch) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= m_local) return;
     const int c = blockIdx.y;
@@ -22,7 +22,7 @@ __global__ void __launch_bounds__(256) delay_response_kernel(const int32_t* __re
     if (idx < 0) idx += nfft;
     const cx<T> w = W[idx];
     const T a = amp[c];
-    H[(size_t)c * m_local + f] = cx<T>(a * w.x, a * w.y);
+    H[(size_t)c * h_pitch + f] = cx<T>(a * w.x, a * w.y);
 }
 
 // The section polynomials are evaluated in DOUBLE precision whatever the storage type T: at low
@@ -68,7 +68,7 @@ template <> __device__ inline double eps_of<double>() { return 2.220446049250313
 template <typename T>
 __global__ void __launch_bounds__(256) sos_response_kernel(const double* __restrict__ b, const double* __restrict__ a, int S, int C,
                                                           double g, const cx<double>* __restrict__ Wd, int nfft,
-                                                          int bin0, int m_local, cx<T>* __restrict__ H) {
+                                                          int bin0, int m_local, cx<T>* __restrict__ H, long h_pitch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lb = reinterpret_cast<double*>(smem);
     double* la = lb + 3 * S;
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) sos_response_kernel(const double* __restr
         Ap = Ap * e.poly(la, S, s);
     }
     cx<double> h = (Ap.x != 0 || Ap.y != 0) ? cdiv(Bp, Ap) : cx<double>((double)eps_of<T>(), 0);
-    H[(size_t)c * m_local + f] = cx<T>((T)h.x, (T)h.y);
+    H[(size_t)c * h_pitch + f] = cx<T>((T)h.x, (T)h.y);
 }
 
 // 1/x in double from a float32 hardware reciprocal refined by two Newton steps (|x| within float
@@ -106,7 +106,7 @@ __device__ inline cx<double> cdiv_fast(cx<double> a, cx<double> b) {
 // the three tap sums of a section are nearly collinear at low frequency and the parameter maps
 // combine them with cancellation, so single-precision sums cost 3 digits of the final gradient.
 template <typename T, int SCH>
-__global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __restrict__ gH, const double* __restrict__ b,
+__global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __restrict__ gH, long g_pitch, const double* __restrict__ b,
                                                               const double* __restrict__ a, int S, int C, double g,
                                                               const cx<double>* __restrict__ Wd, int nfft, int bin0,
                                                               int m_local, double* __restrict__ part) {
@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
         }
         if (Ap.x == 0 && Ap.y == 0) continue;  // guarded bins are the constant eps: zero gradient
         const cx<double> h = cdiv_fast(Bp, Ap);
-        const cx<T> gin = gH[(size_t)c * m_local + f];
+        const cx<T> gin = gH[(size_t)c * g_pitch + f];
         const cx<double> gc((double)gin.x, -(double)gin.y);
         const cx<double> gh = gc * h;            // conj(gH) * H
 #pragma unroll
@@ -285,41 +285,44 @@ static int sos_blocks(int m_local) {
 
 template <typename T>
 static int delay_impl(const int32_t* m, const void* amp, int C, const void* W, int nfft, int bin0, int m_local, void* H,
-                      void* stream) {
+                      long h_pitch, void* stream) {
     FL_REQUIRE(m && amp && W && H, "delay_response: null pointer");
+    FL_REQUIRE(h_pitch >= m_local, "delay_response: h_pitch must be >= m_local");
     FL_REQUIRE(C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local >= 0, "delay_response: bad sizes");
     if (m_local == 0) return FL_OK;
     dim3 grid(cdiv_i(m_local, 256), C);
     hipLaunchKernelGGL((delay_response_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, m, (const T*)amp,
-                       (const cx<T>*)W, nfft, bin0, m_local, (cx<T>*)H);
+                       (const cx<T>*)W, nfft, bin0, m_local, (cx<T>*)H, h_pitch);
     FL_CHECK_LAUNCH("delay_response");
     return FL_OK;
 }
 
 template <typename T>
 static int sos_impl(const void* b, const void* a, int S, int C, double gamma, const void* Wd, int nfft, int bin0,
-                    int m_local, void* H, void* stream) {
+                    int m_local, void* H, long h_pitch, void* stream) {
     FL_REQUIRE(b && a && H && Wd, "sos_response: null pointer");
+    FL_REQUIRE(h_pitch >= m_local, "sos_response: h_pitch must be >= m_local");
     FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local >= 0, "sos_response: bad sizes");
     if (m_local == 0) return FL_OK;
     dim3 grid(cdiv_i(m_local, 256), C);
     hipLaunchKernelGGL((sos_response_kernel<T>), grid, dim3(256), (size_t)6 * S * sizeof(double), (hipStream_t)stream, (const double*)b, (const double*)a, S, C,
-                       gamma, (const cx<double>*)Wd, nfft, bin0, m_local, (cx<T>*)H);
+                       gamma, (const cx<double>*)Wd, nfft, bin0, m_local, (cx<T>*)H, h_pitch);
     FL_CHECK_LAUNCH("sos_response");
     return FL_OK;
 }
 
 template <typename T>
-static int sos_bwd_impl(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* Wd,
+static int sos_bwd_impl(const void* gH, long g_pitch, const void* b, const void* a, int S, int C, double gamma, const void* Wd,
                         int nfft, int bin0, int m_local, void* part, void* stream) {
     FL_REQUIRE(gH && b && a && part && Wd, "sos_response_bwd: null pointer");
+    FL_REQUIRE(g_pitch >= m_local, "sos_response_bwd: g_pitch must be >= m_local");
     FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local > 0, "sos_response_bwd: bad sizes");
     const int sch = g_sos_chunk > 0 ? g_sos_chunk : 6;
 #define FL_SOS_BWD(SC)                                                                                              \
     {                                                                                                               \
         dim3 grid(sos_blocks(m_local), C, cdiv_i(S, SC));                                                           \
         hipLaunchKernelGGL((sos_response_bwd_kernel<T, SC>), grid, dim3(256), (size_t)6 * S * sizeof(double),      \
-                           (hipStream_t)stream, (const cx<T>*)gH, (const double*)b, (const double*)a, S, C, gamma, \
+                           (hipStream_t)stream, (const cx<T>*)gH, g_pitch, (const double*)b, (const double*)a, S, C, gamma, \
                            (const cx<double>*)Wd, nfft, bin0, m_local, (double*)part);                              \
     }
     if (S > 4 && sch == 12) FL_SOS_BWD(12)
@@ -328,7 +331,7 @@ static int sos_bwd_impl(const void* gH, const void* b, const void* a, int S, int
     else if (S > 4) FL_SOS_BWD(4)
     else {
         dim3 grid(sos_blocks(m_local), C, 1);
-        hipLaunchKernelGGL((sos_response_bwd_kernel<T, 4>), grid, dim3(256), (size_t)6 * S * sizeof(double), (hipStream_t)stream, (const cx<T>*)gH,
+        hipLaunchKernelGGL((sos_response_bwd_kernel<T, 4>), grid, dim3(256), (size_t)6 * S * sizeof(double), (hipStream_t)stream, (const cx<T>*)gH, g_pitch,
                            (const double*)b, (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0, m_local,
                            (double*)part);
     }
@@ -342,20 +345,20 @@ using namespace fl;
 
 extern "C" {
 int fl_delay_response_c64(const int32_t* m, const void* amp, int C, const void* W, int nfft, int bin0, int m_local,
-                          void* H, void* stream) {
-    return delay_impl<float>(m, amp, C, W, nfft, bin0, m_local, H, stream);
+                          void* H, long h_pitch, void* stream) {
+    return delay_impl<float>(m, amp, C, W, nfft, bin0, m_local, H, h_pitch, stream);
 }
 int fl_delay_response_c128(const int32_t* m, const void* amp, int C, const void* W, int nfft, int bin0, int m_local,
-                           void* H, void* stream) {
-    return delay_impl<double>(m, amp, C, W, nfft, bin0, m_local, H, stream);
+                          void* H, long h_pitch, void* stream) {
+    return delay_impl<double>(m, amp, C, W, nfft, bin0, m_local, H, h_pitch, stream);
 }
 int fl_sos_response_c64(const void* b, const void* a, int S, int C, double gamma, const void* Wd, int nfft, int bin0,
-                        int m_local, void* H, void* stream) {
-    return sos_impl<float>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, stream);
+                        int m_local, void* H, long h_pitch, void* stream) {
+    return sos_impl<float>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, h_pitch, stream);
 }
 int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamma, const void* Wd, int nfft, int bin0,
-                        int m_local, void* H, void* stream) {
-    return sos_impl<double>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, stream);
+                        int m_local, void* H, long h_pitch, void* stream) {
+    return sos_impl<double>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, h_pitch, stream);
 }
 int fl_sos_bwd_blocks(int m_local) { return sos_blocks(m_local); }
 int fl_debug_set_sos_chunk(int sections_per_thread) {
@@ -383,12 +386,12 @@ int fl_geq_sections_bwd(const void* gain_db, const void* gb, const void* ga, int
     FL_CHECK_LAUNCH("geq_sections_bwd");
     return FL_OK;
 }
-int fl_sos_response_bwd_c64(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* Wd,
-                            int nfft, int bin0, int m_local, void* part, void* stream) {
-    return sos_bwd_impl<float>(gH, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
+int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* b, const void* a, int S, int C, double gamma,
+                            const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
+    return sos_bwd_impl<float>(gH, g_pitch, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
 }
-int fl_sos_response_bwd_c128(const void* gH, const void* b, const void* a, int S, int C, double gamma, const void* Wd,
-                            int nfft, int bin0, int m_local, void* part, void* stream) {
-    return sos_bwd_impl<double>(gH, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
+int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* b, const void* a, int S, int C, double gamma,
+                            const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
+    return sos_bwd_impl<double>(gH, g_pitch, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
 }
 }

@@ -25,7 +25,7 @@ __device__ inline cx<T> shfl_cx(cx<T> v, int src, int width) {
 
 template <typename T, int NMAX>
 __global__ void __launch_bounds__(256) solve_kernel(
-    const cx<T>* __restrict__ P, int one_minus, int adjoint,
+    const cx<T>* __restrict__ P, long p_pitch, int one_minus, int adjoint,
     const cx<T>* __restrict__ R, long rs_b, long rs_n, long rs_k,
     cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
     int B, int M, int N, int K) {
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) solve_kernel(
     for (int j = 0; j < NMAX; ++j) {
         cx<T> v(0, 0);
         if (gi < N && j < N) {
-            v = adjoint ? conj(P[((long)j * N + gi) * M + f]) : P[((long)gi * N + j) * M + f];
+            v = adjoint ? conj(P[((long)j * N + gi) * p_pitch + f]) : P[((long)gi * N + j) * p_pitch + f];
             if (one_minus) v = cx<T>(-v.x, -v.y);
         }
         if (one_minus ? (j == gi) : (j == gi && gi >= N)) v.x += (T)1;
@@ -114,21 +114,21 @@ __global__ void __launch_bounds__(256) solve_kernel(
 }
 
 template <typename T, int NMAX>
-static int launch_solve(const void* P, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
+static int launch_solve(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
                         void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, hipStream_t st) {
     constexpr int BPB = 256 / NMAX;
     dim3 grid(cdiv_i(M, BPB));
-    hipLaunchKernelGGL((solve_kernel<T, NMAX>), grid, dim3(256), 0, st, (const cx<T>*)P, one_minus, adjoint,
+    hipLaunchKernelGGL((solve_kernel<T, NMAX>), grid, dim3(256), 0, st, (const cx<T>*)P, p_pitch, one_minus, adjoint,
                        (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);
     FL_CHECK_LAUNCH("solve");
     return FL_OK;
 }
 
 template <typename T>
-static int solve_impl(const void* P, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
+static int solve_impl(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
                       void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
     FL_REQUIRE(P && R && OUT, "solve: null pointer");
-    FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0, "solve: bad sizes");
+    FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0 && p_pitch >= M, "solve: bad sizes (p_pitch >= M)");
     const int nmax_lim = sizeof(T) == 8 ? 32 : 64;
     if (N > nmax_lim) {
         set_error("solve: N=%d exceeds the register-resident limit (%d) for this precision", N, nmax_lim);
@@ -136,7 +136,7 @@ static int solve_impl(const void* P, int one_minus, int adjoint, const void* R, 
     }
     if (B == 0 || M == 0) return FL_OK;
     hipStream_t st = (hipStream_t)stream;
-#define FL_SOLVE(NM) return launch_solve<T, NM>(P, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, st)
+#define FL_SOLVE(NM) return launch_solve<T, NM>(P, p_pitch, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, st)
     if (N <= 4) FL_SOLVE(4);
     if (N <= 8) FL_SOLVE(8);
     if (N <= 16) FL_SOLVE(16);
@@ -151,12 +151,12 @@ static int solve_impl(const void* P, int one_minus, int adjoint, const void* R, 
 using namespace fl;
 
 extern "C" {
-int fl_solve_c64(const void* P, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+int fl_solve_c64(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
                  long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
-    return solve_impl<float>(P, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+    return solve_impl<float>(P, p_pitch, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
 }
-int fl_solve_c128(const void* P, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+int fl_solve_c128(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
                   long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
-    return solve_impl<double>(P, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+    return solve_impl<double>(P, p_pitch, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
 }
 }

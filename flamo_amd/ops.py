@@ -84,22 +84,53 @@ def twiddles(nfft: int, real: torch.dtype, device: torch.device) -> torch.Tensor
     return W
 
 
-def _transpose(src: torch.Tensor, nbatch: int, rows: int, cols: int) -> torch.Tensor:
-    """src: contiguous memory (nbatch, rows, cols) -> new contiguous (nbatch, cols, rows)."""
-    dst = torch.empty(nbatch * cols * rows, dtype=src.dtype, device=src.device)
-    if dst.numel():
-        _lib.check(_lib.lib().fl_transpose(src.data_ptr(), dst.data_ptr(), nbatch, rows, cols, src.element_size(),
-                                           _stream()), "transpose")
+_ALIGN = 32  # bin rows are padded to a multiple of 32 elements (256 B in c64): aligned planes
+
+
+def _pitch(n: int) -> int:
+    return (int(n) + _ALIGN - 1) // _ALIGN * _ALIGN
+
+
+def _transpose(src: torch.Tensor, nbatch: int, rows: int, cols: int, dst_pitch: Optional[int] = None) -> torch.Tensor:
+    """src: contiguous memory (nbatch, rows, cols) -> new memory (nbatch, cols, dst_pitch) holding
+    the transposed blocks in [..., :rows] (dst_pitch defaults to rows: a plain contiguous result)."""
+    pitch = rows if dst_pitch is None else int(dst_pitch)
+    dst = torch.empty(nbatch * cols * pitch, dtype=src.dtype, device=src.device)
+    if nbatch and rows and cols:
+        _lib.check(_lib.lib().fl_transpose(src.data_ptr(), dst.data_ptr(), nbatch, rows, cols, pitch,
+                                           src.element_size(), _stream()), "transpose")
     return dst
 
 
+def _lead_pitch(mem: torch.Tensor) -> Optional[int]:
+    """For memory-order tensor ``mem`` (lead..., A): the pitch P such that row i of the flattened
+    leading dims starts at element i*P with its A entries contiguous -- or None if the tensor is
+    not laid out that way.  P >= A; P > A means padded rows."""
+    A = mem.shape[-1]
+    if A > 1 and mem.stride(-1) != 1:
+        return None
+    P, expect = None, None
+    for size, stride in reversed(list(zip(mem.shape[:-1], mem.stride()[:-1]))):
+        if size == 1:
+            continue
+        if P is None:
+            if stride < A:
+                return None
+            P, expect = stride, stride * size
+        else:
+            if stride != expect:
+                return None
+            expect *= size
+    return A if P is None else P
+
+
 def _is_planar(x: torch.Tensor) -> bool:
-    """memory order (B, rest..., axis1) contiguous"""
-    return x.movedim(1, -1).is_contiguous()
+    """memory order (B, rest..., axis1) with axis 1 contiguous (rows possibly padded)"""
+    return _lead_pitch(x.movedim(1, -1)) is not None
 
 
 def to_planar(x: torch.Tensor) -> torch.Tensor:
-    """Same logical tensor (B, A, rest...) stored with axis 1 contiguous (memory (B, rest..., A))."""
+    """Same logical tensor (B, A, rest...) stored with axis 1 contiguous (memory (B, rest..., pitch))."""
     if x.dim() < 2:
         raise ValueError("expected at least 2 dims")
     if _is_planar(x):
@@ -107,25 +138,29 @@ def to_planar(x: torch.Tensor) -> torch.Tensor:
     B, A = x.shape[0], x.shape[1]
     rest = tuple(x.shape[2:])
     xc = x.contiguous()  # no-op for the usual channel-innermost layout
-    out = _transpose(xc, B, A, _prod(rest))
-    return out.view(B, *rest, A).movedim(-1, 1)
+    P = _pitch(A)
+    out = _transpose(xc, B, A, _prod(rest), P)
+    return out.view(B, *rest, P)[..., :A].movedim(-1, 1)
 
 
 def _empty_planar(shape: Tuple[int, ...], dtype, device) -> torch.Tensor:
     B, A = shape[0], shape[1]
     rest = tuple(shape[2:])
-    return torch.empty((B, *rest, A), dtype=dtype, device=device).movedim(-1, 1)
+    return torch.empty((B, *rest, _pitch(A)), dtype=dtype, device=device)[..., :A].movedim(-1, 1)
+
+
+def _empty_rows(lead: Tuple[int, ...], A: int, dtype, device) -> torch.Tensor:
+    """memory (lead..., pitch) viewed as (lead..., A)"""
+    return torch.empty((*lead, _pitch(A)), dtype=dtype, device=device)[..., :A]
 
 
 def _bnk(x: torch.Tensor):
     """(B, M, N, K) sizes and element strides (s_b, s_n, s_k) of a planar tensor (B, M, N, rest...)."""
     B, M, N = x.shape[0], x.shape[1], x.shape[2]
     K = _prod(x.shape[3:])
-    mem = x.movedim(1, -1)  # (B, N, rest..., M) contiguous
-    s_b = mem.stride(0)
-    s_n = mem.stride(1)
-    s_k = M  # trailing dims are contiguous just above the bin axis
-    return B, M, N, K, s_b, s_n, s_k
+    P = _lead_pitch(x.movedim(1, -1))  # rows of (B, N, rest...) are P apart
+    assert P is not None
+    return B, M, N, K, N * K * P, K * P, P
 
 
 # ----------------------------------------------------------------------------- kernel timing (bench.py)
@@ -196,21 +231,23 @@ _NORM_INV = {"backward": lambda n: 1.0 / n, "ortho": lambda n: 1.0 / math.sqrt(n
 
 
 def _rfft_launch(xp: torch.Tensor, t_in: int, nfft: int, scale: float, env_log2: float, interior_x2: int):
-    """xp: signal-planar real, logical (B, T, rest...), memory (B, rest..., T).  Returns planar X."""
+    """xp: signal-planar real, logical (B, T, rest...), memory (B, rest..., pitch).  Returns planar X."""
     real = _rdtype(xp)
     dev = xp.device
     B = xp.shape[0]
     rest = tuple(xp.shape[2:])
     nsig = B * _prod(rest)
     M = nfft // 2 + 1
-    X = torch.empty((B, *rest, M), dtype=_cdtype(real), device=dev)
+    x_pitch = _lead_pitch(xp.movedim(1, -1))
+    X = _empty_rows((B, *rest), M, _cdtype(real), dev)
     L = _lib.lib()
     f64 = int(real == torch.float64)
     n_scr = L.fl_fft_scratch_elems(nfft, f64, nsig)
     scratch = torch.empty(max(n_scr, 1), dtype=_cdtype(real), device=dev)
     fn = L.fl_rfft_f64 if f64 else L.fl_rfft_f32
-    _lib.check(fn(xp.movedim(1, -1).data_ptr(), xp.shape[1], t_in, X.data_ptr(), scratch.data_ptr(),
-                  twiddles(nfft, real, dev).data_ptr(), nsig, nfft, scale, env_log2, interior_x2, _stream()), "rfft")
+    _lib.check(fn(xp.data_ptr(), x_pitch, t_in, X.data_ptr(), _pitch(M),
+                  scratch.data_ptr(), twiddles(nfft, real, dev).data_ptr(), nsig, nfft, scale, env_log2, interior_x2,
+                  _stream()), "rfft")
     return X.movedim(-1, 1)
 
 
@@ -222,6 +259,7 @@ def _irfft_launch(Xp: torch.Tensor, nfft: int, t_out: int, t_alloc: int, scale: 
     B = Xp.shape[0]
     rest = tuple(Xp.shape[2:])
     nsig = B * _prod(rest)
+    X_pitch = _lead_pitch(Xp.movedim(1, -1))
     alloc = torch.zeros if t_alloc > t_out else torch.empty
     y = alloc((B, *rest, t_alloc), dtype=real, device=dev)
     L = _lib.lib()
@@ -229,7 +267,7 @@ def _irfft_launch(Xp: torch.Tensor, nfft: int, t_out: int, t_alloc: int, scale: 
     n_scr = L.fl_fft_scratch_elems(nfft, f64, nsig)
     scratch = torch.empty(max(n_scr, 1), dtype=_cdtype(real), device=dev)
     fn = L.fl_irfft_f64 if f64 else L.fl_irfft_f32
-    _lib.check(fn(Xp.movedim(1, -1).data_ptr(), y.data_ptr(), t_alloc, t_out, scratch.data_ptr(),
+    _lib.check(fn(Xp.data_ptr(), X_pitch, y.data_ptr(), t_alloc, t_out, scratch.data_ptr(),
                   twiddles(nfft, real, dev).data_ptr(), nsig, nfft, scale, env_log2, interior_half, _stream()), "irfft")
     return y.movedim(-1, 1)
 
@@ -296,15 +334,16 @@ def irfft(X: torch.Tensor, nfft: int, norm: str = "backward", alias_decay_db: Op
 
 # ----------------------------------------------------------------------------- per-bin MIMO product
 def _h_planar(H: torch.Tensor, per_bin: bool) -> torch.Tensor:
-    """Per-bin responses (M, ...) are used with the bin axis contiguous."""
+    """Per-bin responses (M, ...) are used with the bin axis contiguous (rows possibly padded)."""
     if not per_bin:
         return H.contiguous()
-    if H.movedim(0, -1).is_contiguous():
+    if _lead_pitch(H.movedim(0, -1)) is not None:
         return H
     M = H.shape[0]
     rest = tuple(H.shape[1:])
-    out = _transpose(H.contiguous(), 1, M, _prod(rest))
-    return out.view(*rest, M).movedim(-1, 0)
+    P = _pitch(M)
+    out = _transpose(H.contiguous(), 1, M, _prod(rest), P)
+    return out.view(*rest, P)[..., :M].movedim(-1, 0)
 
 
 def _mimo_launch(H, per_bin, diag, conj_t, X):
@@ -312,9 +351,10 @@ def _mimo_launch(H, per_bin, diag, conj_t, X):
     real = _rdtype(X)
     B, M, Nx, K, xs_b, xs_n, xs_k = _bnk(X)
     L = _lib.lib()
+    hp = _lead_pitch(H.movedim(0, -1)) if per_bin else 0   # pitch of the per-bin response rows
     if diag:
         N = H.shape[-1]
-        hs_f, hs_n = (1, M) if per_bin else (0, 1)
+        hs_f, hs_n = (1, hp) if per_bin else (0, 1)
         Y = _empty_planar(X.shape, X.dtype, X.device)
         _, _, _, _, ys_b, ys_n, ys_k = _bnk(Y)
         fn = L.fl_mimo_diag_c64 if real == torch.float32 else L.fl_mimo_diag_c128
@@ -323,7 +363,7 @@ def _mimo_launch(H, per_bin, diag, conj_t, X):
         return Y
     No_h, Ni_h = H.shape[-2], H.shape[-1]
     if per_bin:
-        hs_f, hs_m, hs_n = 1, Ni_h * M, M
+        hs_f, hs_m, hs_n = 1, Ni_h * hp, hp
     else:
         hs_f, hs_m, hs_n = 0, Ni_h, 1
     if conj_t:
@@ -346,15 +386,16 @@ def _gradh_launch(G, X, diag, scale=1.0):
     B, M, Ni, K, xs_b, xs_n, xs_k = _bnk(X)
     _, _, No, _, gs_b, gs_m, gs_k = _bnk(G)
     L = _lib.lib()
+    P = _pitch(M)
     if diag:
-        dh = torch.empty((Ni, M), dtype=X.dtype, device=X.device)
+        dh = _empty_rows((Ni,), M, X.dtype, X.device)
         fn = L.fl_mimo_gradh_diag_c64 if real == torch.float32 else L.fl_mimo_gradh_diag_c128
-        _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dh.data_ptr(), B, M, Ni, K,
+        _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dh.data_ptr(), P, B, M, Ni, K,
                       _stream()), "mimo_gradh_diag")
         return dh if scale == 1.0 else dh * scale
-    dH = torch.empty((No, Ni, M), dtype=X.dtype, device=X.device)
+    dH = _empty_rows((No, Ni), M, X.dtype, X.device)
     fn = L.fl_mimo_gradh_c64 if real == torch.float32 else L.fl_mimo_gradh_c128
-    _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dH.data_ptr(), float(scale), B, M,
+    _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dH.data_ptr(), P, float(scale), B, M,
                   No, Ni, K, _stream()), "mimo_gradh")
     return dH
 
@@ -410,8 +451,8 @@ def _solve_launch(Pp, one_minus, adjoint, R):
     _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
     L = _lib.lib()
     fn = L.fl_solve_c64 if real == torch.float32 else L.fl_solve_c128
-    _lib.check(fn(Pp.data_ptr(), int(one_minus), int(adjoint), R.data_ptr(), rs_b, rs_n, rs_k, OUT.data_ptr(), os_b,
-                  os_n, os_k, B, M, N, K, _stream()), "solve")
+    _lib.check(fn(Pp.data_ptr(), _lead_pitch(Pp.movedim(0, -1)), int(one_minus), int(adjoint), R.data_ptr(), rs_b, rs_n,
+                  rs_k, OUT.data_ptr(), os_b, os_n, os_k, B, M, N, K, _stream()), "solve")
     return OUT
 
 
@@ -465,11 +506,11 @@ def delay_response(m_int: torch.Tensor, amp: torch.Tensor, nfft: int) -> torch.T
     C_ = max(_prod(shape), 1)
     m32 = m_int.to(torch.int32).contiguous()
     amp = amp.contiguous()
-    H = torch.empty((*shape, m_local), dtype=_cdtype(real), device=dev)
+    H = _empty_rows(shape, m_local, _cdtype(real), dev)
     L = _lib.lib()
     fn = L.fl_delay_response_c64 if real == torch.float32 else L.fl_delay_response_c128
     _lib.check(fn(m32.data_ptr(), amp.data_ptr(), C_, twiddles(nfft, real, dev).data_ptr(), nfft, bin0, m_local,
-                  H.data_ptr(), _stream()), "delay_response")
+                  H.data_ptr(), _pitch(m_local), _stream()), "delay_response")
     return H.movedim(-1, 0)
 
 
@@ -486,12 +527,12 @@ class _Sos(torch.autograd.Function):
         chan = tuple(b.shape[2:])
         C_ = max(_prod(chan), 1)
         bin0, m_local = bin_shard(nfft)
-        H = torch.empty((*chan, m_local), dtype=_cdtype(real), device=dev)
+        H = _empty_rows(chan, m_local, _cdtype(real), dev)
         L = _lib.lib()
         fn = L.fl_sos_response_c64 if real == torch.float32 else L.fl_sos_response_c128
         Wd = twiddles(nfft, torch.float64, dev)
         _lib.check(fn(bc.data_ptr(), ac.data_ptr(), S, C_, float(gamma), Wd.data_ptr(), nfft, bin0, m_local,
-                      H.data_ptr(), _stream()), "sos_response")
+                      H.data_ptr(), _pitch(m_local), _stream()), "sos_response")
         ctx.save_for_backward(bc, ac)
         ctx.cfg = (float(gamma), nfft, S, C_, bin0, m_local, real)
         return H.movedim(-1, 0)
@@ -501,15 +542,15 @@ class _Sos(torch.autograd.Function):
         bc, ac = ctx.saved_tensors
         gamma, nfft, S, C_, bin0, m_local, real = ctx.cfg
         dev = bc.device
-        g = gH.resolve_conj()
-        g = g if g.movedim(0, -1).is_contiguous() else _h_planar(g, True)
+        g = _h_planar(gH.resolve_conj(), True)
+        g_pitch = _lead_pitch(g.movedim(0, -1))
         L = _lib.lib()
         nblk = L.fl_sos_bwd_blocks(m_local)
         part = torch.zeros((nblk, 2, 3, S, C_), dtype=torch.float64, device=dev)
         fn = L.fl_sos_response_bwd_c64 if real == torch.float32 else L.fl_sos_response_bwd_c128
         Wd = twiddles(nfft, torch.float64, dev)
-        _lib.check(fn(g.data_ptr(), bc.data_ptr(), ac.data_ptr(), S, C_, gamma, Wd.data_ptr(), nfft, bin0, m_local,
-                      part.data_ptr(), _stream()), "sos_response_bwd")
+        _lib.check(fn(g.data_ptr(), g_pitch, bc.data_ptr(), ac.data_ptr(), S, C_, gamma, Wd.data_ptr(), nfft, bin0,
+                      m_local, part.data_ptr(), _stream()), "sos_response_bwd")
         tot = part.sum(dim=0)
         return tot[0].view(bc.shape), tot[1].view(ac.shape), None, None, None
 

@@ -16,7 +16,10 @@
  *    thread-local message for the last failure on the calling thread.  No C++ exception
  *    crosses the ABI.  Functions are re-entrant.
  *  - Layout ("bin-planar"): a frequency-domain tensor with logical shape (B, M, N, K) is
- *    stored with the bin axis contiguous: address = b*s_b + n*s_n + k*s_k + f.  A time-domain
+ *    stored with the bin axis contiguous: address = b*s_b + n*s_n + k*s_k + f.  The distance
+ *    between consecutive bin rows (the "pitch", >= the number of bins) is a parameter wherever
+ *    a kernel writes or reads whole rows, so callers can pad rows to an aligned length
+ *    (flamo_amd.ops pads to a multiple of 32 elements = 256 bytes in c64).  A time-domain
  *    tensor (B, T, N) is stored signal-planar: address = sig*stride + t, sig = b*N + n.
  *    Complex numbers are interleaved (re, im) pairs of the real type (f32 -> "c64",
  *    f64 -> "c128").  Strides are in ELEMENTS of the array's own element type.
@@ -71,25 +74,26 @@ int fl_debug_set_fft_fast(int enabled);
  *      padded / truncated to nfft as torch.fft.rfft(n=nfft) does);
  *   e(t) = 2^(env_log2 * t) (anti-alias envelope gamma^-t; env_log2 = 0 disables it);
  *   w_k = 1, or (interior_x2 != 0) 2 for 0 < k < nfft/2 (used by irfft's backward);
- *   X: complex, signal `sig` at X + sig*(nfft/2+1). */
-int fl_rfft_f32(const void* x, long x_sig_stride, int t_in, void* X, void* scratch, const void* W,
+ *   X: complex, signal `sig` at X + sig*X_sig_stride (X_sig_stride >= nfft/2+1). */
+int fl_rfft_f32(const void* x, long x_sig_stride, int t_in, void* X, long X_sig_stride, void* scratch, const void* W,
                 int nsig, int nfft, double scale, double env_log2, int interior_x2, void* stream);
-int fl_rfft_f64(const void* x, long x_sig_stride, int t_in, void* X, void* scratch, const void* W,
+int fl_rfft_f64(const void* x, long x_sig_stride, int t_in, void* X, long X_sig_stride, void* scratch, const void* W,
                 int nsig, int nfft, double scale, double env_log2, int interior_x2, void* stream);
 
 /* y[sig, t] = scale * e(t) * sum_k w_k' Re(v_k X[sig,k] exp(+2 pi i k t / nfft)),  t in [0, t_out)
  *   C2R semantics of torch.fft.irfft: w_k' = 1 for k in {0, nfft/2} (imaginary part ignored),
  *   2 otherwise; v_k = 1, or (interior_half != 0) 1/2 for interior bins (rfft's backward);
  *   t_out <= nfft samples are written per signal at y + sig*y_sig_stride. */
-int fl_irfft_f32(const void* X, void* y, long y_sig_stride, int t_out, void* scratch, const void* W,
+int fl_irfft_f32(const void* X, long X_sig_stride, void* y, long y_sig_stride, int t_out, void* scratch, const void* W,
                  int nsig, int nfft, double scale, double env_log2, int interior_half, void* stream);
-int fl_irfft_f64(const void* X, void* y, long y_sig_stride, int t_out, void* scratch, const void* W,
+int fl_irfft_f64(const void* X, long X_sig_stride, void* y, long y_sig_stride, int t_out, void* scratch, const void* W,
                  int nsig, int nfft, double scale, double env_log2, int interior_half, void* stream);
 
-/* dst[b][c][r] = src[b][r][c]  (batched 2-D transpose through LDS; elem_bytes in {4, 8, 16}).
+/* dst[b*cols*dst_pitch + c*dst_pitch + r] = src[b][r][c]  (batched 2-D transpose through LDS;
+ * elem_bytes in {4, 8, 16}; dst_pitch >= rows lets the caller pad the output rows).
  * Converts the reference's channel-innermost (B, T, N) / (B, M, N) tensors to the planar layout
  * and back. */
-int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, int elem_bytes, void* stream);
+int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, long dst_pitch, int elem_bytes, void* stream);
 
 /* ------------------------------------------------------------------ per-bin complex MIMO product
  * Replace torch.einsum("fmn,bfn...->bfm...") (dsp.py:922-924, 3406-3408 and every Filter
@@ -120,33 +124,33 @@ int fl_mimo_diag_c128(const void* h, long hs_f, long hs_n, int conj_h,
                       void* Y, long ys_b, long ys_n, long ys_k,
                       int B, int M, int N, int K, void* stream);
 
-/* dH[m,n,f] = scale * sum_{b,k} G[b,m,k,f] * conj(X[b,n,k,f])   (planar dH: (m*Ni+n)*M + f).
+/* dH[m,n,f] = scale * sum_{b,k} G[b,m,k,f] * conj(X[b,n,k,f])   (planar dH: (m*Ni+n)*dh_pitch + f).
  * The gradient of the product w.r.t. H (torch complex convention), and -scale = the
  * Recursion's dA = -dR out^H. */
 int fl_mimo_gradh_c64(const void* G, long gs_b, long gs_m, long gs_k,
                       const void* X, long xs_b, long xs_n, long xs_k,
-                      void* dH, double scale, int B, int M, int No, int Ni, int K, void* stream);
+                      void* dH, long dh_pitch, double scale, int B, int M, int No, int Ni, int K, void* stream);
 int fl_mimo_gradh_c128(const void* G, long gs_b, long gs_m, long gs_k,
                        const void* X, long xs_b, long xs_n, long xs_k,
-                       void* dH, double scale, int B, int M, int No, int Ni, int K, void* stream);
-/* dh[n,f] = sum_{b,k} G[b,n,k,f] * conj(X[b,n,k,f])   (planar dh: n*M + f) */
+                       void* dH, long dh_pitch, double scale, int B, int M, int No, int Ni, int K, void* stream);
+/* dh[n,f] = sum_{b,k} G[b,n,k,f] * conj(X[b,n,k,f])   (planar dh: n*dh_pitch + f) */
 int fl_mimo_gradh_diag_c64(const void* G, long gs_b, long gs_n, long gs_k,
                            const void* X, long xs_b, long xs_n, long xs_k,
-                           void* dh, int B, int M, int N, int K, void* stream);
+                           void* dh, long dh_pitch, int B, int M, int N, int K, void* stream);
 int fl_mimo_gradh_diag_c128(const void* G, long gs_b, long gs_n, long gs_k,
                             const void* X, long xs_b, long xs_n, long xs_k,
-                            void* dh, int B, int M, int N, int K, void* stream);
+                            void* dh, long dh_pitch, int B, int M, int N, int K, void* stream);
 
 /* ------------------------------------------------------------------ frequency responses
  * Integer delay lines, Delay/parallelDelay.get_freq_response with isint=True
  * (dsp.py:3356-3365, 3512-3521):  H[c, f] = amp[c] * exp(-2 pi i ((bin0+f) * m[c] mod nfft) / nfft)
  * -- the phase index is reduced in 64-bit integer arithmetic and looked up in W (bit-exact
  * indexing; the reference evaluates exp(-j*omega*m) in floating point).  amp[c] = gamma^m[c]
- * is supplied by the caller (real, same precision as H). H planar: c*m_local + f. */
+ * is supplied by the caller (real, same precision as H). H planar: c*h_pitch + f. */
 int fl_delay_response_c64(const int32_t* m, const void* amp, int C, const void* W, int nfft,
-                          int bin0, int m_local, void* H, void* stream);
+                          int bin0, int m_local, void* H, long h_pitch, void* stream);
 int fl_delay_response_c128(const int32_t* m, const void* amp, int C, const void* W, int nfft,
-                           int bin0, int m_local, void* H, void* stream);
+                           int bin0, int m_local, void* H, long h_pitch, void* stream);
 
 /* Second-order-section cascades, the tail shared by Biquad/SVF/GEQ/PEQ.get_poly_coeff
  * (dsp.py:1520-1526, 2587-2593):  per channel c and bin k,
@@ -157,17 +161,17 @@ int fl_delay_response_c128(const int32_t* m, const void* amp, int C, const void*
  * double precision whatever the storage type: the shelving sections cancel to ~1e-5 of their
  * terms at low frequency, which float32 evaluation (the reference's float32 mode) cannot hold. */
 int fl_sos_response_c64(const void* b, const void* a, int S, int C, double gamma, const void* Wd,
-                        int nfft, int bin0, int m_local, void* H, void* stream);
+                        int nfft, int bin0, int m_local, void* H, long h_pitch, void* stream);
 int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamma, const void* Wd,
-                         int nfft, int bin0, int m_local, void* H, void* stream);
+                         int nfft, int bin0, int m_local, void* H, long h_pitch, void* stream);
 /* Backward: partial sums over bins of dL/db, dL/da.  part: double (nblk, 2, 3, S, C) where
  * nblk = fl_sos_bwd_blocks(m_local); the caller sums over nblk. */
 int fl_sos_bwd_blocks(int m_local);
 /* tuning hook: sections whose sums one thread keeps in registers (12, 6, 4 or 3; 0 = default) */
 int fl_debug_set_sos_chunk(int sections_per_thread);
-int fl_sos_response_bwd_c64(const void* gH, const void* b, const void* a, int S, int C, double gamma,
+int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* b, const void* a, int S, int C, double gamma,
                             const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
-int fl_sos_response_bwd_c128(const void* gH, const void* b, const void* a, int S, int C, double gamma,
+int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* b, const void* a, int S, int C, double gamma,
                              const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
 
 /* Graphic-equaliser design: command gains in dB -> the float32-rounded second-order sections of
@@ -185,12 +189,12 @@ int fl_geq_sections_bwd(const void* gain_db, const void* gb, const void* ga, int
  * Per bin f:  A_f = (one_minus ? I - P[:,:,f] : P[:,:,f]);  if adjoint, A_f := A_f^H;
  *             OUT[b,:,k,f] = A_f^{-1} R[b,:,k,f]
  * LU with partial pivoting, factored ONCE per bin and applied to all B*K right-hand sides
- * (the reference factors the same matrix B times).  P planar: (i*N + j)*M + f.  N <= 64. */
-int fl_solve_c64(const void* P, int one_minus, int adjoint,
+ * (the reference factors the same matrix B times).  P planar: (i*N + j)*p_pitch + f.  N <= 64. */
+int fl_solve_c64(const void* P, long p_pitch, int one_minus, int adjoint,
                  const void* R, long rs_b, long rs_n, long rs_k,
                  void* OUT, long os_b, long os_n, long os_k,
                  int B, int M, int N, int K, void* stream);
-int fl_solve_c128(const void* P, int one_minus, int adjoint,
+int fl_solve_c128(const void* P, long p_pitch, int one_minus, int adjoint,
                   const void* R, long rs_b, long rs_n, long rs_k,
                   void* OUT, long os_b, long os_n, long os_k,
                   int B, int M, int N, int K, void* stream);

@@ -43,7 +43,7 @@ def test_plan_queries_and_errors():
     assert L.fl_fft_plan(2 * 17, 0, None, None) == -2 and b"prime factor" in L.fl_last_error()
     assert L.fl_fft_scratch_elems(96000, 0, 256) == 48000 * 256
     assert L.fl_fft_scratch_elems(2048, 0, 256) == 0
-    assert L.fl_rfft_f32(None, 0, 0, None, None, None, 1, 96000, 1.0, 0.0, 0, None) == -1   # null pointers rejected
+    assert L.fl_rfft_f32(None, 0, 0, None, 48032, None, None, 1, 96000, 1.0, 0.0, 0, None) == -1   # null pointers rejected
 
 
 def test_ops_fail_loudly_without_gpu_tensors():
