@@ -241,11 +241,104 @@ static int gradh_diag_impl(const void* G, long gs_b, long gs_n, long gs_k, const
     return FL_OK;
 }
 
+
+// dW[m,n] = sum_{b,k,f} G[b,m,k,f] conj(X[b,n,k,f]) -- the gradient of a frequency-INDEPENDENT
+// matrix (Gain/Matrix, the FDN mixing matrix) reduced over bins inside the kernel: each block
+// walks bins with a grid stride, keeps a 4x4 tile of sums per lane, reduces across the block and
+// writes one partial tile; the host adds the <= 64 partials.  No (M, No, Ni) tensor is built.
+template <typename T>
+__global__ void __launch_bounds__(256) mimo_gradw_kernel(
+    const cx<T>* __restrict__ G, long gs_b, long gs_m, long gs_k,
+    const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
+    cx<T>* __restrict__ part, int B, int M, int No, int Ni, int K) {
+    const int m0 = blockIdx.y * 4, n0 = blockIdx.z * 4;
+    cx<T> acc[4][4];
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) acc[mm][nn] = cx<T>(0, 0);
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < M; f += gridDim.x * 256)
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < K; ++k) {
+                const cx<T>* g = G + (long)b * gs_b + (long)k * gs_k + f;
+                const cx<T>* x = X + (long)b * xs_b + (long)k * xs_k + f;
+                cx<T> gv[4], xv[4];
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) gv[mm] = (m0 + mm < No) ? g[(long)(m0 + mm) * gs_m] : cx<T>(0, 0);
+#pragma unroll
+                for (int nn = 0; nn < 4; ++nn) xv[nn] = (n0 + nn < Ni) ? x[(long)(n0 + nn) * xs_n] : cx<T>(0, 0);
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                    for (int nn = 0; nn < 4; ++nn) fma_cxc(acc[mm][nn], gv[mm], xv[nn]);
+            }
+    __shared__ T red[4][32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+        for (int nn = 0; nn < 4; ++nn) {
+            T vr = acc[mm][nn].x, vi = acc[mm][nn].y;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                vr += __shfl_xor(vr, off, 64);
+                vi += __shfl_xor(vi, off, 64);
+            }
+            if (lane == 0) {
+                red[wave][(mm * 4 + nn) * 2] = vr;
+                red[wave][(mm * 4 + nn) * 2 + 1] = vi;
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int mm = threadIdx.x / 4, nn = threadIdx.x % 4;
+        const int m = m0 + mm, n = n0 + nn;
+        if (m < No && n < Ni) {
+            T vr = 0, vi = 0;
+            for (int w = 0; w < 4; ++w) {
+                vr += red[w][threadIdx.x * 2];
+                vi += red[w][threadIdx.x * 2 + 1];
+            }
+            part[((size_t)blockIdx.x * No + m) * Ni + n] = cx<T>(vr, vi);
+        }
+    }
+}
+
+static int gradw_blocks(int M) {
+    int nb = cdiv_i(M, 256);
+    if (nb > 64) nb = 64;
+    if (nb < 1) nb = 1;
+    return nb;
+}
+
+template <typename T>
+static int gradw_impl(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                      void* part, int B, int M, int No, int Ni, int K, void* stream) {
+    FL_REQUIRE(G && X && part, "mimo_gradw: null pointer");
+    FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo_gradw: bad sizes");
+    dim3 grid(gradw_blocks(M), cdiv_i(No, 4), cdiv_i(Ni, 4));
+    FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradw: too many channels");
+    hipLaunchKernelGGL((mimo_gradw_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)G, gs_b, gs_m, gs_k,
+                       (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)part, B, M, No, Ni, K);
+    FL_CHECK_LAUNCH("mimo_gradw");
+    return FL_OK;
+}
+
 }  // namespace fl
 
 using namespace fl;
 
 extern "C" {
+
+int fl_mimo_gradw_blocks(int M) { return gradw_blocks(M); }
+int fl_mimo_gradw_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                      void* part, int B, int M, int No, int Ni, int K, void* stream) {
+    return gradw_impl<float>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, part, B, M, No, Ni, K, stream);
+}
+int fl_mimo_gradw_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                       void* part, int B, int M, int No, int Ni, int K, void* stream) {
+    return gradw_impl<double>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, part, B, M, No, Ni, K, stream);
+}
 
 int fl_mimo_c64(const void* H, long hs_f, long hs_m, long hs_n, int conj_h, const void* X, long xs_b, long xs_n, long xs_k,
                 void* Y, long ys_b, long ys_m, long ys_k, int B, int M, int No, int Ni, int K, void* stream) {

@@ -23,9 +23,22 @@ __device__ inline cx<T> shfl_cx(cx<T> v, int src, int width) {
     return cx<T>(__shfl(v.x, src, width), __shfl(v.y, src, width));
 }
 
+// Structured loop matrix of a feedback delay network: P[f] = diag(l[f]) U diag(r[f]) with a
+// frequency-independent mixing matrix U (N x N) and per-bin (or constant, or absent) diagonal
+// factors -- delays, attenuation filters -- on either side.  A = I - P is then built in
+// registers from 2N values per bin instead of being streamed as N^2 values per bin.
+template <typename T>
+struct Dud {
+    const cx<T>* l;   // element (n, f) at l[n*l_sn + f*l_sf]; nullptr = ones
+    long l_sn, l_sf;
+    const cx<T>* U;   // row-major N x N
+    const cx<T>* r;
+    long r_sn, r_sf;
+};
+
 template <typename T, int NMAX>
 __global__ void __launch_bounds__(256) solve_kernel(
-    const cx<T>* __restrict__ P, long p_pitch, int one_minus, int adjoint,
+    const cx<T>* __restrict__ P, long p_pitch, Dud<T> dud, int one_minus, int adjoint,
     const cx<T>* __restrict__ R, long rs_b, long rs_n, long rs_k,
     cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
     int B, int M, int N, int K) {
@@ -34,17 +47,42 @@ __global__ void __launch_bounds__(256) solve_kernel(
     const int f = blockIdx.x * BPB + threadIdx.x / NMAX;
     if (f >= M) return;  // whole lane group leaves together
 
-    // ---- load this lane's row of A
+    // ---- load (or build) this lane's row of A
     cx<T> row[NMAX];
+    if (P) {
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
-        cx<T> v(0, 0);
-        if (gi < N && j < N) {
-            v = adjoint ? conj(P[((long)j * N + gi) * p_pitch + f]) : P[((long)gi * N + j) * p_pitch + f];
-            if (one_minus) v = cx<T>(-v.x, -v.y);
+        for (int j = 0; j < NMAX; ++j) {
+            cx<T> v(0, 0);
+            if (gi < N && j < N) {
+                v = adjoint ? conj(P[((long)j * N + gi) * p_pitch + f]) : P[((long)gi * N + j) * p_pitch + f];
+                if (one_minus) v = cx<T>(-v.x, -v.y);
+            }
+            if (one_minus ? (j == gi) : (j == gi && gi >= N)) v.x += (T)1;
+            row[j] = v;
         }
-        if (one_minus ? (j == gi) : (j == gi && gi >= N)) v.x += (T)1;
-        row[j] = v;
+    } else {
+        // A[i][j] = delta_ij - l_i U_ij r_j ;  A^H[i][j] = delta_ij - conj(l_j U_ji r_i)
+        const cx<T> one(1, 0);
+        cx<T> lv = one, rv = one;
+        if (gi < N) {
+            if (dud.l) lv = dud.l[(long)gi * dud.l_sn + (long)f * dud.l_sf];
+            if (dud.r) rv = dud.r[(long)gi * dud.r_sn + (long)f * dud.r_sf];
+        }
+        const cx<T> own = adjoint ? rv : lv;       // the factor indexed by this lane's row
+        const cx<T> oth = adjoint ? lv : rv;       // the factor indexed by the column (from lane j)
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            const cx<T> oj = shfl_cx(oth, j, NMAX);
+            cx<T> v(0, 0);
+            if (gi < N && j < N) {
+                const cx<T> u = adjoint ? dud.U[(long)j * N + gi] : dud.U[(long)gi * N + j];
+                v = own * u * oj;
+                if (adjoint) v = conj(v);
+                v = cx<T>(-v.x, -v.y);
+            }
+            if (j == gi) v.x += (T)1;
+            row[j] = v;
+        }
     }
 
     // ---- LU with implicit partial pivoting
@@ -114,21 +152,21 @@ __global__ void __launch_bounds__(256) solve_kernel(
 }
 
 template <typename T, int NMAX>
-static int launch_solve(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
+static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
                         void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, hipStream_t st) {
     constexpr int BPB = 256 / NMAX;
     dim3 grid(cdiv_i(M, BPB));
-    hipLaunchKernelGGL((solve_kernel<T, NMAX>), grid, dim3(256), 0, st, (const cx<T>*)P, p_pitch, one_minus, adjoint,
+    hipLaunchKernelGGL((solve_kernel<T, NMAX>), grid, dim3(256), 0, st, (const cx<T>*)P, p_pitch, dud, one_minus, adjoint,
                        (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);
     FL_CHECK_LAUNCH("solve");
     return FL_OK;
 }
 
 template <typename T>
-static int solve_impl(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
+static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
                       void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
-    FL_REQUIRE(P && R && OUT, "solve: null pointer");
-    FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0 && p_pitch >= M, "solve: bad sizes (p_pitch >= M)");
+    FL_REQUIRE((P || dud.U) && R && OUT, "solve: null pointer");
+    FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0 && (!P || p_pitch >= M), "solve: bad sizes (p_pitch >= M)");
     const int nmax_lim = sizeof(T) == 8 ? 32 : 64;
     if (N > nmax_lim) {
         set_error("solve: N=%d exceeds the register-resident limit (%d) for this precision", N, nmax_lim);
@@ -136,7 +174,7 @@ static int solve_impl(const void* P, long p_pitch, int one_minus, int adjoint, c
     }
     if (B == 0 || M == 0) return FL_OK;
     hipStream_t st = (hipStream_t)stream;
-#define FL_SOLVE(NM) return launch_solve<T, NM>(P, p_pitch, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, st)
+#define FL_SOLVE(NM) return launch_solve<T, NM>(P, p_pitch, dud, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, st)
     if (N <= 4) FL_SOLVE(4);
     if (N <= 8) FL_SOLVE(8);
     if (N <= 16) FL_SOLVE(16);
@@ -153,10 +191,26 @@ using namespace fl;
 extern "C" {
 int fl_solve_c64(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
                  long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
-    return solve_impl<float>(P, p_pitch, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+    Dud<float> none = {};
+    return solve_impl<float>(P, p_pitch, none, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
 }
 int fl_solve_c128(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
                   long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
-    return solve_impl<double>(P, p_pitch, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+    Dud<double> none = {};
+    return solve_impl<double>(P, p_pitch, none, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+int fl_solve_dud_c64(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, int adjoint,
+                     const void* R, long rs_b, long rs_n, long rs_k, void* OUT, long os_b, long os_n, long os_k,
+                     int B, int M, int N, int K, void* stream) {
+    FL_REQUIRE(U, "solve_dud: null mixing matrix");
+    Dud<float> d = {(const cx<float>*)l, l_sn, l_sf, (const cx<float>*)U, (const cx<float>*)r, r_sn, r_sf};
+    return solve_impl<float>(nullptr, 0, d, 1, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+int fl_solve_dud_c128(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, int adjoint,
+                      const void* R, long rs_b, long rs_n, long rs_k, void* OUT, long os_b, long os_n, long os_k,
+                      int B, int M, int N, int K, void* stream) {
+    FL_REQUIRE(U, "solve_dud: null mixing matrix");
+    Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf};
+    return solve_impl<double>(nullptr, 0, d, 1, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
 }
 }

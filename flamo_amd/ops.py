@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["rfft", "irfft", "mimo", "solve", "delay_response", "sos_response", "geq_sections", "to_planar", "set_bin_shard",
+__all__ = ["rfft", "irfft", "mimo", "solve", "delay_response", "sos_response", "geq_sections", "solve_dud", "to_planar", "set_bin_shard",
            "bin_shard"]
 
 
@@ -400,6 +400,21 @@ def _gradh_launch(G, X, diag, scale=1.0):
     return dH
 
 
+def _gradw_launch(G, X):
+    """sum over batch, trailing dims AND bins of G x conj(X): (No, Ni) -- gradient of a
+    frequency-independent matrix, reduced in the kernel."""
+    real = _rdtype(X)
+    B, M, Ni, K, xs_b, xs_n, xs_k = _bnk(X)
+    _, _, No, _, gs_b, gs_m, gs_k = _bnk(G)
+    L = _lib.lib()
+    nblk = L.fl_mimo_gradw_blocks(M)
+    part = torch.empty((nblk, No, Ni), dtype=X.dtype, device=X.device)
+    fn = L.fl_mimo_gradw_c64 if real == torch.float32 else L.fl_mimo_gradw_c128
+    _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, part.data_ptr(), B, M, No, Ni, K,
+                  _stream()), "mimo_gradw")
+    return part.sum(dim=0)
+
+
 class _Mimo(torch.autograd.Function):
     @staticmethod
     def forward(ctx, H, X, diag):
@@ -429,8 +444,11 @@ class _Mimo(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gX = _mimo_launch(Hp, per_bin, diag, True, gY)
         if ctx.needs_input_grad[0]:
-            g = _gradh_launch(gY, Xp, diag)  # planar (.., M)
-            gH = g.movedim(-1, 0) if per_bin else g.sum(dim=-1)
+            if per_bin or diag:
+                g = _gradh_launch(gY, Xp, diag)  # planar (.., M)
+                gH = g.movedim(-1, 0) if per_bin else g.sum(dim=-1)
+            else:
+                gH = _gradw_launch(gY, Xp)       # frequency-independent matrix: reduced over bins in-kernel
         return gH, gX, None
 
 
@@ -493,6 +511,79 @@ def solve(P: torch.Tensor, R: torch.Tensor, one_minus: bool = True) -> torch.Ten
     if P.dtype != R.dtype:
         P = P.to(R.dtype)
     return _Solve.apply(P, R, bool(one_minus))
+
+
+def _diag_args(d: Optional[torch.Tensor]):
+    """(ptr, s_n, s_f) of an optional diagonal factor: per-bin (M, N), constant (N,) or None."""
+    if d is None:
+        return None, 0, 0
+    if d.dim() == 1:
+        return d.data_ptr(), d.stride(0), 0
+    return d.data_ptr(), d.stride(1), d.stride(0)
+
+
+def _solve_dud_launch(l, U, r, adjoint, R):
+    real = _rdtype(R)
+    B, M, N, K, rs_b, rs_n, rs_k = _bnk(R)
+    OUT = _empty_planar(R.shape, R.dtype, R.device)
+    _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
+    L = _lib.lib()
+    fn = L.fl_solve_dud_c64 if real == torch.float32 else L.fl_solve_dud_c128
+    lp, l_sn, l_sf = _diag_args(l)
+    rp, r_sn, r_sf = _diag_args(r)
+    _lib.check(fn(lp, l_sn, l_sf, U.data_ptr(), rp, r_sn, r_sf, int(adjoint), R.data_ptr(), rs_b, rs_n, rs_k,
+                  OUT.data_ptr(), os_b, os_n, os_k, B, M, N, K, _stream()), "solve_dud")
+    return OUT
+
+
+class _SolveDUD(torch.autograd.Function):
+    """OUT = (I - diag(l) U diag(r))^-1 R per bin; l, r: per-bin (M,N) / constant (N,) / None."""
+
+    @staticmethod
+    def forward(ctx, l, U, r, R):
+        _require_gpu(U, R)
+        Rp = to_planar(R.resolve_conj())
+        Uc = U.resolve_conj().contiguous()
+        lp = None if l is None else (_h_planar(l.resolve_conj(), True) if l.dim() == 2 else l.resolve_conj().contiguous())
+        rp = None if r is None else (_h_planar(r.resolve_conj(), True) if r.dim() == 2 else r.resolve_conj().contiguous())
+        OUT = _solve_dud_launch(lp, Uc, rp, False, Rp)
+        ctx.have = (l is not None, r is not None)
+        ctx.save_for_backward(*([t for t in (lp, rp) if t is not None] + [Uc, OUT]))
+        return OUT
+
+    @staticmethod
+    def backward(ctx, gOUT):
+        saved = list(ctx.saved_tensors)
+        lp = saved.pop(0) if ctx.have[0] else None
+        rp = saved.pop(0) if ctx.have[1] else None
+        Uc, OUT = saved
+        gR = _solve_dud_launch(lp, Uc, rp, True, to_planar(gOUT.resolve_conj()))          # A^-H g
+        gl = gU = gr = None
+        need_l, need_U, need_r = ctx.needs_input_grad[0] and lp is not None, ctx.needs_input_grad[1], \
+            ctx.needs_input_grad[2] and rp is not None
+        if need_l or need_U or need_r:
+            # dP_ij = sum_b gR_i conj(out_j) with P_ij = l_i U_ij r_j, contracted without forming dP:
+            t1 = OUT if rp is None else _mimo_launch(rp, rp.dim() == 2, True, False, OUT)   # r * out
+            t2 = gR if lp is None else _mimo_launch(lp, lp.dim() == 2, True, True, gR)      # conj(l) * gR
+            if need_U:
+                gU = _gradw_launch(t2, t1)                                                  # sum_f,b t2_i conj(t1_j)
+            if need_l:
+                v = _mimo_launch(Uc, False, False, False, t1)                               # U (r*out)
+                g = _gradh_launch(gR, v, True)                                              # (N, M): sum_b gR conj(v)
+                gl = g.movedim(-1, 0) if lp.dim() == 2 else g.sum(dim=-1)
+            if need_r:
+                w = _mimo_launch(Uc, False, False, True, t2)                                # U^H (conj(l)*gR)
+                g = _gradh_launch(w, OUT, True)                                             # sum_b w conj(out)
+                gr = g.movedim(-1, 0) if rp.dim() == 2 else g.sum(dim=-1)
+        return gl, gU, gr, (gR if ctx.needs_input_grad[3] else None)
+
+
+def solve_dud(l: Optional[torch.Tensor], U: torch.Tensor, r: Optional[torch.Tensor], R: torch.Tensor) -> torch.Tensor:
+    """Per bin f: (I - diag(l[f]) U diag(r[f]))^-1 R[:, f] -- the closed loop of a feedback delay
+    network, with the loop matrix kept in factored form (never materialised)."""
+    cd = R.dtype
+    conv = lambda t: None if t is None else (t if t.dtype == cd else t.to(cd))  # noqa: E731
+    return _SolveDUD.apply(conv(l), conv(U), conv(r), R)
 
 
 # ----------------------------------------------------------------------------- responses

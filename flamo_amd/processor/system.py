@@ -39,6 +39,14 @@ def _as_signal(H: torch.Tensor, diag: bool, M: int) -> torch.Tensor:
     return H.unsqueeze(0)
 
 
+def _diag_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """product of two diagonal responses, each per-bin (M, N) or constant (N,)"""
+    if a.dtype != b.dtype:
+        cd = torch.promote_types(a.dtype, b.dtype)
+        a, b = a.to(cd), b.to(cd)
+    return a * b
+
+
 def _compose(acc, nxt, M: int):
     """(H2, diag2) after (H1, diag1): the response of the cascade."""
     H1, d1 = acc
@@ -244,10 +252,44 @@ class Recursion(nn.Module):
                 elif "feedforward" in key:
                     ext_ff = param
         R = self.feedforward(X, ext_ff)
-        # loop matrix P = F(B(I)) for ONE batch element (it does not depend on the batch)
+        if FUSE_SERIES and ext_param is None and torch.is_tensor(R) and R.is_cuda:
+            dud = self.__factored_loop(R)
+            if dud is not None:
+                # FDN structure: P = diag(l) U diag(r) stays factored, A = I - P is built in registers
+                return ops.solve_dud(dud[0], dud[1], dud[2], R)
+        # generic loop: P = F(B(I)) for ONE batch element (it does not depend on the batch)
         I = self.__identity_like(R)
         P = self.feedforward(self.feedback(I, ext_fb), ext_ff)
         return ops.solve(P, R, one_minus=True)
+
+    def __factored_loop(self, R):
+        """If feedback-then-feedforward is a chain of per-bin modules with exactly one full,
+        frequency-independent matrix U and otherwise diagonal factors (the structure of every FDN
+        in flamo: delays and attenuation are diagonal, only the mixing matrix is full), return
+        (l, U, r) with P = diag(l) U diag(r); else None."""
+        chain = []
+        for path in (self.feedback, self.feedforward):        # applied in this order to the identity
+            mods = list(path) if isinstance(path, Series) else [path]
+            for m in mods:
+                if not (hasattr(m, "_fusable") and m._fusable()):
+                    return None
+                chain.append(m)
+        M = R.shape[1]
+        shape = [1, M, self.output_channels, self.output_channels]
+        l = r = U = None
+        for m in chain:
+            H, diag = m._response_for_fusion(shape, None)
+            shape[2] = m.output_channels
+            if diag:
+                if U is None:
+                    r = H if r is None else _diag_mul(H, r)
+                else:
+                    l = H if l is None else _diag_mul(H, l)
+            else:
+                if U is not None or H.dim() != 2 or H.shape[0] != H.shape[1]:
+                    return None                                    # second full / per-bin full / non-square
+                U = H
+        return None if U is None else (l, U, r)
 
     def __identity_like(self, R: torch.Tensor) -> torch.Tensor:
         """(1, M_local, N, N) identity spectrum, bin-planar, cached per (device, dtype, bins)."""

@@ -141,6 +141,15 @@ int fl_mimo_gradh_diag_c128(const void* G, long gs_b, long gs_n, long gs_k,
                             const void* X, long xs_b, long xs_n, long xs_k,
                             void* dh, long dh_pitch, int B, int M, int N, int K, void* stream);
 
+/* dW[m,n] = sum_{b,k,f} G[b,m,k,f] * conj(X[b,n,k,f]): gradient of a frequency-independent matrix
+ * (Gain/Matrix, dsp.py:466-468; the FDN mixing matrix) with the reduction over bins done in the
+ * kernel.  part: complex (nblk, No, Ni), nblk = fl_mimo_gradw_blocks(M); the caller sums over nblk. */
+int fl_mimo_gradw_blocks(int M);
+int fl_mimo_gradw_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                      void* part, int B, int M, int No, int Ni, int K, void* stream);
+int fl_mimo_gradw_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                       void* part, int B, int M, int No, int Ni, int K, void* stream);
+
 /* ------------------------------------------------------------------ frequency responses
  * Integer delay lines, Delay/parallelDelay.get_freq_response with isint=True
  * (dsp.py:3356-3365, 3512-3521):  H[c, f] = amp[c] * exp(-2 pi i ((bin0+f) * m[c] mod nfft) / nfft)
@@ -198,6 +207,19 @@ int fl_solve_c128(const void* P, long p_pitch, int one_minus, int adjoint,
                   const void* R, long rs_b, long rs_n, long rs_k,
                   void* OUT, long os_b, long os_n, long os_k,
                   int B, int M, int N, int K, void* stream);
+
+/* Same solve with the loop matrix given in the factored form every feedback delay network has
+ * (reverb.py:117-199, e8_fdn.py:60-100: delays and attenuation filters are diagonal, only the
+ * mixing matrix is full):  A_f = I - diag(l[:,f]) U diag(r[:,f]),  U frequency independent (N x N,
+ * row major), l / r per-bin (element (n,f) at n*sn + f*sf), constant (sf = 0) or absent (NULL = 1).
+ * A is built in registers from 2N values per bin; the N^2-per-bin matrix of system.py:420-424 is
+ * never formed.  adjoint != 0 solves with A_f^H (backward). */
+int fl_solve_dud_c64(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, int adjoint,
+                     const void* R, long rs_b, long rs_n, long rs_k, void* OUT, long os_b, long os_n, long os_k,
+                     int B, int M, int N, int K, void* stream);
+int fl_solve_dud_c128(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, int adjoint,
+                      const void* R, long rs_b, long rs_n, long rs_k, void* OUT, long os_b, long os_n, long os_k,
+                      int B, int M, int N, int K, void* stream);
 
 #ifdef __cplusplus
 }

@@ -145,3 +145,39 @@ def test_bin_sharded_core_equals_full_core(gpu):
             finally:
                 ops.set_bin_shard(0, None)
     assert relerr(torch.cat(parts, dim=1), full) < 1e-14
+
+
+def test_factored_fdn_loop_matches_generic_recursion(gpu):
+    """Recursion with P = diag(l) U diag(r) kept factored (ops.solve_dud) against the generic path
+    that materialises P = F(B(I)) and calls ops.solve: outputs and all gradients, vector and
+    matrix right-hand sides, diagonal factors on both sides of the mixing matrix."""
+    from collections import OrderedDict
+    from flamo_amd.processor import dsp, system
+    torch.manual_seed(17)
+    nfft, N = 960, 6
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, 2e-5)):
+        kw = dict(nfft=nfft, alias_decay_db=30.0, device=gpu, dtype=dt)
+        dl = dsp.parallelDelay(size=(N,), max_len=170, isint=True, **kw)
+        pre = dsp.parallelGain(size=(N,), requires_grad=True, **kw)
+        mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+        att = dsp.parallelGEQ(size=(N,), requires_grad=True, **kw)
+        with torch.no_grad():
+            att.param.mul_(0.5)
+            pre.param.copy_(torch.rand(N, device=gpu, dtype=dt) * 0.5 + 0.4)
+        fb = system.Series(OrderedDict(pre=pre, mix=mix, att=att))
+        rec = system.Recursion(fF=dl, fB=fb)
+        params = [pre.param, mix.param, att.param]
+        M = nfft // 2 + 1
+        for shape in ((3, M, N), (1, M, N, N)):
+            X = torch.randn(*shape, dtype=CDT[dt], device=gpu, requires_grad=True)
+            C = torch.randn(*shape, dtype=CDT[dt], device=gpu)
+            res = {}
+            for fuse in (True, False):
+                system.FUSE_SERIES = fuse
+                try:
+                    Y = rec(X)
+                    res[fuse] = [Y.detach()] + list(torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C))), [X] + params))
+                finally:
+                    system.FUSE_SERIES = True
+            for a, b in zip(res[True], res[False]):
+                assert relerr(a, b) < tol

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Secondary benchmark: BASELINE configs[2] -- 16-channel FDN (e8_fdn.py structure), nfft=192000,
+Gain(16,1) -> Recursion(fF=parallelDelay(isint), fB=Series(Matrix orthogonal, parallelGEQ)) -> Gain(1,16),
+FFT / iFFTAntiAlias(30 dB); forward + backward of (y*c).sum() with all parameter gradients.
+Prints bin-solves/s (B*M / time) for float32 and float64.   python tools/bench_fdn.py [--batch B]"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+from collections import OrderedDict
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def build(dev, dtype, N=16, nfft=192000, db=30.0):
+    from flamo_amd.processor import dsp, system
+    kw = dict(nfft=nfft, alias_decay_db=db, device=dev, dtype=dtype)
+    delays = torch.tensor([503, 593, 701, 811, 919, 1031, 1151, 1259, 1381, 1493, 1613, 1741, 1873, 2003, 2381, 2713][:N])
+    ig = dsp.Gain(size=(N, 1), requires_grad=True, **kw)
+    og = dsp.Gain(size=(1, N), requires_grad=True, **kw)
+    dl = dsp.parallelDelay(size=(N,), max_len=3000, isint=True, **kw)
+    dl.assign_value(dl.sample2s(delays.to(dev, dtype)))
+    mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+    att = dsp.parallelGEQ(size=(N,), requires_grad=True, **kw)
+    att.map = lambda x: 20 * torch.log10(torch.sigmoid(x))
+    with torch.no_grad():
+        att.param.copy_(torch.randn_like(att.param) * 0.3 + 2.0)
+    fb = system.Series(OrderedDict(mixing_matrix=mix, attenuation=att))
+    core = system.Series(OrderedDict(input_gain=ig, feedback_loop=system.Recursion(fF=dl, fB=fb), output_gain=og))
+    model = system.Shell(core, dsp.FFT(nfft, dtype=dtype), dsp.iFFTAntiAlias(nfft, alias_decay_db=db, device=dev, dtype=dtype))
+    return model, [ig.param, og.param, mix.param, att.param]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--dtype", default="both")
+    args = ap.parse_args()
+    warnings.simplefilter("ignore")
+    dev = torch.device("cuda:0")
+    nfft, N = 192000, 16
+    out = {}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        if args.dtype not in ("both", name):
+            continue
+        torch.manual_seed(130709)
+        model, params = build(dev, dt, N, nfft)
+        x = torch.randn(args.batch, nfft, 1, device=dev, dtype=dt)
+        c = torch.randn(args.batch, nfft, 1, device=dev, dtype=dt)
+
+        def step():
+            for p in params:
+                p.grad = None
+            y = model(x)
+            (y * c).sum().backward()
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        out[name] = {"ms_per_step": ms, "bin_solves_per_s": args.batch * (nfft // 2 + 1) / (ms * 1e-3)}
+        # the same step replayed from a HIP graph (launch overhead removed)
+        from flamo_amd.graph import GraphedStep
+        gs = GraphedStep(lambda xx: (model(xx) * c).sum(), (x,), params)
+        ref = [p.grad.clone() for p in params]
+        gs(x)
+        torch.cuda.synchronize()
+        err = max(((a - b).norm() / b.norm()).item() for a, b in zip(gs.grads, ref))
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gs(x)
+        torch.cuda.synchronize()
+        msg = (time.perf_counter() - t0) / args.steps * 1e3
+        out[name].update(graph_ms_per_step=msg, graph_bin_solves_per_s=args.batch * (nfft // 2 + 1) / (msg * 1e-3),
+                         graph_vs_eager_grad_relerr=err)
+    print(json.dumps({"workload": f"16-ch FDN, nfft={nfft}, batch {args.batch}, fwd+bwd", **out}))
+
+
+if __name__ == "__main__":
+    main()
