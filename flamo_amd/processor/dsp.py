@@ -25,7 +25,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..functional import (GEQDesign, HadamardMatrix, RotationMatrix, bandpass_filter, eq_freqs, highpass_filter,
-                          lowpass_filter, rad2hertz, skew_matrix)
+                          lowpass_filter, matrix_exp_capturable, rad2hertz, skew_matrix)
 from ..utils import to_complex
 
 _identity = lambda x: x  # noqa: E731
@@ -280,7 +280,9 @@ class Matrix(Gain):
             self.map = _identity
         elif kind == "orthogonal":
             assert N == self.size[1], "Matrix must be square to be orthogonal"
-            self.map = lambda x: torch.matrix_exp(skew_matrix(x))
+            # exp of the skew part (dsp.py:649); fixed-schedule evaluation so that a step can be
+            # captured in a HIP graph (torch.matrix_exp synchronises with the host)
+            self.map = lambda x: matrix_exp_capturable(skew_matrix(x))
         elif kind == "hadamard":
             assert N == self.size[1], "Matrix must be square to be Hadamard"
             assert N % 2 == 0, "Matrix must have even dimensions to be Hadamard"
