@@ -31,6 +31,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 NFFT, NCH, BATCH = 96000, 8, 32
+# HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r01g_pmc_hbm_traffic.csv,
+# grid 393216 = the batch-32 launch): 2*FETCH_SIZE + WRITE_SIZE.  A static number measured by rocprofv3,
+# not re-measured by every bench run.
+PMC_TRAFFIC_BYTES = 231.7e6
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -95,6 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="time eager steps instead of replaying the step from a HIP graph")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     args = ap.parse_args()
     warnings.simplefilter("ignore")
@@ -116,7 +122,7 @@ def main():
     torch.manual_seed(130709 + 1 + rank)
     x = torch.randn(BATCH, NFFT, NCH, device=dev, dtype=dtype)   # resident in HBM before timing
 
-    def step():
+    def eager_step():
         for p in params:
             p.grad = None
         y = model(x)
@@ -127,6 +133,22 @@ def main():
             dist.all_reduce(flat)                       # RCCL; < 4 KB of parameter gradients
         return loss
 
+    step = eager_step
+    if not args.no_graph:
+        # The step is ~45 launches of which a dozen carry the work: replaying it from a HIP graph
+        # takes the Python / launch overhead (about as long as the GPU work itself, and sensitive
+        # to host jitter) out of the loop.  Forward + backward are captured once; the tiny RCCL
+        # gradient all-reduce stays eager after each replay.
+        from flamo_amd.graph import GraphedStep
+        gs = GraphedStep(lambda xx: (model(xx) ** 2).mean(), (x,), params, warmup=2)
+
+        def step():
+            loss = gs.replay()
+            if dist_on:
+                flat = torch.cat([p.grad.reshape(-1) for p in params])
+                dist.all_reduce(flat)
+            return loss
+
     def fence():
         if dist_on:
             dist.barrier()
@@ -135,13 +157,24 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ops.kernel_timer.reset(enabled=(rank == 0))
+    ops.kernel_timer.reset(enabled=(rank == 0 and args.no_graph))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
     ops.kernel_timer.enabled = False
+    roof_steps = args.steps
+    if not args.no_graph and rank == 0:
+        # HIP events cannot be read back from inside a captured graph: the dominant kernel's launch
+        # time is taken with events on the launch stream in eager steps of the same workload, run by
+        # this same command right after the timed replays (rocprofv3 --stats sees both alike)
+        roof_steps = min(args.steps, 10)
+        ops.kernel_timer.reset(enabled=True)
+        for _ in range(roof_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        ops.kernel_timer.enabled = False
     if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -162,11 +195,17 @@ def main():
             roof = {"bound": "hbm", "kernel": "mimo_full_kernel<float,8,4>: Y[b,f,:] = H[f] X[b,f,:] over the whole batch (the per-bin "
                               "complex einsum fmn,bfn->bfm; H = GEQ[f] @ Matrix folded by the Series)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes": alg_bytes, "launch_ms": mean_ms, "launches": n}
+                    "traffic": PMC_TRAFFIC_BYTES, "algorithmic_bytes": alg_bytes, "launch_ms": mean_ms, "launches": n,
+                    "events": "HIP events on the launch stream, " + ("inside the timed eager steps" if args.no_graph else
+                              f"{roof_steps} eager steps run by this command right after the timed graph replays"),
+                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per "
+                                      "MI355X_MICROARCH.md; profiles/r01g_pmc_hbm_traffic.csv"}
         out = {"metric": "freq-bin*channel products/sec (fwd+bwd), nfft=96000 8x8ch", "value": products_per_step / (ms * 1e-3),
                "unit": "products/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+               "timed_region": ("eager steps" if args.no_graph else
+                                "HIP-graph replays of forward+backward (torch.cuda.CUDAGraph), one replay per step"),
                "config": {"workload": "BASELINE configs[1]: Shell(FFT -> Series(Matrix 8x8, GEQ 8x8) -> iFFT), nfft=96000, "
                                       "batch 32 per GPU, fwd+bwd of (y**2).mean(), parameter grads",
                           "nfft": NFFT, "channels": NCH, "batch_per_gpu": BATCH, "parallelism": f"dp{world} (batch)",

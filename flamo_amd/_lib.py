@@ -33,6 +33,8 @@ _SIGNATURES = {
     "fl_debug_set_fft_fast": (_i, [_i]),
     "fl_rfft_f32": (_i, [_vp, _l, _i, _vp, _l, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
     "fl_rfft_f64": (_i, [_vp, _l, _i, _vp, _l, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
+    "fl_rfft_ci_f32": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
+    "fl_rfft_ci_f64": (_i, [_vp, _i, _i, _vp, _l, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
     "fl_irfft_f32": (_i, [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
     "fl_irfft_f64": (_i, [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
     "fl_transpose": (_i, [_vp, _vp, _i, _i, _i, _l, _i, _vp]),

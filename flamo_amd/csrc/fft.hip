@@ -31,9 +31,11 @@ struct Rad {
 
 template <typename T>
 struct FftArgs {
-    const T* xr;        // LOAD_PACK source (real, signal-planar)
+    const T* xr;        // LOAD_PACK source (real): signal-planar, or channel-innermost when ci_n > 0
     long xr_stride;
     int t_in;
+    int ci_n;           // > 0: x is (B, ci_T, ci_n) contiguous, signal sig = b*ci_n + n, sample t at ((b*ci_T + t)*ci_n + n)
+    int ci_T;
     const cx<T>* Xc;    // LOAD_IRFFT_PRE source (half spectrum, L+1 bins per signal)
     cx<T>* Xout;        // EPI_RFFT_POST destination
     T* yr;              // EPI_IRFFT_STORE destination
@@ -44,6 +46,7 @@ struct FftArgs {
     const cx<T>* W;     // W_n^j, j in [0,n)
     int n, L, L1, L2, L1P, L2P, CT, RT, ntiles;
     int per;            // LDS slots per primary row in pass 2 (2 when mirror rows are held)
+    int nsig;
     T scale;
     double env_log2;
     int interior;       // rfft: double interior bins; irfft: halve interior bins
@@ -196,10 +199,18 @@ __device__ inline float envelope<float>(double env_log2, int t) {
 // packed half-length sequence of a real signal: z[j] = x[2j] e(2j) + i x[2j+1] e(2j+1)
 template <typename T>
 __device__ inline cx<T> load_pack(const FftArgs<T>& a, int sig, int j) {
-    const T* x = a.xr + (size_t)sig * a.xr_stride;
     const int t = 2 * j;
-    T re = (t < a.t_in) ? x[t] : (T)0;
-    T im = (t + 1 < a.t_in) ? x[t + 1] : (T)0;
+    T re, im;
+    if (a.ci_n > 0) {   // channel-innermost source: the layout conversion is fused into this load
+        const int b = sig / a.ci_n, n = sig - b * a.ci_n;
+        const T* x = a.xr + ((size_t)b * a.ci_T) * a.ci_n + n;
+        re = (t < a.t_in) ? x[(size_t)t * a.ci_n] : (T)0;
+        im = (t + 1 < a.t_in) ? x[(size_t)(t + 1) * a.ci_n] : (T)0;
+    } else {
+        const T* x = a.xr + (size_t)sig * a.xr_stride;
+        re = (t < a.t_in) ? x[t] : (T)0;
+        im = (t + 1 < a.t_in) ? x[t + 1] : (T)0;
+    }
     if (a.env_log2 != 0.0) {
         re *= envelope<T>(a.env_log2, t);
         im *= envelope<T>(a.env_log2, t + 1);
@@ -233,6 +244,25 @@ __device__ inline cx<T> load_any(const FftArgs<T>& a, int sig, int j) {
     return a.scratch[(size_t)sig * a.L + j];
 }
 
+// Block -> (column tile, signal).  With a channel-innermost source the ci_n signals of one batch
+// item read the SAME cache lines (each uses 1/ci_n of every line), so their blocks are given
+// consecutive slots on the same XCD (block q runs on XCD q % 8): the first one pulls the lines
+// from HBM into that XCD's L2, the others hit there.
+template <typename T>
+__device__ inline bool cols_block(const FftArgs<T>& a, int nsig, int& tile, int& sig) {
+    if (a.ci_n > 0) {
+        const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+        const int n = r % a.ci_n, p = (r / a.ci_n) * 8 + xcd;   // p indexes (batch item, tile) pairs
+        tile = p % a.ntiles;
+        const int b = p / a.ntiles;
+        sig = b * a.ci_n + n;
+        return sig < nsig;
+    }
+    tile = blockIdx.x % a.ntiles;
+    sig = blockIdx.x / a.ntiles;
+    return true;
+}
+
 // ---------------------------------------------------------------- pass 1: column FFTs
 template <typename T, int LOAD, bool INV>
 __global__ void __launch_bounds__(256) fft_cols(FftArgs<T> a) {
@@ -240,7 +270,8 @@ __global__ void __launch_bounds__(256) fft_cols(FftArgs<T> a) {
     cx<T>* buf0 = reinterpret_cast<cx<T>*>(smem);
     cx<T>* buf1 = buf0 + a.CT * a.L1P;
     cx<T>* tw = buf1 + a.CT * a.L1P;
-    const int tile = blockIdx.x % a.ntiles, sig = blockIdx.x / a.ntiles;
+    int tile, sig;
+    if (!cols_block(a, a.nsig, tile, sig)) return;
     const int c0 = tile * a.CT;
     const int nc = min(a.CT, a.L2 - c0);
     const int twstep = a.n / a.L1;
@@ -499,7 +530,8 @@ __global__ void __launch_bounds__(256) fft_cols_fast(FftArgs<T> a) {
     constexpr int LEN = A * B, LENP = LEN | 1;
     cx<T>* U = reinterpret_cast<cx<T>*>(smem);   // [FAST_CT][LENP]
     cx<T>* tw = U + FAST_CT * LENP;               // W_LEN^m
-    const int tile = blockIdx.x % a.ntiles, sig = blockIdx.x / a.ntiles;
+    int tile, sig;
+    if (!cols_block(a, a.nsig, tile, sig)) return;
     const int c0 = tile * FAST_CT;
     const int nc = min(FAST_CT, a.L2 - c0);
     const int twstep = a.n / LEN;
@@ -830,12 +862,22 @@ static int make_plan(int nfft, bool f64, Plan& p) {
 }
 
 template <typename T>
+static size_t cols_grid(const FftArgs<T>& a, int nsig) {
+    if (a.ci_n > 0) {
+        const size_t pairs = (size_t)a.ntiles * (nsig / a.ci_n);
+        return (pairs + 7) / 8 * 8 * a.ci_n;
+    }
+    return (size_t)a.ntiles * nsig;
+}
+
+template <typename T>
 static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipStream_t st) {
     const int esz = (int)sizeof(cx<T>);
     const int budget = LDS_BUDGET / esz;  // complex elements of LDS
     a.n = p.n; a.L = p.L; a.L1 = p.L1; a.L2 = p.L2;
     a.L1P = p.L1 | 1; a.L2P = p.L2 | 1;
     a.rad1 = p.rad1; a.rad2 = p.rad2;
+    a.nsig = nsig;
     if (nsig <= 0) return FL_OK;
     const bool use_fast = g_fast_enabled && p.L1 > 1 && fast_split(p.L1) && fast_split(p.L2);
     if (p.L1 > 1) {
@@ -844,7 +886,7 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
             a.CT = FAST_CT;
             a.ntiles = cdiv_i(p.L2, FAST_CT);
             const size_t lds = (size_t)(FAST_CT * a.L1P + p.L1) * esz;
-            const size_t nblk = (size_t)a.ntiles * nsig;
+            const size_t nblk = cols_grid(a, nsig);
             FL_REQUIRE(nblk < (1ull << 31), "grid too large");
             FL_FAST_DISPATCH(launch_cols_fast, p.L1, inverse, a, (unsigned)nblk, lds, st)
             FL_CHECK_LAUNCH("fft_cols_fast");
@@ -855,7 +897,7 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
             a.CT = ct;
             a.ntiles = cdiv_i(p.L2, ct);
             const size_t lds = (size_t)(2 * ct * a.L1P + p.L1) * esz;
-            const size_t nblk = (size_t)a.ntiles * nsig;
+            const size_t nblk = cols_grid(a, nsig);
             FL_REQUIRE(nblk < (1ull << 31), "grid too large");
             if (inverse)
                 hipLaunchKernelGGL((fft_cols<T, LOAD_IRFFT_PRE, true>), dim3((unsigned)nblk), dim3(256), lds, st, a);
@@ -915,8 +957,8 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
 }
 
 template <typename T>
-static int rfft_impl(const void* x, long x_sig_stride, int t_in, void* X, long X_sig_stride, void* scratch, const void* W,
-                     int nsig, int nfft, double scale, double env_log2, int interior_x2, void* stream) {
+static int rfft_impl(const void* x, long x_sig_stride, int ci_n, int t_in, void* X, long X_sig_stride, void* scratch,
+                     const void* W, int nsig, int nfft, double scale, double env_log2, int interior_x2, void* stream) {
     Plan p;
     int rc = make_plan(nfft, sizeof(T) == 8, p);
     if (rc) return rc;
@@ -927,6 +969,11 @@ static int rfft_impl(const void* x, long x_sig_stride, int t_in, void* X, long X
     a.xr = (const T*)x;
     a.xr_stride = x_sig_stride;
     a.t_in = t_in < nfft ? t_in : nfft;
+    if (ci_n > 0) {
+        FL_REQUIRE(nsig % ci_n == 0, "rfft: nsig must be a multiple of the channel count for a channel-innermost source");
+        a.ci_n = ci_n;
+        a.ci_T = t_in;
+    }
     a.Xout = (cx<T>*)X;
     FL_REQUIRE(X_sig_stride >= nfft / 2 + 1, "rfft: X_sig_stride must be >= nfft/2+1");
     a.xc_stride = X_sig_stride;
@@ -1007,11 +1054,21 @@ int fl_debug_set_fft_fast(int enabled) {
 
 int fl_rfft_f32(const void* x, long xs, int t_in, void* X, long Xs, void* scratch, const void* W, int nsig, int nfft,
                 double scale, double env_log2, int interior_x2, void* stream) {
-    return rfft_impl<float>(x, xs, t_in, X, Xs, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
+    return rfft_impl<float>(x, xs, 0, t_in, X, Xs, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
+}
+int fl_rfft_ci_f32(const void* x, int n_chan, int t_in, void* X, long Xs, void* scratch, const void* W, int nsig, int nfft,
+                   double scale, double env_log2, int interior_x2, void* stream) {
+    FL_REQUIRE(n_chan > 0, "rfft_ci: n_chan must be positive");
+    return rfft_impl<float>(x, 0, n_chan, t_in, X, Xs, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
 }
 int fl_rfft_f64(const void* x, long xs, int t_in, void* X, long Xs, void* scratch, const void* W, int nsig, int nfft,
                 double scale, double env_log2, int interior_x2, void* stream) {
-    return rfft_impl<double>(x, xs, t_in, X, Xs, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
+    return rfft_impl<double>(x, xs, 0, t_in, X, Xs, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
+}
+int fl_rfft_ci_f64(const void* x, int n_chan, int t_in, void* X, long Xs, void* scratch, const void* W, int nsig, int nfft,
+                   double scale, double env_log2, int interior_x2, void* stream) {
+    FL_REQUIRE(n_chan > 0, "rfft_ci: n_chan must be positive");
+    return rfft_impl<double>(x, 0, n_chan, t_in, X, Xs, scratch, W, nsig, nfft, scale, env_log2, interior_x2, stream);
 }
 int fl_irfft_f32(const void* X, long Xs, void* y, long ys, int t_out, void* scratch, const void* W, int nsig, int nfft,
                  double scale, double env_log2, int interior_half, void* stream) {

@@ -80,6 +80,14 @@ int fl_rfft_f32(const void* x, long x_sig_stride, int t_in, void* X, long X_sig_
 int fl_rfft_f64(const void* x, long x_sig_stride, int t_in, void* X, long X_sig_stride, void* scratch, const void* W,
                 int nsig, int nfft, double scale, double env_log2, int interior_x2, void* stream);
 
+/* Same transform reading the reference's channel-innermost time tensor directly: x is (B, t_in, n_chan)
+ * contiguous, signal sig = b*n_chan + n has sample t at x[(b*t_in + t)*n_chan + n]; nsig = B*n_chan.
+ * The layout conversion is fused into the first FFT pass (no separate transpose pass). */
+int fl_rfft_ci_f32(const void* x, int n_chan, int t_in, void* X, long X_sig_stride, void* scratch, const void* W,
+                   int nsig, int nfft, double scale, double env_log2, int interior_x2, void* stream);
+int fl_rfft_ci_f64(const void* x, int n_chan, int t_in, void* X, long X_sig_stride, void* scratch, const void* W,
+                   int nsig, int nfft, double scale, double env_log2, int interior_x2, void* stream);
+
 /* y[sig, t] = scale * e(t) * sum_k w_k' Re(v_k X[sig,k] exp(+2 pi i k t / nfft)),  t in [0, t_out)
  *   C2R semantics of torch.fft.irfft: w_k' = 1 for k in {0, nfft/2} (imaginary part ignored),
  *   2 otherwise; v_k = 1, or (interior_half != 0) 1/2 for interior bins (rfft's backward);

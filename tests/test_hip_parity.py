@@ -116,6 +116,20 @@ def test_fft_ragged_and_layouts(gpu):
         (g,) = torch.autograd.grad(torch.sum(torch.real(X * torch.conj(C.to(gpu)))), [x])
         (gr,) = torch.autograd.grad(torch.sum(torch.real(Xr * torch.conj(C))), [xr])
         assert g.shape == x.shape and relerr(g.cpu(), gr) < 1e-10
+    # channel-innermost source read directly by the first FFT pass (fl_rfft_ci_*), both plans
+    from flamo_amd import _lib
+    ops.CI_MAX_CHANNELS = 16
+    try:
+        for max_single in (0, 8):
+            _lib.lib().fl_debug_set_fft_max_single(max_single)
+            for T in (751, 1500, 1777):
+                x = torch.randn(3, T, 2, 2, dtype=torch.float64, device=gpu)
+                assert relerr(ops.rfft(x, nfft, "backward").cpu(), O.rfft(x.cpu(), nfft)) < 1e-10
+        xb = torch.randn(2, 96000, 8, dtype=torch.float32, device=gpu)       # fast kernels, XCD-grouped blocks
+        assert relerr(ops.rfft(xb, 96000).cpu(), O.rfft(xb.cpu().double(), 96000)) < 1e-5
+    finally:
+        ops.CI_MAX_CHANNELS = 0
+        _lib.lib().fl_debug_set_fft_max_single(0)
     # planar input (time axis contiguous) and empty batch
     xp = torch.randn(2, 3, nfft, dtype=torch.float64, device=gpu).movedim(-1, 1)
     assert relerr(ops.rfft(xp, nfft).cpu(), O.rfft(xp.cpu(), nfft)) < 1e-10
