@@ -48,19 +48,34 @@ def _diag_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def _compose(acc, nxt, M: int):
-    """(H2, diag2) after (H1, diag1): the response of the cascade."""
+    """(H2, diag2) after (H1, diag1): the response of the cascade, H2[f] @ H1[f] per bin.
+
+    The bin-planar memory of a per-bin response (N_out, N_in, M) IS the memory of a signal, so the
+    small matrix products run on the per-bin kernels without copies: left factors act on the
+    response read as a (1, M, N_out, N_in) signal, right factors on it read as (N_out, M, N_in)
+    (output channel as batch)."""
     H1, d1 = acc
     H2, d2 = nxt
     if H1.dtype != H2.dtype:
         cd = torch.promote_types(H1.dtype, H2.dtype)
         H1, H2 = H1.to(cd), H2.to(cd)
+    bin1, bin2 = H1.dim() == (2 if d1 else 3), H2.dim() == (2 if d2 else 3)
     if d1 and d2:
-        return H2 * H1, True                      # (M,N)*(N,), (N,)*(N,), ... broadcast
-    if H1.dim() == (1 if d1 else 2) and H2.dim() == (1 if d2 else 2):   # both frequency independent
+        return H2 * H1, True                                  # (M,N)*(N,), (N,)*(N,), ... broadcast
+    if not bin1 and not bin2:                                 # both frequency independent: tiny matmul
         A = torch.diag_embed(H2) if d2 else H2
         Bm = torch.diag_embed(H1) if d1 else H1
         return A @ Bm, False
-    return ops.mimo(H2, _as_signal(H1, d1, M), diag=d2)[0], False
+    if not d1 and bin1:                                       # per-bin full on the right: left-multiply it
+        return ops.mimo(H2, H1.unsqueeze(0), diag=d2)[0], False
+    if not d2 and bin2:                                       # per-bin full on the left: right-multiply it
+        S2 = H2.permute(1, 0, 2)                              # (N_out, M, N_mid): rows of H2 as batch items
+        R = ops.mimo(H1, S2, diag=True) if d1 else ops.mimo(H1.transpose(-1, -2), S2)
+        return R.permute(1, 0, 2), False
+    # a per-bin diagonal meets a constant full matrix: scale its rows / columns (one small pass)
+    if d2:                                                    # diag(h2[f]) W
+        return H2.unsqueeze(-1) * H1.unsqueeze(0), False
+    return H2.unsqueeze(0) * H1.unsqueeze(1), False           # W diag(h1[f])
 
 
 def _common_attribute(modules, attr, what="Series"):
