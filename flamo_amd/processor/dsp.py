@@ -570,6 +570,263 @@ class parallelGEQ(GEQ):
         assert len(self.size) == 2, "Filter must be 2D, for 3D filters use GEQ module."
 
 
+class SOSFilter(_SOSMixin, Filter):
+    """Cascade of second-order sections given directly by their coefficients, param
+    (n_sections, 6, N_out, N_in) = [b0, b1, b2, a0, a1, a2]; optional a0 normalisation
+    (dsp.py:1767-1964).  Not learnable in the reference (requires_grad=False)."""
+
+    def __init__(self, size: tuple = (1, 1), n_sections: int = 1, nfft: int = 2 ** 11, fs: int = 48000,
+                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32,
+                 normalize_a0: bool = True):
+        self.n_sections = n_sections
+        self.fs = fs
+        self.device = device
+        self.dtype = dtype
+        self.normalize_a0 = normalize_a0
+        self.alias_envelope_dcy = _gamma(alias_decay_db, nfft, device, dtype) ** torch.arange(0, 3, 1, device=device)
+        self.get_map()
+        super().__init__(size=(n_sections, *self.get_size(), *size), nfft=nfft, map=self.map, requires_grad=False,
+                         alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def get_size(self):
+        return (6,)
+
+    def get_map(self):
+        def mapping(x: torch.Tensor) -> torch.Tensor:
+            if not self.normalize_a0:
+                return x
+            a0 = x[:, 3:4]
+            eps = torch.finfo(x.dtype).eps
+            a0_safe = torch.where(torch.abs(a0) > eps, a0, eps * torch.ones_like(a0))
+            y = x / a0_safe                       # every coefficient divided by a0 ...
+            return torch.cat((y[:, :3], torch.ones_like(a0), y[:, 4:]), dim=1)   # ... and a0 itself set to 1
+
+        self.map = mapping
+
+    def init_param(self):
+        with torch.no_grad():
+            self.param.zero_()
+            self.param[:, 0] = 1.0
+            self.param[:, 3] = 1.0
+
+    def check_param_shape(self):
+        assert len(self.size) == 4, "Parameter size must be 4D, expected (K, 6, N_out, N_in)."
+        assert self.size[1] == 6, "Second dimension must be 6: [b0,b1,b2,a0,a1,a2]."
+
+    def _sos_coeffs(self, p):
+        return p[:, 0:3].transpose(0, 1), p[:, 3:6].transpose(0, 1)     # (3, K, ...)
+
+    def _probe_sos(self, z):
+        p = self.map(self.param)
+        g = self.alias_envelope_dcy.to(p.device)
+        zi = z ** (-1)
+        H = None
+        for k in range(p.shape[0]):
+            Bk = to_complex(p[k, 0]) * g[0] + to_complex(p[k, 1]) * g[1] * zi + to_complex(p[k, 2]) * g[2] * zi ** 2
+            Ak = to_complex(p[k, 3]) * g[0] + to_complex(p[k, 4]) * g[1] * zi + to_complex(p[k, 5]) * g[2] * zi ** 2
+            H = Bk / Ak if H is None else H * Bk / Ak
+        return H
+
+    def probe(self, z: torch.Tensor):
+        return self._probe_sos(z)
+
+
+class parallelSOSFilter(SOSFilter):
+    """Per-channel SOS cascades, param (n_sections, 6, N) (dsp.py:1967-2073)."""
+
+    _diag = True
+
+    def __init__(self, size: tuple = (1,), n_sections: int = 1, nfft: int = 2 ** 11, fs: int = 48000,
+                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32,
+                 normalize_a0: bool = True):
+        super().__init__(size=size, n_sections=n_sections, nfft=nfft, fs=fs, alias_decay_db=alias_decay_db,
+                         device=device, dtype=dtype, normalize_a0=normalize_a0)
+
+    def check_param_shape(self):
+        assert len(self.size) == 3, "Parameter size must be 3D, expected (K, 6, N)."
+        assert self.size[1] == 6, "Second dimension must be 6: [b0,b1,b2,a0,a1,a2]."
+
+    def probe(self, z: torch.Tensor):
+        return torch.diag(self._probe_sos(z))
+
+
+class SVF(_SOSMixin, Filter):
+    """Cascaded state-variable filters, param (5, n_sections, N_out, N_in) = raw (f, R, mLP, mBP, mHP)
+    (dsp.py:2076-2366).  The map turns the raw values into (tan(pi*sigmoid/2), softplus/ln2, mix)."""
+
+    _TYPES = ["lowpass", "highpass", "bandpass", "lowshelf", "highshelf", "peaking", "notch", None]
+
+    def __init__(self, size: tuple = (1, 1), n_sections: int = 1, filter_type: str = None, nfft: int = 2 ** 11,
+                 fs: int = 48000, requires_grad: bool = False, alias_decay_db: float = 0.0,
+                 device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        self.fs = fs
+        self.n_sections = n_sections
+        assert filter_type in self._TYPES, "Invalid filter type"
+        self.filter_type = filter_type
+        self.alias_envelope_dcy = _gamma(alias_decay_db, nfft, device, dtype) ** torch.arange(0, 3, 1, device=device,
+                                                                                             dtype=dtype)
+        super().__init__(size=(5, self.n_sections, *size), nfft=nfft, map=self.map_param2svf,
+                         requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def check_param_shape(self):
+        assert len(self.size) == 4, "Filter parameter space must be 4D, for 3D (parallel) filters use parallelSVF module."
+
+    def param2freq(self, param):
+        return torch.tan(torch.pi * torch.div(1, 1 + torch.exp(-param)) * 0.5)
+
+    def param2R(self, param):
+        one = torch.ones(1, device=param.device, dtype=param.dtype)
+        return torch.div(torch.log(one + torch.exp(param)), torch.log(torch.tensor(2, device=param.device, dtype=param.dtype)))
+
+    def param2mix(self, param, R=None):
+        G = 10 ** (-nn.functional.softplus(param[0]))
+        one, zero = torch.ones_like(G), torch.zeros_like(G)
+        ft = self.filter_type
+        if ft == "lowpass":
+            return torch.stack((one, zero, zero))
+        if ft == "highpass":
+            return torch.stack((zero, zero, one))
+        if ft == "bandpass":
+            return torch.stack((zero, one, zero))
+        if ft == "lowshelf":
+            return torch.stack((one, 2 * R * torch.sqrt(G), G * one))
+        if ft == "highshelf":
+            return torch.stack((G * one, 2 * R * torch.sqrt(G), one))
+        if ft in ("peaking", "notch"):
+            return torch.stack((one, 2 * R * torch.sqrt(G), one))
+        bias = torch.ones(param.shape, device=param.device, dtype=param.dtype)   # general SVF: raw mix + (1, 2, 1)
+        bias[1] = 2 * torch.ones(param.shape[1:], device=param.device, dtype=param.dtype)
+        return param + bias
+
+    def map_param2svf(self, param):
+        f = self.param2freq(param[0])
+        r = self.param2R(param[1])
+        if self.filter_type == "peaking":
+            R = 1 / r
+            m = self.param2mix(param[2:], r)
+        else:
+            R = r
+            m = self.param2mix(param[2:], R)
+        return f, R, m[0], m[1], m[2]
+
+    def _sos_coeffs(self, mapped):
+        f, R, mLP, mBP, mHP = mapped
+        f2 = f ** 2
+        b = torch.stack((f2 * mLP + f * mBP + mHP, 2 * f2 * mLP - 2 * mHP, f2 * mLP - f * mBP + mHP))
+        a = torch.stack((f2 + 2 * R * f + 1, 2 * f2 - 2, f2 - 2 * R * f + 1))
+        return b.float(), a.float()     # the reference stores the sections in float32 buffers (dsp.py:2217-2218)
+
+
+class parallelSVF(SVF):
+    """Per-channel SVF cascades, param (5, n_sections, N) (dsp.py:2369-2464)."""
+
+    _diag = True
+
+    def __init__(self, size: tuple = (1,), n_sections: int = 1, filter_type: str = None, nfft: int = 2 ** 11,
+                 fs: int = 48000, requires_grad: bool = False, alias_decay_db: float = 0.0,
+                 device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, n_sections=n_sections, filter_type=filter_type, nfft=nfft, fs=fs,
+                         requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def check_param_shape(self):
+        assert len(self.size) == 3, "Filter parameter space must be 3D, for 4D filters use SVF module."
+
+
+class PEQ(_SOSMixin, Filter):
+    """Parametric equaliser: low shelf, n_bands-2 peaking filters, high shelf; param
+    (n_bands, 3, N_out, N_in) = raw (frequency, resonance, gain dB); design "biquad" | "svf"
+    (dsp.py:2695-2872)."""
+
+    def __init__(self, size: tuple = (1, 1), n_bands: int = 10, f_min: float = 20, f_max: float = 20000,
+                 design: str = "biquad", fs: int = 48000, nfft: int = 2 ** 11, map: callable = _identity,
+                 requires_grad: bool = False, alias_decay_db: float = 0.0, device: Optional[str] = None,
+                 dtype: torch.dtype = torch.float32):
+        self.n_bands = n_bands
+        self.design = design
+        self.fs = fs
+        self.f_min = f_min
+        self.f_max = f_max
+        k = torch.arange(1, n_bands + 1, dtype=dtype)
+        self.center_freq_bias = f_min * (f_max / f_min) ** ((k - 1) / (n_bands - 1))
+        self.alias_envelope_dcy = _gamma(alias_decay_db, nfft, device, dtype) ** torch.arange(0, 3, 1, device=device,
+                                                                                             dtype=dtype)
+        super().__init__(size=(n_bands, 3, *size), nfft=nfft, map=map, requires_grad=requires_grad,
+                         alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def init_param(self):
+        torch.nn.init.uniform_(self.param)
+
+    def check_param_shape(self):
+        assert len(self.size) == 4, "Filter must be 3D, for 2D (parallel) filters use ParallelPEQ module."
+
+    def map_eq(self, param):
+        """raw (n_bands, 3, ...) -> (f, R, G), each (n_bands, ...) (dsp.py:2836-2855)."""
+        R, G = param[:, 1], param[:, 2]
+        cfb = self.center_freq_bias.to(device=param.device, dtype=param.dtype).view(-1, *([1] * (param.dim() - 2)))
+        if self.design == "biquad":
+            bias = cfb / self.fs * 2 * torch.pi
+            f = torch.clamp(torch.sigmoid(param[:, 0]) + bias, min=2 * torch.pi * self.f_min / self.fs,
+                            max=2 * torch.pi * self.f_max / self.fs)
+        else:
+            bias = torch.log(2 * cfb / self.fs / (1 - 2 * cfb / self.fs))
+            f = torch.tan(torch.pi * torch.sigmoid(param[:, 0] + bias) * 0.5)
+        return f, R, G
+
+    def _band_coeffs(self, f, R, G, kind):
+        """(a, b) taps of one band type for all channels at once (dsp.py:2775-2832)."""
+        if self.design == "svf":
+            G = 10 ** (G / 20)
+            one = torch.ones_like(G)
+            mBP = 2 * R * torch.sqrt(G)
+            mLP, mHP = (one, one) if kind == "peaking" else ((G, one) if kind == "lowshelf" else (one, G))
+            f2 = f ** 2
+            b = (f2 * mLP + f * mBP + mHP, 2 * f2 * mLP - 2 * mHP, f2 * mLP - f * mBP + mHP)
+            a = (f2 + 2 * R * f + 1, 2 * f2 - 2, f2 - 2 * R * f + 1)
+        else:
+            G = 10 ** (G / 40)
+            c = torch.cos(f)
+            if kind == "peaking":
+                alpha = torch.sin(f) / (2 * R)
+                b = (1 + alpha * G, -2 * c, 1 - alpha * G)
+                a = (1 + alpha / G, -2 * c, 1 - alpha / G)
+            else:
+                alpha = torch.sin(f) * torch.sqrt((G ** 2 + 1) * (1 / R - 1) + 2 * G)
+                sg = 1.0 if kind == "lowshelf" else -1.0
+                b = (G * ((G + 1) - sg * (G - 1) * c + alpha), sg * 2 * G * ((G - 1) - sg * (G + 1) * c),
+                     G * ((G + 1) - sg * (G - 1) * c - alpha))
+                a = ((G + 1) + sg * (G - 1) * c + alpha, -sg * 2 * ((G - 1) + sg * (G + 1) * c),
+                     (G + 1) + sg * (G - 1) * c - alpha)
+        return torch.stack(a), torch.stack(b)
+
+    def _sos_coeffs(self, mapped):
+        f, R, G = self.map_eq(mapped)
+        a_lo, b_lo = self._band_coeffs(f[0], R[0], G[0], "lowshelf")
+        a_hi, b_hi = self._band_coeffs(f[-1], R[-1], G[-1], "highshelf")
+        a_pk, b_pk = self._band_coeffs(f[1:-1], R[1:-1], G[1:-1], "peaking")          # (3, n_bands-2, ...)
+        b = torch.cat((b_lo.unsqueeze(1), b_pk, b_hi.unsqueeze(1)), dim=1)
+        a = torch.cat((a_lo.unsqueeze(1), a_pk, a_hi.unsqueeze(1)), dim=1)
+        return b.float(), a.float()     # float32 section buffers in the reference (dsp.py:2750-2751)
+
+
+class parallelPEQ(PEQ):
+    """Per-channel parametric equaliser, param (n_bands, 3, N) (dsp.py:2875-3000).  NB: the reference's
+    parallel `map_eq` broadcasts its frequency bias as (n_bands, 1, 1) against (n_bands, N) parameters and
+    cannot run; this class applies the bias per band, as the non-parallel class does."""
+
+    _diag = True
+
+    def __init__(self, size: tuple = (1,), n_bands: int = 10, f_min: float = 20, f_max: float = 20000,
+                 design: str = "biquad", nfft: int = 2 ** 11, fs: int = 48000, map: callable = _identity,
+                 requires_grad: bool = False, alias_decay_db: float = 0.0, device: Optional[str] = None,
+                 dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, n_bands=n_bands, f_min=f_min, f_max=f_max, design=design, fs=fs, nfft=nfft,
+                         map=map, requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device,
+                         dtype=dtype)
+
+    def check_param_shape(self):
+        assert len(self.size) == 3, "Filter must be 2D in the parallel configuration, for 3D filters use PEQ module."
+
+
 # ============================================================================ delays
 class Delay(DSP):
     """Delay matrix, param (N_out, N_in) in units of ``unit/fs`` seconds (dsp.py:3226-3450).
@@ -688,3 +945,122 @@ class parallelDelay(Delay):
 
     def probe(self, z: torch.Tensor):
         return torch.diag_embed(self._probe_delay(z))
+
+
+class GainDelay(DSP):
+    """Gain matrix and delay matrix in one module, param (2, N_out, N_in) = (gains, delays in unit/fs
+    seconds): H[k] = g * gamma^m * exp(-j w_k m) (dsp.py:3554-3702)."""
+
+    _diag = False
+
+    def __init__(self, size: tuple = (1, 1), max_len: int = 2000, isint: bool = False, unit: int = 100,
+                 nfft: int = 2 ** 11, fs: int = 48000, map_gain: Optional[callable] = None,
+                 map_delay: Optional[callable] = None, requires_grad: bool = False, alias_decay_db: float = 0.0,
+                 device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        self.fs = fs
+        self.max_len = max_len
+        self.unit = unit
+        self.isint = isint
+        self._custom_gain_map = map_gain is not None
+        self._custom_delay_map = map_delay is not None
+        self.map_gain = map_gain if map_gain is not None else _identity
+        self.map_delay = map_delay if map_delay is not None else _identity
+        super().__init__(size=(2, *size), nfft=nfft, requires_grad=requires_grad, alias_decay_db=alias_decay_db,
+                         device=device, dtype=dtype)
+        self.initialize_class()
+
+    def forward(self, x, ext_param=None):
+        return self._run(x, ext_param)
+
+    def init_param(self):
+        shape = self.size[1:]
+        with torch.no_grad():
+            nn.init.ones_(self.param[0])
+            if self.isint:
+                d = torch.randint(1, self.max_len, shape, device=self.device, dtype=torch.int64).to(self.param.dtype)
+            else:
+                d = torch.rand(shape, device=self.device, dtype=self.dtype) * self.max_len
+            self.param[1].copy_(self.sample2s(d))
+        self.order = int(torch.ceil(d).max().item()) + 1
+
+    def s2sample(self, delay: torch.Tensor):
+        return delay * self.fs / self.unit
+
+    def sample2s(self, delay: torch.Tensor):
+        return delay / self.fs * self.unit
+
+    def check_input_shape(self, x):
+        if (ops.bin_shard(self.nfft)[1], self.input_channels) != (x.shape[1], x.shape[2]):
+            raise ValueError(
+                f"parameter shape = {self.param.shape} not compatible with input signal of shape = ({x.shape}).")
+
+    def check_param_shape(self):
+        assert len(self.size) == 3 and self.size[0] == 2, "GainDelay parameters must have shape (2, N_out, N_in)."
+
+    def get_gains(self):
+        return lambda param: to_complex(self.map_gain(param[0]))
+
+    def get_delays(self):
+        return lambda param: self.s2sample(self.map_delay(param[1]))
+
+    def get_freq_response(self):
+        gains, delays = self.get_gains(), self.get_delays()
+
+        def response(param):
+            g = gains(param)
+            md = self.s2sample(self.map_delay(param[1].double()))      # samples, float64
+            cd = torch.complex64 if self.dtype == torch.float32 else torch.complex128
+            if self.isint:
+                mi = md.round()
+                D = ops.delay_response(mi.to(torch.int64), (self._gamma_f ** mi).to(self.dtype), self.nfft)
+            else:
+                bin0, m_local = ops.bin_shard(self.nfft)
+                k = torch.arange(bin0, bin0 + m_local, device=md.device, dtype=torch.float64)
+                k = k.view(-1, *([1] * md.dim()))
+                ang = -2 * torch.pi * torch.remainder(k * md.unsqueeze(0) / self.nfft, 1.0)
+                D = torch.polar((self._gamma_f ** md).unsqueeze(0).expand_as(ang).contiguous(), ang).to(cd)
+            return g.to(cd).unsqueeze(0) * D
+
+        self.freq_response = response
+
+    def get_freq_convolve(self):
+        self.freq_convolve = lambda x, param: ops.mimo(self.freq_response(param), x, diag=self._diag)
+        self._own_convolve = self.freq_convolve
+
+    def _bin_response(self, param):
+        return self.freq_response(param), self._diag
+
+    def initialize_class(self):
+        self.check_param_shape()
+        self.get_io()
+        if self.requires_grad and not self._custom_delay_map:
+            self.map_delay = lambda x: nn.functional.softplus(x)
+        self.omega = (2 * torch.pi * torch.arange(0, self.nfft // 2 + 1, device=self.device, dtype=self.dtype)
+                      / self.nfft).unsqueeze(1)
+        self.get_freq_response()
+        self.get_freq_convolve()
+
+    def get_io(self):
+        if self._diag:
+            self.input_channels = self.output_channels = self.size[-1]
+        else:
+            self.input_channels = self.size[-1]
+            self.output_channels = self.size[-2]
+
+
+class parallelGainDelay(GainDelay):
+    """Per-channel gain+delay, param (2, N) (dsp.py:3705-3779)."""
+
+    _diag = True
+
+    def __init__(self, size: tuple = (1,), max_len: int = 2000, isint: bool = False, unit: int = 100,
+                 nfft: int = 2 ** 11, fs: int = 48000, map_gain: Optional[callable] = None,
+                 map_delay: Optional[callable] = None, requires_grad: bool = False, alias_decay_db: float = 0.0,
+                 device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, max_len=max_len, isint=isint, unit=unit, nfft=nfft, fs=fs, map_gain=map_gain,
+                         map_delay=map_delay, requires_grad=requires_grad, alias_decay_db=alias_decay_db,
+                         device=device, dtype=dtype)
+
+    def check_param_shape(self):
+        assert len(self.size) == 2 and self.size[0] == 2, \
+            "parallelGainDelay parameters must have shape (2, N), for MIMO use GainDelay module."

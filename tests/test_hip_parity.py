@@ -164,9 +164,9 @@ def _module_reference(meta, a, dt):
     output).  float32: the pinned float64 oracle evaluated on the float32-rounded parameters and
     inputs -- the GEQ/Biquad cascades are ill-conditioned in their parameters at low frequency,
     so the comparison must start from the very same parameter values."""
-    if dt == torch.float64:
-        return a
-    from test_oracle_golden import _module_response
+    from test_oracle_golden import ORACLE_CLASSES, _module_response
+    if dt == torch.float64 or meta["cls"] not in ORACLE_CLASSES:
+        return a        # (float32 runs of the classes without an oracle restatement use the goldens, looser tolerance)
     from oracle import hotpath as O
     diag = meta["cls"].startswith("parallel")
     param = _f32_exact(a["param"]).requires_grad_(True)
@@ -194,6 +194,11 @@ def test_modules_golden(gpu, dt, name):
     # GEQ sections are float32 inside the reference and their tan()/cos() constants come from the
     # host's float32 libm, which differs by an ulp between hosts: float32-class agreement there
     tol = max(TOL[dt], 2e-6) if "GEQ" in meta["cls"] else TOL[dt]
+    from test_oracle_golden import ORACLE_CLASSES
+    if meta["cls"] not in ORACLE_CLASSES:
+        # SVF / PEQ sections are float32 in the reference (host libm ulps, as for GEQ); in float32 mode the
+        # parameters themselves are rounded before the (steep) parameter maps
+        tol = 2e-6 if dt == torch.float64 else 2e-4
     if "freq_response" in a:
         H = mod.freq_response(mod.param)
         assert H.shape == a["freq_response"].shape
@@ -207,7 +212,7 @@ def test_modules_golden(gpu, dt, name):
     assert relerr(g[0].cpu(), a["gX"]) < tol
     if "gparam" in a:
         # the reference's GEQ gradient itself passes through float32 buffers (dsp.py:2573-2585): 1e-4 class
-        gtol = 1e-3 if "GEQ" in meta["cls"] else max(tol, 1e-9)
+        gtol = 1e-3 if ("GEQ" in meta["cls"] or meta["cls"] not in ORACLE_CLASSES) else max(tol, 1e-9)
         assert relerr(g[1].cpu(), a["gparam"]) < gtol
     # matrix-valued signal (B, M, N, N): the identity-probe path
     Y4 = mod(_dev(a["X4"], gpu, dt))

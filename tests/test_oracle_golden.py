@@ -47,7 +47,10 @@ def _module_response(meta, a, param):
     raise KeyError(cls)
 
 
-_MODULE_CASES = [n for n in golden_names() if load_golden(n)[0].get("cls")]
+ORACLE_CLASSES = {"Gain", "parallelGain", "Matrix", "Filter", "parallelFilter", "Biquad", "parallelBiquad", "GEQ",
+                  "parallelGEQ", "Delay", "parallelDelay"}
+# (SOSFilter / SVF / PEQ / GainDelay goldens are compared with the HIP path directly in the GPU tests)
+_MODULE_CASES = [n for n in golden_names() if load_golden(n)[0].get("cls") in ORACLE_CLASSES]
 
 
 @pytest.mark.parametrize("name", _MODULE_CASES)

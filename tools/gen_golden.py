@@ -154,6 +154,35 @@ def gen_modules(dsp):
          param=geq.param.detach(), H=H, B=Bf, A=Af, center_freq=geq.center_freq, shelving=geq.shelving_crossover)
 
 
+def gen_modules_more(dsp):
+    """SOS-coefficient, state-variable and parametric-EQ filters, gain+delay."""
+    nfft = 96
+    for db in (0.0, 30.0):
+        tag = f"db{int(db)}"
+        kw = dict(nfft=nfft, alias_decay_db=db, dtype=F64)
+        torch.manual_seed(2500 + int(db))
+        sos = dsp.SOSFilter(size=(3, 2), n_sections=2, **kw)
+        sos.assign_value(torch.randn(2, 6, 3, 2, dtype=F64) * 0.3 + torch.tensor([1.0, 0, 0, 1.5, 0, 0], dtype=F64).view(1, 6, 1, 1))
+        module_case(f"sosfilter_{tag}", sos, dict(cls="SOSFilter", kwargs=dict(size=[3, 2], n_sections=2), nfft=nfft, alias_decay_db=db), 2, nfft)
+        psos = dsp.parallelSOSFilter(size=(3,), n_sections=2, normalize_a0=False, **kw)
+        psos.assign_value(torch.randn(2, 6, 3, dtype=F64) * 0.3 + torch.tensor([1.0, 0, 0, 1.5, 0, 0], dtype=F64).view(1, 6, 1))
+        module_case(f"psosfilter_{tag}", psos, dict(cls="parallelSOSFilter", kwargs=dict(size=[3], n_sections=2, normalize_a0=False), nfft=nfft, alias_decay_db=db), 3, nfft)
+        for ft in ("lowpass", "lowshelf", "peaking", None):
+            module_case(f"svf_{ft}_{tag}", dsp.SVF(size=(3, 2), n_sections=2, filter_type=ft, requires_grad=True, **kw),
+                        dict(cls="SVF", kwargs=dict(size=[3, 2], n_sections=2, filter_type=ft, requires_grad=True), nfft=nfft, alias_decay_db=db), 2, nfft)
+        module_case(f"psvf_{tag}", dsp.parallelSVF(size=(3,), n_sections=2, filter_type="highshelf", requires_grad=True, **kw),
+                    dict(cls="parallelSVF", kwargs=dict(size=[3], n_sections=2, filter_type="highshelf", requires_grad=True), nfft=nfft, alias_decay_db=db), 3, nfft)
+        for design in ("biquad", "svf"):
+            module_case(f"peq_{design}_{tag}", dsp.PEQ(size=(2, 2), n_bands=5, design=design, requires_grad=True, **kw),
+                        dict(cls="PEQ", kwargs=dict(size=[2, 2], n_bands=5, design=design, requires_grad=True), nfft=nfft, alias_decay_db=db), 2, nfft)
+        for isint in (True, False):
+            it = "int" if isint else "frac"
+            module_case(f"gaindelay_{it}_{tag}", dsp.GainDelay(size=(3, 2), max_len=40, isint=isint, requires_grad=True, **kw),
+                        dict(cls="GainDelay", kwargs=dict(size=[3, 2], max_len=40, isint=isint, requires_grad=True), nfft=nfft, alias_decay_db=db), 2, nfft)
+        module_case(f"pgaindelay_{tag}", dsp.parallelGainDelay(size=(3,), max_len=40, isint=True, **kw),
+                    dict(cls="parallelGainDelay", kwargs=dict(size=[3], max_len=40, isint=True), nfft=nfft, alias_decay_db=db), 3, nfft)
+
+
 # ----------------------------------------------------------------------------- config-2 miniature
 def gen_config2(dsp, system):
     for db, nfft, B in ((0.0, 240, 2), (30.0, 250, 2)):
@@ -280,8 +309,12 @@ def main():
     import warnings
 
     warnings.filterwarnings("ignore")
+    if "--more-only" in sys.argv:
+        gen_modules_more(dsp)
+        return
     gen_transforms(dsp)
     gen_modules(dsp)
+    gen_modules_more(dsp)
     gen_config2(dsp, system)
     gen_fdn(dsp, system)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
