@@ -8,6 +8,7 @@
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
   Shell(FFT(96000) -> Series(Matrix(8,8,"random"), GEQ((8,8))) -> iFFT(96000)), batch 32 per GPU,
   float32, synthetic white-noise input resident in HBM, forward + backward of loss=(y**2).mean()
+  (evaluated by ops.mean_square: the same value in one streaming pass each way)
   with gradients for every learnable parameter (Matrix and GEQ gains), as in the reference's
   training step (flamo/optimize/trainer.py:172-191; the data tensor does not require grad).
 Metric: frequency-bin x channel products per second =
@@ -126,7 +127,7 @@ def main():
         for p in params:
             p.grad = None
         y = model(x)
-        loss = (y ** 2).mean()
+        loss = ops.mean_square(y)                       # == (y ** 2).mean(), one pass each way
         loss.backward()
         if dist_on:
             flat = torch.cat([p.grad.reshape(-1) for p in params])
@@ -140,7 +141,7 @@ def main():
         # to host jitter) out of the loop.  Forward + backward are captured once; the tiny RCCL
         # gradient all-reduce stays eager after each replay.
         from flamo_amd.graph import GraphedStep
-        gs = GraphedStep(lambda xx: (model(xx) ** 2).mean(), (x,), params, warmup=2)
+        gs = GraphedStep(lambda xx: ops.mean_square(model(xx)), (x,), params, warmup=2)
 
         def step():
             loss = gs.replay()

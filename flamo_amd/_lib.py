@@ -55,14 +55,19 @@ _SIGNATURES = {
     "fl_sos_response_c128": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _l, _vp]),
     "fl_sos_bwd_blocks": (_i, [_i]),
     "fl_debug_set_sos_chunk": (_i, [_i]),
-    "fl_sos_response_bwd_c64": (_i, [_vp, _l, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
-    "fl_sos_response_bwd_c128": (_i, [_vp, _l, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_sos_response_bwd_c64": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
+    "fl_sos_response_bwd_c128": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
     "fl_geq_sections": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "fl_geq_sections_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "fl_solve_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_dud_c64": (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_dud_c128": (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
+    "fl_mean_square_scratch_bytes": (_sz, []),
+    "fl_mean_square_f32": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp]),
+    "fl_mean_square_f64": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp]),
+    "fl_mean_square_bwd_f32": (_i, [_vp, _vp, _vp, _l, _l, _l, _vp]),
+    "fl_mean_square_bwd_f64": (_i, [_vp, _vp, _vp, _l, _l, _l, _vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

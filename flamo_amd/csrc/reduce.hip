@@ -1,0 +1,182 @@
+// Mean-square of a real signal block and its gradient (gfx950 / MI355X).
+//
+//   loss = (1/count) * sum y[r, c]^2          g_y[r, c] = (2/count) * g_loss * y[r, c]
+//
+// the scalar objective the training step puts on the output of the path (trainer.py:179-191
+// reduce criterion(estimations, targets) to one scalar and call backward()).  Written as
+// (y ** 2).mean() in torch this is five elementwise/reduction launches that read or write the
+// whole (B, T, N) output eight times; here it is one streaming read forward and one read + one
+// write backward, in whatever layout the irfft left the signal (rows with a pitch).
+//
+// Deterministic: per-block partial sums in double, combined in a fixed order by a second one-block
+// launch.  (A single launch with a "last block done" ticket needs a device-scope fence per block,
+// which on this multi-XCD part writes back / invalidates the XCD's L2 under the streaming reads:
+// measured 57-85 us for the 98 MB pass instead of ~20.)
+#include "common.h"
+
+namespace fl {
+
+template <typename T> struct Vec4 { T v[4]; };
+template <> struct alignas(16) Vec4<float> { float v[4]; };
+template <> struct alignas(32) Vec4<double> { double v[4]; };
+
+constexpr int MS_MAX_BLOCKS = 4096;
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) mean_square_kernel(const T* __restrict__ y, long rows, long cols, long pitch,
+                                                         double* __restrict__ partial) {
+    double acc = 0.0;
+    const long cv = cols / VEC;
+    for (long r = blockIdx.y; r < rows; r += gridDim.y) {
+        const T* row = y + r * pitch;
+        const long stride = (long)gridDim.x * 256;
+        long c = (long)blockIdx.x * 256 + threadIdx.x;
+        if constexpr (VEC == 4) {
+            // four independent 16-byte loads in flight per lane
+            for (; c + 3 * stride < cv; c += 4 * stride) {
+                Vec4<T> q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const Vec4<T>*>(row + (c + u * stride) * 4);
+                T s[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    s[u] = q[u].v[0] * q[u].v[0] + q[u].v[1] * q[u].v[1] + q[u].v[2] * q[u].v[2] + q[u].v[3] * q[u].v[3];
+                acc += (double)(s[0] + s[1]) + (double)(s[2] + s[3]);
+            }
+            for (; c < cv; c += stride) {
+                const Vec4<T> q = *reinterpret_cast<const Vec4<T>*>(row + c * 4);
+                acc += (double)(q.v[0] * q.v[0] + q.v[1] * q.v[1] + q.v[2] * q.v[2] + q.v[3] * q.v[3]);
+            }
+        } else {
+            for (; c < cv; c += stride) {
+                const T q = row[c];
+                acc += (double)(q * q);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) mean_square_final_kernel(const double* __restrict__ partial, int nblocks,
+                                                               double inv_count, T* __restrict__ loss) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (T)((red[0] + red[1] + red[2] + red[3]) * inv_count);
+}
+
+template <typename T, int VEC>
+__global__ void __launch_bounds__(256) mean_square_bwd_kernel(const T* __restrict__ y, const T* __restrict__ gloss,
+                                                             double two_inv_count, T* __restrict__ gy, long rows,
+                                                             long cols, long pitch) {
+    const T k = (T)(two_inv_count * (double)gloss[0]);
+    const long cv = cols / VEC;
+    for (long r = blockIdx.y; r < rows; r += gridDim.y) {
+        const T* row = y + r * pitch;
+        T* out = gy + r * pitch;
+        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < cv; c += (long)gridDim.x * 256) {
+            if constexpr (VEC == 4) {
+                Vec4<T> q = *reinterpret_cast<const Vec4<T>*>(row + c * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q.v[i] *= k;
+                *reinterpret_cast<Vec4<T>*>(out + c * 4) = q;
+            } else {
+                out[c] = row[c] * k;
+            }
+        }
+    }
+}
+
+static dim3 ms_grid(long rows, long cols, int vec) {
+    const long cv = cols / vec;
+    long gx = (cv + 255) / 256;
+    if (rows == 1) {
+        if (gx > 2048) gx = 2048;   // 8 blocks per CU, each lane keeps several 16-byte loads in flight
+        return dim3((unsigned)(gx < 1 ? 1 : gx), 1);
+    }
+    if (gx > 16) gx = 16;
+    long gy = rows;
+    const long cap = MS_MAX_BLOCKS / (gx < 1 ? 1 : gx);
+    if (gy > cap) gy = cap;
+    return dim3((unsigned)(gx < 1 ? 1 : gx), (unsigned)gy);
+}
+
+template <typename T>
+static int pick_vec(const void* p, const void* q, long cols, long pitch, long rows) {
+    const uintptr_t a = (uintptr_t)p | (uintptr_t)q;
+    const bool ok = (a % (4 * sizeof(T)) == 0) && (cols % 4 == 0) && (rows == 1 || pitch % 4 == 0);
+    return ok ? 4 : 1;
+}
+
+template <typename T>
+static int mean_square_impl(const void* y, long rows, long cols, long pitch, void* loss, void* scratch, void* stream) {
+    FL_REQUIRE(y && loss && scratch, "mean_square: null pointer");
+    FL_REQUIRE(rows > 0 && cols > 0 && pitch >= cols, "mean_square: bad sizes (rows, cols > 0, pitch >= cols)");
+    if (pitch == cols) { cols *= rows; rows = 1; pitch = cols; }
+    const int vec = pick_vec<T>(y, nullptr, cols, pitch, rows);
+    const dim3 grid = ms_grid(rows, cols, vec);
+    double* partial = reinterpret_cast<double*>(scratch);
+    const double inv = 1.0 / ((double)rows * (double)cols);
+    if (vec == 4)
+        hipLaunchKernelGGL((mean_square_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, rows, cols,
+                           pitch, partial);
+    else
+        hipLaunchKernelGGL((mean_square_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y, rows, cols,
+                           pitch, partial);
+    FL_CHECK_LAUNCH("mean_square");
+    hipLaunchKernelGGL((mean_square_final_kernel<T>), dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)partial,
+                       (int)(grid.x * grid.y), inv, (T*)loss);
+    FL_CHECK_LAUNCH("mean_square_final");
+    return FL_OK;
+}
+
+template <typename T>
+static int mean_square_bwd_impl(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream) {
+    FL_REQUIRE(y && gloss && gy, "mean_square_bwd: null pointer");
+    FL_REQUIRE(rows > 0 && cols > 0 && pitch >= cols, "mean_square_bwd: bad sizes");
+    const double two_inv = 2.0 / ((double)rows * (double)cols);
+    if (pitch == cols) { cols *= rows; rows = 1; pitch = cols; }
+    const int vec = pick_vec<T>(y, gy, cols, pitch, rows);
+    dim3 grid = ms_grid(rows, cols, vec);
+    if (rows == 1) grid.x = (unsigned)((cols / vec + 1023) / 1024 < 1 ? 1 : (cols / vec + 1023) / 1024);  // 4 vectors per lane
+    if (vec == 4)
+        hipLaunchKernelGGL((mean_square_bwd_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y,
+                           (const T*)gloss, two_inv, (T*)gy, rows, cols, pitch);
+    else
+        hipLaunchKernelGGL((mean_square_bwd_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)y,
+                           (const T*)gloss, two_inv, (T*)gy, rows, cols, pitch);
+    FL_CHECK_LAUNCH("mean_square_bwd");
+    return FL_OK;
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+extern "C" {
+size_t fl_mean_square_scratch_bytes(void) { return MS_MAX_BLOCKS * sizeof(double); }
+int fl_mean_square_f32(const void* y, long rows, long cols, long pitch, void* loss, void* scratch, void* stream) {
+    return mean_square_impl<float>(y, rows, cols, pitch, loss, scratch, stream);
+}
+int fl_mean_square_f64(const void* y, long rows, long cols, long pitch, void* loss, void* scratch, void* stream) {
+    return mean_square_impl<double>(y, rows, cols, pitch, loss, scratch, stream);
+}
+int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream) {
+    return mean_square_bwd_impl<float>(y, gloss, gy, rows, cols, pitch, stream);
+}
+int fl_mean_square_bwd_f64(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream) {
+    return mean_square_bwd_impl<double>(y, gloss, gy, rows, cols, pitch, stream);
+}
+}

@@ -100,6 +100,36 @@ __device__ inline cx<double> cdiv_fast(cx<double> a, cx<double> b) {
     return cx<double>((a.x * b.x + a.y * b.y) * inv, (a.y * b.x - a.x * b.y) * inv);
 }
 
+// Wavefront reduce-scatter of N per-lane values: after the call the lane holds in a[0..cnt) the
+// wavefront totals of the original entries off .. off+cnt-1.  Each halving step trades half of the
+// lane's values with its partner (N/2 shuffles instead of N); when the count turns odd the rest is
+// reduced by plain butterflies.  72 running sums cost 90 shuffles instead of 432 -- the epilogue,
+// not the bin loop, dominated this kernel.
+template <typename V, int N, int MASK>
+__device__ inline void wave_reduce_scatter(V (&a)[N], int lane, int& off, int& cnt, int& dup_mask) {
+    if constexpr (MASK == 0) {
+        cnt = N;
+    } else if constexpr (N % 2 == 0) {
+        const bool up = (lane & MASK) != 0;
+        V k[N / 2];
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const V keep = up ? a[N / 2 + i] : a[i];
+            const V send = up ? a[i] : a[N / 2 + i];
+            k[i] = keep + __shfl_xor(send, MASK, 64);
+        }
+        if (up) off += N / 2;
+        wave_reduce_scatter<V, N / 2, MASK / 2>(k, lane, off, cnt, dup_mask);
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) a[i] = k[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) a[i] += __shfl_xor(a[i], MASK, 64);
+        dup_mask |= MASK;   // lanes differing in this bit now hold the same totals
+        wave_reduce_scatter<V, N, MASK / 2>(a, lane, off, cnt, dup_mask);
+    }
+}
+
 // Backward: dL/db[p,s,c] = sum_k Re(conj(gH) * H/B_s * z_p),  dL/da[p,s,c] = -sum_k Re(conj(gH) * H/A_s * z_p)
 // One thread walks bins of one channel and keeps the 6*SCH running sums of a chunk of SCH sections
 // in registers (GEQ: 12 sections = one chunk, nothing is recomputed).  Everything stays in double:
@@ -116,13 +146,9 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
     const int c = blockIdx.y;
     stage_taps(b, a, S, C, c, lb, la);
     const int s0 = blockIdx.z * SCH;
-    double acc[2][3][SCH];
+    double acc[6 * SCH];   // [(i*3 + p)*SCH + q]: i = b|a, p = tap, q = section of the chunk
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = 0; q < SCH; ++q) acc[i][p][q] = 0.0;
+    for (int v = 0; v < 6 * SCH; ++v) acc[v] = 0.0;
 
     for (int f = blockIdx.x * 256 + threadIdx.x; f < m_local; f += gridDim.x * 256) {
         const SosEval e = sos_point(Wd, nfft, bin0 + f, g);
@@ -151,29 +177,25 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
                     tb = gc * cdiv_fast(o, Ap);
                 }
                 const cx<double> ta = cdiv_fast(gh, As);
-                acc[0][0][q] += tb.x;
-                acc[0][1][q] += tb.x * e.z1.x - tb.y * e.z1.y;     // Re(tb * z_p)
-                acc[0][2][q] += tb.x * e.z2.x - tb.y * e.z2.y;
-                acc[1][0][q] -= ta.x;
-                acc[1][1][q] -= ta.x * e.z1.x - ta.y * e.z1.y;
-                acc[1][2][q] -= ta.x * e.z2.x - ta.y * e.z2.y;
+                acc[0 * SCH + q] += tb.x;
+                acc[1 * SCH + q] += tb.x * e.z1.x - tb.y * e.z1.y;     // Re(tb * z_p)
+                acc[2 * SCH + q] += tb.x * e.z2.x - tb.y * e.z2.y;
+                acc[3 * SCH + q] -= ta.x;
+                acc[4 * SCH + q] -= ta.x * e.z1.x - ta.y * e.z1.y;
+                acc[5 * SCH + q] -= ta.x * e.z2.x - ta.y * e.z2.y;
             }
         }
     }
-    // block reduction: wavefront shuffles, then the 4 wave partials through LDS
+    // block reduction: wavefront reduce-scatter, then the 4 wave partials through LDS
     __shared__ double red[4][6 * SCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int off = 0, cnt = 0, dup = 0;
+    wave_reduce_scatter<double, 6 * SCH, 32>(acc, lane, off, cnt, dup);
+    if ((lane & dup) == 0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int q = 0; q < SCH; ++q) {
-                double v = acc[i][p][q];
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-                if (lane == 0) red[wave][(i * 3 + p) * SCH + q] = v;
-            }
+        for (int v = 0; v < 6 * SCH; ++v)
+            if (v < cnt) red[wave][off + v] = acc[v];
+    }
     __syncthreads();
     if (threadIdx.x < 6 * SCH) {
         const int i = threadIdx.x / (3 * SCH), p = (threadIdx.x / SCH) % 3, q = threadIdx.x % SCH;
@@ -181,6 +203,112 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
         if (s < S) {
             const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
             part[((((size_t)blockIdx.x * 2 + i) * 3 + p) * S + s) * C + c] = v;
+        }
+    }
+}
+
+// Mixed-precision backward for float32 storage (H, gH are c64).  What needs double stays in double:
+// the section values B_s(k), A_s(k) (they cancel to ~1e-5 of their terms at low frequency).  What
+// does not is done in float: the quotients conj(gH) H / B_s (relative error 1e-7 per bin) and the
+// running sums -- but the sums are kept in the basis {1, d, d^2}, d = 1 - g w, instead of
+// {1, g w, (g w)^2}: at low frequency the three monomial sums are nearly equal and the parameter
+// maps downstream take differences of them (factor 1/theta^2 ~ 1e4..1e5 for a 31 Hz band), which
+// float sums would not survive, while the d-basis sums are the well-scaled quantities those
+// differences are made of.  They are converted back to (b0, b1, b2) gradients in double:
+//   sum Re(t)       = G0,   sum Re(t g w) = G0 - G1,   sum Re(t (g w)^2) = G0 - 2 G1 + G2.
+// H is the forward output (saved), so the cascade product is not re-evaluated: a thread spends
+// ~12 double and ~30 float instructions per section instead of ~80 double ones.
+// Rare route of the mixed kernel: a section value that vanishes or leaves the float range (e.g. a
+// band-pass numerator at DC).  All double, product of the other sections as in the kernel above;
+// (inlined: an out-of-line call costs the hot loop more in saved registers than the code size does).
+__device__ inline void sos_bwd_slow_section(const SosEval& e, const double* lb, const double* la, int S,
+                                                               int s, cx<float> gc, cx<double> Bs, cx<double> As,
+                                                               cx<float>& tb, cx<float>& ta) {
+    cx<double> o(1, 0), Ap(1, 0);
+    for (int t = 0; t < S; ++t) {
+        if (t != s) o = o * e.poly(lb, S, t);
+        Ap = Ap * e.poly(la, S, t);
+    }
+    const cx<double> gcd((double)gc.x, (double)gc.y);
+    const cx<double> tbd = gcd * cdiv(o, Ap);      // conj(gH) H / B_s
+    const cx<double> tad = cdiv(tbd * Bs, As);     // conj(gH) H / A_s
+    tb = cx<float>((float)tbd.x, (float)tbd.y);
+    ta = cx<float>((float)tad.x, (float)tad.y);
+}
+
+template <int SCH>
+__global__ void __launch_bounds__(256) sos_response_bwd_mixed_kernel(
+    const cx<float>* __restrict__ gH, long g_pitch, const cx<float>* __restrict__ H, long h_pitch,
+    const double* __restrict__ b, const double* __restrict__ a, int S, int C, double g,
+    const cx<double>* __restrict__ Wd, int nfft, int bin0, int m_local, double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lb = reinterpret_cast<double*>(smem);
+    double* la = lb + 3 * S;
+    const int c = blockIdx.y;
+    stage_taps(b, a, S, C, c, lb, la);
+    const int s0 = blockIdx.z * SCH;
+    float acc[6 * SCH];   // [(i*3 + p)*SCH + q]: i = b|a, p = power of d, q = section of the chunk
+#pragma unroll
+    for (int v = 0; v < 6 * SCH; ++v) acc[v] = 0.f;
+    const float eps = eps_of<float>();
+
+    for (int f = blockIdx.x * 256 + threadIdx.x; f < m_local; f += gridDim.x * 256) {
+        const cx<float> h = H[(size_t)c * h_pitch + f];
+        if (h.x == eps && h.y == 0.f) continue;   // guarded bin (prod A == 0): constant, zero gradient
+        const SosEval e = sos_point(Wd, nfft, bin0 + f, g);
+        const cx<float> d((float)(1.0 - e.z1.x), (float)(-e.z1.y));
+        const cx<float> d2 = d * d;
+        const cx<float> gin = gH[(size_t)c * g_pitch + f];
+        const cx<float> gc(gin.x, -gin.y);
+        const cx<float> gh = gc * h;              // conj(gH) * H
+#pragma unroll
+        for (int q = 0; q < SCH; ++q) {
+            const int s = s0 + q;
+            if (s < S) {
+                const cx<double> Bs = e.poly(lb, S, s), As = e.poly(la, S, s);
+                const float nb = (float)(Bs.x * Bs.x + Bs.y * Bs.y), na = (float)(As.x * As.x + As.y * As.y);
+                cx<float> tb, ta;
+                if (nb > 1e-30f && nb < 1e30f && na > 1e-30f && na < 1e30f) {
+                    const float ib = __builtin_amdgcn_rcpf(nb), ia = __builtin_amdgcn_rcpf(na);
+                    const cx<float> Bf((float)Bs.x, (float)Bs.y), Af((float)As.x, (float)As.y);
+                    const cx<float> ub = mulc(gh, Bf), ua = mulc(gh, Af);     // gh * conj(.)
+                    tb = cx<float>(ub.x * ib, ub.y * ib);
+                    ta = cx<float>(ua.x * ia, ua.y * ia);
+                } else {
+                    sos_bwd_slow_section(e, lb, la, S, s, gc, Bs, As, tb, ta);
+                }
+                acc[0 * SCH + q] += tb.x;
+                acc[1 * SCH + q] += tb.x * d.x - tb.y * d.y;
+                acc[2 * SCH + q] += tb.x * d2.x - tb.y * d2.y;
+                acc[3 * SCH + q] -= ta.x;
+                acc[4 * SCH + q] -= ta.x * d.x - ta.y * d.y;
+                acc[5 * SCH + q] -= ta.x * d2.x - ta.y * d2.y;
+            }
+        }
+    }
+    __shared__ float red[4][6 * SCH];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int off = 0, cnt = 0, dup = 0;
+    wave_reduce_scatter<float, 6 * SCH, 32>(acc, lane, off, cnt, dup);
+    if ((lane & dup) == 0) {
+#pragma unroll
+        for (int v = 0; v < 6 * SCH; ++v)
+            if (v < cnt) red[wave][off + v] = acc[v];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * SCH) {
+        const int i = threadIdx.x / SCH, q = threadIdx.x % SCH;
+        const int s = s0 + q;
+        if (s < S) {
+            double G[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int j = (i * 3 + p) * SCH + q;
+                G[p] = (double)red[0][j] + (double)red[1][j] + (double)red[2][j] + (double)red[3][j];
+            }
+            const double out[3] = {G[0], G[0] - G[1], G[0] - 2.0 * G[1] + G[2]};
+#pragma unroll
+            for (int p = 0; p < 3; ++p) part[((((size_t)blockIdx.x * 2 + i) * 3 + p) * S + s) * C + c] = out[p];
         }
     }
 }
@@ -277,7 +405,7 @@ static int g_sos_blocks = 0;
 
 static int sos_blocks(int m_local) {
     int nb = cdiv_i(m_local, 256);
-    const int cap = g_sos_blocks > 0 ? g_sos_blocks : 16;
+    const int cap = g_sos_blocks > 0 ? g_sos_blocks : 32;
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return nb;
@@ -312,12 +440,32 @@ static int sos_impl(const void* b, const void* a, int S, int C, double gamma, co
 }
 
 template <typename T>
-static int sos_bwd_impl(const void* gH, long g_pitch, const void* b, const void* a, int S, int C, double gamma, const void* Wd,
-                        int nfft, int bin0, int m_local, void* part, void* stream) {
+static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S, int C,
+                        double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
     FL_REQUIRE(gH && b && a && part && Wd, "sos_response_bwd: null pointer");
-    FL_REQUIRE(g_pitch >= m_local, "sos_response_bwd: g_pitch must be >= m_local");
+    FL_REQUIRE(g_pitch >= m_local && (!H || h_pitch >= m_local), "sos_response_bwd: g_pitch / h_pitch must be >= m_local");
     FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local > 0, "sos_response_bwd: bad sizes");
-    const int sch = g_sos_chunk > 0 ? g_sos_chunk : 6;
+    if constexpr (sizeof(T) == 4) {
+        if (H) {
+#define FL_SOS_MIX(SC)                                                                                              \
+    {                                                                                                               \
+        dim3 grid(sos_blocks(m_local), C, cdiv_i(S, SC));                                                           \
+        hipLaunchKernelGGL((sos_response_bwd_mixed_kernel<SC>), grid, dim3(256), (size_t)6 * S * sizeof(double),   \
+                           (hipStream_t)stream, (const cx<float>*)gH, g_pitch, (const cx<float>*)H, h_pitch,       \
+                           (const double*)b, (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0,     \
+                           m_local, (double*)part);                                                                 \
+    }
+            const int want = g_sos_chunk > 0 ? g_sos_chunk : 8;
+            if (S <= 4 || want <= 4) FL_SOS_MIX(4)
+            else if (S <= 6 || want <= 6) FL_SOS_MIX(6)
+            else if (S <= 8 || want <= 8) FL_SOS_MIX(8)
+            else FL_SOS_MIX(12)
+#undef FL_SOS_MIX
+            FL_CHECK_LAUNCH("sos_response_bwd");
+            return FL_OK;
+        }
+    }
+    const int sch = (g_sos_chunk == 3 || g_sos_chunk == 4 || g_sos_chunk == 6 || g_sos_chunk == 12) ? g_sos_chunk : 6;
 #define FL_SOS_BWD(SC)                                                                                              \
     {                                                                                                               \
         dim3 grid(sos_blocks(m_local), C, cdiv_i(S, SC));                                                           \
@@ -328,13 +476,8 @@ static int sos_bwd_impl(const void* gH, long g_pitch, const void* b, const void*
     if (S > 4 && sch == 12) FL_SOS_BWD(12)
     else if (S > 4 && sch == 6) FL_SOS_BWD(6)
     else if (S > 4 && sch == 3) FL_SOS_BWD(3)
-    else if (S > 4) FL_SOS_BWD(4)
-    else {
-        dim3 grid(sos_blocks(m_local), C, 1);
-        hipLaunchKernelGGL((sos_response_bwd_kernel<T, 4>), grid, dim3(256), (size_t)6 * S * sizeof(double), (hipStream_t)stream, (const cx<T>*)gH, g_pitch,
-                           (const double*)b, (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0, m_local,
-                           (double*)part);
-    }
+    else FL_SOS_BWD(4)
+#undef FL_SOS_BWD
     FL_CHECK_LAUNCH("sos_response_bwd");
     return FL_OK;
 }
@@ -386,12 +529,12 @@ int fl_geq_sections_bwd(const void* gain_db, const void* gb, const void* ga, int
     FL_CHECK_LAUNCH("geq_sections_bwd");
     return FL_OK;
 }
-int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* b, const void* a, int S, int C, double gamma,
-                            const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
-    return sos_bwd_impl<float>(gH, g_pitch, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
+int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
+                            int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
+    return sos_bwd_impl<float>(gH, g_pitch, H, h_pitch, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
 }
-int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* b, const void* a, int S, int C, double gamma,
-                            const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
-    return sos_bwd_impl<double>(gH, g_pitch, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
+int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
+                             int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
+    return sos_bwd_impl<double>(gH, g_pitch, H, h_pitch, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
 }
 }

@@ -640,6 +640,11 @@ def delay_response(m_int: torch.Tensor, amp: torch.Tensor, nfft: int) -> torch.T
     return H.movedim(-1, 0)
 
 
+# float32 modules: mixed-precision backward of the cascade (see fl_sos_response_bwd_c64); False
+# forces the all-double evaluation (tests compare the two)
+SOS_BWD_MIXED = True
+
+
 class _Sos(torch.autograd.Function):
     @staticmethod
     def forward(ctx, b, a, gamma, nfft, real):
@@ -659,23 +664,26 @@ class _Sos(torch.autograd.Function):
         Wd = twiddles(nfft, torch.float64, dev)
         _lib.check(fn(bc.data_ptr(), ac.data_ptr(), S, C_, float(gamma), Wd.data_ptr(), nfft, bin0, m_local,
                       H.data_ptr(), _pitch(m_local), _stream()), "sos_response")
-        ctx.save_for_backward(bc, ac)
+        # the float32 backward reuses the forward output instead of re-evaluating the cascade
+        keep = H if (real == torch.float32 and SOS_BWD_MIXED) else None
+        ctx.save_for_backward(bc, ac, *([keep] if keep is not None else []))
         ctx.cfg = (float(gamma), nfft, S, C_, bin0, m_local, real)
         return H.movedim(-1, 0)
 
     @staticmethod
     def backward(ctx, gH):
-        bc, ac = ctx.saved_tensors
+        bc, ac, *kept = ctx.saved_tensors
         gamma, nfft, S, C_, bin0, m_local, real = ctx.cfg
         dev = bc.device
+        Hf = kept[0] if kept else None
         g = _h_planar(gH.resolve_conj(), True)
         g_pitch = _lead_pitch(g.movedim(0, -1))
         L = _lib.lib()
         nblk = L.fl_sos_bwd_blocks(m_local)
-        part = torch.zeros((nblk, 2, 3, S, C_), dtype=torch.float64, device=dev)
+        part = torch.empty((nblk, 2, 3, S, C_), dtype=torch.float64, device=dev)   # every entry is written
         fn = L.fl_sos_response_bwd_c64 if real == torch.float32 else L.fl_sos_response_bwd_c128
         Wd = twiddles(nfft, torch.float64, dev)
-        _lib.check(fn(g.data_ptr(), g_pitch, bc.data_ptr(), ac.data_ptr(), S, C_, gamma, Wd.data_ptr(), nfft, bin0,
+        _lib.check(fn(g.data_ptr(), g_pitch, None if Hf is None else Hf.data_ptr(), _pitch(m_local), bc.data_ptr(), ac.data_ptr(), S, C_, gamma, Wd.data_ptr(), nfft, bin0,
                       m_local, part.data_ptr(), _stream()), "sos_response_bwd")
         tot = part.sum(dim=0)
         return tot[0].view(bc.shape), tot[1].view(ac.shape), None, None, None
@@ -722,3 +730,70 @@ def sos_response(b: torch.Tensor, a: torch.Tensor, gamma: float, nfft: int, dtyp
     The cascade is evaluated in float64 (coefficients are promoted); ``dtype`` (float32 |
     float64) selects the precision H is stored in."""
     return _Sos.apply(b.to(torch.float64), a.to(torch.float64), float(gamma), int(nfft), dtype)
+
+
+# ----------------------------------------------------------------------------- scalar objective
+_ms_scratch = {}
+
+
+def _ms_scratch_for(dev: torch.device) -> torch.Tensor:
+    """Per-block partials, one buffer per (device, stream)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    s = _ms_scratch.get(key)
+    if s is None:
+        s = torch.empty(_lib.lib().fl_mean_square_scratch_bytes(), dtype=torch.uint8, device=dev)
+        _ms_scratch[key] = s
+    return s
+
+
+def _rows_of(y: torch.Tensor):
+    """(tensor with the same memory, rows, cols, pitch): y's memory as rows of `cols` contiguous
+    elements `pitch` apart.  Works for contiguous tensors and for the signal-planar views the
+    transforms return; anything else is made contiguous first."""
+    if y.is_contiguous():
+        return y, 1, y.numel(), y.numel()
+    if y.dim() >= 2:
+        mem = y.movedim(1, -1)
+        P = _lead_pitch(mem)
+        if P is not None:
+            return y, _prod(mem.shape[:-1]), mem.shape[-1], P
+    yc = y.contiguous()
+    return yc, 1, yc.numel(), yc.numel()
+
+
+class _MeanSquare(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        dev = _require_gpu(y)
+        if y.dtype not in (torch.float32, torch.float64):
+            raise TypeError("mean_square expects a real float32/float64 tensor")
+        if y.numel() == 0:
+            raise ValueError("mean_square of an empty tensor")
+        ym, rows, cols, pitch = _rows_of(y)
+        loss = torch.empty((), dtype=y.dtype, device=dev)
+        L = _lib.lib()
+        fn = L.fl_mean_square_f32 if y.dtype == torch.float32 else L.fl_mean_square_f64
+        with kernel_timer.span("mean_square"):
+            _lib.check(fn(ym.data_ptr(), rows, cols, pitch, loss.data_ptr(), _ms_scratch_for(dev).data_ptr(), _stream()),
+                       "mean_square")
+        ctx.save_for_backward(ym)
+        ctx.layout = (rows, cols, pitch)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (ym,) = ctx.saved_tensors
+        rows, cols, pitch = ctx.layout
+        gy = torch.empty_strided(ym.shape, ym.stride(), dtype=ym.dtype, device=ym.device)
+        g = gloss.to(ym.dtype).contiguous()
+        L = _lib.lib()
+        fn = L.fl_mean_square_bwd_f32 if ym.dtype == torch.float32 else L.fl_mean_square_bwd_f64
+        with kernel_timer.span("mean_square_bwd"):
+            _lib.check(fn(ym.data_ptr(), g.data_ptr(), gy.data_ptr(), rows, cols, pitch, _stream()), "mean_square_bwd")
+        return gy
+
+
+def mean_square(y: torch.Tensor) -> torch.Tensor:
+    """(y ** 2).mean() of a real tensor in one streaming pass each way (forward: one read of y;
+    backward: one read + one write), in whatever layout y is stored."""
+    return _MeanSquare.apply(y)

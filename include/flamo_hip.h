@@ -182,14 +182,18 @@ int fl_sos_response_c64(const void* b, const void* a, int S, int C, double gamma
 int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamma, const void* Wd,
                          int nfft, int bin0, int m_local, void* H, long h_pitch, void* stream);
 /* Backward: partial sums over bins of dL/db, dL/da.  part: double (nblk, 2, 3, S, C) where
- * nblk = fl_sos_bwd_blocks(m_local); the caller sums over nblk. */
+ * nblk = fl_sos_bwd_blocks(m_local); every entry is written (no zero-fill needed), the caller sums
+ * over nblk.  H / h_pitch: the forward output.  _c64 with H != NULL takes the mixed-precision
+ * route (section values in double, quotients and running sums in float in the basis
+ * {1, d, d^2}, d = 1 - g w, converted back in double); H == NULL, and _c128 always, evaluates
+ * everything in double. */
 int fl_sos_bwd_blocks(int m_local);
-/* tuning hook: sections whose sums one thread keeps in registers (12, 6, 4 or 3; 0 = default) */
+/* tuning hook: sections whose sums one thread keeps in registers (0 = default); + 100 * blocks per channel */
 int fl_debug_set_sos_chunk(int sections_per_thread);
-int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* b, const void* a, int S, int C, double gamma,
-                            const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
-int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* b, const void* a, int S, int C, double gamma,
-                             const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
+int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
+                            int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
+int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
+                             int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
 
 /* Graphic-equaliser design: command gains in dB -> the float32-rounded second-order sections of
  * GEQ / parallelGEQ for all C channel pairs at once (replaces the Python double loop over
@@ -228,6 +232,22 @@ int fl_solve_dud_c64(const void* l, long l_sn, long l_sf, const void* U, const v
 int fl_solve_dud_c128(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, int adjoint,
                       const void* R, long rs_b, long rs_n, long rs_k, void* OUT, long os_b, long os_n, long os_k,
                       int B, int M, int N, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Scalar objective on the output of the path: the training step reduces the model output to one
+ * scalar and back-propagates it (flamo/optimize/trainer.py:179-191).  For the mean-square
+ * objective  loss = mean(y^2)  (torch: (y ** 2).mean(), five launches and eight passes over y)
+ *   fl_mean_square_*      loss[0] = (1/(rows*cols)) sum_{r,c} y[r*pitch + c]^2        (one read of y)
+ *   fl_mean_square_bwd_*  gy[r*pitch + c] = (2/(rows*cols)) * gloss[0] * y[r*pitch + c]
+ * y is real, rows of `cols` samples `pitch` apart (any layout the irfft leaves behind; padding
+ * is neither read nor written).  scratch: fl_mean_square_scratch_bytes() bytes private to one
+ * stream (per-block partials in double, combined in a fixed order by a second one-block launch:
+ * the value is deterministic).  loss/gloss are device scalars of y's type. */
+size_t fl_mean_square_scratch_bytes(void);
+int fl_mean_square_f32(const void* y, long rows, long cols, long pitch, void* loss, void* scratch, void* stream);
+int fl_mean_square_f64(const void* y, long rows, long cols, long pitch, void* loss, void* scratch, void* stream);
+int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
+int fl_mean_square_bwd_f64(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -214,3 +214,73 @@ def test_graphed_step_matches_eager(gpu):
     assert relerr(lg, le.detach()) < 1e-6
     for a, p in zip(gg, params):
         assert relerr(a, p.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-6), (torch.float64, 1e-13)])
+def test_mean_square_matches_torch_in_every_layout(gpu, dt, tol):
+    """ops.mean_square == (y ** 2).mean() with gradient 2 y g / count, for contiguous tensors, the
+    signal-planar views the transforms return (dense and padded rows) and odd sizes (scalar path)."""
+    from flamo_amd import ops
+    torch.manual_seed(11)
+    cases = []
+    cases.append(torch.randn(3, 1000, 8, dtype=dt, device=gpu))                               # contiguous
+    cases.append(torch.randn(2, 8, 96000, dtype=dt, device=gpu).movedim(-1, 1))               # planar, dense
+    cases.append(torch.randn(2, 5, 1024, dtype=dt, device=gpu)[..., :1001].movedim(-1, 1))    # planar, padded
+    cases.append(torch.randn(1, 3, 1030, dtype=dt, device=gpu)[..., 1:1028].movedim(-1, 1))   # unaligned base
+    cases.append(torch.randn(7, 13, dtype=dt, device=gpu))                                    # tiny
+    cases.append(torch.randn(4, 600, 6, dtype=dt, device=gpu)[:, ::2])                        # generic strides
+    for y0 in cases:
+        y = y0.clone(memory_format=torch.preserve_format) if y0.is_contiguous() else y0
+        y.requires_grad_(True)
+        loss = ops.mean_square(y)
+        w = torch.tensor(0.75, dtype=dt, device=gpu)
+        (g,) = torch.autograd.grad(loss * w, [y])
+        yr = y0.detach().cpu().double().requires_grad_(True)
+        lr = (yr ** 2).mean()
+        (gr,) = torch.autograd.grad(lr * 0.75, [yr])
+        assert abs(loss.item() - lr.item()) <= tol * abs(lr.item())
+        assert g.shape == y.shape and relerr(g.cpu(), gr) < tol
+    # repeated launches reuse the scratch: same bits every time
+    y = cases[1]
+    vals = {ops.mean_square(y).item() for _ in range(5)}
+    assert len(vals) == 1
+
+
+def test_sos_backward_mixed_precision_matches_double(gpu):
+    """float32 modules: the mixed-precision cascade backward (double section values, float
+    quotients, d-basis sums) against the all-double kernel -- graphic-EQ sections with a 31 Hz
+    band, band-pass sections whose numerator vanishes at DC and Nyquist, with and without the
+    anti-alias radius, S below and above one register chunk."""
+    from flamo_amd import functional as F, ops
+    torch.manual_seed(3)
+    nfft = 9600
+    M = nfft // 2 + 1
+    cf, sc = F.eq_freqs(1)
+    des = F.GEQDesign(cf, sc)
+    gdb = torch.rand(12, 3, 2, dtype=torch.float64) * 24 - 12
+    b_geq, a_geq = (t.double() for t in des.sections(gdb))   # float32-rounded values, held in double
+    th = torch.rand(14, 5, dtype=torch.float64) * 3.0 + 0.05
+    r = 0.5 + 0.49 * torch.rand(14, 5, dtype=torch.float64)
+    b_bp = torch.stack([torch.ones_like(th), torch.zeros_like(th), -torch.ones_like(th)]) * 0.3
+    a_bp = torch.stack([torch.ones_like(th), -2 * r * torch.cos(th), r * r])
+    for (b0, a0), gamma in (((b_geq, a_geq), 1.0), ((b_geq, a_geq), 10 ** (-30 / 20 / nfft)),
+                            ((b_bp, a_bp), 1.0), ((b_bp[:, :3], a_bp[:, :3]), 0.9999)):
+        grads = {}
+        for mixed in (True, False):
+            ops.SOS_BWD_MIXED = mixed
+            try:
+                b = b0.to(gpu).requires_grad_(True)
+                a = a0.to(gpu).requires_grad_(True)
+                H = ops.sos_response(b, a, gamma, nfft, dtype=torch.float32)
+                torch.manual_seed(17)
+                Cw = torch.randn(H.shape, dtype=torch.complex64, device=gpu)
+                grads[mixed] = torch.autograd.grad(torch.sum(torch.real(H * torch.conj(Cw))), [b, a])
+            finally:
+                ops.SOS_BWD_MIXED = True
+        assert H.shape[0] == M
+        for gm, gd in zip(grads[True], grads[False]):
+            assert relerr(gm.cpu(), gd.cpu()) < 5e-6
+            # the second differences the parameter maps take downstream must survive as well
+            dm = gm[0] - 2 * gm[1] + gm[2]
+            dd = gd[0] - 2 * gd[1] + gd[2]
+            assert relerr(dm.cpu(), dd.cpu()) < 5e-5
