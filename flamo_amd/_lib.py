@@ -13,7 +13,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflamo_hip.so")
+LIB_PATH = os.environ.get("FLAMO_HIP_LIB") or os.path.join(_HERE, "libflamo_hip.so")   # override: A/B builds
 CSRC = os.path.join(_HERE, "csrc")
 
 _lock = threading.Lock()

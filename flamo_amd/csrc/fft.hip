@@ -533,54 +533,132 @@ struct RegFFT {
     }
 };
 
-constexpr int FAST_CT = 16;  // columns per workgroup in pass 1 (16 x 8 B = 128-byte segments)
-
-template <typename T, int A, int B, int LOAD, bool INV>
+// Columns per workgroup in pass 1: CT x 8 B (c64) contiguous per row -- 128-byte segments for
+// CT = 16, 256-byte for CT = 32.
+//
+// Inter-pass twiddle W_L^(col * k1), k1 = ka + A kb: factored as W_L^(col ka) * W_L^(col A kb).
+// The first factor is one value per stage-2 thread, the second a (CT x B) table in LDS filled
+// with CT*B gathers per workgroup -- instead of one gather from the master table per OUTPUT
+// element (lanes of a wavefront hit 64 different cache lines each time: the twiddle gathers cost
+// the L1 four times the cycles of the data itself).
+template <typename T, int A, int B, int LOAD, bool INV, int CT>
 __global__ void __launch_bounds__(256) fft_cols_fast(FftArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LEN = A * B, LENP = LEN | 1;
-    cx<T>* U = reinterpret_cast<cx<T>*>(smem);   // [FAST_CT][LENP]
-    cx<T>* tw = U + FAST_CT * LENP;               // W_LEN^m
+    cx<T>* U = reinterpret_cast<cx<T>*>(smem);   // [CT][LENP]
+    cx<T>* tw = U + CT * LENP;                    // W_LEN^m
+    cx<T>* t2 = tw + LEN;                         // [CT][B]: W_L^(col * A * kb)
+    cx<T>* wr = t2 + CT * B;                      // LOAD_IRFFT_PRE only: W_n^(row * L2), row < LEN
+    cx<T>* wc = wr + LEN;                         //                      W_n^(c0 + c)
     int tile, sig;
     if (!cols_block<T, LOAD>(a, a.nsig, tile, sig)) return;
-    const int c0 = tile * FAST_CT;
-    const int nc = min(FAST_CT, a.L2 - c0);
+    const int c0 = tile * CT;
+    const int nc = min(CT, a.L2 - c0);
     const int twstep = a.n / LEN;
     for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[j * twstep];
+    for (int j = threadIdx.x; j < CT * B; j += 256) {
+        const int c = j / B, kb = j - c * B;
+        t2[j] = (c < nc) ? a.W[2 * (c0 + c) * A * kb] : cx<T>(1, 0);
+    }
+    if constexpr (LOAD == LOAD_IRFFT_PRE) {
+        for (int j = threadIdx.x; j < LEN; j += 256) wr[j] = a.W[j * a.L2];
+        if (threadIdx.x < CT) wc[threadIdx.x] = (threadIdx.x < nc) ? a.W[c0 + threadIdx.x] : cx<T>(1, 0);
+    }
     __syncthreads();
-    // stage 1: A-point FFTs over t_a for every (t_b, column)
-    for (int item = threadIdx.x; item < B * FAST_CT; item += 256) {
-        const int tb = item / FAST_CT, c = item % FAST_CT;
-        if (c < nc) {
-            cx<T> v[A];
+    // stage 1: A-point FFTs over t_a for every (t_b, column).  A thread owns up to NR items and
+    // issues the loads of all of them before the first butterfly: the pass is bound by how many
+    // bytes a CU keeps in flight (few workgroups fit beside the LDS tile), not by arithmetic.
+    constexpr int NR = (B * CT + 255) / 256;
+    {
+        cx<T> v[NR][A];
+        if constexpr (LOAD == LOAD_IRFFT_PRE) {
+            // Hermitian pre-step fused into the load (see load_irfft_pre): both halves of every
+            // pair are requested before anything is combined; W_n^j, j = row*L2 + col, comes
+            // from the two small LDS tables instead of a third global load per element.
+            cx<T> xb[NR][A];
 #pragma unroll
-            for (int ta = 0; ta < A; ++ta) v[ta] = load_any<T, LOAD>(a, sig, (ta * B + tb) * a.L2 + c0 + c);
-            RegFFT<T, A, INV>::run(v);
-            cx<T>* u = U + c * LENP + tb;
-            u[0] = v[0];
+            for (int r = 0; r < NR; ++r) {
+                const int item = threadIdx.x + r * 256;
+                const int tb = item / CT, c = item % CT;
+                if (item < B * CT && c < nc) {
+                    const cx<T>* X = a.Xc + (size_t)sig * a.xc_stride;
 #pragma unroll
-            for (int ka = 1; ka < A; ++ka) {
-                cx<T> t = tw[ka * tb];
-                if (INV) t = conj(t);
-                u[ka * B] = v[ka] * t;
+                    for (int ta = 0; ta < A; ++ta) {
+                        const int j = (ta * B + tb) * a.L2 + c0 + c;
+                        v[r][ta] = X[j];
+                        xb[r][ta] = X[a.L - j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int item = threadIdx.x + r * 256;
+                const int tb = item / CT, c = item % CT;
+                if (item < B * CT && c < nc) {
+                    const cx<T> wcol = wc[c];
+#pragma unroll
+                    for (int ta = 0; ta < A; ++ta) {
+                        const int row = ta * B + tb;
+                        cx<T> xa = v[r][ta], xm = xb[r][ta];
+                        if (row == 0 && c0 + c == 0) {  // DC and Nyquist: imaginary parts ignored (C2R)
+                            xa.y = 0;
+                            xm.y = 0;
+                        } else if (a.interior) {
+                            xa = (T)0.5 * xa;
+                            xm = (T)0.5 * xm;
+                        }
+                        xm = conj(xm);
+                        const cx<T> sum = xa + xm, dif = xa - xm;
+                        const cx<T> w = conj(wr[row] * wcol);
+                        v[r][ta] = sum + mul_i(w * dif);
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int item = threadIdx.x + r * 256;
+                const int tb = item / CT, c = item % CT;
+                if (item < B * CT && c < nc) {
+#pragma unroll
+                    for (int ta = 0; ta < A; ++ta) v[r][ta] = load_any<T, LOAD>(a, sig, (ta * B + tb) * a.L2 + c0 + c);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int item = threadIdx.x + r * 256;
+            const int tb = item / CT, c = item % CT;
+            if (item < B * CT && c < nc) {
+                RegFFT<T, A, INV>::run(v[r]);
+                cx<T>* u = U + c * LENP + tb;
+                u[0] = v[r][0];
+#pragma unroll
+                for (int ka = 1; ka < A; ++ka) {
+                    cx<T> t = tw[ka * tb];
+                    if (INV) t = conj(t);
+                    u[ka * B] = v[r][ka] * t;
+                }
             }
         }
     }
     __syncthreads();
     // stage 2: B-point FFTs over t_b for every (k_a, column); inter-pass twiddle; store
     cx<T>* out = a.scratch + (size_t)sig * a.L;
-    for (int item = threadIdx.x; item < A * FAST_CT; item += 256) {
-        const int ka = item / FAST_CT, c = item % FAST_CT;
+    for (int item = threadIdx.x; item < A * CT; item += 256) {
+        const int ka = item / CT, c = item % CT;
         if (c < nc) {
             cx<T> v[B];
             const cx<T>* u = U + c * LENP + ka * B;
 #pragma unroll
             for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
             RegFFT<T, B, INV>::run(v);
+            const cx<T> w1 = a.W[2 * (c0 + c) * ka];
+            const cx<T>* w2 = t2 + c * B;
 #pragma unroll
             for (int kb = 0; kb < B; ++kb) {
                 const int k1 = ka + A * kb;
-                cx<T> w = a.W[2 * (c0 + c) * k1];
+                cx<T> w = w1 * w2[kb];
                 if (INV) w = conj(w);
                 out[(size_t)k1 * a.L2 + c0 + c] = v[kb] * w;
             }
@@ -714,10 +792,17 @@ static const FastSplit* fast_split(int len) {
 
 template <typename T, int A, int B>
 static void launch_cols_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, size_t lds, hipStream_t st) {
-    if (inverse)
-        hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_IRFFT_PRE, true>), dim3(nblk), dim3(256), lds, st, a);
-    else
-        hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_PACK, false>), dim3(nblk), dim3(256), lds, st, a);
+    if (a.CT == 32) {
+        if (inverse)
+            hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_IRFFT_PRE, true, 32>), dim3(nblk), dim3(256), lds, st, a);
+        else
+            hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_PACK, false, 32>), dim3(nblk), dim3(256), lds, st, a);
+    } else {
+        if (inverse)
+            hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_IRFFT_PRE, true, 16>), dim3(nblk), dim3(256), lds, st, a);
+        else
+            hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_PACK, false, 16>), dim3(nblk), dim3(256), lds, st, a);
+    }
 }
 template <typename T, int A, int B>
 static void launch_rows_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, size_t lds, int nthreads, hipStream_t st) {
@@ -810,6 +895,7 @@ __global__ void __launch_bounds__(256) transpose_narrow_kernel(const E* __restri
 // ---------------------------------------------------------------- host-side planning
 static int g_max_single = 0;
 static int g_fast_enabled = 1;
+static int g_fast_ct = 0;   // 0 = default choice, 16 / 32 = forced (tuning hook)
 
 static bool factorize(int n, Rad& rad) {
     rad.n = 0;
@@ -894,9 +980,11 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
     if (p.L1 > 1) {
         FL_REQUIRE(a.scratch != nullptr, "two-pass FFT (nfft=%d) needs a scratch buffer", p.n);
         if (use_fast) {
-            a.CT = FAST_CT;
-            a.ntiles = cdiv_i(p.L2, FAST_CT);
-            const size_t lds = (size_t)(FAST_CT * a.L1P + p.L1) * esz;
+            const FastSplit* f1 = fast_split(p.L1);
+            // 32-column tiles pay off for the inverse (its mirror reads straddle lines), not forward
+            a.CT = (sizeof(T) == 4 && (g_fast_ct == 32 || (g_fast_ct == 0 && inverse))) ? 32 : 16;
+            a.ntiles = cdiv_i(p.L2, a.CT);
+            const size_t lds = (size_t)(a.CT * a.L1P + p.L1 + a.CT * f1->B + (inverse ? p.L1 + a.CT : 0)) * esz;
             const size_t nblk = cols_grid(a, nsig);
             FL_REQUIRE(nblk < (1ull << 31), "grid too large");
             FL_FAST_DISPATCH(launch_cols_fast, p.L1, inverse, a, (unsigned)nblk, lds, st)
@@ -1060,6 +1148,7 @@ int fl_debug_set_fft_max_single(int max_half_len) {
 
 int fl_debug_set_fft_fast(int enabled) {
     g_fast_enabled = enabled != 0;
+    g_fast_ct = (enabled == 32) ? 32 : (enabled == 16 ? 16 : 0);   // tuning: force 16- / 32-column tiles in pass 1
     return FL_OK;
 }
 
