@@ -325,14 +325,29 @@ __global__ void __launch_bounds__(256) sos_response_bwd_mixed_kernel(
 // One thread per (band, channel): ~1 KB of work replaces ~150 tiny elementwise launches per step.
 __device__ inline double f32r(double x) { return (double)(float)x; }
 
-__global__ void __launch_bounds__(256) geq_sections_kernel(const double* __restrict__ gain_db, int nb, int C,
+// in_kind: 0 = command gains in dB (double); 1 / 2 = LINEAR command gains x (double / float),
+// i.e. the module's raw parameters under its default map 20 log10|x| -- then g = 10^(map/20) = |x|
+// and the map, its backward and the dtype casts (ten tiny launches per step) fold into these two.
+__device__ inline double geq_linear_gain(const void* gain, int in_kind, int idx, double* raw) {
+    if (in_kind == 0) {
+        const double v = reinterpret_cast<const double*>(gain)[idx];
+        *raw = v;
+        return pow(10.0, v / 20.0);
+    }
+    const double v = in_kind == 2 ? (double)reinterpret_cast<const float*>(gain)[idx] : reinterpret_cast<const double*>(gain)[idx];
+    *raw = v;
+    return fabs(v);
+}
+
+__global__ void __launch_bounds__(256) geq_sections_kernel(const void* __restrict__ gain, int in_kind, int nb, int C,
                                                           const double* __restrict__ k, double* __restrict__ b,
                                                           double* __restrict__ a) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= nb * C) return;
     const int band = idx / C;
     const int st = nb * C;
-    const double g = pow(10.0, gain_db[idx] / 20.0);
+    double raw;
+    const double g = geq_linear_gain(gain, in_kind, idx, &raw);
     double b0, b1, b2, a0, a1, a2;
     if (band == 0) {
         b0 = f32r(g); b1 = 0; b2 = 0; a0 = 1; a1 = 0; a2 = 0;
@@ -360,18 +375,27 @@ __global__ void __launch_bounds__(256) geq_sections_kernel(const double* __restr
     a[idx] = a0; a[idx + st] = a1; a[idx + 2 * st] = a2;
 }
 
-__global__ void __launch_bounds__(256) geq_sections_bwd_kernel(const double* __restrict__ gain_db,
+// gb / ga: (nblk, 3, nb, C) partial sums blk_stride elements apart (nblk = 1: plain gradients);
+// summed here in block order, so the bin-block partials of the cascade backward need no separate
+// reduction launch.
+__global__ void __launch_bounds__(256) geq_sections_bwd_kernel(const void* __restrict__ gain, int in_kind,
                                                               const double* __restrict__ gb,
-                                                              const double* __restrict__ ga, int nb, int C,
-                                                              const double* __restrict__ k,
-                                                              double* __restrict__ ggain) {
+                                                              const double* __restrict__ ga, long blk_stride, int nblk,
+                                                              int nb, int C, const double* __restrict__ k,
+                                                              void* __restrict__ ggain) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= nb * C) return;
     const int band = idx / C;
     const int st = nb * C;
-    const double g = pow(10.0, gain_db[idx] / 20.0);
-    const double B0 = gb[idx], B1 = gb[idx + st], B2 = gb[idx + 2 * st];
-    const double A0 = ga[idx], A1 = ga[idx + st], A2 = ga[idx + 2 * st];
+    double raw;
+    const double g = geq_linear_gain(gain, in_kind, idx, &raw);
+    double B0 = 0, B1 = 0, B2 = 0, A0 = 0, A1 = 0, A2 = 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+        const double* pb = gb + (size_t)blk * blk_stride + idx;
+        const double* pa = ga + (size_t)blk * blk_stride + idx;
+        B0 += pb[0]; B1 += pb[st]; B2 += pb[2 * st];
+        A0 += pa[0]; A1 += pa[st]; A2 += pa[2 * st];
+    }
     double dg;  // dL/dg
     if (band == 0) {
         dg = B0;
@@ -397,7 +421,13 @@ __global__ void __launch_bounds__(256) geq_sections_bwd_kernel(const double* __r
         const double dsg = 0.5 / sqrt(g);
         dg = B0 * (dsg + t) + B1 * (-2 * c * dsg) + B2 * (dsg - t) + A0 * dsg + A1 * (-2 * c * dsg) + A2 * dsg;
     }
-    ggain[idx] = dg * g * (2.302585092994045684 / 20.0);   // dg/dgain_db = g ln(10) / 20
+    if (in_kind == 0) {
+        reinterpret_cast<double*>(ggain)[idx] = dg * g * (2.302585092994045684 / 20.0);   // dg/dgain_db = g ln(10) / 20
+    } else {
+        const double v = dg * (raw > 0 ? 1.0 : (raw < 0 ? -1.0 : 0.0));                   // g = |x|
+        if (in_kind == 2) reinterpret_cast<float*>(ggain)[idx] = (float)v;
+        else reinterpret_cast<double*>(ggain)[idx] = v;
+    }
 }
 
 static int g_sos_chunk = 0;
@@ -511,21 +541,23 @@ int fl_debug_set_sos_chunk(int sections_per_thread) {
     return FL_OK;
 }
 
-int fl_geq_sections(const void* gain_db, int nb, int C, const void* consts, void* b, void* a, void* stream) {
-    FL_REQUIRE(gain_db && consts && b && a, "geq_sections: null pointer");
+int fl_geq_sections(const void* gain, int in_kind, int nb, int C, const void* consts, void* b, void* a, void* stream) {
+    FL_REQUIRE(gain && consts && b && a, "geq_sections: null pointer");
+    FL_REQUIRE(in_kind >= 0 && in_kind <= 2, "geq_sections: in_kind must be 0 (dB, f64), 1 (linear, f64) or 2 (linear, f32)");
     FL_REQUIRE(nb >= 4 && C > 0, "geq_sections: need >= 4 bands (gain, two shelves, one peak) and C > 0");
     hipLaunchKernelGGL(geq_sections_kernel, dim3(cdiv_i((long)nb * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const double*)gain_db, nb, C, (const double*)consts, (double*)b, (double*)a);
+                       gain, in_kind, nb, C, (const double*)consts, (double*)b, (double*)a);
     FL_CHECK_LAUNCH("geq_sections");
     return FL_OK;
 }
-int fl_geq_sections_bwd(const void* gain_db, const void* gb, const void* ga, int nb, int C, const void* consts,
-                        void* ggain, void* stream) {
-    FL_REQUIRE(gain_db && gb && ga && consts && ggain, "geq_sections_bwd: null pointer");
-    FL_REQUIRE(nb >= 4 && C > 0, "geq_sections_bwd: bad sizes");
+int fl_geq_sections_bwd(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
+                        int C, const void* consts, void* ggain, void* stream) {
+    FL_REQUIRE(gain && gb && ga && consts && ggain, "geq_sections_bwd: null pointer");
+    FL_REQUIRE(in_kind >= 0 && in_kind <= 2, "geq_sections_bwd: bad in_kind");
+    FL_REQUIRE(nb >= 4 && C > 0 && nblk >= 1 && blk_stride >= 0, "geq_sections_bwd: bad sizes");
     hipLaunchKernelGGL(geq_sections_bwd_kernel, dim3(cdiv_i((long)nb * C, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const double*)gain_db, (const double*)gb, (const double*)ga, nb, C, (const double*)consts,
-                       (double*)ggain);
+                       gain, in_kind, (const double*)gb, (const double*)ga, blk_stride, nblk, nb, C,
+                       (const double*)consts, ggain);
     FL_CHECK_LAUNCH("geq_sections_bwd");
     return FL_OK;
 }

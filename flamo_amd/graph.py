@@ -31,12 +31,14 @@ class GraphedStep:
             for _ in range(warmup):
                 self._run_eager()
         torch.cuda.current_stream().wait_stream(side)
-        for p in self.params:                    # grads must exist (and stay the same tensors) before capture
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_out = self._run_captured()
+        # the gradients the captured backward produces live in the graph's pool and are rewritten
+        # in place by every replay: hand them to the parameters as they are (no copy per step)
+        for p, g in zip(self.params, self._static_grads):
+            if g is not None:
+                p.grad = g
 
     def _run_eager(self):
         for p in self.params:
@@ -48,9 +50,7 @@ class GraphedStep:
     def _run_captured(self):
         out = self._fn(*self.static_inputs)
         grads = torch.autograd.grad(out, self.params, allow_unused=True) if self.params else ()
-        for p, g in zip(self.params, grads):
-            if g is not None:
-                p.grad.copy_(g)
+        self._static_grads = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
         return out.detach()
 
     @property

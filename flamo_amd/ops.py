@@ -645,48 +645,67 @@ def delay_response(m_int: torch.Tensor, amp: torch.Tensor, nfft: int) -> torch.T
 SOS_BWD_MIXED = True
 
 
+def _sos_forward_launch(bc, ac, gamma, nfft, real):
+    """bc, ac: contiguous float64 (3, S, chan...) on the GPU -> (H rows buffer (chan..., pitch)[..., :m_local], cfg)"""
+    dev = bc.device
+    S = bc.shape[1]
+    chan = tuple(bc.shape[2:])
+    C_ = max(_prod(chan), 1)
+    bin0, m_local = bin_shard(nfft)
+    H = _empty_rows(chan, m_local, _cdtype(real), dev)
+    L = _lib.lib()
+    fn = L.fl_sos_response_c64 if real == torch.float32 else L.fl_sos_response_c128
+    Wd = twiddles(nfft, torch.float64, dev)
+    with kernel_timer.span("sos_response"):
+        _lib.check(fn(bc.data_ptr(), ac.data_ptr(), S, C_, float(gamma), Wd.data_ptr(), nfft, bin0, m_local,
+                      H.data_ptr(), _pitch(m_local), _stream()), "sos_response")
+    return H, (float(gamma), nfft, S, C_, bin0, m_local, real)
+
+
+def _sos_backward_launch(gH, Hf, bc, ac, cfg):
+    """-> part: float64 (nblk, 2, 3, S, C) per-bin-block partial sums of (dL/db, dL/da)"""
+    gamma, nfft, S, C_, bin0, m_local, real = cfg
+    g = _h_planar(gH.resolve_conj(), True)
+    g_pitch = _lead_pitch(g.movedim(0, -1))
+    L = _lib.lib()
+    nblk = L.fl_sos_bwd_blocks(m_local)
+    part = torch.empty((nblk, 2, 3, S, C_), dtype=torch.float64, device=bc.device)   # every entry is written
+    fn = L.fl_sos_response_bwd_c64 if real == torch.float32 else L.fl_sos_response_bwd_c128
+    Wd = twiddles(nfft, torch.float64, bc.device)
+    with kernel_timer.span("sos_response_bwd"):
+        _lib.check(fn(g.data_ptr(), g_pitch, None if Hf is None else Hf.data_ptr(), _pitch(m_local), bc.data_ptr(),
+                      ac.data_ptr(), S, C_, gamma, Wd.data_ptr(), nfft, bin0, m_local, part.data_ptr(), _stream()),
+                   "sos_response_bwd")
+    return part
+
+
 class _Sos(torch.autograd.Function):
     @staticmethod
     def forward(ctx, b, a, gamma, nfft, real):
-        dev = _require_gpu(b, a)
+        _require_gpu(b, a)
         if b.shape != a.shape or b.shape[0] != 3 or b.dim() < 2:
             raise ValueError("sos_response: b and a must both be (3, n_sections, ...)")
         if b.dtype != torch.float64 or a.dtype != torch.float64:
             raise TypeError("sos_response: coefficients are passed in float64")
         bc, ac = b.contiguous(), a.contiguous()
-        S = b.shape[1]
-        chan = tuple(b.shape[2:])
-        C_ = max(_prod(chan), 1)
-        bin0, m_local = bin_shard(nfft)
-        H = _empty_rows(chan, m_local, _cdtype(real), dev)
-        L = _lib.lib()
-        fn = L.fl_sos_response_c64 if real == torch.float32 else L.fl_sos_response_c128
-        Wd = twiddles(nfft, torch.float64, dev)
-        _lib.check(fn(bc.data_ptr(), ac.data_ptr(), S, C_, float(gamma), Wd.data_ptr(), nfft, bin0, m_local,
-                      H.data_ptr(), _pitch(m_local), _stream()), "sos_response")
+        H, ctx.cfg = _sos_forward_launch(bc, ac, gamma, nfft, real)
         # the float32 backward reuses the forward output instead of re-evaluating the cascade
         keep = H if (real == torch.float32 and SOS_BWD_MIXED) else None
         ctx.save_for_backward(bc, ac, *([keep] if keep is not None else []))
-        ctx.cfg = (float(gamma), nfft, S, C_, bin0, m_local, real)
         return H.movedim(-1, 0)
 
     @staticmethod
     def backward(ctx, gH):
         bc, ac, *kept = ctx.saved_tensors
-        gamma, nfft, S, C_, bin0, m_local, real = ctx.cfg
-        dev = bc.device
-        Hf = kept[0] if kept else None
-        g = _h_planar(gH.resolve_conj(), True)
-        g_pitch = _lead_pitch(g.movedim(0, -1))
-        L = _lib.lib()
-        nblk = L.fl_sos_bwd_blocks(m_local)
-        part = torch.empty((nblk, 2, 3, S, C_), dtype=torch.float64, device=dev)   # every entry is written
-        fn = L.fl_sos_response_bwd_c64 if real == torch.float32 else L.fl_sos_response_bwd_c128
-        Wd = twiddles(nfft, torch.float64, dev)
-        _lib.check(fn(g.data_ptr(), g_pitch, None if Hf is None else Hf.data_ptr(), _pitch(m_local), bc.data_ptr(), ac.data_ptr(), S, C_, gamma, Wd.data_ptr(), nfft, bin0,
-                      m_local, part.data_ptr(), _stream()), "sos_response_bwd")
+        part = _sos_backward_launch(gH, kept[0] if kept else None, bc, ac, ctx.cfg)
         tot = part.sum(dim=0)
         return tot[0].view(bc.shape), tot[1].view(ac.shape), None, None, None
+
+
+def _geq_in_kind(t: torch.Tensor, linear: bool) -> int:
+    if not linear:
+        return 0
+    return 2 if t.dtype == torch.float32 else 1
 
 
 class _GeqSections(torch.autograd.Function):
@@ -699,7 +718,7 @@ class _GeqSections(torch.autograd.Function):
         C_ = max(_prod(chan), 1)
         b = torch.empty((3, nb, *chan), dtype=torch.float64, device=dev)
         a = torch.empty_like(b)
-        _lib.check(_lib.lib().fl_geq_sections(gd.data_ptr(), nb, C_, consts.data_ptr(), b.data_ptr(), a.data_ptr(),
+        _lib.check(_lib.lib().fl_geq_sections(gd.data_ptr(), 0, nb, C_, consts.data_ptr(), b.data_ptr(), a.data_ptr(),
                                               _stream()), "geq_sections")
         ctx.save_for_backward(gd, consts)
         ctx.in_dtype = gain_db.dtype
@@ -713,9 +732,56 @@ class _GeqSections(torch.autograd.Function):
         out = torch.empty_like(gd)
         gb = torch.zeros_like(gd.new_empty((3, *gd.shape))) if gb is None else gb.to(torch.float64).contiguous()
         ga = torch.zeros_like(gb) if ga is None else ga.to(torch.float64).contiguous()
-        _lib.check(_lib.lib().fl_geq_sections_bwd(gd.data_ptr(), gb.data_ptr(), ga.data_ptr(), nb, C_, consts.data_ptr(),
-                                                  out.data_ptr(), _stream()), "geq_sections_bwd")
+        _lib.check(_lib.lib().fl_geq_sections_bwd(gd.data_ptr(), 0, gb.data_ptr(), ga.data_ptr(), 0, 1, nb, C_,
+                                                  consts.data_ptr(), out.data_ptr(), _stream()), "geq_sections_bwd")
         return out.to(ctx.in_dtype), None
+
+
+class _GeqCascade(torch.autograd.Function):
+    """GEQ / parallelGEQ under the default map: raw parameters -> response in two launches
+    (design + cascade), gradient in two (cascade backward + design backward, which also sums the
+    bin-block partials)."""
+
+    @staticmethod
+    def forward(ctx, x, consts, gamma, nfft, real):
+        dev = _require_gpu(x, consts)
+        if x.dtype not in (torch.float32, torch.float64):
+            raise TypeError("geq_cascade expects float32 / float64 parameters")
+        xc = x.contiguous()
+        nb = xc.shape[0]
+        chan = tuple(xc.shape[1:])
+        C_ = max(_prod(chan), 1)
+        kind = _geq_in_kind(xc, True)
+        b = torch.empty((3, nb, *chan), dtype=torch.float64, device=dev)
+        a = torch.empty_like(b)
+        _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), kind, nb, C_, consts.data_ptr(), b.data_ptr(), a.data_ptr(),
+                                              _stream()), "geq_sections")
+        H, ctx.cfg = _sos_forward_launch(b, a, gamma, nfft, real)
+        keep = H if (real == torch.float32 and SOS_BWD_MIXED) else None
+        ctx.save_for_backward(xc, consts, b, a, *([keep] if keep is not None else []))
+        return H.movedim(-1, 0)
+
+    @staticmethod
+    def backward(ctx, gH):
+        xc, consts, b, a, *kept = ctx.saved_tensors
+        part = _sos_backward_launch(gH, kept[0] if kept else None, b, a, ctx.cfg)
+        nblk = part.shape[0]
+        nb = xc.shape[0]
+        C_ = max(_prod(xc.shape[1:]), 1)
+        st = nb * C_
+        out = torch.empty_like(xc)
+        esz = part.element_size()
+        _lib.check(_lib.lib().fl_geq_sections_bwd(xc.data_ptr(), _geq_in_kind(xc, True), part.data_ptr(),
+                                                  part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
+                                                  out.data_ptr(), _stream()), "geq_sections_bwd")
+        return out, None, None, None, None
+
+
+def geq_cascade(x: torch.Tensor, consts: torch.Tensor, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
+    """Response (M, ...) of the graphic equaliser whose raw parameters x (n_bands, ...) go through
+    the default map 20 log10|x| -- same result as sos_response(*geq_sections(20 log10|x|)), with
+    the map and its backward folded into the design kernels."""
+    return _GeqCascade.apply(x, consts, float(gamma), int(nfft), dtype)
 
 
 def geq_sections(gain_db: torch.Tensor, consts: torch.Tensor):

@@ -524,12 +524,18 @@ class parallelBiquad(Biquad):
         assert len(self.size) == 3, "Parameter size must be 3D, for 3D sapce use Biquad module."
 
 
+def _db_of_magnitude(x):
+    """GEQ's default parameter map (dsp.py:2526); a named function so that the module can tell the
+    default from a user map and fold it into the design kernel."""
+    return 20 * torch.log10(torch.abs(x))
+
+
 class GEQ(_SOSMixin, Filter):
     """Graphic equaliser: param (n_bands+3 command gains, N_out, N_in), default map 20 log10|x|
     (dsp.py:2467-2611).  Sections: flat gain, low shelf, octave peaks (R = 2.7), high shelf."""
 
     def __init__(self, size: tuple = (1, 1), octave_interval: int = 1, nfft: int = 2 ** 11, fs: int = 48000,
-                 map: callable = lambda x: 20 * torch.log10(torch.abs(x)), requires_grad: bool = False,
+                 map: callable = _db_of_magnitude, requires_grad: bool = False,
                  alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32):
         self.octave_interval = octave_interval
         self.fs = fs
@@ -547,6 +553,15 @@ class GEQ(_SOSMixin, Filter):
     def check_param_shape(self):
         assert len(self.size) == 3, "Filter must be 3D, for 2D (parallel) filters use ParallelGEQ module."
 
+    def get_freq_response(self):
+        def response(param):
+            if self.map is _db_of_magnitude and param.is_cuda and param.dtype in (torch.float32, torch.float64):
+                # default map: 10^(map(x)/20) = |x|, folded into the design kernel with its backward
+                return ops.geq_cascade(param, self._design.device_consts(param.device), self._gamma_f, self.nfft,
+                                       dtype=self.dtype)
+            return self._sos_to_response(*self._sos_coeffs(self.map(param.double())))
+        self.freq_response = response
+
     def _sos_coeffs(self, gain_db):
         """command gains in dB -> float32 SOS (b, a) for every channel pair at once; the
         reference loops over pairs in Python calling eq.geq (dsp.py:2573-2585)."""
@@ -561,7 +576,7 @@ class parallelGEQ(GEQ):
     _diag = True
 
     def __init__(self, size: tuple = (1,), octave_interval: int = 1, nfft: int = 2 ** 11, fs: int = 48000,
-                 map: callable = lambda x: 20 * torch.log10(torch.abs(x)), requires_grad: bool = False,
+                 map: callable = _db_of_magnitude, requires_grad: bool = False,
                  alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32):
         super().__init__(size=size, octave_interval=octave_interval, nfft=nfft, fs=fs, map=map,
                          requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device, dtype=dtype)

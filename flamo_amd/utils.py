@@ -9,7 +9,9 @@ def get_device():
 
 def to_complex(x: torch.Tensor) -> torch.Tensor:
     """Real tensor -> complex tensor with zero imaginary part (flamo/utils.py:12-22)."""
-    return torch.complex(x, torch.zeros_like(x))
+    if x.is_complex():
+        return x
+    return x.to(torch.complex64 if x.dtype == torch.float32 else (torch.complex128 if x.dtype == torch.float64 else torch.complex32))
 
 
 def get_frequency_samples(num: int, rho: float = 1.0, device="cpu", dtype=torch.float64):

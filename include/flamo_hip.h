@@ -195,15 +195,22 @@ int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_
 int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
                              int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
 
-/* Graphic-equaliser design: command gains in dB -> the float32-rounded second-order sections of
+/* Graphic-equaliser design: command gains -> the float32-rounded second-order sections of
  * GEQ / parallelGEQ for all C channel pairs at once (replaces the Python double loop over
  * flamo/auxiliary/eq.py:57-111 `geq` in dsp.py:2573-2585, 2661-2672), and its backward.
- *   gain_db: double (nb, C);  b, a: double (3, nb, C) holding float32-representable values;
+ *   gain: (nb, C), in_kind 0: command gains in dB, double;
+ *                  in_kind 1 / 2: the module's RAW parameters x (double / float) under its default
+ *                  map 20 log10|x| (dsp.py:2526) -- the linear gain is then |x| and the map, its
+ *                  backward and the dtype casts fold into these two launches;
+ *   b, a: double (3, nb, C) holding float32-representable values;
  *   consts: double [t_lo, t_hi, t2_lo, t2_hi, st_lo, st_hi, pk_t[nb-3], pk_c[nb-3]] -- tan/cos of
- *   the float32 band frequencies as the host evaluates them (flamo/functional.py:555-675). */
-int fl_geq_sections(const void* gain_db, int nb, int C, const void* consts, void* b, void* a, void* stream);
-int fl_geq_sections_bwd(const void* gain_db, const void* gb, const void* ga, int nb, int C, const void* consts,
-                        void* ggain, void* stream);
+ *   the float32 band frequencies as the host evaluates them (flamo/functional.py:555-675).
+ * Backward: gb, ga: double (nblk, 3, nb, C) partial gradients, blk_stride elements between blocks
+ * (fl_sos_response_bwd's `part` is consumed directly: gb = part, ga = part + 3*nb*C,
+ * blk_stride = 6*nb*C); ggain: (nb, C) in gain's type. */
+int fl_geq_sections(const void* gain, int in_kind, int nb, int C, const void* consts, void* b, void* a, void* stream);
+int fl_geq_sections_bwd(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
+                        int C, const void* consts, void* ggain, void* stream);
 
 /* ------------------------------------------------------------------ closed loop
  * Replace torch.linalg.solve(A, B) in system.Recursion.forward (system.py:420-425).
