@@ -14,7 +14,7 @@
 
 namespace fl {
 
-template <typename T, int MT, int BT>
+template <typename T, int MT, int BT, int NU>
 __global__ void __launch_bounds__(256) mimo_full_kernel(
     const cx<T>* __restrict__ H, long hs_f, long hs_m, long hs_n, int conj_h,
     const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
@@ -48,20 +48,28 @@ __global__ void __launch_bounds__(256) mimo_full_kernel(
 #pragma unroll
         for (int mm = 0; mm < MT; ++mm) acc[c][mm] = cx<T>(0, 0);
     const cx<T>* Hf = H + (long)f * hs_f;
-    for (int n = 0; n < Ni; ++n) {
-        cx<T> h[MT], x[BT];
+    // NU input channels per trip: (MT + BT) * NU loads are issued before their FMAs
+    for (int n0 = 0; n0 < Ni; n0 += NU) {
+        cx<T> h[NU][MT], x[NU][BT];
 #pragma unroll
-        for (int mm = 0; mm < MT; ++mm) {
-            const int m = m0 + mm;
-            h[mm] = (m < No) ? Hf[(long)m * hs_m + (long)n * hs_n] : cx<T>(0, 0);
-            if (conj_h) h[mm].y = -h[mm].y;
+        for (int u = 0; u < NU; ++u) {
+            const int n = n0 + u;
+            const bool nv = (NU == 1) || n < Ni;
+#pragma unroll
+            for (int mm = 0; mm < MT; ++mm) {
+                const int m = m0 + mm;
+                h[u][mm] = (nv && m < No) ? Hf[(long)m * hs_m + (long)n * hs_n] : cx<T>(0, 0);
+                if (conj_h) h[u][mm].y = -h[u][mm].y;
+            }
+#pragma unroll
+            for (int c = 0; c < BT; ++c) x[u][c] = (nv && cv[c]) ? X[xoff[c] + (long)n * xs_n] : cx<T>(0, 0);
         }
 #pragma unroll
-        for (int c = 0; c < BT; ++c) x[c] = cv[c] ? X[xoff[c] + (long)n * xs_n] : cx<T>(0, 0);
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int c = 0; c < BT; ++c)
+            for (int c = 0; c < BT; ++c)
 #pragma unroll
-            for (int mm = 0; mm < MT; ++mm) fma_cx(acc[c][mm], h[mm], x[c]);
+                for (int mm = 0; mm < MT; ++mm) fma_cx(acc[c][mm], h[u][mm], x[u][c]);
     }
 #pragma unroll
     for (int c = 0; c < BT; ++c) {
@@ -146,21 +154,14 @@ __global__ void __launch_bounds__(256) mimo_gradh_diag_kernel(
 }
 
 // ---------------------------------------------------------------- host dispatch
-template <typename T, int MT>
-static int launch_full_bt(int bt, dim3 grid, int nct, int nmt, hipStream_t st, const cx<T>* H, long hs_f, long hs_m, long hs_n, int conj_h,
-                          const cx<T>* X, long xs_b, long xs_n, long xs_k, cx<T>* Y, long ys_b, long ys_m, long ys_k,
-                          int B, int M, int No, int Ni, int K) {
-    if (bt == 4)
-        hipLaunchKernelGGL((mimo_full_kernel<T, MT, 4>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
-                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
-    else if (bt == 2)
-        hipLaunchKernelGGL((mimo_full_kernel<T, MT, 2>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
-                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
-    else
-        hipLaunchKernelGGL((mimo_full_kernel<T, MT, 1>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
-                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
-    FL_CHECK_LAUNCH("mimo_full");
-    return FL_OK;
+static int g_mimo_variant = 0;   // tuning hook: mt*100 + bt*10 + nu (0 = default choice)
+
+template <typename T, int MT, int BT, int NU>
+static void launch_full_one(dim3 grid, int nct, int nmt, hipStream_t st, const cx<T>* H, long hs_f, long hs_m, long hs_n, int conj_h,
+                            const cx<T>* X, long xs_b, long xs_n, long xs_k, cx<T>* Y, long ys_b, long ys_m, long ys_k,
+                            int B, int M, int No, int Ni, int K) {
+    hipLaunchKernelGGL((mimo_full_kernel<T, MT, BT, NU>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
+                       xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
 }
 
 template <typename T>
@@ -171,8 +172,14 @@ static int mimo_impl(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
     FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo: bad sizes");
     if (B == 0 || M == 0) return FL_OK;
     const int ncols = B * K;
-    const int bt = ncols >= 4 ? 4 : (ncols >= 2 ? 2 : 1);
-    const int mt = No >= 8 ? 8 : (No >= 4 ? 4 : (No >= 2 ? 2 : 1));
+    int bt = ncols >= 4 ? 4 : (ncols >= 2 ? 2 : 1);
+    int mt = No >= 8 ? 8 : (No >= 4 ? 4 : (No >= 2 ? 2 : 1));
+    int nu = 1;
+    if (g_mimo_variant > 0) {
+        mt = g_mimo_variant / 100;
+        bt = (g_mimo_variant / 10) % 10;
+        nu = g_mimo_variant % 10;
+    }
     const int nct = cdiv_i(ncols, bt), nmt = cdiv_i(No, mt);
     const size_t nblk = (size_t)cdiv_i(cdiv_i(M, 256), 8) * 8 * nct * nmt;
     FL_REQUIRE(nblk < (1ull << 31), "mimo: grid too large");
@@ -181,12 +188,23 @@ static int mimo_impl(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
     const cx<T>* h = (const cx<T>*)H;
     const cx<T>* x = (const cx<T>*)X;
     cx<T>* y = (cx<T>*)Y;
-    switch (mt) {
-        case 8: return launch_full_bt<T, 8>(bt, grid, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
-        case 4: return launch_full_bt<T, 4>(bt, grid, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
-        case 2: return launch_full_bt<T, 2>(bt, grid, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
-        default: return launch_full_bt<T, 1>(bt, grid, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, ys_m, ys_k, B, M, No, Ni, K);
+#define FL_MIMO_CASE(MT_, BT_, NU_)                                                                                   \
+    if (mt == MT_ && bt == BT_ && nu == NU_) {                                                                        \
+        launch_full_one<T, MT_, BT_, NU_>(grid, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, \
+                                          ys_m, ys_k, B, M, No, Ni, K);                                               \
+        FL_CHECK_LAUNCH("mimo_full");                                                                                 \
+        return FL_OK;                                                                                                 \
     }
+    FL_MIMO_CASE(8, 4, 1) FL_MIMO_CASE(8, 2, 1) FL_MIMO_CASE(8, 1, 1)
+    FL_MIMO_CASE(4, 4, 1) FL_MIMO_CASE(4, 2, 1) FL_MIMO_CASE(4, 1, 1)
+    FL_MIMO_CASE(2, 4, 1) FL_MIMO_CASE(2, 2, 1) FL_MIMO_CASE(2, 1, 1)
+    FL_MIMO_CASE(1, 4, 1) FL_MIMO_CASE(1, 2, 1) FL_MIMO_CASE(1, 1, 1)
+    // tuning variants
+    FL_MIMO_CASE(8, 4, 2) FL_MIMO_CASE(8, 2, 2) FL_MIMO_CASE(8, 2, 4) FL_MIMO_CASE(4, 4, 2) FL_MIMO_CASE(4, 4, 4)
+    FL_MIMO_CASE(4, 8, 1) FL_MIMO_CASE(4, 8, 2) FL_MIMO_CASE(8, 8, 1) FL_MIMO_CASE(4, 2, 4) FL_MIMO_CASE(4, 2, 2)
+#undef FL_MIMO_CASE
+    set_error("mimo: no kernel variant mt=%d bt=%d nu=%d", mt, bt, nu);
+    return FL_ERR_UNSUPPORTED;
 }
 
 template <typename T>
@@ -245,7 +263,7 @@ static int gradh_diag_impl(const void* G, long gs_b, long gs_n, long gs_k, const
 // dW[m,n] = sum_{b,k,f} G[b,m,k,f] conj(X[b,n,k,f]) -- the gradient of a frequency-INDEPENDENT
 // matrix (Gain/Matrix, the FDN mixing matrix) reduced over bins inside the kernel: each block
 // walks bins with a grid stride, keeps a 4x4 tile of sums per lane, reduces across the block and
-// writes one partial tile; the host adds the <= 64 partials.  No (M, No, Ni) tensor is built.
+// writes one partial tile; the host adds the <= 256 partials.  No (M, No, Ni) tensor is built.
 template <typename T>
 __global__ void __launch_bounds__(256) mimo_gradw_kernel(
     const cx<T>* __restrict__ G, long gs_b, long gs_m, long gs_k,
@@ -304,9 +322,11 @@ __global__ void __launch_bounds__(256) mimo_gradw_kernel(
     }
 }
 
+static int g_gradw_cap = 0;
 static int gradw_blocks(int M) {
     int nb = cdiv_i(M, 256);
-    if (nb > 64) nb = 64;
+    const int cap = g_gradw_cap > 0 ? g_gradw_cap : 256;
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return nb;
 }
@@ -331,6 +351,11 @@ using namespace fl;
 extern "C" {
 
 int fl_mimo_gradw_blocks(int M) { return gradw_blocks(M); }
+int fl_debug_set_mimo_variant(int variant, int gradw_cap) {
+    g_mimo_variant = variant;
+    g_gradw_cap = gradw_cap;
+    return FL_OK;
+}
 int fl_mimo_gradw_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
                       void* part, int B, int M, int No, int Ni, int K, void* stream) {
     return gradw_impl<float>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, part, B, M, No, Ni, K, stream);

@@ -390,7 +390,23 @@ __global__ void __launch_bounds__(256) geq_sections_bwd_kernel(const void* __res
     double raw;
     const double g = geq_linear_gain(gain, in_kind, idx, &raw);
     double B0 = 0, B1 = 0, B2 = 0, A0 = 0, A1 = 0, A2 = 0;
-    for (int blk = 0; blk < nblk; ++blk) {
+    int blk = 0;
+    for (; blk + 4 <= nblk; blk += 4) {   // 24 independent loads in flight, summed in block order
+        double v[4][6];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double* pb = gb + (size_t)(blk + u) * blk_stride + idx;
+            const double* pa = ga + (size_t)(blk + u) * blk_stride + idx;
+            v[u][0] = pb[0]; v[u][1] = pb[st]; v[u][2] = pb[2 * st];
+            v[u][3] = pa[0]; v[u][4] = pa[st]; v[u][5] = pa[2 * st];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            B0 += v[u][0]; B1 += v[u][1]; B2 += v[u][2];
+            A0 += v[u][3]; A1 += v[u][4]; A2 += v[u][5];
+        }
+    }
+    for (; blk < nblk; ++blk) {
         const double* pb = gb + (size_t)blk * blk_stride + idx;
         const double* pa = ga + (size_t)blk * blk_stride + idx;
         B0 += pb[0]; B1 += pb[st]; B2 += pb[2 * st];

@@ -207,6 +207,51 @@ class KernelTimer:
 kernel_timer = KernelTimer()
 
 
+# ----------------------------------------------------------------------------- response / transform overlap
+# Shell.forward marks the point on the current stream BEFORE the input transform is enqueued; the
+# parameter-only work of the core (response generators, their composition) is then enqueued on a
+# side stream that waits for that point only, so it runs concurrently with the FFT kernels of the
+# input instead of after them.  Under hipGraph capture the fork/join become graph edges.
+# Memory safety rests on stream order, not on record_stream: every side region starts by waiting
+# for an event recorded on the main stream after all earlier main-stream work was enqueued, and the
+# main stream waits for the side stream before it touches a result.
+_fork = {"event": None}
+_side_streams = {}
+
+
+def fork_event():
+    return _fork["event"]
+
+
+def side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _side_streams.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        _side_streams[key] = s
+    return s
+
+
+class fork_point:
+    """with ops.fork_point(x): ...  -- records the fork event for the enclosed forward pass."""
+
+    def __init__(self, x):
+        self.on = torch.is_tensor(x) and x.is_cuda
+        self.dev = x.device if self.on else None
+
+    def __enter__(self):
+        self.prev = _fork["event"]
+        if self.on:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            _fork["event"] = ev
+        return self
+
+    def __exit__(self, *exc):
+        _fork["event"] = self.prev
+        return False
+
+
 # ----------------------------------------------------------------------------- bin sharding (multi-GPU)
 _shard = {"bin0": 0, "m_local": None}
 
@@ -371,7 +416,7 @@ def irfft(X: torch.Tensor, nfft: int, norm: str = "backward", alias_decay_db: Op
 def _h_planar(H: torch.Tensor, per_bin: bool) -> torch.Tensor:
     """Per-bin responses (M, ...) are used with the bin axis contiguous (rows possibly padded)."""
     if not per_bin:
-        return H.contiguous()
+        return H          # frequency-independent: used through its strides, whatever they are
     if _lead_pitch(H.movedim(0, -1)) is not None:
         return H
     M = H.shape[0]
@@ -389,7 +434,7 @@ def _mimo_launch(H, per_bin, diag, conj_t, X):
     hp = _lead_pitch(H.movedim(0, -1)) if per_bin else 0   # pitch of the per-bin response rows
     if diag:
         N = H.shape[-1]
-        hs_f, hs_n = (1, hp) if per_bin else (0, 1)
+        hs_f, hs_n = (1, hp) if per_bin else (0, H.stride(-1))
         Y = _empty_planar(X.shape, X.dtype, X.device)
         _, _, _, _, ys_b, ys_n, ys_k = _bnk(Y)
         fn = L.fl_mimo_diag_c64 if real == torch.float32 else L.fl_mimo_diag_c128
@@ -400,7 +445,7 @@ def _mimo_launch(H, per_bin, diag, conj_t, X):
     if per_bin:
         hs_f, hs_m, hs_n = 1, Ni_h * hp, hp
     else:
-        hs_f, hs_m, hs_n = 0, Ni_h, 1
+        hs_f, hs_m, hs_n = 0, H.stride(-2), H.stride(-1)
     if conj_t:
         No, Ni, hs_m, hs_n = Ni_h, No_h, hs_n, hs_m
     else:

@@ -28,6 +28,14 @@ from .dsp import FFT, Transform, iFFT
 # module on the way back).  Results are identical up to floating-point reassociation.
 FUSE_SERIES = True
 FUSE_MIN_COLUMNS = 4   # batch x trailing columns below which folding does not pay
+# Build the folded response on a side stream, concurrently with the input transform of the
+# enclosing Shell (see ops.fork_point).  The response depends on parameters only.
+OVERLAP_RESPONSES = True
+# Gradients of the parameters are then produced on the side stream while their AccumulateGrad
+# nodes live on the main one; autograd synchronises the two correctly and merely warns about it.
+_quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+if _quiet is not None:
+    _quiet(False)
 
 
 def _as_signal(H: torch.Tensor, diag: bool, M: int) -> torch.Tensor:
@@ -214,13 +222,27 @@ class Series(nn.Sequential):
     def __fused(run, x, ext_param):
         """Apply a run of per-bin modules as one product with the cascade's response."""
         M = x.shape[1]
-        shape = list(x.shape)
-        acc = None
-        for key, module in run:
-            ext = ext_param[key] if (ext_param is not None and key in ext_param) else None
-            resp = module._response_for_fusion(shape, ext)
-            shape[2] = module.output_channels
-            acc = resp if acc is None else _compose(acc, resp, M)
+
+        def build():
+            shape = list(x.shape)
+            acc = None
+            for key, module in run:
+                ext = ext_param[key] if (ext_param is not None and key in ext_param) else None
+                resp = module._response_for_fusion(shape, ext)
+                shape[2] = module.output_channels
+                acc = resp if acc is None else _compose(acc, resp, M)
+            return acc
+
+        ev = ops.fork_event() if OVERLAP_RESPONSES else None
+        if ev is None:
+            acc = build()
+        else:
+            main = torch.cuda.current_stream(x.device)
+            side = ops.side_stream(x.device)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                acc = build()
+            main.wait_stream(side)
         return ops.mimo(acc[0], x, diag=acc[1])
 
     def probe(self, z: torch.Tensor):
@@ -435,9 +457,10 @@ class Shell(nn.Module):
         return layer
 
     def forward(self, x: torch.Tensor, ext_param: dict = None) -> torch.Tensor:
-        x = self.__input_layer(x)
-        x = self.__core(x, ext_param) if ext_param is not None else self.__core(x)
-        return self.__output_layer(x)
+        with ops.fork_point(x):
+            x = self.__input_layer(x)
+            x = self.__core(x, ext_param) if ext_param is not None else self.__core(x)
+            return self.__output_layer(x)
 
     # ---- accessors
     def get_inputLayer(self):
