@@ -1,0 +1,173 @@
+// exp of a small parameter matrix in one launch, and its backward in one launch (gfx950 / MI355X).
+//
+//   E = exp(A),  A = X  or  A = triu(X,1) - triu(X,1)^T
+//
+// the "orthogonal" parameter map of dsp.Matrix (flamo/processor/dsp.py:649:
+// torch.matrix_exp(skew_matrix(x))) -- the mixing matrix of every feedback delay network.  On the
+// device torch.matrix_exp picks its Pade degree from the norm on the HOST (a synchronisation, not
+// capturable in a HIP graph); a sync-free fixed schedule written with torch ops is ~45 tiny launches
+// forward and ~100 backward, which at batch 1 is a third of a 16-channel FDN training step.  Here:
+// one workgroup, matrices in LDS, float64 arithmetic whatever the parameter type,
+//
+//   forward   A_s = A / 2^SQ;  Horner  P_k = I + A_s P_{k+1} / k  (k = ORDER..1, P_{ORDER+1} = I);
+//             E_0 = P_1;  E_{i+1} = E_i^2  (SQ times)
+//   backward  the same schedule reversed, from the stashed P_k and E_i:
+//             G <- G E_i^T + E_i^T G;   dA_s += G P_{k+1}^T / k,  G <- A_s^T G / k
+//
+// |A| up to ~100 agrees with torch.matrix_exp to 1e-13 (2^-10 scaling, order-10 series).
+#include "common.h"
+
+namespace fl {
+
+constexpr int EXPM_ORDER = 10;
+constexpr int EXPM_SQ = 10;
+constexpr int EXPM_SLOTS = EXPM_ORDER + EXPM_SQ + 1;   // stash: A_s, P_2..P_{ORDER+1}, E_0..E_{SQ-1}
+
+// C = alpha * op(A) op(B) [+ C] [+ I];  every thread of the workgroup takes outputs idx, idx+nthreads, ...
+__device__ inline void mm_small(const double* __restrict__ A, bool tA, const double* __restrict__ B, bool tB,
+                                double* __restrict__ C, double alpha, int N, bool add_identity, bool accumulate) {
+    for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
+        const int i = idx / N, j = idx - i * N;
+        double s = 0.0;
+        for (int l = 0; l < N; ++l) {
+            const double a = tA ? A[l * N + i] : A[i * N + l];
+            const double b = tB ? B[j * N + l] : B[l * N + j];
+            s += a * b;
+        }
+        s *= alpha;
+        if (add_identity && i == j) s += 1.0;
+        C[idx] = accumulate ? C[idx] + s : s;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) expm_fwd_kernel(const T* __restrict__ X, int N, int skew, T* __restrict__ E,
+                                                       double* __restrict__ stash) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* A = reinterpret_cast<double*>(smem);
+    double* P = A + N * N;
+    double* Q = P + N * N;
+    const int NN = N * N;
+    const double scale = 1.0 / (double)(1 << EXPM_SQ);
+    for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
+        const int i = idx / N, j = idx - i * N;
+        double v;
+        if (skew) v = (j > i) ? (double)X[i * N + j] : ((j < i) ? -(double)X[j * N + i] : 0.0);
+        else v = (double)X[idx];
+        v *= scale;
+        A[idx] = v;
+        stash[idx] = v;
+        P[idx] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int k = EXPM_ORDER; k >= 1; --k) {
+        double* slot = stash + (size_t)k * NN;                    // P_{k+1}
+        for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) slot[idx] = P[idx];
+        mm_small(A, false, P, false, Q, 1.0 / k, N, true, false);  // P_k = I + A P_{k+1} / k
+        __syncthreads();
+        double* t = P; P = Q; Q = t;
+    }
+    for (int i = 0; i < EXPM_SQ; ++i) {
+        double* slot = stash + (size_t)(EXPM_ORDER + 1 + i) * NN;  // E_i
+        for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) slot[idx] = P[idx];
+        mm_small(P, false, P, false, Q, 1.0, N, false, false);
+        __syncthreads();
+        double* t = P; P = Q; Q = t;
+    }
+    for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) E[idx] = (T)P[idx];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE, int N, int skew,
+                                                       const double* __restrict__ stash, T* __restrict__ gX) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* G = reinterpret_cast<double*>(smem);
+    double* Q = G + N * N;
+    double* dA = Q + N * N;
+    const int NN = N * N;
+    for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
+        G[idx] = (double)gE[idx];
+        dA[idx] = 0.0;
+    }
+    __syncthreads();
+    for (int i = EXPM_SQ - 1; i >= 0; --i) {                       // E_{i+1} = E_i^2
+        const double* Ei = stash + (size_t)(EXPM_ORDER + 1 + i) * NN;
+        mm_small(G, false, Ei, true, Q, 1.0, N, false, false);      // G E_i^T
+        mm_small(Ei, true, G, false, Q, 1.0, N, false, true);       // + E_i^T G   (each thread re-reads only its own Q entries)
+        __syncthreads();
+        double* t = G; G = Q; Q = t;
+    }
+    const double* As = stash;
+    for (int k = 1; k <= EXPM_ORDER; ++k) {                        // P_k = I + A_s P_{k+1} / k
+        const double* Pk1 = stash + (size_t)k * NN;
+        mm_small(G, false, Pk1, true, dA, 1.0 / k, N, false, true); // dA_s += G P_{k+1}^T / k
+        mm_small(As, true, G, false, Q, 1.0 / k, N, false, false);  // G <- A_s^T G / k
+        __syncthreads();
+        double* t = G; G = Q; Q = t;
+    }
+    const double scale = 1.0 / (double)(1 << EXPM_SQ);
+    for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
+        const int i = idx / N, j = idx - i * N;
+        double v;
+        if (skew) v = (j > i) ? (dA[i * N + j] - dA[j * N + i]) : 0.0;
+        else v = dA[idx];
+        gX[idx] = (T)(v * scale);
+    }
+}
+
+static int expm_threads(int N) {
+    int t = (N * N + 63) / 64 * 64;
+    return t > 1024 ? 1024 : t;
+}
+
+template <typename T>
+static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* stash, void* stream) {
+    FL_REQUIRE(X && E && stash, "matrix_exp: null pointer");
+    FL_REQUIRE(N >= 1 && N <= 64, "matrix_exp: 1 <= N <= 64 (one workgroup, matrices in LDS)");
+    const size_t lds = (size_t)3 * N * N * sizeof(double);
+    if (lds > 64 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_fwd_kernel<T>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "matrix_exp LDS size");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL((expm_fwd_kernel<T>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)X, N, skew,
+                       (T*)E, (double*)stash);
+    FL_CHECK_LAUNCH("matrix_exp");
+    return FL_OK;
+}
+
+template <typename T>
+static int expm_bwd_impl(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
+    FL_REQUIRE(gE && stash && gX, "matrix_exp_bwd: null pointer");
+    FL_REQUIRE(N >= 1 && N <= 64, "matrix_exp_bwd: 1 <= N <= 64");
+    const size_t lds = (size_t)3 * N * N * sizeof(double);
+    if (lds > 64 * 1024) {
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_bwd_kernel<T>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "matrix_exp_bwd LDS size");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL((expm_bwd_kernel<T>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)gE, N, skew,
+                       (const double*)stash, (T*)gX);
+    FL_CHECK_LAUNCH("matrix_exp_bwd");
+    return FL_OK;
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+extern "C" {
+size_t fl_matrix_exp_stash_elems(int N) { return (size_t)EXPM_SLOTS * N * N; }
+int fl_matrix_exp_f32(const void* X, int N, int skew, void* E, void* stash, void* stream) {
+    return expm_fwd_impl<float>(X, N, skew, E, stash, stream);
+}
+int fl_matrix_exp_f64(const void* X, int N, int skew, void* E, void* stash, void* stream) {
+    return expm_fwd_impl<double>(X, N, skew, E, stash, stream);
+}
+int fl_matrix_exp_bwd_f32(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
+    return expm_bwd_impl<float>(gE, N, skew, stash, gX, stream);
+}
+int fl_matrix_exp_bwd_f64(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
+    return expm_bwd_impl<double>(gE, N, skew, stash, gX, stream);
+}
+}

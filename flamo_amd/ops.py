@@ -908,3 +908,47 @@ def mean_square(y: torch.Tensor) -> torch.Tensor:
     """(y ** 2).mean() of a real tensor in one streaming pass each way (forward: one read of y;
     backward: one read + one write), in whatever layout y is stored."""
     return _MeanSquare.apply(y)
+
+
+# ----------------------------------------------------------------------------- orthogonal parameter map
+EXPM_MAX_N = 64
+
+
+class _MatrixExp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, skew):
+        dev = _require_gpu(X)
+        if X.dim() != 2 or X.shape[0] != X.shape[1]:
+            raise ValueError("matrix_exp expects one square matrix")
+        if X.dtype not in (torch.float32, torch.float64):
+            raise TypeError("matrix_exp expects a float32 / float64 matrix")
+        N = X.shape[0]
+        if N > EXPM_MAX_N:
+            raise ValueError(f"matrix_exp: N={N} exceeds the single-workgroup limit {EXPM_MAX_N}")
+        Xc = X.contiguous()
+        L = _lib.lib()
+        E = torch.empty_like(Xc)
+        stash = torch.empty(L.fl_matrix_exp_stash_elems(N), dtype=torch.float64, device=dev)
+        fn = L.fl_matrix_exp_f32 if X.dtype == torch.float32 else L.fl_matrix_exp_f64
+        _lib.check(fn(Xc.data_ptr(), N, int(skew), E.data_ptr(), stash.data_ptr(), _stream()), "matrix_exp")
+        ctx.save_for_backward(stash)
+        ctx.cfg = (N, int(skew), X.dtype)
+        return E
+
+    @staticmethod
+    def backward(ctx, gE):
+        (stash,) = ctx.saved_tensors
+        N, skew, dt = ctx.cfg
+        g = gE.to(dt).contiguous()
+        gX = torch.empty_like(g)
+        L = _lib.lib()
+        fn = L.fl_matrix_exp_bwd_f32 if dt == torch.float32 else L.fl_matrix_exp_bwd_f64
+        _lib.check(fn(g.data_ptr(), N, skew, stash.data_ptr(), gX.data_ptr(), _stream()), "matrix_exp_bwd")
+        return gX, None
+
+
+def matrix_exp(X: torch.Tensor, skew: bool = False) -> torch.Tensor:
+    """exp(X), or exp(triu(X,1) - triu(X,1)^T) with skew=True, of one (N, N) parameter matrix
+    (N <= 64) in one launch each way: float64 arithmetic, fixed scaling-and-squaring schedule, no
+    host synchronisation (capturable)."""
+    return _MatrixExp.apply(X, bool(skew))

@@ -262,6 +262,15 @@ class parallelGain(Gain):
         return torch.diag(to_complex(self.map(self.param)))
 
 
+def _orthogonal_map(x):
+    """exp of the skew part (dsp.py:649).  On the GPU: one fused launch each way (ops.matrix_exp);
+    otherwise the same fixed schedule written with torch ops (torch.matrix_exp synchronises with
+    the host and cannot be captured in a HIP graph)."""
+    if x.is_cuda and x.dim() == 2 and x.shape[0] <= ops.EXPM_MAX_N and x.dtype in (torch.float32, torch.float64):
+        return ops.matrix_exp(x, skew=True)
+    return matrix_exp_capturable(skew_matrix(x))
+
+
 class Matrix(Gain):
     """Gain matrix with a structural map: random | orthogonal | hadamard | rotation (dsp.py:579-676)."""
 
@@ -282,7 +291,7 @@ class Matrix(Gain):
             assert N == self.size[1], "Matrix must be square to be orthogonal"
             # exp of the skew part (dsp.py:649); fixed-schedule evaluation so that a step can be
             # captured in a HIP graph (torch.matrix_exp synchronises with the host)
-            self.map = lambda x: matrix_exp_capturable(skew_matrix(x))
+            self.map = _orthogonal_map
         elif kind == "hadamard":
             assert N == self.size[1], "Matrix must be square to be Hadamard"
             assert N % 2 == 0, "Matrix must have even dimensions to be Hadamard"

@@ -259,6 +259,20 @@ int fl_mean_square_f64(const void* y, long rows, long cols, long pitch, void* lo
 int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
 int fl_mean_square_bwd_f64(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Orthogonal parameter map of dsp.Matrix: E = exp(A), A = X (skew = 0) or
+ * A = triu(X,1) - triu(X,1)^T (skew != 0) -- torch.matrix_exp(skew_matrix(x)),
+ * flamo/processor/dsp.py:649 with flamo/functional.py:42-56.  One workgroup, float64 arithmetic,
+ * fixed scaling-and-squaring schedule (2^-10 scaling, order-10 series: |A| up to ~100 agrees with
+ * torch.matrix_exp to 1e-13), no host synchronisation, so a training step stays capturable in a
+ * HIP graph.  X, E, gE, gX: (N, N) row major in the parameter type (_f32 / _f64), N <= 64;
+ * stash: fl_matrix_exp_stash_elems(N) doubles written by the forward and read by the backward. */
+size_t fl_matrix_exp_stash_elems(int N);
+int fl_matrix_exp_f32(const void* X, int N, int skew, void* E, void* stash, void* stream);
+int fl_matrix_exp_f64(const void* X, int N, int skew, void* E, void* stash, void* stream);
+int fl_matrix_exp_bwd_f32(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);
+int fl_matrix_exp_bwd_f64(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -284,3 +284,27 @@ def test_sos_backward_mixed_precision_matches_double(gpu):
             dm = gm[0] - 2 * gm[1] + gm[2]
             dd = gd[0] - 2 * gd[1] + gd[2]
             assert relerr(dm.cpu(), dd.cpu()) < 5e-5
+
+
+@pytest.mark.parametrize("N", [1, 4, 16, 23, 32, 64])
+def test_matrix_exp_kernel_matches_torch(gpu, N):
+    """ops.matrix_exp (one launch each way, fixed schedule) vs torch.matrix_exp on the CPU in float64,
+    values and gradients, plain and through the skew map of the orthogonal Matrix."""
+    from flamo_amd import ops
+    torch.manual_seed(N)
+    for dt, tol in ((torch.float64, 2e-12), (torch.float32, 3e-6)):
+        for skew in (True, False):
+            X0 = torch.randn(N, N, dtype=dt) * (1.0 if skew else 0.3)
+            Xr = X0.double().requires_grad_(True)
+            A = (torch.triu(Xr, 1) - torch.triu(Xr, 1).mT) if skew else Xr
+            Er = torch.matrix_exp(A)
+            Cw = torch.randn(N, N, dtype=torch.float64)
+            (gr,) = torch.autograd.grad((Er * Cw).sum(), [Xr])
+            X = X0.to(gpu).requires_grad_(True)
+            E = ops.matrix_exp(X, skew=skew)
+            (g,) = torch.autograd.grad((E * Cw.to(gpu, dt)).sum(), [X])
+            assert E.dtype == dt and relerr(E.detach().cpu(), Er.detach()) < tol
+            assert relerr(g.cpu(), gr) < tol * 5
+            if skew:   # orthogonal to working precision
+                I = torch.eye(N, dtype=torch.float64)
+                assert (E.detach().cpu().double() @ E.detach().cpu().double().mT - I).abs().max() < tol * 10

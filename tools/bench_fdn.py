@@ -70,8 +70,9 @@ def main():
         out[name] = {"ms_per_step": ms, "bin_solves_per_s": args.batch * (nfft // 2 + 1) / (ms * 1e-3)}
         # the same step replayed from a HIP graph (launch overhead removed)
         from flamo_amd.graph import GraphedStep
+        step()
+        ref = [p.grad.clone() for p in params]           # eager gradients, before the graph takes over p.grad
         gs = GraphedStep(lambda xx: (model(xx) * c).sum(), (x,), params)
-        ref = [p.grad.clone() for p in params]
         gs(x)
         torch.cuda.synchronize()
         err = max(((a - b).norm() / b.norm()).item() for a, b in zip(gs.grads, ref))
