@@ -23,31 +23,47 @@ constexpr int EXPM_ORDER = 10;
 constexpr int EXPM_SQ = 10;
 constexpr int EXPM_SLOTS = EXPM_ORDER + EXPM_SQ + 1;   // stash: A_s, P_2..P_{ORDER+1}, E_0..E_{SQ-1}
 
+// All LDS matrices have rows of NP = N | 1 doubles (odd pitch: transposed reads hit distinct banks).
 // C = alpha * op(A) op(B) [+ C] [+ I];  every thread of the workgroup takes outputs idx, idx+nthreads, ...
+// (pa: row pitch of A -- NP for an LDS matrix, N for a dense one read straight from global memory)
 __device__ inline void mm_small(const double* __restrict__ A, bool tA, const double* __restrict__ B, bool tB,
-                                double* __restrict__ C, double alpha, int N, bool add_identity, bool accumulate) {
+                                double* __restrict__ C, double alpha, int N, bool add_identity, bool accumulate,
+                                int pa = 0) {
+    const int NP = N | 1;
+    if (pa == 0) pa = NP;
     for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
         const int i = idx / N, j = idx - i * N;
-        double s = 0.0;
-        for (int l = 0; l < N; ++l) {
-            const double a = tA ? A[l * N + i] : A[i * N + l];
-            const double b = tB ? B[j * N + l] : B[l * N + j];
-            s += a * b;
+        double s0 = 0.0, s1 = 0.0;
+        int l = 0;
+        for (; l + 1 < N; l += 2) {
+            s0 += (tA ? A[l * pa + i] : A[i * pa + l]) * (tB ? B[j * NP + l] : B[l * NP + j]);
+            s1 += (tA ? A[(l + 1) * pa + i] : A[i * pa + l + 1]) * (tB ? B[j * NP + l + 1] : B[(l + 1) * NP + j]);
         }
-        s *= alpha;
+        if (l < N) s0 += (tA ? A[l * pa + i] : A[i * pa + l]) * (tB ? B[j * NP + l] : B[l * NP + j]);
+        double s = (s0 + s1) * alpha;
         if (add_identity && i == j) s += 1.0;
-        C[idx] = accumulate ? C[idx] + s : s;
+        C[i * NP + j] = accumulate ? C[i * NP + j] + s : s;
     }
+}
+
+// dense (N x N) global <-> padded LDS
+__device__ inline void lds_load(double* __restrict__ dst, const double* __restrict__ src, int N) {
+    const int NP = N | 1;
+    for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) dst[(idx / N) * NP + idx % N] = src[idx];
+}
+__device__ inline void lds_store(double* __restrict__ dst, const double* __restrict__ src, int N) {
+    const int NP = N | 1;
+    for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) dst[idx] = src[(idx / N) * NP + idx % N];
 }
 
 template <typename T>
 __global__ void __launch_bounds__(1024) expm_fwd_kernel(const T* __restrict__ X, int N, int skew, T* __restrict__ E,
                                                        double* __restrict__ stash) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NN = N * N, NP = N | 1;
     double* A = reinterpret_cast<double*>(smem);
-    double* P = A + N * N;
-    double* Q = P + N * N;
-    const int NN = N * N;
+    double* P = A + N * NP;
+    double* Q = P + N * NP;
     const double scale = 1.0 / (double)(1 << EXPM_SQ);
     for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
         const int i = idx / N, j = idx - i * N;
@@ -55,53 +71,58 @@ __global__ void __launch_bounds__(1024) expm_fwd_kernel(const T* __restrict__ X,
         if (skew) v = (j > i) ? (double)X[i * N + j] : ((j < i) ? -(double)X[j * N + i] : 0.0);
         else v = (double)X[idx];
         v *= scale;
-        A[idx] = v;
+        A[i * NP + j] = v;
         stash[idx] = v;
-        P[idx] = (i == j) ? 1.0 : 0.0;
+        P[i * NP + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
     for (int k = EXPM_ORDER; k >= 1; --k) {
-        double* slot = stash + (size_t)k * NN;                    // P_{k+1}
-        for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) slot[idx] = P[idx];
-        mm_small(A, false, P, false, Q, 1.0 / k, N, true, false);  // P_k = I + A P_{k+1} / k
+        lds_store(stash + (size_t)k * NN, P, N);                    // P_{k+1}
+        mm_small(A, false, P, false, Q, 1.0 / k, N, true, false);   // P_k = I + A P_{k+1} / k
         __syncthreads();
         double* t = P; P = Q; Q = t;
     }
     for (int i = 0; i < EXPM_SQ; ++i) {
-        double* slot = stash + (size_t)(EXPM_ORDER + 1 + i) * NN;  // E_i
-        for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) slot[idx] = P[idx];
+        lds_store(stash + (size_t)(EXPM_ORDER + 1 + i) * NN, P, N);  // E_i
         mm_small(P, false, P, false, Q, 1.0, N, false, false);
         __syncthreads();
         double* t = P; P = Q; Q = t;
     }
-    for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) E[idx] = (T)P[idx];
+    for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) E[idx] = (T)P[(idx / N) * NP + idx % N];
 }
 
 template <typename T>
 __global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE, int N, int skew,
                                                        const double* __restrict__ stash, T* __restrict__ gX) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NN = N * N, NP = N | 1;
     double* G = reinterpret_cast<double*>(smem);
-    double* Q = G + N * N;
-    double* dA = Q + N * N;
-    const int NN = N * N;
+    double* Q = G + N * NP;
+    double* dA = Q + N * NP;
+    double* S0 = dA + N * NP;     // stashed matrix of the current step, staged through LDS
+    // A_s: a fifth LDS matrix while it fits in 160 KB (N <= 56), else read from the stash in place
+    const bool as_lds = (size_t)5 * N * NP * sizeof(double) <= 160 * 1024;
+    const double* S1 = as_lds ? S0 + N * NP : stash;
+    const int p1 = as_lds ? NP : N;
     for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
-        G[idx] = (double)gE[idx];
-        dA[idx] = 0.0;
+        const int o = (idx / N) * NP + idx % N;
+        G[o] = (double)gE[idx];
+        dA[o] = 0.0;
     }
-    __syncthreads();
+    if (as_lds) lds_load(S0 + N * NP, stash, N);
     for (int i = EXPM_SQ - 1; i >= 0; --i) {                       // E_{i+1} = E_i^2
-        const double* Ei = stash + (size_t)(EXPM_ORDER + 1 + i) * NN;
-        mm_small(G, false, Ei, true, Q, 1.0, N, false, false);      // G E_i^T
-        mm_small(Ei, true, G, false, Q, 1.0, N, false, true);       // + E_i^T G   (each thread re-reads only its own Q entries)
+        lds_load(S0, stash + (size_t)(EXPM_ORDER + 1 + i) * NN, N);
+        __syncthreads();
+        mm_small(G, false, S0, true, Q, 1.0, N, false, false);      // G E_i^T
+        mm_small(S0, true, G, false, Q, 1.0, N, false, true);       // + E_i^T G  (a thread re-reads only its own Q entries)
         __syncthreads();
         double* t = G; G = Q; Q = t;
     }
-    const double* As = stash;
     for (int k = 1; k <= EXPM_ORDER; ++k) {                        // P_k = I + A_s P_{k+1} / k
-        const double* Pk1 = stash + (size_t)k * NN;
-        mm_small(G, false, Pk1, true, dA, 1.0 / k, N, false, true); // dA_s += G P_{k+1}^T / k
-        mm_small(As, true, G, false, Q, 1.0 / k, N, false, false);  // G <- A_s^T G / k
+        lds_load(S0, stash + (size_t)k * NN, N);
+        __syncthreads();
+        mm_small(G, false, S0, true, dA, 1.0 / k, N, false, true);  // dA_s += G P_{k+1}^T / k
+        mm_small(S1, true, G, false, Q, 1.0 / k, N, false, false, p1);  // G <- A_s^T G / k
         __syncthreads();
         double* t = G; G = Q; Q = t;
     }
@@ -109,8 +130,8 @@ __global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE
     for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
         const int i = idx / N, j = idx - i * N;
         double v;
-        if (skew) v = (j > i) ? (dA[i * N + j] - dA[j * N + i]) : 0.0;
-        else v = dA[idx];
+        if (skew) v = (j > i) ? (dA[i * NP + j] - dA[j * NP + i]) : 0.0;
+        else v = dA[i * NP + j];
         gX[idx] = (T)(v * scale);
     }
 }
@@ -124,7 +145,7 @@ template <typename T>
 static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* stash, void* stream) {
     FL_REQUIRE(X && E && stash, "matrix_exp: null pointer");
     FL_REQUIRE(N >= 1 && N <= 64, "matrix_exp: 1 <= N <= 64 (one workgroup, matrices in LDS)");
-    const size_t lds = (size_t)3 * N * N * sizeof(double);
+    const size_t lds = (size_t)3 * N * (N | 1) * sizeof(double);
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_fwd_kernel<T>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "matrix_exp LDS size");
@@ -140,7 +161,8 @@ template <typename T>
 static int expm_bwd_impl(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
     FL_REQUIRE(gE && stash && gX, "matrix_exp_bwd: null pointer");
     FL_REQUIRE(N >= 1 && N <= 64, "matrix_exp_bwd: 1 <= N <= 64");
-    const size_t lds = (size_t)3 * N * N * sizeof(double);
+    size_t lds = (size_t)5 * N * (N | 1) * sizeof(double);
+    if (lds > 160 * 1024) lds = (size_t)4 * N * (N | 1) * sizeof(double);
     if (lds > 64 * 1024) {
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_bwd_kernel<T>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "matrix_exp_bwd LDS size");
