@@ -32,10 +32,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 NFFT, NCH, BATCH = 96000, 8, 32
-# HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r01g_pmc_hbm_traffic.csv,
+# HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r01h_pmc_hbm_traffic.csv,
 # grid 393216 = the batch-32 launch): 2*FETCH_SIZE + WRITE_SIZE.  A static number measured by rocprofv3,
 # not re-measured by every bench run.
-PMC_TRAFFIC_BYTES = 231.7e6
+PMC_TRAFFIC_BYTES = 224.0e6
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -170,12 +170,17 @@ def main():
         # HIP events cannot be read back from inside a captured graph: the dominant kernel's launch
         # time is taken with events on the launch stream in eager steps of the same workload, run by
         # this same command right after the timed replays (rocprofv3 --stats sees both alike)
+        # (single stream for these steps: an event recorded behind a cross-stream wait is stamped
+        # before the wait resolves, which would add the side stream's tail to the kernel's time)
+        from flamo_amd.processor import system as _system
         roof_steps = min(args.steps, 10)
+        overlap, _system.OVERLAP_RESPONSES = _system.OVERLAP_RESPONSES, False
         ops.kernel_timer.reset(enabled=True)
         for _ in range(roof_steps):
             eager_step()
         torch.cuda.synchronize()
         ops.kernel_timer.enabled = False
+        _system.OVERLAP_RESPONSES = overlap
     if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -198,9 +203,9 @@ def main():
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": PMC_TRAFFIC_BYTES, "algorithmic_bytes": alg_bytes, "launch_ms": mean_ms, "launches": n,
                     "events": "HIP events on the launch stream, " + ("inside the timed eager steps" if args.no_graph else
-                              f"{roof_steps} eager steps run by this command right after the timed graph replays"),
+                              f"{roof_steps} single-stream eager steps run by this command right after the timed graph replays"),
                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per "
-                                      "MI355X_MICROARCH.md; profiles/r01g_pmc_hbm_traffic.csv"}
+                                      "MI355X_MICROARCH.md; profiles/r01h_pmc_hbm_traffic.csv"}
         out = {"metric": "freq-bin*channel products/sec (fwd+bwd), nfft=96000 8x8ch", "value": products_per_step / (ms * 1e-3),
                "unit": "products/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun) from the repo root: bench line with the CPU baseline, the
+# rocprofv3 kernel stats of the same bench command, the two PMC passes for HBM traffic, and the
+# FDN (config 3) numbers.  Everything lands in gpurun_out/final/; tools/summarize_profiles.py
+# turns it into the files committed under profiles/.
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/final
+rm -rf $OUT; mkdir -p $OUT
+cd $ROOT
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python $ROOT/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fdn_stats -o r -- python $ROOT/tools/bench_fdn.py --dtype f32 > /dev/null 2>&1
+cd $ROOT
+python tools/bench_fdn.py 2>/dev/null | tail -1 > $OUT/fdn_b1.json
+python tools/bench_fdn.py --batch 8 2>/dev/null | tail -1 > $OUT/fdn_b8.json
+rm -f $OUT/*/r_kernel_trace.csv.bak
+ls -la $OUT $OUT/stats | head -30
+cut -c1-400 $OUT/bench.json

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""gpurun_out/final/ (written by tools/collect_profiles.sh on the GPU box) -> profiles/<tag>_*:
+the bench line, the rocprofv3 --stats kernel table of the same command, per-kernel HBM traffic from
+the two PMC passes (FETCH_SIZE doubled on gfx950, see MI355X_MICROARCH.md), and the FDN numbers."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "final")
+DST = os.path.join(ROOT, "profiles")
+
+
+def pmc(path, counter):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            grid = r.get("Grid_Size") or r.get("Grid_Size_X") or ""
+            acc[(r["Kernel_Name"], grid)].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01z"
+    os.makedirs(DST, exist_ok=True)
+    bench = json.load(open(os.path.join(SRC, "bench.json")))
+    json.dump(bench, open(os.path.join(DST, f"{tag}_bench.json"), "w"), indent=1)
+    shutil.copy(os.path.join(SRC, "stats", "r_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats_rocprofv3.csv"))
+    if os.path.exists(os.path.join(SRC, "fdn_stats", "r_kernel_stats.csv")):
+        shutil.copy(os.path.join(SRC, "fdn_stats", "r_kernel_stats.csv"), os.path.join(DST, f"{tag}_fdn_kernel_stats_rocprofv3.csv"))
+    fdn = {}
+    for name in ("fdn_b1", "fdn_b8"):
+        p = os.path.join(SRC, name + ".json")
+        if os.path.exists(p) and os.path.getsize(p):
+            fdn[name] = json.load(open(p))
+    json.dump(fdn, open(os.path.join(DST, f"{tag}_fdn_bench.json"), "w"), indent=1)
+    fetch = pmc(os.path.join(SRC, "pmc_fetch", "r_counter_collection.csv"), "FETCH_SIZE")
+    write = pmc(os.path.join(SRC, "pmc_write", "r_counter_collection.csv"), "WRITE_SIZE")
+    rows = []
+    for key in sorted(set(fetch) | set(write)):
+        name, grid = key
+        if "fl::" not in name:
+            continue
+        f = fetch.get(key, [])
+        w = write.get(key, [])
+        fb = 2 * 1024 * sum(f) / len(f) if f else 0.0       # KB -> bytes, x2 on gfx950
+        wb = 1024 * sum(w) / len(w) if w else 0.0
+        rows.append((name, grid, len(f), fb, wb, fb + wb))
+    with open(os.path.join(DST, f"{tag}_pmc_hbm_traffic.csv"), "w", newline="") as fh:
+        wr = csv.writer(fh)
+        wr.writerow(["kernel", "grid_size", "launches", "fetch_bytes_per_launch(2*FETCH_SIZE*1024)", "write_bytes_per_launch(WRITE_SIZE*1024)", "total_bytes_per_launch"])
+        for r in rows:
+            wr.writerow([r[0], r[1], r[2], f"{r[3]:.0f}", f"{r[4]:.0f}", f"{r[5]:.0f}"])
+    big = [r for r in rows if "mimo_full_kernel" in r[0]]
+    big.sort(key=lambda r: -r[5])
+    if big:
+        print("dominant kernel traffic (largest mimo_full launch):", big[0][0][:60], "grid", big[0][1], "bytes %.4g" % big[0][5])
+    print("value %.4g %s, %.4f ms/step; roofline frac %.3f" % (bench["value"], bench["unit"], bench["ms_per_step"],
+                                                               (bench.get("roofline") or {}).get("frac", float("nan"))))
+
+
+if __name__ == "__main__":
+    main()
