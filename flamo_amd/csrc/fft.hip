@@ -896,6 +896,7 @@ __global__ void __launch_bounds__(256) transpose_narrow_kernel(const E* __restri
 static int g_max_single = 0;
 static int g_fast_enabled = 1;
 static int g_fast_ct = 0;   // 0 = default choice, 16 / 32 = forced (tuning hook)
+static int g_fast_rt = 0;   // rows per workgroup in pass 2 (0 = default)
 
 static bool factorize(int n, Rad& rad) {
     rad.n = 0;
@@ -1016,6 +1017,7 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
         const int lds_rows = (LDS_BUDGET / esz - p.L2) / (per * a.L2P);
         if (rt > lds_rows) rt = lds_rows;
         if (rt > 16) rt = 16;
+        if (g_fast_rt > 0 && g_fast_rt < rt) rt = g_fast_rt;
         if (rt > P) rt = P;
         FL_REQUIRE(rt >= 1, "row pass does not fit (L2=%d)", p.L2);
         const int nthreads = (per * rt * fs->A > 256) ? 512 : 256;
@@ -1147,6 +1149,9 @@ int fl_debug_set_fft_max_single(int max_half_len) {
 }
 
 int fl_debug_set_fft_fast(int enabled) {
+    g_fast_enabled = enabled != 0;
+    g_fast_rt = enabled / 1000;
+    enabled %= 1000;
     g_fast_enabled = enabled != 0;
     g_fast_ct = (enabled == 32) ? 32 : (enabled == 16 ? 16 : 0);   // tuning: force 16- / 32-column tiles in pass 1
     return FL_OK;
