@@ -110,8 +110,8 @@ __global__ void __launch_bounds__(256) solve_kernel(
             const bool elim = (my_step < 0) && (gi != best);
             const cx<T> l = elim ? row[k] * inv : cx<T>(0, 0);
 #pragma unroll
-            for (int j = k + 1; j < NMAX; ++j) {
-                if (j < N) {
+            for (int j = 0; j < NMAX; ++j) {   // constant trip count: a bound that depends on k is not unrolled
+                if (j > k && j < N) {
                     const cx<T> pr = shfl_cx(row[j], best, NMAX);
                     row[j] = row[j] - l * pr;
                 }
