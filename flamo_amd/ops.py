@@ -171,10 +171,17 @@ class KernelTimer:
     def __init__(self):
         self.enabled = False
         self.records = {}
+        self.prefill_cycles = 0
 
-    def reset(self, enabled: bool):
+    def reset(self, enabled: bool, prefill_cycles: int = 0):
+        """prefill_cycles > 0: a spin kernel of that many clock cycles is enqueued in front of every
+        timed launch, so that the start event, the launch and the stop event are all queued before the
+        GPU reaches them -- in eager steps the host is slower than the GPU and an event recorded on an
+        idle stream is stamped at once, which would add the host's time between the two calls (and the
+        dispatch latency of a cold queue) to the kernel's."""
         self.enabled = enabled
         self.records = {}
+        self.prefill_cycles = int(prefill_cycles)
 
     def span(self, name):
         timer = self
@@ -184,6 +191,8 @@ class KernelTimer:
                 if timer.enabled:
                     self_.a = torch.cuda.Event(enable_timing=True)
                     self_.b = torch.cuda.Event(enable_timing=True)
+                    if timer.prefill_cycles:
+                        torch.cuda._sleep(timer.prefill_cycles)
                     self_.a.record(torch.cuda.current_stream())
                 return self_
 
