@@ -308,3 +308,40 @@ def test_matrix_exp_kernel_matches_torch(gpu, N):
             if skew:   # orthogonal to working precision
                 I = torch.eye(N, dtype=torch.float64)
                 assert (E.detach().cpu().double() @ E.detach().cpu().double().mT - I).abs().max() < tol * 10
+
+
+def test_response_overlap_is_transparent(gpu):
+    """Building the folded response on the side stream (Shell + Series) changes nothing but timing:
+    eager outputs and gradients are bit-identical with the overlap on and off, and a captured step
+    replays to the same numbers."""
+    from collections import OrderedDict
+    from flamo_amd import ops
+    from flamo_amd.graph import GraphedStep
+    from flamo_amd.processor import dsp, system
+    torch.manual_seed(21)
+    nfft, N = 4800, 4
+    kw = dict(nfft=nfft, device=gpu, dtype=torch.float32, requires_grad=True)
+    core = system.Series(OrderedDict(mix=dsp.Matrix(size=(N, N), matrix_type="orthogonal", **kw), eq=dsp.GEQ(size=(N, N), **kw),
+                                     d=dsp.parallelDelay(size=(N,), max_len=300, isint=True, nfft=nfft, device=gpu,
+                                                         dtype=torch.float32)))
+    model = system.Shell(core, dsp.FFT(nfft), dsp.iFFT(nfft))
+    params = [p for p in model.parameters() if p.requires_grad]
+    x = torch.randn(5, nfft, N, device=gpu)
+    res = {}
+    for on in (True, False):
+        system.OVERLAP_RESPONSES = on
+        try:
+            loss = ops.mean_square(model(x))
+            res[on] = (loss.detach().clone(), [g.clone() for g in torch.autograd.grad(loss, params)])
+        finally:
+            system.OVERLAP_RESPONSES = True
+    assert torch.equal(res[True][0], res[False][0])
+    for ga, gb in zip(res[True][1], res[False][1]):
+        assert torch.equal(ga, gb)
+    gs = GraphedStep(lambda xx: ops.mean_square(model(xx)), (x,), params, warmup=2)
+    for _ in range(2):
+        out = gs.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, res[True][0])
+    for p, gb in zip(params, res[True][1]):
+        assert torch.equal(p.grad, gb)

@@ -6,6 +6,7 @@ Tolerances (relative l2 error against the float64 reference):
   float64 kernels 1e-10, float32 kernels 1e-5 (BASELINE.json north_star: <= 1e-5).
 """
 import ctypes
+from collections import OrderedDict
 
 import pytest
 import torch
@@ -441,3 +442,74 @@ def test_config2_full_size(gpu):
     assert relerr(g[0].cpu(), gref[0]) < 1e-5
     assert relerr(g[1].cpu(), gref[1]) < 1e-5
     assert relerr(g[2].cpu(), gref[2]) < 1e-4
+
+
+def _config5_model(dsp, system, N, nfft, db, a, dev, dt, max_len=2000):
+    """BASELINE config 5 (active-acoustics structure): anti-aliased transforms around
+    Series(GEQ((N,N)), Recursion(fF = Series(Delay((N,N), isint), parallelGain(N)), fB = Matrix orthogonal))."""
+    kw = dict(nfft=nfft, alias_decay_db=db, device=dev, dtype=dt)
+    geq = dsp.GEQ(size=(N, N), **kw)
+    dly = dsp.Delay(size=(N, N), max_len=max_len, isint=True, **kw)
+    gain = dsp.parallelGain(size=(N,), **kw)
+    mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", **kw)
+    geq.assign_value(a["geq"].to(dev, dt))
+    dly.assign_value(a["delay_s"].to(dev, dt))
+    gain.assign_value(a["gain"].to(dev, dt))
+    mix.assign_value(a["U"].to(dev, dt))
+    core = system.Series(OrderedDict(eq=geq, loop=system.Recursion(fF=system.Series(OrderedDict(d=dly, g=gain)), fB=mix)))
+    return system.Shell(core, dsp.FFTAntiAlias(nfft, alias_decay_db=db, dtype=dt), dsp.iFFTAntiAlias(nfft, alias_decay_db=db, dtype=dt))
+
+
+def _config5_params(N, max_len=2000):
+    g = torch.Generator().manual_seed(130709)
+    m = torch.randint(1, max_len, (N, N), generator=g).double()
+    return dict(geq=(torch.rand(12, N, N, generator=g) * (10 ** (6 / 20) - 10 ** (-6 / 20)) + 10 ** (-6 / 20)).float().double(),
+                delay_s=(m / 48000 * 100).float().double(),            # seconds * unit, as Delay stores them
+                gain=(torch.rand(N, generator=g) * 0.5 / N ** 0.5 + 0.01).float().double(),
+                U=torch.randn(N, N, generator=g).float().double())
+
+
+def test_config5_chain_against_oracle(gpu):
+    """Config 5's structure (32x32 GEQ -> Recursion(Delay * parallelGain, orthogonal Matrix), anti-aliasing
+    on) against the float64 oracle at a length the oracle finishes in seconds."""
+    from flamo_amd.processor import dsp, system
+    from oracle import hotpath as O
+    N, nfft, db = 32, 9600, 30.0
+    a = _config5_params(N)
+    torch.manual_seed(5)
+    x = torch.randn(1, nfft, N, dtype=torch.float64) * 0.1
+    x[:, 0] += 1
+    gamma = O.gamma_of(db, nfft, torch.float64)
+    X = O.rfft(x, nfft, alias_decay_db=db)
+    X = O.mimo_full(O.geq_response(a["geq"], nfft, gamma), X)
+    m = O.delay_samples(a["delay_s"], 48000, 100, True)
+    F = O.to_complex(a["gain"]).view(1, N, 1) * O.delay_response(m, nfft, gamma)
+    Bk = O.to_complex(O.orthogonal(a["U"])).unsqueeze(0).expand(F.shape[0], N, N)
+    yref = O.irfft(O.recursion(F, Bk, X), nfft, alias_decay_db=db)
+    for dt_, tol in ((torch.float64, 1e-9), (torch.float32, 1e-5)):
+        model = _config5_model(dsp, system, N, nfft, db, a, gpu, dt_)
+        with torch.no_grad():
+            y = model(x.to(gpu, dt_))
+        assert relerr(y.cpu(), yref) < tol, dt_
+
+
+def test_config5_full_size_runs_and_is_linear(gpu):
+    """Config 5 at its BASELINE size (32x32, nfft=384000, anti-aliasing 30 dB), float32: finite output,
+    linearity in the input and agreement with the float64 run of the same kernels."""
+    from flamo_amd.processor import dsp, system
+    N, nfft, db = 32, 384000, 30.0
+    a = _config5_params(N)
+    torch.manual_seed(6)
+    x1 = torch.zeros(1, nfft, N, dtype=torch.float64)
+    x1[:, 0] = 1
+    x2 = torch.randn(1, nfft, N, dtype=torch.float64) * 0.01
+    m32 = _config5_model(dsp, system, N, nfft, db, a, gpu, torch.float32)
+    with torch.no_grad():
+        y1 = m32(x1.to(gpu, torch.float32))
+        y2 = m32(x2.to(gpu, torch.float32))
+        y12 = m32((x1 + 2 * x2).to(gpu, torch.float32))
+        assert torch.isfinite(y1).all() and y1.shape == (1, nfft, N)
+        assert relerr(y12, y1 + 2 * y2) < 2e-5
+        m64 = _config5_model(dsp, system, N, nfft, db, a, gpu, torch.float64)
+        y64 = m64(x1.to(gpu))
+    assert relerr(y1.double(), y64) < 1e-5
