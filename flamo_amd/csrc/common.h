@@ -50,6 +50,37 @@ template <typename T> __host__ __device__ inline cx<T> cdiv(cx<T> a, cx<T> b) {
     }
 }
 
+// Wavefront reduce-scatter of N per-lane values: after the call the lane holds in a[0..cnt) the
+// wavefront totals of the original entries off .. off+cnt-1.  Each halving step trades half of the
+// lane's values with its partner (N/2 shuffles instead of N); when the count turns odd the rest is
+// reduced by plain butterflies.  72 running sums cost 90 shuffles instead of 432 (the epilogue, not
+// the bin loop, used to dominate the cascade backward).  Lanes whose index has a bit of dup_mask set
+// hold duplicates.
+template <typename V, int N, int MASK>
+__device__ inline void wave_reduce_scatter(V (&a)[N], int lane, int& off, int& cnt, int& dup_mask) {
+    if constexpr (MASK == 0) {
+        cnt = N;
+    } else if constexpr (N % 2 == 0) {
+        const bool up = (lane & MASK) != 0;
+        V k[N / 2];
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const V keep = up ? a[N / 2 + i] : a[i];
+            const V send = up ? a[i] : a[N / 2 + i];
+            k[i] = keep + __shfl_xor(send, MASK, 64);
+        }
+        if (up) off += N / 2;
+        wave_reduce_scatter<V, N / 2, MASK / 2>(k, lane, off, cnt, dup_mask);
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) a[i] = k[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) a[i] += __shfl_xor(a[i], MASK, 64);
+        dup_mask |= MASK;   // lanes differing in this bit now hold the same totals
+        wave_reduce_scatter<V, N, MASK / 2>(a, lane, off, cnt, dup_mask);
+    }
+}
+
 // ---------------------------------------------------------------- error plumbing (host)
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);

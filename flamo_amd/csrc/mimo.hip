@@ -262,54 +262,48 @@ static int gradh_diag_impl(const void* G, long gs_b, long gs_n, long gs_k, const
 
 // dW[m,n] = sum_{b,k,f} G[b,m,k,f] conj(X[b,n,k,f]) -- the gradient of a frequency-INDEPENDENT
 // matrix (Gain/Matrix, the FDN mixing matrix) reduced over bins inside the kernel: each block
-// walks bins with a grid stride, keeps a 4x4 tile of sums per lane, reduces across the block and
+// walks bins with a grid stride, keeps a 4x4 (8x8) tile of sums per lane, reduces across the block and
 // writes one partial tile; the host adds the <= 256 partials.  No (M, No, Ni) tensor is built.
-template <typename T>
+template <typename T, int TM, int TN>
 __global__ void __launch_bounds__(256) mimo_gradw_kernel(
     const cx<T>* __restrict__ G, long gs_b, long gs_m, long gs_k,
     const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
     cx<T>* __restrict__ part, int B, int M, int No, int Ni, int K) {
-    const int m0 = blockIdx.y * 4, n0 = blockIdx.z * 4;
-    cx<T> acc[4][4];
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.z * TN;
+    // accumulators as 2*TM*TN scalars: [2*(mm*TN + nn)] real, [+1] imaginary
+    T acc[2 * TM * TN];
 #pragma unroll
-    for (int mm = 0; mm < 4; ++mm)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn) acc[mm][nn] = cx<T>(0, 0);
+    for (int v = 0; v < 2 * TM * TN; ++v) acc[v] = (T)0;
     for (int f = blockIdx.x * 256 + threadIdx.x; f < M; f += gridDim.x * 256)
         for (int b = 0; b < B; ++b)
             for (int k = 0; k < K; ++k) {
                 const cx<T>* g = G + (long)b * gs_b + (long)k * gs_k + f;
                 const cx<T>* x = X + (long)b * xs_b + (long)k * xs_k + f;
-                cx<T> gv[4], xv[4];
+                cx<T> gv[TM], xv[TN];
 #pragma unroll
-                for (int mm = 0; mm < 4; ++mm) gv[mm] = (m0 + mm < No) ? g[(long)(m0 + mm) * gs_m] : cx<T>(0, 0);
+                for (int mm = 0; mm < TM; ++mm) gv[mm] = (m0 + mm < No) ? g[(long)(m0 + mm) * gs_m] : cx<T>(0, 0);
 #pragma unroll
-                for (int nn = 0; nn < 4; ++nn) xv[nn] = (n0 + nn < Ni) ? x[(long)(n0 + nn) * xs_n] : cx<T>(0, 0);
+                for (int nn = 0; nn < TN; ++nn) xv[nn] = (n0 + nn < Ni) ? x[(long)(n0 + nn) * xs_n] : cx<T>(0, 0);
 #pragma unroll
-                for (int mm = 0; mm < 4; ++mm)
+                for (int mm = 0; mm < TM; ++mm)
 #pragma unroll
-                    for (int nn = 0; nn < 4; ++nn) fma_cxc(acc[mm][nn], gv[mm], xv[nn]);
+                    for (int nn = 0; nn < TN; ++nn) {   // += g * conj(x)
+                        acc[2 * (mm * TN + nn)] += gv[mm].x * xv[nn].x + gv[mm].y * xv[nn].y;
+                        acc[2 * (mm * TN + nn) + 1] += gv[mm].y * xv[nn].x - gv[mm].x * xv[nn].y;
+                    }
             }
-    __shared__ T red[4][32];
+    __shared__ T red[4][2 * TM * TN];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int off = 0, cnt = 0, dup = 0;
+    wave_reduce_scatter<T, 2 * TM * TN, 32>(acc, lane, off, cnt, dup);
+    if ((lane & dup) == 0) {
 #pragma unroll
-    for (int mm = 0; mm < 4; ++mm)
-#pragma unroll
-        for (int nn = 0; nn < 4; ++nn) {
-            T vr = acc[mm][nn].x, vi = acc[mm][nn].y;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                vr += __shfl_xor(vr, off, 64);
-                vi += __shfl_xor(vi, off, 64);
-            }
-            if (lane == 0) {
-                red[wave][(mm * 4 + nn) * 2] = vr;
-                red[wave][(mm * 4 + nn) * 2 + 1] = vi;
-            }
-        }
+        for (int v = 0; v < 2 * TM * TN; ++v)
+            if (v < cnt) red[wave][off + v] = acc[v];
+    }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        const int mm = threadIdx.x / 4, nn = threadIdx.x % 4;
+    if (threadIdx.x < TM * TN) {
+        const int mm = threadIdx.x / TN, nn = threadIdx.x % TN;
         const int m = m0 + mm, n = n0 + nn;
         if (m < No && n < Ni) {
             T vr = 0, vi = 0;
@@ -336,10 +330,18 @@ static int gradw_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
                       void* part, int B, int M, int No, int Ni, int K, void* stream) {
     FL_REQUIRE(G && X && part, "mimo_gradw: null pointer");
     FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo_gradw: bad sizes");
-    dim3 grid(gradw_blocks(M), cdiv_i(No, 4), cdiv_i(Ni, 4));
+    // 8x8 tiles where the matrix allows: every element of G and X is then read No/8 (Ni/8) times
+    // instead of No/4 -- at N = 32 with matrix-valued signals that is 12 GB instead of 25 GB per launch
+    const bool big = No >= 8 && Ni >= 8 && sizeof(T) == 4;
+    const int tm = big ? 8 : 4;
+    dim3 grid(gradw_blocks(M), cdiv_i(No, tm), cdiv_i(Ni, tm));
     FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradw: too many channels");
-    hipLaunchKernelGGL((mimo_gradw_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)G, gs_b, gs_m, gs_k,
-                       (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)part, B, M, No, Ni, K);
+    if (big)
+        hipLaunchKernelGGL((mimo_gradw_kernel<T, 8, 8>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)G, gs_b, gs_m,
+                           gs_k, (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)part, B, M, No, Ni, K);
+    else
+        hipLaunchKernelGGL((mimo_gradw_kernel<T, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)G, gs_b, gs_m,
+                           gs_k, (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)part, B, M, No, Ni, K);
     FL_CHECK_LAUNCH("mimo_gradw");
     return FL_OK;
 }

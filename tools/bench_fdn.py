@@ -2,7 +2,11 @@
 """Secondary benchmark: BASELINE configs[2] -- 16-channel FDN (e8_fdn.py structure), nfft=192000,
 Gain(16,1) -> Recursion(fF=parallelDelay(isint), fB=Series(Matrix orthogonal, parallelGEQ)) -> Gain(1,16),
 FFT / iFFTAntiAlias(30 dB); forward + backward of (y*c).sum() with all parameter gradients.
-Prints bin-solves/s (B*M / time) for float32 and float64.   python tools/bench_fdn.py [--batch B]"""
+Prints bin-solves/s (B*M / time) for float32 and float64.   python tools/bench_fdn.py [--batch B]
+
+--workload config5: BASELINE configs[4] on one GPU -- the active-acoustics structure:
+FFTAntiAlias(384000, 30 dB) -> Series(GEQ((32,32)), Recursion(fF=Series(Delay((32,32), isint), parallelGain(32)),
+fB=Matrix(32,32, orthogonal))) -> iFFTAntiAlias, impulse-like input (1, 384000, 32), gradients for GEQ, gain, matrix."""
 import argparse
 import json
 import os
@@ -35,23 +39,40 @@ def build(dev, dtype, N=16, nfft=192000, db=30.0):
     return model, [ig.param, og.param, mix.param, att.param]
 
 
+def build_config5(dev, dtype, N=32, nfft=384000, db=30.0):
+    from flamo_amd.processor import dsp, system
+    kw = dict(nfft=nfft, alias_decay_db=db, device=dev, dtype=dtype)
+    geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+    dly = dsp.Delay(size=(N, N), max_len=2000, isint=True, **kw)
+    gain = dsp.parallelGain(size=(N,), requires_grad=True, **kw)
+    with torch.no_grad():
+        gain.param.copy_(torch.rand_like(gain.param) * 0.5 / N ** 0.5 + 0.01)
+    mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+    core = system.Series(OrderedDict(eq=geq, loop=system.Recursion(fF=system.Series(OrderedDict(d=dly, g=gain)), fB=mix)))
+    model = system.Shell(core, dsp.FFTAntiAlias(nfft, alias_decay_db=db, dtype=dtype),
+                         dsp.iFFTAntiAlias(nfft, alias_decay_db=db, dtype=dtype))
+    return model, [geq.param, gain.param, mix.param]
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="fdn16", choices=["fdn16", "config5"])
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--dtype", default="both")
     args = ap.parse_args()
     warnings.simplefilter("ignore")
     dev = torch.device("cuda:0")
-    nfft, N = 192000, 16
+    nfft, N = (192000, 16) if args.workload == "fdn16" else (384000, 32)
+    chan = 1 if args.workload == "fdn16" else N
     out = {}
     for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
         if args.dtype not in ("both", name):
             continue
         torch.manual_seed(130709)
-        model, params = build(dev, dt, N, nfft)
-        x = torch.randn(args.batch, nfft, 1, device=dev, dtype=dt)
-        c = torch.randn(args.batch, nfft, 1, device=dev, dtype=dt)
+        model, params = build(dev, dt, N, nfft) if args.workload == "fdn16" else build_config5(dev, dt, N, nfft)
+        x = torch.randn(args.batch, nfft, chan, device=dev, dtype=dt)
+        c = torch.randn(args.batch, nfft, chan, device=dev, dtype=dt)
 
         def step():
             for p in params:
@@ -83,7 +104,8 @@ def main():
         msg = (time.perf_counter() - t0) / args.steps * 1e3
         out[name].update(graph_ms_per_step=msg, graph_bin_solves_per_s=args.batch * (nfft // 2 + 1) / (msg * 1e-3),
                          graph_vs_eager_grad_relerr=err)
-    print(json.dumps({"workload": f"16-ch FDN, nfft={nfft}, batch {args.batch}, fwd+bwd", **out}))
+    what = f"16-ch FDN, nfft={nfft}" if args.workload == "fdn16" else f"config 5 chain {N}x{N}, nfft={nfft}"
+    print(json.dumps({"workload": f"{what}, batch {args.batch}, fwd+bwd", **out}))
 
 
 if __name__ == "__main__":
