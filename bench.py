@@ -141,20 +141,38 @@ def main():
         # to host jitter) out of the loop.  Forward + backward are captured once; the tiny RCCL
         # gradient all-reduce stays eager after each replay.
         from flamo_amd.graph import GraphedStep
-        gs = GraphedStep(lambda xx: ops.mean_square(model(xx)), (x,), params, warmup=2)
+        try:
+            gs = GraphedStep(lambda xx: ops.mean_square(model(xx)), (x,), params, warmup=2)
+        except Exception as e:      # capture refused (e.g. by another thread's activity): time eager steps instead
+            print(f"[bench] HIP-graph capture failed on rank {rank} ({type(e).__name__}: {e}); timing eager steps",
+                  file=sys.stderr)
+            torch.cuda.synchronize()
+            args.no_graph = True
+            gs = None
+        if dist_on:                 # every rank must time the same kind of step
+            flag = torch.tensor([1 if gs is None else 0], device=dev)
+            dist.all_reduce(flag)
+            if flag.item() > 0:
+                args.no_graph, gs = True, None
 
-        def step():
-            loss = gs.replay()
-            if dist_on:
-                flat = torch.cat([p.grad.reshape(-1) for p in params])
-                dist.all_reduce(flat)
-            return loss
+        if gs is not None:
+            def step():
+                loss = gs.replay()
+                if dist_on:
+                    flat = torch.cat([p.grad.reshape(-1) for p in params])
+                    dist.all_reduce(flat)
+                return loss
 
     def fence():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.no_graph:
+        # eager steps are host-bound: the side-stream overlap buys nothing there, and an event recorded
+        # behind a cross-stream wait would be stamped early (see the roofline leg below)
+        from flamo_amd.processor import system as _sys
+        _sys.OVERLAP_RESPONSES = False
     for _ in range(args.warmup):
         step()
     fence()

@@ -32,7 +32,9 @@ class GraphedStep:
                 self._run_eager()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread-local capture mode: a communicator's watchdog thread (RCCL) may query events while this
+        # thread captures; in the default global mode that would invalidate the capture
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.static_out = self._run_captured()
         # the gradients the captured backward produces live in the graph's pool and are rewritten
         # in place by every replay: hand them to the parameters as they are (no copy per step)
