@@ -48,8 +48,8 @@ _SIGNATURES = {
     "fl_mimo_gradh_diag_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _i, _i, _i, _i, _vp]),
     "fl_mimo_gradw_blocks": (_i, [_i]),
     "fl_debug_set_mimo_variant": (_i, [_i, _i]),
-    "fl_mimo_gradw_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _i, _vp]),
-    "fl_mimo_gradw_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradw_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradw_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fl_delay_response_c64": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _l, _vp]),
     "fl_delay_response_c128": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _l, _vp]),
     "fl_sos_response_c64": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _l, _vp]),

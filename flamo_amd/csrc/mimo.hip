@@ -316,6 +316,29 @@ __global__ void __launch_bounds__(256) mimo_gradw_kernel(
     }
 }
 
+// dW[m,n] = sum over the nblk partial tiles: one wavefront per entry, lanes stride over the blocks and
+// combine with a fixed butterfly (deterministic; a serial loop over 256 partials costs 30 us of
+// dependent L2 latency)
+template <typename T>
+__global__ void __launch_bounds__(256) mimo_gradw_final_kernel(const cx<T>* __restrict__ part, int nblk, int count,
+                                                              cx<T>* __restrict__ dW) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= count) return;
+    T vr = 0, vi = 0;
+    for (int b = lane; b < nblk; b += 64) {
+        const cx<T> v = part[(size_t)b * count + e];
+        vr += v.x;
+        vi += v.y;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        vr += __shfl_xor(vr, off, 64);
+        vi += __shfl_xor(vi, off, 64);
+    }
+    if (lane == 0) dW[e] = cx<T>(vr, vi);
+}
+
 static int g_gradw_cap = 0;
 static int gradw_blocks(int M) {
     int nb = cdiv_i(M, 256);
@@ -327,8 +350,8 @@ static int gradw_blocks(int M) {
 
 template <typename T>
 static int gradw_impl(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                      void* part, int B, int M, int No, int Ni, int K, void* stream) {
-    FL_REQUIRE(G && X && part, "mimo_gradw: null pointer");
+                      void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream) {
+    FL_REQUIRE(G && X && part && dW, "mimo_gradw: null pointer");
     FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo_gradw: bad sizes");
     // 8x8 tiles where the matrix allows: every element of G and X is then read No/8 (Ni/8) times
     // instead of No/4 -- at N = 32 with matrix-valued signals that is 12 GB instead of 25 GB per launch
@@ -343,6 +366,9 @@ static int gradw_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
         hipLaunchKernelGGL((mimo_gradw_kernel<T, 4, 4>), grid, dim3(256), 0, (hipStream_t)stream, (const cx<T>*)G, gs_b, gs_m,
                            gs_k, (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)part, B, M, No, Ni, K);
     FL_CHECK_LAUNCH("mimo_gradw");
+    hipLaunchKernelGGL((mimo_gradw_final_kernel<T>), dim3(cdiv_i((long)No * Ni, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const cx<T>*)part, (int)grid.x, No * Ni, (cx<T>*)dW);
+    FL_CHECK_LAUNCH("mimo_gradw_final");
     return FL_OK;
 }
 
@@ -359,12 +385,12 @@ int fl_debug_set_mimo_variant(int variant, int gradw_cap) {
     return FL_OK;
 }
 int fl_mimo_gradw_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                      void* part, int B, int M, int No, int Ni, int K, void* stream) {
-    return gradw_impl<float>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, part, B, M, No, Ni, K, stream);
+                      void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream) {
+    return gradw_impl<float>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, part, dW, B, M, No, Ni, K, stream);
 }
 int fl_mimo_gradw_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                       void* part, int B, int M, int No, int Ni, int K, void* stream) {
-    return gradw_impl<double>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, part, B, M, No, Ni, K, stream);
+                       void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream) {
+    return gradw_impl<double>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, part, dW, B, M, No, Ni, K, stream);
 }
 
 int fl_mimo_c64(const void* H, long hs_f, long hs_m, long hs_n, int conj_h, const void* X, long xs_b, long xs_n, long xs_k,

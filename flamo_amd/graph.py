@@ -25,6 +25,7 @@ class GraphedStep:
         self.params = [p for p in params if p.requires_grad]
         self.static_inputs = [t.clone() for t in example_inputs]
         self._fn = fn
+        self._seed = None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):            # warm-up off the default stream: fills twiddle/constant caches
@@ -47,11 +48,15 @@ class GraphedStep:
             p.grad = None
         out = self._fn(*self.static_inputs)
         out.backward()
+        # the all-ones gradient seed of the captured backward: allocated once here instead of being
+        # filled by a launch in every replay
+        self._seed = torch.ones_like(out)
         return out.detach()
 
     def _run_captured(self):
         out = self._fn(*self.static_inputs)
-        grads = torch.autograd.grad(out, self.params, allow_unused=True) if self.params else ()
+        seed = self._seed if (self._seed is not None and self._seed.shape == out.shape and self._seed.dtype == out.dtype) else None
+        grads = torch.autograd.grad(out, self.params, grad_outputs=seed, allow_unused=True) if self.params else ()
         self._static_grads = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
         return out.detach()
 

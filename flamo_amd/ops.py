@@ -498,10 +498,11 @@ def _gradw_launch(G, X):
     L = _lib.lib()
     nblk = L.fl_mimo_gradw_blocks(M)
     part = torch.empty((nblk, No, Ni), dtype=X.dtype, device=X.device)
+    dW = torch.empty((No, Ni), dtype=X.dtype, device=X.device)
     fn = L.fl_mimo_gradw_c64 if real == torch.float32 else L.fl_mimo_gradw_c128
-    _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, part.data_ptr(), B, M, No, Ni, K,
-                  _stream()), "mimo_gradw")
-    return part.sum(dim=0)
+    _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, part.data_ptr(), dW.data_ptr(), B, M, No, Ni,
+                  K, _stream()), "mimo_gradw")
+    return dW
 
 
 class _Mimo(torch.autograd.Function):

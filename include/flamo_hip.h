@@ -151,15 +151,16 @@ int fl_mimo_gradh_diag_c128(const void* G, long gs_b, long gs_n, long gs_k,
 
 /* dW[m,n] = sum_{b,k,f} G[b,m,k,f] * conj(X[b,n,k,f]): gradient of a frequency-independent matrix
  * (Gain/Matrix, dsp.py:466-468; the FDN mixing matrix) with the reduction over bins done in the
- * kernel.  part: complex (nblk, No, Ni), nblk = fl_mimo_gradw_blocks(M); the caller sums over nblk. */
+ * kernel.  part: complex scratch (nblk, No, Ni), nblk = fl_mimo_gradw_blocks(M), per-block partial tiles;
+ * dW: complex (No, Ni) = their sum in block order (a second tiny launch: deterministic, no atomics). */
 int fl_mimo_gradw_blocks(int M);
 /* tuning hook: variant = mt*100 + bt*10 + nu (register tile MT x BT, nu input channels loaded per
  * trip; 0 = default), gradw_cap = partial blocks of fl_mimo_gradw (0 = default) */
 int fl_debug_set_mimo_variant(int variant, int gradw_cap);
 int fl_mimo_gradw_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                      void* part, int B, int M, int No, int Ni, int K, void* stream);
+                      void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream);
 int fl_mimo_gradw_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                       void* part, int B, int M, int No, int Ni, int K, void* stream);
+                       void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream);
 
 /* ------------------------------------------------------------------ frequency responses
  * Integer delay lines, Delay/parallelDelay.get_freq_response with isint=True
