@@ -81,6 +81,16 @@ __device__ inline void wave_reduce_scatter(V (&a)[N], int lane, int& off, int& c
     }
 }
 
+// 1 / b without branches: scale by max(|re|,|im|) (no overflow in |b|^2), two real divisions instead of
+// the six (three per branch) of Smith's quotient -- the pivot reciprocal of the LU sits on its critical path
+template <typename T> __host__ __device__ inline cx<T> crecip(cx<T> b) {
+    const T s = fmax(fabs(b.x), fabs(b.y));
+    const T is = (T)1 / s;
+    const T x = b.x * is, y = b.y * is;
+    const T d = is / (x * x + y * y);
+    return cx<T>(x * d, -y * d);
+}
+
 // ---------------------------------------------------------------- error plumbing (host)
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);

@@ -36,6 +36,62 @@ struct Dud {
     long r_sn, r_sf;
 };
 
+// ---------------------------------------------------------------- DPP exchanges inside a 16-lane row
+// The pivot search is a chain of dependent exchanges; through ds_bpermute each one is an LDS round
+// trip (~100 cycles the wavefront sits in s_waitcnt: 286 of them were most of this kernel's time).
+// Inside a DPP row the same exchanges are register moves at full VALU rate: mirror within 16 lanes,
+// mirror within 8, quad permutes.
+template <int CTRL>
+__device__ inline float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ inline int dpp_mov(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ inline double dpp_mov(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_MIRROR = 0x140;     // lane i <- lane 15-i of its 16-lane row
+constexpr int DPP_HALF_MIRROR = 0x141;    // lane i <- lane 7-i of its 8-lane half row
+
+template <int CTRL, typename T>
+__device__ inline void argmax_dpp(T& bm, int& best) {
+    const T om = dpp_mov<CTRL>(bm);
+    const int ob = dpp_mov<CTRL>(best);
+    // the lowest lane wins ties, as LAPACK's icamax; bitwise logic and selects, no branches
+    const bool take = (om > bm) | ((om == bm) & (ob < best));
+    bm = take ? om : bm;
+    best = take ? ob : best;
+}
+
+// (largest |.|, its lane) over the NMAX lanes of a group, result in every lane of the group
+template <int NMAX, typename T>
+__device__ inline void group_argmax(T& bm, int& best) {
+    if constexpr (NMAX <= 16) {
+        if constexpr (NMAX >= 16) argmax_dpp<DPP_ROW_MIRROR>(bm, best);
+        if constexpr (NMAX >= 8) argmax_dpp<DPP_HALF_MIRROR>(bm, best);
+        if constexpr (NMAX >= 4) argmax_dpp<DPP_QUAD_XOR2>(bm, best);
+        if constexpr (NMAX >= 2) argmax_dpp<DPP_QUAD_XOR1>(bm, best);
+    } else {
+#pragma unroll
+        for (int off = NMAX / 2; off >= 1; off >>= 1) {
+            const T om = __shfl_xor(bm, off, NMAX);
+            const int ob = __shfl_xor(best, off, NMAX);
+            if (om > bm || (om == bm && ob < best)) {
+                bm = om;
+                best = ob;
+            }
+        }
+    }
+}
+
 template <typename T, int NMAX>
 __global__ void __launch_bounds__(256) solve_kernel(
     const cx<T>* __restrict__ P, long p_pitch, Dud<T> dud, int one_minus, int adjoint,
@@ -95,32 +151,29 @@ __global__ void __launch_bounds__(256) solve_kernel(
         if (k < N) {
             T bm = (my_step < 0) ? (fabs(row[k].x) + fabs(row[k].y)) : (T)-1;
             int best = gi;
-#pragma unroll
-            for (int off = NMAX / 2; off >= 1; off >>= 1) {
-                const T om = __shfl_xor(bm, off, NMAX);
-                const int ob = __shfl_xor(best, off, NMAX);
-                if (om > bm || (om == bm && ob < best)) {
-                    bm = om;
-                    best = ob;
-                }
-            }
+            group_argmax<NMAX>(bm, best);
             pl[k] = best;
             const cx<T> piv = shfl_cx(row[k], best, NMAX);
-            const cx<T> inv = cdiv(cx<T>(1, 0), piv);
+            const cx<T> inv = crecip(piv);
             const bool elim = (my_step < 0) && (gi != best);
             const cx<T> l = elim ? row[k] * inv : cx<T>(0, 0);
+            // no `j < N` guard: padded columns are zero and stay zero, and without per-element branches
+            // the NMAX-k-1 broadcasts of the pivot row are issued back to back behind ONE wait
+            // (constant trip count: a bound that depends on k is not unrolled)
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j) {   // constant trip count: a bound that depends on k is not unrolled
-                if (j > k && j < N) {
+            for (int j = 0; j < NMAX; ++j) {
+                if (j > k) {
                     const cx<T> pr = shfl_cx(row[j], best, NMAX);
                     row[j] = row[j] - l * pr;
                 }
             }
-            if (elim) row[k] = l;
-            if (gi == best) {
-                my_step = k;
-                dinv = inv;
-            }
+            // selects, not branches: a divergent `if` costs an exec-mask save/restore and a branch each
+            row[k].x = elim ? l.x : row[k].x;
+            row[k].y = elim ? l.y : row[k].y;
+            const bool mine = (gi == best);
+            my_step = mine ? k : my_step;
+            dinv.x = mine ? inv.x : dinv.x;
+            dinv.y = mine ? inv.y : dinv.y;
         }
     }
 
@@ -135,16 +188,23 @@ __global__ void __launch_bounds__(256) solve_kernel(
         for (int k = 0; k < NMAX; ++k) {
             if (k < N) {
                 const cx<T> yp = shfl_cx(y, pl[k], NMAX);
-                if (my_step > k && my_step < NMAX) y = y - row[k] * yp;
+                const cx<T> t = row[k] * yp;
+                const bool on = my_step > k && my_step < NMAX;
+                y.x -= on ? t.x : (T)0;
+                y.y -= on ? t.y : (T)0;
             }
         }
         // back substitution: lane pl[k] finishes x_k, the earlier pivots subtract U[.,k] x_k
 #pragma unroll
         for (int k = NMAX - 1; k >= 0; --k) {
             if (k < N) {
-                if (my_step == k) y = y * dinv;
+                const cx<T> yd = y * dinv;
+                y.x = (my_step == k) ? yd.x : y.x;
+                y.y = (my_step == k) ? yd.y : y.y;
                 const cx<T> xk = shfl_cx(y, pl[k], NMAX);
-                if (my_step < k) y = y - row[k] * xk;
+                const cx<T> t = row[k] * xk;
+                y.x -= (my_step < k) ? t.x : (T)0;
+                y.y -= (my_step < k) ? t.y : (T)0;
             }
         }
         if (gi < N) OUT[(long)b * os_b + (long)my_step * os_n + (long)kk * os_k + f] = y;
