@@ -231,28 +231,47 @@ __global__ void __launch_bounds__(256) sos_response_bwd_mixed_kernel(
         const cx<float> gin = gH[(size_t)c * g_pitch + f];
         const cx<float> gc(gin.x, -gin.y);
         const cx<float> gh = gc * h;              // conj(gH) * H
+        // The common route is branch-free: a section whose value vanishes or leaves the float range is
+        // given zero weight here and flagged; flagged sections (rare: a band-pass numerator at DC) are
+        // redone in double after the loop.  A divergent if/else per section costs an exec-mask
+        // save/restore pair and serialises the LDS reads of neighbouring sections.
+        unsigned slow = 0;
 #pragma unroll
         for (int q = 0; q < SCH; ++q) {
             const int s = s0 + q;
-            if (s < S) {
+            if (s < S) {   // uniform
                 const cx<double> Bs = e.poly(lb, S, s), As = e.poly(la, S, s);
                 const float nb = (float)(Bs.x * Bs.x + Bs.y * Bs.y), na = (float)(As.x * As.x + As.y * As.y);
-                cx<float> tb, ta;
-                if (nb > 1e-30f && nb < 1e30f && na > 1e-30f && na < 1e30f) {
-                    const float ib = __builtin_amdgcn_rcpf(nb), ia = __builtin_amdgcn_rcpf(na);
-                    const cx<float> Bf((float)Bs.x, (float)Bs.y), Af((float)As.x, (float)As.y);
-                    const cx<float> ub = mulc(gh, Bf), ua = mulc(gh, Af);     // gh * conj(.)
-                    tb = cx<float>(ub.x * ib, ub.y * ib);
-                    ta = cx<float>(ua.x * ia, ua.y * ia);
-                } else {
-                    sos_bwd_slow_section(e, lb, la, S, s, gc, Bs, As, tb, ta);
-                }
+                const bool ok = (nb > 1e-30f) & (nb < 1e30f) & (na > 1e-30f) & (na < 1e30f);
+                slow |= ok ? 0u : (1u << q);
+                const float ib = ok ? __builtin_amdgcn_rcpf(nb) : 0.f, ia = ok ? __builtin_amdgcn_rcpf(na) : 0.f;
+                const cx<float> Bf((float)Bs.x, (float)Bs.y), Af((float)As.x, (float)As.y);
+                const cx<float> ub = mulc(gh, Bf), ua = mulc(gh, Af);     // gh * conj(.)
+                const cx<float> tb(ok ? ub.x * ib : 0.f, ok ? ub.y * ib : 0.f);
+                const cx<float> ta(ok ? ua.x * ia : 0.f, ok ? ua.y * ia : 0.f);
                 acc[0 * SCH + q] += tb.x;
                 acc[1 * SCH + q] += tb.x * d.x - tb.y * d.y;
                 acc[2 * SCH + q] += tb.x * d2.x - tb.y * d2.y;
                 acc[3 * SCH + q] -= ta.x;
                 acc[4 * SCH + q] -= ta.x * d.x - ta.y * d.y;
                 acc[5 * SCH + q] -= ta.x * d2.x - ta.y * d2.y;
+            }
+        }
+        if (slow) {
+#pragma unroll
+            for (int q = 0; q < SCH; ++q) {
+                if ((slow >> q) & 1u) {
+                    const int s = s0 + q;
+                    const cx<double> Bs = e.poly(lb, S, s), As = e.poly(la, S, s);
+                    cx<float> tb, ta;
+                    sos_bwd_slow_section(e, lb, la, S, s, gc, Bs, As, tb, ta);
+                    acc[0 * SCH + q] += tb.x;
+                    acc[1 * SCH + q] += tb.x * d.x - tb.y * d.y;
+                    acc[2 * SCH + q] += tb.x * d2.x - tb.y * d2.y;
+                    acc[3 * SCH + q] -= ta.x;
+                    acc[4 * SCH + q] -= ta.x * d.x - ta.y * d.y;
+                    acc[5 * SCH + q] -= ta.x * d2.x - ta.y * d2.y;
+                }
             }
         }
     }
