@@ -733,6 +733,12 @@ __global__ void __launch_bounds__(512) fft_rows_fast(FftArgs<T> a) {
     }
     const cx<T>* res = U;
     if (EPI == EPI_RFFT_POST) {
+        // split-step twiddle W_n^k, k = r + L1*k2, as W_n^r * W_n^(L1 k2) from two small LDS tables
+        // (the stage-1 table is free by now) instead of one load from the master table per output --
+        // as many bytes again as the outputs themselves; the mirror bin's twiddle is W_n^(L-k) = -conj(W_n^k)
+        for (int j = threadIdx.x; j < LEN; j += blockDim.x) tw[j] = a.W[a.L1 * j];
+        if (threadIdx.x < nr) tw[LEN + threadIdx.x] = a.W[r0 + threadIdx.x];
+        __syncthreads();
         cx<T>* X = a.Xout + (size_t)sig * a.xc_stride;
         const T hs = (T)0.5 * a.scale;
         const T wi = a.interior ? (T)2 : (T)1;
@@ -745,9 +751,10 @@ __global__ void __launch_bounds__(512) fft_rows_fast(FftArgs<T> a) {
             const int slm = (rowm == r) ? a.per * i : a.per * i + 1;
             const cx<T> zk = res[(a.per * i) * LENP + k2];
             const cx<T> zm = res[slm * LENP + colm];
+            const cx<T> wk = tw[LEN + i] * tw[k2];
             {
                 const cx<T> p = zk + conj(zm), d = zk - conj(zm);
-                const cx<T> o = p + mul_mi(a.W[k] * d);
+                const cx<T> o = p + mul_mi(wk * d);
                 const T sc = (k == 0) ? hs : hs * wi;
                 X[k] = cx<T>(sc * o.x, sc * o.y);
                 if (k == 0) {
@@ -757,13 +764,16 @@ __global__ void __launch_bounds__(512) fft_rows_fast(FftArgs<T> a) {
             }
             if (k != 0 && rowm != r) {
                 const cx<T> p = zm + conj(zk), d = zm - conj(zk);
-                const cx<T> o = p + mul_mi(a.W[km] * d);
+                const cx<T> wm(-wk.x, wk.y);          // W_n^(L-k) = -conj(W_n^k)
+                const cx<T> o = p + mul_mi(wm * d);
                 const T sc = hs * wi;
                 X[km] = cx<T>(sc * o.x, sc * o.y);
             }
         }
     } else {
         T* y = a.yr + (size_t)sig * a.yr_stride;
+        // the (re, im) pair of z[j] is the sample pair (2j, 2j+1): one 2-element store when the row is aligned
+        const bool pair_ok = (reinterpret_cast<uintptr_t>(y) % (2 * sizeof(T))) == 0;
         for (int e = threadIdx.x; e < nr * LEN; e += blockDim.x) {
             const int k2 = e / nr, i = e - k2 * nr;
             const int j = (r0 + i) + a.L1 * k2;
@@ -774,8 +784,12 @@ __global__ void __launch_bounds__(512) fft_rows_fast(FftArgs<T> a) {
                 re *= envelope<T>(a.env_log2, t);
                 im *= envelope<T>(a.env_log2, t + 1);
             }
-            if (t < a.t_out) y[t] = re;
-            if (t + 1 < a.t_out) y[t + 1] = im;
+            if (pair_ok && t + 1 < a.t_out) {
+                *reinterpret_cast<cx<T>*>(y + t) = cx<T>(re, im);
+            } else {
+                if (t < a.t_out) y[t] = re;
+                if (t + 1 < a.t_out) y[t + 1] = im;
+            }
         }
     }
 }
@@ -1014,7 +1028,7 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
         // item (slot, k_a) on its own thread of a 256- or 512-thread workgroup
         const int P = inverse ? p.L1 : (p.L1 / 2 + 1);
         int rt = 512 / (per * fs->A);
-        const int lds_rows = (LDS_BUDGET / esz - p.L2) / (per * a.L2P);
+        const int lds_rows = (LDS_BUDGET / esz - p.L2 - 16) / (per * a.L2P);
         if (rt > lds_rows) rt = lds_rows;
         if (rt > 16) rt = 16;
         if (g_fast_rt > 0 && g_fast_rt < rt) rt = g_fast_rt;
@@ -1023,7 +1037,7 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
         const int nthreads = (per * rt * fs->A > 256) ? 512 : 256;
         a.RT = rt;
         a.ntiles = cdiv_i(P, rt);
-        const size_t lds = (size_t)(per * rt * a.L2P + p.L2) * esz;
+        const size_t lds = (size_t)(per * rt * a.L2P + p.L2 + rt) * esz;   // + rt: the W_n^r table of the split step
         const size_t nblk = (size_t)a.ntiles * nsig;
         FL_REQUIRE(nblk < (1ull << 31), "grid too large");
         FL_FAST_DISPATCH(launch_rows_fast, p.L2, inverse, a, (unsigned)nblk, lds, nthreads, st)
