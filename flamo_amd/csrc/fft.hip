@@ -906,6 +906,48 @@ __global__ void __launch_bounds__(256) transpose_narrow_kernel(const E* __restri
     }
 }
 
+// Vectorised tall-and-narrow transpose for 4-byte elements and NS = 4 / 8 / 16 channels (the (T, N) ->
+// (N, T) conversion of every real input): 16-byte loads of the contiguous source, transposed into
+// LDS, 16-byte stores of NS contiguous runs.  No integer divisions (NS is a power of two), eight
+// 16-byte loads in flight per lane.  TR rows per workgroup, TR % 1024 == 0.
+template <int NS>
+__global__ void __launch_bounds__(256) transpose_tall4_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst,
+                                                             int nlong, int TR, long pitch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* tile = reinterpret_cast<uint32_t*>(smem);   // [NS][TR + 4]
+    const int tp = TR + 4;
+    const int l0 = blockIdx.x * TR;
+    const int nl = min(TR, nlong - l0);                    // multiple of 4 (host checks nlong % 4 == 0)
+    const uint4* s = reinterpret_cast<const uint4*>(src + ((size_t)blockIdx.y * nlong + l0) * NS);
+    const int nvec = nl * NS / 4;
+    for (int v0 = 0; v0 < nvec; v0 += 256 * 8) {
+        uint4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int v = v0 + threadIdx.x + 256 * u;
+            if (v < nvec) q[u] = s[v];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int v = v0 + threadIdx.x + 256 * u;
+            if (v < nvec) {
+                const int e = 4 * v, i = e / NS, c = e % NS;
+                tile[(c + 0) * tp + i] = q[u].x;
+                tile[(c + 1) * tp + i] = q[u].y;
+                tile[(c + 2) * tp + i] = q[u].z;
+                tile[(c + 3) * tp + i] = q[u].w;
+            }
+        }
+    }
+    __syncthreads();
+    const int rv = nl / 4;   // 16-byte vectors per output run
+    for (int v = threadIdx.x; v < rv * NS; v += 256) {
+        const int c = v / rv, iv = v - c * rv;
+        const uint4 o = *reinterpret_cast<const uint4*>(tile + c * tp + 4 * iv);
+        *reinterpret_cast<uint4*>(dst + ((size_t)blockIdx.y * NS + c) * pitch + l0 + 4 * iv) = o;
+    }
+}
+
 // ---------------------------------------------------------------- host-side planning
 static int g_max_single = 0;
 static int g_fast_enabled = 1;
@@ -1205,6 +1247,17 @@ int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, lon
     FL_REQUIRE(nbatch <= 65535, "transpose: batch too large");
     hipStream_t st = (hipStream_t)stream;
     const bool tall = cols <= 64 && rows >= 4 * cols, wide = rows <= 64 && cols >= 4 * rows && dst_pitch == rows;
+    if (tall && elem_bytes == 4 && (cols == 4 || cols == 8 || cols == 16) && rows % 4 == 0 && dst_pitch % 4 == 0 &&
+        (reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) % 16 == 0) {
+        const int tr = (cols == 4) ? 2048 : (cols == 8 ? 1024 : 512);   // 32 KB of LDS per workgroup
+        dim3 g2(cdiv_i(rows, tr), nbatch);
+        const size_t lds = (size_t)cols * (tr + 4) * 4;
+        if (cols == 4) hipLaunchKernelGGL((transpose_tall4_kernel<4>), g2, dim3(256), lds, st, (const uint32_t*)src, (uint32_t*)dst, rows, tr, dst_pitch);
+        else if (cols == 8) hipLaunchKernelGGL((transpose_tall4_kernel<8>), g2, dim3(256), lds, st, (const uint32_t*)src, (uint32_t*)dst, rows, tr, dst_pitch);
+        else hipLaunchKernelGGL((transpose_tall4_kernel<16>), g2, dim3(256), lds, st, (const uint32_t*)src, (uint32_t*)dst, rows, tr, dst_pitch);
+        FL_CHECK_LAUNCH("transpose_tall4");
+        return FL_OK;
+    }
     if (tall || wide) {
         const int nshort = tall ? cols : rows, nlong = tall ? rows : cols;
         int TR = (32 * 1024) / ((nshort + 1) * elem_bytes);   // ~32 KB of LDS
