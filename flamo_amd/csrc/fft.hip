@@ -742,12 +742,15 @@ __global__ void __launch_bounds__(512) fft_rows_fast(FftArgs<T> a) {
         cx<T>* X = a.Xout + (size_t)sig * a.xc_stride;
         const T hs = (T)0.5 * a.scale;
         const T wi = a.interior ? (T)2 : (T)1;
+        const bool full = (nr == 16);   // index arithmetic without integer divisions in the common case
         for (int e = threadIdx.x; e < nr * LEN; e += blockDim.x) {
-            const int k2 = e / nr, i = e - k2 * nr;
+            const int k2 = full ? (e >> 4) : e / nr, i = e - k2 * nr;
             const int r = r0 + i;
             const int k = r + a.L1 * k2;
             const int km = (k == 0) ? 0 : a.L - k;
-            const int rowm = km % a.L1, colm = km / a.L1;
+            // km = L - k = rowm + L1*colm:  r > 0: (L1 - r, L2 - 1 - k2);  r == 0: (0, L2 - k2)
+            const int rowm = (r == 0) ? 0 : a.L1 - r;
+            const int colm = (r == 0) ? ((k2 == 0) ? 0 : LEN - k2) : LEN - 1 - k2;
             const int slm = (rowm == r) ? a.per * i : a.per * i + 1;
             const cx<T> zk = res[(a.per * i) * LENP + k2];
             const cx<T> zm = res[slm * LENP + colm];
@@ -774,8 +777,9 @@ __global__ void __launch_bounds__(512) fft_rows_fast(FftArgs<T> a) {
         T* y = a.yr + (size_t)sig * a.yr_stride;
         // the (re, im) pair of z[j] is the sample pair (2j, 2j+1): one 2-element store when the row is aligned
         const bool pair_ok = (reinterpret_cast<uintptr_t>(y) % (2 * sizeof(T))) == 0;
+        const bool full = (nr == 16);
         for (int e = threadIdx.x; e < nr * LEN; e += blockDim.x) {
-            const int k2 = e / nr, i = e - k2 * nr;
+            const int k2 = full ? (e >> 4) : e / nr, i = e - k2 * nr;
             const int j = (r0 + i) + a.L1 * k2;
             const cx<T> z = res[i * LENP + k2];
             const int t = 2 * j;
