@@ -177,17 +177,23 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
     }
 }
 
-// Mixed-precision backward for float32 storage (H, gH are c64).  What needs double stays in double:
-// the section values B_s(k), A_s(k) (they cancel to ~1e-5 of their terms at low frequency).  What
-// does not is done in float: the quotients conj(gH) H / B_s (relative error 1e-7 per bin) and the
-// running sums -- but the sums are kept in the basis {1, d, d^2}, d = 1 - g w, instead of
-// {1, g w, (g w)^2}: at low frequency the three monomial sums are nearly equal and the parameter
-// maps downstream take differences of them (factor 1/theta^2 ~ 1e4..1e5 for a 31 Hz band), which
-// float sums would not survive, while the d-basis sums are the well-scaled quantities those
-// differences are made of.  They are converted back to (b0, b1, b2) gradients in double:
-//   sum Re(t)       = G0,   sum Re(t g w) = G0 - G1,   sum Re(t (g w)^2) = G0 - 2 G1 + G2.
-// H is the forward output (saved), so the cascade product is not re-evaluated: a thread spends
-// ~12 double and ~30 float instructions per section instead of ~80 double ones.
+// Mixed-precision backward for float32 storage (H, gH are c64): float arithmetic arranged so that
+// nothing is lost where the monomial form b0 + b1 w + b2 w^2 cancels, and written on section PAIRS so
+// that it compiles to packed-float instructions.
+//  * Section values B_s(k), A_s(k): float, from coefficients re-expanded (in double) about w = +1 for
+//    the lower half of the bins and about w = -1 for the upper half.  Near DC the monomial terms
+//    cancel to ~theta^2 of their size (1e-5 for a 31 Hz band: float would keep 2 digits); the shifted
+//    form's terms are each of the size of the result times the section's Q.  A value that vanishes or
+//    leaves the float range is flagged and redone in double after the loop.
+//  * Quotients conj(gH) H / B_s: float, relative error ~1e-7 per bin.  H is the saved forward output
+//    (evaluated in double, rounded once), so the cascade product is not re-evaluated.
+//  * Running sums: float, in the basis {1, d, d^2}, d = 1 - g w, instead of {1, g w, (g w)^2}: at low
+//    frequency the three monomial sums are nearly equal and the parameter maps downstream take
+//    differences of them (factor 1/theta^2 ~ 1e4..1e5), which float sums would not survive, while the
+//    d-basis sums are the well-scaled quantities those differences are made of.  They are converted
+//    back to (b0, b1, b2) gradients in double:
+//      sum Re(t) = G0,   sum Re(t g w) = G0 - G1,   sum Re(t (g w)^2) = G0 - 2 G1 + G2.
+// Agreement with the all-double kernel ~1e-6 (tests/test_hip_kernels.py).
 // Rare route of the mixed kernel: a section value that vanishes or leaves the float range (e.g. a
 // band-pass numerator at DC).  All double, product of the other sections as in the kernel above;
 // (inlined: an out-of-line call costs the hot loop more in saved registers than the code size does).
@@ -206,58 +212,98 @@ __device__ inline void sos_bwd_slow_section(const SosEval& e, const double* lb, 
     ta = cx<float>((float)tad.x, (float)tad.y);
 }
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 template <int SCH>
 __global__ void __launch_bounds__(256) sos_response_bwd_mixed_kernel(
     const cx<float>* __restrict__ gH, long g_pitch, const cx<float>* __restrict__ H, long h_pitch,
     const double* __restrict__ b, const double* __restrict__ a, int S, int C, double g,
     const cx<double>* __restrict__ Wd, int nfft, int bin0, int m_local, double* __restrict__ part) {
+    static_assert(SCH % 2 == 0, "sections are processed in pairs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int SP = (S + 1) & ~1;                            // table pitch: even, so a pair is one 8-byte read
     double* lb = reinterpret_cast<double*>(smem);
     double* la = lb + 3 * S;
+    float* cf = reinterpret_cast<float*>(la + 3 * S + (S & 1));   // [basis][b|a][3][SP], 8-byte aligned
     const int c = blockIdx.y;
     stage_taps(b, a, S, C, c, lb, la);
+    // B(w) = b0 + b1 w + b2 w^2 re-expanded about w = +1 (x = 1 - w) and about w = -1 (x = 1 + w):
+    //   B = (b0+b1+b2) - (b1+2 b2) x + b2 x^2      |      B = (b0-b1+b2) + (b1-2 b2) x + b2 x^2
+    // sums formed in double, stored in float (see the kernel comment for why this form is float-safe)
+    for (int i = threadIdx.x; i < 2 * SP; i += blockDim.x) {
+        const int poly = i / SP, sidx = i - poly * SP;
+        const double* t = poly ? la : lb;
+        const bool real = sidx < S;
+        const double t0 = real ? t[sidx] : 1.0, t1 = real ? t[S + sidx] : 0.0, t2 = real ? t[2 * S + sidx] : 0.0;
+        float* lo = cf + (0 * 2 + poly) * 3 * SP;
+        float* hi = cf + (1 * 2 + poly) * 3 * SP;
+        lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
+        hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+    }
+    __syncthreads();
     const int s0 = blockIdx.z * SCH;
-    float acc[6 * SCH];   // [(i*3 + p)*SCH + q]: i = b|a, p = power of d, q = section of the chunk
+    // running sums of section PAIRS (x: section s0+2u, y: section s0+2u+1): every operation below is a
+    // packed-float instruction (v_pk_*), the only kind that issues two lanes' worth per cycle slot --
+    // unpacked FP32 and FP64 FMAs issue at the same rate, so "float instead of double" alone buys nothing
+    f2 acc[6][SCH / 2];
 #pragma unroll
-    for (int v = 0; v < 6 * SCH; ++v) acc[v] = 0.f;
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int u = 0; u < SCH / 2; ++u) acc[p][u] = (f2)(0.f);
     const float eps = eps_of<float>();
 
     for (int f = blockIdx.x * 256 + threadIdx.x; f < m_local; f += gridDim.x * 256) {
         const cx<float> h = H[(size_t)c * h_pitch + f];
         if (h.x == eps && h.y == 0.f) continue;   // guarded bin (prod A == 0): constant, zero gradient
-        const SosEval e = sos_point(Wd, nfft, bin0 + f, g);
-        const cx<float> d((float)(1.0 - e.z1.x), (float)(-e.z1.y));
+        const int k = bin0 + f;
+        const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
+        const cx<double> z1(g * w1.x, g * w1.y);
+        const cx<float> d((float)(1.0 - z1.x), (float)(-z1.y));
         const cx<float> d2 = d * d;
+        const bool low = 4 * (long)k < nfft;      // w nearer to +1 than to -1
+        const float xr = low ? d.x : (float)(1.0 + z1.x), xi = low ? d.y : (float)z1.y;
+        const float* cb = cf + (low ? 0 : 6 * SP);
+        const float* ca = cb + 3 * SP;
         const cx<float> gin = gH[(size_t)c * g_pitch + f];
         const cx<float> gc(gin.x, -gin.y);
         const cx<float> gh = gc * h;              // conj(gH) * H
-        // The common route is branch-free: a section whose value vanishes or leaves the float range is
-        // given zero weight here and flagged; flagged sections (rare: a band-pass numerator at DC) are
-        // redone in double after the loop.  A divergent if/else per section costs an exec-mask
-        // save/restore pair and serialises the LDS reads of neighbouring sections.
         unsigned slow = 0;
 #pragma unroll
-        for (int q = 0; q < SCH; ++q) {
-            const int s = s0 + q;
-            if (s < S) {   // uniform
-                const cx<double> Bs = e.poly(lb, S, s), As = e.poly(la, S, s);
-                const float nb = (float)(Bs.x * Bs.x + Bs.y * Bs.y), na = (float)(As.x * As.x + As.y * As.y);
-                const bool ok = (nb > 1e-30f) & (nb < 1e30f) & (na > 1e-30f) & (na < 1e30f);
-                slow |= ok ? 0u : (1u << q);
-                const float ib = ok ? __builtin_amdgcn_rcpf(nb) : 0.f, ia = ok ? __builtin_amdgcn_rcpf(na) : 0.f;
-                const cx<float> Bf((float)Bs.x, (float)Bs.y), Af((float)As.x, (float)As.y);
-                const cx<float> ub = mulc(gh, Bf), ua = mulc(gh, Af);     // gh * conj(.)
-                const cx<float> tb(ok ? ub.x * ib : 0.f, ok ? ub.y * ib : 0.f);
-                const cx<float> ta(ok ? ua.x * ia : 0.f, ok ? ua.y * ia : 0.f);
-                acc[0 * SCH + q] += tb.x;
-                acc[1 * SCH + q] += tb.x * d.x - tb.y * d.y;
-                acc[2 * SCH + q] += tb.x * d2.x - tb.y * d2.y;
-                acc[3 * SCH + q] -= ta.x;
-                acc[4 * SCH + q] -= ta.x * d.x - ta.y * d.y;
-                acc[5 * SCH + q] -= ta.x * d2.x - ta.y * d2.y;
+        for (int u = 0; u < SCH / 2; ++u) {
+            const int s = s0 + 2 * u;
+            if (s < S) {   // uniform; the odd member of the last pair may be padding (b = a = 1: weight 1/1, masked below)
+                const f2 b0 = *reinterpret_cast<const f2*>(cb + s), b1 = *reinterpret_cast<const f2*>(cb + SP + s),
+                         b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
+                const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
+                         a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
+                const f2 tbr = b1 + b2 * xr, tbi = b2 * xi, tar = a1 + a2 * xr, tai = a2 * xi;
+                const f2 Br = b0 + tbr * xr - tbi * xi, Bi = tbr * xi + tbi * xr;
+                const f2 Ar = a0 + tar * xr - tai * xi, Ai = tar * xi + tai * xr;
+                const f2 nb = Br * Br + Bi * Bi, na = Ar * Ar + Ai * Ai;
+                const bool ok0 = (nb.x > 1e-30f) & (nb.x < 1e30f) & (na.x > 1e-30f) & (na.x < 1e30f);
+                const bool pad1 = s + 1 >= S;
+                const bool ok1 = (nb.y > 1e-30f) & (nb.y < 1e30f) & (na.y > 1e-30f) & (na.y < 1e30f) & !pad1;
+                slow |= (ok0 ? 0u : (1u << (2 * u))) | ((ok1 | pad1) ? 0u : (2u << (2 * u)));
+                f2 ib, ia;
+                ib.x = ok0 ? __builtin_amdgcn_rcpf(nb.x) : 0.f;
+                ib.y = ok1 ? __builtin_amdgcn_rcpf(nb.y) : 0.f;
+                ia.x = ok0 ? __builtin_amdgcn_rcpf(na.x) : 0.f;
+                ia.y = ok1 ? __builtin_amdgcn_rcpf(na.y) : 0.f;
+                // t = gh * conj(value) / |value|^2
+                const f2 tbR = (Br * gh.x + Bi * gh.y) * ib, tbI = (Br * gh.y - Bi * gh.x) * ib;
+                const f2 taR = (Ar * gh.x + Ai * gh.y) * ia, taI = (Ar * gh.y - Ai * gh.x) * ia;
+                acc[0][u] += tbR;
+                acc[1][u] += tbR * d.x - tbI * d.y;
+                acc[2][u] += tbR * d2.x - tbI * d2.y;
+                acc[3][u] -= taR;
+                acc[4][u] -= taR * d.x - taI * d.y;
+                acc[5][u] -= taR * d2.x - taI * d2.y;
             }
         }
-        if (slow) {
+        if (slow) {   // rare: redo the flagged sections in double
+            SosEval e;
+            e.z1 = z1;
+            e.z2 = z1 * z1;
 #pragma unroll
             for (int q = 0; q < SCH; ++q) {
                 if ((slow >> q) & 1u) {
@@ -265,24 +311,34 @@ __global__ void __launch_bounds__(256) sos_response_bwd_mixed_kernel(
                     const cx<double> Bs = e.poly(lb, S, s), As = e.poly(la, S, s);
                     cx<float> tb, ta;
                     sos_bwd_slow_section(e, lb, la, S, s, gc, Bs, As, tb, ta);
-                    acc[0 * SCH + q] += tb.x;
-                    acc[1 * SCH + q] += tb.x * d.x - tb.y * d.y;
-                    acc[2 * SCH + q] += tb.x * d2.x - tb.y * d2.y;
-                    acc[3 * SCH + q] -= ta.x;
-                    acc[4 * SCH + q] -= ta.x * d.x - ta.y * d.y;
-                    acc[5 * SCH + q] -= ta.x * d2.x - ta.y * d2.y;
+                    const float v[6] = {tb.x, tb.x * d.x - tb.y * d.y, tb.x * d2.x - tb.y * d2.y,
+                                        -ta.x, -(ta.x * d.x - ta.y * d.y), -(ta.x * d2.x - ta.y * d2.y)};
+#pragma unroll
+                    for (int p = 0; p < 6; ++p) {
+                        if (q & 1) acc[p][q / 2].y += v[p];
+                        else acc[p][q / 2].x += v[p];
+                    }
                 }
             }
         }
     }
+    // flatten to [(i*3 + p)*SCH + q] for the reduction
+    float flat[6 * SCH];
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int u = 0; u < SCH / 2; ++u) {
+            flat[p * SCH + 2 * u] = acc[p][u].x;
+            flat[p * SCH + 2 * u + 1] = acc[p][u].y;
+        }
     __shared__ float red[4][6 * SCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int off = 0, cnt = 0, dup = 0;
-    wave_reduce_scatter<float, 6 * SCH, 32>(acc, lane, off, cnt, dup);
+    wave_reduce_scatter<float, 6 * SCH, 32>(flat, lane, off, cnt, dup);
     if ((lane & dup) == 0) {
 #pragma unroll
         for (int v = 0; v < 6 * SCH; ++v)
-            if (v < cnt) red[wave][off + v] = acc[v];
+            if (v < cnt) red[wave][off + v] = flat[v];
     }
     __syncthreads();
     if (threadIdx.x < 2 * SCH) {
@@ -485,12 +541,13 @@ static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitc
 #define FL_SOS_MIX(SC)                                                                                              \
     {                                                                                                               \
         dim3 grid(sos_blocks(m_local), C, cdiv_i(S, SC));                                                           \
-        hipLaunchKernelGGL((sos_response_bwd_mixed_kernel<SC>), grid, dim3(256), (size_t)6 * S * sizeof(double),   \
+        hipLaunchKernelGGL((sos_response_bwd_mixed_kernel<SC>), grid, dim3(256),                                 \
+                           (size_t)(6 * S + 2) * sizeof(double) + (size_t)12 * ((S + 1) & ~1) * sizeof(float),  \
                            (hipStream_t)stream, (const cx<float>*)gH, g_pitch, (const cx<float>*)H, h_pitch,       \
                            (const double*)b, (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0,     \
                            m_local, (double*)part);                                                                 \
     }
-            const int want = g_sos_chunk > 0 ? g_sos_chunk : 8;
+            const int want = g_sos_chunk > 0 ? g_sos_chunk : 12;
             if (S <= 4 || want <= 4) FL_SOS_MIX(4)
             else if (S <= 6 || want <= 6) FL_SOS_MIX(6)
             else if (S <= 8 || want <= 8) FL_SOS_MIX(8)
