@@ -536,6 +536,21 @@ class Shell(nn.Module):
                            device=self.__device(), dtype=self.dtype)
         return x.diag_embed() if (identity and self.input_channels > 1) else x
 
+    def __probe_spectrum(self, identity):
+        """Spectrum of the probe: rfft of the unit impulse is exactly 1 at every bin, so the probe is
+        written in the frequency domain directly -- ones (1, M, N_in), or with ``identity`` the identity
+        matrix per bin (1, M, N_in, N_in) -- instead of transforming nfft x N_in (x N_in) zeros and ones."""
+        N, M = self.input_channels, self.nfft // 2 + 1
+        dev = self.__device()
+        cd = torch.complex128 if self.dtype == torch.float64 else torch.complex64
+        if identity and N > 1:
+            X = ops._empty_planar((1, M, N, N), cd, dev)
+            X.copy_(torch.eye(N, dtype=cd, device=dev).view(1, 1, N, N).expand(1, M, N, N))
+            return X
+        X = ops._empty_planar((1, M, N), cd, dev)
+        X.fill_(1.0)
+        return X
+
     def __with_layers(self, input_layer, output_layer, x):
         saved = (self.get_inputLayer(), self.get_outputLayer())
         self.set_inputLayer(input_layer)
@@ -553,15 +568,30 @@ class Shell(nn.Module):
     def get_time_response(self, fs: int = 48000, identity: bool = False) -> torch.Tensor:
         """Impulse response irfft(core(rfft(delta))) * gamma^-t (system.py:1012-1079); with
         ``identity`` the input is diag_embed'ed so the full N_out x N_in response matrix comes out.
-        The envelope is fused into the inverse-FFT epilogue."""
+        The probe's spectrum is written directly (no input transform) and the envelope is fused into
+        the inverse-FFT epilogue."""
         db = self.__anti_alias_db()
         out = Transform(lambda X: ops.irfft(X, self.nfft, "backward", db if db else None))
-        return self.__with_layers(FFT(self.nfft, dtype=self.dtype), out, self.__probe_signal(fs, identity))
+        if not self.__device().type == "cuda":
+            return self.__with_layers(FFT(self.nfft, dtype=self.dtype), out, self.__probe_signal(fs, identity))
+        return self.__with_layers(nn.Identity(), out, self.__probe_spectrum(identity))
 
     def get_freq_response(self, fs: int = 48000, identity: bool = False) -> torch.Tensor:
-        """rfft(irfft(core(rfft(delta))) * gamma^-t) (system.py:1081-1153): the time-domain
-        round trip is what moves the response from the circle |z| = 1/gamma back to the unit
-        circle; both transforms and the envelope run as two fused HIP FFT calls."""
+        """rfft(irfft(core(rfft(delta))) * gamma^-t) (system.py:1081-1153).  The time-domain round trip
+        is what moves the response from the circle |z| = 1/gamma back to the unit circle; without
+        anti-aliasing (gamma = 1) it is the identity up to the C2R convention (imaginary parts of the
+        DC and Nyquist bins dropped), so neither transform is run; with it, both transforms and the
+        envelope run as two fused HIP FFT calls.  The probe's spectrum is written directly."""
         db = self.__anti_alias_db()
-        out = Transform(lambda X: ops.rfft(ops.irfft(X, self.nfft, "backward", db if db else None), self.nfft))
-        return self.__with_layers(FFT(self.nfft, dtype=self.dtype), out, self.__probe_signal(fs, identity))
+        if db:
+            out = Transform(lambda X: ops.rfft(ops.irfft(X, self.nfft, "backward", db), self.nfft))
+        else:
+            def out_fn(X):
+                Y = X.clone(memory_format=torch.preserve_format)
+                for k in (0, Y.shape[1] - 1):
+                    torch.view_as_real(Y[:, k])[..., 1].zero_()
+                return Y
+            out = Transform(out_fn)
+        if not self.__device().type == "cuda":
+            return self.__with_layers(FFT(self.nfft, dtype=self.dtype), out, self.__probe_signal(fs, identity))
+        return self.__with_layers(nn.Identity(), out, self.__probe_spectrum(identity))
