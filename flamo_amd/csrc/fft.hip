@@ -21,7 +21,7 @@
 
 namespace fl {
 
-enum { LOAD_PACK = 0, LOAD_IRFFT_PRE = 1, LOAD_SCRATCH = 2 };
+enum { LOAD_PACK = 0, LOAD_IRFFT_PRE = 1, LOAD_SCRATCH = 2, LOAD_PACK_FAST = 3 };
 enum { EPI_RFFT_POST = 0, EPI_IRFFT_STORE = 1 };
 
 struct Rad {
@@ -36,6 +36,7 @@ struct FftArgs {
     int t_in;
     int ci_n;           // > 0: x is (B, ci_T, ci_n) contiguous, signal sig = b*ci_n + n, sample t at ((b*ci_T + t)*ci_n + n)
     int ci_T;
+    int pack_fast;      // LOAD_PACK: t_in >= n, rows 2-element aligned: unguarded pair loads
     const cx<T>* Xc;    // LOAD_IRFFT_PRE source (half spectrum, L+1 bins per signal)
     cx<T>* Xout;        // EPI_RFFT_POST destination
     T* yr;              // EPI_IRFFT_STORE destination
@@ -218,6 +219,19 @@ __device__ inline cx<T> load_pack(const FftArgs<T>& a, int sig, int j) {
     return cx<T>(re, im);
 }
 
+// whole-length, aligned, signal-planar rows (the usual case, selected on the host): the sample pair is
+// one unguarded 2-element load -- no per-element layout / length branches in the unrolled loaders
+template <typename T>
+__device__ inline cx<T> load_pack_fast(const FftArgs<T>& a, int sig, int j) {
+    const int t = 2 * j;
+    cx<T> v = *reinterpret_cast<const cx<T>*>(a.xr + (size_t)sig * a.xr_stride + t);
+    if (a.env_log2 != 0.0) {
+        v.x *= envelope<T>(a.env_log2, t);
+        v.y *= envelope<T>(a.env_log2, t + 1);
+    }
+    return v;
+}
+
 // Hermitian pre-step of the inverse real FFT:
 //   Zf[j] = (X[j] + conj X[L-j]) + i conj(W_n^j) (X[j] - conj X[L-j])
 template <typename T>
@@ -240,6 +254,7 @@ __device__ inline cx<T> load_irfft_pre(const FftArgs<T>& a, int sig, int j) {
 template <typename T, int LOAD>
 __device__ inline cx<T> load_any(const FftArgs<T>& a, int sig, int j) {
     if (LOAD == LOAD_PACK) return load_pack<T>(a, sig, j);
+    if (LOAD == LOAD_PACK_FAST) return load_pack_fast<T>(a, sig, j);
     if (LOAD == LOAD_IRFFT_PRE) return load_irfft_pre<T>(a, sig, j);
     return a.scratch[(size_t)sig * a.L + j];
 }
@@ -698,9 +713,13 @@ __global__ void __launch_bounds__(512) fft_rows_fast(FftArgs<T> a) {
             row = r0 + sl;
         }
         cx<T> v[A];
+        if (valid) {   // one guarded region around all A loads (a per-element select guards each load separately)
 #pragma unroll
-        for (int ta = 0; ta < A; ++ta)
-            v[ta] = valid ? load_any<T, LOAD>(a, sig, row * LEN + ta * B + tb) : cx<T>(0, 0);
+            for (int ta = 0; ta < A; ++ta) v[ta] = load_any<T, LOAD>(a, sig, row * LEN + ta * B + tb);
+        } else {
+#pragma unroll
+            for (int ta = 0; ta < A; ++ta) v[ta] = cx<T>(0, 0);
+        }
         RegFFT<T, A, INV>::run(v);
         cx<T>* u = U + sl * LENP + tb;
         u[0] = v[0];
@@ -818,6 +837,8 @@ static void launch_cols_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, s
     } else {
         if (inverse)
             hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_IRFFT_PRE, true, 16>), dim3(nblk), dim3(256), lds, st, a);
+        else if (a.pack_fast)
+            hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_PACK_FAST, false, 16>), dim3(nblk), dim3(256), lds, st, a);
         else
             hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_PACK, false, 16>), dim3(nblk), dim3(256), lds, st, a);
     }
@@ -1135,6 +1156,7 @@ static int rfft_impl(const void* x, long x_sig_stride, int ci_n, int t_in, void*
         a.ci_n = ci_n;
         a.ci_T = t_in;
     }
+    a.pack_fast = ci_n <= 0 && t_in >= nfft && x_sig_stride % 2 == 0 && reinterpret_cast<uintptr_t>(x) % (2 * sizeof(T)) == 0;
     a.Xout = (cx<T>*)X;
     FL_REQUIRE(X_sig_stride >= nfft / 2 + 1, "rfft: X_sig_stride must be >= nfft/2+1");
     a.xc_stride = X_sig_stride;
