@@ -193,7 +193,7 @@ def main():
         from flamo_amd.processor import system as _system
         roof_steps = min(args.steps, 10)
         overlap, _system.OVERLAP_RESPONSES = _system.OVERLAP_RESPONSES, False
-        ops.kernel_timer.reset(enabled=True, prefill_cycles=500_000)     # ~0.2 ms of queued spin before each timed launch
+        ops.kernel_timer.reset(enabled=True, prefill_cycles=500_000)     # ~0.2 ms of queued streaming copies before each timed launch
         for _ in range(roof_steps):
             eager_step()
         torch.cuda.synchronize()
@@ -222,7 +222,7 @@ def main():
                     "traffic": PMC_TRAFFIC_BYTES, "algorithmic_bytes": alg_bytes, "launch_ms": mean_ms, "launches": n,
                     "events": "HIP events on the launch stream, " + ("inside the timed eager steps" if args.no_graph else
                               f"{roof_steps} single-stream eager steps run by this command right after the timed graph replays, "
-                              "each timed launch queued behind a 0.2 ms spin kernel so that it starts from a busy queue"),
+                              "each timed launch queued behind ~0.2 ms of streaming copies so that it starts from a busy queue and memory system"),
                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per "
                                       "MI355X_MICROARCH.md; profiles/r01i_pmc_hbm_traffic.csv"}
         out = {"metric": "freq-bin*channel products/sec (fwd+bwd), nfft=96000 8x8ch", "value": products_per_step / (ms * 1e-3),
