@@ -136,9 +136,9 @@ def main():
 
     step = eager_step
     if not args.no_graph:
-        # The step is ~45 launches of which a dozen carry the work: replaying it from a HIP graph
-        # takes the Python / launch overhead (about as long as the GPU work itself, and sensitive
-        # to host jitter) out of the loop.  Forward + backward are captured once; the tiny RCCL
+        # The step is ~30 launches of which a dozen carry the work: replaying it from a HIP graph takes
+        # the Python / launch overhead (0.1-0.2 ms per step once warm, and sensitive to host jitter) out
+        # of the loop.  Forward + backward are captured once; the tiny RCCL
         # gradient all-reduce stays eager after each replay.
         from flamo_amd.graph import GraphedStep
         try:
@@ -169,10 +169,14 @@ def main():
         torch.cuda.synchronize()
 
     if args.no_graph:
-        # eager steps are host-bound: the side-stream overlap buys nothing there, and an event recorded
-        # behind a cross-stream wait would be stamped early (see the roofline leg below)
+        # the timed eager steps carry HIP events around single launches: an event recorded behind a
+        # cross-stream wait would be stamped early (see the roofline leg below), so one stream only
         from flamo_amd.processor import system as _sys
         _sys.OVERLAP_RESPONSES = False
+        # one-off start-up costs of the eager path (allocator growth, a ~35 ms hiccup around the 8th step on
+        # a fresh process) belong to set-up like the graph capture does, not to the W warm-up steps
+        for _ in range(12):
+            step()
     for _ in range(args.warmup):
         step()
     fence()
