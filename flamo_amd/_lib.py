@@ -74,6 +74,8 @@ _SIGNATURES = {
     "fl_matrix_exp_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "fl_matrix_exp_bwd_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "fl_matrix_exp_bwd_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "fl_eig_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
+    "fl_eig_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

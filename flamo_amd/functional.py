@@ -16,6 +16,24 @@ import torch.nn as nn
 # ----------------------------------------------------------------------------- small maps
 
 
+def get_magnitude(x: torch.Tensor) -> torch.Tensor:
+    """|x| (flamo/functional.py:8-21)."""
+    return torch.abs(x)
+
+
+def get_eigenvalues(x: torch.Tensor) -> torch.Tensor:
+    """Eigenvalues over the last two (equal) dimensions (flamo/functional.py:24-39).  On the GPU: one
+    wavefront per matrix (ops.eigvals, N <= 64); the order of the eigenvalues of a matrix is the order
+    on the diagonal of its Schur form, which is not torch.linalg.eigvals' order."""
+    assert x.shape[-1] == x.shape[-2]
+    if x.shape[-1] == 1:
+        return x
+    if x.is_cuda and x.is_complex() and x.shape[-1] <= 64:
+        from . import ops
+        return ops.eigvals(x)
+    return torch.linalg.eigvals(x)
+
+
 def skew_matrix(X: torch.Tensor) -> torch.Tensor:
     """Skew-symmetric matrix from the strictly upper triangle of X (flamo/functional.py:42-56)."""
     up = torch.triu(X, diagonal=1)

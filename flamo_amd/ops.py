@@ -975,3 +975,59 @@ def matrix_exp(X: torch.Tensor, skew: bool = False) -> torch.Tensor:
     (N <= 64) in one launch each way: float64 arithmetic, fixed scaling-and-squaring schedule, no
     host synchronisation (capturable)."""
     return _MatrixExp.apply(X, bool(skew))
+
+
+# ----------------------------------------------------------------------------- per-bin eigenvalues
+_eig_state = {"info": None}
+
+
+def eigvals_info() -> Optional[torch.Tensor]:
+    """int32 (bins,) convergence flags of the most recent ops.eigvals call (0 = converged; k > 0: the QR
+    iteration gave up with k eigenvalues of that matrix unconverged).  A device tensor: reading it
+    synchronises, which is why eigvals itself does not."""
+    return _eig_state["info"]
+
+
+class _Eigvals(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A):
+        dev = _require_gpu(A)
+        if not A.is_complex():
+            raise TypeError("eigvals expects a complex tensor")
+        if A.dim() < 2 or A.shape[-1] != A.shape[-2]:
+            raise ValueError("eigvals expects (..., N, N)")
+        N = A.shape[-1]
+        lead = tuple(A.shape[:-2])
+        Mt = max(_prod(lead), 1) if lead else 1
+        Ap = _h_planar(A.resolve_conj().reshape(Mt, N, N), True)          # (Mt, N, N) with the bin axis contiguous
+        a_pitch = _lead_pitch(Ap.movedim(0, -1))
+        need_v = ctx.needs_input_grad[0]
+        lam = _empty_rows((N,), Mt, A.dtype, dev)
+        Vv = _empty_rows((N, N), Mt, A.dtype, dev) if need_v else None
+        info = torch.empty(Mt, dtype=torch.int32, device=dev)
+        L = _lib.lib()
+        fn = L.fl_eig_c64 if A.dtype == torch.complex64 else L.fl_eig_c128
+        _lib.check(fn(Ap.data_ptr(), a_pitch, N, Mt, lam.data_ptr(), _pitch(Mt), None if Vv is None else Vv.data_ptr(),
+                      _pitch(Mt), info.data_ptr(), _stream()), "eig")
+        _eig_state["info"] = info
+        if need_v:
+            ctx.save_for_backward(Vv)
+        ctx.meta = (lead, N, Mt)
+        return lam.movedim(-1, 0).reshape(*lead, N)
+
+    @staticmethod
+    def backward(ctx, g):
+        (Vv,) = ctx.saved_tensors                                          # planar (N, N, Mt): V[i, j, f]
+        lead, N, Mt = ctx.meta
+        V = Vv.movedim(-1, 0)                                              # (Mt, N, N), bin-planar view
+        # g_A = V^-H diag(g) V^H  (eigenvector gradients are zero): solve V^H X = diag(g) V^H per bin
+        R = g.resolve_conj().reshape(Mt, N, 1) * V.mH                      # (Mt, N, N)
+        X = _solve_launch(V, False, True, to_planar(R.unsqueeze(0)))[0]      # (V^H)^-1 R, LU per bin
+        return X.reshape(*lead, N, N)
+
+
+def eigvals(A: torch.Tensor) -> torch.Tensor:
+    """Eigenvalues of the (..., N, N) complex matrices, N <= 64, one wavefront per matrix (Hessenberg + shifted
+    QR in LDS).  Order: position on the diagonal of the Schur form, not LAPACK's -- use order-independent
+    functions of the result.  Differentiable (g_A = V^-H diag(g) V^H) for simple eigenvalues."""
+    return _Eigvals.apply(A)

@@ -274,6 +274,23 @@ int fl_matrix_exp_f64(const void* X, int N, int skew, void* E, void* stash, void
 int fl_matrix_exp_bwd_f32(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);
 int fl_matrix_exp_bwd_f64(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-bin eigenvalues of small general complex matrices: torch.linalg.eigvals in
+ * flamo.functional.get_eigenvalues (flamo/functional.py:24-39), applied by the active-acoustics loss to
+ * the (B, F, N, N) loop matrices the path produces (examples/e8_active_acoustics.py:586-603).
+ *   A: planar (N, N, a_pitch), element (i, j, f) at (i*N + j)*a_pitch + f, f < M;  N <= 64
+ *   lam: (N, l_pitch) eigenvalues of every bin (order: position on the diagonal of the Schur form --
+ *        NOT LAPACK's order; compare as sets)
+ *   V:   NULL, or planar (N, N, v_pitch) right eigenvectors as columns, unit 2-norm (needed by the
+ *        backward: g_A = V^-H diag(g_lambda) V^H, one fl_solve per bin)
+ *   info: NULL, or int[M]: 0, or k > 0 if the QR iteration gave up with k eigenvalues unconverged.
+ * One wavefront per matrix (Householder Hessenberg reduction, explicitly shifted QR with Wilkinson
+ * shifts to Schur form, back substitution for the vectors), matrices in LDS. */
+int fl_eig_c64(const void* A, long a_pitch, int N, int M, void* lam, long l_pitch, void* V, long v_pitch, void* info,
+               void* stream);
+int fl_eig_c128(const void* A, long a_pitch, int N, int M, void* lam, long l_pitch, void* V, long v_pitch, void* info,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

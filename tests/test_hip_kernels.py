@@ -345,3 +345,62 @@ def test_response_overlap_is_transparent(gpu):
     assert torch.equal(out, res[True][0])
     for p, gb in zip(params, res[True][1]):
         assert torch.equal(p.grad, gb)
+
+
+@pytest.mark.parametrize("N", [2, 3, 5, 8, 16, 32])
+def test_eigvals_kernel_matches_lapack(gpu, N):
+    """ops.eigvals (Hessenberg + shifted QR, one wavefront per matrix) against torch.linalg.eigvals on the
+    CPU in float64: spectra as sets (matched greedily), an order-independent loss and its gradient."""
+    from flamo_amd import ops
+    torch.manual_seed(100 + N)
+    for cd, tol in ((torch.complex128, 1e-9), (torch.complex64, 2e-4)):
+        A0 = torch.randn(37, N, N, dtype=torch.complex128) / N ** 0.5
+        A0[3] = torch.diag_embed(torch.randn(N, dtype=torch.complex128))               # already triangular
+        A0[5] = torch.triu(A0[5])                                                       # upper triangular
+        A0[7] = A0[7] + A0[7].mH                                                        # Hermitian
+        Ar = A0.clone().requires_grad_(True)
+        lr = torch.linalg.eigvals(Ar)
+        loss_r = ((lr.abs() - 0.7) ** 2).sum() + (lr.real ** 3).sum() * 0.1
+        (gr,) = torch.autograd.grad(loss_r, [Ar])
+        A = A0.to(gpu, cd).requires_grad_(True)
+        l = ops.eigvals(A)
+        assert l.shape == (37, N)
+        loss = ((l.abs() - 0.7) ** 2).sum() + (l.real ** 3).sum() * 0.1
+        (g,) = torch.autograd.grad(loss, [A])
+        # match every computed eigenvalue to the nearest reference one
+        lc, lrc = l.detach().cpu().to(torch.complex128), lr.detach()
+        d = (lc.unsqueeze(-1) - lrc.unsqueeze(-2)).abs()
+        assert d.min(dim=-1).values.max() < tol * 10 and d.min(dim=-2).values.max() < tol * 10
+        assert abs(loss.item() - loss_r.item()) < tol * 10 * abs(loss_r.item())
+        good = torch.ones(37, dtype=torch.bool)
+        good[3] = good[5] = False          # gradients of exactly triangular inputs are fine too, but skip the degenerate ones
+        assert relerr(g.cpu()[good], gr[good]) < (1e-7 if cd == torch.complex128 else 2e-3)
+        assert int(ops.eigvals_info().abs().max()) == 0
+    # batched leading dims and the functional wrapper
+    from flamo_amd import functional as F
+    B4 = torch.randn(2, 5, 4, 4, dtype=torch.complex64, device=gpu)
+    l4 = F.get_eigenvalues(B4)
+    assert l4.shape == (2, 5, 4)
+    tr = torch.diagonal(B4, dim1=-2, dim2=-1).sum(-1)
+    assert relerr(l4.sum(-1).cpu(), tr.cpu()) < 1e-5
+
+
+def test_eigvals_large_and_degenerate(gpu):
+    """N = 48 and 64 (LDS above the default 64 KB), the identity, a Jordan block and a nilpotent matrix."""
+    from flamo_amd import ops
+    torch.manual_seed(9)
+    for N, cd, tol in ((48, torch.complex64, 5e-4), (64, torch.complex64, 1e-3), (40, torch.complex128, 1e-9)):
+        A0 = torch.randn(5, N, N, dtype=torch.complex128) / N ** 0.5
+        lr = torch.linalg.eigvals(A0)
+        with torch.no_grad():
+            l = ops.eigvals(A0.to(gpu, cd)).cpu().to(torch.complex128)
+        d = (l.unsqueeze(-1) - lr.unsqueeze(-2)).abs()
+        assert d.min(dim=-1).values.max() < tol and d.min(dim=-2).values.max() < tol
+        assert int(ops.eigvals_info().abs().max()) == 0
+    N = 6
+    eye = torch.eye(N, dtype=torch.complex128)
+    jordan = 0.5 * eye + torch.diag(torch.ones(N - 1, dtype=torch.complex128), 1)
+    nil = torch.diag(torch.ones(N - 1, dtype=torch.complex128), 1)
+    with torch.no_grad():
+        l = ops.eigvals(torch.stack([eye, jordan, nil]).to(gpu)).cpu()
+    assert (l[0] - 1).abs().max() < 1e-12 and (l[1] - 0.5).abs().max() < 1e-6 and l[2].abs().max() < 1e-6
