@@ -429,8 +429,17 @@ class Parallel(nn.Module):
         return a_in, a_out + b_out
 
     def forward(self, X, ext_param: dict = None):
-        ya = self.branchA(X) if ext_param is None else self.branchA(X, ext_param)
-        yb = self.branchB(X) if ext_param is None else self.branchB(X, ext_param)
+        # external parameters are routed by key: the entry whose key contains "branchA" / "branchB"
+        # goes to that branch (system.py:640-652)
+        ext_a = ext_b = None
+        if ext_param is not None:
+            for key, param in ext_param.items():
+                if "branchA" in key:
+                    ext_a = param
+                elif "branchB" in key:
+                    ext_b = param
+        ya = self.branchA(X) if ext_a is None else self.branchA(X, ext_a)
+        yb = self.branchB(X) if ext_b is None else self.branchB(X, ext_b)
         return ya + yb if self.sum_output else torch.cat((ya, yb), dim=2)
 
 

@@ -513,3 +513,30 @@ def test_config5_full_size_runs_and_is_linear(gpu):
         m64 = _config5_model(dsp, system, N, nfft, db, a, gpu, torch.float64)
         y64 = m64(x1.to(gpu))
     assert relerr(y1.double(), y64) < 1e-5
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("name", golden_names("parallel_"))
+def test_parallel_golden(gpu, dt, name):
+    """system.Parallel (two branches summed / concatenated) against the reference's outputs and gradients."""
+    from flamo_amd.processor import dsp, system
+    meta, a = load_golden(name)
+    rd = torch.float64 if dt == "f64" else torch.float32
+    cd = torch.complex128 if dt == "f64" else torch.complex64
+    tol = 1e-10 if dt == "f64" else 1e-5
+    kw = dict(nfft=meta["nfft"], alias_decay_db=meta["alias_decay_db"], device=gpu, dtype=rd, requires_grad=True)
+    g = dsp.Gain(size=(3, 2), **kw)
+    pg = dsp.parallelGain(size=(3,), **kw)
+    fir = dsp.Filter(size=(5, 3, 2), **kw)
+    g.assign_value(a["g"].to(gpu, rd))
+    pg.assign_value(a["pg"].to(gpu, rd))
+    fir.assign_value(a["fir"].to(gpu, rd))
+    par = system.Parallel(brA=OrderedDict(g=g, pg=pg), brB=fir, sum_output=meta["sum_output"])
+    assert (par.input_channels, par.output_channels) == (meta["input_channels"], meta["output_channels"])
+    X = a["X"].to(gpu, cd).requires_grad_(True)
+    Y = par(X)
+    assert relerr(Y.detach().cpu(), a["Y"]) < tol
+    L = torch.sum(torch.real(Y * torch.conj(a["C"].to(gpu, cd))))
+    gX, gg, gpg, gfir = torch.autograd.grad(L, [X, g.param, pg.param, fir.param])
+    for got, key in ((gX, "gX"), (gg, "gg"), (gpg, "gpg"), (gfir, "gfir")):
+        assert relerr(got.cpu(), a[key]) < tol * 10, key

@@ -303,6 +303,29 @@ def gen_fdn(dsp, system):
              ir_vec=model.get_time_response(identity=False))
 
 
+# ----------------------------------------------------------------------------- Parallel
+def gen_parallel(dsp, system):
+    """system.Parallel (system.py:570-772): two branches on one input, summed and concatenated."""
+    nfft, B = 128, 2
+    M = nfft // 2 + 1
+    for db in (0.0, 30.0):
+        for sum_output in (True, False):
+            torch.manual_seed(4000 + int(db) + int(sum_output))
+            kw = dict(nfft=nfft, alias_decay_db=db, dtype=F64, requires_grad=True)
+            g = dsp.Gain(size=(3, 2), **kw)
+            pg = dsp.parallelGain(size=(3,), **kw)
+            fir = dsp.Filter(size=(5, 3, 2), **kw)
+            par = system.Parallel(brA=OrderedDict(g=g, pg=pg), brB=fir, sum_output=sum_output)
+            X = crandn(B, M, 2).requires_grad_(True)
+            Y = par(X)
+            C = crandn(*Y.shape)
+            gr = vjp_complex(Y, C, [X, g.param, pg.param, fir.param])
+            save(f"parallel_{'sum' if sum_output else 'cat'}_db{int(db)}",
+                 dict(kind="parallel", nfft=nfft, alias_decay_db=db, sum_output=sum_output,
+                      input_channels=par.input_channels, output_channels=par.output_channels),
+                 X=X, Y=Y, C=C, g=g.param, pg=pg.param, fir=fir.param, gX=gr[0], gg=gr[1], gpg=gr[2], gfir=gr[3])
+
+
 def main():
     torch.set_default_dtype(torch.float32)
     dsp, system = refimport.load()
@@ -312,11 +335,15 @@ def main():
     if "--more-only" in sys.argv:
         gen_modules_more(dsp)
         return
+    if "--parallel-only" in sys.argv:
+        gen_parallel(dsp, system)
+        return
     gen_transforms(dsp)
     gen_modules(dsp)
     gen_modules_more(dsp)
     gen_config2(dsp, system)
     gen_fdn(dsp, system)
+    gen_parallel(dsp, system)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print(f"total {total/1024:.1f} KiB")
 
