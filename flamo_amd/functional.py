@@ -274,3 +274,111 @@ def geq(center_freq, shelving_freq, R, gain_db, fs: int = 48000, device="cpu", d
     """Second-order sections of the graphic equaliser for ONE channel: (b, a), each (3, n_bands)
     (flamo/auxiliary/eq.py:57-111)."""
     return GEQDesign(center_freq, shelving_freq, fs, float(R)).sections(gain_db)
+
+
+# ----------------------------------------------------------------------------- accurate GEQ design
+def _interp_clamped(xp: torch.Tensor, fp: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Piecewise-linear interpolation of (xp, fp) at x, held constant outside [xp[0], xp[-1]] -- what
+    flamo.utils.RegularGridInterpolator does in one dimension (flamo/utils.py:51-140), weights written
+    the same way: (f_left * d_right + f_right * d_left) / (d_left + d_right)."""
+    n = xp.shape[0]
+    right = torch.bucketize(x, xp).clamp(max=n - 1)
+    left = (right - 1).clamp(0, n - 1)
+    dl = (x - xp[left]).clamp(min=0)
+    dr = (xp[right] - x).clamp(min=0)
+    both = (dl == 0) & (dr == 0)
+    dl = torch.where(both, torch.ones_like(dl), dl)
+    dr = torch.where(both, torch.ones_like(dr), dr)
+    return (fp[left] * dr + fp[right] * dl) / (dl + dr)
+
+
+def _sos_magnitude_db(b: torch.Tensor, a: torch.Tensor, freqs: torch.Tensor, nfft: int, fs: int) -> torch.Tensor:
+    """dB magnitude of every section (columns of b, a: (3, n)) at the control frequencies: the section is
+    normalised by its a0, sampled on an nfft-point grid and interpolated linearly in dB
+    (flamo/functional.py:933-979, probe_sos)."""
+    f = torch.fft.rfftfreq(nfft, 1 / fs)
+    out = torch.zeros((freqs.shape[0], b.shape[1]), dtype=b.dtype)
+    for k in range(b.shape[1]):
+        a0 = a[0, k].clone()
+        B = torch.fft.rfft(b[:, k] / a0, nfft, dim=0)
+        A = torch.fft.rfft(a[:, k] / a0, nfft, dim=0)
+        h = B / (A + torch.tensor(1e-10))
+        out[:, k] = _interp_clamped(f, 20 * torch.log10(torch.abs(h)), freqs)
+    return out
+
+
+def _bounded_least_squares_lbfgs(G: torch.Tensor, target: torch.Tensor, lower: torch.Tensor, upper: torch.Tensor,
+                                 steps: int = 100) -> torch.Tensor:
+    """argmin mean((G x - target)^2) from x = 1 with torch's L-BFGS (default settings), the iterate
+    clamped to [lower, upper] inside the closure: 100 optimiser steps (flamo/auxiliary/minimize.py:34-78)."""
+    x = nn.Parameter(torch.ones(G.shape[1]))
+    opt = torch.optim.LBFGS([x])
+
+    def closure():
+        opt.zero_grad()
+        loss = torch.mean(torch.pow(torch.matmul(G, x) - target, 2))
+        loss.backward()
+        x.data.clamp_(lower, upper)
+        return loss
+
+    for _ in range(steps):
+        opt.step(closure)
+    return x
+
+
+def _geq_sections_plain(center_freq, shelving_freq, R, gain_db, fs: int, dtype):
+    """Graphic-equaliser sections evaluated band by band with tensor arithmetic in ``dtype``, the way
+    flamo.auxiliary.eq.geq does when it is called directly (eq.py:57-111 with functional.py:555-675) --
+    GEQDesign above restates the *module's* mixed-precision route instead.  (b, a), each (3, n_bands)."""
+    nb = len(center_freq) + len(shelving_freq) + 1
+    assert len(gain_db) == nb, "The number of gains must be equal to the number of frequencies."
+    b = torch.zeros((3, nb), dtype=dtype)
+    a = torch.zeros((3, nb), dtype=dtype)
+    two = torch.tensor(2, dtype=dtype)
+    for k in range(nb):
+        g = db2mag(gain_db[k].reshape(-1)[0].to(dtype))
+        if k == 0:
+            bb = torch.stack([g, torch.zeros((), dtype=dtype), torch.zeros((), dtype=dtype)])
+            aa = torch.tensor([1, 0, 0], dtype=dtype)
+        elif k == 1 or k == nb - 1:
+            t = torch.tan(hertz2rad(shelving_freq[0 if k == 1 else 1], fs) / 2)
+            t2, g2, g4 = t ** 2, g ** 0.5, g ** 0.25
+            num = torch.stack([g2 * t2 + torch.sqrt(two) * t * g4 + 1, 2 * g2 * t2 - 2, g2 * t2 - torch.sqrt(two) * t * g4 + 1])
+            den = torch.stack([g2 + torch.sqrt(two) * t * g4 + t2, 2 * t2 - 2 * g2, g2 - torch.sqrt(two) * t * g4 + t2])
+            num = g2 * num
+            bb, aa = (num, den) if k == 1 else (den * g, num)
+        else:
+            w = hertz2rad(center_freq[k - 2], fs)
+            t = torch.tan(w / (torch.sqrt(R) / (R - 1)) / 2)
+            sg = torch.sqrt(g)
+            bb = torch.stack([sg + g * t, -2 * sg * torch.cos(w), sg - g * t])
+            aa = torch.stack([sg + t, -2 * sg * torch.cos(w), sg - t])
+        b[:, k], a[:, k] = bb, aa
+    return b, a
+
+
+def accurate_geq(target_gain: torch.Tensor, center_freq: torch.Tensor, shelving_crossover: torch.Tensor, fs: int = 48000,
+                 device="cpu", dtype=torch.float32):
+    """Graphic-equaliser sections whose cascade interpolates the target gains (dB, one per band centre
+    plus the two band edges): the command gains are fitted by bounded least squares on the dB interaction
+    matrix of 10 dB prototype sections at 101 log-spaced control frequencies (Schlecht & Habets 2017;
+    flamo/auxiliary/eq.py:114-182).  A host-side design on a dozen numbers: runs on the CPU in the
+    reference's float32.  Returns (b, a), each (3, n_bands + 3)."""
+    target_gain = target_gain.detach().to("cpu")
+    center_freq = center_freq.detach().to("cpu", dtype)
+    shelving_crossover = shelving_crossover.detach().to("cpu", dtype)
+    assert len(target_gain) == len(center_freq) + 2, \
+        "The number of target gains must be equal to the number of center frequencies + 2."
+    nfft = 2 ** 16
+    n_sec = len(center_freq) + len(shelving_crossover)
+    R = torch.tensor(2.7, dtype=dtype)
+    ctrl = torch.round(torch.logspace(np.log10(1), np.log10(fs / 2.1), 101, dtype=dtype))
+    knots = torch.cat((torch.tensor([1], dtype=dtype), center_freq, torch.tensor([fs / 2.1], dtype=dtype)))
+    wanted = _interp_clamped(knots, target_gain, ctrl)
+    proto = 10.0                                                   # dB
+    pb, pa = _geq_sections_plain(center_freq, shelving_crossover, R, torch.full((n_sec + 1, 1), proto, dtype=dtype), fs, dtype)
+    G = _sos_magnitude_db(pb, pa, ctrl, nfft, fs) / proto
+    upper = torch.tensor([torch.inf] + [2 * proto] * n_sec, dtype=dtype)
+    gains = _bounded_least_squares_lbfgs(G, wanted, -upper, upper)
+    b, a = _geq_sections_plain(center_freq, shelving_crossover, R, gains.detach(), fs, dtype)
+    return b.to(device), a.to(device)

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..functional import (GEQDesign, HadamardMatrix, RotationMatrix, bandpass_filter, eq_freqs, highpass_filter,
+from ..functional import (GEQDesign, accurate_geq, HadamardMatrix, RotationMatrix, bandpass_filter, eq_freqs, highpass_filter,
                           lowpass_filter, matrix_exp_capturable, rad2hertz, skew_matrix)
 from ..utils import to_complex
 
@@ -589,6 +589,70 @@ class parallelGEQ(GEQ):
                  alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32):
         super().__init__(size=size, octave_interval=octave_interval, nfft=nfft, fs=fs, map=map,
                          requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def check_param_shape(self):
+        assert len(self.size) == 2, "Filter must be 2D, for 3D filters use GEQ module."
+
+
+class AccurateGEQ(_SOSMixin, Filter):
+    """Graphic equaliser whose command gains are fitted so that the cascade interpolates the TARGET gains:
+    param (n_bands + 2 target gains, N_out, N_in), map 20 log10(x); not learnable (dsp.py:3002-3123).
+    The fit (functional.accurate_geq: bounded least squares by L-BFGS on a dozen numbers, float32 as in
+    the reference) runs on the host once per parameter value -- the reference repeats it for every
+    channel pair on every forward call; the cascade itself is evaluated by ops.sos_response."""
+
+    def __init__(self, size: tuple = (1, 1), octave_interval: int = 1, nfft: int = 2 ** 11, fs: int = 48000,
+                 map: callable = lambda x: 20 * torch.log10(x), alias_decay_db: float = 0.0,
+                 start_freq: float = 31.25, end_freq: float = 16000.0, device: Optional[str] = None,
+                 dtype: torch.dtype = torch.float32):
+        self.octave_interval = octave_interval
+        self.fs = fs
+        self.center_freq, self.shelving_crossover = eq_freqs(interval=octave_interval, start_freq=start_freq,
+                                                             end_freq=end_freq)
+        self.n_gains = len(self.center_freq) + 2
+        self.alias_envelope_dcy = _gamma(alias_decay_db, nfft, device, dtype) ** torch.arange(0, 3, 1, device=device,
+                                                                                             dtype=dtype)
+        self._design_cache = (None, None)
+        super().__init__(size=(self.n_gains, *size), nfft=nfft, map=map, requires_grad=False,
+                         alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+
+    def init_param(self):
+        torch.nn.init.uniform_(self.param, a=10 ** (-6 / 20), b=10 ** (6 / 20))
+
+    def check_param_shape(self):
+        assert len(self.size) == 3, "Filter must be 3D, for 2D (parallel) filters use ParallelGEQ module."
+
+    def _sos_coeffs(self, target_db):
+        """target gains in dB (n_gains, chan...) -> float32-valued SOS (b, a), each (3, n_gains + 1, chan...)"""
+        host = target_db.detach().to("cpu")
+        key = (tuple(host.shape), str(host.dtype), host.contiguous().numpy().tobytes())
+        if self._design_cache[0] != key:
+            chan = tuple(host.shape[1:])
+            flat = host.reshape(host.shape[0], -1)
+            bs, as_ = [], []
+            for c in range(flat.shape[1]):
+                b, a = accurate_geq(flat[:, c], self.center_freq, self.shelving_crossover, fs=self.fs)
+                bs.append(b)
+                as_.append(a)
+            b = torch.stack(bs, dim=-1).reshape(3, -1, *chan)
+            a = torch.stack(as_, dim=-1).reshape(3, -1, *chan)
+            self._design_cache = (key, (b, a))
+        b, a = self._design_cache[1]
+        return b.to(target_db.device), a.to(target_db.device)
+
+
+class parallelAccurateGEQ(AccurateGEQ):
+    """Per-channel AccurateGEQ, param (n_bands + 2, N) (dsp.py:3126-3220)."""
+
+    _diag = True
+
+    def __init__(self, size: tuple = (1,), octave_interval: int = 1, nfft: int = 2 ** 11, fs: int = 48000,
+                 map: callable = lambda x: 20 * torch.log10(x), alias_decay_db: float = 0.0,
+                 start_freq: float = 31.25, end_freq: float = 16000.0, device: Optional[str] = None,
+                 dtype: torch.dtype = torch.float32):
+        super().__init__(size=size, octave_interval=octave_interval, nfft=nfft, fs=fs, map=map,
+                         alias_decay_db=alias_decay_db, start_freq=start_freq, end_freq=end_freq, device=device,
+                         dtype=dtype)
 
     def check_param_shape(self):
         assert len(self.size) == 2, "Filter must be 2D, for 3D filters use GEQ module."

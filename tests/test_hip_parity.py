@@ -200,6 +200,11 @@ def test_modules_golden(gpu, dt, name):
         # SVF / PEQ sections are float32 in the reference (host libm ulps, as for GEQ); in float32 mode the
         # parameters themselves are rounded before the (steep) parameter maps
         tol = 2e-6 if dt == torch.float64 else 2e-4
+    if "AccurateGEQ" in meta["cls"]:
+        # the command gains come out of 100 float32 L-BFGS steps on the host: the reference's own result moves
+        # by ~5e-4 from one host CPU to another (BLAS / libm ulps amplified by the iteration); the kernels
+        # behind it are held to the usual tolerance in test_accurate_geq_kernels_tight below
+        tol = 3e-3
     if "freq_response" in a:
         H = mod.freq_response(mod.param)
         assert H.shape == a["freq_response"].shape
@@ -540,3 +545,25 @@ def test_parallel_golden(gpu, dt, name):
     gX, gg, gpg, gfir = torch.autograd.grad(L, [X, g.param, pg.param, fir.param])
     for got, key in ((gX, "gX"), (gg, "gg"), (gpg, "gpg"), (gfir, "gfir")):
         assert relerr(got.cpu(), a[key]) < tol * 10, key
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_accurate_geq_kernels_tight(gpu, dt):
+    """AccurateGEQ behind its host-side design: the cascade evaluated by the HIP kernel against the oracle's
+    tail on the very sections this run designed (no L-BFGS noise in the comparison)."""
+    from flamo_amd.processor import dsp
+    from oracle import hotpath as O
+    rd = torch.float64 if dt == "f64" else torch.float32
+    meta, a = load_golden("accgeq_db30")
+    mod = dsp.AccurateGEQ(size=(2, 2), nfft=meta["nfft"], alias_decay_db=meta["alias_decay_db"], device=gpu, dtype=rd)
+    mod.assign_value(a["param"].to(gpu, rd))
+    b, a_ = mod._sos_coeffs(mod.map(mod.param.double()))
+    assert b.shape == (3, mod.n_gains + 1, 2, 2)
+    gamma = O.gamma_of(meta["alias_decay_db"], meta["nfft"], torch.float64)
+    Href = O.sos_response(b.cpu().double(), a_.cpu().double(), meta["nfft"], gamma)
+    H = mod.freq_response(mod.param)
+    assert relerr(H.cpu(), Href) < (1e-10 if dt == "f64" else 1e-5)
+    # the design is cached per parameter value: a second call does not refit
+    key = mod._design_cache[0]
+    mod.freq_response(mod.param)
+    assert mod._design_cache[0] is key

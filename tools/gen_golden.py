@@ -303,6 +303,20 @@ def gen_fdn(dsp, system):
              ir_vec=model.get_time_response(identity=False))
 
 
+# ----------------------------------------------------------------------------- AccurateGEQ
+def gen_accurate_geq(dsp):
+    """AccurateGEQ / parallelAccurateGEQ (dsp.py:3002-3220): target gains fitted by L-BFGS, then the SOS tail."""
+    nfft = 96
+    for db in (0.0, 30.0):
+        tag = f"db{int(db)}"
+        kw = dict(nfft=nfft, alias_decay_db=db, dtype=F64)
+        torch.manual_seed(4500 + int(db))
+        module_case(f"accgeq_{tag}", dsp.AccurateGEQ(size=(2, 2), **kw),
+                    dict(cls="AccurateGEQ", kwargs=dict(size=[2, 2]), nfft=nfft, alias_decay_db=db), 2, nfft)
+        module_case(f"paccgeq_{tag}", dsp.parallelAccurateGEQ(size=(3,), **kw),
+                    dict(cls="parallelAccurateGEQ", kwargs=dict(size=[3]), nfft=nfft, alias_decay_db=db), 3, nfft)
+
+
 # ----------------------------------------------------------------------------- Parallel
 def gen_parallel(dsp, system):
     """system.Parallel (system.py:570-772): two branches on one input, summed and concatenated."""
@@ -338,12 +352,16 @@ def main():
     if "--parallel-only" in sys.argv:
         gen_parallel(dsp, system)
         return
+    if "--accgeq-only" in sys.argv:
+        gen_accurate_geq(dsp)
+        return
     gen_transforms(dsp)
     gen_modules(dsp)
     gen_modules_more(dsp)
     gen_config2(dsp, system)
     gen_fdn(dsp, system)
     gen_parallel(dsp, system)
+    gen_accurate_geq(dsp)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print(f"total {total/1024:.1f} KiB")
 
