@@ -237,12 +237,17 @@ kernel_timer = KernelTimer()
 # Memory safety rests on stream order, not on record_stream: every side region starts by waiting
 # for an event recorded on the main stream after all earlier main-stream work was enqueued, and the
 # main stream waits for the side stream before it touches a result.
-_fork = {"event": None}
+_fork = {"event": None, "memo": None}
 _side_streams = {}
 
 
 def fork_event():
     return _fork["event"]
+
+
+def forward_memo():
+    """dict scoped to the current Shell.forward call (None outside one): per-forward memo of responses"""
+    return _fork["memo"]
 
 
 def side_stream(dev: torch.device) -> "torch.cuda.Stream":
@@ -262,15 +267,16 @@ class fork_point:
         self.dev = x.device if self.on else None
 
     def __enter__(self):
-        self.prev = _fork["event"]
+        self.prev = (_fork["event"], _fork["memo"])
         if self.on:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.dev))
             _fork["event"] = ev
+            _fork["memo"] = {}
         return self
 
     def __exit__(self, *exc):
-        _fork["event"] = self.prev
+        _fork["event"], _fork["memo"] = self.prev
         return False
 
 

@@ -177,6 +177,23 @@ class DSP(nn.Module):
     def _gamma_on(self, t: torch.Tensor) -> torch.Tensor:
         return self.gamma.to(device=t.device)
 
+    def _response_once(self, param):
+        """freq_response(param), evaluated once per forward pass of the enclosing Shell: a Recursion applies
+        its feedforward path twice (to the identity and to the signal) and the reference regenerates the
+        (M, N_out, N_in) response each time.  Keyed by module, parameter tensor and its version counter; the
+        memo lives in the Shell.forward scope (ops.fork_point), so nothing survives a parameter update.
+        Reusing one response tensor at several places of the autograd graph is what autograd is for."""
+        memo = ops.forward_memo()
+        if memo is None or not torch.is_tensor(param):
+            return self.freq_response(param)
+        stream = torch.cuda.current_stream(param.device).cuda_stream if param.is_cuda else 0   # no cross-stream reuse
+        key = (id(self), id(param), param._version, ops.bin_shard(self.nfft), torch.is_grad_enabled(), stream)
+        H = memo.get(key)
+        if H is None:
+            H = self.freq_response(param)
+            memo[key] = H
+        return H
+
     # ---- protocol used by system.Series to fold adjacent per-bin modules into one pass
     def _bin_response(self, param):
         """(H, diag) such that forward(x) == ops.mimo(H, x, diag), or None if this module is not a
@@ -381,11 +398,11 @@ class Filter(DSP):
         self.freq_response = response
 
     def get_freq_convolve(self):
-        self.freq_convolve = lambda x, param: ops.mimo(self.freq_response(param), x, diag=self._diag)
+        self.freq_convolve = lambda x, param: ops.mimo(self._response_once(param), x, diag=self._diag)
         self._own_convolve = self.freq_convolve
 
     def _bin_response(self, param):
-        return self.freq_response(param), self._diag
+        return self._response_once(param), self._diag
 
     def initialize_class(self):
         self.check_param_shape()
@@ -984,11 +1001,11 @@ class Delay(DSP):
         assert len(self.size) == 2, "delay must be 2D, for 1D (parallel) delay use parallelDelay module."
 
     def get_freq_convolve(self):
-        self.freq_convolve = lambda x, param: ops.mimo(self.freq_response(param), x, diag=self._diag)
+        self.freq_convolve = lambda x, param: ops.mimo(self._response_once(param), x, diag=self._diag)
         self._own_convolve = self.freq_convolve
 
     def _bin_response(self, param):
-        return self.freq_response(param), self._diag
+        return self._response_once(param), self._diag
 
     def initialize_class(self):
         self.check_param_shape()
@@ -1112,11 +1129,11 @@ class GainDelay(DSP):
         self.freq_response = response
 
     def get_freq_convolve(self):
-        self.freq_convolve = lambda x, param: ops.mimo(self.freq_response(param), x, diag=self._diag)
+        self.freq_convolve = lambda x, param: ops.mimo(self._response_once(param), x, diag=self._diag)
         self._own_convolve = self.freq_convolve
 
     def _bin_response(self, param):
-        return self.freq_response(param), self._diag
+        return self._response_once(param), self._diag
 
     def initialize_class(self):
         self.check_param_shape()
