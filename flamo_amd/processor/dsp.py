@@ -186,12 +186,21 @@ class DSP(nn.Module):
         memo = ops.forward_memo()
         if memo is None or not torch.is_tensor(param):
             return self.freq_response(param)
-        stream = torch.cuda.current_stream(param.device).cuda_stream if param.is_cuda else 0   # no cross-stream reuse
-        key = (id(self), id(param), param._version, ops.bin_shard(self.nfft), torch.is_grad_enabled(), stream)
-        H = memo.get(key)
-        if H is None:
+        key = (id(self), id(param), param._version, ops.bin_shard(self.nfft), torch.is_grad_enabled())
+        hit = memo.get(key)
+        if hit is None:
             H = self.freq_response(param)
-            memo[key] = H
+            ev = None
+            if param.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(param.device))
+            memo[key] = (H, ev, torch.cuda.current_stream(param.device).cuda_stream if param.is_cuda else 0)
+            return H
+        H, ev, produced_on = hit
+        if ev is not None:
+            cur = torch.cuda.current_stream(param.device)
+            if cur.cuda_stream != produced_on:
+                cur.wait_event(ev)      # reuse on another stream (side-stream response build vs main): order it
         return H
 
     # ---- protocol used by system.Series to fold adjacent per-bin modules into one pass
