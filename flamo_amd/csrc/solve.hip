@@ -16,6 +16,8 @@
 // rank-1 update per step, not a dense tile contraction, so MFMA does not apply.
 #include "common.h"
 
+#include <type_traits>
+
 namespace fl {
 
 template <typename T>
@@ -211,11 +213,255 @@ __global__ void __launch_bounds__(256) solve_kernel(
     }
 }
 
+// ---------------------------------------------------------------- N <= 16: rows in place, DPP broadcasts
+// The kernel above is bound by vector-ALU issue (a wave64 instruction occupies its 16-lane SIMD for four
+// cycles; ~3500 of them per 4 bins at N = 16), and a third of those instructions only exist because a
+// row stays in the lane it was loaded into: the pivot lane is data, so every broadcast of the pivot row is
+// a ds_bpermute behind a wait, and the (value, lane) arg-max is five instructions per exchange.  Here rows
+// are PHYSICALLY exchanged -- after step k the pivot row sits in lane k -- which makes every broadcast
+// source a compile-time lane: one DPP move (row_newbcast:k for 16-lane groups, quad permutes for 4 and 8).
+// The exchange itself (2 N bpermutes) is paid only when needed: threshold pivoting keeps the diagonal
+// entry whenever it is within a factor 2 of the column maximum (growth is bounded as with partial pivoting,
+// by 3^(N-1) instead of 2^(N-1) in theory and indistinguishable in practice), and I - P of a damped loop is
+// nowhere near that.  The pivot search is one integer max per exchange: the magnitude's bit pattern with the
+// (inverted) lane number in its low bits.
+template <int I, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+// lanes of the 4-lane banks selected by BANKS take the moved value, the others keep their own
+template <int CTRL, int BANKS>
+__device__ inline int dpp_merge(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, BANKS, false);
+}
+
+// the value lane K of each NMAX-lane group holds, in every lane of the group
+template <int NMAX, int K>
+__device__ inline int group_bcast(int v) {
+    static_assert(NMAX == 4 || NMAX == 8 || NMAX == 16, "DPP broadcasts stay inside a 16-lane row");
+    if constexpr (NMAX == 16) {
+        return dpp_mov<0x150 + K>(v);                          // row_newbcast:K
+    } else if constexpr (NMAX == 4) {
+        return dpp_mov<K * 0x55>(v);                           // quad_perm:[K,K,K,K]
+    } else {
+        const int t = dpp_mov<(K & 3) * 0x55>(v);              // every quad: its lane K%4 ...
+        if constexpr (K < 4) return dpp_merge<0x114, 0xA>(t);  // ... row_shr:4 into quads 1 and 3
+        else return dpp_merge<0x104, 0x5>(t);                  // ... row_shl:4 into quads 0 and 2
+    }
+}
+template <int NMAX, int K>
+__device__ inline float group_bcast(float v) {
+    return __builtin_bit_cast(float, group_bcast<NMAX, K>(__builtin_bit_cast(int, v)));
+}
+template <int NMAX, int K>
+__device__ inline double group_bcast(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = group_bcast<NMAX, K>((int)(b & 0xffffffffLL));
+    const int hi = group_bcast<NMAX, K>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+template <int NMAX, int K, typename T>
+__device__ inline cx<T> group_bcast(cx<T> v) {
+    return cx<T>(group_bcast<NMAX, K>(v.x), group_bcast<NMAX, K>(v.y));
+}
+
+// reciprocals from the hardware estimate (an IEEE division is ~10 instructions, and the pivot reciprocal is on
+// the critical path of every elimination step): v_rcp_f32 is accurate to 1 ulp as it is; v_rcp_f64 takes two
+// Newton steps
+__device__ inline float rcp_est(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline double rcp_est(double x) { return __builtin_amdgcn_rcp(x); }
+__device__ inline float rcp_full(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ inline double rcp_full(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return fma(r, fma(-x, r, 1.0), r);
+}
+// 1 / b, scaled by ~1/max(|re|,|im|) against overflow of |b|^2; the scale cancels exactly whatever its rounding,
+// so the raw estimate serves for it
+template <typename T>
+__device__ inline cx<T> crecip_fast(cx<T> b) {
+    const T is = rcp_est(fmax(fabs(b.x), fabs(b.y)));
+    const T x = b.x * is, y = b.y * is;
+    const T d = is * rcp_full(x * x + y * y);
+    return cx<T>(x * d, -y * d);
+}
+
+// acc - l * p.  float: two packed FMAs, (-l.x,-l.x)*(p.x,p.y) and (l.y,-l.y)*(p.y,p.x) -- the broadcast and the swap
+// are operand selectors of v_pk_fma_f32, the two multiplier pairs are formed once per elimination step
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <typename T> struct CMul { T lx, ly; };
+template <> struct CMul<float> { f2v nlxx, lyny; };
+__device__ inline CMul<float> cmul_of(cx<float> l) { return {f2v{-l.x, -l.x}, f2v{l.y, -l.y}}; }
+__device__ inline CMul<double> cmul_of(cx<double> l) { return {l.x, l.y}; }
+__device__ inline cx<float> cfnma(cx<float> acc, const CMul<float>& m, cx<float> p) {
+    f2v a = {acc.x, acc.y};
+    a = __builtin_elementwise_fma(m.nlxx, f2v{p.x, p.y}, a);
+    a = __builtin_elementwise_fma(m.lyny, f2v{p.y, p.x}, a);
+    return cx<float>(a.x, a.y);
+}
+__device__ inline cx<double> cfnma(cx<double> acc, const CMul<double>& m, cx<double> p) {
+    return cx<double>(fma(m.ly, p.y, fma(-m.lx, p.x, acc.x)), fma(-m.ly, p.x, fma(-m.lx, p.y, acc.y)));
+}
+// compiler barrier on a register-resident complex value, as ONE 64-bit operand per component pair (separate
+// 32-bit operands would split the register pairs the packed instructions need)
+__device__ inline void opaque(cx<float>& v) {
+    unsigned long long t = __builtin_bit_cast(unsigned long long, v);
+    asm("" : "+v"(t));
+    v = __builtin_bit_cast(cx<float>, t);
+}
+__device__ inline void opaque(cx<double>& v) { asm("" : "+v"(v.x), "+v"(v.y)); }
+
+template <typename T, int NMAX>
+__global__ void __launch_bounds__(256) solve_inplace_kernel(
+    const cx<T>* __restrict__ P, long p_pitch, Dud<T> dud, int one_minus, int adjoint,
+    const cx<T>* __restrict__ R, long rs_b, long rs_n, long rs_k,
+    cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
+    int B, int M, int N, int K) {
+    constexpr int BPB = 256 / NMAX;
+    const int gi = threadIdx.x % NMAX;
+    const int f = blockIdx.x * BPB + threadIdx.x / NMAX;
+    // the frequency-independent mixing matrix, zero-padded to NMAX x NMAX (and transposed for the adjoint
+    // system), staged once per workgroup: the row build below reads it with compile-time offsets, no guards
+    __shared__ cx<T> Us[NMAX * NMAX];
+    if (!P) {
+        for (int e = threadIdx.x; e < NMAX * NMAX; e += 256) {
+            const int i = e / NMAX, j = e % NMAX;
+            cx<T> u(0, 0);
+            if (i < N && j < N) u = adjoint ? conj(dud.U[(long)j * N + i]) : dud.U[(long)i * N + j];
+            Us[e] = u;
+        }
+        __syncthreads();
+    }
+    if (f >= M) return;  // whole lane group leaves together; no exchange below crosses a group
+
+    // ---- load (or build) this lane's row of A; rows and columns >= N are those of the identity
+    cx<T> row[NMAX];
+    if (P) {
+        const int gr = min(gi, N - 1);                       // padded lanes read a valid row and discard it
+        const cx<T>* p = adjoint ? P + (long)gr * p_pitch + f : P + (long)gr * N * p_pitch + f;
+        const long step = adjoint ? (long)N * p_pitch : p_pitch;
+        const T sgn = one_minus ? (T)-1 : (T)1;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            cx<T> v(0, 0);
+            if (j < N) {                                     // uniform
+                v = p[(long)j * step];
+                v = cx<T>(sgn * v.x, (adjoint ? -sgn : sgn) * v.y);
+                v.x = gi < N ? v.x : (T)0;
+                v.y = gi < N ? v.y : (T)0;
+            }
+            if (one_minus ? (j == gi) : (j == gi && gi >= N)) v.x += (T)1;
+            row[j] = v;
+        }
+    } else {
+        // A[i][j] = delta_ij - l_i U_ij r_j ;  A^H[i][j] = delta_ij - conj(r_i) conj(U_ji) conj(l_j)
+        const cx<T> one(1, 0);
+        cx<T> lv = one, rv = one;
+        if (gi < N) {
+            if (dud.l) lv = dud.l[(long)gi * dud.l_sn + (long)f * dud.l_sf];
+            if (dud.r) rv = dud.r[(long)gi * dud.r_sn + (long)f * dud.r_sf];
+        }
+        const cx<T> own = adjoint ? conj(rv) : lv;
+        const cx<T> oth = adjoint ? conj(lv) : rv;
+        const cx<T>* urow = Us + gi * NMAX;
+        static_for<0, NMAX>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            const cx<T> v = own * urow[J] * group_bcast<NMAX, J>(oth);
+            row[J] = cx<T>((J == gi ? (T)1 : (T)0) - v.x, -v.y);
+        });
+    }
+
+    // ---- LU, threshold partial pivoting, rows exchanged in place
+    int orig = gi;          // which row of A (= which entry of the right-hand side) this lane holds
+    cx<T> dinv(0, 0);       // reciprocal of this lane's pivot
+    static_for<0, NMAX>([&](auto kc) {
+        constexpr int KK = decltype(kc)::value;
+        if constexpr (KK < NMAX - 1) {
+            const float mag = (gi >= KK) ? (float)(fabs(row[KK].x) + fabs(row[KK].y)) : -1.0f;
+            // non-negative floats order like their bit patterns; the low bits carry NMAX-1-lane so that the
+            // lowest lane wins among (nearly) equal magnitudes, as icamax would pick
+            const int key = (__builtin_bit_cast(int, mag) & ~(NMAX - 1)) | (NMAX - 1 - gi);
+            int kmax = key;
+            if constexpr (NMAX >= 16) kmax = max(kmax, dpp_mov<DPP_ROW_MIRROR>(kmax));
+            if constexpr (NMAX >= 8) kmax = max(kmax, dpp_mov<DPP_HALF_MIRROR>(kmax));
+            kmax = max(kmax, dpp_mov<DPP_QUAD_XOR2>(kmax));
+            kmax = max(kmax, dpp_mov<DPP_QUAD_XOR1>(kmax));
+            // keep the diagonal unless it is more than 2x smaller than the column maximum: a factor 2 is one
+            // exponent step, i.e. 1 << 23 on the bit pattern (denormal magnitudes compare conservatively)
+            const bool exchange = group_bcast<NMAX, KK>(key) + (1 << 23) < kmax;
+            if (__any(exchange)) {      // uniform over the wavefront; groups that keep their diagonal map to themselves
+                const int best = NMAX - 1 - (kmax & (NMAX - 1));
+                const int partner = exchange ? (gi == KK ? best : (gi == best ? KK : gi)) : gi;
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j) row[j] = shfl_cx(row[j], partner, NMAX);
+                orig = __shfl(orig, partner, NMAX);
+            }
+            // values merged from the two paths are opaque from here on: InstCombine otherwise walks the chain of
+            // 15 two-way merges per register recursively (compile time doubles with every step)
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) opaque(row[j]);
+            asm("" : "+v"(orig));
+        }
+        const cx<T> inv = crecip_fast(group_bcast<NMAX, KK>(row[KK]));
+        const bool below = gi > KK;
+        cx<T> l = row[KK] * inv;
+        l.x = below ? l.x : (T)0;
+        l.y = below ? l.y : (T)0;
+        const auto lm = cmul_of(l);
+        static_for<KK + 1, NMAX>([&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            row[J] = cfnma(row[J], lm, group_bcast<NMAX, KK>(row[J]));
+        });
+        row[KK].x = below ? l.x : row[KK].x;
+        row[KK].y = below ? l.y : row[KK].y;
+        dinv.x = (gi == KK) ? inv.x : dinv.x;
+        dinv.y = (gi == KK) ? inv.y : dinv.y;
+    });
+
+    // ---- apply to every right-hand side: lane k ends up with x_k
+    const int ncols = B * K;
+    for (int col = 0; col < ncols; ++col) {
+        const int b = col / K, kk = col - b * K;
+        cx<T> y(0, 0);
+        if (gi < N) y = R[(long)b * rs_b + (long)orig * rs_n + (long)kk * rs_k + f];
+        static_for<0, NMAX - 1>([&](auto kc) {          // forward: y_i -= L[i][k] y_k, i > k
+            constexpr int KK = decltype(kc)::value;
+            const cx<T> m((gi > KK) ? row[KK].x : (T)0, (gi > KK) ? row[KK].y : (T)0);
+            y = cfnma(y, cmul_of(m), group_bcast<NMAX, KK>(y));
+        });
+        static_for<0, NMAX>([&](auto kc) {              // back: x_k = y_k / U[k][k];  y_i -= U[i][k] x_k, i < k
+            constexpr int KK = NMAX - 1 - decltype(kc)::value;
+            const cx<T> yd = y * dinv;
+            y.x = (gi == KK) ? yd.x : y.x;
+            y.y = (gi == KK) ? yd.y : y.y;
+            if constexpr (KK > 0) {
+                const cx<T> m((gi < KK) ? row[KK].x : (T)0, (gi < KK) ? row[KK].y : (T)0);
+                y = cfnma(y, cmul_of(m), group_bcast<NMAX, KK>(y));
+            }
+        });
+        if (gi < N) OUT[(long)b * os_b + (long)gi * os_n + (long)kk * os_k + f] = y;
+    }
+}
+
+static int g_solve_variant = 0;   // tuning hook: 1 forces the shuffle kernel for every N
+
 template <typename T, int NMAX>
 static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
                         void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, hipStream_t st) {
     constexpr int BPB = 256 / NMAX;
     dim3 grid(cdiv_i(M, BPB));
+    if constexpr (NMAX <= 16) {
+        if (g_solve_variant == 0) {
+            hipLaunchKernelGGL((solve_inplace_kernel<T, NMAX>), grid, dim3(256), 0, st, (const cx<T>*)P, p_pitch, dud, one_minus,
+                               adjoint, (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);
+            FL_CHECK_LAUNCH("solve");
+            return FL_OK;
+        }
+    }
     hipLaunchKernelGGL((solve_kernel<T, NMAX>), grid, dim3(256), 0, st, (const cx<T>*)P, p_pitch, dud, one_minus, adjoint,
                        (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);
     FL_CHECK_LAUNCH("solve");
@@ -249,6 +495,10 @@ static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_mi
 using namespace fl;
 
 extern "C" {
+int fl_debug_set_solve_variant(int variant) {
+    g_solve_variant = variant;
+    return FL_OK;
+}
 int fl_solve_c64(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
                  long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
     Dud<float> none = {};

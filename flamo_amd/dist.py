@@ -50,6 +50,12 @@ def bin_shard(nfft: int, rank: Optional[int] = None, world: Optional[int] = None
         ops.set_bin_shard(0, None)
 
 
+def _host_staged(t: torch.Tensor, group) -> bool:
+    """gloo moves host memory: device tensors are staged through the host (ranks sharing one GPU on a
+    test rig; RCCL refuses two ranks on one device).  Transport only -- no arithmetic moves to the CPU."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 class _AllGatherBins(torch.autograd.Function):
     """(B, m_local, ...) per rank -> (B, M, ...) on every rank; backward = local slice."""
 
@@ -70,8 +76,13 @@ class _AllGatherBins(torch.autograd.Function):
         send = send.contiguous()
         cplx = send.is_complex()
         buf = torch.view_as_real(send) if cplx else send
-        out = torch.empty((world * buf.shape[0], *buf.shape[1:]), dtype=buf.dtype, device=buf.device)
-        dist.all_gather_into_tensor(out, buf, group=group)     # concatenated along dim 0
+        if _host_staged(buf, group):
+            parts = [torch.empty(buf.shape, dtype=buf.dtype) for _ in range(world)]
+            dist.all_gather(parts, buf.cpu(), group=group)
+            out = torch.stack(parts).to(buf.device)
+        else:
+            out = torch.empty((world * buf.shape[0], *buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+            dist.all_gather_into_tensor(out, buf, group=group)     # concatenated along dim 0
         out = out.view(world, *buf.shape)
         if cplx:
             out = torch.view_as_complex(out)
@@ -102,7 +113,12 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None) -> None:
     if not ps:
         return
     flat = torch.cat([p.grad.reshape(-1).to(torch.float64) for p in ps])
-    dist.all_reduce(flat, group=group)
+    if _host_staged(flat, group):
+        host = flat.cpu()
+        dist.all_reduce(host, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.all_reduce(flat, group=group)
     off = 0
     for p in ps:
         n = p.grad.numel()

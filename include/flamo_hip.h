@@ -243,6 +243,9 @@ int fl_solve_dud_c64(const void* l, long l_sn, long l_sf, const void* U, const v
 int fl_solve_dud_c128(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, int adjoint,
                       const void* R, long rs_b, long rs_n, long rs_k, void* OUT, long os_b, long os_n, long os_k,
                       int B, int M, int N, int K, void* stream);
+/* tuning/test hook: 0 (default) = N <= 16 factor with rows exchanged in place (compile-time DPP broadcasts,
+ * threshold pivoting); 1 = the shuffle kernel with implicit partial pivoting for every N */
+int fl_debug_set_solve_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------------
  * Scalar objective on the output of the path: the training step reduces the model output to one

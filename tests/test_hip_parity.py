@@ -567,3 +567,62 @@ def test_accurate_geq_kernels_tight(gpu, dt):
     key = mod._design_cache[0]
     mod.freq_response(mod.param)
     assert mod._design_cache[0] is key
+
+
+# ----------------------------------------------------------------------------- config 4: colorless FDN training
+@pytest.mark.parametrize("name", ["colorless6", "colorless16"])
+def test_colorless_training_golden(gpu, dt, name):
+    """BASELINE configs[3] in miniature: the Adam trajectory of examples/e8_colorless_fdn.py (|H| output layer,
+    mse + 0.2 sparsity) recorded from the reference -- first estimate, first gradients, every step's losses, final
+    parameters."""
+    from tools import train_colorless_fdn as T
+    meta, a = load_golden(name)
+    model = T.build(gpu, dt, meta["N"], meta["nfft"], meta["alias_decay_db"], meta["delays"])
+    assert list(model.state_dict().keys()) == meta["state_keys"]
+    core = model.get_core()
+    ig, og, mix = core.input_gain, core.output_gain, core.feedback_loop.feedback
+    ig.assign_value(_dev(a["in_gain0"], gpu, dt))
+    og.assign_value(_dev(a["out_gain0"], gpu, dt))
+    mix.assign_value(_dev(a["U_param0"], gpu, dt))
+    x, tgt = _dev(a["x"], gpu, dt), _dev(a["target"], gpu, dt)
+    tol = 1e-9 if dt == torch.float64 else 2e-5
+    est = model(x)
+    assert est.shape == a["est0"].shape and relerr(est.detach().cpu(), a["est0"]) < tol
+    (T.mse_criterion(est, tgt) + 0.2 * T.sparsity_criterion(model)).backward()
+    for p_, key in ((ig.param, "g_in_gain0"), (og.param, "g_out_gain0"), (mix.param, "g_U_param0")):
+        assert relerr(p_.grad.cpu(), a[key]) < 10 * tol, key
+    log = T.train(model, x, tgt, meta["steps"], meta["lr"], log=[])
+    log = torch.stack(log).double().cpu()
+    assert relerr(log, a["losses"]) < 10 * tol
+    # Adam's first steps are lr * sign(g): parameters whose gradient is ~0 amplify rounding, so the float32 run is
+    # compared on the trajectory and on the parameters at a looser bound
+    ptol = 1e-8 if dt == torch.float64 else 2e-3
+    for p_, key in ((ig.param, "in_gain"), (og.param, "out_gain"), (mix.param, "U_param")):
+        assert relerr(p_.detach().cpu(), a[key]) < ptol, key
+
+
+def test_colorless_training_bin_sharded_two_ranks(gpu, tmp_path):
+    """Two ranks sharing the GPU (gloo transport, staged through the host; RCCL refuses two ranks on one device):
+    bin-sharded training must retrace the unsharded trajectory -- losses and final parameters."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "train_colorless_fdn.py")
+    common = ["--N", "6", "--nfft", "4800", "--batch", "2", "--steps", "4", "--warmup", "0", "--lr", "1e-2",
+              "--dtype", "float64"]
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    subprocess.run([sys.executable, tool, *common, "--dump", one], check=True, timeout=600, cwd=root)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", str(port), tool, *common, "--gpus", "2",
+                    "--backend", "gloo", "--share-gpu", "--dump", two], check=True, timeout=900, cwd=root)
+    r1, r2 = torch.load(one), torch.load(two)
+    assert relerr(torch.tensor(r2["losses"], dtype=torch.float64), torch.tensor(r1["losses"], dtype=torch.float64)) < 1e-10
+    assert r1["losses"][0][2] > r1["losses"][-1][2]            # it trains
+    for k, v in r1["state"].items():
+        assert relerr(r2["state"][k], v) < 1e-9, k

@@ -175,3 +175,31 @@ def test_accurate_geq_design_port(name):
     A = torch.stack(as_, -1).reshape(3, -1, *chan).double()
     H = O.sos_response(b, A, meta["nfft"], O.gamma_of(meta["alias_decay_db"], meta["nfft"], torch.float64))
     assert relerr(H, a["freq_response"]) < 3e-3
+
+
+@pytest.mark.parametrize("name", ["colorless6", "colorless16"])
+def test_colorless_training_oracle(name):
+    """BASELINE configs[3] in miniature: the oracle's FDN with the |.| output layer under the colorless criteria
+    (mse + 0.2 sparsity) and Adam, against the trajectory recorded from the reference."""
+    import math
+    meta, a = load_golden(name)
+    N, nfft = meta["N"], meta["nfft"]
+    ps = [a[k].clone().requires_grad_(True) for k in ("in_gain0", "out_gain0", "U_param0")]
+    opt = torch.optim.Adam(ps, lr=meta["lr"])
+    log = []
+    for it in range(meta["steps"]):
+        opt.zero_grad()
+        est = O.fdn_forward(a["x"], ps[0], ps[1], ps[2], a["delays_s"], nfft, meta["alias_decay_db"], output="abs")
+        mse = torch.mean((est.sum(-1) - a["target"].squeeze(-1)) ** 2)
+        sp = -(torch.sum(torch.abs(O.orthogonal(ps[2]))) - N * math.sqrt(N)) / (N * (math.sqrt(N) - 1))
+        loss = mse + 0.2 * sp
+        loss.backward()
+        if it == 0:
+            assert relerr(est.detach(), a["est0"]) < 1e-10
+            for p_, key in zip(ps, ("g_in_gain0", "g_out_gain0", "g_U_param0")):
+                assert relerr(p_.grad, a[key]) < 1e-9, key
+        opt.step()
+        log.append([mse.item(), sp.item(), loss.item()])
+    assert relerr(torch.tensor(log, dtype=torch.float64), a["losses"]) < 1e-9
+    for p_, key in zip(ps, ("in_gain", "out_gain", "U_param")):
+        assert relerr(p_.detach(), a[key]) < 1e-8, key

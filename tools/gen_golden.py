@@ -222,7 +222,7 @@ def build_fdn(dsp, system, N, nfft, db, delays, with_attn, dtype=F64, out_layer=
     if out_layer == "ifft_aa":
         ol = dsp.iFFTAntiAlias(nfft=nfft, alias_decay_db=db, dtype=dtype)
     else:
-        ol = dsp.Transform(lambda x: torch.abs(x))
+        ol = dsp.Transform(lambda x: torch.abs(x), dtype=dtype)
     model = system.Shell(core=core, input_layer=dsp.FFT(nfft, dtype=dtype), output_layer=ol)
     return model, dict(input_gain=input_gain, output_gain=output_gain, delays=dl, mix=mix, att=att, rec=rec)
 
@@ -340,6 +340,47 @@ def gen_parallel(dsp, system):
                  X=X, Y=Y, C=C, g=g.param, pg=pg.param, fir=fir.param, gX=gr[0], gg=gr[1], gpg=gr[2], gfir=gr[3])
 
 
+# ----------------------------------------------------------------------------- config 4: colorless FDN training
+def gen_colorless(dsp, system):
+    """examples/e8_colorless_fdn.py in miniature: FDN with an orthogonal feedback matrix, |.| output layer,
+    DatasetColorless batches (impulse of M samples -> flat magnitude), criteria mse_loss + 0.2 sparsity_loss
+    (flamo/optimize/loss.py:12-103), Adam steps as Trainer.train_step does them (trainer.py:70, 162-191)."""
+    from flamo.optimize.loss import mse_loss, sparsity_loss
+    from flamo.optimize.dataset import DatasetColorless
+    specs = [("colorless6", 6, 480, [59, 97, 131, 151, 163, 169], 2, 1e-2, 8),
+             ("colorless16", 16, 1500, [53, 61, 71, 79, 89, 97, 103, 109, 127, 137, 149, 157, 167, 179, 191, 199], 1, 1e-3, 5)]
+    for name, N, nfft, delays, B, lr, steps in specs:
+        torch.manual_seed(4400 + N)
+        db = 30.0
+        model, p = build_fdn(dsp, system, N, nfft, db, delays, False, out_layer="abs")
+        M = nfft // 2 + 1
+        ds = DatasetColorless(input_shape=(1, M, 1), target_shape=(1, M, 1), expand=B, device="cpu", dtype=F64)
+        x = torch.stack([ds[i][0] for i in range(B)])
+        tgt = torch.stack([ds[i][1] for i in range(B)])
+        plist = [p["input_gain"].param, p["output_gain"].param, p["mix"].param]
+        init = [q.detach().clone() for q in plist]
+        crit = [(1.0, mse_loss(nfft=nfft), False), (0.2, sparsity_loss(), True)]
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
+        log, g0 = [], None
+        for it in range(steps):
+            opt.zero_grad()
+            est = model(x)
+            parts = [c(est, tgt, model) if rm else c(est, tgt) for _, c, rm in crit]
+            loss = sum(a * t for (a, _, _), t in zip(crit, parts))
+            loss.backward()
+            if it == 0:
+                g0 = [q.grad.detach().clone() for q in plist]
+                est0 = est.detach().clone()
+            opt.step()
+            log.append([float(parts[0]), float(parts[1]), float(loss)])
+        save(name, dict(kind="colorless", N=N, nfft=nfft, alias_decay_db=db, delays=delays, B=B, lr=lr, steps=steps,
+                        state_keys=list(model.state_dict().keys())),
+             x=x, target=tgt, est0=est0, losses=np.array(log),
+             in_gain0=init[0], out_gain0=init[1], U_param0=init[2],
+             g_in_gain0=g0[0], g_out_gain0=g0[1], g_U_param0=g0[2],
+             in_gain=plist[0], out_gain=plist[1], U_param=plist[2], delays_s=p["delays"].param.detach())
+
+
 def main():
     torch.set_default_dtype(torch.float32)
     dsp, system = refimport.load()
@@ -355,6 +396,9 @@ def main():
     if "--accgeq-only" in sys.argv:
         gen_accurate_geq(dsp)
         return
+    if "--colorless-only" in sys.argv:
+        gen_colorless(dsp, system)
+        return
     gen_transforms(dsp)
     gen_modules(dsp)
     gen_modules_more(dsp)
@@ -362,6 +406,7 @@ def main():
     gen_fdn(dsp, system)
     gen_parallel(dsp, system)
     gen_accurate_geq(dsp)
+    gen_colorless(dsp, system)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print(f"total {total/1024:.1f} KiB")
 
