@@ -153,6 +153,299 @@ __global__ void __launch_bounds__(256) mimo_gradh_diag_kernel(
     dh[(long)n * dh_pitch + f] = acc;
 }
 
+// ---------------------------------------------------------------- matrix-valued signals: MFMA
+// When the signal carries >= 8 columns per bin and the channel count is >= 16 -- Recursion pushing the identity
+// through a 32 x 32 loop (system.py:417-419), Shell.get_freq_response(identity=True), the matrix gradients of
+// those -- the per-bin product is a genuine dense contraction: 8 N^3 flop against 24 N^2 bytes per bin,
+// 10.7 flop/B at N = 32, and the lane-per-bin FMA stream above is bound by vector issue (measured 1.88 ms
+// for 192001 bins of 32x32x32: 27 TFLOP/s, 1.7 TB/s) rather than by HBM (0.6 ms).  The matrix cores take the
+// bin-planar layout as it is through the BLOCKED fp32 instruction v_mfma_f32_4x4x1_16b_f32: one instruction is
+// 16 independent 4x4 outer-product updates, one block per bin --
+//     lane = 4*bin + q :   srcA = A[4rb+q][t]   srcB = B[t][4cb+q]   acc[v] = D[4rb+v][4cb+q]
+// so 16 adjacent bins of one plane are one 128-byte segment per q and nothing is transposed or staged.
+// A wavefront owns 16 bins x (4 RB rows) x 8 columns: RB*2 accumulator tiles for the real and for the
+// imaginary part (128 VGPRs at RB = 8); the four real products of a complex one are four MFMAs
+// (Dr += Ar Br, Dr += (-Ai) Bi, Di += Ar Bi, Di += Ai Br).  The four wavefronts of a workgroup take
+// adjacent column tiles of the same bins, so A is fetched from HBM once and from the L1/L2 after.
+//   D[i, j, f] = scale * sum_t opA(A)[i, t, f] opB(B)[t, j, f],    t = (t1, t2),  j = (j1, j2)
+// covers the forward product (t = input channel, j = (batch, column)) and the per-bin matrix gradient
+// (t = (batch, column), j = input channel, B conjugated).
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct MmaArgs {
+    const cx<float>* A;
+    long sa_f, sa_i, sa_t1, sa_t2;
+    const cx<float>* B;
+    long sb_j1, sb_j2, sb_t1, sb_t2;
+    cx<float>* D;
+    long sd_i, sd_j1, sd_j2;
+    float scale;
+    int conj_a, conj_b;
+    int M, NI, J1, J2, T1, T2, nct, nrt;
+};
+
+template <int RB, int DEPTH>
+__global__ void __launch_bounds__(256) mimo_mfma_kernel(MmaArgs a) {
+    const int lane = threadIdx.x & 63, q = lane & 3, bl = lane >> 2;
+    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int ct = (int)(wid % a.nct);
+    const long r = wid / a.nct;
+    const int rt = (int)(r % a.nrt);
+    const long bg = r / a.nrt;
+    if (bg * 16 >= a.M) return;                       // uniform over the wavefront
+    const int f = (int)(bg * 16) + bl;
+    const bool fv = f < a.M;
+    const int fc = fv ? f : a.M - 1;                  // lanes past the last bin read a valid one and store nothing
+    const cx<float>* ap[RB];
+    float am[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int i = rt * 4 * RB + 4 * rb + q;
+        am[rb] = i < a.NI ? 1.f : 0.f;
+        ap[rb] = a.A + (long)fc * a.sa_f + (long)(i < a.NI ? i : 0) * a.sa_i;
+    }
+    const cx<float>* bp[2];
+    float bm[2];
+    long doff[2];
+    bool bv[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int col = ct * 8 + cb * 4 + q;
+        bv[cb] = col < a.J1 * a.J2;
+        const int j1 = bv[cb] ? col / a.J2 : 0, j2 = bv[cb] ? col - j1 * a.J2 : 0;
+        bm[cb] = bv[cb] ? 1.f : 0.f;
+        bp[cb] = a.B + (long)j1 * a.sb_j1 + (long)j2 * a.sb_j2 + fc;
+        doff[cb] = (long)j1 * a.sd_j1 + (long)j2 * a.sd_j2 + f;
+    }
+    const float sa = a.conj_a ? -1.f : 1.f, sb = a.conj_b ? -1.f : 1.f;
+    v4f dr[RB][2], di[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) dr[rb][cb] = di[rb][cb] = (v4f)(0.f);
+
+    // DEPTH steps of operands are in flight: a wavefront holds 128 accumulators, so one (two at RB = 4) lives
+    // on a SIMD and nothing else hides the ~2000-cycle load latency behind the 512 MFMA cycles of a step
+    const int T = a.T1 * a.T2;
+    long aoff = 0, boff = 0;       // offsets of the next step to request
+    int t2 = 0, tl = 0;
+    cx<float> av[DEPTH][RB], bw[DEPTH][2];
+    auto request = [&](int s) {
+        if (tl < T) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) av[s][rb] = ap[rb][aoff];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) bw[s][cb] = bp[cb][boff];
+        }
+        ++tl;
+        if (++t2 == a.T2) {
+            t2 = 0;
+            aoff += a.sa_t1 - (long)(a.T2 - 1) * a.sa_t2;
+            boff += a.sb_t1 - (long)(a.T2 - 1) * a.sb_t2;
+        } else {
+            aoff += a.sa_t2;
+            boff += a.sb_t2;
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s) request(s);
+    for (int t0 = 0; t0 < T; t0 += DEPTH) {
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            if (t0 + s < T) {                        // uniform
+                float bx[2], by[2];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    bx[cb] = bw[s][cb].x * bm[cb];
+                    by[cb] = bw[s][cb].y * (sb * bm[cb]);
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) {
+                    const float ax = av[s][rb].x * am[rb], ay = av[s][rb].y * (sa * am[rb]), nay = -ay;
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        dr[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(ax, bx[cb], dr[rb][cb], 0, 0, 0);
+                        di[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(ax, by[cb], di[rb][cb], 0, 0, 0);
+                        dr[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(nay, by[cb], dr[rb][cb], 0, 0, 0);
+                        di[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(ay, bx[cb], di[rb][cb], 0, 0, 0);
+                    }
+                }
+                request(s);
+            }
+        }
+    }
+    if (!fv) return;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = rt * 4 * RB + 4 * rb + v;
+                if (bv[cb] && i < a.NI) a.D[doff[cb] + (long)i * a.sd_i] = cx<float>(a.scale * dr[rb][cb][v], a.scale * di[rb][cb][v]);
+            }
+}
+
+// The same product with operands staged through LDS.  In the kernel above a wavefront's 16 bins are one 128-byte
+// piece per plane, and the planes of a 32 x 32 matrix are 1.5 MB apart: HBM sees scattered 128-byte requests
+// and delivers 2.2 TB/s whatever the prefetch depth.  Here a workgroup owns 64 adjacent bins and a 16 x 16 tile
+// of the output: every wavefront loads whole 512-byte rows of a plane (as the lane-per-bin kernels do), the
+// 16 + 16 operand planes of a contraction step sit in LDS ([plane][64 bins], double-buffered, one barrier per
+// step), and wavefront w feeds its MFMAs for bins 16w..16w+15 from there: lane (bin, q) reads plane 4rb+q.
+// Plane rows are padded to 80 elements so the four q of a read land in different bank halves.
+// WB bin groups of 16 x WC column parts = the 4 wavefronts; a wavefront accumulates (4 RBW) rows x (4 CBW) columns.
+//   <4,1,4,4>: 64 bins, 16 x 16 output tile;   <2,2,8,4>: 32 bins, 32 x 32 tile (each operand element is loaded
+//   once per 32 output columns/rows instead of once per 16: the kernel is bound by bytes per CU, ~10 B/cycle)
+template <int WB, int WC, int RBW, int CBW>
+__global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
+    constexpr int BINS = 16 * WB, PST = BINS + 16, RT = 4 * RBW, CT = 4 * CBW * WC, PPP = 256 / BINS;   // planes per pass
+    constexpr int NPA = RT / PPP, NPB = CT / PPP;
+    static_assert(WB * WC == 4 && RT % PPP == 0 && CT % PPP == 0, "tile shape");
+    __shared__ cx<float> sA[2][RT][PST], sB[2][CT][PST];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 3, bl = lane >> 2;
+    // XCD-aware order: the nrt*nct tiles of one bin tile run back to back on one XCD and share its L2
+    const int inner = a.nrt * a.nct;
+    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+    const int bt = (r / inner) * 8 + xcd, rem = r % inner;
+    if ((long)bt * BINS >= a.M) return;               // uniform over the workgroup, before any barrier
+    const int rt = rem / a.nct, ct = rem % a.nct;
+    const int ncols = a.J1 * a.J2;
+    // ---- loader role: thread (lp, lb) fetches bin bt*BINS+lb of planes lp, lp+PPP, ... of A and of B
+    const int lb = tid % BINS, lp = tid / BINS;
+    const int fl = min(bt * BINS + lb, a.M - 1);
+    const cx<float>* ga[NPA];
+    const cx<float>* gb[NPB];
+    float ma[NPA], mb[NPB];
+#pragma unroll
+    for (int i = 0; i < NPA; ++i) {
+        const int row = rt * RT + lp + PPP * i;
+        ma[i] = row < a.NI ? 1.f : 0.f;
+        ga[i] = a.A + (long)fl * a.sa_f + (long)(row < a.NI ? row : 0) * a.sa_i;
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int col = ct * CT + lp + PPP * i;
+        const bool cv = col < ncols;
+        const int j1 = cv ? col / a.J2 : 0, j2 = cv ? col - j1 * a.J2 : 0;
+        mb[i] = cv ? 1.f : 0.f;
+        gb[i] = a.B + (long)j1 * a.sb_j1 + (long)j2 * a.sb_j2 + fl;
+    }
+    const float sga = a.conj_a ? -1.f : 1.f, sgb = a.conj_b ? -1.f : 1.f;
+    const int T = a.T1 * a.T2;
+    long aoff = 0, boff = 0;
+    int t2 = 0;
+    cx<float> ra[NPA], rb_[NPB];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) ra[i] = ga[i][aoff];
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) rb_[i] = gb[i][boff];
+        if (++t2 == a.T2) {
+            t2 = 0;
+            aoff += a.sa_t1 - (long)(a.T2 - 1) * a.sa_t2;
+            boff += a.sb_t1 - (long)(a.T2 - 1) * a.sb_t2;
+        } else {
+            aoff += a.sa_t2;
+            boff += a.sb_t2;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) sA[buf][lp + PPP * i][lb] = cx<float>(ra[i].x * ma[i], ra[i].y * (sga * ma[i]));
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) sB[buf][lp + PPP * i][lb] = cx<float>(rb_[i].x * mb[i], rb_[i].y * (sgb * mb[i]));
+    };
+    v4f dr[RBW][CBW], di[RBW][CBW];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) dr[rb][cb] = di[rb][cb] = (v4f)(0.f);
+    fetch();
+    stage(0);
+    if (T > 1) fetch();
+    __syncthreads();
+    const int g = w % WB, h = w / WB;
+    const int bin = 16 * g + bl;
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        cx<float> av[RBW], bv[CBW];
+#pragma unroll
+        for (int k = 0; k < RBW; ++k) av[k] = sA[buf][4 * k + q][bin];
+#pragma unroll
+        for (int k = 0; k < CBW; ++k) bv[k] = sB[buf][h * 4 * CBW + 4 * k + q][bin];
+        if (t + 1 < T) stage(buf ^ 1);            // step t+1: fetched during step t-1, free to overwrite (read in t-1)
+        if (t + 2 < T) fetch();                   // step t+2 in flight across the MFMAs below
+        // two sweeps over the accumulator tiles: the second update of a tile is far behind the first
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                dr[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rb].x, bv[cb].x, dr[rb][cb], 0, 0, 0);
+                di[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rb].x, bv[cb].y, di[rb][cb], 0, 0, 0);
+            }
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) {
+            const float nay = -av[rb].y;
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb) {
+                dr[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(nay, bv[cb].y, dr[rb][cb], 0, 0, 0);
+                di[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[rb].y, bv[cb].x, di[rb][cb], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const int f = bt * BINS + bin;
+    if (f >= a.M) return;
+#pragma unroll
+    for (int cb = 0; cb < CBW; ++cb) {
+        const int col = ct * CT + h * 4 * CBW + 4 * cb + q;
+        if (col >= ncols) continue;
+        const int j1 = col / a.J2, j2 = col - j1 * a.J2;
+        cx<float>* d = a.D + (long)j1 * a.sd_j1 + (long)j2 * a.sd_j2 + f;
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = rt * RT + 4 * rb + v;
+                if (i < a.NI) d[(long)i * a.sd_i] = cx<float>(a.scale * dr[rb][cb][v], a.scale * di[rb][cb][v]);
+            }
+    }
+}
+
+static int g_mfma_enabled = 1, g_mfma_rb = 0, g_mfma_depth = 0;   // tuning: row blocks per wavefront, prefetch depth
+
+// rows >= 16, >= 8 output columns and a contraction >= 8: below that the product is HBM-bound and the
+// 512-byte-per-plane accesses of the lane-per-bin kernels serve it better
+static bool mfma_applies(int rows, int cols, int depth) { return g_mfma_enabled && rows >= 16 && cols >= 8 && depth >= 8; }
+
+static int launch_mfma(MmaArgs a, hipStream_t st) {
+    if (g_mfma_rb == 0 || g_mfma_rb == 1) {   // operands through LDS
+        const bool wide = g_mfma_rb == 0 && a.NI > 16 && a.J1 * a.J2 > 16;
+        const int rtile = wide ? 32 : 16, ctile = wide ? 32 : 16, bins = wide ? 32 : 64;
+        a.nrt = cdiv_i(a.NI, rtile);
+        a.nct = cdiv_i(a.J1 * a.J2, ctile);
+        const long nb = (long)cdiv_i(cdiv_i(a.M, bins), 8) * 8 * a.nrt * a.nct;
+        FL_REQUIRE(nb < (1ll << 31), "mimo: grid too large");
+        if (wide) hipLaunchKernelGGL((mimo_mfma_lds_kernel<2, 2, 8, 4>), dim3((unsigned)nb), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((mimo_mfma_lds_kernel<4, 1, 4, 4>), dim3((unsigned)nb), dim3(256), 0, st, a);
+        FL_CHECK_LAUNCH("mimo_mfma_lds");
+        return FL_OK;
+    }
+    const int rbn = g_mfma_rb;
+    a.nrt = cdiv_i(a.NI, 4 * rbn);
+    a.nct = cdiv_i(a.J1 * a.J2, 8);
+    const long waves = (long)cdiv_i(a.M, 16) * a.nrt * a.nct;
+    const long nblk = (waves + 3) / 4;
+    FL_REQUIRE(nblk < (1ll << 31), "mimo: grid too large");
+    const int depth = g_mfma_depth ? g_mfma_depth : 4;
+#define FL_MFMA_CASE(RB_, D_) \
+    if (rbn == RB_ && depth == D_) hipLaunchKernelGGL((mimo_mfma_kernel<RB_, D_>), dim3((unsigned)nblk), dim3(256), 0, st, a);
+    FL_MFMA_CASE(8, 4) FL_MFMA_CASE(8, 2) FL_MFMA_CASE(8, 6) FL_MFMA_CASE(4, 4) FL_MFMA_CASE(4, 2) FL_MFMA_CASE(4, 6)
+#undef FL_MFMA_CASE
+    FL_CHECK_LAUNCH("mimo_mfma");
+    return FL_OK;
+}
+
 // ---------------------------------------------------------------- host dispatch
 static int g_mimo_variant = 0;   // tuning hook: mt*100 + bt*10 + nu (0 = default choice)
 
@@ -172,6 +465,16 @@ static int mimo_impl(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
     FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo: bad sizes");
     if (B == 0 || M == 0) return FL_OK;
     const int ncols = B * K;
+    if constexpr (sizeof(T) == 4) {
+        if (g_mimo_variant == 0 && mfma_applies(No, ncols, Ni)) {
+            MmaArgs a = {};
+            a.A = (const cx<float>*)H; a.sa_f = hs_f; a.sa_i = hs_m; a.sa_t1 = 0; a.sa_t2 = hs_n; a.conj_a = conj_h;
+            a.B = (const cx<float>*)X; a.sb_j1 = xs_b; a.sb_j2 = xs_k; a.sb_t1 = 0; a.sb_t2 = xs_n; a.conj_b = 0;
+            a.D = (cx<float>*)Y; a.sd_i = ys_m; a.sd_j1 = ys_b; a.sd_j2 = ys_k; a.scale = 1.f;
+            a.M = M; a.NI = No; a.J1 = B; a.J2 = K; a.T1 = 1; a.T2 = Ni;
+            return launch_mfma(a, (hipStream_t)stream);
+        }
+    }
     int bt = ncols >= 4 ? 4 : (ncols >= 2 ? 2 : 1);
     int mt = No >= 8 ? 8 : (No >= 4 ? 4 : (No >= 2 ? 2 : 1));
     int nu = 1;
@@ -230,6 +533,16 @@ static int gradh_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
     FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo_gradh: bad sizes");
     if (M == 0) return FL_OK;
     hipStream_t st = (hipStream_t)stream;
+    if constexpr (sizeof(T) == 4) {
+        if (g_mimo_variant == 0 && mfma_applies(No, Ni, B * K)) {
+            MmaArgs a = {};
+            a.A = (const cx<float>*)G; a.sa_f = 1; a.sa_i = gs_m; a.sa_t1 = gs_b; a.sa_t2 = gs_k; a.conj_a = 0;
+            a.B = (const cx<float>*)X; a.sb_j1 = 0; a.sb_j2 = xs_n; a.sb_t1 = xs_b; a.sb_t2 = xs_k; a.conj_b = 1;
+            a.D = (cx<float>*)dH; a.sd_i = (long)Ni * dh_pitch; a.sd_j1 = 0; a.sd_j2 = dh_pitch; a.scale = (float)scale;
+            a.M = M; a.NI = No; a.J1 = 1; a.J2 = Ni; a.T1 = B; a.T2 = K;
+            return launch_mfma(a, st);
+        }
+    }
     if (No >= 4 && Ni >= 4) {
         dim3 grid(cdiv_i(M, 256), cdiv_i(No, 4), cdiv_i(Ni, 4));
         FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradh: too many channels");
@@ -380,6 +693,13 @@ extern "C" {
 
 int fl_mimo_gradw_blocks(int M) { return gradw_blocks(M); }
 int fl_debug_set_mimo_variant(int variant, int gradw_cap) {
+    g_mfma_enabled = variant != -1;        // -1: lane-per-bin kernels everywhere (default tiles)
+    g_mfma_rb = g_mfma_depth = 0;
+    if (variant <= -10) {                  // -(10*rb + depth): MFMA kernel with that tile / prefetch depth
+        g_mfma_rb = (-variant) / 10;
+        g_mfma_depth = (-variant) % 10;
+    }
+    if (variant < 0) variant = 0;
     g_mimo_variant = variant;
     g_gradw_cap = gradw_cap;
     return FL_OK;

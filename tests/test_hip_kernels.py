@@ -20,7 +20,10 @@ def test_transpose_bit_exact(gpu, shape):
 
 
 @pytest.mark.parametrize("No,Ni,K,B", [(1, 1, 1, 1), (3, 2, 1, 5), (8, 8, 1, 32), (5, 7, 3, 2), (16, 16, 16, 1),
-                                       (32, 32, 1, 3), (1, 16, 1, 4), (16, 1, 1, 4)])
+                                       (32, 32, 1, 3), (1, 16, 1, 4), (16, 1, 1, 4),
+                                       # matrix-valued signals on the MFMA kernels: full, ragged rows/columns/depth,
+                                       # batched columns, both tile shapes (<= 16 and > 16 rows or columns)
+                                       (32, 32, 32, 1), (20, 9, 11, 2), (16, 24, 8, 1), (33, 17, 5, 4), (40, 32, 36, 1)])
 def test_mimo_shapes_against_einsum(gpu, No, Ni, K, B):
     from flamo_amd import ops
     torch.manual_seed(No * 100 + Ni)
@@ -404,3 +407,27 @@ def test_eigvals_large_and_degenerate(gpu):
     with torch.no_grad():
         l = ops.eigvals(torch.stack([eye, jordan, nil]).to(gpu)).cpu()
     assert (l[0] - 1).abs().max() < 1e-12 and (l[1] - 0.5).abs().max() < 1e-6 and l[2].abs().max() < 1e-6
+
+
+def test_mimo_mfma_matches_lane_kernels(gpu):
+    """The MFMA kernels (matrix-valued signals) against the lane-per-bin kernels on the same data, bins not a
+    multiple of the 32/64-bin workgroup tiles: forward, adjoint and the per-bin matrix gradient."""
+    from flamo_amd import _lib, ops
+    L = _lib.lib()
+    torch.manual_seed(11)
+    M = 1000 + 37
+    for No, Ni, B, K in ((32, 32, 1, 32), (24, 16, 2, 10), (16, 8, 1, 16)):
+        H = torch.randn(M, No, Ni, dtype=torch.complex64, device=gpu, requires_grad=True)
+        X = torch.randn(B, M, Ni, K, dtype=torch.complex64, device=gpu, requires_grad=True)
+        C = torch.randn(B, M, No, K, dtype=torch.complex64, device=gpu)
+        out = {}
+        try:
+            for v in (0, -1, -14):       # default (LDS-staged, wide tile where it applies), lane kernels, 16x16 tile
+                L.fl_debug_set_mimo_variant(v, 0)
+                Y = ops.mimo(H, X)
+                out[v] = (Y.detach(),) + torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C))), [H, X])
+        finally:
+            L.fl_debug_set_mimo_variant(0, 0)
+        for v in (0, -14):
+            for got, ref in zip(out[v], out[-1]):
+                assert relerr(got.cpu(), ref.cpu()) < 1e-6
