@@ -179,6 +179,7 @@ struct MmaArgs {
     long sb_j1, sb_j2, sb_t1, sb_t2;
     cx<float>* D;
     long sd_i, sd_j1, sd_j2;
+    cx<float>* part;     // non-null: sum over bins instead of storing D -- one (NI x J) partial per bin-tile slot
     float scale;
     int conj_a, conj_b;
     int M, NI, J1, J2, T1, T2, nct, nrt;
@@ -303,23 +304,45 @@ __global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
     static_assert(WB * WC == 4 && RT % PPP == 0 && CT % PPP == 0, "tile shape");
     __shared__ cx<float> sA[2][RT][PST], sB[2][CT][PST];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 3, bl = lane >> 2;
-    // XCD-aware order: the nrt*nct tiles of one bin tile run back to back on one XCD and share its L2
+    // XCD-aware order: the nrt*nct tiles of one bin tile run back to back on one XCD and share its L2.
+    // Reduction mode: a workgroup walks bin tiles bt0, bt0 + slots, ... and keeps accumulating.
     const int inner = a.nrt * a.nct;
-    const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
-    const int bt = (r / inner) * 8 + xcd, rem = r % inner;
+    const bool red = a.part != nullptr;
+    int bt, rem, slots;
+    if (red) {
+        bt = blockIdx.x / inner;
+        rem = blockIdx.x % inner;
+        slots = gridDim.x / inner;
+    } else {
+        const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
+        bt = (r / inner) * 8 + xcd;
+        rem = r % inner;
+        slots = 1 << 30;
+    }
+    const int bt0 = bt;
     if ((long)bt * BINS >= a.M) return;               // uniform over the workgroup, before any barrier
     const int rt = rem / a.nct, ct = rem % a.nct;
     const int ncols = a.J1 * a.J2;
-    // ---- loader role: thread (lp, lb) fetches bin bt*BINS+lb of planes lp, lp+PPP, ... of A and of B
-    const int lb = tid % BINS, lp = tid / BINS;
+    const int lb = tid % BINS, lp = tid / BINS;       // loader role: bin lb of planes lp, lp+PPP, ... of A and of B
+    const int g = w % WB, h = w / WB;                 // MFMA role: bin group g, column part h
+    const int bin = 16 * g + bl;
+    const float sga = a.conj_a ? -1.f : 1.f, sgb = a.conj_b ? -1.f : 1.f;
+    const int T = a.T1 * a.T2;
+    v4f dr[RBW][CBW], di[RBW][CBW];
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb) dr[rb][cb] = di[rb][cb] = (v4f)(0.f);
+  for (; (long)bt * BINS < a.M; bt += slots) {
     const int fl = min(bt * BINS + lb, a.M - 1);
+    const float binm = (bt * BINS + lb < a.M) ? 1.f : 0.f;      // bins past the end add nothing to a bin sum
     const cx<float>* ga[NPA];
     const cx<float>* gb[NPB];
     float ma[NPA], mb[NPB];
 #pragma unroll
     for (int i = 0; i < NPA; ++i) {
         const int row = rt * RT + lp + PPP * i;
-        ma[i] = row < a.NI ? 1.f : 0.f;
+        ma[i] = row < a.NI ? binm : 0.f;
         ga[i] = a.A + (long)fl * a.sa_f + (long)(row < a.NI ? row : 0) * a.sa_i;
     }
 #pragma unroll
@@ -330,8 +353,6 @@ __global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
         mb[i] = cv ? 1.f : 0.f;
         gb[i] = a.B + (long)j1 * a.sb_j1 + (long)j2 * a.sb_j2 + fl;
     }
-    const float sga = a.conj_a ? -1.f : 1.f, sgb = a.conj_b ? -1.f : 1.f;
-    const int T = a.T1 * a.T2;
     long aoff = 0, boff = 0;
     int t2 = 0;
     cx<float> ra[NPA], rb_[NPB];
@@ -355,17 +376,10 @@ __global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
 #pragma unroll
         for (int i = 0; i < NPB; ++i) sB[buf][lp + PPP * i][lb] = cx<float>(rb_[i].x * mb[i], rb_[i].y * (sgb * mb[i]));
     };
-    v4f dr[RBW][CBW], di[RBW][CBW];
-#pragma unroll
-    for (int rb = 0; rb < RBW; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < CBW; ++cb) dr[rb][cb] = di[rb][cb] = (v4f)(0.f);
     fetch();
     stage(0);
     if (T > 1) fetch();
     __syncthreads();
-    const int g = w % WB, h = w / WB;
-    const int bin = 16 * g + bl;
     for (int t = 0; t < T; ++t) {
         const int buf = t & 1;
         cx<float> av[RBW], bv[CBW];
@@ -394,6 +408,7 @@ __global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
         }
         __syncthreads();
     }
+    if (red) continue;
     const int f = bt * BINS + bin;
     if (f >= a.M) return;
 #pragma unroll
@@ -410,6 +425,38 @@ __global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
                 if (i < a.NI) d[(long)i * a.sd_i] = cx<float>(a.scale * dr[rb][cb][v], a.scale * di[rb][cb][v]);
             }
     }
+    return;
+  }
+    // ---- reduction mode: every accumulator holds 16 per-block (bin mod 16) sums, one per lane group of 4; fold
+    // them (fixed butterfly: deterministic), then the WB bin groups through LDS, and write this slot's partial
+    cx<float>(*sred)[RT][CT + 1] = reinterpret_cast<cx<float>(*)[RT][CT + 1]>(&sA[0][0][0]);
+    static_assert(sizeof(cx<float>) * WB * RT * (CT + 1) <= sizeof(sA), "partials fit in the operand buffer");
+#pragma unroll
+    for (int rb = 0; rb < RBW; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float x = dr[rb][cb][v], y = di[rb][cb][v];
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) {
+                    x += __shfl_xor(x, off, 64);
+                    y += __shfl_xor(y, off, 64);
+                }
+                if (bl == 0) sred[g][4 * rb + v][h * 4 * CBW + 4 * cb + q] = cx<float>(x, y);
+            }
+    __syncthreads();
+    for (int e = tid; e < RT * CT; e += 256) {
+        const int i = e / CT, j = e % CT;
+        float x = 0.f, y = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < WB; ++gg) {
+            x += sred[gg][i][j].x;
+            y += sred[gg][i][j].y;
+        }
+        const int row = rt * RT + i, col = ct * CT + j;
+        if (row < a.NI && col < ncols) a.part[((size_t)bt0 * a.NI + row) * ncols + col] = cx<float>(a.scale * x, a.scale * y);
+    }
 }
 
 static int g_mfma_enabled = 1, g_mfma_rb = 0, g_mfma_depth = 0;   // tuning: row blocks per wavefront, prefetch depth
@@ -418,17 +465,19 @@ static int g_mfma_enabled = 1, g_mfma_rb = 0, g_mfma_depth = 0;   // tuning: row
 // 512-byte-per-plane accesses of the lane-per-bin kernels serve it better
 static bool mfma_applies(int rows, int cols, int depth) { return g_mfma_enabled && rows >= 16 && cols >= 8 && depth >= 8; }
 
-static int launch_mfma(MmaArgs a, hipStream_t st) {
-    if (g_mfma_rb == 0 || g_mfma_rb == 1) {   // operands through LDS
-        const bool wide = g_mfma_rb == 0 && a.NI > 16 && a.J1 * a.J2 > 16;
+static int launch_mfma(MmaArgs a, hipStream_t st, int red_slots = 0, int* slots_used = nullptr) {
+    if (g_mfma_rb == 0 || g_mfma_rb == 1 || a.part) {   // operands through LDS
+        const bool wide = g_mfma_rb != 1 && a.NI > 16 && a.J1 * a.J2 > 16;
         const int rtile = wide ? 32 : 16, ctile = wide ? 32 : 16, bins = wide ? 32 : 64;
         a.nrt = cdiv_i(a.NI, rtile);
         a.nct = cdiv_i(a.J1 * a.J2, ctile);
-        const long nb = (long)cdiv_i(cdiv_i(a.M, bins), 8) * 8 * a.nrt * a.nct;
+        long nb = (long)cdiv_i(cdiv_i(a.M, bins), 8) * 8 * a.nrt * a.nct;
+        if (a.part) nb = (long)min(red_slots, cdiv_i(a.M, bins)) * a.nrt * a.nct;   // red_slots bin-tile slots
         FL_REQUIRE(nb < (1ll << 31), "mimo: grid too large");
         if (wide) hipLaunchKernelGGL((mimo_mfma_lds_kernel<2, 2, 8, 4>), dim3((unsigned)nb), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((mimo_mfma_lds_kernel<4, 1, 4, 4>), dim3((unsigned)nb), dim3(256), 0, st, a);
         FL_CHECK_LAUNCH("mimo_mfma_lds");
+        if (slots_used) *slots_used = (int)(nb / (a.nrt * a.nct));
         return FL_OK;
     }
     const int rbn = g_mfma_rb;
@@ -668,6 +717,23 @@ static int gradw_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
     FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo_gradw: bad sizes");
     // 8x8 tiles where the matrix allows: every element of G and X is then read No/8 (Ni/8) times
     // instead of No/4 -- at N = 32 with matrix-valued signals that is 12 GB instead of 25 GB per launch
+    if constexpr (sizeof(T) == 4) {
+        if (g_mimo_variant == 0 && mfma_applies(No, Ni, B * K)) {
+            // per-bin outer products on the matrix cores, summed over bins in the accumulators (mimo_mfma_lds_kernel)
+            MmaArgs a = {};
+            a.A = (const cx<float>*)G; a.sa_f = 1; a.sa_i = gs_m; a.sa_t1 = gs_b; a.sa_t2 = gs_k; a.conj_a = 0;
+            a.B = (const cx<float>*)X; a.sb_j1 = 0; a.sb_j2 = xs_n; a.sb_t1 = xs_b; a.sb_t2 = xs_k; a.conj_b = 1;
+            a.part = (cx<float>*)part; a.scale = 1.f;
+            a.M = M; a.NI = No; a.J1 = 1; a.J2 = Ni; a.T1 = B; a.T2 = K;
+            int slots = 0;
+            int rc = launch_mfma(a, (hipStream_t)stream, gradw_blocks(M), &slots);
+            if (rc) return rc;
+            hipLaunchKernelGGL((mimo_gradw_final_kernel<T>), dim3(cdiv_i((long)No * Ni, 4)), dim3(256), 0, (hipStream_t)stream,
+                               (const cx<T>*)part, slots, No * Ni, (cx<T>*)dW);
+            FL_CHECK_LAUNCH("mimo_gradw_final");
+            return FL_OK;
+        }
+    }
     const bool big = No >= 8 && Ni >= 8 && sizeof(T) == 4;
     const int tm = big ? 8 : 4;
     dim3 grid(gradw_blocks(M), cdiv_i(No, tm), cdiv_i(Ni, tm));

@@ -431,3 +431,15 @@ def test_mimo_mfma_matches_lane_kernels(gpu):
         for v in (0, -14):
             for got, ref in zip(out[v], out[-1]):
                 assert relerr(got.cpu(), ref.cpu()) < 1e-6
+        # frequency-independent matrix: its gradient is the per-bin outer product summed over bins in the accumulators
+        W = torch.randn(No, Ni, dtype=torch.complex64, device=gpu, requires_grad=True)
+        gw = {}
+        try:
+            for v in (0, -1):
+                L.fl_debug_set_mimo_variant(v, 0)
+                Y = ops.mimo(W, X)
+                gw[v] = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C))), [W])[0]
+        finally:
+            L.fl_debug_set_mimo_variant(0, 0)
+        ref = torch.einsum("bfmk,bfnk->mn", C.cpu().to(torch.complex128), X.detach().cpu().to(torch.complex128).conj())
+        assert relerr(gw[0].cpu(), ref) < 2e-6 and relerr(gw[-1].cpu(), ref) < 2e-6

@@ -44,10 +44,10 @@ __global__ void __launch_bounds__(256) rate_kernel(float* out, int iters) {
 }
 
 template <int KIND>
-void run(const char* name, double flop_per_instr, int per_round) {
+void run(const char* name, double flop_per_instr, int per_round, int blocks = 2048) {
     float* out;
     hipMalloc(&out, 4096 * 256 * sizeof(float));
-    const int iters = 4000, blocks = 2048;
+    const int iters = 4000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -60,8 +60,9 @@ void run(const char* name, double flop_per_instr, int per_round) {
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double instr = (double)blocks * 4 * iters * per_round;
-    printf("%-12s %8.3f ms  %7.1f TFLOP/s  (%.1f cycles per instruction per SIMD at 2.4 GHz, 1024 SIMDs)\n", name, ms,
-           instr * flop_per_instr / (ms * 1e-3) / 1e12, ms * 1e-3 * 2.4e9 / (instr / 1024));
+    const double simds = blocks >= 256 ? 1024 : blocks * 4;
+    printf("%-12s blocks %5d %8.3f ms  %7.1f TFLOP/s  (%.1f cycles per instruction per SIMD at 2.4 GHz)\n", name, blocks, ms,
+           instr * flop_per_instr / (ms * 1e-3) / 1e12, ms * 1e-3 * 2.4e9 / (instr / simds));
     hipFree(out);
 }
 
@@ -70,5 +71,8 @@ int main() {
     run<1>("16x16x4", 2048, 8);
     run<2>("32x32x2", 4096, 4);
     run<3>("v_pk_fma_f32", 256, 16);
+    run<0>("4x4x1_16b", 512, 8, 256);      // one workgroup per CU: one wavefront per SIMD
+    run<1>("16x16x4", 2048, 8, 256);
+    run<3>("v_pk_fma_f32", 256, 16, 256);
     return 0;
 }

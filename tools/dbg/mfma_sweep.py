@@ -33,3 +33,19 @@ for v in (-1, 0, -14):
         t = e0.elapsed_time(e1) / 10 * 1e-3
         print(f"variant {v:4d} adj={int(adj)}: {t * 1e6:8.1f} us  {flop / t / 1e12:6.1f} TFLOP/s  {byt / t / 1e12:5.2f} TB/s")
 L.fl_debug_set_mimo_variant(0, 0)
+# constant-matrix gradient (sum over bins): MFMA reduction against the lane-per-bin reduction
+Gp = ops.to_planar(torch.randn(1, M, N, N, dtype=torch.complex64, device=dev))
+for v in (-1, 0):
+    L.fl_debug_set_mimo_variant(v, 0)
+    for _ in range(2):
+        ops._gradw_launch(Gp, Xp)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        ops._gradw_launch(Gp, Xp)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / 10 * 1e-3
+    print(f"gradw variant {v:3d}: {t * 1e6:8.1f} us  {flop / t / 1e12:6.1f} TFLOP/s  {2 * 8.0 * N * N * M / t / 1e12:5.2f} TB/s")
+L.fl_debug_set_mimo_variant(0, 0)
