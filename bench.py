@@ -32,10 +32,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 NFFT, NCH, BATCH = 96000, 8, 32
-# HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r01j_pmc_hbm_traffic.csv,
+# HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r01k_pmc_hbm_traffic.csv,
 # grid 393216 = the batch-32 launch): 2*FETCH_SIZE + WRITE_SIZE.  A static number measured by rocprofv3,
 # not re-measured by every bench run.
-PMC_TRAFFIC_BYTES = 223.7e6
+PMC_TRAFFIC_BYTES = 222.5e6
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -228,7 +228,7 @@ def main():
                               f"{roof_steps} single-stream eager steps run by this command right after the timed graph replays, "
                               "each timed launch queued behind ~0.2 ms of streaming copies so that it starts from a busy queue and memory system"),
                     "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per "
-                                      "MI355X_MICROARCH.md; profiles/r01j_pmc_hbm_traffic.csv"}
+                                      "MI355X_MICROARCH.md; profiles/r01k_pmc_hbm_traffic.csv"}
         out = {"metric": "freq-bin*channel products/sec (fwd+bwd), nfft=96000 8x8ch", "value": products_per_step / (ms * 1e-3),
                "unit": "products/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -14,7 +14,14 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fdn_stats -o r -- python $ROOT/tools/bench_fdn.py --dtype f32 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_stats -o r -- python $ROOT/tools/bench_fdn.py --workload config5 --dtype f32 --steps 5 > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -o r -- python $ROOT/tools/train_colorless_fdn.py --steps 20 --warmup 2 > /dev/null 2>&1
+# matrix-core activity of the config-5 chain (its own pass: counters only)
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/c5_pmc -o r -- python $ROOT/tools/bench_fdn.py --workload config5 --dtype f32 --steps 2 > /dev/null 2>&1
 cd $ROOT
+python tools/bench_fdn.py --workload config5 --dtype f32 --steps 8 2>/dev/null | tail -1 > $OUT/config5.json
+python tools/train_colorless_fdn.py --steps 50 2>/dev/null | tail -1 > $OUT/colorless.json
+python tools/train_colorless_fdn.py --steps 200 --graph 2>/dev/null | tail -1 > $OUT/colorless_graph.json
 python tools/bench_fdn.py 2>/dev/null | tail -1 > $OUT/fdn_b1.json
 python tools/bench_fdn.py --batch 8 2>/dev/null | tail -1 > $OUT/fdn_b8.json
 rm -f $OUT/*/r_kernel_trace.csv.bak

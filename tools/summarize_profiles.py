@@ -31,8 +31,24 @@ def main():
     shutil.copy(os.path.join(SRC, "stats", "r_kernel_stats.csv"), os.path.join(DST, f"{tag}_bench_kernel_stats_rocprofv3.csv"))
     if os.path.exists(os.path.join(SRC, "fdn_stats", "r_kernel_stats.csv")):
         shutil.copy(os.path.join(SRC, "fdn_stats", "r_kernel_stats.csv"), os.path.join(DST, f"{tag}_fdn_kernel_stats_rocprofv3.csv"))
+    for sub, name in (("c5_stats", "config5"), ("c4_stats", "colorless")):
+        if os.path.exists(os.path.join(SRC, sub, "r_kernel_stats.csv")):
+            shutil.copy(os.path.join(SRC, sub, "r_kernel_stats.csv"), os.path.join(DST, f"{tag}_{name}_kernel_stats_rocprofv3.csv"))
+    mf = os.path.join(SRC, "c5_pmc", "r_counter_collection.csv")
+    if os.path.exists(mf):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(mf)):
+            if "fl::" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        with open(os.path.join(DST, f"{tag}_config5_pmc_sq.csv"), "w", newline="") as fh:
+            wr = csv.writer(fh)
+            names = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
+            wr.writerow(["kernel", "launches"] + [n + "_per_launch" for n in names])
+            for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("SQ_BUSY_CYCLES", [0]))):
+                n = max(len(x) for x in v.values())
+                wr.writerow([k[:120], n] + ["%.0f" % (sum(v.get(c, [0])) / max(len(v.get(c, [1])), 1)) for c in names])
     fdn = {}
-    for name in ("fdn_b1", "fdn_b8"):
+    for name in ("fdn_b1", "fdn_b8", "config5", "colorless", "colorless_graph"):
         p = os.path.join(SRC, name + ".json")
         if os.path.exists(p) and os.path.getsize(p):
             fdn[name] = json.load(open(p))
