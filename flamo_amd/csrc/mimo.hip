@@ -183,6 +183,7 @@ struct MmaArgs {
     float scale;
     int conj_a, conj_b;
     int M, NI, J1, J2, T1, T2, nct, nrt;
+    int vec_store;       // 16-byte stores through LDS (D and its strides 16-byte aligned)
 };
 
 template <int RB, int DEPTH>
@@ -302,7 +303,9 @@ __global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
     constexpr int BINS = 16 * WB, PST = BINS + 16, RT = 4 * RBW, CT = 4 * CBW * WC, PPP = 256 / BINS;   // planes per pass
     constexpr int NPA = RT / PPP, NPB = CT / PPP;
     static_assert(WB * WC == 4 && RT % PPP == 0 && CT % PPP == 0, "tile shape");
-    __shared__ cx<float> sA[2][RT][PST], sB[2][CT][PST];
+    __shared__ __attribute__((aligned(16))) cx<float> smem[2 * (RT + CT) * PST];
+    cx<float>(*sA)[RT][PST] = reinterpret_cast<cx<float>(*)[RT][PST]>(smem);
+    cx<float>(*sB)[CT][PST] = reinterpret_cast<cx<float>(*)[CT][PST]>(smem + 2 * RT * PST);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, q = lane & 3, bl = lane >> 2;
     // XCD-aware order: the nrt*nct tiles of one bin tile run back to back on one XCD and share its L2.
     // Reduction mode: a workgroup walks bin tiles bt0, bt0 + slots, ... and keeps accumulating.
@@ -409,6 +412,48 @@ __global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
         __syncthreads();
     }
     if (red) continue;
+    if (a.vec_store) {
+        // The output tile leaves through LDS: the accumulator layout gives a store instruction 128-byte pieces of
+        // four planes at 8 bytes per lane, and the 1.6 GB result was half of the kernel's time (store issue, not
+        // bandwidth).  Per row block: 4 rows x CT columns = 4 CT planes of BINS bins are written to LDS, then
+        // every thread stores 16 bytes (two bins) of a plane row -- whole rows of 256/512 bytes per plane.
+        constexpr int OPS = BINS + 2, HB = BINS / 2, PPS = 256 / HB, NPASS = 4 * CT / PPS;
+        static_assert(4 * CT * OPS <= 2 * (RT + CT) * PST, "output block fits in the operand buffer");
+        cx<float>(*sO)[OPS] = reinterpret_cast<cx<float>(*)[OPS]>(smem);
+        const int pl = tid / HB, bp = tid % HB;
+        const int f0 = bt * BINS + 2 * bp;
+        long dcol[NPASS];
+        bool cvv[NPASS];
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const int col = ct * CT + (pl + PPS * i) % CT;
+            cvv[i] = col < ncols;
+            const int j1 = cvv[i] ? col / a.J2 : 0, j2 = cvv[i] ? col - j1 * a.J2 : 0;
+            dcol[i] = (long)j1 * a.sd_j1 + (long)j2 * a.sd_j2 + f0;
+        }
+#pragma unroll
+        for (int rb = 0; rb < RBW; ++rb) {
+#pragma unroll
+            for (int cb = 0; cb < CBW; ++cb)
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    sO[v * CT + h * 4 * CBW + 4 * cb + q][bin] = cx<float>(a.scale * dr[rb][cb][v], a.scale * di[rb][cb][v]);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < NPASS; ++i) {
+                const int p = pl + PPS * i;
+                const int row = rt * RT + 4 * rb + p / CT;
+                if (cvv[i] && row < a.NI && f0 < a.M) {
+                    const float4 val = *reinterpret_cast<const float4*>(&sO[p][2 * bp]);
+                    cx<float>* d = a.D + dcol[i] + (long)row * a.sd_i;
+                    if (f0 + 1 < a.M) *reinterpret_cast<float4*>(d) = val;
+                    else *d = cx<float>(val.x, val.y);
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int f = bt * BINS + bin;
     if (f >= a.M) return;
 #pragma unroll
@@ -429,8 +474,8 @@ __global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
   }
     // ---- reduction mode: every accumulator holds 16 per-block (bin mod 16) sums, one per lane group of 4; fold
     // them (fixed butterfly: deterministic), then the WB bin groups through LDS, and write this slot's partial
-    cx<float>(*sred)[RT][CT + 1] = reinterpret_cast<cx<float>(*)[RT][CT + 1]>(&sA[0][0][0]);
-    static_assert(sizeof(cx<float>) * WB * RT * (CT + 1) <= sizeof(sA), "partials fit in the operand buffer");
+    cx<float>(*sred)[RT][CT + 1] = reinterpret_cast<cx<float>(*)[RT][CT + 1]>(smem);
+    static_assert(WB * RT * (CT + 1) <= 2 * (RT + CT) * PST, "partials fit in the operand buffer");
 #pragma unroll
     for (int rb = 0; rb < RBW; ++rb)
 #pragma unroll
@@ -459,6 +504,7 @@ __global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
     }
 }
 
+static int g_mfma_vec = 1;   // tuning: 0 = direct 8-byte stores from the accumulator layout
 static int g_mfma_enabled = 1, g_mfma_rb = 0, g_mfma_depth = 0;   // tuning: row blocks per wavefront, prefetch depth
 
 // rows >= 16, >= 8 output columns and a contraction >= 8: below that the product is HBM-bound and the
@@ -473,6 +519,7 @@ static int launch_mfma(MmaArgs a, hipStream_t st, int red_slots = 0, int* slots_
         a.nct = cdiv_i(a.J1 * a.J2, ctile);
         long nb = (long)cdiv_i(cdiv_i(a.M, bins), 8) * 8 * a.nrt * a.nct;
         if (a.part) nb = (long)min(red_slots, cdiv_i(a.M, bins)) * a.nrt * a.nct;   // red_slots bin-tile slots
+        a.vec_store = !a.part && g_mfma_vec && ((uintptr_t)a.D % 16 == 0) && a.sd_i % 2 == 0 && a.sd_j1 % 2 == 0 && a.sd_j2 % 2 == 0;
         FL_REQUIRE(nb < (1ll << 31), "mimo: grid too large");
         if (wide) hipLaunchKernelGGL((mimo_mfma_lds_kernel<2, 2, 8, 4>), dim3((unsigned)nb), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((mimo_mfma_lds_kernel<4, 1, 4, 4>), dim3((unsigned)nb), dim3(256), 0, st, a);
@@ -767,6 +814,8 @@ int fl_debug_set_mimo_variant(int variant, int gradw_cap) {
     }
     if (variant < 0) variant = 0;
     g_mimo_variant = variant;
+    g_mfma_vec = gradw_cap != -2;          // gradw_cap -2: direct stores in the MFMA kernels
+    if (gradw_cap < 0) gradw_cap = 0;
     g_gradw_cap = gradw_cap;
     return FL_OK;
 }
