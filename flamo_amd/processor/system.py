@@ -294,10 +294,43 @@ class Recursion(nn.Module):
             if dud is not None:
                 # FDN structure: P = diag(l) U diag(r) stays factored, A = I - P is built in registers
                 return ops.solve_dud(dud[0], dud[1], dud[2], R)
+            P = self.__composed_loop(R)
+            if P is not None:
+                return ops.solve(P, R, one_minus=True)
         # generic loop: P = F(B(I)) for ONE batch element (it does not depend on the batch)
         I = self.__identity_like(R)
         P = self.feedforward(self.feedback(I, ext_fb), ext_ff)
         return ops.solve(P, R, one_minus=True)
+
+    def __loop_chain(self):
+        """The per-bin modules of feedback-then-feedforward in the order they act on the identity, or None if
+        some module is not a plain per-bin product."""
+        chain = []
+        for path in (self.feedback, self.feedforward):
+            mods = list(path) if isinstance(path, Series) else [path]
+            for m in mods:
+                if isinstance(m, Series):
+                    return None
+                if not (hasattr(m, "_fusable") and m._fusable()):
+                    return None
+                chain.append(m)
+        return chain
+
+    def __composed_loop(self, R):
+        """P[f] = F[f] B[f] from the modules' responses (the Series planner's composition) instead of pushing a
+        (1, M, N, N) identity through them: the first module's product with the identity is its own response --
+        one 1.6 GB product and its backward less at N = 32, nfft = 384000."""
+        chain = self.__loop_chain()
+        if chain is None:
+            return None
+        M = R.shape[1]
+        shape = [1, M, self.output_channels, self.output_channels]
+        acc = None
+        for m in chain:
+            resp = m._response_for_fusion(shape, None)
+            shape[2] = m.output_channels
+            acc = resp if acc is None else _compose(acc, resp, M)
+        return _as_signal(acc[0], acc[1], M)
 
     def __factored_loop(self, R):
         """If feedback-then-feedforward is a chain of per-bin modules with exactly one full,

@@ -186,6 +186,49 @@ def test_factored_fdn_loop_matches_generic_recursion(gpu):
                 assert relerr(a, b) < tol
 
 
+def test_composed_loop_matches_identity_recursion(gpu):
+    """Loops that are not diag-U-diag -- a per-bin full matrix (Delay(N,N), FIR Filter) or two full matrices in
+    the loop -- take P from the composition of the modules' responses; against the reference's way (push the
+    identity through feedback and feedforward): outputs and every gradient, vector and matrix inputs."""
+    from collections import OrderedDict
+    from flamo_amd.processor import dsp, system
+    torch.manual_seed(19)
+    nfft = 480
+    M = nfft // 2 + 1
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, 3e-5)):
+        kw = dict(nfft=nfft, alias_decay_db=30.0, device=gpu, dtype=dt)
+        for N, case in ((5, "delay"), (4, "fir"), (17, "two_matrices")):
+            gain = dsp.parallelGain(size=(N,), requires_grad=True, **kw)
+            mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+            with torch.no_grad():
+                gain.param.copy_(torch.rand(N, device=gpu, dtype=dt) * 0.4 / N ** 0.5 + 0.05)
+            if case == "delay":
+                full = dsp.Delay(size=(N, N), max_len=60, isint=True, **kw)
+            elif case == "fir":
+                full = dsp.Filter(size=(7, N, N), requires_grad=True, **kw)
+                with torch.no_grad():
+                    full.param.mul_(0.3)
+            else:
+                full = dsp.Matrix(size=(N, N), matrix_type="random", requires_grad=True, **kw)
+                with torch.no_grad():
+                    full.param.mul_(0.5 / N ** 0.5)
+            rec = system.Recursion(fF=system.Series(OrderedDict(d=full, g=gain)), fB=mix)
+            params = [p for p in rec.parameters() if p.requires_grad]
+            for shape in ((2, M, N), (1, M, N, N)):
+                X = torch.randn(*shape, dtype=CDT[dt], device=gpu, requires_grad=True)
+                C = torch.randn(*shape, dtype=CDT[dt], device=gpu)
+                res = {}
+                for fuse in (True, False):
+                    system.FUSE_SERIES = fuse
+                    try:
+                        Y = rec(X)
+                        res[fuse] = [Y.detach()] + list(torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C))), [X] + params))
+                    finally:
+                        system.FUSE_SERIES = True
+                for a, b in zip(res[True], res[False]):
+                    assert relerr(a, b) < tol, (case, shape)
+
+
 def test_graphed_step_matches_eager(gpu):
     """A forward+backward step replayed from a HIP graph gives the same loss and gradients as eager."""
     from collections import OrderedDict
