@@ -132,8 +132,8 @@ class DSP(nn.Module):
         self.dtype = dtype
         self.param = nn.Parameter(torch.empty(self.size, device=device, dtype=dtype), requires_grad=requires_grad)
         # transforms along dim 0 (taps -> response), on the same HIP FFT as the signal path
-        self.fft = lambda x: ops.rfft(x.unsqueeze(0), self.nfft)[0]
-        self.ifft = lambda x: ops.irfft(x.unsqueeze(0), self.nfft)[0]
+        self.fft = lambda x: ops.rfft(x.unsqueeze(0), self.nfft).squeeze(0)
+        self.ifft = lambda x: ops.irfft(x.unsqueeze(0), self.nfft).squeeze(0)
         self.alias_decay_db = torch.tensor(alias_decay_db, device=device, dtype=dtype)
         self.init_param()
         self.get_gamma()

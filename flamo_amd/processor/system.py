@@ -75,7 +75,7 @@ def _compose(acc, nxt, M: int):
         Bm = torch.diag_embed(H1) if d1 else H1
         return A @ Bm, False
     if not d1 and bin1:                                       # per-bin full on the right: left-multiply it
-        return ops.mimo(H2, H1.unsqueeze(0), diag=d2)[0], False
+        return ops.mimo(H2, H1.unsqueeze(0), diag=d2).squeeze(0), False   # squeeze, not [0]: select_backward zero-fills and copies the whole tensor
     if not d2 and bin2:                                       # per-bin full on the left: right-multiply it
         S2 = H2.permute(1, 0, 2)                              # (N_out, M, N_mid): rows of H2 as batch items
         R = ops.mimo(H1, S2, diag=True) if d1 else ops.mimo(H1.transpose(-1, -2), S2)
