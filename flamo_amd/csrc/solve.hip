@@ -315,15 +315,22 @@ __device__ inline void opaque(cx<float>& v) {
 }
 __device__ inline void opaque(cx<double>& v) { asm("" : "+v"(v.x), "+v"(v.y)); }
 
-template <typename T, int NMAX>
+// LANES lanes per bin, RPL rows per lane: row s*LANES + g of A lives in slot s of lane g, NMAX = LANES * RPL.
+// RPL = 1 is the layout described above (N <= 16).  RPL = 2 (16 < N <= 32, float) keeps the 16-lane DPP row as the
+// group -- a 32-lane group has no one-instruction broadcast -- and every broadcast of a pivot-row element now
+// feeds two row updates; which slot holds the pivot (K / LANES) and which slots still have rows below it are
+// known at compile time, so finished slots drop out of the update loops altogether.
+template <typename T, int LANES, int RPL>
 __global__ void __launch_bounds__(256) solve_inplace_kernel(
     const cx<T>* __restrict__ P, long p_pitch, Dud<T> dud, int one_minus, int adjoint,
     const cx<T>* __restrict__ R, long rs_b, long rs_n, long rs_k,
     cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
     int B, int M, int N, int K) {
-    constexpr int BPB = 256 / NMAX;
-    const int gi = threadIdx.x % NMAX;
-    const int f = blockIdx.x * BPB + threadIdx.x / NMAX;
+    constexpr int NMAX = LANES * RPL, BPB = 256 / LANES;
+    const int thr_steps = adjoint >> 8;     // tuning: exponent steps of the pivot threshold (host passes >= 1)
+    adjoint &= 1;
+    const int gi = threadIdx.x % LANES;
+    const int f = blockIdx.x * BPB + threadIdx.x / LANES;
     // the frequency-independent mixing matrix, zero-padded to NMAX x NMAX (and transposed for the adjoint
     // system), staged once per workgroup: the row build below reads it with compile-time offsets, no guards
     __shared__ cx<T> Us[NMAX * NMAX];
@@ -336,117 +343,264 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
         }
         __syncthreads();
     }
+    cx<T> row[RPL][NMAX];
+    if constexpr (LANES == 16) {
+        if (P) {
+            // A materialised P is read through LDS: with a row per lane a load instruction touches 16 planes x 4
+            // bins (32-byte pieces of planes ~1 MB apart).  Here the 256 threads fetch CR matrix rows (columns for
+            // the adjoint system) of the block's 16 bins with 16 consecutive threads on one plane (128 bytes), park
+            // them in LDS and the four lanes that own those rows pick them up.  Every thread stays for the barriers.
+            constexpr int CR = 4, NLD = CR * NMAX / 16;
+            __shared__ cx<T> Pt[CR][NMAX][17];
+            const int lb = threadIdx.x % 16;
+            const int fl = min(blockIdx.x * BPB + lb, M - 1);
+            const T sgn = one_minus ? (T)-1 : (T)1;
+            static_for<0, NMAX / CR>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                cx<T> v[NLD];
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int e = threadIdx.x / 16 + 16 * i;          // (row in chunk, column)
+                    const int pr = e / NMAX, pj = e % NMAX, ri = c * CR + pr;
+                    cx<T> x(0, 0);
+                    if (ri < N && pj < N) {
+                        x = P[(adjoint ? (long)pj * N + ri : (long)ri * N + pj) * p_pitch + fl];
+                        x = cx<T>(sgn * x.x, (adjoint ? -sgn : sgn) * x.y);
+                    }
+                    if (one_minus ? (pj == ri) : (pj == ri && ri >= N)) x.x += (T)1;
+                    v[i] = x;
+                }
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    const int e = threadIdx.x / 16 + 16 * i;
+                    Pt[e / NMAX][e % NMAX][lb] = v[i];
+                }
+                __syncthreads();
+                constexpr int S = (c * CR) / LANES;                   // the slot these rows live in
+                if ((gi >> 2) == ((c * CR) % LANES) / 4) {
+#pragma unroll
+                    for (int j = 0; j < NMAX; ++j) row[S][j] = Pt[gi & 3][j][threadIdx.x / 16];
+                }
+                __syncthreads();
+            });
+        }
+    }
     if (f >= M) return;  // whole lane group leaves together; no exchange below crosses a group
 
-    // ---- load (or build) this lane's row of A; rows and columns >= N are those of the identity
-    cx<T> row[NMAX];
+    // ---- load (or build) this lane's rows of A; rows and columns >= N are those of the identity
     if (P) {
-        const int gr = min(gi, N - 1);                       // padded lanes read a valid row and discard it
-        const cx<T>* p = adjoint ? P + (long)gr * p_pitch + f : P + (long)gr * N * p_pitch + f;
-        const long step = adjoint ? (long)N * p_pitch : p_pitch;
-        const T sgn = one_minus ? (T)-1 : (T)1;
+      if constexpr (LANES != 16) {
 #pragma unroll
-        for (int j = 0; j < NMAX; ++j) {
-            cx<T> v(0, 0);
-            if (j < N) {                                     // uniform
-                v = p[(long)j * step];
-                v = cx<T>(sgn * v.x, (adjoint ? -sgn : sgn) * v.y);
-                v.x = gi < N ? v.x : (T)0;
-                v.y = gi < N ? v.y : (T)0;
+        for (int s = 0; s < RPL; ++s) {
+            const int ri = s * LANES + gi;
+            const int gr = min(ri, N - 1);                   // padded rows read a valid row and discard it
+            const cx<T>* p = adjoint ? P + (long)gr * p_pitch + f : P + (long)gr * N * p_pitch + f;
+            const long step = adjoint ? (long)N * p_pitch : p_pitch;
+            const T sgn = one_minus ? (T)-1 : (T)1;
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j) {
+                cx<T> v(0, 0);
+                if (j < N) {                                 // uniform
+                    v = p[(long)j * step];
+                    v = cx<T>(sgn * v.x, (adjoint ? -sgn : sgn) * v.y);
+                    v.x = ri < N ? v.x : (T)0;
+                    v.y = ri < N ? v.y : (T)0;
+                }
+                if (one_minus ? (j == ri) : (j == ri && ri >= N)) v.x += (T)1;
+                row[s][j] = v;
             }
-            if (one_minus ? (j == gi) : (j == gi && gi >= N)) v.x += (T)1;
-            row[j] = v;
         }
+      }
     } else {
         // A[i][j] = delta_ij - l_i U_ij r_j ;  A^H[i][j] = delta_ij - conj(r_i) conj(U_ji) conj(l_j)
         const cx<T> one(1, 0);
-        cx<T> lv = one, rv = one;
-        if (gi < N) {
-            if (dud.l) lv = dud.l[(long)gi * dud.l_sn + (long)f * dud.l_sf];
-            if (dud.r) rv = dud.r[(long)gi * dud.r_sn + (long)f * dud.r_sf];
+        cx<T> own[RPL], oth[RPL];
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int ri = s * LANES + gi;
+            cx<T> lv = one, rv = one;
+            if (ri < N) {
+                if (dud.l) lv = dud.l[(long)ri * dud.l_sn + (long)f * dud.l_sf];
+                if (dud.r) rv = dud.r[(long)ri * dud.r_sn + (long)f * dud.r_sf];
+            }
+            own[s] = adjoint ? conj(rv) : lv;
+            oth[s] = adjoint ? conj(lv) : rv;
         }
-        const cx<T> own = adjoint ? conj(rv) : lv;
-        const cx<T> oth = adjoint ? conj(lv) : rv;
-        const cx<T>* urow = Us + gi * NMAX;
         static_for<0, NMAX>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
-            const cx<T> v = own * urow[J] * group_bcast<NMAX, J>(oth);
-            row[J] = cx<T>((J == gi ? (T)1 : (T)0) - v.x, -v.y);
+            const cx<T> oj = group_bcast<LANES, J % LANES>(oth[J / LANES]);
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) {
+                const int ri = s * LANES + gi;
+                const cx<T> v = own[s] * Us[ri * NMAX + J] * oj;
+                row[s][J] = cx<T>((J == ri ? (T)1 : (T)0) - v.x, -v.y);
+            }
         });
     }
 
     // ---- LU, threshold partial pivoting, rows exchanged in place
-    int orig = gi;          // which row of A (= which entry of the right-hand side) this lane holds
-    cx<T> dinv(0, 0);       // reciprocal of this lane's pivot
+    int orig[RPL];          // which row of A (= which entry of the right-hand side) each slot holds
+    cx<T> dinv[RPL];        // reciprocal of each slot's pivot
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) {
+        orig[s] = s * LANES + gi;
+        dinv[s] = cx<T>(0, 0);
+    }
     static_for<0, NMAX>([&](auto kc) {
         constexpr int KK = decltype(kc)::value;
+        constexpr int SK = KK / LANES, LK = KK % LANES;       // slot and lane of the diagonal
         if constexpr (KK < NMAX - 1) {
-            const float mag = (gi >= KK) ? (float)(fabs(row[KK].x) + fabs(row[KK].y)) : -1.0f;
-            // non-negative floats order like their bit patterns; the low bits carry NMAX-1-lane so that the
-            // lowest lane wins among (nearly) equal magnitudes, as icamax would pick
-            const int key = (__builtin_bit_cast(int, mag) & ~(NMAX - 1)) | (NMAX - 1 - gi);
-            int kmax = key;
-            if constexpr (NMAX >= 16) kmax = max(kmax, dpp_mov<DPP_ROW_MIRROR>(kmax));
-            if constexpr (NMAX >= 8) kmax = max(kmax, dpp_mov<DPP_HALF_MIRROR>(kmax));
+            // non-negative floats order like their bit patterns; the low bits carry NMAX-1-row so that the lowest
+            // row wins among (nearly) equal magnitudes, as icamax would pick.  Rows above K are no candidates:
+            // whole slots below SK, and the lanes below LK of slot SK.
+            int dkey = 0, kmax = (int)0x80000000;
+#pragma unroll
+            for (int s = SK; s < RPL; ++s) {
+                const int ri = s * LANES + gi;
+                float mag = (float)(fabs(row[s][KK].x) + fabs(row[s][KK].y));
+                if (s == SK) mag = (gi >= LK) ? mag : -1.0f;
+                const int key = (__builtin_bit_cast(int, mag) & ~(NMAX - 1)) | (NMAX - 1 - ri);
+                if (s == SK) dkey = key;
+                kmax = max(kmax, key);
+            }
+            if constexpr (LANES >= 16) kmax = max(kmax, dpp_mov<DPP_ROW_MIRROR>(kmax));
+            if constexpr (LANES >= 8) kmax = max(kmax, dpp_mov<DPP_HALF_MIRROR>(kmax));
             kmax = max(kmax, dpp_mov<DPP_QUAD_XOR2>(kmax));
             kmax = max(kmax, dpp_mov<DPP_QUAD_XOR1>(kmax));
             // keep the diagonal unless it is more than 2x smaller than the column maximum: a factor 2 is one
             // exponent step, i.e. 1 << 23 on the bit pattern (denormal magnitudes compare conservatively)
-            const bool exchange = group_bcast<NMAX, KK>(key) + (1 << 23) < kmax;
+            const bool exchange = group_bcast<LANES, LK>(dkey) + (thr_steps << 23) < kmax;
             if (__any(exchange)) {      // uniform over the wavefront; groups that keep their diagonal map to themselves
                 const int best = NMAX - 1 - (kmax & (NMAX - 1));
-                const int partner = exchange ? (gi == KK ? best : (gi == best ? KK : gi)) : gi;
+                const int lb = best % LANES, sb = best / LANES;
+                const int src = exchange ? (gi == LK ? lb : (gi == lb ? LK : gi)) : gi;
+                const bool atk = exchange & (gi == LK), atb = exchange & (gi == lb);
 #pragma unroll
-                for (int j = 0; j < NMAX; ++j) row[j] = shfl_cx(row[j], partner, NMAX);
-                orig = __shfl(orig, partner, NMAX);
+                for (int j = 0; j < NMAX; ++j) {
+                    cx<T> q[RPL];
+#pragma unroll
+                    for (int s = 0; s < RPL; ++s) q[s] = shfl_cx(row[s][j], src, LANES);
+                    cx<T> from_b = q[0];
+#pragma unroll
+                    for (int s = 1; s < RPL; ++s) {
+                        from_b.x = (sb == s) ? q[s].x : from_b.x;
+                        from_b.y = (sb == s) ? q[s].y : from_b.y;
+                    }
+#pragma unroll
+                    for (int s = 0; s < RPL; ++s) {
+                        cx<T> v = row[s][j];
+                        if (s == SK) {
+                            v.x = atk ? from_b.x : v.x;
+                            v.y = atk ? from_b.y : v.y;
+                        }
+                        const bool tb = atb & (sb == s);
+                        v.x = tb ? q[SK].x : v.x;
+                        v.y = tb ? q[SK].y : v.y;
+                        row[s][j] = v;
+                    }
+                }
+                {
+                    int q[RPL];
+#pragma unroll
+                    for (int s = 0; s < RPL; ++s) q[s] = __shfl(orig[s], src, LANES);
+                    int from_b = q[0];
+#pragma unroll
+                    for (int s = 1; s < RPL; ++s) from_b = (sb == s) ? q[s] : from_b;
+#pragma unroll
+                    for (int s = 0; s < RPL; ++s) {
+                        int v = orig[s];
+                        if (s == SK) v = atk ? from_b : v;
+                        v = (atb & (sb == s)) ? q[SK] : v;
+                        orig[s] = v;
+                    }
+                }
             }
             // values merged from the two paths are opaque from here on: InstCombine otherwise walks the chain of
-            // 15 two-way merges per register recursively (compile time doubles with every step)
+            // two-way merges per register recursively (compile time doubles with every step)
 #pragma unroll
-            for (int j = 0; j < NMAX; ++j) opaque(row[j]);
-            asm("" : "+v"(orig));
+            for (int s = 0; s < RPL; ++s) {
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j) opaque(row[s][j]);
+                asm("" : "+v"(orig[s]));
+            }
         }
-        const cx<T> inv = crecip_fast(group_bcast<NMAX, KK>(row[KK]));
-        const bool below = gi > KK;
-        cx<T> l = row[KK] * inv;
-        l.x = below ? l.x : (T)0;
-        l.y = below ? l.y : (T)0;
-        const auto lm = cmul_of(l);
+        const cx<T> inv = crecip_fast(group_bcast<LANES, LK>(row[SK][KK]));
+        // rows below K: the lanes above LK of slot SK, and every later slot
+        cx<T> l[RPL];
+#pragma unroll
+        for (int s = SK; s < RPL; ++s) {
+            l[s] = row[s][KK] * inv;
+            if (s == SK) {
+                l[s].x = (gi > LK) ? l[s].x : (T)0;
+                l[s].y = (gi > LK) ? l[s].y : (T)0;
+            }
+        }
         static_for<KK + 1, NMAX>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
-            row[J] = cfnma(row[J], lm, group_bcast<NMAX, KK>(row[J]));
+            const cx<T> pr = group_bcast<LANES, LK>(row[SK][J]);
+#pragma unroll
+            for (int s = SK; s < RPL; ++s) row[s][J] = cfnma(row[s][J], cmul_of(l[s]), pr);
         });
-        row[KK].x = below ? l.x : row[KK].x;
-        row[KK].y = below ? l.y : row[KK].y;
-        dinv.x = (gi == KK) ? inv.x : dinv.x;
-        dinv.y = (gi == KK) ? inv.y : dinv.y;
+#pragma unroll
+        for (int s = SK; s < RPL; ++s) {
+            if (s == SK) {
+                row[s][KK].x = (gi > LK) ? l[s].x : row[s][KK].x;
+                row[s][KK].y = (gi > LK) ? l[s].y : row[s][KK].y;
+            } else {
+                row[s][KK] = l[s];
+            }
+        }
+        dinv[SK].x = (gi == LK) ? inv.x : dinv[SK].x;
+        dinv[SK].y = (gi == LK) ? inv.y : dinv[SK].y;
     });
 
-    // ---- apply to every right-hand side: lane k ends up with x_k
+    // ---- apply to every right-hand side: slot s of lane g ends up with x_{s*LANES+g}
     const int ncols = B * K;
     for (int col = 0; col < ncols; ++col) {
         const int b = col / K, kk = col - b * K;
-        cx<T> y(0, 0);
-        if (gi < N) y = R[(long)b * rs_b + (long)orig * rs_n + (long)kk * rs_k + f];
+        cx<T> y[RPL];
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            y[s] = cx<T>(0, 0);
+            if (s * LANES + gi < N) y[s] = R[(long)b * rs_b + (long)orig[s] * rs_n + (long)kk * rs_k + f];
+        }
         static_for<0, NMAX - 1>([&](auto kc) {          // forward: y_i -= L[i][k] y_k, i > k
             constexpr int KK = decltype(kc)::value;
-            const cx<T> m((gi > KK) ? row[KK].x : (T)0, (gi > KK) ? row[KK].y : (T)0);
-            y = cfnma(y, cmul_of(m), group_bcast<NMAX, KK>(y));
+            constexpr int SK = KK / LANES, LK = KK % LANES;
+            const cx<T> yk = group_bcast<LANES, LK>(y[SK]);
+#pragma unroll
+            for (int s = SK; s < RPL; ++s) {
+                cx<T> m = row[s][KK];
+                if (s == SK) m = cx<T>((gi > LK) ? m.x : (T)0, (gi > LK) ? m.y : (T)0);
+                y[s] = cfnma(y[s], cmul_of(m), yk);
+            }
         });
         static_for<0, NMAX>([&](auto kc) {              // back: x_k = y_k / U[k][k];  y_i -= U[i][k] x_k, i < k
             constexpr int KK = NMAX - 1 - decltype(kc)::value;
-            const cx<T> yd = y * dinv;
-            y.x = (gi == KK) ? yd.x : y.x;
-            y.y = (gi == KK) ? yd.y : y.y;
+            constexpr int SK = KK / LANES, LK = KK % LANES;
+            const cx<T> yd = y[SK] * dinv[SK];
+            y[SK].x = (gi == LK) ? yd.x : y[SK].x;
+            y[SK].y = (gi == LK) ? yd.y : y[SK].y;
             if constexpr (KK > 0) {
-                const cx<T> m((gi < KK) ? row[KK].x : (T)0, (gi < KK) ? row[KK].y : (T)0);
-                y = cfnma(y, cmul_of(m), group_bcast<NMAX, KK>(y));
+                const cx<T> xk = group_bcast<LANES, LK>(y[SK]);
+#pragma unroll
+                for (int s = 0; s <= SK; ++s) {
+                    cx<T> m = row[s][KK];
+                    if (s == SK) m = cx<T>((gi < LK) ? m.x : (T)0, (gi < LK) ? m.y : (T)0);
+                    y[s] = cfnma(y[s], cmul_of(m), xk);
+                }
             }
         });
-        if (gi < N) OUT[(long)b * os_b + (long)gi * os_n + (long)kk * os_k + f] = y;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int ri = s * LANES + gi;
+            if (ri < N) OUT[(long)b * os_b + (long)ri * os_n + (long)kk * os_k + f] = y[s];
+        }
     }
 }
 
+static int g_solve_rpl2_p = 0;    // tuning: variant 3 = two-rows-per-lane kernel also for a materialised P
+static int g_solve_thr = 1;       // pivot threshold 2^-thr (tuning: variant 10 + thr)
 static int g_solve_variant = 0;   // tuning hook: 1 forces the shuffle kernel for every N
 
 template <typename T, int NMAX>
@@ -454,12 +608,21 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
                         void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, hipStream_t st) {
     constexpr int BPB = 256 / NMAX;
     dim3 grid(cdiv_i(M, BPB));
-    if constexpr (NMAX <= 16) {
-        if (g_solve_variant == 0) {
-            hipLaunchKernelGGL((solve_inplace_kernel<T, NMAX>), grid, dim3(256), 0, st, (const cx<T>*)P, p_pitch, dud, one_minus,
-                               adjoint, (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);
+    if (g_solve_variant == 0) {
+        if constexpr (NMAX <= 16) {
+            hipLaunchKernelGGL((solve_inplace_kernel<T, NMAX, 1>), grid, dim3(256), 0, st, (const cx<T>*)P, p_pitch, dud, one_minus,
+                               adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);
             FL_CHECK_LAUNCH("solve");
             return FL_OK;
+        } else if constexpr (NMAX == 32 && sizeof(T) == 4) {    // two rows per lane, 16 lanes per bin
+            // (a materialised P keeps the shuffle kernel for now: its row-per-lane loads are 32-byte pieces here)
+            if (!P || g_solve_rpl2_p) {
+                hipLaunchKernelGGL((solve_inplace_kernel<T, 16, 2>), dim3(cdiv_i(M, 16)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
+                                   dud, one_minus, adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b,
+                                   os_n, os_k, B, M, N, K);
+                FL_CHECK_LAUNCH("solve");
+                return FL_OK;
+            }
         }
     }
     hipLaunchKernelGGL((solve_kernel<T, NMAX>), grid, dim3(256), 0, st, (const cx<T>*)P, p_pitch, dud, one_minus, adjoint,
@@ -496,6 +659,13 @@ using namespace fl;
 
 extern "C" {
 int fl_debug_set_solve_variant(int variant) {
+    g_solve_thr = 1;
+    g_solve_rpl2_p = variant == 3;
+    if (variant == 3) variant = 0;
+    if (variant >= 10) {          // 10 + t: in-place kernels with pivot threshold 2^-t
+        g_solve_thr = variant - 10;
+        variant = 0;
+    }
     g_solve_variant = variant;
     return FL_OK;
 }

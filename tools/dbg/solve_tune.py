@@ -29,7 +29,7 @@ def main():
     L = _lib.lib()
     torch.manual_seed(0)
     for real, cd in ((torch.float32, torch.complex64), (torch.float64, torch.complex128)):
-        for N, M in [(int(a), 96001) for a in os.environ.get("SOLVE_NS", "4,8,16").split(",")]:
+        for N, M in [(int(a), 96001) for a in os.environ.get("SOLVE_NS", "4,8,16,32").split(",")]:
             U = torch.linalg.qr(torch.randn(N, N, dtype=torch.float64))[0].to(dev, cd)
             l = (0.98 * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64))).to(dev, cd)
             R = torch.randn(1, M, N, dtype=cd, device=dev)
