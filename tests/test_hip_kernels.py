@@ -486,3 +486,44 @@ def test_mimo_mfma_matches_lane_kernels(gpu):
             L.fl_debug_set_mimo_variant(0, 0)
         ref = torch.einsum("bfmk,bfnk->mn", C.cpu().to(torch.complex128), X.detach().cpu().to(torch.complex128).conj())
         assert relerr(gw[0].cpu(), ref) < 2e-6 and relerr(gw[-1].cpu(), ref) < 2e-6
+
+
+@pytest.mark.parametrize("N", [3, 8, 13, 16, 17, 24, 32])
+def test_factored_solve_all_sizes_and_row_exchanges(gpu, N):
+    """(I - diag(l) U diag(r))^-1 R through fl_solve_dud_* for every kernel shape (4/8/16 lanes per bin, two rows per
+    lane above 16), with loops that never exchange rows (damped orthogonal) and loops that must (U = 3 x a
+    permutation with a zero diagonal + noise: the diagonal of I - P is far below the column maximum at every
+    step), forward and gradients (the adjoint solve), float32 and float64, against LAPACK in float64."""
+    from flamo_amd import _lib, ops
+    torch.manual_seed(100 + N)
+    M = 203
+    for cd, tol in ((torch.complex128, 1e-11), (torch.complex64, 2e-5)):
+        for kind in ("orthogonal", "permutation"):
+            if kind == "orthogonal":
+                U64 = torch.linalg.qr(torch.randn(N, N, dtype=torch.float64))[0].to(torch.complex128)
+                l64 = 0.97 * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64))
+            else:
+                perm = torch.roll(torch.arange(N), 1)
+                U64 = (3.0 * torch.eye(N, dtype=torch.float64)[perm] + 0.05 * torch.randn(N, N, dtype=torch.float64)).to(torch.complex128)
+                l64 = torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64))
+            r64 = (0.8 + 0.2 * torch.rand(N, dtype=torch.float64)).to(torch.complex128)
+            R64 = torch.randn(2, M, N, dtype=torch.complex128)
+            C64 = torch.randn(2, M, N, dtype=torch.complex128)
+            ref_in = [t.clone().requires_grad_(True) for t in (l64, U64, r64, R64)]
+            A = torch.eye(N, dtype=torch.complex128) - ref_in[0].unsqueeze(-1) * ref_in[1] * ref_in[2]
+            Yr = torch.linalg.solve(A.unsqueeze(0), ref_in[3].unsqueeze(-1)).squeeze(-1)
+            gr = torch.autograd.grad(torch.sum(torch.real(Yr * torch.conj(C64))), ref_in)
+            dev_in = [t.detach().to(gpu, cd).requires_grad_(True) for t in (l64, U64, r64, R64)]
+            outs = {}
+            try:
+                for variant in (0, 1):      # in-place kernels / shuffle kernel
+                    _lib.lib().fl_debug_set_solve_variant(variant)
+                    Y = ops.solve_dud(dev_in[0], dev_in[1], dev_in[2], dev_in[3])
+                    g = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C64.to(gpu, cd)))), dev_in)
+                    outs[variant] = [Y.detach()] + list(g)
+            finally:
+                _lib.lib().fl_debug_set_solve_variant(0)
+            scale = 30.0 if kind == "permutation" else 1.0      # conditioning of the exchanged systems
+            for variant in (0, 1):
+                for got, want in zip(outs[variant], [Yr.detach()] + list(gr)):
+                    assert relerr(got.cpu().to(torch.complex128), want) < tol * scale, (kind, variant)
