@@ -355,9 +355,11 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
             const int lb = threadIdx.x % 16;
             const int fl = min(blockIdx.x * BPB + lb, M - 1);
             const T sgn = one_minus ? (T)-1 : (T)1;
+            // every load of the block is requested before the first is consumed (the row registers are still empty, so
+            // there is room): one memory latency per workgroup instead of one per pass
+            cx<T> pre[NMAX / CR][NLD];
             static_for<0, NMAX / CR>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
-                cx<T> v[NLD];
 #pragma unroll
                 for (int i = 0; i < NLD; ++i) {
                     const int e = threadIdx.x / 16 + 16 * i;          // (row in chunk, column)
@@ -368,12 +370,15 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
                         x = cx<T>(sgn * x.x, (adjoint ? -sgn : sgn) * x.y);
                     }
                     if (one_minus ? (pj == ri) : (pj == ri && ri >= N)) x.x += (T)1;
-                    v[i] = x;
+                    pre[c][i] = x;
                 }
+            });
+            static_for<0, NMAX / CR>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
 #pragma unroll
                 for (int i = 0; i < NLD; ++i) {
                     const int e = threadIdx.x / 16 + 16 * i;
-                    Pt[e / NMAX][e % NMAX][lb] = v[i];
+                    Pt[e / NMAX][e % NMAX][lb] = pre[c][i];
                 }
                 __syncthreads();
                 constexpr int S = (c * CR) / LANES;                   // the slot these rows live in

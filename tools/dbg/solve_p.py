@@ -24,3 +24,19 @@ for N, M in ((16, 96001), (32, 96001), (24, 48001)):
             e1.record(); torch.cuda.synchronize()
             print(f"N={N} M={M} adjoint={int(adj)} variant {v}: {e0.elapsed_time(e1)/5*1e3:8.1f} us  err {err:.1e}")
 L.fl_debug_set_solve_variant(0)
+# the factored loop with the same number of right-hand sides, for reference
+for N, M in ((32, 96001),):
+    U = torch.linalg.qr(torch.randn(N, N, dtype=torch.float64))[0].to(dev, torch.complex64)
+    l = ops._h_planar((0.98 * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64))).to(dev, torch.complex64), True)
+    for B in (1, 2):
+        R = ops.to_planar(torch.randn(B, M, N, dtype=torch.complex64, device=dev))
+        for v in (0, 1):
+            L.fl_debug_set_solve_variant(v)
+            for _ in range(2): ops._solve_dud_launch(l, U, None, False, R)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): ops._solve_dud_launch(l, U, None, False, R)
+            e1.record(); torch.cuda.synchronize()
+            print(f"factored N={N} M={M} B={B} variant {v}: {e0.elapsed_time(e1)/5*1e3:8.1f} us")
+L.fl_debug_set_solve_variant(0)
