@@ -186,111 +186,9 @@ struct MmaArgs {
     int vec_store;       // 16-byte stores through LDS (D and its strides 16-byte aligned)
 };
 
-template <int RB, int DEPTH>
-__global__ void __launch_bounds__(256) mimo_mfma_kernel(MmaArgs a) {
-    const int lane = threadIdx.x & 63, q = lane & 3, bl = lane >> 2;
-    const long wid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int ct = (int)(wid % a.nct);
-    const long r = wid / a.nct;
-    const int rt = (int)(r % a.nrt);
-    const long bg = r / a.nrt;
-    if (bg * 16 >= a.M) return;                       // uniform over the wavefront
-    const int f = (int)(bg * 16) + bl;
-    const bool fv = f < a.M;
-    const int fc = fv ? f : a.M - 1;                  // lanes past the last bin read a valid one and store nothing
-    const cx<float>* ap[RB];
-    float am[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const int i = rt * 4 * RB + 4 * rb + q;
-        am[rb] = i < a.NI ? 1.f : 0.f;
-        ap[rb] = a.A + (long)fc * a.sa_f + (long)(i < a.NI ? i : 0) * a.sa_i;
-    }
-    const cx<float>* bp[2];
-    float bm[2];
-    long doff[2];
-    bool bv[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int col = ct * 8 + cb * 4 + q;
-        bv[cb] = col < a.J1 * a.J2;
-        const int j1 = bv[cb] ? col / a.J2 : 0, j2 = bv[cb] ? col - j1 * a.J2 : 0;
-        bm[cb] = bv[cb] ? 1.f : 0.f;
-        bp[cb] = a.B + (long)j1 * a.sb_j1 + (long)j2 * a.sb_j2 + fc;
-        doff[cb] = (long)j1 * a.sd_j1 + (long)j2 * a.sd_j2 + f;
-    }
-    const float sa = a.conj_a ? -1.f : 1.f, sb = a.conj_b ? -1.f : 1.f;
-    v4f dr[RB][2], di[RB][2];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) dr[rb][cb] = di[rb][cb] = (v4f)(0.f);
-
-    // DEPTH steps of operands are in flight: a wavefront holds 128 accumulators, so one (two at RB = 4) lives
-    // on a SIMD and nothing else hides the ~2000-cycle load latency behind the 512 MFMA cycles of a step
-    const int T = a.T1 * a.T2;
-    long aoff = 0, boff = 0;       // offsets of the next step to request
-    int t2 = 0, tl = 0;
-    cx<float> av[DEPTH][RB], bw[DEPTH][2];
-    auto request = [&](int s) {
-        if (tl < T) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) av[s][rb] = ap[rb][aoff];
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) bw[s][cb] = bp[cb][boff];
-        }
-        ++tl;
-        if (++t2 == a.T2) {
-            t2 = 0;
-            aoff += a.sa_t1 - (long)(a.T2 - 1) * a.sa_t2;
-            boff += a.sb_t1 - (long)(a.T2 - 1) * a.sb_t2;
-        } else {
-            aoff += a.sa_t2;
-            boff += a.sb_t2;
-        }
-    };
-#pragma unroll
-    for (int s = 0; s < DEPTH; ++s) request(s);
-    for (int t0 = 0; t0 < T; t0 += DEPTH) {
-#pragma unroll
-        for (int s = 0; s < DEPTH; ++s) {
-            if (t0 + s < T) {                        // uniform
-                float bx[2], by[2];
-#pragma unroll
-                for (int cb = 0; cb < 2; ++cb) {
-                    bx[cb] = bw[s][cb].x * bm[cb];
-                    by[cb] = bw[s][cb].y * (sb * bm[cb]);
-                }
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) {
-                    const float ax = av[s][rb].x * am[rb], ay = av[s][rb].y * (sa * am[rb]), nay = -ay;
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb) {
-                        dr[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(ax, bx[cb], dr[rb][cb], 0, 0, 0);
-                        di[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(ax, by[cb], di[rb][cb], 0, 0, 0);
-                        dr[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(nay, by[cb], dr[rb][cb], 0, 0, 0);
-                        di[rb][cb] = __builtin_amdgcn_mfma_f32_4x4x1f32(ay, bx[cb], di[rb][cb], 0, 0, 0);
-                    }
-                }
-                request(s);
-            }
-        }
-    }
-    if (!fv) return;
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int i = rt * 4 * RB + 4 * rb + v;
-                if (bv[cb] && i < a.NI) a.D[doff[cb] + (long)i * a.sd_i] = cx<float>(a.scale * dr[rb][cb][v], a.scale * di[rb][cb][v]);
-            }
-}
-
-// The same product with operands staged through LDS.  In the kernel above a wavefront's 16 bins are one 128-byte
-// piece per plane, and the planes of a 32 x 32 matrix are 1.5 MB apart: HBM sees scattered 128-byte requests
-// and delivers 2.2 TB/s whatever the prefetch depth.  Here a workgroup owns 64 adjacent bins and a 16 x 16 tile
+// Operands are staged through LDS.  (A first version fed the MFMAs straight from global memory: a wavefront's 16
+// bins are one 128-byte piece per plane, the planes of a 32 x 32 matrix are 1.5 MB apart, and HBM delivered 2.2 TB/s
+// whatever the prefetch depth.)  A workgroup owns 64 adjacent bins and a 16 x 16 tile
 // of the output: every wavefront loads whole 512-byte rows of a plane (as the lane-per-bin kernels do), the
 // 16 + 16 operand planes of a contraction step sit in LDS ([plane][64 bins], double-buffered, one barrier per
 // step), and wavefront w feeds its MFMAs for bins 16w..16w+15 from there: lane (bin, q) reads plane 4rb+q.
@@ -505,40 +403,25 @@ __global__ void __launch_bounds__(256) mimo_mfma_lds_kernel(MmaArgs a) {
 }
 
 static int g_mfma_vec = 1;   // tuning: 0 = direct 8-byte stores from the accumulator layout
-static int g_mfma_enabled = 1, g_mfma_rb = 0, g_mfma_depth = 0;   // tuning: row blocks per wavefront, prefetch depth
+static int g_mfma_enabled = 1, g_mfma_tile16 = 0;   // tuning: off / always the 64-bin 16x16 tile
 
 // rows >= 16, >= 8 output columns and a contraction >= 8: below that the product is HBM-bound and the
 // 512-byte-per-plane accesses of the lane-per-bin kernels serve it better
 static bool mfma_applies(int rows, int cols, int depth) { return g_mfma_enabled && rows >= 16 && cols >= 8 && depth >= 8; }
 
 static int launch_mfma(MmaArgs a, hipStream_t st, int red_slots = 0, int* slots_used = nullptr) {
-    if (g_mfma_rb == 0 || g_mfma_rb == 1 || a.part) {   // operands through LDS
-        const bool wide = g_mfma_rb != 1 && a.NI > 16 && a.J1 * a.J2 > 16;
-        const int rtile = wide ? 32 : 16, ctile = wide ? 32 : 16, bins = wide ? 32 : 64;
-        a.nrt = cdiv_i(a.NI, rtile);
-        a.nct = cdiv_i(a.J1 * a.J2, ctile);
-        long nb = (long)cdiv_i(cdiv_i(a.M, bins), 8) * 8 * a.nrt * a.nct;
-        if (a.part) nb = (long)min(red_slots, cdiv_i(a.M, bins)) * a.nrt * a.nct;   // red_slots bin-tile slots
-        a.vec_store = !a.part && g_mfma_vec && ((uintptr_t)a.D % 16 == 0) && a.sd_i % 2 == 0 && a.sd_j1 % 2 == 0 && a.sd_j2 % 2 == 0;
-        FL_REQUIRE(nb < (1ll << 31), "mimo: grid too large");
-        if (wide) hipLaunchKernelGGL((mimo_mfma_lds_kernel<2, 2, 8, 4>), dim3((unsigned)nb), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((mimo_mfma_lds_kernel<4, 1, 4, 4>), dim3((unsigned)nb), dim3(256), 0, st, a);
-        FL_CHECK_LAUNCH("mimo_mfma_lds");
-        if (slots_used) *slots_used = (int)(nb / (a.nrt * a.nct));
-        return FL_OK;
-    }
-    const int rbn = g_mfma_rb;
-    a.nrt = cdiv_i(a.NI, 4 * rbn);
-    a.nct = cdiv_i(a.J1 * a.J2, 8);
-    const long waves = (long)cdiv_i(a.M, 16) * a.nrt * a.nct;
-    const long nblk = (waves + 3) / 4;
-    FL_REQUIRE(nblk < (1ll << 31), "mimo: grid too large");
-    const int depth = g_mfma_depth ? g_mfma_depth : 4;
-#define FL_MFMA_CASE(RB_, D_) \
-    if (rbn == RB_ && depth == D_) hipLaunchKernelGGL((mimo_mfma_kernel<RB_, D_>), dim3((unsigned)nblk), dim3(256), 0, st, a);
-    FL_MFMA_CASE(8, 4) FL_MFMA_CASE(8, 2) FL_MFMA_CASE(8, 6) FL_MFMA_CASE(4, 4) FL_MFMA_CASE(4, 2) FL_MFMA_CASE(4, 6)
-#undef FL_MFMA_CASE
-    FL_CHECK_LAUNCH("mimo_mfma");
+    const bool wide = !g_mfma_tile16 && a.NI > 16 && a.J1 * a.J2 > 16;
+    const int rtile = wide ? 32 : 16, ctile = wide ? 32 : 16, bins = wide ? 32 : 64;
+    a.nrt = cdiv_i(a.NI, rtile);
+    a.nct = cdiv_i(a.J1 * a.J2, ctile);
+    long nb = (long)cdiv_i(cdiv_i(a.M, bins), 8) * 8 * a.nrt * a.nct;
+    if (a.part) nb = (long)min(red_slots, cdiv_i(a.M, bins)) * a.nrt * a.nct;   // red_slots bin-tile slots
+    a.vec_store = !a.part && g_mfma_vec && ((uintptr_t)a.D % 16 == 0) && a.sd_i % 2 == 0 && a.sd_j1 % 2 == 0 && a.sd_j2 % 2 == 0;
+    FL_REQUIRE(nb < (1ll << 31), "mimo: grid too large");
+    if (wide) hipLaunchKernelGGL((mimo_mfma_lds_kernel<2, 2, 8, 4>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((mimo_mfma_lds_kernel<4, 1, 4, 4>), dim3((unsigned)nb), dim3(256), 0, st, a);
+    FL_CHECK_LAUNCH("mimo_mfma_lds");
+    if (slots_used) *slots_used = (int)(nb / (a.nrt * a.nct));
     return FL_OK;
 }
 
@@ -807,11 +690,7 @@ extern "C" {
 int fl_mimo_gradw_blocks(int M) { return gradw_blocks(M); }
 int fl_debug_set_mimo_variant(int variant, int gradw_cap) {
     g_mfma_enabled = variant != -1;        // -1: lane-per-bin kernels everywhere (default tiles)
-    g_mfma_rb = g_mfma_depth = 0;
-    if (variant <= -10) {                  // -(10*rb + depth): MFMA kernel with that tile / prefetch depth
-        g_mfma_rb = (-variant) / 10;
-        g_mfma_depth = (-variant) % 10;
-    }
+    g_mfma_tile16 = variant == -14;        // -14: MFMA kernels with the 64-bin 16x16 tile everywhere
     if (variant < 0) variant = 0;
     g_mimo_variant = variant;
     g_mfma_vec = gradw_cap != -2;          // gradw_cap -2: direct stores in the MFMA kernels

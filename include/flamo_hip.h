@@ -155,7 +155,9 @@ int fl_mimo_gradh_diag_c128(const void* G, long gs_b, long gs_n, long gs_k,
  * dW: complex (No, Ni) = their sum in block order (a second tiny launch: deterministic, no atomics). */
 int fl_mimo_gradw_blocks(int M);
 /* tuning hook: variant = mt*100 + bt*10 + nu (register tile MT x BT, nu input channels loaded per
- * trip; 0 = default), gradw_cap = partial blocks of fl_mimo_gradw (0 = default) */
+ * trip; 0 = default; -1 = lane-per-bin kernels also where the MFMA kernels apply, -14 = MFMA kernels with
+ * the 64-bin 16x16 tile only), gradw_cap = partial blocks of fl_mimo_gradw (0 = default; -2 = MFMA
+ * kernels store straight from the accumulator layout instead of through LDS) */
 int fl_debug_set_mimo_variant(int variant, int gradw_cap);
 int fl_mimo_gradw_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
                       void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream);
