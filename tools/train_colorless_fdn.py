@@ -65,7 +65,7 @@ def sparsity_criterion(model):
     return -(torch.sum(torch.abs(A)) - N * math.sqrt(N)) / (N * (math.sqrt(N) - 1))
 
 
-def train(model, x, target, steps, lr, group=None, log=None, graphed=False, on_ready=None):
+def train(model, x, target, steps, lr, group=None, log=None, graphed=False, on_ready=None, fused_adam=False):
     """`steps` iterations of Trainer.train_step.  With a process group the core runs on this rank's bins.
     graphed (one GPU): forward + criteria + backward replayed from a HIP graph, the Adam update launched behind it."""
     import torch.distributed as dist
@@ -73,7 +73,8 @@ def train(model, x, target, steps, lr, group=None, log=None, graphed=False, on_r
     sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
     rank = dist.get_rank(group) if sharded else 0
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=lr)
+    # fused_adam: the same update in one launch for all parameters (torch's foreach default is ~12 launches)
+    opt = torch.optim.Adam(params, lr=lr, fused=True) if fused_adam else torch.optim.Adam(params, lr=lr)
     if graphed and steps > 0:
         assert not sharded, "graph replay is wired for the single-GPU run"
         from flamo_amd.graph import GraphedStep
@@ -127,6 +128,7 @@ def main():
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"])
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) or gloo (ranks sharing one GPU, staged through host)")
     ap.add_argument("--graph", action="store_true", help="replay forward+backward from a HIP graph (one GPU)")
+    ap.add_argument("--fused-adam", action="store_true", help="torch.optim.Adam(fused=True): one launch per update")
     ap.add_argument("--dump", default=None, help="rank 0 saves {losses, state_dict} here (torch.save)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks on cuda:0 (test rigs with one GPU)")
     args = ap.parse_args()
@@ -153,7 +155,7 @@ def main():
         torch.cuda.synchronize()
         clock["t0"] = time.perf_counter()
 
-    train(model, x, target, args.steps, args.lr, log=log, graphed=args.graph, on_ready=start_clock)
+    train(model, x, target, args.steps, args.lr, log=log, graphed=args.graph, on_ready=start_clock, fused_adam=args.fused_adam)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -169,7 +171,7 @@ def main():
                           "ms_per_step": 1e3 * dt / args.steps, "scaling": "strong", "dtype": args.dtype,
                           "config": {"workload": "configs[3] colorless FDN training", "N": args.N, "nfft": args.nfft,
                                      "batch": args.batch, "sharding": "bins" if world > 1 else "none", "lr": args.lr,
-                                     "graph_replay": bool(args.graph)},
+                                     "graph_replay": bool(args.graph), "fused_adam": bool(args.fused_adam)},
                           "loss_first": log[0], "loss_last": log[-1]}))
         if args.dump:
             torch.save({"losses": log, "state": {k: v.detach().cpu() for k, v in model.state_dict().items()}}, args.dump)
