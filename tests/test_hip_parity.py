@@ -626,3 +626,40 @@ def test_colorless_training_bin_sharded_two_ranks(gpu, tmp_path):
     assert r1["losses"][0][2] > r1["losses"][-1][2]            # it trains
     for k, v in r1["state"].items():
         assert relerr(r2["state"][k], v) < 1e-9, k
+
+
+# ----------------------------------------------------------------------------- config 1: e7_biquad training
+def test_e7_biquad_training_golden(gpu, dt):
+    """BASELINE configs[0] at its own size: Shell(FFT(96000) -> Biquad((2,1), 2 sections, highpass, alias 30 dB) -> |.|),
+    impulse input, nn.MSELoss, Adam -- first estimate and gradient, every step's loss, final parameters against the
+    trajectory recorded from the reference (examples/e7_biquad.py)."""
+    from flamo_amd.processor import dsp, system
+    meta, a = load_golden("e7_biquad")
+    nfft, dec = meta["nfft"], meta["decimation"]
+    target = _dev(a["target"], gpu, dt)     # stored whole (the reference builds it through a float32 FFT of `a`)
+    filt = dsp.Biquad(size=(2, 1), n_sections=meta["n_sections"], filter_type="highpass", nfft=nfft, fs=meta["fs"],
+                      requires_grad=True, alias_decay_db=meta["alias_decay_db"], device=gpu, dtype=dt)
+    model = system.Shell(core=filt, input_layer=dsp.FFT(nfft, dtype=dt),
+                         output_layer=dsp.Transform(lambda z: torch.abs(z), device=gpu, dtype=dt))
+    assert list(model.state_dict().keys()) == meta["state_keys"]
+    filt.assign_value(_dev(a["param0"], gpu, dt))
+    x = torch.zeros(1, nfft, 1, device=gpu, dtype=dt)
+    x[:, 0, :] = 1
+    tol = 1e-9 if dt == torch.float64 else 2e-5
+    with torch.no_grad():
+        assert relerr(model.get_freq_response()[:, ::dec].cpu(), a["fr0_dec"]) < tol
+    crit = torch.nn.MSELoss()
+    opt = torch.optim.Adam(model.parameters(), lr=meta["lr"])
+    losses = []
+    for it in range(meta["steps"]):
+        opt.zero_grad()
+        est = model(x)
+        loss = crit(est, target)
+        loss.backward()
+        if it == 0:
+            assert relerr(est.detach()[:, ::dec].cpu(), a["est0_dec"]) < tol
+            assert relerr(filt.param.grad.cpu(), a["g_param0"]) < (1e-7 if dt == torch.float64 else 2e-3)
+        opt.step()
+        losses.append(loss.detach())
+    assert relerr(torch.stack(losses).double().cpu(), a["losses"]) < 10 * tol
+    assert relerr(filt.param.detach().cpu(), a["param"]) < (1e-8 if dt == torch.float64 else 1e-3)

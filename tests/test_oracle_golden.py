@@ -203,3 +203,30 @@ def test_colorless_training_oracle(name):
     assert relerr(torch.tensor(log, dtype=torch.float64), a["losses"]) < 1e-9
     for p_, key in zip(ps, ("in_gain", "out_gain", "U_param")):
         assert relerr(p_.detach(), a[key]) < 1e-8, key
+
+
+def test_e7_biquad_training_oracle():
+    """BASELINE configs[0] at its own size (nfft = 96000): the oracle's Biquad response under MSE and Adam against
+    the trajectory recorded from examples/e7_biquad.py's model in the reference."""
+    meta, a = load_golden("e7_biquad")
+    nfft, dec = meta["nfft"], meta["decimation"]
+    target = a["target"]        # stored whole: the reference builds it through a float32 FFT (host-dependent rounding)
+    tf = torch.prod(torch.fft.rfft(a["b"], nfft, dim=0), dim=1) / torch.prod(torch.fft.rfft(a["a"].double(), nfft, dim=0), dim=1)
+    assert relerr(torch.abs(tf[..., 0]).unsqueeze(0), target) < 1e-6          # |prod B / prod A| of the stored sections
+    p = a["param0"].clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=meta["lr"])
+    g_ = O.gamma_of(meta["alias_decay_db"], nfft, torch.float64)
+    losses = []
+    for it in range(meta["steps"]):
+        opt.zero_grad()
+        H = O.biquad_response(p, "highpass", nfft, meta["fs"], g_)            # (M, 2, 1)
+        est = torch.abs(H[..., 0]).unsqueeze(0)                               # impulse spectrum is all ones
+        loss = torch.mean((est - target) ** 2)
+        loss.backward()
+        if it == 0:
+            assert relerr(est.detach()[:, ::dec], a["est0_dec"]) < 1e-10
+            assert relerr(p.grad, a["g_param0"]) < 1e-8
+        opt.step()
+        losses.append(loss.item())
+    assert relerr(torch.tensor(losses, dtype=torch.float64), a["losses"]) < 1e-9
+    assert relerr(p.detach(), a["param"]) < 1e-8

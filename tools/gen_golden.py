@@ -381,6 +381,46 @@ def gen_colorless(dsp, system):
              in_gain=plist[0], out_gain=plist[1], U_param=plist[2], delays_s=p["delays"].param.detach())
 
 
+# ----------------------------------------------------------------------------- config 1: e7_biquad training
+def gen_biquad_training(dsp, system):
+    """BASELINE configs[0], examples/e7_biquad.py at its own size: Shell(FFT(96000) -> Biquad((2,1), 2 sections,
+    highpass, alias 30 dB) -> |.|), impulse input, target = |prod B / prod A| of random highpass sections
+    (e7_biquad.py:23-61), nn.MSELoss, Adam steps as Trainer.train_step does them.  The estimates are stored
+    decimated (every 97th bin).  The target is stored whole: highpass_filter returns `a` in float32, so the reference's
+    target goes through a single-precision FFT whose rounding (1e-7) differs from host to host."""
+    from flamo.functional import highpass_filter, signal_gallery
+    torch.manual_seed(130709)
+    nfft, fs, in_ch, out_ch, n_sections, lr, steps = 96000, 48000, 1, 2, 2, 1e-3, 6
+    b, a = highpass_filter(fc=torch.tensor(fs // 2, dtype=F64) * torch.rand(size=(n_sections, out_ch, in_ch), dtype=F64),
+                           gain=torch.tensor(-1) + torch.tensor(2) * torch.rand(size=(n_sections, out_ch, in_ch), dtype=F64), fs=fs)
+    target_filter = torch.prod(torch.fft.rfft(b, nfft, dim=0), dim=1) / torch.prod(torch.fft.rfft(a, nfft, dim=0), dim=1)
+    filt = dsp.Biquad(size=(out_ch, in_ch), n_sections=n_sections, filter_type="highpass", nfft=nfft, fs=fs,
+                      requires_grad=True, alias_decay_db=30, dtype=F64)
+    model = system.Shell(core=filt, input_layer=dsp.FFT(nfft, dtype=F64), output_layer=dsp.Transform(lambda x: torch.abs(x), dtype=F64))
+    x = signal_gallery(1, n_samples=nfft, n=in_ch, signal_type="impulse", fs=fs, dtype=F64)
+    target = torch.abs(torch.einsum("...ji,...i->...j", target_filter, model.get_inputLayer()(x)))
+    param0 = filt.param.detach().clone()
+    with torch.no_grad():
+        fr0 = model.get_freq_response()
+    crit = torch.nn.MSELoss()
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    losses, est0, g0 = [], None, None
+    for it in range(steps):
+        opt.zero_grad()
+        est = model(x)
+        loss = crit(est, target)
+        loss.backward()
+        if it == 0:
+            est0, g0 = est.detach().clone(), filt.param.grad.detach().clone()
+        opt.step()
+        losses.append(float(loss))
+    dec = slice(None, None, 97)
+    save("e7_biquad", dict(kind="e7_biquad", nfft=nfft, fs=fs, alias_decay_db=30.0, n_sections=n_sections, lr=lr, steps=steps,
+                           decimation=97, state_keys=list(model.state_dict().keys())),
+         b=b, a=a, param0=param0, param=filt.param.detach(), g_param0=g0, losses=np.array(losses),
+         est0_dec=est0[:, dec], target=target, fr0_dec=fr0[:, dec])
+
+
 def main():
     torch.set_default_dtype(torch.float32)
     dsp, system = refimport.load()
@@ -399,6 +439,9 @@ def main():
     if "--colorless-only" in sys.argv:
         gen_colorless(dsp, system)
         return
+    if "--biquad-only" in sys.argv:
+        gen_biquad_training(dsp, system)
+        return
     gen_transforms(dsp)
     gen_modules(dsp)
     gen_modules_more(dsp)
@@ -407,6 +450,7 @@ def main():
     gen_parallel(dsp, system)
     gen_accurate_geq(dsp)
     gen_colorless(dsp, system)
+    gen_biquad_training(dsp, system)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print(f"total {total/1024:.1f} KiB")
 
