@@ -663,3 +663,29 @@ def test_e7_biquad_training_golden(gpu, dt):
         losses.append(loss.detach())
     assert relerr(torch.stack(losses).double().cpu(), a["losses"]) < 10 * tol
     assert relerr(filt.param.detach().cpu(), a["param"]) < (1e-8 if dt == torch.float64 else 1e-3)
+
+
+def test_config5_chain_bin_sharded_two_ranks(gpu, tmp_path):
+    """BASELINE configs[4]'s structure (32 x 32: MFMA products, composed loop matrix, N = 32 solve) with the bins
+    sharded over two ranks sharing the GPU (gloo transport staged through the host): output of the inverse transform
+    behind the all-gather and every parameter gradient equal the unsharded run."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "run_sharded_chain.py")
+    common = ["--N", "32", "--nfft", "3840", "--steps", "1", "--warmup", "0", "--dtype", "float64"]
+    one, two = str(tmp_path / "one.pt"), str(tmp_path / "two.pt")
+    subprocess.run([sys.executable, tool, *common, "--dump", one], check=True, timeout=600, cwd=root)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                    "--master-addr", "127.0.0.1", "--master-port", str(port), tool, *common, "--gpus", "2",
+                    "--backend", "gloo", "--share-gpu", "--dump", two], check=True, timeout=900, cwd=root)
+    r1, r2 = torch.load(one), torch.load(two)
+    assert relerr(r2["y"], r1["y"]) < 1e-11
+    for g2, g1 in zip(r2["grads"], r1["grads"]):
+        assert relerr(g2, g1) < 1e-9
