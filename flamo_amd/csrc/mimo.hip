@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) mimo_full_kernel(
     const int inner = nct * nmt;
     const int xcd = blockIdx.x & 7, r = blockIdx.x >> 3;
     const int ft = (r / inner) * 8 + xcd, rem = r % inner;
-    const int f = ft * blockDim.x + threadIdx.x;      // 256 bins per workgroup, 64 when the launch is small
+    const int f = ft * 256 + threadIdx.x;
     if (f >= M) return;
     const int col0 = (rem % nct) * BT;
     const int m0 = (rem / nct) * MT;
@@ -427,13 +427,12 @@ static int launch_mfma(MmaArgs a, hipStream_t st, int red_slots = 0, int* slots_
 
 // ---------------------------------------------------------------- host dispatch
 static int g_mimo_variant = 0;   // tuning hook: mt*100 + bt*10 + nu (0 = default choice)
-static int g_mimo_tpb = 0;       // tuning hook: threads per workgroup of mimo_full (gradw_cap -64 / -256)
 
 template <typename T, int MT, int BT, int NU>
-static void launch_full_one(dim3 grid, int tpb, int nct, int nmt, hipStream_t st, const cx<T>* H, long hs_f, long hs_m, long hs_n, int conj_h,
+static void launch_full_one(dim3 grid, int nct, int nmt, hipStream_t st, const cx<T>* H, long hs_f, long hs_m, long hs_n, int conj_h,
                             const cx<T>* X, long xs_b, long xs_n, long xs_k, cx<T>* Y, long ys_b, long ys_m, long ys_k,
                             int B, int M, int No, int Ni, int K) {
-    hipLaunchKernelGGL((mimo_full_kernel<T, MT, BT, NU>), grid, dim3(tpb), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
+    hipLaunchKernelGGL((mimo_full_kernel<T, MT, BT, NU>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
                        xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
 }
 
@@ -464,12 +463,7 @@ static int mimo_impl(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
         nu = g_mimo_variant % 10;
     }
     const int nct = cdiv_i(ncols, bt), nmt = cdiv_i(No, mt);
-    // small launches (a response composed with a constant matrix: 48001 bins x 2 column tiles = 376 workgroups of
-    // 256 threads on 256 CUs) leave most of the machine idle: one wavefront per workgroup spreads them out
-    int tpb = 256;
-    if (g_mimo_tpb > 0) tpb = g_mimo_tpb;
-    else if ((size_t)cdiv_i(M, 256) * nct * nmt < 1536) tpb = 64;
-    const size_t nblk = (size_t)cdiv_i(cdiv_i(M, tpb), 8) * 8 * nct * nmt;
+    const size_t nblk = (size_t)cdiv_i(cdiv_i(M, 256), 8) * 8 * nct * nmt;
     FL_REQUIRE(nblk < (1ull << 31), "mimo: grid too large");
     dim3 grid((unsigned)nblk);
     hipStream_t st = (hipStream_t)stream;
@@ -478,7 +472,7 @@ static int mimo_impl(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
     cx<T>* y = (cx<T>*)Y;
 #define FL_MIMO_CASE(MT_, BT_, NU_)                                                                                   \
     if (mt == MT_ && bt == BT_ && nu == NU_) {                                                                        \
-        launch_full_one<T, MT_, BT_, NU_>(grid, tpb, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, \
+        launch_full_one<T, MT_, BT_, NU_>(grid, nct, nmt, st, h, hs_f, hs_m, hs_n, conj_h, x, xs_b, xs_n, xs_k, y, ys_b, \
                                           ys_m, ys_k, B, M, No, Ni, K);                                               \
         FL_CHECK_LAUNCH("mimo_full");                                                                                 \
         return FL_OK;                                                                                                 \
@@ -702,7 +696,6 @@ int fl_debug_set_mimo_variant(int variant, int gradw_cap) {
     if (variant < 0) variant = 0;
     g_mimo_variant = variant;
     g_mfma_vec = gradw_cap != -2;          // gradw_cap -2: direct stores in the MFMA kernels
-    g_mimo_tpb = (gradw_cap == -64 || gradw_cap == -256) ? -gradw_cap : 0;
     if (gradw_cap < 0) gradw_cap = 0;
     g_gradw_cap = gradw_cap;
     return FL_OK;
