@@ -460,8 +460,7 @@ def test_mimo_mfma_matches_lane_kernels(gpu):
     from flamo_amd import _lib, ops
     L = _lib.lib()
     torch.manual_seed(11)
-    M = 1000 + 37
-    for No, Ni, B, K in ((32, 32, 1, 32), (24, 16, 2, 10), (16, 8, 1, 16)):
+    for No, Ni, B, K, M in ((32, 32, 1, 32, 1037), (24, 16, 2, 10, 1037), (16, 8, 1, 16, 1037), (32, 32, 1, 32, 5), (17, 9, 1, 9, 1)):
         H = torch.randn(M, No, Ni, dtype=torch.complex64, device=gpu, requires_grad=True)
         X = torch.randn(B, M, Ni, K, dtype=torch.complex64, device=gpu, requires_grad=True)
         C = torch.randn(B, M, No, K, dtype=torch.complex64, device=gpu)
