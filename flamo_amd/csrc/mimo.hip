@@ -14,7 +14,9 @@
 
 namespace fl {
 
-template <typename T, int MT, int BT, int NU>
+// HC: H does not depend on the bin (Gain / Matrix, hs_f = 0): its address is then uniform over the wavefront and the
+// compiler fetches it with scalar loads -- MT*Ni fewer vector loads per thread in the small composition launches
+template <typename T, int MT, int BT, int NU, bool HC = false>
 __global__ void __launch_bounds__(256) mimo_full_kernel(
     const cx<T>* __restrict__ H, long hs_f, long hs_m, long hs_n, int conj_h,
     const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
@@ -47,7 +49,7 @@ __global__ void __launch_bounds__(256) mimo_full_kernel(
     for (int c = 0; c < BT; ++c)
 #pragma unroll
         for (int mm = 0; mm < MT; ++mm) acc[c][mm] = cx<T>(0, 0);
-    const cx<T>* Hf = H + (long)f * hs_f;
+    const cx<T>* Hf = HC ? H : H + (long)f * hs_f;
     // NU input channels per trip: (MT + BT) * NU loads are issued before their FMAs
     for (int n0 = 0; n0 < Ni; n0 += NU) {
         cx<T> h[NU][MT], x[NU][BT];
@@ -428,12 +430,18 @@ static int launch_mfma(MmaArgs a, hipStream_t st, int red_slots = 0, int* slots_
 // ---------------------------------------------------------------- host dispatch
 static int g_mimo_variant = 0;   // tuning hook: mt*100 + bt*10 + nu (0 = default choice)
 
+static int g_mimo_hc = 1;   // tuning: 0 = constant matrices through the per-bin addressing (gradw_cap -4)
+
 template <typename T, int MT, int BT, int NU>
 static void launch_full_one(dim3 grid, int nct, int nmt, hipStream_t st, const cx<T>* H, long hs_f, long hs_m, long hs_n, int conj_h,
                             const cx<T>* X, long xs_b, long xs_n, long xs_k, cx<T>* Y, long ys_b, long ys_m, long ys_k,
                             int B, int M, int No, int Ni, int K) {
-    hipLaunchKernelGGL((mimo_full_kernel<T, MT, BT, NU>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
-                       xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
+    if (NU == 1 && hs_f == 0 && g_mimo_hc)
+        hipLaunchKernelGGL((mimo_full_kernel<T, MT, BT, 1, true>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
+                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
+    else
+        hipLaunchKernelGGL((mimo_full_kernel<T, MT, BT, NU>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
+                           xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
 }
 
 template <typename T>
@@ -696,6 +704,7 @@ int fl_debug_set_mimo_variant(int variant, int gradw_cap) {
     if (variant < 0) variant = 0;
     g_mimo_variant = variant;
     g_mfma_vec = gradw_cap != -2;          // gradw_cap -2: direct stores in the MFMA kernels
+    g_mimo_hc = gradw_cap != -4;
     if (gradw_cap < 0) gradw_cap = 0;
     g_gradw_cap = gradw_cap;
     return FL_OK;
