@@ -689,3 +689,30 @@ def test_config5_chain_bin_sharded_two_ranks(gpu, tmp_path):
     assert relerr(r2["y"], r1["y"]) < 1e-11
     for g2, g1 in zip(r2["grads"], r1["grads"]):
         assert relerr(g2, g1) < 1e-9
+
+
+def test_bench_contract_line(gpu):
+    """bench.py prints exactly one JSON line on stdout with the fields the driver reads, a roofline object for the
+    per-bin product and (without --no-cpu-baseline) a cpu_baseline object."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline"], check=True, timeout=600, cwd=root, capture_output=True, text=True).stdout
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "products/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
+    M = 96000 // 2 + 1
+    assert abs(d["value"] - 2 * 32 * M * 8 * 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.2 < r["frac"] < 1.0
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
+    assert r["traffic"] >= r["algorithmic_bytes"]
