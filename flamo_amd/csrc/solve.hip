@@ -475,7 +475,8 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
             // keep the diagonal unless it is more than 2x smaller than the column maximum: a factor 2 is one
             // exponent step, i.e. 1 << 23 on the bit pattern (denormal magnitudes compare conservatively)
             const bool exchange = group_bcast<LANES, LK>(dkey) + (thr_steps << 23) < kmax;
-            if (__any(exchange)) {      // uniform over the wavefront; groups that keep their diagonal map to themselves
+            if (__builtin_expect(__any(exchange), 0)) {   // uniform over the wavefront (and rare: laid out off the hot path);
+                                                          // groups that keep their diagonal map to themselves
                 const int best = NMAX - 1 - (kmax & (NMAX - 1));
                 const int lb = best % LANES, sb = best / LANES;
                 const int src = exchange ? (gi == LK ? lb : (gi == lb ? LK : gi)) : gi;
