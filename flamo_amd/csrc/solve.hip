@@ -454,6 +454,9 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
     static_for<0, NMAX>([&](auto kc) {
         constexpr int KK = decltype(kc)::value;
         constexpr int SK = KK / LANES, LK = KK % LANES;       // slot and lane of the diagonal
+        // steps >= N act on identity rows: skipped (uniform branch).  For RPL > 1 the branch also keeps the compiler
+        // from interleaving neighbouring steps, which is what drove that kernel's register count
+        if (RPL > 1 && KK >= N) return;
         if constexpr (KK < NMAX - 1) {
             // non-negative floats order like their bit patterns; the low bits carry NMAX-1-row so that the lowest
             // row wins among (nearly) equal magnitudes, as icamax would pick.  Rows above K are no candidates:

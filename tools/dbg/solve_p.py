@@ -25,7 +25,7 @@ for N, M in ((16, 96001), (32, 96001), (24, 48001)):
             print(f"N={N} M={M} adjoint={int(adj)} variant {v}: {e0.elapsed_time(e1)/5*1e3:8.1f} us  err {err:.1e}")
 L.fl_debug_set_solve_variant(0)
 # the factored loop with the same number of right-hand sides, for reference
-for N, M in ((32, 96001),):
+for N, M in ((32, 96001), (24, 96001), (17, 96001)):
     U = torch.linalg.qr(torch.randn(N, N, dtype=torch.float64))[0].to(dev, torch.complex64)
     l = ops._h_planar((0.98 * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64))).to(dev, torch.complex64), True)
     for B in (1, 2):
