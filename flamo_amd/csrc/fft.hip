@@ -681,6 +681,125 @@ __global__ void __launch_bounds__(256) fft_cols_fast(FftArgs<T> a) {
     }
 }
 
+// Inverse column pass with mirror columns paired in one workgroup.  The Hermitian pre-step needs X[j] and X[L-j]
+// for every element: the kernel above fetches both for each of its 32 columns, so every element of X crosses the
+// CU boundary twice (once as itself, once as the partner of an element of another tile) -- 196 MB of loads for 98 MB
+// of data, and at ~10 B/cycle/CU that, not HBM, is what holds the pass at 63 us against the forward pass's 45.
+// With j = row L2 + col the partner of (row, col) is (L1-1-row, L2-col): a whole other column, rows reversed.  Here a
+// workgroup owns 16 columns c <= L2/2 AND their 16 partners L2-c; a thread that holds X[j] and X[L-j] produces both
+//     Zf[j]   = s + t,     Zf[L-j] = conj(s - t),      s = xa + conj(xm),  t = i conj(W_n^j) (xa - conj(xm))
+// (W_n^(L-j) = -conj(W_n^j)), and the eight rows ta B + tb it holds for column c are, reversed, the eight rows
+// (A-1-ta) B + (B-1-tb) of item (B-1-tb) of column L2-c: a complete input of that column's first-stage FFT.
+// Columns 0 and L2/2 are their own partners (within the column, other rows): they are processed as plain columns.
+template <typename T, int A, int B>
+__global__ void __launch_bounds__(256) fft_cols_ipair(FftArgs<T> a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int CT = 32, CD = 16, LEN = A * B, LENP = LEN | 1;
+    cx<T>* U = reinterpret_cast<cx<T>*>(smem);   // [CT][LENP]: local columns 0..15 = c, 16..31 = partner of column lc-16
+    cx<T>* tw = U + CT * LENP;                    // W_LEN^m
+    cx<T>* t2 = tw + LEN;                         // [CT][B]: W_L^(col * A * kb)
+    cx<T>* wr = t2 + CT * B;                      // W_n^(row * L2)
+    cx<T>* wc = wr + LEN;                         // W_n^(d0 + c), c < CD
+    int tile, sig;
+    if (!cols_block<T, LOAD_IRFFT_PRE>(a, a.nsig, tile, sig)) return;
+    const int ndirect = a.L2 / 2 + 1;             // columns 0 .. L2/2
+    const int d0 = tile * CD;
+    const int nd = min(CD, ndirect - d0);
+    auto paired = [&](int c) { return c >= 1 && 2 * c != a.L2; };          // c = global direct column
+    auto gcol = [&](int lc) { return lc < CD ? d0 + lc : a.L2 - (d0 + lc - CD); };
+    auto live = [&](int lc) { return lc < CD ? lc < nd : (lc - CD < nd && paired(d0 + lc - CD)); };
+    const int twstep = a.n / LEN;
+    for (int j = threadIdx.x; j < LEN; j += 256) {
+        tw[j] = a.W[j * twstep];
+        wr[j] = a.W[j * a.L2];
+    }
+    for (int j = threadIdx.x; j < CT * B; j += 256) {
+        const int lc = j / B, kb = j - lc * B;
+        t2[j] = live(lc) ? a.W[2 * gcol(lc) * A * kb] : cx<T>(1, 0);
+    }
+    if (threadIdx.x < CD) wc[threadIdx.x] = (threadIdx.x < nd) ? a.W[d0 + threadIdx.x] : cx<T>(1, 0);
+    __syncthreads();
+    // stage 1: every load of the thread's items is requested before anything is combined
+    constexpr int NR = (B * CD + 255) / 256;
+    {
+        cx<T> v[NR][A], xb[NR][A];
+        const cx<T>* X = a.Xc + (size_t)sig * a.xc_stride;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int item = threadIdx.x + r * 256;
+            const int tb = item / CD, c = item % CD;
+            if (item < B * CD && c < nd) {
+#pragma unroll
+                for (int ta = 0; ta < A; ++ta) {
+                    const int j = (ta * B + tb) * a.L2 + d0 + c;
+                    v[r][ta] = X[j];
+                    xb[r][ta] = X[a.L - j];
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int item = threadIdx.x + r * 256;
+            const int tb = item / CD, c = item % CD;
+            if (item < B * CD && c < nd) {
+                const cx<T> wcol = wc[c];
+                cx<T> zd[A], zm[A];
+#pragma unroll
+                for (int ta = 0; ta < A; ++ta) {
+                    const int row = ta * B + tb;
+                    cx<T> xa = v[r][ta], xm = xb[r][ta];
+                    if (row == 0 && d0 + c == 0) {  // DC and Nyquist: imaginary parts ignored (C2R)
+                        xa.y = 0;
+                        xm.y = 0;
+                    } else if (a.interior) {
+                        xa = (T)0.5 * xa;
+                        xm = (T)0.5 * xm;
+                    }
+                    xm = conj(xm);
+                    const cx<T> sum = xa + xm, dif = xa - xm;
+                    const cx<T> t = mul_i(conj(wr[row] * wcol) * dif);
+                    zd[ta] = sum + t;
+                    zm[A - 1 - ta] = conj(sum - t);
+                }
+                RegFFT<T, A, true>::run(zd);
+                cx<T>* u = U + c * LENP + tb;
+                u[0] = zd[0];
+#pragma unroll
+                for (int ka = 1; ka < A; ++ka) u[ka * B] = zd[ka] * conj(tw[ka * tb]);
+                if (paired(d0 + c)) {
+                    const int tbm = B - 1 - tb;
+                    RegFFT<T, A, true>::run(zm);
+                    cx<T>* um = U + (c + CD) * LENP + tbm;
+                    um[0] = zm[0];
+#pragma unroll
+                    for (int ka = 1; ka < A; ++ka) um[ka * B] = zm[ka] * conj(tw[ka * tbm]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // stage 2: B-point FFTs over t_b for every (k_a, local column); inter-pass twiddle; store
+    cx<T>* out = a.scratch + (size_t)sig * a.L;
+    for (int item = threadIdx.x; item < A * CT; item += 256) {
+        const int ka = item / CT, lc = item % CT;
+        if (live(lc)) {
+            cx<T> v[B];
+            const cx<T>* u = U + lc * LENP + ka * B;
+#pragma unroll
+            for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
+            RegFFT<T, B, true>::run(v);
+            const int col = gcol(lc);
+            const cx<T> w1 = a.W[2 * col * ka];
+            const cx<T>* w2 = t2 + lc * B;
+#pragma unroll
+            for (int kb = 0; kb < B; ++kb) {
+                const int k1 = ka + A * kb;
+                out[(size_t)k1 * a.L2 + col] = v[kb] * conj(w1 * w2[kb]);
+            }
+        }
+    }
+}
+
 // pass 2 fast: rows of length LEN = A*B; nslots*A <= 256 so every thread owns at most one
 // stage-2 item and the natural-order result can be written back into the same LDS buffer.
 template <typename T, int A, int B, int LOAD, int EPI, bool INV>
@@ -844,6 +963,10 @@ static void launch_cols_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, s
     }
 }
 template <typename T, int A, int B>
+static void launch_cols_ipair(const FftArgs<T>& a, unsigned nblk, size_t lds, hipStream_t st) {
+    hipLaunchKernelGGL((fft_cols_ipair<T, A, B>), dim3(nblk), dim3(256), lds, st, a);
+}
+template <typename T, int A, int B>
 static void launch_rows_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, size_t lds, int nthreads, hipStream_t st) {
     if (inverse)
         hipLaunchKernelGGL((fft_rows_fast<T, A, B, LOAD_SCRATCH, EPI_IRFFT_STORE, true>), dim3(nblk), dim3(nthreads), lds, st, a);
@@ -977,6 +1100,7 @@ __global__ void __launch_bounds__(256) transpose_tall4_kernel(const uint32_t* __
 static int g_max_single = 0;
 static int g_fast_enabled = 1;
 static int g_fast_ct = 0;   // 0 = default choice, 16 / 32 = forced (tuning hook)
+static int g_fast_pair = 1; // inverse column pass with mirror columns paired (tuning hook: mode 2 switches it off)
 static int g_fast_rt = 0;   // rows per workgroup in pass 2 (0 = default)
 
 static bool factorize(int n, Rad& rad) {
@@ -1064,12 +1188,17 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
         if (use_fast) {
             const FastSplit* f1 = fast_split(p.L1);
             // 32-column tiles pay off for the inverse (its mirror reads straddle lines), not forward
+            const bool pair = inverse && sizeof(T) == 4 && g_fast_pair && g_fast_ct == 0 && a.ci_n == 0;
             a.CT = (sizeof(T) == 4 && (g_fast_ct == 32 || (g_fast_ct == 0 && inverse))) ? 32 : 16;
-            a.ntiles = cdiv_i(p.L2, a.CT);
+            a.ntiles = pair ? cdiv_i(p.L2 / 2 + 1, 16) : cdiv_i(p.L2, a.CT);
             const size_t lds = (size_t)(a.CT * a.L1P + p.L1 + a.CT * f1->B + (inverse ? p.L1 + a.CT : 0)) * esz;
             const size_t nblk = cols_grid(a, nsig);
             FL_REQUIRE(nblk < (1ull << 31), "grid too large");
-            FL_FAST_DISPATCH(launch_cols_fast, p.L1, inverse, a, (unsigned)nblk, lds, st)
+            if (pair) {
+                FL_FAST_DISPATCH(launch_cols_ipair, p.L1, a, (unsigned)nblk, lds, st)
+            } else {
+                FL_FAST_DISPATCH(launch_cols_fast, p.L1, inverse, a, (unsigned)nblk, lds, st)
+            }
             FL_CHECK_LAUNCH("fft_cols_fast");
         } else {
             int ct = (budget - p.L1) / (2 * a.L1P);
@@ -1236,6 +1365,7 @@ int fl_debug_set_fft_fast(int enabled) {
     enabled %= 1000;
     g_fast_enabled = enabled != 0;
     g_fast_ct = (enabled == 32) ? 32 : (enabled == 16 ? 16 : 0);   // tuning: force 16- / 32-column tiles in pass 1
+    g_fast_pair = enabled != 2;                                     // 2: inverse column pass without mirror pairing
     return FL_OK;
 }
 

@@ -66,7 +66,8 @@ size_t fl_fft_scratch_elems(int nfft, int is_f64, int nsig);
 /* test hook: largest half-length handled in one pass (0 restores the default) */
 int fl_debug_set_fft_max_single(int max_half_len);
 /* test hook: 0 forces the generic Stockham kernels where the two-register-stage fast kernels
- * would be chosen (default 1) */
+ * would be chosen (default 1); 2 = fast kernels, inverse column pass without mirror-column pairing;
+ * 16 / 32 = column-tile width forced; + 1000 * rows per workgroup of the row pass */
 int fl_debug_set_fft_fast(int enabled);
 
 /* X[sig, k] = scale * w_k * sum_t x[sig, t] * e(t) * exp(-2 pi i k t / nfft),  k in [0, nfft/2]

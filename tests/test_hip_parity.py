@@ -101,6 +101,12 @@ def test_fft_fast_kernels_match_generic(gpu):
             finally:
                 L.fl_debug_set_fft_fast(1)
             assert relerr(Xf, Xg) < tol and relerr(yf, yg) < tol
+            L.fl_debug_set_fft_fast(2)          # fast kernels, inverse column pass without mirror-column pairing
+            try:
+                yu = ops.irfft(Z, nfft, "ortho", 30.0)
+            finally:
+                L.fl_debug_set_fft_fast(1)
+            assert relerr(yf, yu) < tol
 
 
 def test_fft_ragged_and_layouts(gpu):
