@@ -35,7 +35,7 @@ NFFT, NCH, BATCH = 96000, 8, 32
 # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r01k_pmc_hbm_traffic.csv,
 # grid 393216 = the batch-32 launch): 2*FETCH_SIZE + WRITE_SIZE.  A static number measured by rocprofv3,
 # not re-measured by every bench run.
-PMC_TRAFFIC_BYTES = 223.5e6
+PMC_TRAFFIC_BYTES = 222.8e6
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
