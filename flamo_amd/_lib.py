@@ -38,6 +38,13 @@ _SIGNATURES = {
     "fl_irfft_f32": (_i, [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
     "fl_irfft_f64": (_i, [_vp, _l, _vp, _l, _i, _vp, _vp, _i, _i, _d, _d, _i, _vp]),
     "fl_transpose": (_i, [_vp, _vp, _i, _i, _i, _l, _i, _vp]),
+    "fl_spec_plan": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
+    "fl_spec_supports": (_i, [_i, _i, _i]),
+    "fl_debug_set_spec": (_i, [_i, _i]),
+    "fl_spec_cols_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _vp]),
+    "fl_spec_mid_f32": (_i, [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
+    "fl_spec_cols_inv_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp]),
+    "fl_permute_bins_c64": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp]),
     "fl_mimo_c64": (_i, [_vp, _l, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _i, _vp]),
     "fl_mimo_c128": (_i, [_vp, _l, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _i, _vp]),
     "fl_mimo_diag_c64": (_i, [_vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),

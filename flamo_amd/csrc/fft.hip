@@ -18,6 +18,7 @@
 // The anti-alias envelope gamma^-t of FFTAntiAlias / iFFTAntiAlias (dsp.py:158-162,201-205)
 // is applied in the loader / epilogue (no separate pass).
 #include "common.h"
+#include "regfft.h"
 
 namespace fl {
 
@@ -54,88 +55,6 @@ struct FftArgs {
     Rad rad1, rad2;
 };
 
-// ---------------------------------------------------------------- radix butterflies (in registers)
-template <typename T, int R, bool INV>
-struct Bfly;
-
-template <typename T, bool INV>
-struct Bfly<T, 2, INV> {
-    static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
-        cx<T> a = v[0], b = v[1];
-        v[0] = a + b;
-        v[1] = a - b;
-    }
-};
-
-template <typename T, bool INV>
-struct Bfly<T, 4, INV> {
-    static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
-        cx<T> t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
-        cx<T> t3 = INV ? mul_i(d) : mul_mi(d);
-        v[0] = t0 + t2;
-        v[1] = t1 + t3;
-        v[2] = t0 - t2;
-        v[3] = t1 - t3;
-    }
-};
-
-template <typename T, bool INV>
-struct Bfly<T, 3, INV> {
-    static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
-        const T h = (T)0.86602540378443864676;  // sin(2pi/3)
-        cx<T> t = v[1] + v[2];
-        cx<T> u = cx<T>(v[0].x - (T)0.5 * t.x, v[0].y - (T)0.5 * t.y);
-        cx<T> d = v[1] - v[2];
-        cx<T> w = INV ? mul_i(d) : mul_mi(d);
-        w = cx<T>(h * w.x, h * w.y);
-        v[0] = v[0] + t;
-        v[1] = u + w;
-        v[2] = u - w;
-    }
-};
-
-template <typename T, bool INV>
-struct Bfly<T, 5, INV> {
-    static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
-        const T c1 = (T)0.30901699437494742410;   // cos(2pi/5)
-        const T c2 = (T)-0.80901699437494742410;  // cos(4pi/5)
-        const T s1 = (T)0.95105651629515357212;   // sin(2pi/5)
-        const T s2 = (T)0.58778525229247312917;   // sin(4pi/5)
-        cx<T> a1 = v[1] + v[4], a2 = v[2] + v[3], d1 = v[1] - v[4], d2 = v[2] - v[3];
-        cx<T> m1 = cx<T>(v[0].x + c1 * a1.x + c2 * a2.x, v[0].y + c1 * a1.y + c2 * a2.y);
-        cx<T> m2 = cx<T>(v[0].x + c2 * a1.x + c1 * a2.x, v[0].y + c2 * a1.y + c1 * a2.y);
-        cx<T> e1 = cx<T>(s1 * d1.x + s2 * d2.x, s1 * d1.y + s2 * d2.y);
-        cx<T> e2 = cx<T>(s2 * d1.x - s1 * d2.x, s2 * d1.y - s1 * d2.y);
-        cx<T> j1 = INV ? mul_i(e1) : mul_mi(e1);
-        cx<T> j2 = INV ? mul_i(e2) : mul_mi(e2);
-        v[0] = v[0] + a1 + a2;
-        v[1] = m1 + j1;
-        v[4] = m1 - j1;
-        v[2] = m2 + j2;
-        v[3] = m2 - j2;
-    }
-};
-
-// generic odd prime radix: direct O(R^2) DFT with w_R^j = tw[j * step] (forward table)
-template <typename T, int R, bool INV>
-struct Bfly {
-    static __device__ inline void run(cx<T>* v, const cx<T>* tw, int step) {
-        cx<T> o[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) {
-            cx<T> acc = v[0];
-#pragma unroll
-            for (int j = 1; j < R; ++j) {
-                cx<T> w = tw[((j * k) % R) * step];
-                if (INV) w = conj(w);
-                fma_cx(acc, v[j], w);
-            }
-            o[k] = acc;
-        }
-#pragma unroll
-        for (int k = 0; k < R; ++k) v[k] = o[k];
-    }
-};
 
 // One Stockham (decimation-in-frequency, autosort) stage of radix R on nseq sequences of
 // length len stored at stride lenP in LDS:  y[q + s(Rp + k)] = w_p^k sum_j x[q + s(p + m j)] w_R^{jk}
@@ -416,137 +335,6 @@ __global__ void __launch_bounds__(256) fft_rows(FftArgs<T> a) {
 // are compile-time constants.  Compared with the generic Stockham path (one LDS round trip per
 // radix-2..5 stage) this does a quarter of the LDS traffic and a third of the barriers.
 
-constexpr double kPi = 3.141592653589793238462643383279502884;
-
-constexpr double c_sin_small(double x) {  // |x| <= pi/4
-    double x2 = x * x, term = x, sum = x;
-    for (int k = 1; k < 14; ++k) {
-        term *= -x2 / ((2 * k) * (2 * k + 1));
-        sum += term;
-    }
-    return sum;
-}
-constexpr double c_cos_small(double x) {
-    double x2 = x * x, term = 1, sum = 1;
-    for (int k = 1; k < 14; ++k) {
-        term *= -x2 / ((2 * k - 1) * (2 * k));
-        sum += term;
-    }
-    return sum;
-}
-// cos / sin of 2*pi*m/R with exact octant reduction
-constexpr double c_cos2pi(int m, int R) {
-    m %= R;
-    if (m < 0) m += R;
-    // fold to [0, R/2]: cos(2pi m/R) = cos(2pi (R-m)/R)
-    if (2 * m > R) m = R - m;
-    // now angle in [0, pi]; cos(pi - x) = -cos x
-    bool neg = false;
-    if (4 * m > R) { m = R - 2 * m; neg = true; /* angle' = pi - angle = pi*(R-2m)/R -> use half-angle form below */
-        // angle' = pi * m' / R with m' = R - 2m_old ; handle by separate formula
-        double x = kPi * (double)m / (double)R;           // in [0, pi/2)
-        double v = (x <= kPi / 4) ? c_cos_small(x) : c_sin_small(kPi / 2 - x);
-        return -v;
-    }
-    (void)neg;
-    double x = 2 * kPi * (double)m / (double)R;           // in [0, pi/2]
-    return (x <= kPi / 4) ? c_cos_small(x) : c_sin_small(kPi / 2 - x);
-}
-constexpr double c_sin2pi(int m, int R) {
-    m %= R;
-    if (m < 0) m += R;
-    bool neg = false;
-    if (2 * m > R) { m = R - m; neg = true; }              // sin(2pi - x) = -sin x
-    double v = 0;
-    if (4 * m > R) {                                       // angle in (pi/2, pi]: sin(pi - x)
-        double x = kPi * (double)(R - 2 * m) / (double)R;  // pi - angle, in [0, pi/2)
-        v = (x <= kPi / 4) ? c_sin_small(x) : c_cos_small(kPi / 2 - x);
-    } else {
-        double x = 2 * kPi * (double)m / (double)R;
-        v = (x <= kPi / 4) ? c_sin_small(x) : c_cos_small(kPi / 2 - x);
-    }
-    return neg ? -v : v;
-}
-
-template <int R>
-struct TwTab {
-    double re[R], im[R];  // W_R^m = exp(-2 pi i m / R)
-    constexpr TwTab() : re{}, im{} {
-        for (int m = 0; m < R; ++m) {
-            re[m] = c_cos2pi(m, R);
-            im[m] = -c_sin2pi(m, R);
-        }
-    }
-};
-
-constexpr bool is_base_radix(int R) { return R == 2 || R == 3 || R == 4 || R == 5 || R == 7 || R == 11 || R == 13; }
-constexpr int first_factor(int R) {
-    if (R % 4 == 0) return 4;
-    if (R % 2 == 0) return 2;
-    if (R % 3 == 0) return 3;
-    if (R % 5 == 0) return 5;
-    if (R % 7 == 0) return 7;
-    if (R % 11 == 0) return 11;
-    return 13;
-}
-
-// Natural-order in-register FFT of size R: v[k] <- sum_t v[t] W_R^(+-tk)
-template <typename T, int R, bool INV>
-struct RegFFT {
-    static __device__ __forceinline__ void run(cx<T> (&v)[R]) {
-        if constexpr (R == 1) {
-            return;
-        } else if constexpr (R == 7 || R == 11 || R == 13) {
-            constexpr TwTab<R> tw = TwTab<R>();
-            cx<T> o[R];
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                cx<T> acc = v[0];
-#pragma unroll
-                for (int j = 1; j < R; ++j) {
-                    const int m = (j * k) % R;
-                    const cx<T> w((T)tw.re[m], INV ? (T)(-tw.im[m]) : (T)tw.im[m]);
-                    fma_cx(acc, v[j], w);
-                }
-                o[k] = acc;
-            }
-#pragma unroll
-            for (int k = 0; k < R; ++k) v[k] = o[k];
-        } else if constexpr (is_base_radix(R)) {
-            Bfly<T, R, INV>::run(v, nullptr, 0);
-        } else {
-            constexpr int R1 = first_factor(R), R2 = R / R1;
-            constexpr TwTab<R> tw = TwTab<R>();
-            cx<T> w[R];
-#pragma unroll
-            for (int t2 = 0; t2 < R2; ++t2) {
-                cx<T> sub[R1];
-#pragma unroll
-                for (int t1 = 0; t1 < R1; ++t1) sub[t1] = v[t1 * R2 + t2];
-                RegFFT<T, R1, INV>::run(sub);
-#pragma unroll
-                for (int k1 = 0; k1 < R1; ++k1) {
-                    const int m = (t2 * k1) % R;
-                    if (m == 0) {
-                        w[k1 * R2 + t2] = sub[k1];
-                    } else {
-                        const cx<T> tf((T)tw.re[m], INV ? (T)(-tw.im[m]) : (T)tw.im[m]);
-                        w[k1 * R2 + t2] = sub[k1] * tf;
-                    }
-                }
-            }
-#pragma unroll
-            for (int k1 = 0; k1 < R1; ++k1) {
-                cx<T> sub[R2];
-#pragma unroll
-                for (int t2 = 0; t2 < R2; ++t2) sub[t2] = w[k1 * R2 + t2];
-                RegFFT<T, R2, INV>::run(sub);
-#pragma unroll
-                for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = sub[k2];
-            }
-        }
-    }
-};
 
 // Columns per workgroup in pass 1: CT x 8 B (c64) contiguous per row -- 128-byte segments for
 // CT = 16, 256-byte for CT = 32.

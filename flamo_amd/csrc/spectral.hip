@@ -1,0 +1,735 @@
+// Fused frequency-sampling pipeline for gfx950 (MI355X):   y = irfft( H[f] . rfft(x) )   in three launches.
+//
+// flamo's Shell applies FFT -> per-bin products -> iFFT (system.py:839-855 with dsp.py:88, dsp.py:922-924,
+// dsp.py:114).  When the core is a chain of per-bin products the whole Shell is ONE linear operator per batch
+// item and the spectrum in between is private to it, so it is kept in whatever layout suits the hardware:
+//
+//   time domain      x, y : (B, T, G)  channel-innermost, exactly as the user hands it in / gets it back
+//   column pass  (K1)     : L1-point FFTs over t1 of the packed sequence z[c + L2 t1] = x[2j] + i x[2j+1] for a
+//                           tile of CT columns x ALL G channels (CT*G*8 B = 256-byte runs of x per row: whole
+//                           lines, no layout-conversion pass), inter-pass twiddle, scratch S[b][k1][c][g]
+//   row pass     (mid)    : a workgroup owns rows k1 = r and L1-r of ALL channels of one batch item: L2-point
+//                           FFTs over c, real-FFT split step (couples bin k with L-k = the mirror row), the
+//                           per-bin product Y[f] = H[f] X[f] on the 2 L2 bins it holds, Hermitian pre-step of
+//                           the inverse transform, L2-point inverse FFTs, twiddle, scratch S2[b][k1][c][g].
+//                           The spectrum leaves only if the backward pass needs it, in "row-major bin order"
+//                           i = k1*L2 + k2 for bin k = k1 + L1*k2 (contiguous 8*L2-byte runs; Nyquist at i = L).
+//   column pass  (K3)     : L1-point inverse FFTs over k1 for a tile of columns x all channels, scale, anti-alias
+//                           envelope, y written channel-innermost.
+//
+// Against the layered route (layout conversion, two FFT passes, product, two inverse passes) the (B, M, N)
+// spectrum is never written and re-read between the transforms and the product: 6 passes over the data
+// instead of 11.  The same three kernels run the backward pass (irfft' = weighted rfft, rfft' = weighted irfft).
+#include "common.h"
+#include "regfft.h"
+#include <type_traits>
+
+namespace fl {
+
+typedef cx<float> cf;
+
+// lane <-> lane^1 exchange of one dword (DPP quad_perm [1,0,3,2])
+__device__ __forceinline__ float swap1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+struct ColsArgs {
+    const float* x;       // forward: real (Bn, t_len, G)
+    float* y;             // inverse: real (Bn, t_len, G)
+    cf* S;                // (Bn, L1, L2, G)
+    const cf* W;          // W_n^j, j < n
+    int n, L, L1, L2, G, cgs /* log2 CG */, CT, nct /* L2 / CT */, ngt /* G / CG */;
+    int t_len, t_lim;
+    float scale;
+    double env_log2;
+};
+
+// Global accesses as (workgroup-uniform base pointer) + (32-bit byte offset per lane): the address then costs one
+// VGPR per access (scalar base + vector offset form) instead of a 64-bit pair -- with 16..50 accesses in flight per
+// thread that is a wavefront per SIMD.  Every array addressed this way spans < 4 GB per batch item.
+template <typename P>
+__device__ __forceinline__ P& at(P* base, unsigned byte_off) {
+    return *reinterpret_cast<P*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(base)) + byte_off);
+}
+
+// streaming data (read once / written once): non-temporal, so that it does not evict the response slices the batch
+// items of a row pair share in the XCD's L2
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf ld_nt(const cf* base, unsigned byte_off) {
+    const v2f q = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(base) + byte_off));
+    return cf(q.x, q.y);
+}
+__device__ __forceinline__ void st_nt(cf* base, unsigned byte_off, cf v) {
+    v2f q;
+    q.x = v.x;
+    q.y = v.y;
+    __builtin_nontemporal_store(q, reinterpret_cast<v2f*>(reinterpret_cast<char*>(base) + byte_off));
+}
+
+__device__ __forceinline__ float env_at(double env_log2, int t) { return exp2f((float)(env_log2 * (double)t)); }
+
+// ---------------------------------------------------------------- K1: forward column pass
+// Workgroup = (batch item, tile of CT columns, tile of CG channels): VT = CT*CG "virtual columns" v = cl*CG + gl,
+// lanes run over v, so every global access of a wavefront is VT*8 contiguous bytes per row.
+// The (re, im) pair of z[j] sits G floats apart in x: the even lane of a channel pair loads x[2j][g..g+1], the
+// odd one x[2j+1][g..g+1] (8-byte loads, the VT lanes cover one contiguous run of both sample rows), and one
+// DPP exchange turns that into (re, im) per channel.
+template <int A, int B, int VT, int RG, bool PLAIN>
+__global__ void __launch_bounds__(256, 3) spec_cols_fwd(ColsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LEN = A * B, LENP = LEN | 1;
+    cf* U = reinterpret_cast<cf*>(smem);   // [VT][LENP]
+    cf* tw = U + VT * LENP;                 // W_LEN^m
+    cf* t2 = tw + LEN;                      // [CT][B]: W_L^(c * A * kb)
+    int blk = blockIdx.x;
+    const int ct = blk % a.nct; blk /= a.nct;
+    const int gt = blk % a.ngt;
+    const int b = blk / a.ngt;
+    const int CG = 1 << a.cgs;
+    const int c0 = ct * a.CT, g0 = gt * CG;
+    const int twstep = a.n / LEN;
+    for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[j * twstep];
+    for (int j = threadIdx.x; j < a.CT * B; j += 256) {
+        const int cl = j / B, kb = j - cl * B;
+        t2[j] = a.W[2 * (c0 + cl) * A * kb];
+    }
+    __syncthreads();
+    constexpr int NIT = B * VT, NR = (NIT + 255) / 256;
+    const float* xb = a.x + (size_t)b * a.t_len * a.G + g0;
+#pragma unroll 1
+    for (int r0 = 0; r0 < NR; r0 += RG) {
+        cf v[RG][A];
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            const int item = threadIdx.x + (r0 + rr) * 256;
+            if (r0 + rr < NR && item < NIT) {
+                const int tb = item / VT, vv = item % VT;
+                const int cl = vv >> a.cgs, gl = vv & (CG - 1);
+                const int par = gl & 1;
+#pragma unroll
+                for (int ta = 0; ta < A; ++ta) {
+                    const int j = c0 + cl + a.L2 * (ta * B + tb);
+                    const int t = 2 * j + par;
+                    float2 q = make_float2(0.f, 0.f);
+                    if (PLAIN || t < a.t_lim) q = at(reinterpret_cast<const float2*>(xb), 4u * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par)));
+                    v[rr][ta] = cf(q.x, q.y);
+                }
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            const int item = threadIdx.x + (r0 + rr) * 256;
+            if (r0 + rr < NR && item < NIT) {
+                const int tb = item / VT, vv = item % VT;
+                const int cl = vv >> a.cgs, gl = vv & (CG - 1);
+                const int par = gl & 1;
+#pragma unroll
+                for (int ta = 0; ta < A; ++ta) {
+                    cf q = v[rr][ta];
+                    if (!PLAIN && a.env_log2 != 0.0) {
+                        const int t = 2 * (c0 + cl + a.L2 * (ta * B + tb)) + par;
+                        const float e = env_at(a.env_log2, t);
+                        q.x *= e;
+                        q.y *= e;
+                    }
+                    // even lane holds (re_g, re_g+1), odd lane (im_g-1, im_g)
+                    const float got = swap1(par ? q.x : q.y);
+                    v[rr][ta] = par ? cf(got, q.y) : cf(q.x, got);
+                }
+                RegFFT<float, A, false>::run(v[rr]);
+                cf* u = U + vv * LENP + tb;
+                u[0] = v[rr][0];
+#pragma unroll
+                for (int ka = 1; ka < A; ++ka) u[ka * B] = v[rr][ka] * tw[ka * tb];
+            }
+        }
+    }
+    __syncthreads();
+    cf* out = a.S + (size_t)b * a.L1 * a.L2 * a.G + g0;
+    for (int item = threadIdx.x; item < A * VT; item += 256) {
+        const int ka = item / VT, vv = item % VT;
+        const int cl = vv >> a.cgs, gl = vv & (CG - 1);
+        const int c = c0 + cl;
+        cf v[B];
+        const cf* u = U + vv * LENP + ka * B;
+#pragma unroll
+        for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
+        RegFFT<float, B, false>::run(v);
+        const cf w1 = a.W[2 * c * ka];
+        const cf* w2 = t2 + cl * B;
+#pragma unroll
+        for (int kb = 0; kb < B; ++kb) {
+            const int k1 = ka + A * kb;
+            at(out, 8u * (((unsigned)k1 * (unsigned)a.L2 + (unsigned)c) * (unsigned)a.G + (unsigned)gl)) = v[kb] * (w1 * w2[kb]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- K3: inverse column pass
+template <int A, int B, int VT, int RG>
+__global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LEN = A * B, LENP = LEN | 1;
+    cf* U = reinterpret_cast<cf*>(smem);   // [VT][LENP]
+    cf* tw = U + VT * LENP;                 // W_LEN^m
+    int blk = blockIdx.x;
+    const int ct = blk % a.nct; blk /= a.nct;
+    const int gt = blk % a.ngt;
+    const int b = blk / a.ngt;
+    const int CG = 1 << a.cgs;
+    const int c0 = ct * a.CT, g0 = gt * CG;
+    const int twstep = a.n / LEN;
+    for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[j * twstep];
+    __syncthreads();
+    constexpr int NIT = B * VT, NR = (NIT + 255) / 256;
+    const cf* in = a.S + (size_t)b * a.L1 * a.L2 * a.G + g0;
+#pragma unroll 1
+    for (int r0 = 0; r0 < NR; r0 += RG) {
+        cf v[RG][A];
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            const int item = threadIdx.x + (r0 + rr) * 256;
+            if (r0 + rr < NR && item < NIT) {
+                const int tb = item / VT, vv = item % VT;
+                const int cl = vv >> a.cgs, gl = vv & (CG - 1);
+#pragma unroll
+                for (int ta = 0; ta < A; ++ta)
+                    v[rr][ta] = at(in, 8u * (((unsigned)(ta * B + tb) * (unsigned)a.L2 + (unsigned)(c0 + cl)) * (unsigned)a.G + (unsigned)gl));
+            }
+        }
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            const int item = threadIdx.x + (r0 + rr) * 256;
+            if (r0 + rr < NR && item < NIT) {
+                const int tb = item / VT, vv = item % VT;
+                RegFFT<float, A, true>::run(v[rr]);
+                cf* u = U + vv * LENP + tb;
+                u[0] = v[rr][0];
+#pragma unroll
+                for (int ka = 1; ka < A; ++ka) u[ka * B] = v[rr][ka] * conj(tw[ka * tb]);
+            }
+        }
+    }
+    __syncthreads();
+    float* yb = a.y + (size_t)b * a.t_len * a.G + g0;
+    for (int item = threadIdx.x; item < A * VT; item += 256) {
+        const int ka = item / VT, vv = item % VT;
+        const int cl = vv >> a.cgs, gl = vv & (CG - 1);
+        const int par = gl & 1;
+        cf v[B];
+        const cf* u = U + vv * LENP + ka * B;
+#pragma unroll
+        for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
+        RegFFT<float, B, true>::run(v);
+#pragma unroll
+        for (int kb = 0; kb < B; ++kb) {
+            const int t1 = ka + A * kb;
+            const int t = 2 * (c0 + cl + a.L2 * t1) + par;
+            // (re_g, im_g) per lane -> even lane (re_g, re_g+1) at sample 2j, odd lane (im_g-1, im_g) at 2j+1
+            const float got = swap1(par ? v[kb].x : v[kb].y);
+            float2 q = par ? make_float2(got, v[kb].y) : make_float2(v[kb].x, got);
+            float s = a.scale;
+            if (a.env_log2 != 0.0) s *= env_at(a.env_log2, t);
+            q.x *= s;
+            q.y *= s;
+            if (t < a.t_lim) at(reinterpret_cast<float2*>(yb), 4u * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par))) = q;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- mid: rows + split + product + pre-step + inverse rows
+struct MidArgs {
+    const cf* S;          // (Bn, L1, L2, NI)
+    cf* S2;               // (Bn, L1, L2, NO)                      [DO_INV]
+    cf* Xs;               // spectrum out, row-major bin order: Xs[b*xs_b + n*xs_n + i], or null
+    long xs_b, xs_n;
+    const cf* H;          // H[m*hs_m + n*hs_n + i], row-major bin order  [HAS_H]
+    long hs_m, hs_n;
+    int conj_h;
+    const cf* W;
+    int n, L, L1, L2, Bn;
+    float spec_scale;     // scale of the forward transform
+    int spec_interior2;   // double the interior bins of the spectrum (irfft backward)
+    int pre_half;         // halve the interior bins in front of the inverse transform (rfft backward)
+};
+
+// bin pair (k, L-k) number p of primary row r: where the partner sits (slot, column); false when p owns no pair
+__device__ __forceinline__ bool pair_of(int r, bool selfm, int p, int LEN, int& slotB, int& colB, bool& dc) {
+    dc = false;
+    if (r == 0) {
+        if (2 * p > LEN) return false;
+        dc = p == 0;
+        slotB = 0;
+        colB = (2 * p == LEN || p == 0) ? p : LEN - p;
+    } else if (selfm) {
+        if (2 * p >= LEN) return false;
+        slotB = 0;
+        colB = LEN - 1 - p;
+    } else {
+        slotB = 1;
+        colB = LEN - 1 - p;
+    }
+    return true;
+}
+
+// BG batch items per workgroup (256*BG threads): a response row fetched for a bin pair is applied to the BG spectra in
+// registers, so the response's trips through the TA/L2 shrink by BG (at one item per workgroup they are 8x the
+// signal's bytes).  Streaming data (scratch, stored spectrum) is non-temporal so that it does not evict the response
+// slice that the batch items of a row pair share in their XCD's L2.
+template <int A, int B, int NI, int NO, bool HAS_H, bool DO_INV, int BG, int MS>
+__global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LEN = A * B, LENP = LEN | 1, NCH = NI > NO ? NI : NO, NT = 256 * MS;
+    constexpr int RPR = NT / A;              // rows per stage-2 round (every k_a of a row in the same round)
+    // MS: the product of a bin pair is split over MS threads (output channels); 256*MS threads
+    static_assert(NT % A == 0 && NO % MS == 0 && NI % MS == 0, "tile shape");
+    cf* U = reinterpret_cast<cf*>(smem);     // [BG][2][NCH][LENP]
+    cf* tw = U + BG * 2 * NCH * LENP;        // W_LEN^m
+    cf* ws = tw + LEN;                       // W_n^(L1*k2)
+    cf* wi2 = ws + LEN;                      // [2][B]: W_L^(row * A * kb)
+    // XCD-aware order: the batch groups of one row pair run back to back on the same XCD (block q runs on XCD
+    // q % 8), so that pair's slice of H is fetched from HBM once and from that L2 afterwards
+    const int P = a.L1 / 2 + 1;
+    const int nbq = (a.Bn + BG - 1) / BG;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int r = (q / nbq) * 8 + xcd, b0 = (q % nbq) * BG;
+    if (r >= P) return;
+    const int nb = min(BG, a.Bn - b0);
+    const int rm = (a.L1 - r) % a.L1;
+    const bool selfm = rm == r;
+    const int tid = threadIdx.x;
+    for (int j = tid; j < LEN; j += NT) {
+        tw[j] = a.W[j * (a.n / LEN)];
+        ws[j] = a.W[a.L1 * j];
+    }
+    if (DO_INV && tid < 2 * B) {
+        const int slot = tid / B, kb = tid - slot * B;
+        wi2[tid] = a.W[2 * (slot ? rm : r) * A * kb];
+    }
+    __syncthreads();
+    const unsigned bstride_i = (unsigned)a.L1 * (unsigned)a.L2 * NI, bstride_o = (unsigned)a.L1 * (unsigned)a.L2 * NO;
+    // ---- P1: load + first stage of the forward row FFTs.  item = (batch item, slot, tb, n), n fastest: the loads of
+    // a wavefront cover contiguous (tb, n) runs of a scratch row
+    {
+        const cf* Sb = a.S + (size_t)b0 * bstride_i;
+        for (int item = tid; item < BG * 2 * B * NI; item += NT) {
+            const int nn = item % NI, tb = (item / NI) % B, bs = item / (NI * B);
+            const int slot = bs & 1, bb = bs >> 1;
+            if ((slot && selfm) || bb >= nb) continue;
+            const unsigned src0 = (unsigned)bb * bstride_i + (unsigned)(slot ? rm : r) * (unsigned)a.L2 * NI + nn;
+            cf v[A];
+#pragma unroll
+            for (int ta = 0; ta < A; ++ta) v[ta] = ld_nt(Sb, 8u * (src0 + (unsigned)(ta * B + tb) * NI));
+            RegFFT<float, A, false>::run(v);
+            cf* u = U + (bs * NCH + nn) * LENP + tb;
+            u[0] = v[0];
+#pragma unroll
+            for (int ka = 1; ka < A; ++ka) u[ka * B] = v[ka] * tw[ka * tb];
+        }
+    }
+    __syncthreads();
+    // ---- P2: second stage, natural order written back in place (read all, barrier, write all per round)
+    for (int row0 = 0; row0 < BG * 2 * NI; row0 += RPR) {
+        const int rl = row0 + tid % RPR, ka = tid / RPR;
+        const int bs = rl / NI, nn = rl % NI;
+        const bool act = rl < BG * 2 * NI && !((bs & 1) && selfm) && (bs >> 1) < nb;
+        cf v[B];
+        cf* urow = U + (bs * NCH + nn) * LENP;
+        if (act) {
+#pragma unroll
+            for (int tb = 0; tb < B; ++tb) v[tb] = urow[ka * B + tb];
+            RegFFT<float, B, false>::run(v);
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int kb = 0; kb < B; ++kb) urow[ka + A * kb] = v[kb];
+        }
+        __syncthreads();
+    }
+    // ---- P3: split step, spectrum store, product, Hermitian pre-step.  Thread (p, ms): bin pair (k, L-k) number p, output
+    // channels [ms NO/MS, (ms+1) NO/MS), all BG batch items.  The MS threads of a pair read the same two columns of U
+    // (all input channels) and write their own output channels back into them: one barrier between the two.
+    {
+        const cf wr = a.W[r];
+        const float hs = 0.5f * a.spec_scale, wi = a.spec_interior2 ? 2.f : 1.f;
+        const float ph = a.pre_half ? 0.5f : 1.f;
+        const int ms = tid / 256;
+        for (int p0 = 0; p0 < LEN; p0 += 256) {
+            const int p = p0 + (tid & 255);
+            int slotB = 0, colB = 0;
+            bool dc = false;
+            const bool valid = p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
+            const unsigned ik = (unsigned)r * LEN + p;
+            const unsigned im = dc ? (unsigned)a.L : (unsigned)(slotB ? rm : r) * LEN + colB;
+            cf xk[BG][NI], xm[BG][NI];
+            cf wk(1.f, 0.f);
+            if (valid) {
+                wk = wr * ws[p];
+#pragma unroll
+                for (int bb = 0; bb < BG; ++bb) {
+#pragma unroll
+                    for (int nn = 0; nn < NI; ++nn) {
+                        const cf zk = U[((2 * bb) * NCH + nn) * LENP + p];
+                        const cf zm = U[((2 * bb + slotB) * NCH + nn) * LENP + colB];
+                        if (dc) {
+                            xk[bb][nn] = cf(a.spec_scale * (zk.x + zk.y), 0.f);     // X[0]
+                            xm[bb][nn] = cf(a.spec_scale * (zk.x - zk.y), 0.f);     // X[L]
+                        } else {
+                            const cf pk = zk + conj(zm), dk = zk - conj(zm);
+                            const cf ok = pk + mul_mi(wk * dk);
+                            const cf pm = zm + conj(zk), dm = zm - conj(zk);
+                            const cf wm(-wk.x, wk.y);                               // W_n^(L-k) = -conj(W_n^k)
+                            const cf om = pm + mul_mi(wm * dm);
+                            xk[bb][nn] = cf(hs * wi * ok.x, hs * wi * ok.y);
+                            xm[bb][nn] = cf(hs * wi * om.x, hs * wi * om.y);
+                        }
+                    }
+                }
+                if (a.Xs) {     // the MS threads of a pair share the stores: input channels [ms NI/MS, (ms+1) NI/MS)
+#pragma unroll
+                    for (int bb = 0; bb < BG; ++bb) {
+                        if (bb >= nb) break;
+                        cf* xo = a.Xs + (size_t)(b0 + bb) * a.xs_b;
+#pragma unroll
+                        for (int n2 = 0; n2 < NI / MS; ++n2) {
+                            const int nn = ms * (NI / MS) + n2;
+                            cf vk = xk[bb][0], vm = xm[bb][0];
+#pragma unroll
+                            for (int e = 1; e < NI; ++e)
+                                if (e == nn) { vk = xk[bb][e]; vm = xm[bb][e]; }
+                            st_nt(xo, 8u * ((unsigned)nn * (unsigned)a.xs_n + ik), vk);
+                            if (im != ik) st_nt(xo, 8u * ((unsigned)nn * (unsigned)a.xs_n + im), vm);
+                        }
+                    }
+                }
+            }
+            if (!DO_INV) continue;
+            if (MS > 1) __syncthreads();
+            if (!valid) continue;
+            const cf cwk = conj(wk);
+#pragma unroll
+            for (int m2 = 0; m2 < NO / MS; ++m2) {
+                const int m = ms * (NO / MS) + m2;
+                cf hkv[NI], hmv[NI];
+                if (HAS_H) {
+                    // plane (m, n) as a workgroup-uniform base (scalar arithmetic), the bin as the lane's 32-bit offset
+                    const cf* Hm = a.H + (size_t)__builtin_amdgcn_readfirstlane(m) * a.hs_m;
+#pragma unroll
+                    for (int nn = 0; nn < NI; ++nn) {
+                        hkv[nn] = at(Hm + (size_t)nn * a.hs_n, 8u * ik);
+                        hmv[nn] = at(Hm + (size_t)nn * a.hs_n, 8u * im);
+                        if (a.conj_h) {
+                            hkv[nn].y = -hkv[nn].y;
+                            hmv[nn].y = -hmv[nn].y;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int bb = 0; bb < BG; ++bb) {
+                    cf yk, ym;
+                    if (HAS_H) {
+                        yk = cf(0.f, 0.f);
+                        ym = cf(0.f, 0.f);
+#pragma unroll
+                        for (int nn = 0; nn < NI; ++nn) {
+                            fma_cx(yk, hkv[nn], xk[bb][nn]);
+                            fma_cx(ym, hmv[nn], xm[bb][nn]);
+                        }
+                    } else {
+                        yk = xk[bb][0];
+                        ym = xm[bb][0];
+#pragma unroll
+                        for (int e = 1; e < NI; ++e)
+                            if (e == m) { yk = xk[bb][e]; ym = xm[bb][e]; }
+                    }
+                    cf zk, zm;
+                    if (dc) {      // Zf[0] from the real parts of Y[0] and Y[L] (C2R semantics)
+                        zk = cf(yk.x + ym.x, yk.x - ym.x);
+                        zm = zk;
+                    } else {
+                        const cf xa(ph * yk.x, ph * yk.y), xb(ph * ym.x, ph * ym.y);
+                        const cf s_ = xa + conj(xb), t_ = mul_i(cwk * (xa - conj(xb)));
+                        zk = s_ + t_;
+                        zm = conj(s_ - t_);
+                    }
+                    U[((2 * bb) * NCH + m) * LENP + p] = zk;
+                    if (im != ik && !dc) U[((2 * bb + slotB) * NCH + m) * LENP + colB] = zm;
+                }
+            }
+        }
+    }
+    if (!DO_INV) return;
+    __syncthreads();
+    // ---- P4: first stage of the inverse row FFTs, in place (a thread owns positions tb + B*i of its row)
+    for (int item = tid; item < BG * 2 * B * NO; item += NT) {
+        const int m = item % NO, tb = (item / NO) % B, bs = item / (NO * B);
+        if (((bs & 1) && selfm) || (bs >> 1) >= nb) continue;
+        cf* u = U + (bs * NCH + m) * LENP + tb;
+        cf v[A];
+#pragma unroll
+        for (int ta = 0; ta < A; ++ta) v[ta] = u[ta * B];
+        RegFFT<float, A, true>::run(v);
+        u[0] = v[0];
+#pragma unroll
+        for (int ka = 1; ka < A; ++ka) u[ka * B] = v[ka] * conj(tw[ka * tb]);
+    }
+    __syncthreads();
+    // ---- P5: second stage, inter-pass twiddle conj(W_L^(row*c)), store
+    {
+        cf* S2b = a.S2 + (size_t)b0 * bstride_o;
+        for (int row0 = 0; row0 < BG * 2 * NO; row0 += RPR) {
+            const int rl = row0 + tid % RPR, ka = tid / RPR;
+            const int bs = rl / NO, m = rl % NO;
+            const int slot = bs & 1, bb = bs >> 1;
+            if (rl >= BG * 2 * NO || (slot && selfm) || bb >= nb) continue;
+            const int row = slot ? rm : r;
+            cf v[B];
+            const cf* u = U + (bs * NCH + m) * LENP + ka * B;
+#pragma unroll
+            for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
+            RegFFT<float, B, true>::run(v);
+            const cf w1 = a.W[2 * row * ka];
+            const unsigned dst0 = (unsigned)bb * bstride_o + (unsigned)row * (unsigned)a.L2 * NO + m;
+#pragma unroll
+            for (int kb = 0; kb < B; ++kb) {
+                const int c = ka + A * kb;
+                st_nt(S2b, 8u * (dst0 + (unsigned)c * NO), v[kb] * conj(w1 * wi2[slot * B + kb]));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- bin order conversion
+// natural bin order k <-> row-major order i = (k % L1) * L2 + k / L1 (Nyquist bin L stays at L), per plane
+__global__ void __launch_bounds__(256) permute_bins_kernel(const cf* __restrict__ src, long sp, cf* __restrict__ dst, long dp,
+                                                           int L1, int L2, int inverse) {
+    const int L = L1 * L2;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i > L) return;
+    const cf* s = src + (size_t)blockIdx.y * sp;
+    cf* d = dst + (size_t)blockIdx.y * dp;
+    const int k = (i == L) ? L : (i / L2) + L1 * (i % L2);
+    if (inverse) d[k] = s[i];      // row-major -> natural
+    else d[i] = s[k];              // natural -> row-major (coalesced stores)
+}
+
+// ---------------------------------------------------------------- host side
+struct Split { int len, A, B; };
+static const Split kSplits[] = {{200, 8, 25}, {240, 16, 15}, {300, 12, 25}, {320, 16, 20}, {400, 16, 25}, {480, 32, 15}};
+static const Split* split_of(int len) {
+    for (const Split& s : kSplits)
+        if (s.len == len) return &s;
+    return nullptr;
+}
+
+static int spec_plan(int nfft, int& L1, int& L2) {
+    // (L1, L2): column length x row length; both must be fast-split lengths and L2 >= L1 so a row pair of all channels
+    // stays small
+    static const int pairs[][2] = {{200, 240}, {300, 320}, {400, 480}};
+    for (auto& p : pairs)
+        if (2L * p[0] * p[1] == nfft) {
+            L1 = p[0];
+            L2 = p[1];
+            return FL_OK;
+        }
+    set_error("spectral: nfft=%d has no fused plan", nfft);
+    return FL_ERR_UNSUPPORTED;
+}
+
+static int g_spec_vt = 32, g_spec_rg = 2;
+
+static int cols_setup(ColsArgs& a, int nfft, int Bn, int t_len, int t_lim, int G, const void* W, int vt) {
+    int L1, L2;
+    int rc = spec_plan(nfft, L1, L2);
+    if (rc) return rc;
+    FL_REQUIRE(Bn > 0 && G >= 2 && (G & 1) == 0 && t_len >= 0 && W, "spectral cols: bad arguments (even channel count >= 2)");
+    int cg = G < vt ? G : vt;
+    FL_REQUIRE((cg & (cg - 1)) == 0 && G % cg == 0, "spectral cols: channel count must be a power of two or a multiple of %d", vt);
+    int cgs = 0;
+    while ((1 << cgs) < cg) ++cgs;
+    a.n = nfft; a.L = nfft / 2; a.L1 = L1; a.L2 = L2; a.G = G; a.cgs = cgs; a.CT = vt / cg;
+    FL_REQUIRE(L2 % a.CT == 0, "spectral cols: column tile does not divide the row length");
+    a.nct = L2 / a.CT; a.ngt = G / cg;
+    a.t_len = t_len; a.t_lim = t_lim < nfft ? t_lim : nfft;
+    a.W = (const cf*)W;
+    return FL_OK;
+}
+
+template <int A, int B>
+static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStream_t st) {
+    constexpr int LEN = A * B, LENP = LEN | 1;
+#define FL_COLS(VT_, RG_)                                                                                        \
+    {                                                                                                            \
+        const size_t lds = ((size_t)VT_ * LENP + LEN + (size_t)VT_ * B) * sizeof(cf);                            \
+        if (inverse) hipLaunchKernelGGL((spec_cols_inv<A, B, VT_, RG_>), dim3(nblk), dim3(256), lds, st, a);     \
+        else if (a.env_log2 == 0.0 && a.t_lim >= a.n)                                                            \
+            hipLaunchKernelGGL((spec_cols_fwd<A, B, VT_, RG_, true>), dim3(nblk), dim3(256), lds, st, a);        \
+        else hipLaunchKernelGGL((spec_cols_fwd<A, B, VT_, RG_, false>), dim3(nblk), dim3(256), lds, st, a);      \
+    }
+    const int vt = a.CT << a.cgs;
+    if (vt == 32) {
+        if (g_spec_rg == 1) FL_COLS(32, 1) else if (g_spec_rg == 4) FL_COLS(32, 4) else FL_COLS(32, 2)
+    } else {
+        if (g_spec_rg == 1) FL_COLS(16, 1) else FL_COLS(16, 2)
+    }
+#undef FL_COLS
+}
+
+static int cols_launch(bool inverse, const ColsArgs& a, int Bn, hipStream_t st) {
+    const size_t nblk = (size_t)Bn * a.nct * a.ngt;
+    FL_REQUIRE(nblk < (1ull << 31), "spectral cols: grid too large");
+    switch (a.L1) {
+        case 200: launch_cols<8, 25>(inverse, a, (unsigned)nblk, st); break;
+        case 300: launch_cols<12, 25>(inverse, a, (unsigned)nblk, st); break;
+        case 400: launch_cols<16, 25>(inverse, a, (unsigned)nblk, st); break;
+        default: set_error("spectral cols: unsupported column length %d", a.L1); return FL_ERR_UNSUPPORTED;
+    }
+    FL_CHECK_LAUNCH(inverse ? "spec_cols_inv" : "spec_cols_fwd");
+    return FL_OK;
+}
+
+static int g_mid_bg = 1;
+
+template <int A, int B, int NI, int NO, int BG, int MS>
+static void launch_mid_bg(const MidArgs& a, hipStream_t st) {
+    constexpr int LEN = A * B, LENP = LEN | 1, NCH = NI > NO ? NI : NO;
+    const size_t lds = ((size_t)BG * 2 * NCH * LENP + 2 * LEN + 2 * B) * sizeof(cf);
+    const int P = a.L1 / 2 + 1;
+    const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * cdiv_i(a.Bn, BG));
+    if (a.S2) {
+        if (a.H) hipLaunchKernelGGL((spec_mid<A, B, NI, NO, true, true, BG, MS>), dim3(nblk), dim3(256 * MS), lds, st, a);
+        else if constexpr (NI == NO) hipLaunchKernelGGL((spec_mid<A, B, NI, NO, false, true, BG, MS>), dim3(nblk), dim3(256 * MS), lds, st, a);
+    } else {
+        if constexpr (NI == NO) hipLaunchKernelGGL((spec_mid<A, B, NI, NO, false, false, BG, MS>), dim3(nblk), dim3(256 * MS), lds, st, a);
+    }
+}
+
+template <int A, int B, int NI, int NO>
+static void launch_mid_n(const MidArgs& a, unsigned, hipStream_t st) {
+    constexpr int LEN = A * B, LENP = LEN | 1, NCH = NI > NO ? NI : NO;
+    // (two batch items per workgroup -- the response row applied to two spectra -- measured slower at config 2:
+    // 104 us with 256 threads, 118 us with 512, against 98 us; the kernel keeps the BG/MS parameters for that experiment)
+    launch_mid_bg<A, B, NI, NO, 1, 1>(a, st);
+}
+
+template <int A, int B>
+static int launch_mid(const MidArgs& a, int NI, int NO, unsigned nblk, hipStream_t st) {
+#define FL_MID(NI_, NO_)                              \
+    if (NI == NI_ && NO == NO_) {                     \
+        launch_mid_n<A, B, NI_, NO_>(a, nblk, st);    \
+        return FL_OK;                                 \
+    }
+    FL_MID(2, 2) FL_MID(4, 4) FL_MID(8, 8) FL_MID(16, 16)
+    FL_MID(2, 4) FL_MID(4, 2) FL_MID(2, 8) FL_MID(8, 2) FL_MID(4, 8) FL_MID(8, 4)
+#undef FL_MID
+    set_error("spectral mid: no kernel for %d -> %d channels", NI, NO);
+    return FL_ERR_UNSUPPORTED;
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+extern "C" {
+
+int fl_spec_plan(int nfft, int* L1, int* L2) {
+    int l1 = 0, l2 = 0;
+    int rc = spec_plan(nfft, l1, l2);
+    if (rc) return rc;
+    if (L1) *L1 = l1;
+    if (L2) *L2 = l2;
+    return FL_OK;
+}
+
+int fl_spec_supports(int nfft, int n_in, int n_out) {
+    int l1, l2;
+    if (spec_plan(nfft, l1, l2) != FL_OK) return 0;
+    auto ok = [](int c) { return c == 2 || c == 4 || c == 8 || c == 16; };
+    if (!ok(n_in) || !ok(n_out)) return 0;
+    if (n_in != n_out && (n_in > 8 || n_out > 8)) return 0;
+    return 1;
+}
+
+int fl_debug_set_spec(int vt, int rg) {
+    g_spec_vt = (vt == 16) ? 16 : 32;
+    g_spec_rg = (rg % 100 == 1 || rg % 100 == 4) ? rg % 100 : 2;
+    g_mid_bg = (rg >= 100) ? (rg / 100) % 10 : 1;     // rg = 100*(2: two batch items per workgroup) + load group
+    return FL_OK;
+}
+
+int fl_spec_cols_fwd_f32(const void* x, int Bn, int t_len, int G, void* S, const void* W, int nfft, double env_log2,
+                         void* stream) {
+    FL_REQUIRE(x && S, "spec_cols_fwd: null pointer");
+    FL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 8 == 0, "spec_cols_fwd: x must be 8-byte aligned");
+    if (Bn == 0) return FL_OK;
+    ColsArgs a = {};
+    int rc = cols_setup(a, nfft, Bn, t_len, t_len, G, W, g_spec_vt);
+    if (rc) return rc;
+    a.x = (const float*)x;
+    a.S = (cf*)S;
+    a.env_log2 = env_log2;
+    return cols_launch(false, a, Bn, (hipStream_t)stream);
+}
+
+int fl_spec_cols_inv_f32(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                         double env_log2, void* stream) {
+    FL_REQUIRE(S2 && y, "spec_cols_inv: null pointer");
+    FL_REQUIRE(reinterpret_cast<uintptr_t>(y) % 8 == 0, "spec_cols_inv: y must be 8-byte aligned");
+    FL_REQUIRE(t_out >= 0 && t_out <= t_len, "spec_cols_inv: t_out must be in [0, t_len]");
+    if (Bn == 0) return FL_OK;
+    ColsArgs a = {};
+    int rc = cols_setup(a, nfft, Bn, t_len, t_out, G, W, g_spec_vt);
+    if (rc) return rc;
+    a.y = (float*)y;
+    a.S = (cf*)S2;
+    a.scale = (float)scale;
+    a.env_log2 = env_log2;
+    return cols_launch(true, a, Bn, (hipStream_t)stream);
+}
+
+int fl_spec_mid_f32(const void* S, void* S2, void* Xs, long xs_b, long xs_n, const void* H, long hs_m, long hs_n, int conj_h,
+                    const void* W, int nfft, int Bn, int NI, int NO, double spec_scale, int spec_interior2, int pre_half,
+                    void* stream) {
+    FL_REQUIRE(S && W, "spec_mid: null pointer");
+    FL_REQUIRE(S2 || Xs, "spec_mid: nothing to produce");
+    FL_REQUIRE(H == nullptr || S2 != nullptr, "spec_mid: a product without the inverse half is not a mode");
+    FL_REQUIRE(H != nullptr || NI == NO, "spec_mid: channel counts differ without a response");
+    if (Bn == 0) return FL_OK;
+    MidArgs a = {};
+    int rc = spec_plan(nfft, a.L1, a.L2);
+    if (rc) return rc;
+    a.S = (const cf*)S; a.S2 = (cf*)S2; a.Xs = (cf*)Xs; a.xs_b = xs_b; a.xs_n = xs_n;
+    a.H = (const cf*)H; a.hs_m = hs_m; a.hs_n = hs_n; a.conj_h = conj_h;
+    a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn;
+    a.spec_scale = (float)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half;
+    const int P = a.L1 / 2 + 1;
+    const size_t nblk = (size_t)cdiv_i(P, 8) * 8 * Bn;
+    FL_REQUIRE(nblk < (1ull << 31), "spec_mid: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.L2) {
+        case 240: rc = launch_mid<16, 15>(a, NI, NO, (unsigned)nblk, st); break;
+        case 320: rc = launch_mid<16, 20>(a, NI, NO, (unsigned)nblk, st); break;
+        case 480: rc = launch_mid<32, 15>(a, NI, NO, (unsigned)nblk, st); break;
+        default: set_error("spec_mid: unsupported row length %d", a.L2); return FL_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    FL_CHECK_LAUNCH("spec_mid");
+    return FL_OK;
+}
+
+int fl_permute_bins_c64(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
+                        void* stream) {
+    FL_REQUIRE(src && dst && nplanes >= 0 && nplanes <= 65535, "permute_bins: bad arguments");
+    int L1, L2;
+    int rc = spec_plan(nfft, L1, L2);
+    if (rc) return rc;
+    FL_REQUIRE(src_pitch > L1 * L2 && dst_pitch > L1 * L2, "permute_bins: pitch must be >= nfft/2+1");
+    if (nplanes == 0) return FL_OK;
+    hipLaunchKernelGGL(permute_bins_kernel, dim3(cdiv_i(L1 * L2 + 1, 256), nplanes), dim3(256), 0, (hipStream_t)stream,
+                       (const cf*)src, src_pitch, (cf*)dst, dst_pitch, L1, L2, inverse);
+    FL_CHECK_LAUNCH("permute_bins");
+    return FL_OK;
+}
+
+}  // extern "C"

@@ -19,7 +19,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["rfft", "irfft", "mimo", "solve", "delay_response", "sos_response", "geq_sections", "solve_dud", "to_planar", "set_bin_shard",
+__all__ = ["rfft", "irfft", "spectral_apply", "permute_bins", "mimo", "solve", "delay_response", "sos_response", "geq_sections", "solve_dud", "to_planar", "set_bin_shard",
            "bin_shard"]
 
 
@@ -440,6 +440,149 @@ def irfft(X: torch.Tensor, nfft: int, norm: str = "backward", alias_decay_db: Op
     return _Irfft.apply(X, int(nfft), _NORM_INV[norm](nfft), env)
 
 
+# ----------------------------------------------------------------------------- fused Shell pipeline
+# y = irfft(H[f] . rfft(x)) in three launches (csrc/spectral.hip): time-domain tensors stay channel-innermost
+# (B, T, G), the spectrum between the transforms and the product never goes through HBM, and what does cross the
+# boundary (the spectrum kept for the backward pass, H, dL/dH) is bin-planar in ROW-MAJOR BIN ORDER
+# (bin k = k1 + L1 k2 at element k1 L2 + k2).  float32 only; everything else takes the layered operators above.
+def spectral_supported(nfft: int, n_in: int, n_out: int) -> bool:
+    return bool(_lib.lib().fl_spec_supports(int(nfft), int(n_in), int(n_out)))
+
+
+class _PermuteBins(torch.autograd.Function):
+    """(M, rest...) per-bin tensor: natural bin order <-> row-major bin order of the fused pipeline's plan."""
+
+    @staticmethod
+    def forward(ctx, H, nfft, inverse):
+        _require_gpu(H)
+        if H.dtype != torch.complex64:
+            raise TypeError("permute_bins expects a complex64 tensor")
+        M = nfft // 2 + 1
+        if H.shape[0] != M:
+            raise ValueError(f"permute_bins: expected {M} bins along dim 0, got {H.shape[0]}")
+        Hp = _h_planar(H.resolve_conj(), True)
+        rest = tuple(H.shape[1:])
+        out = _empty_rows(rest, M, H.dtype, H.device)
+        _lib.check(_lib.lib().fl_permute_bins_c64(Hp.data_ptr(), _lead_pitch(Hp.movedim(0, -1)), out.data_ptr(), _pitch(M),
+                                                  max(_prod(rest), 1), nfft, int(inverse), _stream()), "permute_bins")
+        ctx.cfg = (nfft, inverse)
+        return out.movedim(-1, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        nfft, inverse = ctx.cfg
+        return _PermuteBins.apply(g, nfft, not inverse), None, None
+
+
+def permute_bins(H: torch.Tensor, nfft: int, inverse: bool = False) -> torch.Tensor:
+    """Per-bin tensor (M, ...) from natural to row-major bin order (``inverse``: back)."""
+    return _PermuteBins.apply(H, int(nfft), bool(inverse))
+
+
+def _spec_cols_fwd(x, nfft, env_log2):
+    """x: contiguous real float32 (B, T, G) -> scratch (B*L*G,) complex64"""
+    B, T, G = x.shape
+    S = torch.empty(B * (nfft // 2) * G, dtype=torch.complex64, device=x.device)
+    with kernel_timer.span("spec_cols_fwd"):
+        _lib.check(_lib.lib().fl_spec_cols_fwd_f32(x.data_ptr(), B, T, G, S.data_ptr(),
+                                                   twiddles(nfft, torch.float32, x.device).data_ptr(), nfft, env_log2, _stream()),
+                   "spec_cols_fwd")
+    return S
+
+
+def _spec_mid(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, want_inverse, spec_scale, interior2, pre_half):
+    """-> (S2 or None, spectrum rows (B, NI, M) or None).  Hrm: (M, NO_h, NI_h) row-major-order response view or None."""
+    dev = S.device
+    M = nfft // 2 + 1
+    Xs = _empty_rows((B, NI), M, torch.complex64, dev) if want_spec else None
+    S2 = None
+    if want_inverse:
+        S2 = S if NI == NO else torch.empty(B * (nfft // 2) * NO, dtype=torch.complex64, device=dev)   # row pairs are private: in place
+    hp = hs_m = hs_n = 0
+    if Hrm is not None:
+        hp = _lead_pitch(Hrm.movedim(0, -1))
+        hs_m, hs_n = Hrm.shape[2] * hp, hp
+        if conj_t:
+            hs_m, hs_n = hs_n, hs_m
+    P = _pitch(M)
+    tag = f"spec_mid[{NI}->{NO}" + (",H" if Hrm is not None else "") + (",inv" if want_inverse else "") + (",spec" if want_spec else "") + "]"
+    with kernel_timer.span(tag):
+        _lib.check(_lib.lib().fl_spec_mid_f32(S.data_ptr(), None if S2 is None else S2.data_ptr(),
+                                              None if Xs is None else Xs.data_ptr(), NI * P, P,
+                                              None if Hrm is None else Hrm.data_ptr(), hs_m, hs_n, int(bool(conj_t)),
+                                              twiddles(nfft, torch.float32, dev).data_ptr(), nfft, B, NI, NO, spec_scale,
+                                              int(interior2), int(pre_half), _stream()), "spec_mid")
+    return S2, Xs
+
+
+def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2):
+    alloc = torch.zeros if t_len > t_out else torch.empty
+    y = alloc((B, t_len, G), dtype=torch.float32, device=S2.device)
+    with kernel_timer.span("spec_cols_inv"):
+        _lib.check(_lib.lib().fl_spec_cols_inv_f32(S2.data_ptr(), y.data_ptr(), B, t_len, t_out, G,
+                                                   twiddles(nfft, torch.float32, S2.device).data_ptr(), nfft, scale, env_log2,
+                                                   _stream()), "spec_cols_inv")
+    return y
+
+
+class _SpectralApply(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Hrm, nfft, scale_f, env_f, scale_i, env_i):
+        _require_gpu(x, Hrm)
+        if x.dtype != torch.float32 or x.dim() != 3:
+            raise TypeError("spectral_apply expects a real float32 (B, T, N) signal")
+        M = nfft // 2 + 1
+        if Hrm.dim() != 3 or Hrm.shape[0] != M or Hrm.dtype != torch.complex64:
+            raise ValueError(f"spectral_apply: the response must be complex64 ({M}, N_out, N_in)")
+        NO, NI = Hrm.shape[1], Hrm.shape[2]
+        if x.shape[2] != NI:
+            raise ValueError(f"response expects {NI} input channels, signal has {x.shape[2]}")
+        xc = x.contiguous()
+        if xc.data_ptr() % 8:
+            xc = xc.clone()
+        Hp = _h_planar(Hrm.resolve_conj(), True)
+        B, T = xc.shape[0], xc.shape[1]
+        S = _spec_cols_fwd(xc, nfft, env_f)
+        S2, Xs = _spec_mid(S, B, NI, NO, nfft, Hp, False, ctx.needs_input_grad[1], True, scale_f, 0, 0)
+        y = _spec_cols_inv(S2, B, nfft, nfft, NO, nfft, scale_i, env_i)
+        ctx.save_for_backward(Hp, *([Xs] if Xs is not None else []))
+        ctx.cfg = (nfft, scale_f, env_f, scale_i, env_i, T, NI, NO)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        Hp, *kept = ctx.saved_tensors
+        nfft, scale_f, env_f, scale_i, env_i, T, NI, NO = ctx.cfg
+        need_x, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g = gy.contiguous()
+        if g.data_ptr() % 8:
+            g = g.clone()
+        B = g.shape[0]
+        # irfft' : g_Y[k] = w_k scale_i sum_t g_y[t] e_i(t) exp(-j w_k t) -- a forward transform with doubled interior bins
+        Sg = _spec_cols_fwd(g, nfft, env_i)
+        # rfft' : g_x[t] = scale_f e_f(t) Re sum_k g_X[k] exp(+j w_k t), g_X = H^H g_Y -- an inverse transform with halved interior bins
+        S3, gYs = _spec_mid(Sg, B, NO, NI if need_x else NO, nfft, Hp if need_x else None, True, need_h, need_x, scale_i, 1, 1)
+        gx = gH = None
+        if need_x:
+            gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f, env_f)
+        if need_h:
+            Xs = kept[0]
+            gH = _gradh_launch(gYs.movedim(-1, 1), Xs.movedim(-1, 1), False).movedim(-1, 0)
+        return gx, gH, None, None, None, None, None
+
+
+def spectral_apply(x: torch.Tensor, Hrm: torch.Tensor, nfft: int, norm_f: str = "backward", norm_i: str = "backward",
+                   db_f: Optional[float] = None, db_i: Optional[float] = None) -> torch.Tensor:
+    """irfft(H[f] . rfft(x [* gamma_f^-t], n=nfft, norm_f), n=nfft, norm_i) [* gamma_i^-t] along dim 1 of a real float32
+    (B, T, N_in) signal, with ``Hrm`` the (M, N_out, N_in) per-bin response in ROW-MAJOR bin order
+    (``permute_bins``).  Returns (B, nfft, N_out), contiguous."""
+    if norm_f not in _NORM_FWD or norm_i not in _NORM_INV:
+        raise ValueError(f"Invalid normalization mode: {norm_f if norm_f not in _NORM_FWD else norm_i}")
+    env_f = 0.0 if not db_f else env_log2_of(db_f, nfft)
+    env_i = 0.0 if not db_i else env_log2_of(db_i, nfft)
+    return _SpectralApply.apply(x, Hrm, int(nfft), _NORM_FWD[norm_f](nfft), env_f, _NORM_INV[norm_i](nfft), env_i)
+
+
 # ----------------------------------------------------------------------------- per-bin MIMO product
 def _h_planar(H: torch.Tensor, per_bin: bool) -> torch.Tensor:
     """Per-bin responses (M, ...) are used with the bin axis contiguous (rows possibly padded)."""
@@ -503,8 +646,9 @@ def _gradh_launch(G, X, diag, scale=1.0):
         return dh if scale == 1.0 else dh * scale
     dH = _empty_rows((No, Ni), M, X.dtype, X.device)
     fn = L.fl_mimo_gradh_c64 if real == torch.float32 else L.fl_mimo_gradh_c128
-    _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dH.data_ptr(), P, float(scale), B, M,
-                  No, Ni, K, _stream()), "mimo_gradh")
+    with kernel_timer.span(f"mimo_gradh[cols={B * K},{No}x{Ni}]"):
+        _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dH.data_ptr(), P, float(scale), B, M,
+                      No, Ni, K, _stream()), "mimo_gradh")
     return dH
 
 
@@ -519,8 +663,9 @@ def _gradw_launch(G, X):
     part = torch.empty((nblk, No, Ni), dtype=X.dtype, device=X.device)
     dW = torch.empty((No, Ni), dtype=X.dtype, device=X.device)
     fn = L.fl_mimo_gradw_c64 if real == torch.float32 else L.fl_mimo_gradw_c128
-    _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, part.data_ptr(), dW.data_ptr(), B, M, No, Ni,
-                  K, _stream()), "mimo_gradw")
+    with kernel_timer.span(f"mimo_gradw[cols={B * K},{No}x{Ni}]"):
+        _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, part.data_ptr(), dW.data_ptr(), B, M, No, Ni,
+                      K, _stream()), "mimo_gradw")
     return dW
 
 

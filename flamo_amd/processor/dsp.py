@@ -60,6 +60,7 @@ class FFT(Transform):
     def __init__(self, nfft: int = 2 ** 11, norm: str = "backward", dtype: torch.dtype = torch.float32):
         self.nfft, self.norm = nfft, norm
         super().__init__(transform=lambda x: ops.rfft(x, self.nfft, self.norm), dtype=dtype)
+        self._own_transform = self.transform
 
 
 class iFFT(Transform):
@@ -68,6 +69,7 @@ class iFFT(Transform):
     def __init__(self, nfft: int = 2 ** 11, norm: str = "backward", dtype: torch.dtype = torch.float32):
         self.nfft, self.norm = nfft, norm
         super().__init__(transform=lambda x: ops.irfft(x, self.nfft, self.norm), dtype=dtype)
+        self._own_transform = self.transform
 
 
 class _AntiAliasMixin:
@@ -97,6 +99,7 @@ class FFTAntiAlias(Transform, _AntiAliasMixin):
             return ops.rfft(x, self.nfft, self.norm, self._alias_db)
 
         super().__init__(transform=transform, device=device, dtype=dtype)
+        self._own_transform = self.transform
 
 
 class iFFTAntiAlias(Transform, _AntiAliasMixin):
@@ -112,6 +115,7 @@ class iFFTAntiAlias(Transform, _AntiAliasMixin):
             return ops.irfft(x, self.nfft, self.norm, self._alias_db)
 
         super().__init__(transform=transform, device=device, dtype=dtype)
+        self._own_transform = self.transform
 
 
 # ============================================================================ core base class

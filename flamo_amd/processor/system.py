@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..functional import signal_gallery
-from .dsp import FFT, Transform, iFFT
+from .dsp import FFT, FFTAntiAlias, Transform, iFFT, iFFTAntiAlias
 
 
 # Series-level fusion: adjacent per-bin products H_k ... H_2 H_1 X are evaluated as (H_k ... H_1) X --
@@ -31,6 +31,8 @@ FUSE_MIN_COLUMNS = 4   # batch x trailing columns below which folding does not p
 # Build the folded response on a side stream, concurrently with the input transform of the
 # enclosing Shell (see ops.fork_point).  The response depends on parameters only.
 OVERLAP_RESPONSES = True
+# Shell(FFT -> per-bin chain -> iFFT) as one fused operator (ops.spectral_apply) when the plan and channel counts allow
+FUSE_SHELL = True
 # Gradients of the parameters are then produced on the side stream while their AccumulateGrad
 # nodes live on the main one; autograd synchronises the two correctly and merely warns about it.
 _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -219,31 +221,46 @@ class Series(nn.Sequential):
         return input
 
     @staticmethod
-    def __fused(run, x, ext_param):
-        """Apply a run of per-bin modules as one product with the cascade's response."""
-        M = x.shape[1]
+    def _run_response(run, shape, ext_param, device):
+        """(H, diag): response of a run of per-bin modules acting on a signal of the given shape, built on the
+        side stream (concurrently with the input transform of the enclosing Shell) when a fork point is set."""
+        M = shape[1]
 
         def build():
-            shape = list(x.shape)
+            shp = list(shape)
             acc = None
             for key, module in run:
                 ext = ext_param[key] if (ext_param is not None and key in ext_param) else None
-                resp = module._response_for_fusion(shape, ext)
-                shape[2] = module.output_channels
+                resp = module._response_for_fusion(shp, ext)
+                shp[2] = module.output_channels
                 acc = resp if acc is None else _compose(acc, resp, M)
             return acc
 
         ev = ops.fork_event() if OVERLAP_RESPONSES else None
         if ev is None:
+            return build()
+        main = torch.cuda.current_stream(device)
+        side = ops.side_stream(device)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
             acc = build()
-        else:
-            main = torch.cuda.current_stream(x.device)
-            side = ops.side_stream(x.device)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                acc = build()
-            main.wait_stream(side)
+        main.wait_stream(side)
+        # the response lives in the side stream's pool: keep it until the enclosing Shell.forward returns, so that a
+        # later side-stream region of the same forward (which waits for the fork point only) cannot be handed its
+        # memory while a main-stream kernel still reads it (no_grad / inference, where nothing else retains it)
+        memo = ops.forward_memo()
+        if memo is not None:
+            memo.setdefault("_keep_alive", []).append(acc[0])
+        return acc
+
+    @staticmethod
+    def __fused(run, x, ext_param):
+        """Apply a run of per-bin modules as one product with the cascade's response."""
+        acc = Series._run_response(run, list(x.shape), ext_param, x.device)
         return ops.mimo(acc[0], x, diag=acc[1])
+
+    def _all_fusable(self) -> bool:
+        return len(self) > 0 and all(hasattr(m, "_fusable") and m._fusable() for m in self)
 
     def probe(self, z: torch.Tensor):
         H = None
@@ -500,9 +517,56 @@ class Shell(nn.Module):
 
     def forward(self, x: torch.Tensor, ext_param: dict = None) -> torch.Tensor:
         with ops.fork_point(x):
+            if FUSE_SHELL:
+                y = self.__fused_forward(x, ext_param)
+                if y is not None:
+                    return y
             x = self.__input_layer(x)
             x = self.__core(x, ext_param) if ext_param is not None else self.__core(x)
             return self.__output_layer(x)
+
+    def __fused_forward(self, x, ext_param):
+        """FFT -> chain of per-bin products -> iFFT as ONE operator (ops.spectral_apply: three launches, the spectrum
+        never makes a round trip through HBM between the transforms and the product, no layout conversion).  Returns
+        None when this Shell / input is not of that form; the layered path then runs."""
+        fin, fout, core = self.__input_layer, self.__output_layer, self.__core
+        if not (type(fin) in (FFT, FFTAntiAlias) and type(fout) in (iFFT, iFFTAntiAlias)):
+            return None
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[0] > 0):
+            return None
+        if fin.transform is not fin._own_transform or fout.transform is not fout._own_transform:
+            return None
+        if fin.nfft != fout.nfft or fin.nfft != self.nfft:
+            return None
+        if isinstance(core, Series):
+            if not core._all_fusable():
+                return None
+            run = list(core._modules.items())
+        elif hasattr(core, "_fusable") and core._fusable():
+            run = [("0", core)]
+            if ext_param is not None:
+                ext_param = {"0": ext_param}
+        else:
+            return None
+        n_in, n_out = run[0][1].input_channels, run[-1][1].output_channels
+        if x.shape[2] != n_in or not ops.spectral_supported(self.nfft, n_in, n_out):
+            return None
+        if ops.bin_shard(self.nfft) != (0, self.nfft // 2 + 1):
+            return None
+        nfft, M = self.nfft, self.nfft // 2 + 1
+        if isinstance(fin, FFTAntiAlias):
+            fin._check(x)
+        acc = Series._run_response(run, [x.shape[0], M, n_in], ext_param, x.device)
+        H, diag = acc
+        if diag:
+            H = torch.diag_embed(H)
+        if H.dim() == 2:
+            H = H.unsqueeze(0).expand(M, *H.shape)
+        if H.dtype != torch.complex64:
+            H = H.to(torch.complex64)
+        Hrm = ops.permute_bins(H, nfft) if acc[0].dim() == (2 if diag else 3) else H   # constant responses need no reordering
+        return ops.spectral_apply(x, Hrm, nfft, fin.norm, fout.norm, getattr(fin, "_alias_db", None),
+                                  getattr(fout, "_alias_db", None))
 
     # ---- accessors
     def get_inputLayer(self):

@@ -104,6 +104,45 @@ int fl_irfft_f64(const void* X, long X_sig_stride, void* y, long y_sig_stride, i
  * and back. */
 int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, long dst_pitch, int elem_bytes, void* stream);
 
+/* ------------------------------------------------------------------ fused Shell pipeline (float32)
+ * Replaces the whole of Shell.forward (flamo/processor/system.py:839-855) when the input layer is
+ * dsp.FFT / FFTAntiAlias (dsp.py:88, 161-162), the core is a chain of per-bin products (Series.forward,
+ * system.py:299-300, over dsp.py:466, 552, 922-924, 1021) and the output layer is dsp.iFFT / iFFTAntiAlias
+ * (dsp.py:114, 204-205):   y = irfft( H[f] . rfft(x) )   in three launches, the (B, M, N) spectrum never
+ * making a round trip through HBM between the transforms and the product.  Time-domain tensors are taken
+ * and produced channel-innermost (B, T, G) as the reference's users hand them in (no layout conversion).
+ * nfft/2 = L1*L2 (fl_spec_plan).  Between the launches the data sits in a scratch array S (B, L1, L2, G)
+ * of complex values; spectra and responses that cross the boundary (the spectrum kept for the backward
+ * pass, H and its gradient) are bin-planar in ROW-MAJOR BIN ORDER: bin k = k1 + L1*k2 (k1 < L1, k2 < L2)
+ * is element i = k1*L2 + k2 of its plane, the Nyquist bin nfft/2 is element nfft/2 (fl_permute_bins_c64
+ * converts).  The backward pass runs the same three kernels (irfft' = weighted rfft, rfft' = weighted irfft).
+ */
+/* FL_OK and (L1, L2) when the fused pipeline supports this transform length */
+int fl_spec_plan(int nfft, int* L1, int* L2);
+/* 1 when (nfft, input channels, output channels) has a fused kernel */
+int fl_spec_supports(int nfft, int n_in, int n_out);
+/* tuning hook: virtual columns per workgroup of the column passes (16 | 32), load group */
+int fl_debug_set_spec(int vt, int rg);
+/* K1: S[b][k1][c][g] = W_L^(c k1) sum_t1 z[c + L2 t1] W_L1^(t1 k1),  z[j] = e(2j) x[b][2j][g] + i e(2j+1) x[b][2j+1][g];
+ * x: real (Bn, t_len, G) contiguous, 8-byte aligned, G even (a power of two <= 32 or a multiple of 32); samples at
+ * t >= min(t_len, nfft) count as zero. */
+int fl_spec_cols_fwd_f32(const void* x, int Bn, int t_len, int G, void* S, const void* W, int nfft, double env_log2,
+                         void* stream);
+/* mid: rows k1 = r, L1 - r of all channels per workgroup.  Forward row FFTs and split step give the spectrum
+ *   X[k] = spec_scale * w_k * rfft(.)[k]  (w_k = 2 on interior bins if spec_interior2), stored to Xs if non-null
+ *   (Xs[b*xs_b + n*xs_n + i], row-major bin order);  if S2 is non-null:  Y[k] = op(H[k]) X[k]  (H null: Y = X,
+ *   NI == NO; H[m*hs_m + n*hs_n + i]; conj_h: conj(H) -- pass swapped strides for H^H), interior bins halved if
+ *   pre_half, Hermitian pre-step, inverse row FFTs and twiddle into S2 (Bn, L1, L2, NO). */
+int fl_spec_mid_f32(const void* S, void* S2, void* Xs, long xs_b, long xs_n, const void* H, long hs_m, long hs_n, int conj_h,
+                    const void* W, int nfft, int Bn, int NI, int NO, double spec_scale, int spec_interior2, int pre_half,
+                    void* stream);
+/* K3: y[b][t][g] = scale * e(t) * (unnormalised inverse transform of S2), t < t_out <= t_len; y: real (Bn, t_len, G) */
+int fl_spec_cols_inv_f32(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                         double env_log2, void* stream);
+/* per plane: dst[i] = src[k(i)] (inverse = 0, natural -> row-major bin order) or dst[k(i)] = src[i] (inverse = 1) */
+int fl_permute_bins_c64(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
+                        void* stream);
+
 /* ------------------------------------------------------------------ per-bin complex MIMO product
  * Replace torch.einsum("fmn,bfn...->bfm...") (dsp.py:922-924, 3406-3408 and every Filter
  * subclass), einsum("mn,bfn...->bfm...") (Gain/Matrix, dsp.py:466-468) with hs_f = 0,

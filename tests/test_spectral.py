@@ -1,0 +1,217 @@
+"""GPU tests of the fused Shell pipeline (csrc/spectral.hip, ops.spectral_apply):
+   y = irfft(H[f] . rfft(x)) in three launches, against torch.fft on the CPU in float64 (the reference's own
+   primitives, dsp.py:88 / dsp.py:114 / dsp.py:922-924) and against the layered HIP operators.
+Tolerance: float32 kernels, relative l2 error 1e-5 against float64 (BASELINE.json north_star)."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from conftest import relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+PLANS = {96000: (200, 240), 192000: (300, 320), 384000: (400, 480)}
+
+
+def _ref(x, H, nfft, norm_f="backward", norm_i="backward", db_f=0.0, db_i=0.0):
+    """float64 CPU: irfft(H . rfft(x e_f)) e_i with the reference's rising envelopes (dsp.py:158-162, 201-205)"""
+    x = x.detach().cpu().double()
+    H = H.detach().cpu().to(torch.complex128)
+    t = torch.arange(nfft, dtype=torch.float64)
+    ef = 10.0 ** (abs(db_f) / (20.0 * nfft) * t) if db_f else None
+    ei = 10.0 ** (abs(db_i) / (20.0 * nfft) * t) if db_i else None
+    xx = x[:, :nfft]
+    if ef is not None:
+        xx = xx * ef[: xx.shape[1], None]
+    X = torch.fft.rfft(xx, n=nfft, dim=1, norm=norm_f)
+    Y = torch.einsum("fmn,bfn->bfm", H, X)
+    y = torch.fft.irfft(Y, n=nfft, dim=1, norm=norm_i)
+    if ei is not None:
+        y = y * ei[:, None]
+    return X, y
+
+
+@pytest.mark.parametrize("nfft", sorted(PLANS))
+def test_plan_and_bin_order(gpu, nfft):
+    import ctypes
+    from flamo_amd import _lib, ops
+    L1, L2 = ctypes.c_int(), ctypes.c_int()
+    assert _lib.lib().fl_spec_plan(nfft, ctypes.byref(L1), ctypes.byref(L2)) == 0
+    assert (L1.value, L2.value) == PLANS[nfft]
+    M = nfft // 2 + 1
+    H = torch.arange(M, device=gpu, dtype=torch.float32).to(torch.complex64).view(M, 1, 1).expand(M, 2, 3).contiguous()
+    Hr = ops.permute_bins(H, nfft)
+    i = torch.arange(M - 1, device=gpu)
+    k = i // L2.value + L1.value * (i % L2.value)
+    assert torch.equal(Hr[:-1, 1, 2].real.long(), k) and Hr[-1, 0, 0].real.item() == M - 1   # bit exact: an index map
+    assert torch.equal(ops.permute_bins(Hr, nfft, inverse=True), H)
+
+
+@pytest.mark.parametrize("N", [2, 4, 8, 16])
+@pytest.mark.parametrize("vt", [32, 16])
+def test_transform_round_trip_and_spectrum(gpu, N, vt):
+    """K1 + mid + K3 without a response: the spectrum it leaves (row-major bin order) is rfft(x), the output is x"""
+    from flamo_amd import _lib, ops
+    nfft, B = 96000, 3
+    _lib.lib().fl_debug_set_spec(vt, 2)
+    try:
+        torch.manual_seed(N)
+        x = torch.randn(B, nfft, N, device=gpu)
+        S = ops._spec_cols_fwd(x, nfft, 0.0)
+        S2, Xs = ops._spec_mid(S, B, N, N, nfft, None, False, True, True, 1.0, 0, 0)
+        y = ops._spec_cols_inv(S2, B, nfft, nfft, N, nfft, 1.0 / nfft, 0.0)
+        Xref = torch.fft.rfft(x.cpu().double(), n=nfft, dim=1)
+        X = ops.permute_bins(Xs.movedim(-1, 0), nfft, inverse=True)            # (M, B, N) natural order
+        assert relerr(X.permute(1, 0, 2).cpu(), Xref) < TOL
+        assert relerr(y.cpu(), x.cpu().double()) < TOL
+    finally:
+        _lib.lib().fl_debug_set_spec(32, 2)
+
+
+@pytest.mark.parametrize("nfft,N,B", [(96000, 8, 3), (96000, 4, 2), (96000, 2, 5), (96000, 16, 2), (192000, 8, 2), (384000, 4, 2),
+                                      (192000, 16, 1), (384000, 2, 1)])
+def test_spectral_apply_against_torch_fft(gpu, nfft, N, B):
+    from flamo_amd import ops
+    torch.manual_seed(nfft + N)
+    M = nfft // 2 + 1
+    x = torch.randn(B, nfft, N, device=gpu, requires_grad=True)
+    H = (torch.randn(M, N, N, device=gpu, dtype=torch.complex64) / N ** 0.5).requires_grad_(True)
+    y = ops.spectral_apply(x, ops.permute_bins(H, nfft), nfft)
+    assert y.shape == (B, nfft, N) and y.is_contiguous()
+    c = torch.randn(B, nfft, N, device=gpu)
+    gx, gH = torch.autograd.grad((y * c).sum(), [x, H])
+    xr = x.detach().cpu().double().requires_grad_(True)
+    Hr = H.detach().cpu().to(torch.complex128).requires_grad_(True)
+    Y = torch.einsum("fmn,bfn->bfm", Hr, torch.fft.rfft(xr, n=nfft, dim=1))
+    yr = torch.fft.irfft(Y, n=nfft, dim=1)
+    gxr, gHr = torch.autograd.grad((yr * c.cpu().double()).sum(), [xr, Hr])
+    assert relerr(y.detach().cpu(), yr.detach()) < TOL
+    assert relerr(gx.cpu(), gxr) < TOL
+    assert relerr(gH.cpu(), gHr) < TOL
+
+
+@pytest.mark.parametrize("norm_f,norm_i,db_f,db_i,T", [("backward", "backward", 0.0, 30.0, 96000), ("ortho", "ortho", 30.0, 30.0, 96000),
+                                                        ("forward", "forward", 30.0, 0.0, 96000), ("backward", "backward", 0.0, 0.0, 50001),
+                                                        ("backward", "backward", 0.0, 0.0, 96017)])
+def test_spectral_apply_norms_envelopes_lengths(gpu, norm_f, norm_i, db_f, db_i, T):
+    from flamo_amd import ops
+    nfft, N, B = 96000, 4, 2
+    torch.manual_seed(T)
+    M = nfft // 2 + 1
+    x = torch.randn(B, T, N, device=gpu, requires_grad=True)
+    H = (torch.randn(M, N, N, device=gpu, dtype=torch.complex64) / N ** 0.5)
+    y = ops.spectral_apply(x, ops.permute_bins(H, nfft), nfft, norm_f, norm_i, db_f or None, db_i or None)
+    c = torch.randn(B, nfft, N, device=gpu)
+    (gx,) = torch.autograd.grad((y * c).sum(), [x])
+    assert gx.shape == x.shape
+    xr = x.detach().cpu().double().requires_grad_(True)
+    t = torch.arange(nfft, dtype=torch.float64)
+    xx = xr[:, :nfft]
+    if db_f:
+        xx = xx * (10.0 ** (db_f / (20.0 * nfft) * t))[: xx.shape[1], None]
+    Y = torch.einsum("fmn,bfn->bfm", H.cpu().to(torch.complex128), torch.fft.rfft(xx, n=nfft, dim=1, norm=norm_f))
+    yr = torch.fft.irfft(Y, n=nfft, dim=1, norm=norm_i)
+    if db_i:
+        yr = yr * (10.0 ** (db_i / (20.0 * nfft) * t))[:, None]
+    (gxr,) = torch.autograd.grad((yr * c.cpu().double()).sum(), [xr])
+    assert relerr(y.detach().cpu(), yr.detach()) < TOL
+    assert relerr(gx.cpu(), gxr) < TOL
+
+
+def _config2(gpu, N, nfft, db=0.0):
+    from flamo_amd.processor import dsp, system
+    kw = dict(nfft=nfft, alias_decay_db=db, device=gpu, dtype=torch.float32)
+    mat = dsp.Matrix(size=(N, N), matrix_type="random", requires_grad=True, **kw)
+    geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+    core = system.Series(OrderedDict(mix=mat, eq=geq))
+    if db:
+        shell = system.Shell(core, dsp.FFTAntiAlias(nfft, alias_decay_db=db, device=gpu), dsp.iFFTAntiAlias(nfft, alias_decay_db=db, device=gpu))
+    else:
+        shell = system.Shell(core, dsp.FFT(nfft), dsp.iFFT(nfft))
+    return shell, [mat.param, geq.param]
+
+
+@pytest.mark.parametrize("db", [0.0, 30.0])
+@pytest.mark.parametrize("grad_in", [False, True])
+def test_shell_fused_equals_layered_and_oracle(gpu, db, grad_in):
+    """BASELINE configs[1] through Shell.forward: fused operator == layered operators == float64 oracle (outputs, parameter
+    gradients, input gradient)."""
+    from flamo_amd import ops
+    from flamo_amd.processor import system
+    from oracle import hotpath as O
+    nfft, N, B = 96000, 8, 3
+    torch.manual_seed(7)
+    shell, params = _config2(gpu, N, nfft, db)
+    x = torch.randn(B, nfft, N, device=gpu, requires_grad=grad_in)
+    wanted = params + ([x] if grad_in else [])
+
+    def run():
+        ops.kernel_timer.reset(True)
+        y = shell(x)
+        g = torch.autograd.grad(ops.mean_square(y), wanted)
+        torch.cuda.synchronize()
+        used = set(ops.kernel_timer.records)
+        ops.kernel_timer.enabled = False
+        return y.detach(), g, used
+
+    y1, g1, used1 = run()
+    assert any(k.startswith("spec_mid") for k in used1), used1            # the fused operator ran
+    system.FUSE_SHELL = False
+    try:
+        y2, g2, used2 = run()
+    finally:
+        system.FUSE_SHELL = True
+    assert not any(k.startswith("spec_") for k in used2)
+    assert relerr(y1, y2) < TOL
+    for a, b in zip(g1, g2):
+        assert relerr(a, b) < 3e-5
+    if db == 0.0:
+        W, G = (p.detach().cpu().double().requires_grad_(True) for p in params)
+        xo = x.detach().cpu().double().requires_grad_(grad_in)
+        yo = O.config2_forward(xo, W, G, nfft)
+        go = torch.autograd.grad((yo ** 2).mean(), [W, G] + ([xo] if grad_in else []))
+        assert relerr(y1.cpu(), yo.detach()) < TOL
+        for a, b in zip(g1, go):
+            assert relerr(a.cpu(), b) < TOL
+
+
+def test_shell_fused_under_graph_capture(gpu):
+    """forward + backward of the fused Shell replayed from a HIP graph == eager"""
+    from flamo_amd import ops
+    from flamo_amd.graph import GraphedStep
+    nfft, N, B = 96000, 8, 4
+    torch.manual_seed(11)
+    shell, params = _config2(gpu, N, nfft)
+    x = torch.randn(B, nfft, N, device=gpu)
+    loss = ops.mean_square(shell(x))
+    ge = torch.autograd.grad(loss, params)
+    gs = GraphedStep(lambda xx: ops.mean_square(shell(xx)), (x,), params, warmup=2)
+    for _ in range(3):
+        lg = gs.replay()
+    torch.cuda.synchronize()
+    assert abs(lg.item() - loss.item()) <= 1e-6 * abs(loss.item())
+    for p, g in zip(params, ge):
+        assert relerr(p.grad, g) < 1e-6
+
+
+def test_unsupported_shapes_take_the_layered_path(gpu):
+    """odd channel counts, float64, 4-D signals and other transform lengths fall back to the layered operators, silently
+    and with the same results"""
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    for nfft, N, dt in ((96000, 3, torch.float32), (96000, 4, torch.float64), (4800, 4, torch.float32)):
+        kw = dict(nfft=nfft, device=gpu, dtype=dt)
+        shell = system.Shell(system.Series(dsp.Matrix(size=(N, N), **kw)), dsp.FFT(nfft, dtype=dt), dsp.iFFT(nfft, dtype=dt))
+        x = torch.randn(2, nfft, N, device=gpu, dtype=dt)
+        ops.kernel_timer.reset(True)
+        with torch.no_grad():
+            y = shell(x)
+        torch.cuda.synchronize()
+        used = set(ops.kernel_timer.records)
+        ops.kernel_timer.enabled = False
+        assert not any(k.startswith("spec_") for k in used)
+        W = shell.get_core()[0].param.detach().cpu().double()
+        yr = torch.fft.irfft(torch.einsum("mn,bfn->bfm", W.to(torch.complex128), torch.fft.rfft(x.cpu().double(), n=nfft, dim=1)), n=nfft, dim=1)
+        assert relerr(y.cpu(), yr) < (1e-10 if dt == torch.float64 else TOL)

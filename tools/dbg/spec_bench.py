@@ -1,0 +1,74 @@
+"""Per-kernel timings of the fused Shell pipeline at BASELINE configs[1] (HIP events, single stream).
+    python tools/dbg/spec_bench.py [--vt 32] [--steps 30]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from flamo_amd import _lib, ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--vt", type=int, default=32)
+ap.add_argument("--rg", type=int, default=2)
+ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--nfft", type=int, default=96000)
+ap.add_argument("--n", type=int, default=8)
+ap.add_argument("--batch", type=int, default=32)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+nfft, N, B = args.nfft, args.n, args.batch
+M = nfft // 2 + 1
+_lib.lib().fl_debug_set_spec(args.vt, args.rg)
+torch.manual_seed(0)
+x = torch.randn(B, nfft, N, device=dev)
+H = ops.permute_bins(torch.randn(M, N, N, device=dev, dtype=torch.complex64) / N ** 0.5, nfft).requires_grad_(True)
+xg = x.clone().requires_grad_(True)
+
+
+def step(with_x):
+    y = ops.spectral_apply(xg if with_x else x, H, nfft)
+    loss = ops.mean_square(y)
+    torch.autograd.grad(loss, [H] + ([xg] if with_x else []))
+
+
+for with_x in (False, True):
+    for _ in range(5):
+        step(with_x)
+    torch.cuda.synchronize()
+    ops.kernel_timer.reset(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        step(with_x)
+    e1.record()
+    torch.cuda.synchronize()
+    ops.kernel_timer.enabled = False
+    tot = 0.0
+    print(f"--- vt={args.vt} input_grad={with_x}: {e0.elapsed_time(e1) / args.steps * 1e3:.1f} us per step (eager, events)")
+    for k, (n, ms) in sorted(ops.kernel_timer.summary().items()):
+        print(f"   {k:34s} x{n / args.steps:.0f}  {ms * 1e3:7.1f} us")
+        tot += ms * n / args.steps
+    print(f"   sum of timed kernels {tot * 1e3:.1f} us")
+
+# ---- mid-kernel variants (tuning): response-row prefetch modes, no-response floor
+S = ops._spec_cols_fwd(x, nfft, 0.0)
+Hp = ops._h_planar(H.detach(), True)
+for pf in (1, 3, 2):
+    _lib.lib().fl_debug_set_spec(args.vt, 100 * pf + args.rg)
+    for _ in range(3):
+        ops._spec_mid(S.clone(), B, N, N, nfft, Hp, False, True, True, 1.0, 0, 0)
+    torch.cuda.synchronize()
+    ops.kernel_timer.reset(True)
+    for _ in range(10):
+        ops._spec_mid(S.clone(), B, N, N, nfft, Hp, False, True, True, 1.0, 0, 0)
+    torch.cuda.synchronize()
+    print(f"mid pf={pf}:", {k: round(v[1] * 1e3, 1) for k, v in ops.kernel_timer.summary().items()})
+ops.kernel_timer.reset(True)
+for _ in range(10):
+    ops._spec_mid(S.clone(), B, N, N, nfft, None, False, True, True, 1.0, 0, 0)
+    ops._spec_mid(S.clone(), B, N, N, nfft, None, False, False, True, 1.0, 0, 0)
+torch.cuda.synchronize()
+print("mid without response:", {k: round(v[1] * 1e3, 1) for k, v in ops.kernel_timer.summary().items()})
+ops.kernel_timer.enabled = False
