@@ -10,6 +10,21 @@
 
 namespace fl {
 
+// Bin number of element f of a response row.  bin0 >= 0: the contiguous range bin0, bin0+1, ... (bin-sharded execution).
+// bin0 < 0: the whole spectrum in the ROW-MAJOR bin order of the fused Shell pipeline (spectral.hip) with row length
+// L2 = -bin0: element f = k1*L2 + k2 holds bin k1 + L1*k2 (L1 = nfft/2/L2), element nfft/2 the Nyquist bin.
+__device__ __forceinline__ int bin_of(int f, int bin0, int nfft) {
+    if (bin0 >= 0) return bin0 + f;
+    const int L2 = -bin0, L = nfft >> 1;
+    if (f >= L) return L;
+    const int k1 = f / L2;
+    return k1 + (L / L2) * (f - k1 * L2);
+}
+static bool bin_range_ok(int bin0, int m_local, int nfft) {
+    if (bin0 >= 0) return true;
+    return nfft % 2 == 0 && (nfft / 2) % (-bin0) == 0 && m_local == nfft / 2 + 1;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) delay_response_kernel(const int32_t* __restrict__ m, const T* __restrict__ amp,
                                                             const cx<T>* __restrict__ W, int nfft, double inv_nfft,
@@ -19,7 +34,7 @@ __global__ void __launch_bounds__(256) delay_response_kernel(const int32_t* __re
     const int c = blockIdx.y;
     // (k m) mod nfft exactly, without the 64-bit integer division (~100 instructions, most of this kernel's time):
     // |k m| < 2^53 is exact in double, the quotient estimate is off by at most one
-    const long long prod = (long long)(bin0 + f) * (long long)m[c];
+    const long long prod = (long long)bin_of(f, bin0, nfft) * (long long)m[c];
     long long idx = prod - (long long)((double)prod * inv_nfft) * nfft;
     idx += (idx < 0) ? nfft : 0;
     idx -= (idx >= nfft) ? nfft : 0;
@@ -79,7 +94,7 @@ __global__ void __launch_bounds__(256) sos_response_kernel(const double* __restr
     stage_taps(b, a, S, C, c, lb, la);
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= m_local) return;
-    const SosEval e = sos_point(Wd, nfft, bin0 + f, g);
+    const SosEval e = sos_point(Wd, nfft, bin_of(f, bin0, nfft), g);
     cx<double> Bp(1, 0), Ap(1, 0);
     for (int s = 0; s < S; ++s) {
         Bp = Bp * e.poly(lb, S, s);
@@ -124,7 +139,7 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
     for (int v = 0; v < 6 * SCH; ++v) acc[v] = 0.0;
 
     for (int f = blockIdx.x * 256 + threadIdx.x; f < m_local; f += gridDim.x * 256) {
-        const SosEval e = sos_point(Wd, nfft, bin0 + f, g);
+        const SosEval e = sos_point(Wd, nfft, bin_of(f, bin0, nfft), g);
         cx<double> Bp(1, 0), Ap(1, 0);
         for (int s = 0; s < S; ++s) {
             Bp = Bp * e.poly(lb, S, s);
@@ -258,7 +273,7 @@ __global__ void __launch_bounds__(256) sos_response_bwd_mixed_kernel(
     for (int f = blockIdx.x * 256 + threadIdx.x; f < m_local; f += gridDim.x * 256) {
         const cx<float> h = H[(size_t)c * h_pitch + f];
         if (h.x == eps && h.y == 0.f) continue;   // guarded bin (prod A == 0): constant, zero gradient
-        const int k = bin0 + f;
+        const int k = bin_of(f, bin0, nfft);
         const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
         const cx<double> z1(g * w1.x, g * w1.y);
         const cx<float> d((float)(1.0 - z1.x), (float)(-z1.y));
@@ -510,7 +525,7 @@ static int delay_impl(const int32_t* m, const void* amp, int C, const void* W, i
                       long h_pitch, void* stream) {
     FL_REQUIRE(m && amp && W && H, "delay_response: null pointer");
     FL_REQUIRE(h_pitch >= m_local, "delay_response: h_pitch must be >= m_local");
-    FL_REQUIRE(C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local >= 0, "delay_response: bad sizes");
+    FL_REQUIRE(C > 0 && C <= 65535 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) && m_local >= 0, "delay_response: bad sizes");
     if (m_local == 0) return FL_OK;
     dim3 grid(cdiv_i(m_local, 256), C);
     hipLaunchKernelGGL((delay_response_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, m, (const T*)amp,
@@ -524,7 +539,7 @@ static int sos_impl(const void* b, const void* a, int S, int C, double gamma, co
                     int m_local, void* H, long h_pitch, void* stream) {
     FL_REQUIRE(b && a && H && Wd, "sos_response: null pointer");
     FL_REQUIRE(h_pitch >= m_local, "sos_response: h_pitch must be >= m_local");
-    FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local >= 0, "sos_response: bad sizes");
+    FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) && m_local >= 0, "sos_response: bad sizes");
     if (m_local == 0) return FL_OK;
     dim3 grid(cdiv_i(m_local, 256), C);
     hipLaunchKernelGGL((sos_response_kernel<T>), grid, dim3(256), (size_t)6 * S * sizeof(double), (hipStream_t)stream, (const double*)b, (const double*)a, S, C,
@@ -538,7 +553,7 @@ static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitc
                         double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
     FL_REQUIRE(gH && b && a && part && Wd, "sos_response_bwd: null pointer");
     FL_REQUIRE(g_pitch >= m_local && (!H || h_pitch >= m_local), "sos_response_bwd: g_pitch / h_pitch must be >= m_local");
-    FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin0 >= 0 && m_local > 0, "sos_response_bwd: bad sizes");
+    FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) && m_local > 0, "sos_response_bwd: bad sizes");
     if constexpr (sizeof(T) == 4) {
         if (H) {
 #define FL_SOS_MIX(SC)                                                                                              \

@@ -281,7 +281,7 @@ class fork_point:
 
 
 # ----------------------------------------------------------------------------- bin sharding (multi-GPU)
-_shard = {"bin0": 0, "m_local": None}
+_shard = {"bin0": 0, "m_local": None, "order": None}
 
 
 def set_bin_shard(bin0: int = 0, m_local: Optional[int] = None) -> None:
@@ -296,6 +296,43 @@ def bin_shard(nfft: int) -> Tuple[int, int]:
     if _shard["m_local"] is None:
         return 0, M
     return _shard["bin0"], _shard["m_local"]
+
+
+class row_major_bins:
+    """with ops.row_major_bins(nfft): per-bin responses are generated in the ROW-MAJOR bin order of the fused
+    Shell pipeline (element k1*L2 + k2 = bin k1 + L1*k2): natively by the cascade / integer-delay kernels,
+    through ``permute_bins`` by everything else (``DSP._response_once``)."""
+
+    def __init__(self, nfft: int):
+        import ctypes
+        L1, L2 = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().fl_spec_plan(int(nfft), ctypes.byref(L1), ctypes.byref(L2)), "spec_plan")
+        self.order = (int(nfft), L1.value, L2.value)
+
+    def __enter__(self):
+        self.prev = _shard.get("order")
+        _shard["order"] = self.order
+        return self
+
+    def __exit__(self, *exc):
+        _shard["order"] = self.prev
+        return False
+
+
+def bin_order(nfft: int):
+    """(L1, L2) when responses for this nfft are to be generated in row-major bin order, else None"""
+    o = _shard.get("order")
+    return (o[1], o[2]) if (o is not None and o[0] == int(nfft)) else None
+
+
+def _bin0_arg(nfft: int) -> Tuple[int, int]:
+    """(bin0, m_local) as the response kernels take them: bin0 = -L2 selects row-major order"""
+    o = bin_order(nfft)
+    if o is not None:
+        if _shard["m_local"] is not None:
+            raise RuntimeError("row-major bin order and bin sharding are mutually exclusive")
+        return -o[1], nfft // 2 + 1
+    return bin_shard(nfft)
 
 
 # ----------------------------------------------------------------------------- transforms
@@ -846,7 +883,7 @@ def delay_response(m_int: torch.Tensor, amp: torch.Tensor, nfft: int) -> torch.T
     for the local bin range.  m_int: integer tensor (any shape); amp: real, same shape."""
     dev = _require_gpu(m_int, amp)
     real = _rdtype(amp)
-    bin0, m_local = bin_shard(nfft)
+    bin0, m_local = _bin0_arg(nfft)
     shape = tuple(m_int.shape)
     C_ = max(_prod(shape), 1)
     m32 = m_int.to(torch.int32).contiguous()
@@ -870,7 +907,7 @@ def _sos_forward_launch(bc, ac, gamma, nfft, real):
     S = bc.shape[1]
     chan = tuple(bc.shape[2:])
     C_ = max(_prod(chan), 1)
-    bin0, m_local = bin_shard(nfft)
+    bin0, m_local = _bin0_arg(nfft)
     H = _empty_rows(chan, m_local, _cdtype(real), dev)
     L = _lib.lib()
     fn = L.fl_sos_response_c64 if real == torch.float32 else L.fl_sos_response_c128

@@ -189,11 +189,11 @@ class DSP(nn.Module):
         Reusing one response tensor at several places of the autograd graph is what autograd is for."""
         memo = ops.forward_memo()
         if memo is None or not torch.is_tensor(param):
-            return self.freq_response(param)
-        key = (id(self), id(param), param._version, ops.bin_shard(self.nfft), torch.is_grad_enabled())
+            return self._response_in_order(param)
+        key = (id(self), id(param), param._version, ops.bin_shard(self.nfft), ops.bin_order(self.nfft), torch.is_grad_enabled())
         hit = memo.get(key)
         if hit is None:
-            H = self.freq_response(param)
+            H = self._response_in_order(param)
             ev = None
             if param.is_cuda:
                 ev = torch.cuda.Event()
@@ -206,6 +206,26 @@ class DSP(nn.Module):
             if cur.cuda_stream != produced_on:
                 cur.wait_event(ev)      # reuse on another stream (side-stream response build vs main): order it
         return H
+
+    # Classes whose freq_response hands back the output of the cascade / integer-delay kernels untouched set this: those
+    # kernels write the row-major bin order of the fused Shell pipeline themselves (ops.row_major_bins); every other
+    # per-bin response is generated in natural order and reordered by one gather.
+    _native_bin_order = False
+
+    def _response_in_order(self, param):
+        H = self.freq_response(param)
+        if ops.bin_order(self.nfft) is None:
+            return H
+        per_bin = torch.is_tensor(H) and H.dim() >= 1 and H.shape[0] == self.nfft // 2 + 1 and H.dim() == (2 if getattr(self, "_diag", False) else 3)
+        if not per_bin or (self._native_bin_order and self._native_now(param)):
+            return H
+        if H.dtype != torch.complex64:
+            raise RuntimeError("row-major bin order is a float32 path")
+        return ops.permute_bins(H, self.nfft)
+
+    def _native_now(self, param) -> bool:
+        """True when this call of freq_response went through the kernels that honour ops.row_major_bins"""
+        return True
 
     # ---- protocol used by system.Series to fold adjacent per-bin modules into one pass
     def _bin_response(self, param):
@@ -462,6 +482,8 @@ class _SOSMixin:
     """Second-order-section cascades share one tail: weight the 3 taps by gamma^[0,1,2] and
     evaluate prod B / prod A per bin (dsp.py:1520-1526) -- here directly in ``ops.sos_response``,
     without building the (M, sections, ...) tensors."""
+
+    _native_bin_order = True     # every response of these classes comes straight out of the cascade kernels
 
     def _sos_to_response(self, b, a):
         return ops.sos_response(b, a, self._gamma_f, self.nfft, dtype=self.dtype)
@@ -986,6 +1008,11 @@ class Delay(DSP):
     def get_delays(self):
         return lambda param: self.s2sample(self.map(param))
 
+    _native_bin_order = True
+
+    def _native_now(self, param) -> bool:
+        return bool(self.isint)      # integer delays: the exact-phase kernel; fractional ones are torch expressions
+
     def get_freq_response(self):
         m = self.get_delays()
 
@@ -1120,6 +1147,11 @@ class GainDelay(DSP):
 
     def get_delays(self):
         return lambda param: self.s2sample(self.map_delay(param[1]))
+
+    _native_bin_order = True
+
+    def _native_now(self, param) -> bool:
+        return bool(self.isint)      # gain x integer-delay response (an elementwise product keeps the bin order)
 
     def get_freq_response(self):
         gains, delays = self.get_gains(), self.get_delays()

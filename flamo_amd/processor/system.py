@@ -556,16 +556,15 @@ class Shell(nn.Module):
         nfft, M = self.nfft, self.nfft // 2 + 1
         if isinstance(fin, FFTAntiAlias):
             fin._check(x)
-        acc = Series._run_response(run, [x.shape[0], M, n_in], ext_param, x.device)
-        H, diag = acc
+        with ops.row_major_bins(nfft):      # the responses come out in the pipeline's bin order (no reordering pass)
+            H, diag = Series._run_response(run, [x.shape[0], M, n_in], ext_param, x.device)
         if diag:
             H = torch.diag_embed(H)
         if H.dim() == 2:
             H = H.unsqueeze(0).expand(M, *H.shape)
         if H.dtype != torch.complex64:
             H = H.to(torch.complex64)
-        Hrm = ops.permute_bins(H, nfft) if acc[0].dim() == (2 if diag else 3) else H   # constant responses need no reordering
-        return ops.spectral_apply(x, Hrm, nfft, fin.norm, fout.norm, getattr(fin, "_alias_db", None),
+        return ops.spectral_apply(x, H, nfft, fin.norm, fout.norm, getattr(fin, "_alias_db", None),
                                   getattr(fout, "_alias_db", None))
 
     # ---- accessors

@@ -209,7 +209,11 @@ int fl_mimo_gradw_c128(const void* G, long gs_b, long gs_m, long gs_k, const voi
  * (dsp.py:3356-3365, 3512-3521):  H[c, f] = amp[c] * exp(-2 pi i ((bin0+f) * m[c] mod nfft) / nfft)
  * -- the phase index is reduced in 64-bit integer arithmetic and looked up in W (bit-exact
  * indexing; the reference evaluates exp(-j*omega*m) in floating point).  amp[c] = gamma^m[c]
- * is supplied by the caller (real, same precision as H). H planar: c*h_pitch + f. */
+ * is supplied by the caller (real, same precision as H). H planar: c*h_pitch + f.
+ * Bin range (here and in the cascade entry points below): element f of a row is bin bin0 + f, f < m_local
+ * (bin0 >= 0: the contiguous range a rank owns under bin sharding); bin0 < 0 asks for the whole spectrum
+ * (m_local = nfft/2+1) in the ROW-MAJOR bin order of the fused Shell pipeline with row length L2 = -bin0:
+ * element k1*L2 + k2 is bin k1 + (nfft/2/L2)*k2, element nfft/2 the Nyquist bin (see fl_spec_plan). */
 int fl_delay_response_c64(const int32_t* m, const void* amp, int C, const void* W, int nfft,
                           int bin0, int m_local, void* H, long h_pitch, void* stream);
 int fl_delay_response_c128(const int32_t* m, const void* amp, int C, const void* W, int nfft,

@@ -215,3 +215,62 @@ def test_unsupported_shapes_take_the_layered_path(gpu):
         W = shell.get_core()[0].param.detach().cpu().double()
         yr = torch.fft.irfft(torch.einsum("mn,bfn->bfm", W.to(torch.complex128), torch.fft.rfft(x.cpu().double(), n=nfft, dim=1)), n=nfft, dim=1)
         assert relerr(y.cpu(), yr) < (1e-10 if dt == torch.float64 else TOL)
+
+
+def _zoo(kind, gpu, nfft, N):
+    from flamo_amd.processor import dsp
+    kw = dict(nfft=nfft, alias_decay_db=0.0, device=gpu, dtype=torch.float32, requires_grad=True)
+    if kind == "fir":
+        return [dsp.Filter(size=(5, N, N), **kw)]
+    if kind == "pfir+gain":
+        return [dsp.parallelFilter(size=(7, N), **kw), dsp.Gain(size=(N, N), **kw)]
+    if kind == "biquad":
+        return [dsp.Biquad(size=(N, N), n_sections=2, filter_type="lowpass", **kw)]
+    if kind == "delay+matrix":
+        d = dsp.parallelDelay(size=(N,), max_len=3000, isint=True, nfft=nfft, device=gpu)
+        return [d, dsp.Matrix(size=(N, N), matrix_type="random", **kw)]   # (an orthogonal mix after pure delays leaves the loss flat: gradient = rounding noise)
+    if kind == "fracdelay":
+        return [dsp.Delay(size=(N, N), max_len=500, isint=False, **kw)]
+    if kind == "gaindelay+peq":
+        return [dsp.parallelGainDelay(size=(N,), max_len=800, isint=True, nfft=nfft, device=gpu, requires_grad=True),
+                dsp.parallelGEQ(size=(N,), **kw)]
+    if kind == "gain-only":
+        return [dsp.Gain(size=(N, N), **kw), dsp.parallelGain(size=(N,), **kw)]
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["fir", "pfir+gain", "biquad", "delay+matrix", "fracdelay", "gaindelay+peq", "gain-only"])
+def test_shell_fused_module_zoo(gpu, kind):
+    """every kind of per-bin module through the fused Shell: responses generated natively in the pipeline's bin order
+    (cascades, integer delays), reordered by a gather (FIR, fractional delays) or bin-independent -- against the
+    layered operators on the same modules (which the goldens pin to the reference)"""
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    nfft, N, B = 96000, 4, 2
+    torch.manual_seed(3)
+    mods = _zoo(kind, gpu, nfft, N)
+    shell = system.Shell(system.Series(*mods), dsp.FFT(nfft), dsp.iFFT(nfft))
+    params = [p for p in shell.parameters() if p.requires_grad]
+    x = torch.randn(B, nfft, N, device=gpu, requires_grad=True)
+
+    def run():
+        ops.kernel_timer.reset(True)
+        y = shell(x)
+        g = torch.autograd.grad(ops.mean_square(y), params + [x], allow_unused=True)
+        torch.cuda.synchronize()
+        used = set(ops.kernel_timer.records)
+        ops.kernel_timer.enabled = False
+        return y.detach(), g, used
+
+    y1, g1, used1 = run()
+    assert any(k.startswith("spec_mid") for k in used1), used1
+    system.FUSE_SHELL = False
+    try:
+        y2, g2, _ = run()
+    finally:
+        system.FUSE_SHELL = True
+    assert relerr(y1, y2) < TOL
+    for a, b in zip(g1, g2):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert relerr(a, b) < 1e-4, kind
