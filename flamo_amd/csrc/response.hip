@@ -104,6 +104,56 @@ __global__ void __launch_bounds__(256) sos_response_kernel(const double* __restr
     H[(size_t)c * h_pitch + f] = cx<T>((T)h.x, (T)h.y);
 }
 
+// Cascade response times a real constant matrix on the right, H[m][n] = sum_j G[m][j] W[j][n] (Series of Matrix then a
+// cascade-type filter): one thread per (output channel m, bin) walks the Nmid cascades of its row, stores G (the
+// backward pass needs it) and the product -- the composition pass over the response-sized tensors and the real -> complex
+// conversion of W (three tiny launches) never run.  G is rounded to float before the product, as the separate passes do.
+template <int NIW>
+__global__ void __launch_bounds__(256) sos_response_rc_kernel(const double* __restrict__ b, const double* __restrict__ a, int S,
+                                                             int C, int Nmid, const float* __restrict__ Wr, double g,
+                                                             const cx<double>* __restrict__ Wd, int nfft, int bin0, int m_local,
+                                                             cx<float>* __restrict__ G, long g_pitch, cx<float>* __restrict__ H,
+                                                             long h_pitch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* lb = reinterpret_cast<double*>(smem);            // [Nmid][3][S]
+    double* la = lb + Nmid * 3 * S;
+    float* lw = reinterpret_cast<float*>(la + Nmid * 3 * S);   // [Nmid][NIW]
+    const int m = blockIdx.y;
+    for (int i = threadIdx.x; i < Nmid * 3 * S; i += 256) {
+        const int j = i / (3 * S), e = i - j * 3 * S;
+        lb[i] = b[(size_t)e * C + m * Nmid + j];
+        la[i] = a[(size_t)e * C + m * Nmid + j];
+    }
+    for (int i = threadIdx.x; i < Nmid * NIW; i += 256) lw[i] = Wr[i];
+    __syncthreads();
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= m_local) return;
+    const SosEval e = sos_point(Wd, nfft, bin_of(f, bin0, nfft), g);
+    cx<float> acc[NIW];
+#pragma unroll
+    for (int n = 0; n < NIW; ++n) acc[n] = cx<float>(0.f, 0.f);
+    for (int j = 0; j < Nmid; ++j) {
+        const double* tb = lb + j * 3 * S;
+        const double* ta = la + j * 3 * S;
+        cx<double> Bp(1, 0), Ap(1, 0);
+        for (int s = 0; s < S; ++s) {
+            Bp = Bp * e.poly(tb, S, s);
+            Ap = Ap * e.poly(ta, S, s);
+        }
+        const cx<double> h = (Ap.x != 0 || Ap.y != 0) ? cdiv(Bp, Ap) : cx<double>((double)eps_of<float>(), 0);
+        const cx<float> hf((float)h.x, (float)h.y);
+        G[(size_t)(m * Nmid + j) * g_pitch + f] = hf;
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) {
+            const float w = lw[j * NIW + n];
+            acc[n].x += w * hf.x;
+            acc[n].y += w * hf.y;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NIW; ++n) H[(size_t)(m * NIW + n) * h_pitch + f] = acc[n];
+}
+
 // 1/x in double from a float32 hardware reciprocal refined by two Newton steps (|x| within float
 // range, which |B_s|^2 of a filter section always is): ~8 instructions instead of a full divide.
 __device__ inline double fast_rcp(double x) {
@@ -232,18 +282,45 @@ __device__ inline void sos_bwd_slow_section(const SosEval& e, const double* lb, 
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-template <int SCH>
-__global__ void __launch_bounds__(256) sos_response_bwd_mixed_kernel(
+// NIW > 0: "right constant factor" mode.  The cascade's response G (channel pair c = m*Nmid + j) was multiplied by a
+// real constant matrix W (Nmid x NIW) on the right, H[m][n] = sum_j G[m][j] W[j][n] (a Series of Matrix then a
+// cascade-type filter): gH then holds dL/dH (planes (m*NIW + n)), and the kernel forms
+//     dL/dG[m][j] = sum_n dL/dH[m][n] W[j][n]                      on the fly (no (M, No, Nmid) gradient tensor), and
+//     dL/dW[j][n] += Re(conj(G[m][j]) dL/dH[m][n])                 summed over its bins (per-block partials in partW)
+// -- the two composition-backward passes over the response-sized tensors disappear into this ALU-bound kernel.
+struct SosRC {
+    int Nmid, nbx;       // nbx: bin blocks (the grid is 1-D in this mode)
+    const float* Wr;     // (Nmid, NIW) row-major
+    float* partW;        // (gridDim.x, C, NIW)
+};
+
+template <int SCH, int NIW>
+__global__ void __launch_bounds__(256, 3) sos_response_bwd_mixed_kernel(
     const cx<float>* __restrict__ gH, long g_pitch, const cx<float>* __restrict__ H, long h_pitch,
     const double* __restrict__ b, const double* __restrict__ a, int S, int C, double g,
-    const cx<double>* __restrict__ Wd, int nfft, int bin0, int m_local, double* __restrict__ part) {
+    const cx<double>* __restrict__ Wd, int nfft, int bin0, int m_local, double* __restrict__ part, SosRC rc) {
     static_assert(SCH % 2 == 0, "sections are processed in pairs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int SP = (S + 1) & ~1;                            // table pitch: even, so a pair is one 8-byte read
     double* lb = reinterpret_cast<double*>(smem);
     double* la = lb + 3 * S;
     float* cf = reinterpret_cast<float*>(la + 3 * S + (S & 1));   // [basis][b|a][3][SP], 8-byte aligned
-    const int c = blockIdx.y;
+    // block -> (bin block bx, channel pair c).  Constant-factor mode: the Nmid pairs (m, j) of one output channel m read
+    // the same NIW gradient planes; their blocks get ids 8 apart (block q runs on XCD q % 8), i.e. consecutive slots
+    // of ONE XCD, so those planes cross the fabric once and come from that L2 for the other Nmid - 1 blocks
+    int bx, c, nbx;
+    if (NIW > 0) {
+        nbx = rc.nbx;
+        const int id = blockIdx.x, xcd = id & 7, t = id >> 3;
+        const int j = t % rc.Nmid, pr = (t / rc.Nmid) * 8 + xcd;        // pr = m * nbx + bx
+        if (pr >= (C / rc.Nmid) * nbx) return;
+        bx = pr % nbx;
+        c = (pr / nbx) * rc.Nmid + j;
+    } else {
+        bx = blockIdx.x;
+        nbx = gridDim.x;
+        c = blockIdx.y;
+    }
     stage_taps(b, a, S, C, c, lb, la);
     // B(w) = b0 + b1 w + b2 w^2 re-expanded about w = +1 (x = 1 - w) and about w = -1 (x = 1 + w):
     //   B = (b0+b1+b2) - (b1+2 b2) x + b2 x^2      |      B = (b0-b1+b2) + (b1-2 b2) x + b2 x^2
@@ -269,9 +346,37 @@ __global__ void __launch_bounds__(256) sos_response_bwd_mixed_kernel(
 #pragma unroll
         for (int u = 0; u < SCH / 2; ++u) acc[p][u] = (f2)(0.f);
     const float eps = eps_of<float>();
+    constexpr int NW = NIW > 0 ? NIW : 1;
+    float wrow[NW], accw[NW];
+    const cx<float>* gbase = gH + (size_t)c * g_pitch;
+    if (NIW > 0) {
+        const int mrow = c / rc.Nmid, j = c - mrow * rc.Nmid;
+        gbase = gH + (size_t)mrow * NIW * g_pitch;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            wrow[n] = rc.Wr[j * NIW + n];
+            accw[n] = 0.f;
+        }
+    }
 
-    for (int f = blockIdx.x * 256 + threadIdx.x; f < m_local; f += gridDim.x * 256) {
+    const int fstride = nbx * 256;
+    for (int f = bx * 256 + threadIdx.x; f < m_local; f += fstride) {
         const cx<float> h = H[(size_t)c * h_pitch + f];
+        cx<float> gv[NW];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) gv[n] = gbase[(size_t)n * g_pitch + f];
+        cx<float> gin;
+        if (NIW > 0) {
+            gin = cx<float>(0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                gin.x += wrow[n] * gv[n].x;
+                gin.y += wrow[n] * gv[n].y;
+                if (blockIdx.z == 0) accw[n] += h.x * gv[n].x + h.y * gv[n].y;
+            }
+        } else {
+            gin = gv[0];
+        }
         if (h.x == eps && h.y == 0.f) continue;   // guarded bin (prod A == 0): constant, zero gradient
         const int k = bin_of(f, bin0, nfft);
         const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
@@ -282,7 +387,6 @@ __global__ void __launch_bounds__(256) sos_response_bwd_mixed_kernel(
         const float xr = low ? d.x : (float)(1.0 + z1.x), xi = low ? d.y : (float)z1.y;
         const float* cb = cf + (low ? 0 : 6 * SP);
         const float* ca = cb + 3 * SP;
-        const cx<float> gin = gH[(size_t)c * g_pitch + f];
         const cx<float> gc(gin.x, -gin.y);
         const cx<float> gh = gc * h;              // conj(gH) * H
         unsigned slow = 0;
@@ -371,8 +475,22 @@ __global__ void __launch_bounds__(256) sos_response_bwd_mixed_kernel(
             }
             const double out[3] = {G[0], G[0] - G[1], G[0] - 2.0 * G[1] + G[2]};
 #pragma unroll
-            for (int p = 0; p < 3; ++p) part[((((size_t)blockIdx.x * 2 + i) * 3 + p) * S + s) * C + c] = out[p];
+            for (int p = 0; p < 3; ++p) part[((((size_t)bx * 2 + i) * 3 + p) * S + s) * C + c] = out[p];
         }
+    }
+    if (NIW > 0 && blockIdx.z == 0) {
+        __shared__ float redw[4][NW];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            float v = accw[n];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) redw[wave][n] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < NW)
+            rc.partW[((size_t)bx * C + c) * NW + threadIdx.x] =
+                redw[0][threadIdx.x] + redw[1][threadIdx.x] + redw[2][threadIdx.x] + redw[3][threadIdx.x];
     }
 }
 
@@ -550,7 +668,8 @@ static int sos_impl(const void* b, const void* a, int S, int C, double gamma, co
 
 template <typename T>
 static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S, int C,
-                        double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
+                        double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream,
+                        int rc_ni = 0, SosRC rc = SosRC{0, 0, nullptr, nullptr}) {
     FL_REQUIRE(gH && b && a && part && Wd, "sos_response_bwd: null pointer");
     FL_REQUIRE(g_pitch >= m_local && (!H || h_pitch >= m_local), "sos_response_bwd: g_pitch / h_pitch must be >= m_local");
     FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) && m_local > 0, "sos_response_bwd: bad sizes");
@@ -559,22 +678,34 @@ static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitc
 #define FL_SOS_MIX(SC)                                                                                              \
     {                                                                                                               \
         dim3 grid(sos_blocks(m_local), C, cdiv_i(S, SC));                                                           \
-        hipLaunchKernelGGL((sos_response_bwd_mixed_kernel<SC>), grid, dim3(256),                                 \
-                           (size_t)(6 * S + 2) * sizeof(double) + (size_t)12 * ((S + 1) & ~1) * sizeof(float),  \
-                           (hipStream_t)stream, (const cx<float>*)gH, g_pitch, (const cx<float>*)H, h_pitch,       \
-                           (const double*)b, (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0,     \
-                           m_local, (double*)part);                                                                 \
+        if (rc_ni > 0) {                                                                                           \
+            rc.nbx = sos_blocks(m_local);                                                                          \
+            grid = dim3(cdiv_i((C / rc.Nmid) * rc.nbx, 8) * 8 * rc.Nmid, 1, cdiv_i(S, SC));                        \
+        }                                                                                                          \
+        const size_t lds = (size_t)(6 * S + 2) * sizeof(double) + (size_t)12 * ((S + 1) & ~1) * sizeof(float);    \
+        FL_SOS_MIX_N(SC, 0) else FL_SOS_MIX_N(SC, 2) else FL_SOS_MIX_N(SC, 4) else FL_SOS_MIX_N(SC, 8)            \
+        else FL_SOS_MIX_N(SC, 16) else {                                                                          \
+            set_error("sos_response_bwd: no kernel for %d input channels of the constant factor", rc_ni);          \
+            return FL_ERR_UNSUPPORTED;                                                                             \
+        }                                                                                                          \
     }
+#define FL_SOS_MIX_N(SC, NIW_)                                                                                      \
+    if (rc_ni == NIW_)                                                                                              \
+        hipLaunchKernelGGL((sos_response_bwd_mixed_kernel<SC, NIW_>), grid, dim3(256), lds, (hipStream_t)stream,   \
+                           (const cx<float>*)gH, g_pitch, (const cx<float>*)H, h_pitch, (const double*)b,           \
+                           (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0, m_local, (double*)part, rc);
             const int want = g_sos_chunk > 0 ? g_sos_chunk : 12;
             if (S <= 4 || want <= 4) FL_SOS_MIX(4)
             else if (S <= 6 || want <= 6) FL_SOS_MIX(6)
             else if (S <= 8 || want <= 8) FL_SOS_MIX(8)
             else FL_SOS_MIX(12)
 #undef FL_SOS_MIX
+#undef FL_SOS_MIX_N
             FL_CHECK_LAUNCH("sos_response_bwd");
             return FL_OK;
         }
     }
+    FL_REQUIRE(rc_ni == 0, "sos_response_bwd: the constant-factor mode needs float32 and the saved forward response");
     const int sch = (g_sos_chunk == 3 || g_sos_chunk == 4 || g_sos_chunk == 6 || g_sos_chunk == 12) ? g_sos_chunk : 6;
 #define FL_SOS_BWD(SC)                                                                                              \
     {                                                                                                               \
@@ -644,6 +775,37 @@ int fl_geq_sections_bwd(const void* gain, int in_kind, const void* gb, const voi
 int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
                             int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
     return sos_bwd_impl<float>(gH, g_pitch, H, h_pitch, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
+}
+int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
+                           const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
+                           void* stream) {
+    FL_REQUIRE(b && a && Wr && Wd && G && H, "sos_response_rc: null pointer");
+    FL_REQUIRE(g_pitch >= m_local && h_pitch >= m_local, "sos_response_rc: pitches must be >= m_local");
+    FL_REQUIRE(S > 0 && S <= 64 && No > 0 && No <= 65535 && Nmid > 0 && Nmid <= 32 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) &&
+                   m_local >= 0, "sos_response_rc: bad sizes");
+    if (m_local == 0) return FL_OK;
+    dim3 grid(cdiv_i(m_local, 256), No);
+    const size_t lds = (size_t)Nmid * 6 * S * sizeof(double) + (size_t)Nmid * Ni * sizeof(float);
+#define FL_RC_FWD(NIW_)                                                                                                      \
+    if (Ni == NIW_) {                                                                                                        \
+        hipLaunchKernelGGL((sos_response_rc_kernel<NIW_>), grid, dim3(256), lds, (hipStream_t)stream, (const double*)b,      \
+                           (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma, (const cx<double>*)Wd, nfft, bin0, \
+                           m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);                                         \
+        FL_CHECK_LAUNCH("sos_response_rc");                                                                                  \
+        return FL_OK;                                                                                                        \
+    }
+    FL_RC_FWD(2) FL_RC_FWD(4) FL_RC_FWD(8) FL_RC_FWD(16)
+#undef FL_RC_FWD
+    set_error("sos_response_rc: no kernel for %d input channels of the constant factor", Ni);
+    return FL_ERR_UNSUPPORTED;
+}
+int fl_sos_response_bwd_rc_c64(const void* gHfull, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
+                               int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,
+                               int bin0, int m_local, void* part, void* partW, void* stream) {
+    FL_REQUIRE(G && Wr && partW && No > 0 && Nmid > 0 && Ni > 0, "sos_response_bwd_rc: bad arguments");
+    SosRC rc{Nmid, 0, (const float*)Wr, (float*)partW};
+    return sos_bwd_impl<float>(gHfull, g_pitch, G, h_pitch, b, a, S, No * Nmid, gamma, Wd, nfft, bin0, m_local, part, stream,
+                               Ni, rc);
 }
 int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
                              int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {

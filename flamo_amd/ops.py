@@ -1033,6 +1033,117 @@ class _GeqCascade(torch.autograd.Function):
         return out, None, None, None, None
 
 
+def cascade_rc_supported(real: torch.dtype, n_in: int) -> bool:
+    """cascade response times a real constant matrix with n_in columns: fused backward available"""
+    return real == torch.float32 and SOS_BWD_MIXED and int(n_in) in (2, 4, 8, 16)
+
+
+def _cascade_rc_forward(b, a, Wr, gamma, nfft, real):
+    """G = cascade(b, a) (No, Nmid per bin), H = G @ Wr in one launch.  Returns (H view (M, No, Ni), G rows, cfg)."""
+    if b.dim() != 4:
+        raise ValueError("cascade_rc expects a full (N_out, N_mid) cascade")
+    dev = b.device
+    S, No, Nmid = b.shape[1], b.shape[2], b.shape[3]
+    if Wr.dim() != 2 or Wr.shape[0] != Nmid:
+        raise ValueError(f"cascade_rc: the constant factor must be ({Nmid}, N_in), got {tuple(Wr.shape)}")
+    Ni = Wr.shape[1]
+    bin0, m_local = _bin0_arg(nfft)
+    G = _empty_rows((No, Nmid), m_local, torch.complex64, dev)
+    H = _empty_rows((No, Ni), m_local, torch.complex64, dev)
+    Wc = Wr.contiguous()
+    P = _pitch(m_local)
+    with kernel_timer.span("sos_response_rc"):
+        _lib.check(_lib.lib().fl_sos_response_rc_c64(b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni, Wc.data_ptr(), float(gamma),
+                                                     twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local,
+                                                     G.data_ptr(), P, H.data_ptr(), P, _stream()), "sos_response_rc")
+    return H.movedim(-1, 0), G, (float(gamma), nfft, S, No * Nmid, bin0, m_local, real)
+
+
+def _cascade_rc_backward(gH, G, b, a, Wr, cfg):
+    """-> (part: float64 (nblk, 2, 3, S, C), gW: float32 (Nmid, Ni))"""
+    gamma, nfft, S, C_, bin0, m_local, real = cfg
+    No, Nmid = G.shape[0], G.shape[1]
+    Ni = Wr.shape[1]
+    g = _h_planar(gH.resolve_conj(), True)
+    L = _lib.lib()
+    nblk = L.fl_sos_bwd_blocks(m_local)
+    part = torch.empty((nblk, 2, 3, S, C_), dtype=torch.float64, device=b.device)
+    partW = torch.empty((nblk, No, Nmid, Ni), dtype=torch.float32, device=b.device)
+    Wc = Wr.contiguous()
+    with kernel_timer.span("sos_response_bwd_rc"):
+        _lib.check(L.fl_sos_response_bwd_rc_c64(g.data_ptr(), _lead_pitch(g.movedim(0, -1)), G.data_ptr(), _pitch(m_local),
+                                                b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni, Wc.data_ptr(), gamma,
+                                                twiddles(nfft, torch.float64, b.device).data_ptr(), nfft, bin0, m_local,
+                                                part.data_ptr(), partW.data_ptr(), _stream()), "sos_response_bwd_rc")
+    return part, partW.sum(dim=(0, 1))
+
+
+class _SosRC(torch.autograd.Function):
+    """sos_response(b, a) @ Wr with the composition's backward folded into the cascade's backward kernel"""
+
+    @staticmethod
+    def forward(ctx, b, a, Wr, gamma, nfft, real):
+        _require_gpu(b, a, Wr)
+        if b.shape != a.shape or b.shape[0] != 3 or b.dim() != 4:
+            raise ValueError("sos_response_rc: b and a must both be (3, n_sections, N_out, N_mid)")
+        bc, ac = b.contiguous(), a.contiguous()
+        H, G, ctx.cfg = _cascade_rc_forward(bc, ac, Wr, gamma, nfft, real)
+        ctx.save_for_backward(bc, ac, G, Wr)
+        return H
+
+    @staticmethod
+    def backward(ctx, gH):
+        bc, ac, G, Wr = ctx.saved_tensors
+        part, gW = _cascade_rc_backward(gH, G, bc, ac, Wr, ctx.cfg)
+        tot = part.sum(dim=0)
+        return tot[0].view(bc.shape), tot[1].view(ac.shape), gW.to(Wr.dtype), None, None, None
+
+
+class _GeqCascadeRC(torch.autograd.Function):
+    """geq_cascade(x) @ Wr: design + cascade + product forward; cascade backward (with the composition folded in) +
+    design backward."""
+
+    @staticmethod
+    def forward(ctx, x, consts, Wr, gamma, nfft, real):
+        dev = _require_gpu(x, consts, Wr)
+        xc = x.contiguous()
+        nb = xc.shape[0]
+        chan = tuple(xc.shape[1:])
+        C_ = max(_prod(chan), 1)
+        b = torch.empty((3, nb, *chan), dtype=torch.float64, device=dev)
+        a = torch.empty_like(b)
+        _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), _geq_in_kind(xc, True), nb, C_, consts.data_ptr(), b.data_ptr(),
+                                              a.data_ptr(), _stream()), "geq_sections")
+        H, G, ctx.cfg = _cascade_rc_forward(b, a, Wr, gamma, nfft, real)
+        ctx.save_for_backward(xc, consts, b, a, G, Wr)
+        return H
+
+    @staticmethod
+    def backward(ctx, gH):
+        xc, consts, b, a, G, Wr = ctx.saved_tensors
+        part, gW = _cascade_rc_backward(gH, G, b, a, Wr, ctx.cfg)
+        nblk = part.shape[0]
+        nb = xc.shape[0]
+        C_ = max(_prod(xc.shape[1:]), 1)
+        st = nb * C_
+        out = torch.empty_like(xc)
+        esz = part.element_size()
+        _lib.check(_lib.lib().fl_geq_sections_bwd(xc.data_ptr(), _geq_in_kind(xc, True), part.data_ptr(),
+                                                  part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
+                                                  out.data_ptr(), _stream()), "geq_sections_bwd")
+        return out, None, gW.to(Wr.dtype), None, None, None
+
+
+def sos_response_rc(b, a, Wr, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
+    """sos_response(b, a) (M, N_out, N_mid) times the real constant matrix Wr (N_mid, N_in) on the right, per bin."""
+    return _SosRC.apply(b.to(torch.float64), a.to(torch.float64), Wr.to(torch.float32), float(gamma), int(nfft), dtype)
+
+
+def geq_cascade_rc(x, consts, Wr, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
+    """geq_cascade(x, ...) (M, N_out, N_mid) times the real constant matrix Wr (N_mid, N_in) on the right, per bin."""
+    return _GeqCascadeRC.apply(x, consts, Wr.to(torch.float32), float(gamma), int(nfft), dtype)
+
+
 def geq_cascade(x: torch.Tensor, consts: torch.Tensor, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
     """Response (M, ...) of the graphic equaliser whose raw parameters x (n_bands, ...) go through
     the default map 20 log10|x| -- same result as sos_response(*geq_sections(20 log10|x|)), with

@@ -236,16 +236,20 @@ class DSP(nn.Module):
     def _fusable(self) -> bool:
         return getattr(self, "_own_convolve", None) is not None and self.freq_convolve is self._own_convolve
 
-    def _response_for_fusion(self, shape, ext_param):
-        """Same checks and side effects as forward() (shape check, ext_param logging), but returns
-        the response instead of applying it."""
+    def _param_for_fusion(self, shape, ext_param):
+        """Same checks and side effects as forward() (shape check, ext_param logging); returns the parameter
+        tensor the response is to be built from."""
         from types import SimpleNamespace
         self.check_input_shape(SimpleNamespace(shape=tuple(shape)))
         if ext_param is None:
-            return self._bin_response(self.param)
+            return self.param
         with torch.no_grad():
             self.assign_value(ext_param)
-        return self._bin_response(ext_param)
+        return ext_param
+
+    def _response_for_fusion(self, shape, ext_param):
+        """forward()'s checks, but returns the response instead of applying it."""
+        return self._bin_response(self._param_for_fusion(shape, ext_param))
 
 
 # ============================================================================ gains / matrices
@@ -277,6 +281,11 @@ class Gain(DSP):
 
     def _bin_response(self, param):
         return to_complex(self.map(param)), self._diag
+
+    def _real_matrix(self, param):
+        """the mapped parameter as the real matrix it is (the response is its complex cast, dsp.py:466-468)"""
+        W = self.map(param)
+        return None if (W.is_complex() or W.dim() != 2) else W
 
     def initialize_class(self):
         self.check_param_shape()
@@ -488,6 +497,21 @@ class _SOSMixin:
     def _sos_to_response(self, b, a):
         return ops.sos_response(b, a, self._gamma_f, self.nfft, dtype=self.dtype)
 
+    def _response_times_matrix(self, param, Wr):
+        """freq_response(param) @ Wr (a real constant matrix on the right) as one operator whose backward folds the
+        composition into the cascade kernel; None when this module / dtype has no such path."""
+        if self._diag or not param.is_cuda or not ops.cascade_rc_supported(self.dtype, Wr.shape[1]):
+            return None
+        if getattr(self, "_own_response", None) is not self.freq_response:
+            return None
+        spec = self._cascade_spec(param)
+        if spec[0] == "geq":
+            return ops.geq_cascade_rc(spec[1], spec[2], Wr, self._gamma_f, self.nfft, dtype=self.dtype)
+        return ops.sos_response_rc(spec[1], spec[2], Wr, self._gamma_f, self.nfft, dtype=self.dtype)
+
+    def _cascade_spec(self, param):
+        return ("sos", *self._sos_coeffs(self.map(param.double())))
+
     def _sections_spectra(self, b, a):
         """B, A as the reference returns them from get_poly_coeff: rfft of the weighted taps."""
         env = self.alias_envelope_dcy.to(b.device).view(3, *([1] * (b.dim() - 1)))
@@ -498,6 +522,7 @@ class _SOSMixin:
         # module dtype: the cascade is ill-conditioned in its coefficients at low frequency and
         # the float64 reference is the parity target
         self.freq_response = lambda param: self._sos_to_response(*self._sos_coeffs(self.map(param.double())))
+        self._own_response = self.freq_response
 
     def get_poly_coeff(self, param):
         """(H, B, A) for *mapped* parameters, as in the reference.  H comes from the fused kernel;
@@ -622,6 +647,12 @@ class GEQ(_SOSMixin, Filter):
                                        dtype=self.dtype)
             return self._sos_to_response(*self._sos_coeffs(self.map(param.double())))
         self.freq_response = response
+        self._own_response = response
+
+    def _cascade_spec(self, param):
+        if self.map is _db_of_magnitude and param.is_cuda and param.dtype in (torch.float32, torch.float64):
+            return ("geq", param, self._design.device_consts(param.device))
+        return ("sos", *self._sos_coeffs(self.map(param.double())))
 
     def _sos_coeffs(self, gain_db):
         """command gains in dB -> float32 SOS (b, a) for every channel pair at once; the

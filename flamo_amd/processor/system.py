@@ -33,6 +33,8 @@ FUSE_MIN_COLUMNS = 4   # batch x trailing columns below which folding does not p
 OVERLAP_RESPONSES = True
 # Shell(FFT -> per-bin chain -> iFFT) as one fused operator (ops.spectral_apply) when the plan and channel counts allow
 FUSE_SHELL = True
+# Series(Matrix, cascade-type filter, ...): response and gradients of the pair from one fused operator (ops.*_rc)
+FUSE_MATRIX_CASCADE = True
 # Gradients of the parameters are then produced on the side stream while their AccumulateGrad
 # nodes live on the main one; autograd synchronises the two correctly and merely warns about it.
 _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -226,14 +228,34 @@ class Series(nn.Sequential):
         side stream (concurrently with the input transform of the enclosing Shell) when a fork point is set."""
         M = shape[1]
 
+        def ext_of(key):
+            return ext_param[key] if (ext_param is not None and key in ext_param) else None
+
         def build():
             shp = list(shape)
             acc = None
-            for key, module in run:
-                ext = ext_param[key] if (ext_param is not None and key in ext_param) else None
-                resp = module._response_for_fusion(shp, ext)
+            i = 0
+            while i < len(run):
+                key, module = run[i]
+                if acc is None and FUSE_MATRIX_CASCADE and i + 1 < len(run):
+                    # Matrix then cascade-type filter: one operator for (cascade response) @ (matrix), whose backward
+                    # computes both factors' gradients inside the cascade's backward kernel
+                    nxt_key, nxt = run[i + 1]
+                    if hasattr(module, "_real_matrix") and not module._diag and hasattr(nxt, "_response_times_matrix"):
+                        Wr = module._real_matrix(module._param_for_fusion(shp, ext_of(key)))
+                        if Wr is not None:
+                            shp2 = list(shp)
+                            shp2[2] = module.output_channels
+                            H = nxt._response_times_matrix(nxt._param_for_fusion(shp2, ext_of(nxt_key)), Wr)
+                            if H is not None:
+                                acc = (H, False)
+                                shp[2] = nxt.output_channels
+                                i += 2
+                                continue
+                resp = module._response_for_fusion(shp, ext_of(key))
                 shp[2] = module.output_channels
                 acc = resp if acc is None else _compose(acc, resp, M)
+                i += 1
             return acc
 
         ev = ops.fork_event() if OVERLAP_RESPONSES else None

@@ -244,6 +244,22 @@ int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_
                             int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
 int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
                              int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
+/* Cascade response times a real constant matrix on the right -- Series(Matrix, <cascade-type filter>), system.py:299-300
+ * over dsp.py:466-468 and dsp.py:922-924 (the reference applies the two modules one after the other):
+ *   G[m*Nmid + j, f] as fl_sos_response_c64 (planes of pitch g_pitch; kept for the backward pass),
+ *   H[m*Ni + n, f] = sum_j G[m][j] Wr[j][n]   (planes of pitch h_pitch), Wr float (Nmid, Ni) row-major, Ni in {2,4,8,16}. */
+int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
+                           const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
+                           void* stream);
+/* The same backward pass when the cascade's response G (No x Nmid per bin, channel pair c = m*Nmid + j) was multiplied on
+ * the right by a real constant matrix W (Nmid x Ni) -- Series(Matrix, <cascade-type filter>), system.py:299-300 over
+ * dsp.py:466-468 and dsp.py:922-924:  H[m][n] = sum_j G[m][j] W[j][n].  gHfull: dL/dH, planes (m*Ni + n) of pitch g_pitch;
+ * G: the saved forward response of the cascade (planes c, pitch h_pitch).  part as above (for G's coefficients);
+ * partW: float (fl_sos_bwd_blocks(m_local), No*Nmid, Ni), per-block partials of Re(conj(G[m][j]) dL/dH[m][n]) -- summed
+ * over blocks and over m they are dL/dW[j][n].  Replaces two response-sized composition-backward passes.  Ni in {2,4,8,16}. */
+int fl_sos_response_bwd_rc_c64(const void* gHfull, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
+                               int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,
+                               int bin0, int m_local, void* part, void* partW, void* stream);
 
 /* Graphic-equaliser design: command gains -> the float32-rounded second-order sections of
  * GEQ / parallelGEQ for all C channel pairs at once (replaces the Python double loop over

@@ -274,3 +274,46 @@ def test_shell_fused_module_zoo(gpu, kind):
         assert (a is None) == (b is None)
         if a is not None:
             assert relerr(a, b) < 1e-4, kind
+
+
+@pytest.mark.parametrize("kind", ["geq", "biquad", "svf", "geq-orth-4"])
+def test_matrix_cascade_operator_equals_composition(gpu, kind):
+    """Series(Matrix, cascade filter): the fused pair operator (response = cascade @ matrix, both gradients from the cascade's
+    backward kernel) against the generic composition of the two modules' responses"""
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    nfft, B = 96000, 2
+    N = 4 if kind.endswith("4") else 8
+    torch.manual_seed(5)
+    kw = dict(nfft=nfft, alias_decay_db=0.0, device=gpu, dtype=torch.float32, requires_grad=True)
+    mat = dsp.Matrix(size=(N, N), matrix_type="orthogonal" if "orth" in kind else "random", **kw)
+    if kind.startswith("geq"):
+        flt = dsp.GEQ(size=(N, N), **kw)
+    elif kind == "biquad":
+        flt = dsp.Biquad(size=(N, N), n_sections=3, filter_type="bandpass", **kw)
+    else:
+        flt = dsp.SVF(size=(N, N), n_sections=2, **kw)
+    shell = system.Shell(system.Series(OrderedDict(mix=mat, flt=flt)), dsp.FFT(nfft), dsp.iFFT(nfft))
+    params = [mat.param, flt.param]
+    x = torch.randn(B, nfft, N, device=gpu)
+
+    def run():
+        ops.kernel_timer.reset(True)
+        y = shell(x)
+        g = torch.autograd.grad(ops.mean_square(y), params)
+        torch.cuda.synchronize()
+        used = set(ops.kernel_timer.records)
+        ops.kernel_timer.enabled = False
+        return y.detach(), g, used
+
+    y1, g1, used1 = run()
+    assert "sos_response_bwd_rc" in used1, used1
+    system.FUSE_MATRIX_CASCADE = False
+    try:
+        y2, g2, used2 = run()
+    finally:
+        system.FUSE_MATRIX_CASCADE = True
+    assert "sos_response_bwd_rc" not in used2
+    assert relerr(y1, y2) < TOL
+    for a, b in zip(g1, g2):
+        assert relerr(a, b) < 2e-5, kind
