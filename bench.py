@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+Headline workload (BASELINE.json configs[1], the configuration the metric is quoted on):
   Shell(FFT(96000) -> Series(Matrix(8,8,"random"), GEQ((8,8))) -> iFFT(96000)), batch 32 per GPU,
   float32, synthetic white-noise input resident in HBM, forward + backward of loss=(y**2).mean()
   (evaluated by ops.mean_square: the same value in one streaming pass each way)
@@ -13,13 +13,21 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
   training step (flamo/optimize/trainer.py:172-191; the data tensor does not require grad).
 Metric: frequency-bin x channel products per second =
   (sum over per-bin MIMO modules of B*M*N_out*N_in) / time(fwd+bwd), whole job over all GPUs.
-Multi-GPU: batch data parallel (bins are independent but so are batch items, and config 2's
-parameters are a few KB): each rank owns 32 signals, parameter gradients are all-reduced over
-RCCL each step; "weak" scaling.
+Multi-GPU: batch data parallel for the headline line (bins are independent but so are batch items, and config 2's
+parameters are a few KB): each rank owns 32 signals, parameter gradients are all-reduced over RCCL each step; "weak"
+scaling.  The bin-sharded forms are timed beside it when more than one rank runs: "bin_sharded" in the
+JSON line (config 2 through two all-to-alls per direction; the config-5 structure through the all-gather).
+
+The one JSON line also carries (rank 0): `roofline` (dominant kernel) and `kernels` (every hot kernel's launch time,
+algorithmic bytes and fraction of the HBM peak), `step_roofline` (the unfused 1.057 GB/step count and the
+fused pipeline's own count against the step time), `input_grad` (the same step with the gradient of the input),
+`secondary` (BASELINE configs[2..4] on one GPU: bin-solves/s, solve TFLOP/s), `device` (what rocminfo / a copy probe say)
+and `cpu_baseline` (the oracle's torch-CPU graph on the host cores).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 import warnings
@@ -30,13 +38,12 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 NFFT, NCH, BATCH = 96000, 8, 32
-# HBM bytes per launch of the dominant kernel from the PMC passes (profiles/r01k_pmc_hbm_traffic.csv,
-# grid 393216 = the batch-32 launch): 2*FETCH_SIZE + WRITE_SIZE.  A static number measured by rocprofv3,
-# not re-measured by every bench run.
-PMC_TRAFFIC_BYTES = 222.8e6
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+FP32_PEAK_TFLOPS = 157.3    # vector FP32, spec
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")   # written by tools/summarize_profiles.py from the two PMC passes
 
 
 def build_model(dev, dtype):
@@ -48,50 +55,208 @@ def build_model(dev, dtype):
     return system.Shell(core, dsp.FFT(NFFT, dtype=dtype), dsp.iFFT(NFFT, dtype=dtype)), [mat.param, geq.param]
 
 
-def cpu_baseline(W, G, budget_s=20.0):
-    """The same graph on the host cores through the CPU oracle (a port of the reference's torch
-    ops), float32 like the reference's default module dtype.  Bounded sample: a probe step at
-    batch 1 sizes the largest batch (<= 32) whose timed steps fit in ~budget_s; throughput is
-    reported on that sample (the work is linear in the batch apart from the response build)."""
-    from oracle import hotpath as O
+# ----------------------------------------------------------------------------- device facts
+def device_info(dev):
+    """Peaks as the box reports them (SURVEY 8-d3 asks for them to be re-read, not assumed): CU count and clock from
+    rocminfo, a float4 device copy as the live HBM ceiling."""
+    info = {"name": torch.cuda.get_device_name(dev), "hbm_peak_spec_GBs": HBM_PEAK_GBS, "fp32_vector_peak_spec_TFLOPs": FP32_PEAK_TFLOPS}
     try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
+        out = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=20).stdout
+        gpu = out[out.index("gfx9"):] if "gfx9" in out else out
+        cus = [int(l.split(":")[1]) for l in gpu.splitlines() if l.strip().startswith("Compute Unit:")]
+        mhz = [int(l.split(":")[1]) for l in gpu.splitlines() if l.strip().startswith("Max Clock Freq. (MHz):")]
+        if cus and mhz:
+            info.update(compute_units=cus[0], max_clock_mhz=mhz[0],
+                        fp32_vector_peak_from_rocminfo_TFLOPs=round(cus[0] * 4 * 32 * 2 * mhz[0] * 1e6 / 1e12, 1))
+    except Exception as e:     # noqa: BLE001 -- a missing tool only drops the field
+        info["rocminfo_error"] = type(e).__name__
+    try:
+        props = torch.cuda.get_device_properties(dev)
+        info.update(hbm_bytes=props.total_memory, multiprocessors=props.multi_processor_count)
+    except Exception:          # noqa: BLE001
+        pass
+    n = 64 * 1024 * 1024
+    a, b = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    a.zero_()
+    for _ in range(3):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    info["hbm_copy_probe_GBs"] = round(10 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    return info
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(W, G, budget_s=45.0):
+    """The same graph on the host cores through the CPU oracle (a port of the reference's torch ops), float32 like the
+    reference's default module dtype: one warm-up step and THREE timed steps at the full batch of 32 when
+    the probe says they fit the budget, else at the largest batch that does (the work is linear in the batch apart from
+    the response build); the sample is stated.  Thread count: torch's CPU ops do not scale to every SMT thread of a
+    large host on these shapes (os.cpu_count() threads can be an order of magnitude SLOWER than 16), so one step at
+    batch 1 is timed at 16, 64 and os.cpu_count() threads, all three times are reported, and the fastest count is the
+    one used -- and stated as "cores"."""
+    from oracle import hotpath as O
+    ncpu = os.cpu_count() or 1
     Wc = W.detach().cpu().float().requires_grad_(True)
     Gc = G.detach().cpu().float().requires_grad_(True)
-
-    def step(x):
-        y = O.config2_forward(x, Wc, Gc, NFFT)
-        torch.autograd.grad((y ** 2).mean(), [Wc, Gc])
 
     def timed(b, n):
         x = torch.randn(b, NFFT, NCH, dtype=torch.float32)
         t0 = time.perf_counter()
         for _ in range(n):
-            step(x)
+            y = O.config2_forward(x, Wc, Gc, NFFT)
+            torch.autograd.grad((y ** 2).mean(), [Wc, Gc])
         return (time.perf_counter() - t0) / n
 
-    # torch's CPU ops do not scale to hundreds of SMT threads on these shapes: probe a few thread
-    # counts at batch 1 and keep the fastest (the count actually used is reported as "cores")
-    best = None
-    for cores in sorted({min(avail, c) for c in (16, 64, avail)}):
+    probe = {}
+    for cores in sorted({min(ncpu, c) for c in (16, 64, ncpu)}):
         torch.set_num_threads(cores)
         timed(1, 1)                  # warm-up (thread pools, FFT plans)
-        t = timed(1, 1)
-        if best is None or t < best[0]:
-            best = (t, cores)
-        if t > budget_s / 3:
+        probe[cores] = timed(1, 1)
+        if probe[cores] > 8.0:       # an oversubscribed host: larger counts only get worse
             break
-    t1, cores = best
+    cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
-    b = int(max(1, min(BATCH, budget_s / 2 / max(t1, 1e-3))))
-    n = 2 if b < BATCH or t1 * BATCH * 2 < budget_s else 1
-    dt = timed(b, n)
+    per_item = max(probe[cores], 1e-3)
+    b = int(max(1, min(BATCH, budget_s / 4 / per_item * 1.5)))     # batch-1 steps overstate the per-item cost (response build)
+    timed(b, 1)                       # warm-up at the timed size
+    dt = timed(b, 3)
     M = NFFT // 2 + 1
     return {"value": 2 * b * M * NCH * NCH / dt, "unit": "products/s", "cores": cores, "kind": "port",
-            "sample": f"config 2 graph (nfft={NFFT}, {NCH}x{NCH}, float32) at batch {b} of {BATCH}, {n} timed step(s) "
-                      f"after warm-up, {dt:.2f} s/step, torch {torch.__version__} CPU ops"}
+            "threads_probe_s_per_batch1_step": {str(k): round(v, 3) for k, v in probe.items()}, "os_cpu_count": ncpu,
+            "sample": f"config 2 graph (nfft={NFFT}, {NCH}x{NCH}, float32) at batch {b} of {BATCH}, 1 warm-up + 3 timed steps, "
+                      f"{dt:.2f} s/step, {cores} threads (fastest of the probe; os.cpu_count() = {ncpu}), torch {torch.__version__} CPU ops"}
+
+
+# ----------------------------------------------------------------------------- secondary workloads (one GPU)
+def _graph_ms(fn, inputs, params, steps):
+    from flamo_amd.graph import GraphedStep
+    gs = GraphedStep(fn, inputs, params)
+    for _ in range(3):
+        gs.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gs.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def secondary(dev):
+    """BASELINE configs[2] (16-channel FDN, nfft=192000, batch 1 and 8), configs[3] (colorless FDN training step) and the
+    configs[4] structure (32x32 chain, nfft=384000) on this GPU: ms/step from HIP-graph replays, bin-solves/s, and the
+    closed-loop solve's launch time -> vector TFLOP/s (M (8 (2/3) N^3 + B K 16 N^2) flop per launch)."""
+    from flamo_amd import ops
+    import bench_fdn
+    import train_colorless_fdn as tc
+    out = {}
+    dt = torch.float32
+
+    def solve_rate(model, x, c, params, N, nfft, B):
+        ops.kernel_timer.reset(True, prefill_cycles=300_000)
+        for _ in range(4):
+            for p in params:
+                p.grad = None
+            (model(x) * c).sum().backward()
+        torch.cuda.synchronize()
+        ops.kernel_timer.enabled = False
+        t = {k: v for k, v in ops.kernel_timer.summary().items() if k.startswith("solve")}
+        if not t:
+            return None
+        ms = sum(v[1] for v in t.values()) / len(t)
+        M = nfft // 2 + 1
+        flop = M * (8.0 * (2.0 / 3.0) * N ** 3 + B * 16.0 * N ** 2)
+        return {"launch_ms": round(ms, 4), "TFLOPs": round(flop / (ms * 1e-3) / 1e12, 2),
+                "frac_fp32_vector_peak": round(flop / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 3),
+                "launches_per_step": {k: v[0] // 4 for k, v in t.items()}}
+
+    for B in (1, 8):
+        torch.manual_seed(130709)
+        model, params = bench_fdn.build(dev, dt, 16, 192000)
+        x = torch.randn(B, 192000, 1, device=dev)
+        c = torch.randn(B, 192000, 1, device=dev)
+        ms = _graph_ms(lambda xx: (model(xx) * c).sum(), (x,), params, 20)
+        out[f"config3_fdn16_batch{B}"] = {"ms_per_step": round(ms, 4), "bin_solves_per_s": B * 96001 / (ms * 1e-3),
+                                          "solve": solve_rate(model, x, c, params, 16, 192000, B)}
+    # configs[3]: one training step (forward, criteria, backward replayed; Adam behind it)
+    torch.manual_seed(130709)
+    model = tc.build(dev, dt, 16, 192000)
+    x, target = tc.colorless_batch(1, 192000, dev, dt)
+    tc.train(model, x, target, 3, 1e-3)
+    clock = {}
+
+    def start():
+        torch.cuda.synchronize()
+        clock["t0"] = time.perf_counter()
+    tc.train(model, x, target, 50, 1e-3, graphed=True, on_ready=start, fused_adam=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - clock["t0"]) / 50 * 1e3
+    out["config4_colorless_training"] = {"ms_per_step": round(ms, 4), "bin_solves_per_s": 96001 / (ms * 1e-3)}
+    # configs[4] structure on one GPU
+    torch.manual_seed(130709)
+    model, params = bench_fdn.build_config5(dev, dt, 32, 384000)
+    x = torch.randn(1, 384000, 32, device=dev)
+    c = torch.randn(1, 384000, 32, device=dev)
+    ms = _graph_ms(lambda xx: (model(xx) * c).sum(), (x,), params, 5)
+    out["config5_chain_32x32"] = {"ms_per_step": round(ms, 3), "bin_solves_per_s": 192001 / (ms * 1e-3),
+                                  "solve": solve_rate(model, x, c, params, 32, 384000, 32)}
+    return out
+
+
+# ----------------------------------------------------------------------------- bin-sharded forms (ranks > 1)
+def bin_sharded(dev, model, params, x, steps):
+    """SURVEY 8-e1 beside the batch-parallel headline.  (a) config 2 with the core bin-sharded: local input transform of
+    the rank's batch items, all-to-all into bin shards, per-bin product on the local bins, all-to-all back, local inverse
+    transform (two data-path collectives each way, 98 MB per rank each).  (b) the configs[4] structure with the input
+    replicated: responses / loop solve on the rank's bins, ONE all-gather of the (B, M, 32) spectrum in front of the
+    inverse transform.  Eager steps (collectives are not captured), max over ranks."""
+    import torch.distributed as dist
+    from flamo_amd import dist as fd, ops
+    import bench_fdn
+    world = dist.get_world_size()
+
+    def timed(step, n):
+        for _ in range(2):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item() / n * 1e3
+
+    def step2():
+        for p in params:
+            p.grad = None
+        ops.mean_square(fd.bin_exchange_forward(model, x)).backward()
+        fd.all_reduce_grads(params)
+    ms2 = timed(step2, max(3, min(steps, 10)))
+    M = NFFT // 2 + 1
+    torch.manual_seed(130709)
+    m5, p5 = bench_fdn.build_config5(dev, torch.float32, 32, 384000)
+    x5 = torch.randn(1, 384000, 32, device=dev)
+    c5 = torch.randn(1, 384000, 32, device=dev)
+
+    def step5():
+        for p in p5:
+            p.grad = None
+        (fd.sharded_forward(m5, x5) * c5).sum().backward()
+        fd.all_reduce_grads(p5)
+    ms5 = timed(step5, 5)
+    return {"config2_bins_all_to_all": {"ms_per_step": round(ms2, 4), "products_per_s": 2 * BATCH * world * M * NCH * NCH / (ms2 * 1e-3),
+                                        "scaling": "weak", "collectives": "2 all-to-all forward + 2 backward (98 MB per rank each), "
+                                                                          "1 flat gradient all-reduce"},
+            "config5_chain_bins_all_gather": {"ms_per_step": round(ms5, 3), "bin_solves_per_s": 192001 / (ms5 * 1e-3),
+                                              "scaling": "strong", "collectives": "1 all-gather of the (1, 192001, 32) spectrum "
+                                                                                  "(49 MB), 1 flat gradient all-reduce"}}
 
 
 def main():
@@ -100,6 +265,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the input-gradient, secondary-workload and bin-sharded legs")
     ap.add_argument("--no-graph", action="store_true",
                     help="time eager steps instead of replaying the step from a HIP graph")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -136,20 +302,19 @@ def main():
     pending = []
 
     def sync_gradients():
-        """Data-parallel gradient sum: < 4 KB, one flat RCCL all-reduce per step, issued asynchronously (the
-        communicator's stream waits for the flattening copy; the next step does not wait for the collective,
-        as in DDP) -- every one of them is waited for inside the timed region's closing fence."""
-        flat = torch.cat([p.grad.reshape(-1) for p in params])
-        pending.append((dist.all_reduce(flat, async_op=True), flat))
-        while len(pending) > 4:                         # bounded queue: keep at most 4 collectives in flight
-            pending.pop(0)[0].wait()
+        """Data-parallel gradient sum: < 4 KB through one cached flat buffer and ONE RCCL all-reduce per step, issued
+        asynchronously (the next step does not wait for the collective, as in DDP); every one of them is waited for
+        inside the timed region's closing fence."""
+        from flamo_amd import dist as fd
+        pending.append(fd.all_reduce_grads(params, async_op=True))
+        while len(pending) > 2:                         # the flat buffer is shared: keep the queue short
+            pending.pop(0)()
 
     step = eager_step
+    gs = None
     if not args.no_graph:
-        # The step is ~30 launches of which a dozen carry the work: replaying it from a HIP graph takes
-        # the Python / launch overhead (0.1-0.2 ms per step once warm, and sensitive to host jitter) out
-        # of the loop.  Forward + backward are captured once; the tiny RCCL
-        # gradient all-reduce stays eager after each replay.
+        # forward + backward are captured once (torch.cuda.CUDAGraph) and replayed; the tiny RCCL gradient all-reduce
+        # stays eager after each replay
         from flamo_amd.graph import GraphedStep
         try:
             gs = GraphedStep(lambda xx: ops.mean_square(model(xx)), (x,), params, warmup=2)
@@ -174,72 +339,108 @@ def main():
 
     def fence():
         while pending:
-            pending.pop(0)[0].wait()
+            pending.pop(0)()
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     if args.no_graph:
-        # the timed eager steps carry HIP events around single launches: an event recorded behind a
-        # cross-stream wait would be stamped early (see the roofline leg below), so one stream only
-        from flamo_amd.processor import system as _sys
-        _sys.OVERLAP_RESPONSES = False
-        # one-off start-up costs of the eager path (allocator growth, a ~35 ms hiccup around the 8th step on
-        # a fresh process) belong to set-up like the graph capture does, not to the W warm-up steps
-        for _ in range(12):
+        for _ in range(12):          # allocator growth and first-launch costs belong to set-up, like the capture does
             step()
     for _ in range(args.warmup):
         step()
     fence()
-    ops.kernel_timer.reset(enabled=(rank == 0 and args.no_graph))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    ops.kernel_timer.enabled = False
     if dist_on:                     # max over ranks; before rank 0 goes on alone into the roofline leg
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    roof_steps = args.steps
-    if not args.no_graph and rank == 0:
-        # HIP events cannot be read back from inside a captured graph: the dominant kernel's launch
-        # time is taken with events on the launch stream in eager steps of the same workload, run by
-        # this same command right after the timed replays (rocprofv3 --stats sees both alike)
-        # (single stream for these steps: an event recorded behind a cross-stream wait is stamped
-        # before the wait resolves, which would add the side stream's tail to the kernel's time)
-        from flamo_amd.processor import system as _system
+
+    # ---- bin-sharded forms: every rank takes part (collectives), before rank 0 goes on alone
+    sharded = None
+    if dist_on and not args.no_extras and dtype == torch.float32:
+        try:
+            sharded = bin_sharded(dev, model, params, x, args.steps)
+        except Exception as e:      # noqa: BLE001 -- the headline line must survive a failure of a side leg
+            sharded = {"error": f"{type(e).__name__}: {e}"[:300]}
+        for p, g in zip(params, gs.grads if gs is not None else [None] * len(params)):
+            if g is not None:
+                p.grad = g           # the replay's static gradient tensors back in place
+
+    M = NFFT // 2 + 1
+    esz = 8 if dtype == torch.float32 else 16
+    products_per_step = 2 * BATCH * M * NCH * NCH * world   # two per-bin MIMO modules (Matrix, GEQ)
+    ms = elapsed / args.steps * 1e3
+    out = None
+    if rank == 0:
+        # ---- roofline leg: HIP events cannot be read back from inside a captured graph, so every hot kernel's launch
+        # time is taken with events on the launch stream in eager steps of the same workload, run by this same command
+        # right after the timed replays, each timed launch queued behind ~0.2 ms of streaming copies so that it starts
+        # from a busy queue (an event recorded on an idle stream is stamped at once and would add the host's launch
+        # latency to the kernel's time); rocprofv3 --kernel-trace of this command sees replays and eager steps alike
+        # (profiles/).  The copies also flush the 256 MB infinity cache, so these launch times are cache-cold: up to
+        # ~5 % above the replayed ones in the rocprofv3 trace.
         roof_steps = min(args.steps, 10)
-        overlap, _system.OVERLAP_RESPONSES = _system.OVERLAP_RESPONSES, False
-        ops.kernel_timer.reset(enabled=True, prefill_cycles=500_000)     # ~0.2 ms of queued streaming copies before each timed launch
+        ops.kernel_timer.reset(enabled=True, prefill_cycles=500_000)
         for _ in range(roof_steps):
             eager_step(sync_grads=False)        # rank 0 only: no collective in here
         torch.cuda.synchronize()
         ops.kernel_timer.enabled = False
-        _system.OVERLAP_RESPONSES = overlap
-
-    M = NFFT // 2 + 1
-    products_per_step = 2 * BATCH * M * NCH * NCH * world   # two per-bin MIMO modules (Matrix, GEQ)
-    ms = elapsed / args.steps * 1e3
-    if rank == 0:
-        esz = 8 if dtype == torch.float32 else 16
         timers = ops.kernel_timer.summary()
+        sig = esz * BATCH * M * NCH            # one (B, M, N) complex spectrum / scratch array, or a (B, T, N) real signal
+        hb = esz * M * NCH * NCH
+        alg = {   # algorithmic HBM bytes per launch
+            "spec_cols_fwd": 2 * sig,                                        # x in, scratch out (twice per step: fwd + bwd)
+            f"spec_mid[{NCH}->{NCH},H,inv,spec]": 3 * sig + hb,               # scratch in; spectrum (kept for backward), scratch out; H
+            f"spec_mid[{NCH}->{NCH},spec]": 2 * sig,                          # backward: scratch in, dL/dY out
+            "spec_cols_inv": 2 * sig,
+            f"mimo_gradh[cols={BATCH},{NCH}x{NCH}]": 2 * sig + hb,
+            "mean_square": sig, "mean_square_bwd": 2 * sig,
+            "sos_response_rc": 2 * hb, "sos_response_bwd_rc": 2 * hb,
+            f"mimo_bin_fwd[cols={BATCH},{NCH}x{NCH}]": 2 * sig + hb,
+        }
+        kernels = {}
+        for k, (n, mean_ms) in timers.items():
+            ent = {"launch_ms": round(mean_ms, 4), "launches_per_step": n // roof_steps}
+            if k in alg:
+                gbs = alg[k] / (mean_ms * 1e-3) / 1e9
+                ent.update(algorithmic_bytes=alg[k], GBs=round(gbs, 1), frac_hbm_peak=round(gbs / HBM_PEAK_GBS, 3))
+            kernels[k] = ent
+        traffic = None
+        try:
+            with open(PMC_FILE) as f:
+                traffic = json.load(f)
+        except Exception:           # noqa: BLE001 -- no profile committed yet
+            pass
         roof = None
-        key = f"mimo_bin_fwd[cols={BATCH},{NCH}x{NCH}]"      # the per-bin complex einsum over the full batch
+        key = f"spec_mid[{NCH}->{NCH},H,inv,spec]"
+        fused = key in timers
+        if not fused:
+            key = f"mimo_bin_fwd[cols={BATCH},{NCH}x{NCH}]"
         if key in timers:
             n, mean_ms = timers[key]
-            alg_bytes = esz * (BATCH * M * NCH + BATCH * M * NCH) + esz * M * NCH * NCH   # X + Y + H per launch
-            achieved = alg_bytes / (mean_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "mimo_full_kernel<float,8,4>: Y[b,f,:] = H[f] X[b,f,:] over the whole batch (the per-bin "
-                              "complex einsum fmn,bfn->bfm; H = GEQ[f] @ Matrix folded by the Series)",
+            achieved = alg[key] / (mean_ms * 1e-3) / 1e9
+            # the layered route moves these bytes for the same work: row pass of the forward transform (2 sig), the
+            # per-bin product (2 sig + H), pre-step/column pass of the inverse (2 sig)
+            layered = 6 * sig + hb
+            roof = {"bound": "hbm",
+                    "kernel": ("spec_mid<16,15,8,8>: forward row FFTs + real-FFT split step + per-bin complex einsum Y[b,f,:] = H[f] X[b,f,:] "
+                               "(H = GEQ[f] @ Matrix) + Hermitian pre-step + inverse row FFTs of one batch item's row pair, in one kernel"
+                               if fused else "mimo_full_kernel<float,8,4>: Y[b,f,:] = H[f] X[b,f,:] over the whole batch"),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": PMC_TRAFFIC_BYTES, "algorithmic_bytes": alg_bytes, "launch_ms": mean_ms, "launches": n,
-                    "events": "HIP events on the launch stream, " + ("inside the timed eager steps" if args.no_graph else
-                              f"{roof_steps} single-stream eager steps run by this command right after the timed graph replays, "
-                              "each timed launch queued behind ~0.2 ms of streaming copies so that it starts from a busy queue and memory system"),
-                    "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per "
-                                      "MI355X_MICROARCH.md; profiles/r01k_pmc_hbm_traffic.csv"}
+                    "traffic": (traffic or {}).get(key if fused else "mimo_full", {}).get("bytes_per_launch"),
+                    "algorithmic_bytes": alg[key], "launch_ms": mean_ms, "launches": n,
+                    "layered_route_bytes": layered if fused else None,
+                    "layered_route_equivalent_GBs": (layered / (mean_ms * 1e-3) / 1e9) if fused else None,
+                    "events": f"HIP events on the launch stream, {roof_steps} eager steps run by this command right after the timed graph "
+                              "replays, each timed launch queued behind ~0.2 ms of streaming copies (busy queue, cold infinity cache)",
+                    "traffic_source": (traffic or {}).get("source", "no PMC profile committed for this kernel yet")}
+        unfused_bytes = (2 * sig + hb) + (3 * sig + 2 * hb) + (2 * sig) + (3 * sig)      # GEQ fwd/bwd + Matrix fwd/bwd
+        fused_bytes = sum(alg.get(k, 0) * v["launches_per_step"] for k, v in kernels.items())
         out = {"metric": "freq-bin*channel products/sec (fwd+bwd), nfft=96000 8x8ch", "value": products_per_step / (ms * 1e-3),
                "unit": "products/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -251,12 +452,52 @@ def main():
                           "nfft": NFFT, "channels": NCH, "batch_per_gpu": BATCH, "parallelism": f"dp{world} (batch)",
                           "input_grad": False},
                "roofline": roof,
-               "kernel_ms": {k: round(v[1], 4) for k, v in timers.items()}}
+               "step_roofline": {"unfused_bytes_per_step": unfused_bytes, "unfused_floor_ms": unfused_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                                 "frac_of_unfused_floor": unfused_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 / ms,
+                                 "pipeline_bytes_per_step": fused_bytes, "pipeline_floor_ms": fused_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                                 "frac_of_pipeline_floor": fused_bytes / (HBM_PEAK_GBS * 1e9) * 1e3 / ms,
+                                 "note": "unfused = the einsum passes of SURVEY 8-d3 alone (1.057 GB); pipeline = every streaming "
+                                         "pass of the step as built (transforms, product, objective, gradients)"},
+               "kernels": kernels}
+        if sharded is not None:
+            out["bin_sharded"] = sharded
+        if not args.no_extras and dtype == torch.float32:
+            try:
+                out["input_grad"] = input_grad_leg(model, params, x, args.steps, products_per_step // world)
+            except Exception as e:  # noqa: BLE001
+                out["input_grad"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:
+                out["secondary"] = secondary(dev)
+            except Exception as e:  # noqa: BLE001
+                out["secondary"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            out["device"] = device_info(dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params[0], params[1])
         print(json.dumps(out))
     if dist_on:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def input_grad_leg(model, params, x, steps, products):
+    """The same step with the gradient of the input as well (SURVEY 8-d1 "+ input"): the backward then runs the
+    adjoint product and the inverse half of the pipeline too."""
+    from flamo_amd import ops
+    xg = x.detach().clone().requires_grad_(True)
+    saved = [p.grad for p in params]
+    from flamo_amd.graph import GraphedStep      # differentiates with respect to `params`: the input joins them
+    gs = GraphedStep(lambda xx: ops.mean_square(model(xg)), (x,), list(params) + [xg], warmup=2)
+    for _ in range(3):
+        gs.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gs.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    for p, g in zip(params, saved):
+        p.grad = g
+    return {"ms_per_step": round(ms, 4), "products_per_s": products / (ms * 1e-3), "input_grad": True}
 
 
 if __name__ == "__main__":

@@ -107,23 +107,167 @@ def take_local_bins(X: torch.Tensor, group=None) -> torch.Tensor:
     return X[:, bin0:bin0 + m_local]
 
 
-def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None) -> None:
-    """Sum the gradients of replicated parameters over ranks with ONE flat all-reduce."""
+_flat_cache = {}
+
+
+def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op: bool = False):
+    """Sum the gradients of replicated parameters over ranks with ONE flat all-reduce per dtype, through a flat
+    buffer that is allocated once per parameter set (no cat / cast / per-parameter temporaries per step): the gradients
+    are copied into views of the buffer (one multi-tensor copy), reduced in place, and copied back.
+    async_op: returns a callable that waits for the collective and copies the sums back (call it before the
+    gradients are read); None otherwise."""
     ps = [p for p in params if p.grad is not None]
     if not ps:
-        return
-    flat = torch.cat([p.grad.reshape(-1).to(torch.float64) for p in ps])
-    if _host_staged(flat, group):
-        host = flat.cpu()
-        dist.all_reduce(host, group=group)
-        flat = host.to(flat.device)
-    else:
-        dist.all_reduce(flat, group=group)
-    off = 0
+        return (lambda: None) if async_op else None
+    by_dtype = {}
     for p in ps:
-        n = p.grad.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad).to(p.grad.dtype))
-        off += n
+        by_dtype.setdefault(p.grad.dtype, []).append(p)
+    pending = []
+    for dt, plist in by_dtype.items():
+        key = (dt, plist[0].grad.device, tuple(p.grad.numel() for p in plist))
+        ent = _flat_cache.get(key)
+        if ent is None:
+            flat = torch.empty(sum(key[2]), dtype=dt, device=key[1])
+            views, off = [], 0
+            for n in key[2]:
+                views.append(flat[off:off + n])
+                off += n
+            ent = _flat_cache[key] = (flat, views)
+        flat, views = ent
+        grads = [p.grad.reshape(-1) for p in plist]
+        torch._foreach_copy_(views, grads)
+        if _host_staged(flat, group):
+            host = flat.cpu()
+            dist.all_reduce(host, group=group)
+            flat.copy_(host)
+            work = None
+        else:
+            work = dist.all_reduce(flat, group=group, async_op=async_op)
+        pending.append((work, views, plist))
+
+    def finish():
+        for work, views, plist in pending:
+            if work is not None:
+                work.wait()
+            dst, src = [], []
+            for p, v in zip(plist, views):
+                if p.grad.is_contiguous():
+                    dst.append(p.grad.view(-1))
+                    src.append(v)
+                else:
+                    p.grad.copy_(v.view_as(p.grad))
+            if dst:
+                torch._foreach_copy_(dst, src)
+
+    if async_op:
+        return finish
+    finish()
+    return None
+
+
+# ----------------------------------------------------------------------------- batch-sharded <-> bin-sharded spectra
+def _split_sizes(M: int, world: int):
+    return [shard_bins(M, r, world)[1] for r in range(world)]
+
+
+class _BatchToBins(torch.autograd.Function):
+    """(B_local, M, rest...) on every rank (batch-sharded, all bins) -> (B_local * world, m_local, rest...) (all batch
+    items, this rank's bins): one all-to-all.  Backward: the opposite exchange."""
+
+    @staticmethod
+    def forward(ctx, X, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        Bl, M = X.shape[0], X.shape[1]
+        rest = tuple(X.shape[2:])
+        sizes = _split_sizes(M, world)
+        ctx.meta = (Bl, M, rest, sizes, group)
+        # send block q: my batch items, rank q's bins, laid out (m_q, Bl, rest...) so that blocks concatenate along dim 0
+        send = X.movedim(1, 0).contiguous()                                # (M, Bl, rest...)
+        recv = torch.empty((sizes[rank] * world, Bl, *rest), dtype=X.dtype, device=X.device)
+        _all_to_all(recv, send, [sizes[rank]] * world, sizes, group)
+        # recv: world blocks (m_local, Bl, rest...) -> (world*Bl, m_local, rest...)
+        out = recv.view(world, sizes[rank], Bl, *rest).movedim(1, 2).reshape(world * Bl, sizes[rank], *rest)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Bl, M, rest, sizes, group = ctx.meta
+        return _bins_to_batch(g, Bl, M, rest, sizes, group), None
+
+
+def _bins_to_batch(Y, Bl, M, rest, sizes, group):
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ml = sizes[rank]
+    send = Y.reshape(world, Bl, ml, *rest).movedim(2, 1).contiguous().view(world * ml, Bl, *rest)   # block q: batch items of rank q
+    recv = torch.empty((M, Bl, *rest), dtype=Y.dtype, device=Y.device)
+    _all_to_all(recv, send, sizes, [ml] * world, group)
+    return recv.movedim(0, 1)                                                # (Bl, M, rest...)
+
+
+class _BinsToBatch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Y, M, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        sizes = _split_sizes(M, world)
+        Bl = Y.shape[0] // world
+        rest = tuple(Y.shape[2:])
+        ctx.meta = group
+        return _bins_to_batch(Y, Bl, M, rest, sizes, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _BatchToBins.apply(g, ctx.meta), None, None
+
+
+def _all_to_all(recv, send, recv_splits, send_splits, group):
+    cplx = send.is_complex()
+    s = torch.view_as_real(send) if cplx else send
+    r = torch.view_as_real(recv) if cplx else recv
+    if dist.get_backend(group) == "gloo":
+        # gloo has no all_to_all_single on every build: pairwise through all_gather of the split tables is overkill for a
+        # test transport -- emulate with point-to-point lists (host memory)
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        sh = s.cpu() if s.is_cuda else s
+        outs = list(torch.split(torch.empty((sum(recv_splits), *sh.shape[1:]), dtype=sh.dtype), recv_splits))
+        ins = list(torch.split(sh, send_splits))
+        reqs = []
+        for q in range(world):
+            if q == rank:
+                outs[q].copy_(ins[q])
+            else:
+                reqs.append(dist.isend(ins[q].contiguous(), q, group=group))
+        for q in range(world):
+            if q != rank:
+                dist.recv(outs[q], q, group=group)
+        for w in reqs:
+            w.wait()
+        r.copy_(torch.cat(outs).to(r.device))
+    else:
+        dist.all_to_all_single(r, s, recv_splits, send_splits, group=group)
+
+
+def batch_to_bins(X: torch.Tensor, group=None) -> torch.Tensor:
+    """Batch-sharded spectrum (B_local, M, ...) -> bin-sharded (B_local * world, m_local, ...) (differentiable)."""
+    return _BatchToBins.apply(X, group)
+
+
+def bins_to_batch(Y: torch.Tensor, M: int, group=None) -> torch.Tensor:
+    """Bin-sharded (B_local * world, m_local, ...) -> batch-sharded (B_local, M, ...) (differentiable)."""
+    return _BinsToBatch.apply(Y, M, group)
+
+
+def bin_exchange_forward(shell, x: torch.Tensor, group=None) -> torch.Tensor:
+    """``shell(x)`` for a batch-sharded input with the core evaluated bin-sharded (large-batch form):
+    local input transform of this rank's batch items -> all-to-all into bin shards (every rank: all batch items, its
+    own bins) -> core on the local bins with locally generated responses -> all-to-all back -> local inverse
+    transform.  Two data-path collectives per direction; parameters replicated."""
+    X = shell.get_inputLayer()(x)
+    M = X.shape[1]
+    Xb = batch_to_bins(X, group)
+    with bin_shard(shell.nfft, dist.get_rank(group), dist.get_world_size(group)):
+        Yb = shell.get_core()(Xb)
+    Y = bins_to_batch(Yb, M, group)
+    return shell.get_outputLayer()(Y)
 
 
 def sharded_forward(shell, x: torch.Tensor, group=None) -> torch.Tensor:

@@ -760,8 +760,9 @@ def _solve_launch(Pp, one_minus, adjoint, R):
     _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
     L = _lib.lib()
     fn = L.fl_solve_c64 if real == torch.float32 else L.fl_solve_c128
-    _lib.check(fn(Pp.data_ptr(), _lead_pitch(Pp.movedim(0, -1)), int(one_minus), int(adjoint), R.data_ptr(), rs_b, rs_n,
-                  rs_k, OUT.data_ptr(), os_b, os_n, os_k, B, M, N, K, _stream()), "solve")
+    with kernel_timer.span("solve_adj" if adjoint else "solve"):
+        _lib.check(fn(Pp.data_ptr(), _lead_pitch(Pp.movedim(0, -1)), int(one_minus), int(adjoint), R.data_ptr(), rs_b, rs_n,
+                      rs_k, OUT.data_ptr(), os_b, os_n, os_k, B, M, N, K, _stream()), "solve")
     return OUT
 
 
@@ -822,8 +823,9 @@ def _solve_dud_launch(l, U, r, adjoint, R):
     fn = L.fl_solve_dud_c64 if real == torch.float32 else L.fl_solve_dud_c128
     lp, l_sn, l_sf = _diag_args(l)
     rp, r_sn, r_sf = _diag_args(r)
-    _lib.check(fn(lp, l_sn, l_sf, U.data_ptr(), rp, r_sn, r_sf, int(adjoint), R.data_ptr(), rs_b, rs_n, rs_k,
-                  OUT.data_ptr(), os_b, os_n, os_k, B, M, N, K, _stream()), "solve_dud")
+    with kernel_timer.span("solve_dud_adj" if adjoint else "solve_dud"):
+        _lib.check(fn(lp, l_sn, l_sf, U.data_ptr(), rp, r_sn, r_sf, int(adjoint), R.data_ptr(), rs_b, rs_n, rs_k,
+                      OUT.data_ptr(), os_b, os_n, os_k, B, M, N, K, _stream()), "solve_dud")
     return OUT
 
 

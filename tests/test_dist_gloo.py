@@ -47,7 +47,25 @@ def _worker(rank, world, port, M, results):
             ok_ctx = ops.bin_shard(2 * (M - 1)) == (b0, ml) == (bin0, m_local)
         ok_ctx = ok_ctx and ops.bin_shard(2 * (M - 1)) == (0, M)
         rl = fd.all_gather_bins(full.real[:, bin0:bin0 + m_local].contiguous(), M)
-        results[rank] = bool(ok_fwd and ok_bwd and ok_red and ok_ctx and torch.equal(rl, full.real))
+        # batch-sharded <-> bin-sharded exchange (all-to-all both ways) with autograd
+        Bl = 2
+        torch.manual_seed(1)
+        glob = torch.randn(world * Bl, M, 3, dtype=torch.complex128)          # the global batch, known to both ranks
+        mine = glob[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
+        xb = fd.batch_to_bins(mine)
+        ok_x = xb.shape == (world * Bl, m_local, 3) and torch.equal(xb, glob[:, bin0:bin0 + m_local])
+        back = fd.bins_to_batch(xb * 2.0, M)
+        ok_x = ok_x and torch.equal(back, 2.0 * mine)
+        wgt = torch.randn(Bl, M, 3, dtype=torch.complex128)
+        (gm,) = torch.autograd.grad(torch.sum(torch.real(back * torch.conj(wgt))), [mine])
+        ok_x = ok_x and torch.allclose(gm, 2.0 * wgt)
+        # asynchronous gradient all-reduce through the cached flat buffer, twice (buffer reuse)
+        for rep in range(2):
+            p.grad = torch.full((5,), float(rank + 1 + rep))
+            fin = fd.all_reduce_grads([p], async_op=True)
+            fin()
+            ok_red = ok_red and torch.allclose(p.grad, torch.full((5,), float(sum(r + 1 + rep for r in range(world)))))
+        results[rank] = bool(ok_fwd and ok_bwd and ok_red and ok_ctx and ok_x and torch.equal(rl, full.real))
     finally:
         dist.destroy_process_group()
 

@@ -721,4 +721,16 @@ def test_bench_contract_line(gpu):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.2 < r["frac"] < 1.0
     assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
-    assert r["traffic"] >= r["algorithmic_bytes"]
+    assert r["algorithmic_bytes"] == 3 * 8 * 32 * M * 8 + 8 * M * 64      # scratch in, spectrum + scratch out, H
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes"]
+    sr = d["step_roofline"]
+    assert abs(sr["unfused_bytes_per_step"] - 1.057e9) < 2e6 and 0 < sr["frac_of_unfused_floor"] < 1
+    assert sr["pipeline_bytes_per_step"] > sr["unfused_bytes_per_step"]
+    for k in ("spec_cols_fwd", "spec_cols_inv", "spec_mid[8->8,H,inv,spec]", "mimo_gradh[cols=32,8x8]"):
+        assert 0.1 < d["kernels"][k]["frac_hbm_peak"] < 1.0, k
+    assert d["input_grad"]["ms_per_step"] > d["ms_per_step"]
+    sec = d["secondary"]
+    for k in ("config3_fdn16_batch1", "config3_fdn16_batch8", "config4_colorless_training", "config5_chain_32x32"):
+        assert sec[k]["ms_per_step"] > 0 and sec[k]["bin_solves_per_s"] > 0, k
+    assert 0 < sec["config3_fdn16_batch1"]["solve"]["frac_fp32_vector_peak"] < 1
+    assert d["device"]["hbm_copy_probe_GBs"] > 1000
