@@ -69,6 +69,7 @@ _SIGNATURES = {
     "fl_sos_response_bwd_rc_c64": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _d, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "fl_geq_sections": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fl_geq_sections_bwd": (_i, [_vp, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp]),
+    "fl_geq_sections_bwd_w": (_i, [_vp, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "fl_solve_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_dud_c64": (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),

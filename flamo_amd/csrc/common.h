@@ -37,10 +37,13 @@ template <typename T> __host__ __device__ inline void fma_cxc(cx<T>& acc, cx<T> 
     acc.x += a.x * b.x + a.y * b.y;
     acc.y += a.y * b.x - a.x * b.y;
 }
-// ---- float: the same operators on 2-element vectors, so that they become packed instructions (v_pk_add_f32 /
+#ifdef FL_PACKED_COMPLEX
+// ---- float: the same operators on 2-element vectors (opt-in: the transform kernels define FL_PACKED_COMPLEX), so that they become packed instructions (v_pk_add_f32 /
 // v_pk_mul_f32 / v_pk_fma_f32, two floats per lane per issue slot) with the swizzles and sign flips of complex
 // arithmetic as operand selectors; written with scalars the compiler packs about half of them and pays for the
-// other half with register shuffles (v_mov was a fifth of the FFT kernels' instructions)
+// other half with register shuffles (v_mov was a fifth of the FFT kernels' instructions).  Not for the ALU-bound
+// kernels (solves, cascades): a packed FMA has the throughput of two scalar ones on this part, and the sign flips cost
+// extra instructions there (the N = 32 solve went 1.95 -> 3.1 ms with these operators).
 typedef float f2 __attribute__((ext_vector_type(2)));
 __host__ __device__ inline f2 v2(cx<float> a) { return f2{a.x, a.y}; }
 __host__ __device__ inline cx<float> c2(f2 v) { return cx<float>(v.x, v.y); }
@@ -57,11 +60,12 @@ __host__ __device__ inline cx<float> mulc(cx<float> a, cx<float> b) {     // a *
 }
 // (the accumulating products acc += a*b keep the scalar form: four v_fma_f32 with no operand shuffles -- a packed
 // FMA has the throughput of two scalar ones on this part, and its sign flip costs an extra instruction)
-// acc + s*a (real s)
-template <typename T> __host__ __device__ inline cx<T> axpy(T s, cx<T> a, cx<T> acc) { return cx<T>(acc.x + s * a.x, acc.y + s * a.y); }
-__host__ __device__ inline cx<float> axpy(float s, cx<float> a, cx<float> acc) {
+__host__ __device__ inline cx<float> axpy(float s, cx<float> a, cx<float> acc) {     // acc + s*a (real s)
     return c2(__builtin_elementwise_fma(f2{s, s}, v2(a), v2(acc)));
 }
+#endif
+// acc + s*a (real s)
+template <typename T> __host__ __device__ inline cx<T> axpy(T s, cx<T> a, cx<T> acc) { return cx<T>(acc.x + s * a.x, acc.y + s * a.y); }
 
 template <typename T> __host__ __device__ inline cx<T> mul_i(cx<T> a) { return cx<T>(-a.y, a.x); }     // i*a
 template <typename T> __host__ __device__ inline cx<T> mul_mi(cx<T> a) { return cx<T>(a.y, -a.x); }    // -i*a

@@ -17,6 +17,7 @@
 //
 // The anti-alias envelope gamma^-t of FFTAntiAlias / iFFTAntiAlias (dsp.py:158-162,201-205)
 // is applied in the loader / epilogue (no separate pass).
+#define FL_PACKED_COMPLEX 1
 #include "common.h"
 #include "regfft.h"
 

@@ -430,7 +430,8 @@ static int launch_mfma(MmaArgs a, hipStream_t st, int red_slots = 0, int* slots_
 // ---------------------------------------------------------------- host dispatch
 static int g_mimo_variant = 0;   // tuning hook: mt*100 + bt*10 + nu (0 = default choice)
 
-static int g_mimo_hc = 1;   // tuning: 0 = constant matrices through the per-bin addressing (gradw_cap -4)
+static int g_mimo_hc = 1;
+static int g_gradh_tile = 4;   // 4 = 4x4 tiles (default), 84 = 8x4, 8 = 8x8 where the matrix allows (tuning hook)   // tuning: 0 = constant matrices through the per-bin addressing (gradw_cap -4)
 
 template <typename T, int MT, int BT, int NU>
 static void launch_full_one(dim3 grid, int nct, int nmt, hipStream_t st, const cx<T>* H, long hs_f, long hs_m, long hs_n, int conj_h,
@@ -530,7 +531,21 @@ static int gradh_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
             return launch_mfma(a, st);
         }
     }
-    if (No >= 4 && Ni >= 4) {
+    // Larger register tiles read G and X once per bin instead of once per 4x4 tile (config 2: 326 -> 221 MB of fabric
+    // traffic per launch) -- and measure SLOWER: 4x4 65 us, 8x4 68 us, 8x8 88 us (tools/dbg/gradh_tile.py, cold caches):
+    // the second read of a 4x4 tile comes from the L2, while 64 / 128 accumulator registers cost occupancy.  Kept
+    // behind the tuning hook.
+    if (sizeof(T) == 4 && No >= 8 && Ni >= 8 && g_gradh_tile != 4) {
+        const int tn = g_gradh_tile == 84 ? 4 : 8;
+        dim3 grid(cdiv_i(M, 256), cdiv_i(No, 8), cdiv_i(Ni, tn));
+        FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradh: too many channels");
+        if (tn == 8)
+            hipLaunchKernelGGL((mimo_gradh_kernel<T, 8, 8>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
+                               (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K);
+        else
+            hipLaunchKernelGGL((mimo_gradh_kernel<T, 8, 4>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
+                               (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K);
+    } else if (No >= 4 && Ni >= 4) {
         dim3 grid(cdiv_i(M, 256), cdiv_i(No, 4), cdiv_i(Ni, 4));
         FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradh: too many channels");
         hipLaunchKernelGGL((mimo_gradh_kernel<T, 4, 4>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
@@ -705,6 +720,7 @@ int fl_debug_set_mimo_variant(int variant, int gradw_cap) {
     g_mimo_variant = variant;
     g_mfma_vec = gradw_cap != -2;          // gradw_cap -2: direct stores in the MFMA kernels
     g_mimo_hc = gradw_cap != -4;
+    g_gradh_tile = gradw_cap == -88 ? 8 : (gradw_cap == -84 ? 84 : 4);
     if (gradw_cap < 0) gradw_cap = 0;
     g_gradw_cap = gradw_cap;
     return FL_OK;

@@ -559,11 +559,26 @@ __global__ void __launch_bounds__(256) geq_sections_kernel(const void* __restric
 // gb / ga: (nblk, 3, nb, C) partial sums blk_stride elements apart (nblk = 1: plain gradients);
 // summed here in block order, so the bin-block partials of the cascade backward need no separate
 // reduction launch.
+// The launch can carry a second small reduction in its tail blocks (wrows > 0): gW[e] = sum over wrows rows of
+// partW[row * wn + e] -- the constant factor's gradient partials of the fused Matrix-then-GEQ operator -- one wavefront
+// per entry (lanes stride over the rows, fixed butterfly: deterministic); a launch of its own costs more than the sum.
 __global__ void __launch_bounds__(256) geq_sections_bwd_kernel(const void* __restrict__ gain, int in_kind,
                                                               const double* __restrict__ gb,
                                                               const double* __restrict__ ga, long blk_stride, int nblk,
                                                               int nb, int C, const double* __restrict__ k,
-                                                              void* __restrict__ ggain) {
+                                                              void* __restrict__ ggain, int main_blocks,
+                                                              const float* __restrict__ partW, int wrows, int wn,
+                                                              float* __restrict__ gW) {
+    if ((int)blockIdx.x >= main_blocks) {
+        const int e = ((int)blockIdx.x - main_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (e >= wn) return;
+        float v = 0.f;
+        for (int r = lane; r < wrows; r += 64) v += partW[(size_t)r * wn + e];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) gW[e] = v;
+        return;
+    }
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= nb * C) return;
     const int band = idx / C;
@@ -766,10 +781,22 @@ int fl_geq_sections_bwd(const void* gain, int in_kind, const void* gb, const voi
     FL_REQUIRE(gain && gb && ga && consts && ggain, "geq_sections_bwd: null pointer");
     FL_REQUIRE(in_kind >= 0 && in_kind <= 2, "geq_sections_bwd: bad in_kind");
     FL_REQUIRE(nb >= 4 && C > 0 && nblk >= 1 && blk_stride >= 0, "geq_sections_bwd: bad sizes");
-    hipLaunchKernelGGL(geq_sections_bwd_kernel, dim3(cdiv_i((long)nb * C, 256)), dim3(256), 0, (hipStream_t)stream,
+    const int mb = cdiv_i((long)nb * C, 256);
+    hipLaunchKernelGGL(geq_sections_bwd_kernel, dim3(mb), dim3(256), 0, (hipStream_t)stream,
                        gain, in_kind, (const double*)gb, (const double*)ga, blk_stride, nblk, nb, C,
-                       (const double*)consts, ggain);
+                       (const double*)consts, ggain, mb, (const float*)nullptr, 0, 0, (float*)nullptr);
     FL_CHECK_LAUNCH("geq_sections_bwd");
+    return FL_OK;
+}
+int fl_geq_sections_bwd_w(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
+                          int C, const void* consts, void* ggain, const void* partW, int wrows, int wn, void* gW, void* stream) {
+    FL_REQUIRE(gain && gb && ga && consts && ggain && partW && gW, "geq_sections_bwd_w: null pointer");
+    FL_REQUIRE(nb >= 4 && C > 0 && nblk > 0 && in_kind >= 0 && in_kind <= 2 && wrows > 0 && wn > 0, "geq_sections_bwd_w: bad sizes");
+    const int mb = cdiv_i((long)nb * C, 256);
+    hipLaunchKernelGGL(geq_sections_bwd_kernel, dim3(mb + cdiv_i(wn, 4)), dim3(256), 0, (hipStream_t)stream,
+                       gain, in_kind, (const double*)gb, (const double*)ga, blk_stride, nblk, nb, C,
+                       (const double*)consts, ggain, mb, (const float*)partW, wrows, wn, (float*)gW);
+    FL_CHECK_LAUNCH("geq_sections_bwd_w");
     return FL_OK;
 }
 int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,

@@ -20,6 +20,7 @@
 // Against the layered route (layout conversion, two FFT passes, product, two inverse passes) the (B, M, N)
 // spectrum is never written and re-read between the transforms and the product: 6 passes over the data
 // instead of 11.  The same three kernels run the backward pass (irfft' = weighted rfft, rfft' = weighted irfft).
+#define FL_PACKED_COMPLEX 1
 #include "common.h"
 #include "regfft.h"
 #include <type_traits>
@@ -251,6 +252,7 @@ struct MidArgs {
     float spec_scale;     // scale of the forward transform
     int spec_interior2;   // double the interior bins of the spectrum (irfft backward)
     int pre_half;         // halve the interior bins in front of the inverse transform (rfft backward)
+    int dbg_hfake;        // tuning: every bin reads the first 64 bins' response (cache-resident) -- isolates the fetch cost
 };
 
 // bin pair (k, L-k) number p of primary row r: where the partner sits (slot, column); false when p owns no pair
@@ -415,10 +417,11 @@ __global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
                 if (HAS_H) {
                     // plane (m, n) as a workgroup-uniform base (scalar arithmetic), the bin as the lane's 32-bit offset
                     const cf* Hm = a.H + (size_t)__builtin_amdgcn_readfirstlane(m) * a.hs_m;
+                    const unsigned hoff_k = a.dbg_hfake ? 8u * (ik & 63u) : 8u * ik, hoff_m = a.dbg_hfake ? 8u * (im & 63u) : 8u * im;
 #pragma unroll
                     for (int nn = 0; nn < NI; ++nn) {
-                        hkv[nn] = at(Hm + (size_t)nn * a.hs_n, 8u * ik);
-                        hmv[nn] = at(Hm + (size_t)nn * a.hs_n, 8u * im);
+                        hkv[nn] = at(Hm + (size_t)nn * a.hs_n, hoff_k);
+                        hmv[nn] = at(Hm + (size_t)nn * a.hs_n, hoff_m);
                         if (a.conj_h) {
                             hkv[nn].y = -hkv[nn].y;
                             hmv[nn].y = -hmv[nn].y;
@@ -589,7 +592,7 @@ static int cols_launch(bool inverse, const ColsArgs& a, int Bn, hipStream_t st) 
     return FL_OK;
 }
 
-static int g_mid_bg = 1;
+static int g_mid_bg = 1, g_mid_hfake = 0;
 
 template <int A, int B, int NI, int NO, int BG, int MS>
 static void launch_mid_bg(const MidArgs& a, hipStream_t st) {
@@ -654,7 +657,8 @@ int fl_spec_supports(int nfft, int n_in, int n_out) {
 int fl_debug_set_spec(int vt, int rg) {
     g_spec_vt = (vt == 16) ? 16 : 32;
     g_spec_rg = (rg % 100 == 1 || rg % 100 == 4) ? rg % 100 : 2;
-    g_mid_bg = (rg >= 100) ? (rg / 100) % 10 : 1;     // rg = 100*(2: two batch items per workgroup) + load group
+    g_mid_bg = (rg >= 100) ? (rg / 100) % 10 : 1;
+    g_mid_hfake = rg >= 1000;     // rg = 100*(2: two batch items per workgroup) + load group
     return FL_OK;
 }
 
@@ -702,7 +706,7 @@ int fl_spec_mid_f32(const void* S, void* S2, void* Xs, long xs_b, long xs_n, con
     a.S = (const cf*)S; a.S2 = (cf*)S2; a.Xs = (cf*)Xs; a.xs_b = xs_b; a.xs_n = xs_n;
     a.H = (const cf*)H; a.hs_m = hs_m; a.hs_n = hs_n; a.conj_h = conj_h;
     a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn;
-    a.spec_scale = (float)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half;
+    a.spec_scale = (float)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half; a.dbg_hfake = g_mid_hfake;
     const int P = a.L1 / 2 + 1;
     const size_t nblk = (size_t)cdiv_i(P, 8) * 8 * Bn;
     FL_REQUIRE(nblk < (1ull << 31), "spec_mid: grid too large");

@@ -1077,7 +1077,7 @@ def _cascade_rc_backward(gH, G, b, a, Wr, cfg):
                                                 b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni, Wc.data_ptr(), gamma,
                                                 twiddles(nfft, torch.float64, b.device).data_ptr(), nfft, bin0, m_local,
                                                 part.data_ptr(), partW.data_ptr(), _stream()), "sos_response_bwd_rc")
-    return part, partW.sum(dim=(0, 1))
+    return part, partW
 
 
 class _SosRC(torch.autograd.Function):
@@ -1096,9 +1096,9 @@ class _SosRC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gH):
         bc, ac, G, Wr = ctx.saved_tensors
-        part, gW = _cascade_rc_backward(gH, G, bc, ac, Wr, ctx.cfg)
+        part, partW = _cascade_rc_backward(gH, G, bc, ac, Wr, ctx.cfg)
         tot = part.sum(dim=0)
-        return tot[0].view(bc.shape), tot[1].view(ac.shape), gW.to(Wr.dtype), None, None, None
+        return tot[0].view(bc.shape), tot[1].view(ac.shape), partW.sum(dim=(0, 1)).to(Wr.dtype), None, None, None
 
 
 class _GeqCascadeRC(torch.autograd.Function):
@@ -1123,17 +1123,20 @@ class _GeqCascadeRC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gH):
         xc, consts, b, a, G, Wr = ctx.saved_tensors
-        part, gW = _cascade_rc_backward(gH, G, b, a, Wr, ctx.cfg)
+        part, partW = _cascade_rc_backward(gH, G, b, a, Wr, ctx.cfg)
         nblk = part.shape[0]
         nb = xc.shape[0]
         C_ = max(_prod(xc.shape[1:]), 1)
         st = nb * C_
         out = torch.empty_like(xc)
+        gW = torch.empty_like(Wr, memory_format=torch.contiguous_format)
         esz = part.element_size()
-        _lib.check(_lib.lib().fl_geq_sections_bwd(xc.data_ptr(), _geq_in_kind(xc, True), part.data_ptr(),
-                                                  part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
-                                                  out.data_ptr(), _stream()), "geq_sections_bwd")
-        return out, None, gW.to(Wr.dtype), None, None, None
+        # design backward (sums the bin-block partials) + the constant factor's partials, one launch
+        _lib.check(_lib.lib().fl_geq_sections_bwd_w(xc.data_ptr(), _geq_in_kind(xc, True), part.data_ptr(),
+                                                    part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
+                                                    out.data_ptr(), partW.data_ptr(), partW.shape[0] * partW.shape[1],
+                                                    partW.shape[2] * partW.shape[3], gW.data_ptr(), _stream()), "geq_sections_bwd_w")
+        return out, None, gW, None, None, None
 
 
 def sos_response_rc(b, a, Wr, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:

@@ -277,6 +277,11 @@ int fl_sos_response_bwd_rc_c64(const void* gHfull, long g_pitch, const void* G, 
 int fl_geq_sections(const void* gain, int in_kind, int nb, int C, const void* consts, void* b, void* a, void* stream);
 int fl_geq_sections_bwd(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
                         int C, const void* consts, void* ggain, void* stream);
+/* fl_geq_sections_bwd with a second small reduction in the same launch: gW[e] = sum_r partW[r*wn + e], r < wrows,
+ * e < wn (float) -- the partials fl_sos_response_bwd_rc_c64 leaves for the constant factor's gradient (wrows =
+ * blocks * No, wn = Nmid * Ni). */
+int fl_geq_sections_bwd_w(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
+                          int C, const void* consts, void* ggain, const void* partW, int wrows, int wn, void* gW, void* stream);
 
 /* ------------------------------------------------------------------ closed loop
  * Replace torch.linalg.solve(A, B) in system.Recursion.forward (system.py:420-425).

@@ -55,7 +55,7 @@ for with_x in (False, True):
 # ---- mid-kernel variants (tuning): response-row prefetch modes, no-response floor
 S = ops._spec_cols_fwd(x, nfft, 0.0)
 Hp = ops._h_planar(H.detach(), True)
-for pf in (1, 3, 2):
+for pf in (1, 11):
     _lib.lib().fl_debug_set_spec(args.vt, 100 * pf + args.rg)
     for _ in range(3):
         ops._spec_mid(S.clone(), B, N, N, nfft, Hp, False, True, True, 1.0, 0, 0)
