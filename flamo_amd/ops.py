@@ -13,6 +13,7 @@ pass over (B, M, ...) data is one of the HIP kernels.
 from __future__ import annotations
 
 import math
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -36,6 +37,10 @@ def _require_gpu(*ts: torch.Tensor) -> torch.device:
         dev = t.device if dev is None else dev
         if t.device != dev:
             raise RuntimeError("flamo_amd: tensors on different devices")
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        # the launches go to the CURRENT device's stream: foreign pointers there are a fault or a silent mis-ordering
+        raise RuntimeError(f"flamo_amd: tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "wrap the call in `with torch.cuda.device(...)`")
     return dev
 
 
@@ -69,18 +74,37 @@ def _prod(xs) -> int:
 
 
 _twiddles = {}
+_twiddles_lock = threading.Lock()
 
 
 def twiddles(nfft: int, real: torch.dtype, device: torch.device) -> torch.Tensor:
-    """Master table W[j] = exp(-2 pi i j / nfft), cached per (nfft, precision, device)."""
+    """Master table W[j] = exp(-2 pi i j / nfft), cached per (nfft, precision, device).  The table is filled on
+    whichever stream asks first; a consumer on ANOTHER stream waits for the fill's event (first forward pass: the
+    input transform fills the table on the main stream while a response generator reads it on the side stream)."""
     key = (int(nfft), real, device.index if device.index is not None else torch.cuda.current_device())
-    W = _twiddles.get(key)
-    if W is None:
-        W = torch.empty(nfft, dtype=_cdtype(real), device=device)
-        L = _lib.lib()
-        fn = L.fl_twiddle_fill_f32 if real == torch.float32 else L.fl_twiddle_fill_f64
-        _lib.check(fn(W.data_ptr(), nfft, _stream()), "twiddle_fill")
-        _twiddles[key] = W
+    ent = _twiddles.get(key)
+    if ent is None:
+        with _twiddles_lock:
+            ent = _twiddles.get(key)
+            if ent is None:
+                W = torch.empty(nfft, dtype=_cdtype(real), device=device)
+                L = _lib.lib()
+                fn = L.fl_twiddle_fill_f32 if real == torch.float32 else L.fl_twiddle_fill_f64
+                cur = torch.cuda.current_stream(device)
+                _lib.check(fn(W.data_ptr(), nfft, cur.cuda_stream), "twiddle_fill")
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                ent = _twiddles[key] = [W, ev, cur.cuda_stream]
+    W, ev, filled_on = ent
+    if ev is not None:
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream != filled_on:
+            if torch.cuda.is_current_stream_capturing():
+                cur.wait_event(ev)
+            elif ev.query():
+                ent[1] = None           # the fill has completed: no ordering needed any more
+            else:
+                cur.wait_event(ev)
     return W
 
 
@@ -237,25 +261,35 @@ kernel_timer = KernelTimer()
 # Memory safety rests on stream order, not on record_stream: every side region starts by waiting
 # for an event recorded on the main stream after all earlier main-stream work was enqueued, and the
 # main stream waits for the side stream before it touches a result.
-_fork = {"event": None, "memo": None}
-_side_streams = {}
+class _PerThread(threading.local):
+    """State of the forward pass in flight on THIS thread (two models driven from two threads, or autograd's worker
+    threads, never see each other's fork point, memo, bin range or side streams)."""
+
+    def __init__(self):
+        self.fork = {"event": None, "memo": None}
+        self.shard = {"bin0": 0, "m_local": None, "order": None}
+        self.side_streams = {}
+
+
+_tls = _PerThread()
 
 
 def fork_event():
-    return _fork["event"]
+    return _tls.fork["event"]
 
 
 def forward_memo():
     """dict scoped to the current Shell.forward call (None outside one): per-forward memo of responses"""
-    return _fork["memo"]
+    return _tls.fork["memo"]
 
 
 def side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    """The side stream of (this thread, device)."""
     key = dev.index if dev.index is not None else torch.cuda.current_device()
-    s = _side_streams.get(key)
+    s = _tls.side_streams.get(key)
     if s is None:
         s = torch.cuda.Stream(device=dev)
-        _side_streams[key] = s
+        _tls.side_streams[key] = s
     return s
 
 
@@ -267,35 +301,35 @@ class fork_point:
         self.dev = x.device if self.on else None
 
     def __enter__(self):
-        self.prev = (_fork["event"], _fork["memo"])
+        f = _tls.fork
+        self.prev = (f["event"], f["memo"])
         if self.on:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.dev))
-            _fork["event"] = ev
-            _fork["memo"] = {}
+            f["event"] = ev
+            f["memo"] = {}
         return self
 
     def __exit__(self, *exc):
-        _fork["event"], _fork["memo"] = self.prev
+        _tls.fork["event"], _tls.fork["memo"] = self.prev
         return False
 
 
 # ----------------------------------------------------------------------------- bin sharding (multi-GPU)
-_shard = {"bin0": 0, "m_local": None, "order": None}
 
 
 def set_bin_shard(bin0: int = 0, m_local: Optional[int] = None) -> None:
     """Restrict the response generators to bins [bin0, bin0+m_local) (flamo_amd.dist sets this
     per rank; default: all nfft//2+1 bins)."""
-    _shard["bin0"] = int(bin0)
-    _shard["m_local"] = None if m_local is None else int(m_local)
+    _tls.shard["bin0"] = int(bin0)
+    _tls.shard["m_local"] = None if m_local is None else int(m_local)
 
 
 def bin_shard(nfft: int) -> Tuple[int, int]:
     M = nfft // 2 + 1
-    if _shard["m_local"] is None:
+    if _tls.shard["m_local"] is None:
         return 0, M
-    return _shard["bin0"], _shard["m_local"]
+    return _tls.shard["bin0"], _tls.shard["m_local"]
 
 
 class row_major_bins:
@@ -310,18 +344,18 @@ class row_major_bins:
         self.order = (int(nfft), L1.value, L2.value)
 
     def __enter__(self):
-        self.prev = _shard.get("order")
-        _shard["order"] = self.order
+        self.prev = _tls.shard.get("order")
+        _tls.shard["order"] = self.order
         return self
 
     def __exit__(self, *exc):
-        _shard["order"] = self.prev
+        _tls.shard["order"] = self.prev
         return False
 
 
 def bin_order(nfft: int):
     """(L1, L2) when responses for this nfft are to be generated in row-major bin order, else None"""
-    o = _shard.get("order")
+    o = _tls.shard.get("order")
     return (o[1], o[2]) if (o is not None and o[0] == int(nfft)) else None
 
 
@@ -329,7 +363,7 @@ def _bin0_arg(nfft: int) -> Tuple[int, int]:
     """(bin0, m_local) as the response kernels take them: bin0 = -L2 selects row-major order"""
     o = bin_order(nfft)
     if o is not None:
-        if _shard["m_local"] is not None:
+        if _tls.shard["m_local"] is not None:
             raise RuntimeError("row-major bin order and bin sharding are mutually exclusive")
         return -o[1], nfft // 2 + 1
     return bin_shard(nfft)

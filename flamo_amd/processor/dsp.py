@@ -198,9 +198,10 @@ class DSP(nn.Module):
             if param.is_cuda:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(param.device))
-            memo[key] = (H, ev, torch.cuda.current_stream(param.device).cuda_stream if param.is_cuda else 0)
+            # the entry keeps `param` alive: the key holds its id(), which must not be recycled while the memo lives
+            memo[key] = (H, ev, torch.cuda.current_stream(param.device).cuda_stream if param.is_cuda else 0, param)
             return H
-        H, ev, produced_on = hit
+        H, ev, produced_on, _ = hit
         if ev is not None:
             cur = torch.cuda.current_stream(param.device)
             if cur.cuda_stream != produced_on:
@@ -234,7 +235,14 @@ class DSP(nn.Module):
         return None
 
     def _fusable(self) -> bool:
-        return getattr(self, "_own_convolve", None) is not None and self.freq_convolve is self._own_convolve
+        """True when applying this module is exactly ops.mimo(response, x): its freq_convolve is the library's own, its
+        forward() is the library's own (a user subclass that overrides forward is called as the reference would call
+        it) and no forward hooks are registered (the fused paths bypass Module.__call__)."""
+        if getattr(self, "_own_convolve", None) is None or self.freq_convolve is not self._own_convolve:
+            return False
+        if type(self).forward not in _LIBRARY_FORWARDS:
+            return False
+        return not (self._forward_hooks or self._forward_pre_hooks)
 
     def _param_for_fusion(self, shape, ext_param):
         """Same checks and side effects as forward() (shape check, ext_param logging); returns the parameter
@@ -969,6 +977,12 @@ class PEQ(_SOSMixin, Filter):
                      (G + 1) + sg * (G - 1) * c - alpha)
         return torch.stack(a), torch.stack(b)
 
+    def compute_biquad_coeff(self, f, R, G, type="peaking"):
+        """(a, b), each (*f.shape, 3): the taps of one band type, as the reference's method of the same name returns
+        them (dsp.py:2790-2842: float32 buffers, tap index last)."""
+        a, b = self._band_coeffs(f, R, G, type)
+        return a.movedim(0, -1).float(), b.movedim(0, -1).float()
+
     def _sos_coeffs(self, mapped):
         f, R, G = self.map_eq(mapped)
         a_lo, b_lo = self._band_coeffs(f[0], R[0], G[0], "lowshelf")
@@ -1245,3 +1259,9 @@ class parallelGainDelay(GainDelay):
     def check_param_shape(self):
         assert len(self.size) == 2 and self.size[0] == 2, \
             "parallelGainDelay parameters must have shape (2, N), for MIMO use GainDelay module."
+
+
+# forward() implementations of this library: a module is folded into fused paths only while its class still uses one
+# of them (see DSP._fusable)
+_LIBRARY_FORWARDS = {cls.__dict__["forward"] for cls in list(globals().values())
+                     if isinstance(cls, type) and issubclass(cls, DSP) and "forward" in cls.__dict__}

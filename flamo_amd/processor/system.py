@@ -84,10 +84,17 @@ def _compose(acc, nxt, M: int):
         S2 = H2.permute(1, 0, 2)                              # (N_out, M, N_mid): rows of H2 as batch items
         R = ops.mimo(H1, S2, diag=True) if d1 else ops.mimo(H1.transpose(-1, -2), S2)
         return R.permute(1, 0, 2), False
-    # a per-bin diagonal meets a constant full matrix: scale its rows / columns (one small pass)
-    if d2:                                                    # diag(h2[f]) W
-        return H2.unsqueeze(-1) * H1.unsqueeze(0), False
-    return H2.unsqueeze(0) * H1.unsqueeze(1), False           # W diag(h1[f])
+    # a per-bin diagonal meets a constant full matrix: R[f, p, q] = W[p, q] h[f, p]  (rows scaled: diag(h2[f]) W)  or
+    # W[p, q] h[f, q]  (columns scaled: W diag(h1[f])).  As ONE launch of the constant-matrix product kernel: the
+    # diagonal response read as a (1, M, C) signal, times the (P*Q, C) selection matrix A[(p,q), c] = W[p,q] [c == p or q]
+    # (built from P*Q*C parameter-sized scalars) -- no elementwise pass over the (M, P, Q) tensor in torch.
+    W, h, rows = (H1, H2, True) if d2 else (H2, H1, False)
+    P, Q = W.shape
+    C = P if rows else Q
+    eye = torch.eye(C, dtype=W.dtype, device=W.device)
+    A = (W.unsqueeze(-1) * (eye.unsqueeze(1) if rows else eye.unsqueeze(0))).reshape(P * Q, C)
+    R = ops.mimo(A, h.unsqueeze(0))                           # (1, M, P*Q), bin-planar
+    return R.squeeze(0).unflatten(-1, (P, Q)), False
 
 
 def _common_attribute(modules, attr, what="Series"):
@@ -311,6 +318,12 @@ class Recursion(nn.Module):
         self.alias_decay_db = self.__check_attribute("alias_decay_db")
         self.dtype = self.__check_attribute("dtype")
         self.input_channels, self.output_channels = self.__check_io()
+        # the closed-loop solve keeps a loop-matrix row per lane: one wavefront per bin bounds the loop size (the
+        # reference's torch.linalg.solve has no such bound; there is deliberately no torch fallback on this path)
+        limit = 32 if self.dtype == torch.float64 else 64
+        assert self.output_channels <= limit, (
+            f"Recursion: {self.output_channels} loop channels exceed the HIP solve kernel's limit of {limit} "
+            f"({'float64' if self.dtype == torch.float64 else 'float32'}); see INTEGRATION.md")
 
     @staticmethod
     def __as_series(path, name):
@@ -513,6 +526,16 @@ class Parallel(nn.Module):
         ya = self.branchA(X) if ext_a is None else self.branchA(X, ext_a)
         yb = self.branchB(X) if ext_b is None else self.branchB(X, ext_b)
         return ya + yb if self.sum_output else torch.cat((ya, yb), dim=2)
+
+    def probe(self, z: torch.Tensor):
+        """Transfer matrix at a complex z: H_A + H_B, or the two stacked along the output channels (system.py:740-758)."""
+        HA, HB = self.branchA.probe(z), self.branchB.probe(z)
+        return HA + HB if self.sum_output else torch.cat([HA, HB], dim=0)
+
+    def probe_w(self, w: torch.Tensor):
+        """The same in the w = 1/z variable (system.py:760-772)."""
+        HA, HB = self.branchA.probe_w(w), self.branchB.probe_w(w)
+        return HA + HB if self.sum_output else torch.cat([HA, HB], dim=0)
 
 
 # ============================================================================ Shell

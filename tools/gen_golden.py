@@ -31,6 +31,12 @@ def npy(t):
 def save(name, meta, **arrays):
     os.makedirs(OUT, exist_ok=True)
     arrays = {k: (npy(v) if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    if name.startswith("r2_"):     # lossless: values that ARE float32 numbers are stored as float32 (tests upcast)
+        for k, v in list(arrays.items()):
+            if v.dtype == np.float64 and np.array_equal(v.astype(np.float32).astype(np.float64), v):
+                arrays[k] = v.astype(np.float32)
+            elif v.dtype == np.complex128 and np.array_equal(v.astype(np.complex64).astype(np.complex128), v):
+                arrays[k] = v.astype(np.complex64)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=json.dumps(meta), **arrays)
     sz = os.path.getsize(os.path.join(OUT, name + ".npz"))
     print(f"{name:40s} {sz/1024:8.1f} KiB")
@@ -421,12 +427,147 @@ def gen_biquad_training(dsp, system):
          est0_dec=est0[:, dec], target=target, fr0_dec=fr0[:, dec])
 
 
+# ----------------------------------------------------------------------------- round 2: reference float32 beside float64, API vectors
+def _f32vals(t):
+    """float32-representable values held in float64 (both precisions of the reference then see the SAME numbers)"""
+    return t.float().double()
+
+
+def gen_round2(dsp, system):
+    F32 = torch.float32
+    # (a) config-2 miniature at the size SURVEY 8-c4 names (nfft=960, B=3, 8x8): float64 AND float32 runs of the reference
+    for db in (0.0, 30.0):
+        torch.manual_seed(7000 + int(db))
+        N, nfft, B = 8, 960, 3
+        W = _f32vals(torch.randn(N, N))
+        Gp = _f32vals(torch.empty(12, N, N).uniform_(10 ** (-6 / 20), 10 ** (6 / 20)))
+        x = _f32vals(torch.randn(B, nfft, N))
+        res = {}
+        for tag, dt in (("64", F64), ("32", F32)):
+            kw = dict(nfft=nfft, alias_decay_db=db, dtype=dt)
+            mat = dsp.Matrix(size=(N, N), matrix_type="random", requires_grad=True, **kw)
+            geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+            mat.assign_value(W.to(dt))
+            geq.assign_value(Gp.to(dt))
+            core = system.Series(OrderedDict({"mix": mat, "eq": geq}))
+            if db:
+                model = system.Shell(core, dsp.FFTAntiAlias(nfft, alias_decay_db=db, dtype=dt), dsp.iFFTAntiAlias(nfft, alias_decay_db=db, dtype=dt))
+            else:
+                model = system.Shell(core, dsp.FFT(nfft, dtype=dt), dsp.iFFT(nfft, dtype=dt))
+            xx = x.to(dt).requires_grad_(True)
+            y = model(xx)
+            g = torch.autograd.grad((y ** 2).mean(), [xx, mat.param, geq.param])
+            res[tag] = (y, *g)
+        save(f"r2_config2_960_db{int(db)}", dict(kind="config2", nfft=nfft, alias_decay_db=db, N=N, B=B, anti_alias_layers=bool(db)),
+             x=x, W=W, geq_param=Gp, y=res["64"][0], gx=res["64"][1], gW=res["64"][2], gG=res["64"][3],
+             y32=res["32"][0], gx32=res["32"][1], gW32=res["32"][2], gG32=res["32"][3])
+    # (b) FDNs: float32 run of the reference beside the float64 one (damped and undamped loop), and an e10_probe-sized one
+    specs = [("r2_fdn6_db30", 6, 480, 30.0, [59, 97, 131, 151, 163, 169], True, "wgn"),
+             ("r2_fdn6_db0", 6, 480, 0.0, [59, 97, 131, 151, 163, 169], True, "impulse"),
+             ("r2_fdn16_db30", 16, 1500, 30.0, [53, 61, 71, 79, 89, 97, 103, 109, 127, 137, 149, 157, 167, 179, 191, 199], True, "impulse"),
+             ("r2_fdn4_4096", 4, 4096, 30.0, [887, 911, 941, 1699], False, "impulse")]
+    for name, N, nfft, db, delays, attn, sig in specs:
+        torch.manual_seed(7100 + N + int(db))
+        pv = dict(in_gain=_f32vals(torch.randn(N, 1)), out_gain=_f32vals(torch.randn(1, N)), U_param=_f32vals(torch.randn(N, N)),
+                  attn_param=_f32vals(torch.randn(12 if attn else 1, N) * 0.3 + 2.0))
+        x = torch.zeros(1, nfft, 1, dtype=F64)
+        if sig == "impulse":
+            x[:, 0] = 1
+        else:
+            x = _f32vals(torch.randn(1, nfft, 1))
+        c = _f32vals(torch.randn(1, nfft, 1))
+        out = {}
+        for tag, dt in (("64", F64), ("32", F32)):
+            model, p = build_fdn(dsp, system, N, nfft, db, delays, attn, dtype=dt)
+            p["input_gain"].assign_value(pv["in_gain"].to(dt))
+            p["output_gain"].assign_value(pv["out_gain"].to(dt))
+            p["mix"].assign_value(pv["U_param"].to(dt))
+            if attn:
+                p["att"].assign_value(pv["attn_param"].to(dt))
+            xx = x.to(dt).requires_grad_(True)
+            y = model(xx)
+            plist = [p["input_gain"].param, p["output_gain"].param, p["mix"].param] + ([p["att"].param] if attn else [])
+            g = torch.autograd.grad(torch.sum(y * c.to(dt)), [xx] + plist)
+            out[tag] = (y, g)
+            if tag == "64":
+                dsec = p["delays"].param.detach().clone()
+                keys = list(model.state_dict().keys())
+        arrays = dict(x=x, c=c, delays_s=dsec, y=out["64"][0], y32=out["32"][0], gx=out["64"][1][0], gx32=out["32"][1][0],
+                      g_in_gain=out["64"][1][1], g_out_gain=out["64"][1][2], g_U_param=out["64"][1][3],
+                      g_U_param32=out["32"][1][3], **{k: v for k, v in pv.items() if attn or k != "attn_param"})
+        if attn:
+            arrays.update(g_attn_param=out["64"][1][4], g_attn_param32=out["32"][1][4])
+        save(name, dict(kind="fdn", N=N, nfft=nfft, alias_decay_db=db, delays=delays, attn=attn, state_keys=keys), **arrays)
+    # (c) transforms: float32 run beside float64
+    for i, (nfft, db) in enumerate(((960, None), (4096, 30.0))):
+        torch.manual_seed(7200 + i)
+        x = _f32vals(torch.randn(1, nfft, 2))
+        Z = _f32vals(torch.randn(1, nfft // 2 + 1, 2)) + 1j * _f32vals(torch.randn(1, nfft // 2 + 1, 2))
+        r = {}
+        for tag, dt in (("64", F64), ("32", F32)):
+            if db is None:
+                f, g = dsp.FFT(nfft, dtype=dt), dsp.iFFT(nfft, dtype=dt)
+            else:
+                f, g = dsp.FFTAntiAlias(nfft, alias_decay_db=db, dtype=dt), dsp.iFFTAntiAlias(nfft, alias_decay_db=db, dtype=dt)
+            r[tag] = (f(x.to(dt)), g(Z.to(torch.complex128 if dt == F64 else torch.complex64)))
+        save(f"r2_fft_{nfft}", dict(kind="transform", nfft=nfft, T=nfft, norm="backward", alias_decay_db=db),
+             x=x, Z=Z, X=r["64"][0], y=r["64"][1], X32=r["32"][0], y32=r["32"][1])
+    # (d) config-5 structure in miniature (N=8, nfft=960): outputs and ALL gradients from the reference
+    torch.manual_seed(7300)
+    N, nfft, db = 8, 960, 30.0
+    kw = dict(nfft=nfft, alias_decay_db=db, dtype=F64)
+    geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+    dly = dsp.Delay(size=(N, N), max_len=200, isint=True, **kw)
+    gain = dsp.parallelGain(size=(N,), requires_grad=True, **kw)
+    mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+    geq.assign_value(_f32vals(torch.empty(12, N, N).uniform_(10 ** (-6 / 20), 10 ** (6 / 20))))
+    gain.assign_value(_f32vals(torch.rand(N) * 0.5 / N ** 0.5 + 0.01))
+    mix.assign_value(_f32vals(torch.randn(N, N)))
+    dly.assign_value(dly.sample2s(torch.randint(1, 200, (N, N)).double()))
+    core = system.Series(OrderedDict(eq=geq, loop=system.Recursion(fF=system.Series(OrderedDict(d=dly, g=gain)), fB=mix)))
+    model = system.Shell(core, dsp.FFTAntiAlias(nfft, alias_decay_db=db, dtype=F64), dsp.iFFTAntiAlias(nfft, alias_decay_db=db, dtype=F64))
+    x = _f32vals(torch.randn(1, nfft, N) * 0.1).requires_grad_(True)
+    c = _f32vals(torch.randn(1, nfft, N))
+    y = model(x)
+    g = torch.autograd.grad(torch.sum(y * c), [x, geq.param, gain.param, mix.param])
+    save("r2_config5_mini", dict(kind="config5", N=N, nfft=nfft, alias_decay_db=db, max_len=200, state_keys=list(model.state_dict().keys())),
+         x=x, c=c, geq=geq.param, delay_s=dly.param, gain=gain.param, U=mix.param, y=y, gx=g[0], g_geq=g[1], g_gain=g[2], g_U=g[3])
+    # (e) Parallel.probe / probe_w and PEQ.compute_biquad_coeff (API vectors)
+    torch.manual_seed(7400)
+    kw = dict(nfft=96, alias_decay_db=0.0, dtype=F64)
+    ga = dsp.Gain(size=(3, 2), **kw)
+    gb = dsp.Gain(size=(3, 2), **kw)
+    pg = dsp.parallelGain(size=(3,), **kw)
+    z = torch.tensor(0.3 + 0.8j, dtype=C128)
+    arrays = dict(ga=ga.param, gb=gb.param, pg=pg.param, z=z)
+    for so in (True, False):
+        par = system.Parallel(brA=OrderedDict(g=ga, pg=pg), brB=gb, sum_output=so)
+        arrays[f"probe_{int(so)}"] = par.probe(z)
+        arrays[f"probe_w_{int(so)}"] = par.probe_w(1 / z)
+    save("r2_parallel_probe", dict(kind="parallel_probe", nfft=96), **arrays)
+    arrays = {}
+    f = _f32vals(torch.rand(4, 2, 2) * 1.5 + 0.05)
+    R = _f32vals(torch.rand(4, 2, 2) * 0.7 + 0.2)
+    G = _f32vals(torch.randn(4, 2, 2) * 6)
+    arrays.update(f=f, R=R, G=G)
+    for design in ("biquad", "svf"):
+        peq = dsp.PEQ(size=(2, 2), n_bands=4, design=design, nfft=96, dtype=F32)
+        for kind in ("peaking", "lowshelf", "highshelf"):
+            a_, b_ = peq.compute_biquad_coeff(f.float(), R.float(), G.float(), type=kind)
+            arrays[f"a_{design}_{kind}"] = a_
+            arrays[f"b_{design}_{kind}"] = b_
+    save("r2_peq_coeff", dict(kind="peq_coeff"), **arrays)
+
+
 def main():
     torch.set_default_dtype(torch.float32)
     dsp, system = refimport.load()
     import warnings
 
     warnings.filterwarnings("ignore")
+    if "--round2-only" in sys.argv:
+        gen_round2(dsp, system)
+        return
     if "--more-only" in sys.argv:
         gen_modules_more(dsp)
         return
@@ -451,6 +592,7 @@ def main():
     gen_accurate_geq(dsp)
     gen_colorless(dsp, system)
     gen_biquad_training(dsp, system)
+    gen_round2(dsp, system)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print(f"total {total/1024:.1f} KiB")
 
