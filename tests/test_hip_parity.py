@@ -317,8 +317,8 @@ def test_fdn_golden(gpu, dt, name):
     from flamo_amd.processor import dsp, system
     from oracle import hotpath as O
     meta, a = load_golden(name)
-    if dt == torch.float32 and meta["alias_decay_db"] == 0.0:
-        pytest.skip("undamped loop (alias_decay_db=0): resonant bins are conditioned ~1e6, float32 parity not claimed")
+    # (the undamped loop, alias_decay_db = 0, runs in float32 too: measured 3e-7 against float64 where the reference's own
+    # float32 run is 1.5e-4 off -- tests/test_round2_parity.py prints both)
     amap = lambda p_: 20 * torch.log10(torch.sigmoid(p_))  # noqa: E731
     full = dt == torch.float64
     if not full:   # expected values: float64 oracle on the float32-rounded parameters / input
