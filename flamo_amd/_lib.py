@@ -41,6 +41,7 @@ _SIGNATURES = {
     "fl_spec_plan": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     "fl_spec_supports": (_i, [_i, _i, _i]),
     "fl_debug_set_spec": (_i, [_i, _i]),
+    "fl_debug_set_spec_times": (_i, [_vp]),
     "fl_spec_cols_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _vp]),
     "fl_spec_mid_f32": (_i, [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "fl_spec_cols_inv_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp]),

@@ -253,6 +253,7 @@ struct MidArgs {
     int spec_interior2;   // double the interior bins of the spectrum (irfft backward)
     int pre_half;         // halve the interior bins in front of the inverse transform (rfft backward)
     int dbg_hfake;        // tuning: every bin reads the first 64 bins' response (cache-resident) -- isolates the fetch cost
+    long long* dbg_times; // tuning: per-workgroup cycle stamps at the phase boundaries (8 per workgroup), or null
 };
 
 // bin pair (k, L-k) number p of primary row r: where the partner sits (slot, column); false when p owns no pair
@@ -278,17 +279,19 @@ __device__ __forceinline__ bool pair_of(int r, bool selfm, int p, int LEN, int& 
 // registers, so the response's trips through the TA/L2 shrink by BG (at one item per workgroup they are 8x the
 // signal's bytes).  Streaming data (scratch, stored spectrum) is non-temporal so that it does not evict the response
 // slice that the batch items of a row pair share in their XCD's L2.
-template <int A, int B, int NI, int NO, bool HAS_H, bool DO_INV, int BG, int MS>
-__global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
+template <int A, int B, int NI, int NO, bool HAS_H, bool DO_INV, int BG, int MS, int PFD = 0, int NTH = MS, int P3V = 0>
+__global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 ? 4 : 1)) spec_mid(MidArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LEN = A * B, LENP = LEN | 1, NCH = NI > NO ? NI : NO, NT = 256 * MS;
+    constexpr int LEN = A * B, LENP = LEN | 1, NCH = NI > NO ? NI : NO, NT = 256 * NTH;
     constexpr int RPR = NT / A;              // rows per stage-2 round (every k_a of a row in the same round)
-    // MS: the product of a bin pair is split over MS threads (output channels); 256*MS threads
+    // MS: the product of a bin pair is split over MS threads (output channels); 256*NTH threads in the workgroup
+    // (NTH > MS: the extra threads take part in the FFT phases only)
     static_assert(NT % A == 0 && NO % MS == 0 && NI % MS == 0, "tile shape");
     cf* U = reinterpret_cast<cf*>(smem);     // [BG][2][NCH][LENP]
     cf* tw = U + BG * 2 * NCH * LENP;        // W_LEN^m
     cf* ws = tw + LEN;                       // W_n^(L1*k2)
     cf* wi2 = ws + LEN;                      // [2][B]: W_L^(row * A * kb)
+    cf* nyq = wi2 + 2 * B;                   // [BG][NCH]: the Nyquist bin of row pair 0 (P3V == 1)
     // XCD-aware order: the batch groups of one row pair run back to back on the same XCD (block q runs on XCD
     // q % 8), so that pair's slice of H is fetched from HBM once and from that L2 afterwards
     const int P = a.L1 / 2 + 1;
@@ -309,6 +312,7 @@ __global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
         wi2[tid] = a.W[2 * (slot ? rm : r) * A * kb];
     }
     __syncthreads();
+    if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + 0] = clock64();
     const unsigned bstride_i = (unsigned)a.L1 * (unsigned)a.L2 * NI, bstride_o = (unsigned)a.L1 * (unsigned)a.L2 * NO;
     // ---- P1: load + first stage of the forward row FFTs.  item = (batch item, slot, tb, n), n fastest: the loads of
     // a wavefront cover contiguous (tb, n) runs of a scratch row
@@ -330,6 +334,7 @@ __global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
         }
     }
     __syncthreads();
+    if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + 1] = clock64();
     // ---- P2: second stage, natural order written back in place (read all, barrier, write all per round)
     for (int row0 = 0; row0 < BG * 2 * NI; row0 += RPR) {
         const int rl = row0 + tid % RPR, ka = tid / RPR;
@@ -349,6 +354,8 @@ __global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
         }
         __syncthreads();
     }
+    if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + 2] = clock64();
+    if constexpr (P3V == 0) {
     // ---- P3: split step, spectrum store, product, Hermitian pre-step.  Thread (p, ms): bin pair (k, L-k) number p, output
     // channels [ms NO/MS, (ms+1) NO/MS), all BG batch items.  The MS threads of a pair read the same two columns of U
     // (all input channels) and write their own output channels back into them: one barrier between the two.
@@ -361,7 +368,7 @@ __global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
             const int p = p0 + (tid & 255);
             int slotB = 0, colB = 0;
             bool dc = false;
-            const bool valid = p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
+            const bool valid = ms < MS && p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
             const unsigned ik = (unsigned)r * LEN + p;
             const unsigned im = dc ? (unsigned)a.L : (unsigned)(slotB ? rm : r) * LEN + colB;
             cf xk[BG][NI], xm[BG][NI];
@@ -407,21 +414,38 @@ __global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
                 }
             }
             if (!DO_INV) continue;
+            if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + 6] = clock64();
             if (MS > 1) __syncthreads();
             if (!valid) continue;
             const cf cwk = conj(wk);
+            // response rows: row m2 + PFD is requested before row m2 is used (PFD + 1 rows of 2 NI values in registers);
+            // plane (m, n) is a workgroup-uniform base (scalar arithmetic), the bin the lane's 32-bit offset
+            constexpr int NB = PFD + 1;
+            cf hrows[NB][2 * NI];
+            const unsigned hoff_k = a.dbg_hfake ? 8u * (ik & 63u) : 8u * ik, hoff_m = a.dbg_hfake ? 8u * (im & 63u) : 8u * im;
+            auto load_row = [&](int m2, cf* dst) {
+                const cf* Hm = a.H + (size_t)__builtin_amdgcn_readfirstlane(ms * (NO / MS) + m2) * a.hs_m;
+#pragma unroll
+                for (int nn = 0; nn < NI; ++nn) {
+                    dst[nn] = at(Hm + (size_t)nn * a.hs_n, hoff_k);
+                    dst[NI + nn] = at(Hm + (size_t)nn * a.hs_n, hoff_m);
+                }
+            };
+            if (HAS_H) {
+#pragma unroll
+                for (int i = 0; i < PFD; ++i)
+                    if (i < NO / MS) load_row(i, hrows[i]);
+            }
 #pragma unroll
             for (int m2 = 0; m2 < NO / MS; ++m2) {
                 const int m = ms * (NO / MS) + m2;
                 cf hkv[NI], hmv[NI];
                 if (HAS_H) {
-                    // plane (m, n) as a workgroup-uniform base (scalar arithmetic), the bin as the lane's 32-bit offset
-                    const cf* Hm = a.H + (size_t)__builtin_amdgcn_readfirstlane(m) * a.hs_m;
-                    const unsigned hoff_k = a.dbg_hfake ? 8u * (ik & 63u) : 8u * ik, hoff_m = a.dbg_hfake ? 8u * (im & 63u) : 8u * im;
+                    if (m2 + PFD < NO / MS) load_row(m2 + PFD, hrows[(m2 + PFD) % NB]);
 #pragma unroll
                     for (int nn = 0; nn < NI; ++nn) {
-                        hkv[nn] = at(Hm + (size_t)nn * a.hs_n, hoff_k);
-                        hmv[nn] = at(Hm + (size_t)nn * a.hs_n, hoff_m);
+                        hkv[nn] = hrows[m2 % NB][nn];
+                        hmv[nn] = hrows[m2 % NB][NI + nn];
                         if (a.conj_h) {
                             hkv[nn].y = -hkv[nn].y;
                             hmv[nn].y = -hmv[nn].y;
@@ -462,8 +486,128 @@ __global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
             }
         }
     }
+    }
+    if constexpr (P3V == 1) {
+        // ---- P3 in three sweeps (BG batch items per workgroup, 256*BG threads), so that a response row fetched for a
+        // bin serves the BG spectra the workgroup holds -- the response's trips through the L2 -> L1 path (measured
+        // 31 B/clk/CU for 8-byte loads: 245 KB per row pair = 8k cycles, the largest single cost of the one-item form)
+        // shrink by BG, and the product runs one thread per BIN (not per pair) with 2 NI + 2 NI values in registers:
+        //   a) split step per (item, pair): spectrum written back in place (and to global memory for the backward pass)
+        //   b) product per bin: Y[item][:, bin] = H[:, :, bin] X[item][:, bin], in place
+        //   c) Hermitian pre-step per (item, pair), in place
+        static_assert(HAS_H && DO_INV && NTH == BG, "three-sweep product: response + inverse half, 256 threads per item");
+        const cf wr = a.W[r];
+        const float hs = 0.5f * a.spec_scale, wi = a.spec_interior2 ? 2.f : 1.f;
+        const float ph = a.pre_half ? 0.5f : 1.f;
+        const int bbt = tid / 256;                      // the batch item this thread serves in sweeps a and c
+        for (int p0 = 0; p0 < LEN; p0 += 256) {        // ---- a
+            const int p = p0 + (tid & 255);
+            int slotB = 0, colB = 0;
+            bool dc = false;
+            if (!(p < LEN && bbt < nb && pair_of(r, selfm, p, LEN, slotB, colB, dc))) continue;
+            const unsigned ik = (unsigned)r * LEN + p;
+            const unsigned im = dc ? (unsigned)a.L : (unsigned)(slotB ? rm : r) * LEN + colB;
+            const cf wk = wr * ws[p];
+            cf* xo = a.Xs ? a.Xs + (size_t)(b0 + bbt) * a.xs_b : nullptr;
+#pragma unroll
+            for (int nn = 0; nn < NI; ++nn) {
+                cf* pk = U + ((2 * bbt) * NCH + nn) * LENP + p;
+                cf* pm = U + ((2 * bbt + slotB) * NCH + nn) * LENP + colB;
+                const cf zk = *pk, zm = *pm;
+                cf xk, xm;
+                if (dc) {
+                    xk = cf(a.spec_scale * (zk.x + zk.y), 0.f);     // X[0]
+                    xm = cf(a.spec_scale * (zk.x - zk.y), 0.f);     // X[L]
+                    nyq[bbt * NCH + nn] = xm;
+                } else {
+                    const cf pk_ = zk + conj(zm), dk = zk - conj(zm);
+                    const cf ok = pk_ + mul_mi(wk * dk);
+                    const cf pm_ = zm + conj(zk), dm = zm - conj(zk);
+                    const cf wm(-wk.x, wk.y);
+                    const cf om = pm_ + mul_mi(wm * dm);
+                    xk = cf(hs * wi * ok.x, hs * wi * ok.y);
+                    xm = cf(hs * wi * om.x, hs * wi * om.y);
+                    if (im != ik) *pm = xm;
+                }
+                *pk = xk;
+                if (xo) {
+                    st_nt(xo, 8u * ((unsigned)nn * (unsigned)a.xs_n + ik), xk);
+                    if (im != ik) st_nt(xo, 8u * ((unsigned)nn * (unsigned)a.xs_n + im), xm);
+                }
+            }
+        }
+        __syncthreads();
+        {                                                // ---- b: one thread per bin held by the workgroup
+            const int nbins = (selfm ? 1 : 2) * LEN + (r == 0 ? 1 : 0);
+            for (int j = tid; j < nbins; j += NT) {
+                const bool isnyq = j == (selfm ? 1 : 2) * LEN;
+                const int slot = isnyq ? 0 : j / LEN, col = isnyq ? 0 : j - slot * LEN;
+                const unsigned ib = isnyq ? (unsigned)a.L : (unsigned)(slot ? rm : r) * LEN + col;
+                cf x[BG][NI];
+#pragma unroll
+                for (int bb = 0; bb < BG; ++bb)
+#pragma unroll
+                    for (int nn = 0; nn < NI; ++nn)
+                        x[bb][nn] = isnyq ? nyq[bb * NCH + nn] : U[((2 * bb + slot) * NCH + nn) * LENP + col];
+                const unsigned hoff = 8u * ib;
+                // MC response rows requested together (MC*NI loads in flight per thread): the sweep is a chain of
+                // NO/MC load round trips, each ~3.5k cycles under the kernel's own traffic -- not NO of them
+                // (MC = 4 rows in flight spills under the 128-register cap of this form and measured slower: 109 us against 95)
+                constexpr int MC = 1;
+#pragma unroll
+                for (int m0 = 0; m0 < NO; m0 += MC) {
+                    cf h[MC][NI];
+#pragma unroll
+                    for (int mc = 0; mc < MC; ++mc) {
+                        const cf* Hm = a.H + (size_t)(m0 + mc) * a.hs_m;
+#pragma unroll
+                        for (int nn = 0; nn < NI; ++nn) h[mc][nn] = at(Hm + (size_t)nn * a.hs_n, hoff);
+                    }
+#pragma unroll
+                    for (int mc = 0; mc < MC; ++mc) {
+                        if (a.conj_h) {
+#pragma unroll
+                            for (int nn = 0; nn < NI; ++nn) h[mc][nn].y = -h[mc][nn].y;
+                        }
+#pragma unroll
+                        for (int bb = 0; bb < BG; ++bb) {
+                            cf y(0.f, 0.f);
+#pragma unroll
+                            for (int nn = 0; nn < NI; ++nn) fma_cx(y, h[mc][nn], x[bb][nn]);
+                            if (isnyq) nyq[bb * NCH + m0 + mc] = y;
+                            else U[((2 * bb + slot) * NCH + m0 + mc) * LENP + col] = y;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int p0 = 0; p0 < LEN; p0 += 256) {        // ---- c
+            const int p = p0 + (tid & 255);
+            int slotB = 0, colB = 0;
+            bool dc = false;
+            if (!(p < LEN && bbt < nb && pair_of(r, selfm, p, LEN, slotB, colB, dc))) continue;
+            const bool self = !dc && slotB == 0 && colB == p;
+            const cf cwk = conj(wr * ws[p]);
+#pragma unroll
+            for (int m = 0; m < NO; ++m) {
+                cf* pk = U + ((2 * bbt) * NCH + m) * LENP + p;
+                cf* pm = U + ((2 * bbt + slotB) * NCH + m) * LENP + colB;
+                const cf yk = *pk, ym = dc ? nyq[bbt * NCH + m] : *pm;
+                if (dc) {      // Zf[0] from the real parts of Y[0] and Y[L] (C2R semantics)
+                    *pk = cf(yk.x + ym.x, yk.x - ym.x);
+                } else {
+                    const cf xa(ph * yk.x, ph * yk.y), xb(ph * ym.x, ph * ym.y);
+                    const cf s_ = xa + conj(xb), t_ = mul_i(cwk * (xa - conj(xb)));
+                    *pk = s_ + t_;
+                    if (!self) *pm = conj(s_ - t_);
+                }
+            }
+        }
+    }
     if (!DO_INV) return;
     __syncthreads();
+    if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + 3] = clock64();
     // ---- P4: first stage of the inverse row FFTs, in place (a thread owns positions tb + B*i of its row)
     for (int item = tid; item < BG * 2 * B * NO; item += NT) {
         const int m = item % NO, tb = (item / NO) % B, bs = item / (NO * B);
@@ -478,6 +622,7 @@ __global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
         for (int ka = 1; ka < A; ++ka) u[ka * B] = v[ka] * conj(tw[ka * tb]);
     }
     __syncthreads();
+    if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + 4] = clock64();
     // ---- P5: second stage, inter-pass twiddle conj(W_L^(row*c)), store
     {
         cf* S2b = a.S2 + (size_t)b0 * bstride_o;
@@ -501,6 +646,7 @@ __global__ void __launch_bounds__(256 * MS) spec_mid(MidArgs a) {
             }
         }
     }
+    if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + 5] = clock64();
 }
 
 // ---------------------------------------------------------------- bin order conversion
@@ -592,16 +738,21 @@ static int cols_launch(bool inverse, const ColsArgs& a, int Bn, hipStream_t st) 
     return FL_OK;
 }
 
-static int g_mid_bg = 1, g_mid_hfake = 0;
+static int g_mid_bg = 1, g_mid_hfake = 0, g_mid_pfd = 0;
+static long long* g_mid_times = nullptr;
 
 template <int A, int B, int NI, int NO, int BG, int MS>
 static void launch_mid_bg(const MidArgs& a, hipStream_t st) {
     constexpr int LEN = A * B, LENP = LEN | 1, NCH = NI > NO ? NI : NO;
-    const size_t lds = ((size_t)BG * 2 * NCH * LENP + 2 * LEN + 2 * B) * sizeof(cf);
+    const size_t lds = ((size_t)BG * 2 * NCH * LENP + 2 * LEN + 2 * B + BG * NCH) * sizeof(cf);
     const int P = a.L1 / 2 + 1;
     const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * cdiv_i(a.Bn, BG));
     if (a.S2) {
-        if (a.H) hipLaunchKernelGGL((spec_mid<A, B, NI, NO, true, true, BG, MS>), dim3(nblk), dim3(256 * MS), lds, st, a);
+        if (a.H) {
+            if (g_mid_pfd == 1) hipLaunchKernelGGL((spec_mid<A, B, NI, NO, true, true, BG, MS, 1>), dim3(nblk), dim3(256 * MS), lds, st, a);
+            else if (g_mid_pfd == 2) hipLaunchKernelGGL((spec_mid<A, B, NI, NO, true, true, BG, MS, 2>), dim3(nblk), dim3(256 * MS), lds, st, a);
+            else hipLaunchKernelGGL((spec_mid<A, B, NI, NO, true, true, BG, MS, 0>), dim3(nblk), dim3(256 * MS), lds, st, a);
+        }
         else if constexpr (NI == NO) hipLaunchKernelGGL((spec_mid<A, B, NI, NO, false, true, BG, MS>), dim3(nblk), dim3(256 * MS), lds, st, a);
     } else {
         if constexpr (NI == NO) hipLaunchKernelGGL((spec_mid<A, B, NI, NO, false, false, BG, MS>), dim3(nblk), dim3(256 * MS), lds, st, a);
@@ -613,6 +764,36 @@ static void launch_mid_n(const MidArgs& a, unsigned, hipStream_t st) {
     constexpr int LEN = A * B, LENP = LEN | 1, NCH = NI > NO ? NI : NO;
     // (two batch items per workgroup -- the response row applied to two spectra -- measured slower at config 2:
     // 104 us with 256 threads, 118 us with 512, against 98 us; the kernel keeps the BG/MS parameters for that experiment)
+    // response present + inverse half: BG batch items per workgroup with the three-sweep product (the response row of a bin
+    // is fetched once per BG items)
+    if (a.H && a.S2 && g_mid_bg == 5) {       // one item per workgroup, three-sweep product
+        constexpr int LEN = A * B, LENP = LEN | 1, NCH = NI > NO ? NI : NO;
+        const int P = a.L1 / 2 + 1;
+        const size_t lds = ((size_t)2 * NCH * LENP + 2 * LEN + 2 * B + NCH) * sizeof(cf);
+        const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * a.Bn);
+        hipLaunchKernelGGL((spec_mid<A, B, NI, NO, true, true, 1, 1, 0, 1, 1>), dim3(nblk), dim3(256), lds, st, a);
+        return;
+    }
+    if (a.H && a.S2 && a.Bn > 1 && g_mid_bg >= 2) {
+        constexpr int LEN = A * B, LENP = LEN | 1, NCH = NI > NO ? NI : NO;
+        const int P = a.L1 / 2 + 1;
+        if constexpr ((size_t)2 * 2 * NCH * LENP * sizeof(cf) <= 70 * 1024) {
+            if (g_mid_bg == 2 || a.Bn < 4 || (size_t)4 * 2 * NCH * LENP * sizeof(cf) > 150 * 1024) {
+                const size_t lds = ((size_t)2 * 2 * NCH * LENP + 2 * LEN + 2 * B + 2 * NCH) * sizeof(cf);
+                const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * cdiv_i(a.Bn, 2));
+                hipLaunchKernelGGL((spec_mid<A, B, NI, NO, true, true, 2, 1, 0, 2, 1>), dim3(nblk), dim3(512), lds, st, a);
+                return;
+            }
+        }
+        if constexpr ((size_t)4 * 2 * NCH * LENP * sizeof(cf) <= 150 * 1024) {
+            if (g_mid_bg == 4 && a.Bn >= 4) {
+                const size_t lds = ((size_t)4 * 2 * NCH * LENP + 2 * LEN + 2 * B + 4 * NCH) * sizeof(cf);
+                const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * cdiv_i(a.Bn, 4));
+                hipLaunchKernelGGL((spec_mid<A, B, NI, NO, true, true, 4, 1, 0, 4, 1>), dim3(nblk), dim3(1024), lds, st, a);
+                return;
+            }
+        }
+    }
     launch_mid_bg<A, B, NI, NO, 1, 1>(a, st);
 }
 
@@ -654,11 +835,17 @@ int fl_spec_supports(int nfft, int n_in, int n_out) {
     return 1;
 }
 
+int fl_debug_set_spec_times(void* buf) {
+    g_mid_times = (long long*)buf;
+    return FL_OK;
+}
+
 int fl_debug_set_spec(int vt, int rg) {
     g_spec_vt = (vt == 16) ? 16 : 32;
     g_spec_rg = (rg % 100 == 1 || rg % 100 == 4) ? rg % 100 : 2;
     g_mid_bg = (rg >= 100) ? (rg / 100) % 10 : 1;
-    g_mid_hfake = rg >= 1000;     // rg = 100*(2: two batch items per workgroup) + load group
+    g_mid_hfake = (rg / 1000) % 10 == 1;
+    g_mid_pfd = (rg / 10000) % 10;       // rg = 10000*prefetch depth + 1000*fake + 100*bg + load group     // rg = 100*(2: two batch items per workgroup) + load group
     return FL_OK;
 }
 
@@ -706,7 +893,7 @@ int fl_spec_mid_f32(const void* S, void* S2, void* Xs, long xs_b, long xs_n, con
     a.S = (const cf*)S; a.S2 = (cf*)S2; a.Xs = (cf*)Xs; a.xs_b = xs_b; a.xs_n = xs_n;
     a.H = (const cf*)H; a.hs_m = hs_m; a.hs_n = hs_n; a.conj_h = conj_h;
     a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn;
-    a.spec_scale = (float)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half; a.dbg_hfake = g_mid_hfake;
+    a.spec_scale = (float)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half; a.dbg_hfake = g_mid_hfake; a.dbg_times = g_mid_times;
     const int P = a.L1 / 2 + 1;
     const size_t nblk = (size_t)cdiv_i(P, 8) * 8 * Bn;
     FL_REQUIRE(nblk < (1ull << 31), "spec_mid: grid too large");

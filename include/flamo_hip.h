@@ -123,6 +123,8 @@ int fl_spec_plan(int nfft, int* L1, int* L2);
 int fl_spec_supports(int nfft, int n_in, int n_out);
 /* tuning hook: virtual columns per workgroup of the column passes (16 | 32), load group */
 int fl_debug_set_spec(int vt, int rg);
+/* tuning hook: device buffer of 8 int64 per workgroup of fl_spec_mid_f32 for cycle stamps at its phase boundaries (null: off) */
+int fl_debug_set_spec_times(void* buf);
 /* K1: S[b][k1][c][g] = W_L^(c k1) sum_t1 z[c + L2 t1] W_L1^(t1 k1),  z[j] = e(2j) x[b][2j][g] + i e(2j+1) x[b][2j+1][g];
  * x: real (Bn, t_len, G) contiguous, 8-byte aligned, G even (a power of two <= 32 or a multiple of 32); samples at
  * t >= min(t_len, nfft) count as zero. */

@@ -317,3 +317,25 @@ def test_matrix_cascade_operator_equals_composition(gpu, kind):
     assert relerr(y1, y2) < TOL
     for a, b in zip(g1, g2):
         assert relerr(a, b) < 2e-5, kind
+
+
+@pytest.mark.parametrize("variant", [2, 4, 5])
+def test_mid_kernel_variants_agree(gpu, variant):
+    """the row kernel's experimental forms (tuning hook: 2 / 4 batch items per workgroup with the three-sweep product, one
+    item with the three-sweep product) give the default form's results (odd batch: the tail group is partial)"""
+    from flamo_amd import _lib, ops
+    nfft, N, B = 96000, 8, 5
+    torch.manual_seed(variant)
+    M = nfft // 2 + 1
+    x = torch.randn(B, nfft, N, device=gpu)
+    H = ops.permute_bins(torch.randn(M, N, N, device=gpu, dtype=torch.complex64) / N ** 0.5, nfft)
+    y0 = ops.spectral_apply(x, H, nfft)
+    _lib.lib().fl_debug_set_spec(32, 100 * variant + 2)
+    try:
+        y1 = ops.spectral_apply(x, H, nfft)
+        xg = x.clone().requires_grad_(True)
+        (g1,) = torch.autograd.grad(ops.spectral_apply(xg, H, nfft).square().sum(), [xg])
+    finally:
+        _lib.lib().fl_debug_set_spec(32, 2)
+    (g0,) = torch.autograd.grad(ops.spectral_apply(xg, H, nfft).square().sum(), [xg])
+    assert relerr(y1, y0) < 1e-6 and relerr(g1, g0) < 1e-6

@@ -55,7 +55,7 @@ for with_x in (False, True):
 # ---- mid-kernel variants (tuning): response-row prefetch modes, no-response floor
 S = ops._spec_cols_fwd(x, nfft, 0.0)
 Hp = ops._h_planar(H.detach(), True)
-for pf in (1, 11):
+for pf in (1, 5, 2, 4):
     _lib.lib().fl_debug_set_spec(args.vt, 100 * pf + args.rg)
     for _ in range(3):
         ops._spec_mid(S.clone(), B, N, N, nfft, Hp, False, True, True, 1.0, 0, 0)
@@ -72,3 +72,25 @@ for _ in range(10):
 torch.cuda.synchronize()
 print("mid without response:", {k: round(v[1] * 1e3, 1) for k, v in ops.kernel_timer.summary().items()})
 ops.kernel_timer.enabled = False
+
+# ---- phase timeline of the mid kernel (cycle stamps of one lane per workgroup)
+nwg = ((nfft // 2 // 240 // 2 + 1 + 7) // 8) * 8 * B if nfft == 96000 else 0
+for bgv in ((5, 2) if nwg else ()):
+    _lib.lib().fl_debug_set_spec(args.vt, 100 * bgv + args.rg)
+    print(f"--- batch items per workgroup: {bgv}")
+    buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+    _lib.lib().fl_debug_set_spec_times(buf.data_ptr())
+    ops._spec_mid(S.clone(), B, N, N, nfft, Hp, False, True, True, 1.0, 0, 0)
+    torch.cuda.synchronize()
+    _lib.lib().fl_debug_set_spec_times(None)
+    t = buf.view(nwg, 8).cpu().double()
+    t = t[t[:, 5] > 0]
+    d = (t[:, 1:6] - t[:, 0:5])
+    names = ["P1 load+fft16", "P2 fft15", "P3 split/product/pre", "P4 ifft16", "P5 ifft15+store"]
+    tot = (t[:, 5] - t[:, 0]).mean().item()
+    print(f"mid phases (shader cycles per workgroup, mean over {len(t)} workgroups; whole body {tot:.0f}):")
+    for n_, v in zip(names, d.mean(0).tolist()):
+        print(f"   {n_:24s} {v:9.0f}  ({100 * v / tot:4.1f} %)")
+    print(f"   of P3: LDS reads + split step + spectrum store {(t[:, 6] - t[:, 2]).mean().item():9.0f}, product + pre-step {(t[:, 3] - t[:, 6]).mean().item():9.0f}")
+    span = (t[:, 5].max() - t[:, 0].min()).item()
+    print(f"   kernel span {span:.0f} cycles; sum of workgroup bodies / 256 CUs = {(t[:, 5] - t[:, 0]).sum().item() / 256:.0f}")
