@@ -121,8 +121,10 @@ def cpu_baseline(W, G, budget_s=45.0):
             break
     cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
-    per_item = max(probe[cores], 1e-3)
-    b = int(max(1, min(BATCH, budget_s / 4 / per_item * 1.5)))     # batch-1 steps overstate the per-item cost (response build)
+    t1, t4 = probe[cores], timed(4, 1)          # step time = response build + batch * per-item cost: two points fix both
+    per_item = max((t4 - t1) / 3, 1e-4)
+    fixed = max(t1 - per_item, 0.0)
+    b = int(max(1, min(BATCH, (budget_s / 4 - fixed) / per_item)))
     timed(b, 1)                       # warm-up at the timed size
     dt = timed(b, 3)
     M = NFFT // 2 + 1

@@ -132,10 +132,14 @@ __global__ void __launch_bounds__(256) sos_response_rc_kernel(const double* __re
     cx<float> acc[NIW];
 #pragma unroll
     for (int n = 0; n < NIW; ++n) acc[n] = cx<float>(0.f, 0.f);
+#pragma unroll 2
     for (int j = 0; j < Nmid; ++j) {
         const double* tb = lb + j * 3 * S;
         const double* ta = la + j * 3 * S;
         cx<double> Bp(1, 0), Ap(1, 0);
+        // (unrolled by 4: the LDS reads of four sections' taps are issued together -- one latency per four sections instead of
+        // one per section; two cascades interleaved by the outer unroll: the products are dependent chains)
+#pragma unroll 4
         for (int s = 0; s < S; ++s) {
             Bp = Bp * e.poly(tb, S, s);
             Ap = Ap * e.poly(ta, S, s);

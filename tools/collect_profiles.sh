@@ -10,12 +10,14 @@ rm -rf $OUT; mkdir -p $OUT
 cd $ROOT
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python $ROOT/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r -- python $ROOT/bench.py --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fdn_stats -o r -- python $ROOT/tools/bench_fdn.py --dtype f32 > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c5_stats -o r -- python $ROOT/tools/bench_fdn.py --workload config5 --dtype f32 --steps 5 > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c4_stats -o r -- python $ROOT/tools/train_colorless_fdn.py --steps 20 --warmup 2 > /dev/null 2>&1
+# SQ activity of the bench step's kernels (its own pass: counters only)
+timeout 600 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/bench_sq -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 # matrix-core activity of the config-5 chain (its own pass: counters only)
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $OUT/c5_pmc -o r -- python $ROOT/tools/bench_fdn.py --workload config5 --dtype f32 --steps 2 > /dev/null 2>&1
 cd $ROOT

@@ -70,10 +70,40 @@ def main():
         wr.writerow(["kernel", "grid_size", "launches", "fetch_bytes_per_launch(2*FETCH_SIZE*1024)", "write_bytes_per_launch(WRITE_SIZE*1024)", "total_bytes_per_launch"])
         for r in rows:
             wr.writerow([r[0], r[1], r[2], f"{r[3]:.0f}", f"{r[4]:.0f}", f"{r[5]:.0f}"])
-    big = [r for r in rows if "mimo_full_kernel" in r[0]]
+    # what bench.py reads back as roofline.traffic: bytes per launch of the dominant kernels, keyed by bench.py's kernel tags
+    def largest(pat):
+        c = [r for r in rows if pat in r[0]]
+        c.sort(key=lambda r: -r[5])
+        return c[0] if c else None
+    tags = {"spec_mid[8->8,H,inv,spec]": "spec_mid<16, 15, 8, 8, true, true", "spec_mid[8->8,spec]": "spec_mid<16, 15, 8, 8, false, false",
+            "spec_cols_fwd": "spec_cols_fwd<", "spec_cols_inv": "spec_cols_inv<", "mimo_gradh[cols=32,8x8]": "mimo_gradh_kernel<float, 4, 4>",
+            "sos_response_rc": "sos_response_rc_kernel", "sos_response_bwd_rc": "sos_response_bwd_mixed_kernel", "mimo_full": "mimo_full_kernel<float, 8, 4, 1, false>"}
+    traffic = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 3`, FETCH_SIZE doubled per "
+                         f"MI355X_MICROARCH.md; profiles/{tag}_pmc_hbm_traffic.csv"}
+    for k, pat in tags.items():
+        r = largest(pat)
+        if r:
+            traffic[k] = {"bytes_per_launch": r[5], "fetch_bytes": r[3], "write_bytes": r[4], "launches": r[2], "kernel": r[0][:100]}
+    json.dump(traffic, open(os.path.join(DST, "pmc_hbm_traffic.json"), "w"), indent=1)
+    sq = os.path.join(SRC, "bench_sq", "r_counter_collection.csv")
+    if os.path.exists(sq):
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for r in csv.DictReader(open(sq)):
+            if "fl::" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        names = ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
+        with open(os.path.join(DST, f"{tag}_bench_pmc_sq.csv"), "w", newline="") as fh:
+            wr = csv.writer(fh)
+            wr.writerow(["kernel", "launches"] + [n + "_per_launch" for n in names] + ["valu_per_wave_cycle", "lds_conflict_per_active"])
+            for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("SQ_BUSY_CYCLES", [0]))):
+                n = max(len(x) for x in v.values())
+                m = {c: (sum(v.get(c, [0])) / max(len(v.get(c, [1])), 1)) for c in names}
+                wr.writerow([k[:120], n] + ["%.0f" % m[c] for c in names] +
+                            ["%.3f" % (m["SQ_ACTIVE_INST_VALU"] / max(m["SQ_WAVE_CYCLES"], 1)), "%.3f" % (m["SQ_LDS_BANK_CONFLICT"] / max(m["SQ_LDS_IDX_ACTIVE"], 1))])
+    big = [r for r in rows if "spec_mid<" in r[0]]
     big.sort(key=lambda r: -r[5])
     if big:
-        print("dominant kernel traffic (largest mimo_full launch):", big[0][0][:60], "grid", big[0][1], "bytes %.4g" % big[0][5])
+        print("dominant kernel traffic (largest spec_mid launch):", big[0][0][:60], "grid", big[0][1], "bytes %.4g" % big[0][5])
     print("value %.4g %s, %.4f ms/step; roofline frac %.3f" % (bench["value"], bench["unit"], bench["ms_per_step"],
                                                                (bench.get("roofline") or {}).get("frac", float("nan"))))
 
