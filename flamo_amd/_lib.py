@@ -40,6 +40,8 @@ _SIGNATURES = {
     "fl_transpose": (_i, [_vp, _vp, _i, _i, _i, _l, _i, _vp]),
     "fl_spec_plan": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     "fl_spec_supports": (_i, [_i, _i, _i]),
+    "fl_spec_aux_elems": (_sz, [_i]),
+    "fl_spec_aux_fill_f32": (_i, [_vp, _i, _vp]),
     "fl_debug_set_spec": (_i, [_i, _i]),
     "fl_debug_set_spec_times": (_i, [_vp]),
     "fl_spec_cols_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _vp]),

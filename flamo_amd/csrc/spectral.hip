@@ -88,18 +88,10 @@ __global__ void __launch_bounds__(256, 3) spec_cols_fwd(ColsArgs a) {
     const int b = blk / a.ngt;
     const int CG = 1 << a.cgs;
     const int c0 = ct * a.CT, g0 = gt * CG;
-    const int twstep = a.n / LEN;
-    for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[j * twstep];
-    for (int j = threadIdx.x; j < a.CT * B; j += 256) {
-        const int cl = j / B, kb = j - cl * B;
-        t2[j] = a.W[2 * (c0 + cl) * A * kb];
-    }
-    __syncthreads();
     constexpr int NIT = B * VT, NR = (NIT + 255) / 256;
     const float* xb = a.x + (size_t)b * a.t_len * a.G + g0;
-#pragma unroll 1
-    for (int r0 = 0; r0 < NR; r0 += RG) {
-        cf v[RG][A];
+    cf v[RG][A];
+    auto load_group = [&](int r0) {
 #pragma unroll
         for (int rr = 0; rr < RG; ++rr) {
             const int item = threadIdx.x + (r0 + rr) * 256;
@@ -117,6 +109,20 @@ __global__ void __launch_bounds__(256, 3) spec_cols_fwd(ColsArgs a) {
                 }
             }
         }
+    };
+    // the first group's samples are requested BEFORE the twiddle tables are fetched: the tables' latency (a dependent
+    // global round trip in front of the barrier) then overlaps the data's instead of preceding it
+    load_group(0);
+    const cf* aux = a.W + a.n;                     // contiguous copies: W_L1^j (L1), W_L2^j (L2), W_n^(L1 j) (L2)
+    for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = aux[j];
+    for (int j = threadIdx.x; j < a.CT * B; j += 256) {
+        const int cl = j / B, kb = j - cl * B;
+        t2[j] = a.W[2 * (c0 + cl) * A * kb];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int r0 = 0; r0 < NR; r0 += RG) {
+        if (r0 > 0) load_group(r0);
 #pragma unroll
         for (int rr = 0; rr < RG; ++rr) {
             const int item = threadIdx.x + (r0 + rr) * 256;
@@ -179,14 +185,10 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
     const int b = blk / a.ngt;
     const int CG = 1 << a.cgs;
     const int c0 = ct * a.CT, g0 = gt * CG;
-    const int twstep = a.n / LEN;
-    for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[j * twstep];
-    __syncthreads();
     constexpr int NIT = B * VT, NR = (NIT + 255) / 256;
     const cf* in = a.S + (size_t)b * a.L1 * a.L2 * a.G + g0;
-#pragma unroll 1
-    for (int r0 = 0; r0 < NR; r0 += RG) {
-        cf v[RG][A];
+    cf v[RG][A];
+    auto load_group = [&](int r0) {
 #pragma unroll
         for (int rr = 0; rr < RG; ++rr) {
             const int item = threadIdx.x + (r0 + rr) * 256;
@@ -198,6 +200,13 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
                     v[rr][ta] = at(in, 8u * (((unsigned)(ta * B + tb) * (unsigned)a.L2 + (unsigned)(c0 + cl)) * (unsigned)a.G + (unsigned)gl));
             }
         }
+    };
+    load_group(0);                                 // data first, tables behind it (see the forward pass)
+    for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[a.n + j];
+    __syncthreads();
+#pragma unroll 1
+    for (int r0 = 0; r0 < NR; r0 += RG) {
+        if (r0 > 0) load_group(r0);
 #pragma unroll
         for (int rr = 0; rr < RG; ++rr) {
             const int item = threadIdx.x + (r0 + rr) * 256;
@@ -303,9 +312,25 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
     const int rm = (a.L1 - r) % a.L1;
     const bool selfm = rm == r;
     const int tid = threadIdx.x;
-    for (int j = tid; j < LEN; j += NT) {
-        tw[j] = a.W[j * (a.n / LEN)];
-        ws[j] = a.W[a.L1 * j];
+    const unsigned bstride_i = (unsigned)a.L1 * (unsigned)a.L2 * NI, bstride_o = (unsigned)a.L1 * (unsigned)a.L2 * NO;
+    // ---- P1: load + first stage of the forward row FFTs.  item = (batch item, slot, tb, n), n fastest: the loads of
+    // a wavefront cover contiguous (tb, n) runs of a scratch row.  The first item's samples are requested before the
+    // twiddle tables (whose round trip would otherwise sit in front of the data's).
+    const cf* Sb = a.S + (size_t)b0 * bstride_i;
+    cf v0[A];
+    auto p1_load = [&](int item, cf* v) {
+        const int nn = item % NI, tb = (item / NI) % B, bs = item / (NI * B);
+        const int slot = bs & 1, bb = bs >> 1;
+        if (item >= BG * 2 * B * NI || (slot && selfm) || bb >= nb) return false;
+        const unsigned src0 = (unsigned)bb * bstride_i + (unsigned)(slot ? rm : r) * (unsigned)a.L2 * NI + nn;
+#pragma unroll
+        for (int ta = 0; ta < A; ++ta) v[ta] = ld_nt(Sb, 8u * (src0 + (unsigned)(ta * B + tb) * NI));
+        return true;
+    };
+    const bool have0 = p1_load(tid, v0);
+    for (int j = tid; j < LEN; j += NT) {       // contiguous copies behind the master table (fl_spec_aux_fill_f32)
+        tw[j] = a.W[a.n + a.L1 + j];
+        ws[j] = a.W[a.n + a.L1 + a.L2 + j];
     }
     if (DO_INV && tid < 2 * B) {
         const int slot = tid / B, kb = tid - slot * B;
@@ -313,19 +338,19 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
     }
     __syncthreads();
     if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + 0] = clock64();
-    const unsigned bstride_i = (unsigned)a.L1 * (unsigned)a.L2 * NI, bstride_o = (unsigned)a.L1 * (unsigned)a.L2 * NO;
-    // ---- P1: load + first stage of the forward row FFTs.  item = (batch item, slot, tb, n), n fastest: the loads of
-    // a wavefront cover contiguous (tb, n) runs of a scratch row
     {
-        const cf* Sb = a.S + (size_t)b0 * bstride_i;
         for (int item = tid; item < BG * 2 * B * NI; item += NT) {
             const int nn = item % NI, tb = (item / NI) % B, bs = item / (NI * B);
-            const int slot = bs & 1, bb = bs >> 1;
-            if ((slot && selfm) || bb >= nb) continue;
-            const unsigned src0 = (unsigned)bb * bstride_i + (unsigned)(slot ? rm : r) * (unsigned)a.L2 * NI + nn;
             cf v[A];
+            bool have;
+            if (item == tid) {
+                have = have0;
 #pragma unroll
-            for (int ta = 0; ta < A; ++ta) v[ta] = ld_nt(Sb, 8u * (src0 + (unsigned)(ta * B + tb) * NI));
+                for (int ta = 0; ta < A; ++ta) v[ta] = v0[ta];
+            } else {
+                have = p1_load(item, v);
+            }
+            if (!have) continue;
             RegFFT<float, A, false>::run(v);
             cf* u = U + (bs * NCH + nn) * LENP + tb;
             u[0] = v[0];
@@ -649,6 +674,19 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
     if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + 5] = clock64();
 }
 
+// ---------------------------------------------------------------- contiguous twiddle copies
+// W[n + j] = W_L1^j (j < L1), W[n + L1 + j] = W_L2^j (j < L2), W[n + L1 + L2 + j] = W_n^(L1 j) (j < L2): what every
+// workgroup of the three kernels stages into LDS -- as contiguous runs instead of L1 + 2 L2 gathers from the master table
+// (each gather a cache line of its own, and a dependent round trip in front of the first barrier)
+__global__ void __launch_bounds__(256) spec_aux_fill_kernel(cf* W, int n, int L1, int L2) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < L1) W[n + j] = W[j * (n / L1)];
+    if (j < L2) {
+        W[n + L1 + j] = W[j * (n / L2)];
+        W[n + L1 + L2 + j] = W[L1 * j];
+    }
+}
+
 // ---------------------------------------------------------------- bin order conversion
 // natural bin order k <-> row-major order i = (k % L1) * L2 + k / L1 (Nyquist bin L stays at L), per plane
 __global__ void __launch_bounds__(256) permute_bins_kernel(const cf* __restrict__ src, long sp, cf* __restrict__ dst, long dp,
@@ -823,6 +861,22 @@ int fl_spec_plan(int nfft, int* L1, int* L2) {
     if (rc) return rc;
     if (L1) *L1 = l1;
     if (L2) *L2 = l2;
+    return FL_OK;
+}
+
+size_t fl_spec_aux_elems(int nfft) {
+    int l1, l2;
+    if (spec_plan(nfft, l1, l2) != FL_OK) return 0;
+    return (size_t)l1 + 2 * (size_t)l2;
+}
+
+int fl_spec_aux_fill_f32(void* W, int nfft, void* stream) {
+    FL_REQUIRE(W, "spec_aux_fill: null pointer");
+    int l1, l2;
+    int rc = spec_plan(nfft, l1, l2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(spec_aux_fill_kernel, dim3(cdiv_i(l2 > l1 ? l2 : l1, 256)), dim3(256), 0, (hipStream_t)stream, (cf*)W, nfft, l1, l2);
+    FL_CHECK_LAUNCH("spec_aux_fill");
     return FL_OK;
 }
 

@@ -87,11 +87,15 @@ def twiddles(nfft: int, real: torch.dtype, device: torch.device) -> torch.Tensor
         with _twiddles_lock:
             ent = _twiddles.get(key)
             if ent is None:
-                W = torch.empty(nfft, dtype=_cdtype(real), device=device)
                 L = _lib.lib()
+                # float32 tables of the fused pipeline's lengths carry its contiguous copies behind the nfft entries
+                aux = int(L.fl_spec_aux_elems(int(nfft))) if real == torch.float32 else 0
+                W = torch.empty(nfft + aux, dtype=_cdtype(real), device=device)
                 fn = L.fl_twiddle_fill_f32 if real == torch.float32 else L.fl_twiddle_fill_f64
                 cur = torch.cuda.current_stream(device)
                 _lib.check(fn(W.data_ptr(), nfft, cur.cuda_stream), "twiddle_fill")
+                if aux:
+                    _lib.check(L.fl_spec_aux_fill_f32(W.data_ptr(), nfft, cur.cuda_stream), "spec_aux_fill")
                 ev = torch.cuda.Event()
                 ev.record(cur)
                 ent = _twiddles[key] = [W, ev, cur.cuda_stream]

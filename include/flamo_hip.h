@@ -119,6 +119,11 @@ int fl_transpose(const void* src, void* dst, int nbatch, int rows, int cols, lon
  */
 /* FL_OK and (L1, L2) when the fused pipeline supports this transform length */
 int fl_spec_plan(int nfft, int* L1, int* L2);
+/* The three kernels below take W = the master twiddle table (nfft entries, fl_twiddle_fill_f32) FOLLOWED by
+ * fl_spec_aux_elems(nfft) entries of contiguous copies (W_L1^j, W_L2^j, W_n^(L1 j)) written by fl_spec_aux_fill_f32
+ * (launch it behind the master fill on the same stream). */
+size_t fl_spec_aux_elems(int nfft);
+int fl_spec_aux_fill_f32(void* W, int nfft, void* stream);
 /* 1 when (nfft, input channels, output channels) has a fused kernel */
 int fl_spec_supports(int nfft, int n_in, int n_out);
 /* tuning hook: virtual columns per workgroup of the column passes (16 | 32), load group */
