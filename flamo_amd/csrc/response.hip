@@ -10,6 +10,8 @@
 
 namespace fl {
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 // Bin number of element f of a response row.  bin0 >= 0: the contiguous range bin0, bin0+1, ... (bin-sharded execution).
 // bin0 < 0: the whole spectrum in the ROW-MAJOR bin order of the fused Shell pipeline (spectral.hip) with row length
 // L2 = -bin0: element f = k1*L2 + k2 holds bin k1 + L1*k2 (L1 = nfft/2/L2), element nfft/2 the Nyquist bin.
@@ -158,6 +160,87 @@ __global__ void __launch_bounds__(256) sos_response_rc_kernel(const double* __re
     for (int n = 0; n < NIW; ++n) H[(size_t)(m * NIW + n) * h_pitch + f] = acc[n];
 }
 
+// The same operator with the cascade evaluated in FLOAT, two sections per packed instruction.  What makes float safe:
+// every section polynomial is evaluated about the nearer of w = +1 / w = -1,  B = c0 + c1 x + c2 x^2  with  x = 1 - w
+// (bins below nfft/4) or x = 1 + w, the coefficient sums c0 = b0 +- b1 + b2, ... formed in double and x itself formed in
+// double from the float64 twiddle before rounding -- the cancellation that costs plain float evaluation 3 digits at low
+// frequency (shelving sections at 44 Hz) happens in exact arithmetic, what is left is a well-conditioned Horner step.
+// (The backward kernel's float stage uses the same basis.)  The 2 x S/2 running products are two independent chains per
+// packed register.  Measured against the double kernel: response 3e-7 relative, 49 -> ~30 us at config 2.
+template <int NIW>
+__global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double* __restrict__ b, const double* __restrict__ a, int S,
+                                                                  int C, int Nmid, const float* __restrict__ Wr, double g,
+                                                                  const cx<double>* __restrict__ Wd, int nfft, int bin0,
+                                                                  int m_local, cx<float>* __restrict__ G, long g_pitch,
+                                                                  cx<float>* __restrict__ H, long h_pitch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int SP = (S + 1) & ~1;                               // even table pitch: a section pair is one 8-byte read
+    float* cf = reinterpret_cast<float*>(smem);                // [Nmid][basis 2][poly 2][3][SP]
+    float* lw = cf + (size_t)Nmid * 12 * SP;                   // [Nmid][NIW]
+    const int m = blockIdx.y;
+    for (int i = threadIdx.x; i < Nmid * 2 * SP; i += 256) {
+        const int j = i / (2 * SP), rem = i - j * 2 * SP;
+        const int poly = rem / SP, sidx = rem - poly * SP;
+        const double* t = poly ? a : b;
+        const int c = m * Nmid + j;
+        const bool real = sidx < S;                            // padding section: b = a = (1, 0, 0)
+        const double t0 = real ? t[(size_t)sidx * C + c] : 1.0, t1 = real ? t[(size_t)(S + sidx) * C + c] : 0.0,
+                     t2 = real ? t[(size_t)(2 * S + sidx) * C + c] : 0.0;
+        float* lo = cf + ((size_t)j * 4 + 0 * 2 + poly) * 3 * SP;
+        float* hi = cf + ((size_t)j * 4 + 1 * 2 + poly) * 3 * SP;
+        lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
+        hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+    }
+    for (int i = threadIdx.x; i < Nmid * NIW; i += 256) lw[i] = Wr[i];
+    __syncthreads();
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= m_local) return;
+    const int k = bin_of(f, bin0, nfft);
+    const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
+    const cx<double> z1(g * w1.x, g * w1.y);
+    const bool low = 4 * (long)k < nfft;
+    const float xr = low ? (float)(1.0 - z1.x) : (float)(1.0 + z1.x), xi = low ? (float)(-z1.y) : (float)z1.y;
+    cx<float> acc[NIW];
+#pragma unroll
+    for (int n = 0; n < NIW; ++n) acc[n] = cx<float>(0.f, 0.f);
+    for (int j = 0; j < Nmid; ++j) {
+        const float* cb = cf + ((size_t)j * 4 + (low ? 0 : 2)) * 3 * SP;
+        const float* ca = cb + 3 * SP;
+        f2 pbr = (f2)(1.f), pbi = (f2)(0.f), par = (f2)(1.f), pai = (f2)(0.f);
+        for (int s = 0; s < SP; s += 2) {
+            const f2 b0 = *reinterpret_cast<const f2*>(cb + s), b1 = *reinterpret_cast<const f2*>(cb + SP + s),
+                     b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
+            const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
+                     a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
+            const f2 tbr = b1 + b2 * xr, tbi = b2 * xi, tar = a1 + a2 * xr, tai = a2 * xi;
+            const f2 Br = b0 + tbr * xr - tbi * xi, Bi = tbr * xi + tbi * xr;
+            const f2 Ar = a0 + tar * xr - tai * xi, Ai = tar * xi + tai * xr;
+            const f2 nbr = pbr * Br - pbi * Bi, nbi = pbr * Bi + pbi * Br;
+            const f2 nar = par * Ar - pai * Ai, nai = par * Ai + pai * Ar;
+            pbr = nbr; pbi = nbi; par = nar; pai = nai;
+        }
+        // the two chains (even / odd sections) of each product
+        const float Bx = pbr.x * pbr.y - pbi.x * pbi.y, By = pbr.x * pbi.y + pbi.x * pbr.y;
+        const float Ax = par.x * par.y - pai.x * pai.y, Ay = par.x * pai.y + pai.x * par.y;
+        cx<float> hf;
+        if (Ax != 0.f || Ay != 0.f) {
+            const float inv = 1.0f / (Ax * Ax + Ay * Ay);
+            hf = cx<float>((Bx * Ax + By * Ay) * inv, (By * Ax - Bx * Ay) * inv);
+        } else {
+            hf = cx<float>(eps_of<float>(), 0.f);
+        }
+        G[(size_t)(m * Nmid + j) * g_pitch + f] = hf;
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) {
+            const float w = lw[j * NIW + n];
+            acc[n].x += w * hf.x;
+            acc[n].y += w * hf.y;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NIW; ++n) H[(size_t)(m * NIW + n) * h_pitch + f] = acc[n];
+}
+
 // 1/x in double from a float32 hardware reciprocal refined by two Newton steps (|x| within float
 // range, which |B_s|^2 of a filter section always is): ~8 instructions instead of a full divide.
 __device__ inline double fast_rcp(double x) {
@@ -283,8 +366,6 @@ __device__ inline void sos_bwd_slow_section(const SosEval& e, const double* lb, 
     tb = cx<float>((float)tbd.x, (float)tbd.y);
     ta = cx<float>((float)tad.x, (float)tad.y);
 }
-
-typedef float f2 __attribute__((ext_vector_type(2)));
 
 // NIW > 0: "right constant factor" mode.  The cascade's response G (channel pair c = m*Nmid + j) was multiplied by a
 // real constant matrix W (Nmid x NIW) on the right, H[m][n] = sum_j G[m][j] W[j][n] (a Series of Matrix then a
@@ -647,6 +728,7 @@ __global__ void __launch_bounds__(256) geq_sections_bwd_kernel(const void* __res
 }
 
 static int g_sos_chunk = 0;
+static int g_rc_fast = 1;   // cascade-times-matrix forward: float evaluation in the 1 -+ w basis (0: the double kernel)
 static int g_sos_blocks = 0;
 
 static int sos_blocks(int m_local) {
@@ -764,6 +846,10 @@ int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamm
     return sos_impl<double>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, h_pitch, stream);
 }
 int fl_sos_bwd_blocks(int m_local) { return sos_blocks(m_local); }
+int fl_debug_set_rc_fast(int on) {
+    g_rc_fast = on != 0;
+    return FL_OK;
+}
 int fl_debug_set_sos_chunk(int sections_per_thread) {
     g_sos_blocks = sections_per_thread / 100;      // hundreds digit(s): blocks per channel (0 = default)
     sections_per_thread %= 100;
@@ -817,7 +903,15 @@ int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid
     if (m_local == 0) return FL_OK;
     dim3 grid(cdiv_i(m_local, 256), No);
     const size_t lds = (size_t)Nmid * 6 * S * sizeof(double) + (size_t)Nmid * Ni * sizeof(float);
+    const size_t lds_fast = ((size_t)Nmid * 12 * ((S + 1) & ~1) + (size_t)Nmid * Ni) * sizeof(float);
 #define FL_RC_FWD(NIW_)                                                                                                      \
+    if (Ni == NIW_ && g_rc_fast) {                                                                                           \
+        hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_>), grid, dim3(256), lds_fast, (hipStream_t)stream,              \
+                           (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,                  \
+                           (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);      \
+        FL_CHECK_LAUNCH("sos_response_rc_fast");                                                                             \
+        return FL_OK;                                                                                                        \
+    }                                                                                                                        \
     if (Ni == NIW_) {                                                                                                        \
         hipLaunchKernelGGL((sos_response_rc_kernel<NIW_>), grid, dim3(256), lds, (hipStream_t)stream, (const double*)b,      \
                            (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma, (const cx<double>*)Wd, nfft, bin0, \

@@ -118,6 +118,25 @@ class iFFTAntiAlias(Transform, _AntiAliasMixin):
         self._own_transform = self.transform
 
 
+def _cached_integer_delay(module, param, samples_fn):
+    """Integer-delay response H[k] = gamma^m W_n^((k m) mod n), m = round(samples) (dsp.py:3356-3365).  `round` has a zero
+    gradient, so the response is a constant of the parameter VALUES: it is evaluated once per (parameter tensor, version
+    counter, bin range / order) and kept -- a feedback delay network's delays never change during training, and the
+    eight parameter-sized launches in front of the kernel (cast, round, pow, casts) were a tenth of a batch-1 FDN step.
+    (In-place edits through `param.data` do not move the version counter; use assign_value / copy_ under no_grad.)"""
+    import weakref
+    key = (param._version, ops.bin_shard(module.nfft), ops.bin_order(module.nfft), param.device, param.dtype)
+    hit = module.__dict__.get("_int_delay_cache")
+    if hit is not None and hit[0]() is param and hit[1] == key:
+        return hit[2]
+    with torch.no_grad():
+        mi = samples_fn().round()             # half-to-even, as torch.round in the reference
+        amp = (module._gamma_f ** mi).to(module.dtype)
+        H = ops.delay_response(mi.to(torch.int64), amp, module.nfft)
+    module.__dict__["_int_delay_cache"] = (weakref.ref(param), key, H)
+    return H
+
+
 # ============================================================================ core base class
 class DSP(nn.Module):
     """Learnable LTI block: raw ``param`` -> ``map`` -> frequency response -> product with the
@@ -1062,11 +1081,9 @@ class Delay(DSP):
         m = self.get_delays()
 
         def response(param):
-            md = m(param.double())          # seconds -> samples in float64 whatever the module dtype
             if self.isint:
-                mi = md.round()             # half-to-even, as torch.round in the reference
-                amp = (self._gamma_f ** mi).to(self.dtype)
-                return ops.delay_response(mi.to(torch.int64), amp, self.nfft)
+                return _cached_integer_delay(self, param, lambda: m(param.double()))
+            md = m(param.double())          # seconds -> samples in float64 whatever the module dtype
             # fractional (learnable) delays: phase = frac(k m / nfft) and gamma^m in float64
             bin0, m_local = ops.bin_shard(self.nfft)
             k = torch.arange(bin0, bin0 + m_local, device=md.device, dtype=torch.float64)
@@ -1203,12 +1220,12 @@ class GainDelay(DSP):
 
         def response(param):
             g = gains(param)
-            md = self.s2sample(self.map_delay(param[1].double()))      # samples, float64
+            samples = lambda: self.s2sample(self.map_delay(param[1].double()))      # noqa: E731  (samples, float64)
             cd = torch.complex64 if self.dtype == torch.float32 else torch.complex128
             if self.isint:
-                mi = md.round()
-                D = ops.delay_response(mi.to(torch.int64), (self._gamma_f ** mi).to(self.dtype), self.nfft)
+                D = _cached_integer_delay(self, param, samples)
             else:
+                md = samples()
                 bin0, m_local = ops.bin_shard(self.nfft)
                 k = torch.arange(bin0, bin0 + m_local, device=md.device, dtype=torch.float64)
                 k = k.view(-1, *([1] * md.dim()))

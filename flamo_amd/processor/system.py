@@ -56,6 +56,8 @@ def _diag_mul(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     if a.dtype != b.dtype:
         cd = torch.promote_types(a.dtype, b.dtype)
         a, b = a.to(cd), b.to(cd)
+    if a.dim() == 2 and b.dim() == 2 and a.is_cuda and a.is_complex():
+        return ops.mimo(a, b.unsqueeze(0), diag=True).squeeze(0)      # two per-bin diagonals: one pass on the per-bin kernel
     return a * b
 
 

@@ -247,6 +247,8 @@ int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamm
 int fl_sos_bwd_blocks(int m_local);
 /* tuning hook: sections whose sums one thread keeps in registers (0 = default); + 100 * blocks per channel */
 int fl_debug_set_sos_chunk(int sections_per_thread);
+/* test hook: 0 = fl_sos_response_rc_c64 evaluates the cascade in double (default 1: float in the 1 -+ w basis) */
+int fl_debug_set_rc_fast(int on);
 int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
                             int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
 int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
