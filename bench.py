@@ -267,7 +267,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the input-gradient, secondary-workload and bin-sharded legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the input-gradient, secondary-workload and device legs")
+    ap.add_argument("--no-bin-sharded", action="store_true", help="ranks > 1: skip the bin-sharded legs")
     ap.add_argument("--no-graph", action="store_true",
                     help="time eager steps instead of replaying the step from a HIP graph")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -364,7 +365,7 @@ def main():
 
     # ---- bin-sharded forms: every rank takes part (collectives), before rank 0 goes on alone
     sharded = None
-    if dist_on and not args.no_extras and dtype == torch.float32:
+    if dist_on and not args.no_bin_sharded and dtype == torch.float32:
         try:
             sharded = bin_sharded(dev, model, params, x, args.steps)
         except Exception as e:      # noqa: BLE001 -- the headline line must survive a failure of a side leg
