@@ -427,9 +427,84 @@ static int launch_mfma(MmaArgs a, hipStream_t st, int red_slots = 0, int* slots_
     return FL_OK;
 }
 
+// ---------------------------------------------------------------- streaming form of the per-bin product (8 x 8, vector signals)
+// Y[b,:,f] = H[:,:,f] X[b,:,f] with the SIGNAL streamed through an LDS ring by LDS-DMA (global_load_lds, 16 bytes per lane:
+// one instruction moves two 512-byte plane rows of a 64-bin tile, no VGPR round trip) and the RESPONSE of the tile held in
+// registers for the whole batch: one wavefront per workgroup owns 64 bins, fetches its 64 response values per lane once
+// (H crosses the fabric exactly once, whatever the L2 does), then walks the batch in chunks of CB columns -- the chunk
+// t+1 is in flight while chunk t is multiplied and stored.  No barriers (single wavefront), ~32 KB of LDS per workgroup so
+// that the ~3 workgroups a CU gets are resident together.  Bin tiles past M read clamped addresses and store nothing.
+template <int NCH, int CB>
+__global__ void __launch_bounds__(64) mimo_stream_kernel(const cx<float>* __restrict__ H, long hs_m, long hs_n, int conj_h,
+                                                         const cx<float>* __restrict__ X, long xs_b, long xs_n,
+                                                         cx<float>* __restrict__ Y, long ys_b, long ys_m, int B, int M, long x_rows_end) {
+    __shared__ __attribute__((aligned(16))) cx<float> xt[2][CB][NCH][64];
+    const int lane = threadIdx.x;
+    // XCD-aware order is not needed: nothing is shared between workgroups
+    const int f0 = blockIdx.x * 64;
+    const int f = f0 + lane;
+    const bool live = f < M;
+    const int fc = live ? f : M - 1;
+    cx<float> h[NCH][NCH];
+#pragma unroll
+    for (int m = 0; m < NCH; ++m)
+#pragma unroll
+        for (int n = 0; n < NCH; ++n) {
+            h[m][n] = H[(long)m * hs_m + (long)n * hs_n + fc];
+            if (conj_h) h[m][n].y = -h[m][n].y;
+        }
+    // DMA of one chunk: instruction (c, np) moves plane rows n = 2 np and 2 np + 1 of column c: lanes 0..31 the first row,
+    // 32..63 the second, 16 bytes (two bins) each; the LDS image [c][n][64 bins] is lane-linear as the instruction requires
+    const int half = lane >> 5, piece = lane & 31;
+    auto dma = [&](int chunk, int buf) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int col = chunk * CB + c;
+            const cx<float>* colp = X + (long)(col < B ? col : B - 1) * xs_b;
+#pragma unroll
+            for (int np = 0; np < NCH / 2; ++np) {
+                long off = (long)(2 * np + half) * xs_n + f0 + 2 * piece;
+                if (off + 2 > x_rows_end) off = x_rows_end - 2;          // last tile of the last plane: stay inside the allocation
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(colp + off),
+                                                 (__attribute__((address_space(3))) void*)(&xt[buf][c][2 * np][0]), 16, 0, 0);
+            }
+        }
+    };
+    // gridDim.y batch splits: workgroup (tile, s) walks columns [s*per, (s+1)*per)
+    const int per = ((B + (int)gridDim.y - 1) / (int)gridDim.y + CB - 1) / CB * CB;
+    const int c_begin = blockIdx.y * per, c_end = min(B, c_begin + per);
+    if (c_begin >= c_end) return;
+    const int chunk0 = c_begin / CB, nchunk = (c_end - c_begin + CB - 1) / CB;
+    dma(chunk0, 0);
+    for (int tt = 0; tt < nchunk; ++tt) {
+        const int t = chunk0 + tt;
+        const int buf = tt & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): chunk t has landed (and the previous chunk's stores have left)
+        if (tt + 1 < nchunk) dma(t + 1, buf ^ 1);
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int col = t * CB + c;
+            if (col >= c_end) break;
+            cx<float> x[NCH];
+#pragma unroll
+            for (int n = 0; n < NCH; ++n) x[n] = xt[buf][c][n][lane];
+            cx<float>* yp = Y + (long)col * ys_b + f;
+#pragma unroll
+            for (int m = 0; m < NCH; ++m) {
+                cx<float> acc(0.f, 0.f);
+#pragma unroll
+                for (int n = 0; n < NCH; ++n) fma_cx(acc, h[m][n], x[n]);
+                if (live) yp[(long)m * ys_m] = acc;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- host dispatch
 static int g_mimo_variant = 0;   // tuning hook: mt*100 + bt*10 + nu (0 = default choice)
 
+static int g_mimo_stream_split = 1, g_mimo_stream_cb = 4;
+static int g_mimo_stream = 0;   // 8x8 vector-signal products through the LDS-DMA streaming kernel (tuning hook: gradw_cap -16)
 static int g_mimo_hc = 1;
 static int g_gradh_tile = 4;   // 4 = 4x4 tiles (default), 84 = 8x4, 8 = 8x8 where the matrix allows (tuning hook)   // tuning: 0 = constant matrices through the per-bin addressing (gradw_cap -4)
 
@@ -461,6 +536,24 @@ static int mimo_impl(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
             a.D = (cx<float>*)Y; a.sd_i = ys_m; a.sd_j1 = ys_b; a.sd_j2 = ys_k; a.scale = 1.f;
             a.M = M; a.NI = No; a.J1 = B; a.J2 = K; a.T1 = 1; a.T2 = Ni;
             return launch_mfma(a, (hipStream_t)stream);
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+        // 8 x 8 per-bin responses on vector signals with 16-byte-aligned planes: the streaming kernel
+        if (g_mimo_stream && g_mimo_variant == 0 && hs_f == 1 && K == 1 && No == 8 && Ni == 8 && B >= 4 &&
+            reinterpret_cast<uintptr_t>(X) % 16 == 0 && xs_n % 2 == 0 && xs_b % 2 == 0) {
+            const long x_rows_end = (long)(Ni - 1) * xs_n + (xs_n < M + 2 ? xs_n : ((M + 1) & ~1L));   // elements addressable in a column
+            const int bs = g_mimo_stream_split > 0 ? g_mimo_stream_split : 1;
+            if (g_mimo_stream_cb == 2)
+                hipLaunchKernelGGL((mimo_stream_kernel<8, 2>), dim3(cdiv_i(M, 64), bs), dim3(64), 0, (hipStream_t)stream,
+                                   (const cx<float>*)H, hs_m, hs_n, conj_h, (const cx<float>*)X, xs_b, xs_n, (cx<float>*)Y, ys_b,
+                                   ys_m, B, M, x_rows_end);
+            else
+                hipLaunchKernelGGL((mimo_stream_kernel<8, 4>), dim3(cdiv_i(M, 64), bs), dim3(64), 0, (hipStream_t)stream,
+                                   (const cx<float>*)H, hs_m, hs_n, conj_h, (const cx<float>*)X, xs_b, xs_n, (cx<float>*)Y, ys_b,
+                                   ys_m, B, M, x_rows_end);
+            FL_CHECK_LAUNCH("mimo_stream");
+            return FL_OK;
         }
     }
     int bt = ncols >= 4 ? 4 : (ncols >= 2 ? 2 : 1);
@@ -720,6 +813,11 @@ int fl_debug_set_mimo_variant(int variant, int gradw_cap) {
     g_mimo_variant = variant;
     g_mfma_vec = gradw_cap != -2;          // gradw_cap -2: direct stores in the MFMA kernels
     g_mimo_hc = gradw_cap != -4;
+    g_mimo_stream = gradw_cap <= -1600 || gradw_cap == -16;      // -16, or -(1600 + 10*splits + cb)
+    if (gradw_cap <= -1600) {
+        g_mimo_stream_split = ((-gradw_cap - 1600) / 10);
+        g_mimo_stream_cb = (-gradw_cap - 1600) % 10;
+    }
     g_gradh_tile = gradw_cap == -88 ? 8 : (gradw_cap == -84 ? 84 : 4);
     if (gradw_cap < 0) gradw_cap = 0;
     g_gradw_cap = gradw_cap;
