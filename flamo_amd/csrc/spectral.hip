@@ -724,7 +724,14 @@ static int spec_plan(int nfft, int& L1, int& L2) {
     return FL_ERR_UNSUPPORTED;
 }
 
-static int g_spec_vt = 32, g_spec_rg = 2;
+static int g_spec_vt = 0, g_spec_rg = 0;      // 0 = pick per shape (below); fl_debug_set_spec overrides
+
+// Column-pass tile: virtual columns per workgroup and loads in flight per thread group. Measured under graph replay on
+// the whole training step (tools/dbg/graph_ab.py): 16 virtual columns (27 KB of LDS, five workgroups per CU) win for
+// up to 8 channels at every plan length (3 % at nfft=96000, 11 % at 192000); with 16 channels a 16-wide tile would be a
+// single column of 128-byte segments and the 32-wide tile with all loads in flight is ahead.
+static int cols_vt(int G) { return g_spec_vt ? g_spec_vt : (G <= 8 ? 16 : 32); }
+static int cols_rg(int vt, int L1) { return g_spec_rg ? g_spec_rg : (vt == 32 ? 4 : (L1 <= 200 ? 1 : 2)); }
 
 static int cols_setup(ColsArgs& a, int nfft, int Bn, int t_len, int t_lim, int G, const void* W, int vt) {
     int L1, L2;
@@ -756,9 +763,10 @@ static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStrea
     }
     const int vt = a.CT << a.cgs;
     if (vt == 32) {
-        if (g_spec_rg == 1) FL_COLS(32, 1) else if (g_spec_rg == 4) FL_COLS(32, 4) else FL_COLS(32, 2)
+        const int rg = cols_rg(32, a.L1);
+        if (rg == 1) FL_COLS(32, 1) else if (rg == 4) FL_COLS(32, 4) else FL_COLS(32, 2)
     } else {
-        if (g_spec_rg == 1) FL_COLS(16, 1) else FL_COLS(16, 2)
+        if (cols_rg(16, a.L1) == 1) FL_COLS(16, 1) else FL_COLS(16, 2)
     }
 #undef FL_COLS
 }
@@ -895,8 +903,8 @@ int fl_debug_set_spec_times(void* buf) {
 }
 
 int fl_debug_set_spec(int vt, int rg) {
-    g_spec_vt = (vt == 16) ? 16 : 32;
-    g_spec_rg = (rg % 100 == 1 || rg % 100 == 4) ? rg % 100 : 2;
+    g_spec_vt = (vt == 16 || vt == 32) ? vt : 0;
+    g_spec_rg = (rg % 100 == 1 || rg % 100 == 4 || rg % 100 == 2) ? rg % 100 : 0;
     g_mid_bg = (rg >= 100) ? (rg / 100) % 10 : 1;
     g_mid_hfake = (rg / 1000) % 10 == 1;
     g_mid_pfd = (rg / 10000) % 10;       // rg = 10000*prefetch depth + 1000*fake + 100*bg + load group     // rg = 100*(2: two batch items per workgroup) + load group
@@ -909,7 +917,7 @@ int fl_spec_cols_fwd_f32(const void* x, int Bn, int t_len, int G, void* S, const
     FL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 8 == 0, "spec_cols_fwd: x must be 8-byte aligned");
     if (Bn == 0) return FL_OK;
     ColsArgs a = {};
-    int rc = cols_setup(a, nfft, Bn, t_len, t_len, G, W, g_spec_vt);
+    int rc = cols_setup(a, nfft, Bn, t_len, t_len, G, W, cols_vt(G));
     if (rc) return rc;
     a.x = (const float*)x;
     a.S = (cf*)S;
@@ -924,7 +932,7 @@ int fl_spec_cols_inv_f32(const void* S2, void* y, int Bn, int t_len, int t_out, 
     FL_REQUIRE(t_out >= 0 && t_out <= t_len, "spec_cols_inv: t_out must be in [0, t_len]");
     if (Bn == 0) return FL_OK;
     ColsArgs a = {};
-    int rc = cols_setup(a, nfft, Bn, t_len, t_out, G, W, g_spec_vt);
+    int rc = cols_setup(a, nfft, Bn, t_len, t_out, G, W, cols_vt(G));
     if (rc) return rc;
     a.y = (float*)y;
     a.S = (cf*)S2;

@@ -126,7 +126,7 @@ size_t fl_spec_aux_elems(int nfft);
 int fl_spec_aux_fill_f32(void* W, int nfft, void* stream);
 /* 1 when (nfft, input channels, output channels) has a fused kernel */
 int fl_spec_supports(int nfft, int n_in, int n_out);
-/* tuning hook: virtual columns per workgroup of the column passes (16 | 32), load group */
+/* tuning hook: virtual columns per workgroup of the column passes (16 | 32; 0 = per-shape choice), load group (1 | 2 | 4; 0 = auto) */
 int fl_debug_set_spec(int vt, int rg);
 /* tuning hook: device buffer of 8 int64 per workgroup of fl_spec_mid_f32 for cycle stamps at its phase boundaries (null: off) */
 int fl_debug_set_spec_times(void* buf);

@@ -10,8 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from flamo_amd import _lib, ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--vt", type=int, default=32)
-ap.add_argument("--rg", type=int, default=2)
+ap.add_argument("--vt", type=int, default=0)
+ap.add_argument("--rg", type=int, default=0)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--nfft", type=int, default=96000)
 ap.add_argument("--n", type=int, default=8)
