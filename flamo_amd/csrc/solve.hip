@@ -662,6 +662,252 @@ static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_mi
     return FL_ERR_UNSUPPORTED;
 }
 
+
+// ---------------------------------------------------------------- gradients of the factored loop matrix
+// Backward of OUT = (I - diag(l) U diag(r))^-1 R, after the adjoint solve gR = A^-H g.  With P = diag(l) U diag(r) and
+// dP_ij = sum gR_i conj(out_j) (sums over batch b and signal column k), one pass over (gR, OUT, l, r) gives all three:
+//   gU_ij   = sum_{f,b,k} conj(l_i) gR_i conj(r_j out_j)
+//   gl_i[f] = sum_{b,k} gR_i conj((U (r . out))_i)
+//   gr_j[f] = sum_{b,k} (U^H (conj(l) . gR))_j conj(out_j)
+// (the layered form is five launches -- two diagonal products, the outer-product reduction and its final, a matrix
+// product, a per-bin reduction -- each re-reading gR / OUT).  Thread (i, bl): row i of bin f0 + bl, BPI = 256 / NP
+// bins per iteration, bl fastest so the loads of a row run along f.  r . out and conj(l) . gR of the iteration's bins go
+// through LDS; a lane keeps row i of the gU sum in registers across its block's bins; the lanes of a row are combined
+// with a fixed butterfly and the per-block partials summed by a final launch (deterministic).
+template <typename T> struct alignas(2 * sizeof(cx<T>)) cx2 { cx<T> a, b; };
+// 1 + 0i in memory, deliberately not const: a constant the compiler can see through turns the loads of an absent factor
+// back into a branch
+__device__ double kOneRe[2] = {1.0, 0.0};
+__device__ float kOneRef[2] = {1.f, 0.f};
+template <typename T> __device__ inline const cx<T>* one_ptr() {
+    if constexpr (sizeof(T) == 8) return reinterpret_cast<const cx<T>*>(kOneRe);
+    else return reinterpret_cast<const cx<T>*>(kOneRef);
+}
+
+template <typename T, int NP, bool WR>
+__global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud_grads_kernel(Dud<T> d, const cx<T>* __restrict__ gR, const cx<T>* __restrict__ OUT, long s_b,
+                                                        long s_n, long s_k, int B, int M, int N, int K, int bins_per_block,
+                                                        cx<T>* __restrict__ gl, long gl_sn, cx<T>* __restrict__ gr, long gr_sn,
+                                                        cx<T>* __restrict__ partU) {
+    constexpr int BPI = 256 / NP, LDT = NP + 2;      // rows 16-byte aligned and conflict-free for 16-byte reads
+    extern __shared__ __attribute__((aligned(32))) char smem_dg[];
+    cx<T>* Us = reinterpret_cast<cx<T>*>(smem_dg);   // [NP][LDT]
+    cx<T>* t1s = Us + NP * LDT;                        // [2][BPI][LDT]: r . out
+    cx<T>* t2s = t1s + 2 * BPI * LDT;                  // [2][BPI][LDT]: conj(l) . gR
+    const int tid = threadIdx.x, i = tid / BPI, bl = tid % BPI;
+    const bool row = i < N;
+    for (int e = tid; e < NP * NP; e += 256) {
+        const int a = e / NP, b = e % NP;
+        Us[a * LDT + b] = (a < N && b < N) ? d.U[a * N + b] : cx<T>(0, 0);
+    }
+    cx<T> accU[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) accU[j] = cx<T>(0, 0);
+    const int f_begin = blockIdx.x * bins_per_block;
+    const int f_end = min(M, f_begin + bins_per_block);
+    // rounds q = (iteration, b, k) flattened, k fastest.  The chain of a wavefront is what bounds this kernel (every
+    // workgroup is resident at once): the round is kept short -- uniform counters instead of divisions, per-lane base
+    // pointers, 16-byte LDS reads -- and PF rounds of operands are in flight per thread.
+    const int BK = B * K;
+    const int rounds = f_begin < f_end ? ((f_end - f_begin + BPI - 1) / BPI) * BK : 0;
+    struct Ops { cx<T> g, o, l, r; };
+    // Loads are unconditional, from clamped addresses (lanes outside the problem re-read the last valid element and are
+    // zeroed when consumed; an absent factor reads a constant 1 with stride 0): loads under divergent control flow get an
+    // s_waitcnt vmcnt(0) at the join, which would serialise every round on the memory latency.
+    const int ic = min(i, N - 1), span = f_end - f_begin - 1;
+    const long lane_off = (long)ic * s_n + f_begin;
+    const cx<T>* gRp = gR + lane_off;
+    const cx<T>* OUTp = OUT + lane_off;
+    const cx<T>* one = one_ptr<T>();
+    const long l_sf = d.l ? d.l_sf : 0, r_sf = d.r ? d.r_sf : 0;
+    const cx<T>* lp = d.l ? d.l + (long)ic * d.l_sn + (long)f_begin * d.l_sf : one;
+    const cx<T>* rp = d.r ? d.r + (long)ic * d.r_sn + (long)f_begin * d.r_sf : one;
+    int fit = 0, fb = 0, fk = 0;               // fetch side (uniform)
+    auto fetch = [&]() {
+        Ops x;
+        const int fl = min(fit * BPI + bl, span);
+        const long off = (long)fb * s_b + (long)fk * s_k + fl;
+        x.g = gRp[off];
+        x.o = OUTp[off];
+        x.l = lp[(long)fl * l_sf];
+        x.r = rp[(long)fl * r_sf];
+        if (++fk == K) {
+            fk = 0;
+            if (++fb == B) {
+                fb = 0;
+                ++fit;
+            }
+        }
+        return x;
+    };
+    constexpr int PF = 2;
+    Ops ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) ring[u] = fetch();
+    cx<T> gl_acc(0, 0), gr_acc(0, 0);
+    int cit = 0, cbk = 0;                        // consume side (uniform)
+    __syncthreads();                             // U is in LDS
+    // (rounds past the end run on zeros -- no early exit inside the unrolled body, whose phi moves cost more than the
+    // arithmetic they skip)
+    for (int q0 = 0; q0 < rounds; q0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int q = q0 + u;
+            Ops x = ring[u];
+            ring[u] = fetch();
+            if (!(row && cit * BPI + bl <= span)) x.g = x.o = cx<T>(0, 0);
+            cx<T>* t1b = t1s + (q & 1) * BPI * LDT;     // double-buffered: one barrier per round
+            cx<T>* t2b = t2s + (q & 1) * BPI * LDT;
+            const cx<T> t2 = mulc(x.g, x.l);            // conj(l) gR
+            t1b[bl * LDT + i] = x.r * x.o;
+            if (WR) t2b[bl * LDT + i] = t2;
+            __syncthreads();
+            cx<T> v(0, 0);
+            const cx2<T>* t1v = reinterpret_cast<const cx2<T>*>(t1b + bl * LDT);
+            const cx2<T>* urow = reinterpret_cast<const cx2<T>*>(Us + i * LDT);
+#pragma unroll
+            for (int j = 0; j < NP; j += 2) {
+                const cx2<T> tt = t1v[j / 2], uu = urow[j / 2];
+                fma_cxc(accU[j], t2, tt.a);
+                fma_cxc(accU[j + 1], t2, tt.b);
+                fma_cx(v, uu.a, tt.a);
+                fma_cx(v, uu.b, tt.b);
+            }
+            fma_cxc(gl_acc, x.g, v);
+            if (WR) {
+                cx<T> w(0, 0);
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {          // w_i += conj(U_ji) t2_j
+                    const cx<T> uji = Us[j * LDT + i], t2j = t2b[bl * LDT + j];
+                    w.x += uji.x * t2j.x + uji.y * t2j.y;
+                    w.y += uji.x * t2j.y - uji.y * t2j.x;
+                }
+                fma_cxc(gr_acc, w, x.o);
+            }
+            if (++cbk == BK) {
+                const int f = f_begin + cit * BPI + bl;
+                if (row && f < f_end) {
+                    if (gl) gl[(long)i * gl_sn + f] = gl_acc;
+                    if (WR) gr[(long)i * gr_sn + f] = gr_acc;
+                }
+                gl_acc = cx<T>(0, 0);
+                gr_acc = cx<T>(0, 0);
+                cbk = 0;
+                ++cit;
+            }
+        }
+    }
+    if (!partU) return;
+    // the BPI lanes of a row are consecutive threads: butterfly inside the wavefront (BPI <= 64)
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        T vr = accU[j].x, vi = accU[j].y;
+        if constexpr (BPI <= 16) {      // the lanes of a row sit inside one DPP row: register moves, no LDS round trips
+            vr += dpp_mov<0xB1>(vr);    // quad_perm [1,0,3,2]
+            vi += dpp_mov<0xB1>(vi);
+            vr += dpp_mov<0x4E>(vr);    // quad_perm [2,3,0,1]
+            vi += dpp_mov<0x4E>(vi);
+            if constexpr (BPI >= 8) {
+                vr += dpp_mov<0x141>(vr);   // row_half_mirror
+                vi += dpp_mov<0x141>(vi);
+            }
+            if constexpr (BPI >= 16) {
+                vr += dpp_mov<0x140>(vr);   // row_mirror
+                vi += dpp_mov<0x140>(vi);
+            }
+        } else {
+#pragma unroll
+            for (int off = BPI / 2; off >= 1; off >>= 1) {
+                vr += __shfl_xor(vr, off, 64);
+                vi += __shfl_xor(vi, off, 64);
+            }
+        }
+        if (bl == 0 && row && j < N) partU[((size_t)blockIdx.x * N + i) * N + j] = cx<T>(vr, vi);
+    }
+}
+
+// per-block partials -> gU.  Thread (pg, e): element e0 + e, partials pg, pg + 16, ...: 128-byte coalesced reads, 16
+// independent chains per element, combined in a fixed order
+template <typename T>
+__global__ void __launch_bounds__(256) dud_grads_final_kernel(const cx<T>* __restrict__ part, int nblk, int count, cx<T>* __restrict__ gU) {
+    __shared__ cx<T> red[16][17];
+    const int e = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    const int el = blockIdx.x * 16 + e;
+    T vr = 0, vi = 0;
+    if (el < count) {
+#pragma unroll 8
+        for (int b = pg; b < nblk; b += 16) {
+            const cx<T> v = part[(size_t)b * count + el];
+            vr += v.x;
+            vi += v.y;
+        }
+    }
+    red[pg][e] = cx<T>(vr, vi);
+    __syncthreads();
+    if (pg == 0 && el < count) {
+        cx<T> a = red[0][e];
+#pragma unroll
+        for (int p = 1; p < 16; ++p) a = a + red[p][e];
+        gU[el] = a;
+    }
+}
+
+static int dud_grads_blocks(int M, int N) {
+    int np = 4;
+    while (np < N) np *= 2;
+    const int bpi = 256 / np;
+    int nblk = cdiv_i(M, bpi);
+    return nblk > 768 ? 768 : nblk;      // three resident workgroups per CU: one wave of workgroups
+}
+
+template <typename T>
+static int dud_grads_impl(const Dud<T>& d, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N, int K,
+                          void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* stream) {
+    FL_REQUIRE(d.U && gR && OUT, "solve_dud_grads: null pointer");
+    FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0, "solve_dud_grads: bad sizes");
+    FL_REQUIRE((partU == nullptr) == (gU == nullptr), "solve_dud_grads: partU and gU go together");
+    FL_REQUIRE((!gl || (d.l && d.l_sf)) && (!gr || (d.r && d.r_sf)), "solve_dud_grads: gl / gr are per-bin gradients of per-bin factors");
+    const int nmax_lim = sizeof(T) == 8 ? 32 : 64;
+    if (N > nmax_lim) {
+        set_error("solve_dud_grads: N=%d exceeds the register-resident limit (%d) for this precision", N, nmax_lim);
+        return FL_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = dud_grads_blocks(M, N);
+    if (B == 0 || M == 0) {
+        if (gU) {
+            int rc = check_hip(hipMemsetAsync(gU, 0, sizeof(cx<T>) * N * N, st), "solve_dud_grads: memset");
+            if (rc) return rc;
+        }
+        return FL_OK;
+    }
+#define FL_DG(NP_)                                                                                                              \
+    {                                                                                                                           \
+        constexpr int BPI = 256 / NP_;                                                                                          \
+        const int per = cdiv_i(cdiv_i(M, nblk), BPI) * BPI;                                                                     \
+        const size_t lds = ((size_t)NP_ * (NP_ + 2) + 4 * (size_t)BPI * (NP_ + 2)) * sizeof(cx<T>);                             \
+        if (gr)                                                                                                                 \
+            hipLaunchKernelGGL((dud_grads_kernel<T, NP_, true>), dim3(nblk), dim3(256), lds, st, d, (const cx<T>*)gR,           \
+                               (const cx<T>*)OUT, s_b, s_n, s_k, B, M, N, K, per, (cx<T>*)gl, gl_sn, (cx<T>*)gr, gr_sn,         \
+                               (cx<T>*)partU);                                                                                  \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((dud_grads_kernel<T, NP_, false>), dim3(nblk), dim3(256), lds, st, d, (const cx<T>*)gR,          \
+                               (const cx<T>*)OUT, s_b, s_n, s_k, B, M, N, K, per, (cx<T>*)gl, gl_sn, (cx<T>*)gr, gr_sn,         \
+                               (cx<T>*)partU);                                                                                  \
+    }
+    if (N <= 4) FL_DG(4) else if (N <= 8) FL_DG(8) else if (N <= 16) FL_DG(16) else if (N <= 32) FL_DG(32) else {
+        if constexpr (sizeof(T) == 4) FL_DG(64) else return FL_ERR_UNSUPPORTED;
+    }
+#undef FL_DG
+    FL_CHECK_LAUNCH("solve_dud_grads");
+    if (gU) {
+        hipLaunchKernelGGL((dud_grads_final_kernel<T>), dim3(cdiv_i(N * N, 16)), dim3(256), 0, st, (const cx<T>*)partU, nblk, N * N,
+                           (cx<T>*)gU);
+        FL_CHECK_LAUNCH("solve_dud_grads_final");
+    }
+    return FL_OK;
+}
+
 }  // namespace fl
 
 using namespace fl;
@@ -701,5 +947,18 @@ int fl_solve_dud_c128(const void* l, long l_sn, long l_sf, const void* U, const 
     FL_REQUIRE(U, "solve_dud: null mixing matrix");
     Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf};
     return solve_impl<double>(nullptr, 0, d, 1, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+int fl_solve_dud_grads_blocks(int M, int N) { return dud_grads_blocks(M, N); }
+int fl_solve_dud_grads_c64(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, const void* gR,
+                           const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N, int K, void* gl, long gl_sn, void* gr,
+                           long gr_sn, void* partU, void* gU, void* stream) {
+    Dud<float> d = {(const cx<float>*)l, l_sn, l_sf, (const cx<float>*)U, (const cx<float>*)r, r_sn, r_sf};
+    return dud_grads_impl<float>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream);
+}
+int fl_solve_dud_grads_c128(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, const void* gR,
+                            const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N, int K, void* gl, long gl_sn, void* gr,
+                            long gr_sn, void* partU, void* gU, void* stream) {
+    Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf};
+    return dud_grads_impl<double>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream);
 }
 }

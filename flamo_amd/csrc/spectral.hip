@@ -807,7 +807,6 @@ static void launch_mid_bg(const MidArgs& a, hipStream_t st) {
 
 template <int A, int B, int NI, int NO>
 static void launch_mid_n(const MidArgs& a, unsigned, hipStream_t st) {
-    constexpr int LEN = A * B, LENP = LEN | 1, NCH = NI > NO ? NI : NO;
     // (two batch items per workgroup -- the response row applied to two spectra -- measured slower at config 2:
     // 104 us with 256 threads, 118 us with 512, against 98 us; the kernel keeps the BG/MS parameters for that experiment)
     // response present + inverse half: BG batch items per workgroup with the three-sweep product (the response row of a bin

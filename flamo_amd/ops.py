@@ -867,6 +867,33 @@ def _solve_dud_launch(l, U, r, adjoint, R):
     return OUT
 
 
+# one-pass backward of the factored solve (fl_solve_dud_grads_*); False = the layered form (tests compare the two)
+FUSE_DUD_GRADS = True
+
+
+def _dud_grads_launch(lp, Uc, rp, gR, OUT, need_l, need_U, need_r):
+    """(gl (M, N) | None, gU (N, N) | None, gr (M, N) | None) from gR = A^-H g and OUT = A^-1 R (planar, same strides)."""
+    real = _rdtype(OUT)
+    B, M, N, K, s_b, s_n, s_k = _bnk(OUT)
+    assert _bnk(gR) == (B, M, N, K, s_b, s_n, s_k)
+    dev = OUT.device
+    L = _lib.lib()
+    gl = _empty_rows((N,), M, OUT.dtype, dev) if need_l else None
+    gr = _empty_rows((N,), M, OUT.dtype, dev) if need_r else None
+    part = gU = None
+    if need_U:
+        part = torch.empty((L.fl_solve_dud_grads_blocks(M, N), N, N), dtype=OUT.dtype, device=dev)
+        gU = torch.empty((N, N), dtype=OUT.dtype, device=dev)
+    lptr, l_sn, l_sf = _diag_args(lp)
+    rptr, r_sn, r_sf = _diag_args(rp)
+    fn = L.fl_solve_dud_grads_c64 if real == torch.float32 else L.fl_solve_dud_grads_c128
+    ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+    with kernel_timer.span("solve_dud_grads"):
+        _lib.check(fn(lptr, l_sn, l_sf, Uc.data_ptr(), rptr, r_sn, r_sf, gR.data_ptr(), OUT.data_ptr(), s_b, s_n, s_k, B, M, N, K,
+                      ptr(gl), _pitch(M), ptr(gr), _pitch(M), ptr(part), ptr(gU), _stream()), "solve_dud_grads")
+    return (None if gl is None else gl.movedim(-1, 0)), gU, (None if gr is None else gr.movedim(-1, 0))
+
+
 class _SolveDUD(torch.autograd.Function):
     """OUT = (I - diag(l) U diag(r))^-1 R per bin; l, r: per-bin (M,N) / constant (N,) / None."""
 
@@ -892,7 +919,10 @@ class _SolveDUD(torch.autograd.Function):
         gl = gU = gr = None
         need_l, need_U, need_r = ctx.needs_input_grad[0] and lp is not None, ctx.needs_input_grad[1], \
             ctx.needs_input_grad[2] and rp is not None
-        if need_l or need_U or need_r:
+        fusable = (lp is None or lp.dim() == 2) and (rp is None or rp.dim() == 2)      # per-bin or absent diagonal factors
+        if (need_l or need_U or need_r) and fusable and FUSE_DUD_GRADS:
+            gl, gU, gr = _dud_grads_launch(lp, Uc, rp, gR, OUT, need_l, need_U, need_r)
+        elif need_l or need_U or need_r:
             # dP_ij = sum_b gR_i conj(out_j) with P_ij = l_i U_ij r_j, contracted without forming dP:
             t1 = OUT if rp is None else _mimo_launch(rp, rp.dim() == 2, True, False, OUT)   # r * out
             t2 = gR if lp is None else _mimo_launch(lp, lp.dim() == 2, True, True, gR)      # conj(l) * gR

@@ -319,6 +319,20 @@ int fl_solve_dud_c64(const void* l, long l_sn, long l_sf, const void* U, const v
 int fl_solve_dud_c128(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, int adjoint,
                       const void* R, long rs_b, long rs_n, long rs_k, void* OUT, long os_b, long os_n, long os_k,
                       int B, int M, int N, int K, void* stream);
+/* Backward of the factored solve in one pass (replaces the five launches of the layered form in autograd over
+ * system.py:420-424: two diagonal products, an outer-product reduction, a matrix product, a per-bin reduction).
+ * gR = A^-H g (fl_solve_dud with adjoint) and OUT = A^-1 R share the strides (s_b, s_n, s_k), bins contiguous.
+ *   gU[i][j]  = sum_{f,b,k} conj(l_i) gR_i conj(r_j out_j)        (N x N; needs partU: fl_solve_dud_grads_blocks(M,N) x N x N)
+ *   gl[i][f]  = sum_{b,k} gR_i conj((U (r . out))_i)               (per-bin l only; rows gl_sn apart)
+ *   gr[j][f]  = sum_{b,k} (U^H (conj(l) . gR))_j conj(out_j)       (per-bin r only)
+ * Any of gl, gr, (partU, gU) may be NULL.  Deterministic (fixed-order reductions). */
+int fl_solve_dud_grads_blocks(int M, int N);
+int fl_solve_dud_grads_c64(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, const void* gR,
+                           const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N, int K, void* gl, long gl_sn, void* gr,
+                           long gr_sn, void* partU, void* gU, void* stream);
+int fl_solve_dud_grads_c128(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, const void* gR,
+                            const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N, int K, void* gl, long gl_sn, void* gr,
+                            long gr_sn, void* partU, void* gU, void* stream);
 /* tuning/test hook: 0 (default) = N <= 16 factor with rows exchanged in place (compile-time DPP broadcasts,
  * threshold pivoting); 1 = the shuffle kernel with implicit partial pivoting for every N */
 int fl_debug_set_solve_variant(int variant);

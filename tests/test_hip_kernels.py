@@ -528,3 +528,51 @@ def test_factored_solve_all_sizes_and_row_exchanges(gpu, N):
             for variant in (0, 1):
                 for got, want in zip(outs[variant], [Yr.detach()] + list(gr)):
                     assert relerr(got.cpu().to(torch.complex128), want) < tol * scale, (kind, variant)
+
+
+@pytest.mark.parametrize("N", [3, 4, 6, 16, 20, 32, 48])
+@pytest.mark.parametrize("have", [(True, False), (False, True), (True, True), (False, False)])
+def test_factored_solve_one_pass_gradients(gpu, N, have):
+    """fl_solve_dud_grads_* (one pass: gl, gU, gr) against the layered backward (five launches) and against autograd
+    through LAPACK in float64; per-bin / absent diagonal factors, several batch items and signal columns, a bin count
+    that is no multiple of the kernel's bins per iteration."""
+    from flamo_amd import ops
+    torch.manual_seed(7 * N + have[0] + 2 * have[1])
+    M, B, K = 331, 2, 3
+    for cd, tol in ((torch.complex128, 1e-11), (torch.complex64, 3e-5)):
+        if cd == torch.complex128 and N > 32:
+            continue
+        U64 = torch.linalg.qr(torch.randn(N, N, dtype=torch.float64))[0].to(torch.complex128)
+        l64 = 0.95 * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64)) if have[0] else None
+        r64 = (0.7 + 0.25 * torch.rand(M, N, dtype=torch.float64)) * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64)) \
+            if have[1] else None
+        if not have[0] and not have[1]:
+            U64 = 0.9 * U64
+        R64 = torch.randn(B, M, N, K, dtype=torch.complex128)
+        C64 = torch.randn(B, M, N, K, dtype=torch.complex128)
+        names = ["l", "U", "r", "R"]
+        ref_in = [None if t is None else t.clone().requires_grad_(True) for t in (l64, U64, r64, R64)]
+        P = ref_in[1].unsqueeze(0).expand(M, N, N)
+        if have[0]:
+            P = ref_in[0].unsqueeze(-1) * P
+        if have[1]:
+            P = P * ref_in[2].unsqueeze(-2)
+        A = torch.eye(N, dtype=torch.complex128) - P
+        Yr = torch.linalg.solve(A.unsqueeze(0), ref_in[3])
+        live = [i for i, t in enumerate(ref_in) if t is not None]
+        gref = torch.autograd.grad(torch.sum(torch.real(Yr * torch.conj(C64))), [ref_in[i] for i in live])
+        got = {}
+        try:
+            for fused in (True, False):
+                ops.FUSE_DUD_GRADS = fused
+                dev_in = [None if t is None else t.detach().to(gpu, cd).requires_grad_(True) for t in (l64, U64, r64, R64)]
+                Y = ops.solve_dud(dev_in[0], dev_in[1], dev_in[2], dev_in[3])
+                g = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C64.to(gpu, cd)))), [dev_in[i] for i in live])
+                got[fused] = [Y.detach()] + list(g)
+        finally:
+            ops.FUSE_DUD_GRADS = True
+        for fused in (True, False):
+            for name, a, b in zip(["Y"] + [names[i] for i in live], got[fused], [Yr.detach()] + list(gref)):
+                assert relerr(a.cpu().to(torch.complex128), b) < tol, (name, fused, cd)
+        for a, b in zip(got[True], got[False]):
+            assert relerr(a, b) < (1e-12 if cd == torch.complex128 else 3e-6)
