@@ -241,6 +241,64 @@ __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double*
     for (int n = 0; n < NIW; ++n) H[(size_t)(m * NIW + n) * h_pitch + f] = acc[n];
 }
 
+// The plain cascade response (one channel per blockIdx.y) with the same float evaluation: what the float32 modules
+// outside the Matrix-then-cascade operator run (the FDN attenuation filters, a full GEQ matrix in front of a loop).
+// A block stages its channel's two coefficient tables once and walks BINS_PER_BLOCK bins.
+constexpr int kSosFastBins = 1024;
+__global__ void __launch_bounds__(256) sos_response_fast_kernel(const double* __restrict__ b, const double* __restrict__ a, int S, int C,
+                                                               double g, const cx<double>* __restrict__ Wd, int nfft, int bin0,
+                                                               int m_local, cx<float>* __restrict__ H, long h_pitch) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int SP = (S + 1) & ~1;
+    float* cf = reinterpret_cast<float*>(smem);                // [basis 2][poly 2][3][SP]
+    const int c = blockIdx.y;
+    for (int i = threadIdx.x; i < 2 * SP; i += 256) {
+        const int poly = i / SP, sidx = i - poly * SP;
+        const double* t = poly ? a : b;
+        const bool real = sidx < S;                            // padding section: b = a = (1, 0, 0)
+        const double t0 = real ? t[(size_t)sidx * C + c] : 1.0, t1 = real ? t[(size_t)(S + sidx) * C + c] : 0.0,
+                     t2 = real ? t[(size_t)(2 * S + sidx) * C + c] : 0.0;
+        float* lo = cf + (0 * 2 + poly) * 3 * SP;
+        float* hi = cf + (1 * 2 + poly) * 3 * SP;
+        lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
+        hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+    }
+    __syncthreads();
+    const int f_end = min(m_local, (int)(blockIdx.x + 1) * kSosFastBins);
+    for (int f = blockIdx.x * kSosFastBins + threadIdx.x; f < f_end; f += 256) {
+        const int k = bin_of(f, bin0, nfft);
+        const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
+        const cx<double> z1(g * w1.x, g * w1.y);
+        const bool low = 4 * (long)k < nfft;
+        const float xr = low ? (float)(1.0 - z1.x) : (float)(1.0 + z1.x), xi = low ? (float)(-z1.y) : (float)z1.y;
+        const float* cb = cf + (low ? 0 : 6 * SP);
+        const float* ca = cb + 3 * SP;
+        f2 pbr = (f2)(1.f), pbi = (f2)(0.f), par = (f2)(1.f), pai = (f2)(0.f);
+        for (int s = 0; s < SP; s += 2) {
+            const f2 b0 = *reinterpret_cast<const f2*>(cb + s), b1 = *reinterpret_cast<const f2*>(cb + SP + s),
+                     b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
+            const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
+                     a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
+            const f2 tbr = b1 + b2 * xr, tbi = b2 * xi, tar = a1 + a2 * xr, tai = a2 * xi;
+            const f2 Br = b0 + tbr * xr - tbi * xi, Bi = tbr * xi + tbi * xr;
+            const f2 Ar = a0 + tar * xr - tai * xi, Ai = tar * xi + tai * xr;
+            const f2 nbr = pbr * Br - pbi * Bi, nbi = pbr * Bi + pbi * Br;
+            const f2 nar = par * Ar - pai * Ai, nai = par * Ai + pai * Ar;
+            pbr = nbr; pbi = nbi; par = nar; pai = nai;
+        }
+        const float Bx = pbr.x * pbr.y - pbi.x * pbi.y, By = pbr.x * pbi.y + pbi.x * pbr.y;
+        const float Ax = par.x * par.y - pai.x * pai.y, Ay = par.x * pai.y + pai.x * par.y;
+        cx<float> hf;
+        if (Ax != 0.f || Ay != 0.f) {
+            const float inv = 1.0f / (Ax * Ax + Ay * Ay);
+            hf = cx<float>((Bx * Ax + By * Ay) * inv, (By * Ax - Bx * Ay) * inv);
+        } else {
+            hf = cx<float>(eps_of<float>(), 0.f);
+        }
+        H[(size_t)c * h_pitch + f] = hf;
+    }
+}
+
 // 1/x in double from a float32 hardware reciprocal refined by two Newton steps (|x| within float
 // range, which |B_s|^2 of a filter section always is): ~8 instructions instead of a full divide.
 __device__ inline double fast_rcp(double x) {
@@ -755,11 +813,21 @@ static int delay_impl(const int32_t* m, const void* amp, int C, const void* W, i
 
 template <typename T>
 static int sos_impl(const void* b, const void* a, int S, int C, double gamma, const void* Wd, int nfft, int bin0,
-                    int m_local, void* H, long h_pitch, void* stream) {
+                    int m_local, void* H, long h_pitch, void* stream, bool float_eval = false) {
     FL_REQUIRE(b && a && H && Wd, "sos_response: null pointer");
     FL_REQUIRE(h_pitch >= m_local, "sos_response: h_pitch must be >= m_local");
     FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) && m_local >= 0, "sos_response: bad sizes");
     if (m_local == 0) return FL_OK;
+    if constexpr (sizeof(T) == 4) {
+        if (g_rc_fast && float_eval) {      // float evaluation in the 1 -+ w basis, section pairs packed
+            const int SP = (S + 1) & ~1;
+            hipLaunchKernelGGL(sos_response_fast_kernel, dim3(cdiv_i(m_local, kSosFastBins), C), dim3(256), (size_t)12 * SP * sizeof(float),
+                               (hipStream_t)stream, (const double*)b, (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0,
+                               m_local, (cx<float>*)H, h_pitch);
+            FL_CHECK_LAUNCH("sos_response_fast");
+            return FL_OK;
+        }
+    }
     dim3 grid(cdiv_i(m_local, 256), C);
     hipLaunchKernelGGL((sos_response_kernel<T>), grid, dim3(256), (size_t)6 * S * sizeof(double), (hipStream_t)stream, (const double*)b, (const double*)a, S, C,
                        gamma, (const cx<double>*)Wd, nfft, bin0, m_local, (cx<T>*)H, h_pitch);
@@ -841,6 +909,10 @@ int fl_sos_response_c64(const void* b, const void* a, int S, int C, double gamma
                         int m_local, void* H, long h_pitch, void* stream) {
     return sos_impl<float>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, h_pitch, stream);
 }
+int fl_sos_response_f32eval_c64(const void* b, const void* a, int S, int C, double gamma, const void* Wd, int nfft, int bin0,
+                                int m_local, void* H, long h_pitch, void* stream) {
+    return sos_impl<float>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, h_pitch, stream, true);
+}
 int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamma, const void* Wd, int nfft, int bin0,
                         int m_local, void* H, long h_pitch, void* stream) {
     return sos_impl<double>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, h_pitch, stream);
@@ -895,7 +967,7 @@ int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_
 }
 int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
                            const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
-                           void* stream) {
+                           int float_eval, void* stream) {
     FL_REQUIRE(b && a && Wr && Wd && G && H, "sos_response_rc: null pointer");
     FL_REQUIRE(g_pitch >= m_local && h_pitch >= m_local, "sos_response_rc: pitches must be >= m_local");
     FL_REQUIRE(S > 0 && S <= 64 && No > 0 && No <= 65535 && Nmid > 0 && Nmid <= 32 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) &&
@@ -905,7 +977,7 @@ int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid
     const size_t lds = (size_t)Nmid * 6 * S * sizeof(double) + (size_t)Nmid * Ni * sizeof(float);
     const size_t lds_fast = ((size_t)Nmid * 12 * ((S + 1) & ~1) + (size_t)Nmid * Ni) * sizeof(float);
 #define FL_RC_FWD(NIW_)                                                                                                      \
-    if (Ni == NIW_ && g_rc_fast) {                                                                                           \
+    if (Ni == NIW_ && g_rc_fast && float_eval) {                                                                             \
         hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_>), grid, dim3(256), lds_fast, (hipStream_t)stream,              \
                            (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,                  \
                            (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);      \

@@ -966,12 +966,19 @@ def delay_response(m_int: torch.Tensor, amp: torch.Tensor, nfft: int) -> torch.T
     return H.movedim(-1, 0)
 
 
+# float32 modules: evaluate the cascade forward in float (fl_sos_response_f32eval_c64: 3e-7 against 6e-8 of the double
+# evaluation rounded once, about twice as fast) where that is safe for the gradients -- always for graphic-equaliser
+# sections (benign parameter map: gradient within 2e-7 of the double evaluation's), for raw section coefficients only
+# when no gradient is taken: the backward reuses the saved response and a parametric equaliser's map amplifies the extra
+# error to 1e-5 .. 1e-4 (tools/dbg/rc_fast_grad.py).  False = double everywhere.
+FLOAT_CASCADE_EVAL = True
+
 # float32 modules: mixed-precision backward of the cascade (see fl_sos_response_bwd_c64); False
 # forces the all-double evaluation (tests compare the two)
 SOS_BWD_MIXED = True
 
 
-def _sos_forward_launch(bc, ac, gamma, nfft, real):
+def _sos_forward_launch(bc, ac, gamma, nfft, real, float_eval=False):
     """bc, ac: contiguous float64 (3, S, chan...) on the GPU -> (H rows buffer (chan..., pitch)[..., :m_local], cfg)"""
     dev = bc.device
     S = bc.shape[1]
@@ -980,7 +987,10 @@ def _sos_forward_launch(bc, ac, gamma, nfft, real):
     bin0, m_local = _bin0_arg(nfft)
     H = _empty_rows(chan, m_local, _cdtype(real), dev)
     L = _lib.lib()
-    fn = L.fl_sos_response_c64 if real == torch.float32 else L.fl_sos_response_c128
+    if real == torch.float32:
+        fn = L.fl_sos_response_f32eval_c64 if (float_eval and FLOAT_CASCADE_EVAL) else L.fl_sos_response_c64
+    else:
+        fn = L.fl_sos_response_c128
     Wd = twiddles(nfft, torch.float64, dev)
     with kernel_timer.span("sos_response"):
         _lib.check(fn(bc.data_ptr(), ac.data_ptr(), S, C_, float(gamma), Wd.data_ptr(), nfft, bin0, m_local,
@@ -1014,7 +1024,8 @@ class _Sos(torch.autograd.Function):
         if b.dtype != torch.float64 or a.dtype != torch.float64:
             raise TypeError("sos_response: coefficients are passed in float64")
         bc, ac = b.contiguous(), a.contiguous()
-        H, ctx.cfg = _sos_forward_launch(bc, ac, gamma, nfft, real)
+        # raw section coefficients: float evaluation only when no gradient will reuse the saved response (see FLOAT_CASCADE_EVAL)
+        H, ctx.cfg = _sos_forward_launch(bc, ac, gamma, nfft, real, not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         # the float32 backward reuses the forward output instead of re-evaluating the cascade
         keep = H if (real == torch.float32 and SOS_BWD_MIXED) else None
         ctx.save_for_backward(bc, ac, *([keep] if keep is not None else []))
@@ -1082,7 +1093,7 @@ class _GeqCascade(torch.autograd.Function):
         a = torch.empty_like(b)
         _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), kind, nb, C_, consts.data_ptr(), b.data_ptr(), a.data_ptr(),
                                               _stream()), "geq_sections")
-        H, ctx.cfg = _sos_forward_launch(b, a, gamma, nfft, real)
+        H, ctx.cfg = _sos_forward_launch(b, a, gamma, nfft, real, True)     # graphic-equaliser sections
         keep = H if (real == torch.float32 and SOS_BWD_MIXED) else None
         ctx.save_for_backward(xc, consts, b, a, *([keep] if keep is not None else []))
         return H.movedim(-1, 0)
@@ -1108,7 +1119,7 @@ def cascade_rc_supported(real: torch.dtype, n_in: int) -> bool:
     return real == torch.float32 and SOS_BWD_MIXED and int(n_in) in (2, 4, 8, 16)
 
 
-def _cascade_rc_forward(b, a, Wr, gamma, nfft, real):
+def _cascade_rc_forward(b, a, Wr, gamma, nfft, real, float_eval):
     """G = cascade(b, a) (No, Nmid per bin), H = G @ Wr in one launch.  Returns (H view (M, No, Ni), G rows, cfg)."""
     if b.dim() != 4:
         raise ValueError("cascade_rc expects a full (N_out, N_mid) cascade")
@@ -1125,7 +1136,8 @@ def _cascade_rc_forward(b, a, Wr, gamma, nfft, real):
     with kernel_timer.span("sos_response_rc"):
         _lib.check(_lib.lib().fl_sos_response_rc_c64(b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni, Wc.data_ptr(), float(gamma),
                                                      twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local,
-                                                     G.data_ptr(), P, H.data_ptr(), P, _stream()), "sos_response_rc")
+                                                     G.data_ptr(), P, H.data_ptr(), P, int(bool(float_eval and FLOAT_CASCADE_EVAL)),
+                                                     _stream()), "sos_response_rc")
     return H.movedim(-1, 0), G, (float(gamma), nfft, S, No * Nmid, bin0, m_local, real)
 
 
@@ -1157,7 +1169,8 @@ class _SosRC(torch.autograd.Function):
         if b.shape != a.shape or b.shape[0] != 3 or b.dim() != 4:
             raise ValueError("sos_response_rc: b and a must both be (3, n_sections, N_out, N_mid)")
         bc, ac = b.contiguous(), a.contiguous()
-        H, G, ctx.cfg = _cascade_rc_forward(bc, ac, Wr, gamma, nfft, real)
+        H, G, ctx.cfg = _cascade_rc_forward(bc, ac, Wr, gamma, nfft, real,
+                                            not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         ctx.save_for_backward(bc, ac, G, Wr)
         return H
 
@@ -1184,7 +1197,7 @@ class _GeqCascadeRC(torch.autograd.Function):
         a = torch.empty_like(b)
         _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), _geq_in_kind(xc, True), nb, C_, consts.data_ptr(), b.data_ptr(),
                                               a.data_ptr(), _stream()), "geq_sections")
-        H, G, ctx.cfg = _cascade_rc_forward(b, a, Wr, gamma, nfft, real)
+        H, G, ctx.cfg = _cascade_rc_forward(b, a, Wr, gamma, nfft, real, True)
         ctx.save_for_backward(xc, consts, b, a, G, Wr)
         return H
 

@@ -238,6 +238,12 @@ int fl_sos_response_c64(const void* b, const void* a, int S, int C, double gamma
                         int nfft, int bin0, int m_local, void* H, long h_pitch, void* stream);
 int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamma, const void* Wd,
                          int nfft, int bin0, int m_local, void* H, long h_pitch, void* stream);
+/* fl_sos_response_c64 with the cascade evaluated in float (section polynomials about w = +1 / -1 with coefficient sums
+ * formed in double, two sections per packed instruction): response within 3e-7 of the double evaluation's, about twice
+ * as fast.  For forward-only use: the mixed-precision backward reuses the saved forward response, and parameter maps
+ * with cancellation (parametric equalisers) amplify the extra 2e-7 to 1e-5 .. 1e-4 in the gradient. */
+int fl_sos_response_f32eval_c64(const void* b, const void* a, int S, int C, double gamma, const void* Wd,
+                                int nfft, int bin0, int m_local, void* H, long h_pitch, void* stream);
 /* Backward: partial sums over bins of dL/db, dL/da.  part: double (nblk, 2, 3, S, C) where
  * nblk = fl_sos_bwd_blocks(m_local); every entry is written (no zero-fill needed), the caller sums
  * over nblk.  H / h_pitch: the forward output.  _c64 with H != NULL takes the mixed-precision
@@ -247,7 +253,7 @@ int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamm
 int fl_sos_bwd_blocks(int m_local);
 /* tuning hook: sections whose sums one thread keeps in registers (0 = default); + 100 * blocks per channel */
 int fl_debug_set_sos_chunk(int sections_per_thread);
-/* test hook: 0 = fl_sos_response_rc_c64 evaluates the cascade in double (default 1: float in the 1 -+ w basis) */
+/* test hook: 0 = the float evaluations (fl_sos_response_f32eval_c64, fl_sos_response_rc_c64 with float_eval) fall back to double */
 int fl_debug_set_rc_fast(int on);
 int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
                             int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
@@ -256,10 +262,12 @@ int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* H, long h
 /* Cascade response times a real constant matrix on the right -- Series(Matrix, <cascade-type filter>), system.py:299-300
  * over dsp.py:466-468 and dsp.py:922-924 (the reference applies the two modules one after the other):
  *   G[m*Nmid + j, f] as fl_sos_response_c64 (planes of pitch g_pitch; kept for the backward pass),
- *   H[m*Ni + n, f] = sum_j G[m][j] Wr[j][n]   (planes of pitch h_pitch), Wr float (Nmid, Ni) row-major, Ni in {2,4,8,16}. */
+ *   H[m*Ni + n, f] = sum_j G[m][j] Wr[j][n]   (planes of pitch h_pitch), Wr float (Nmid, Ni) row-major, Ni in {2,4,8,16}.
+ * float_eval != 0: the cascade in float as in fl_sos_response_f32eval_c64 (graphic-equaliser sections, whose parameter
+ * map is benign: gradient within 2e-7 of the double evaluation's; or forward-only use). */
 int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
                            const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
-                           void* stream);
+                           int float_eval, void* stream);
 /* The same backward pass when the cascade's response G (No x Nmid per bin, channel pair c = m*Nmid + j) was multiplied on
  * the right by a real constant matrix W (Nmid x Ni) -- Series(Matrix, <cascade-type filter>), system.py:299-300 over
  * dsp.py:466-468 and dsp.py:922-924:  H[m][n] = sum_j G[m][j] W[j][n].  gHfull: dL/dH, planes (m*Ni + n) of pitch g_pitch;

@@ -368,3 +368,56 @@ def test_cascade_times_matrix_float_evaluation(gpu, db):
     worst = [((h.cpu() - Href).abs().max() / Href.abs().max()).item() for h in Hs]
     print(f"\ncascade x matrix response, largest deviation / scale: float evaluation {worst[0]:.1e}, double evaluation {worst[1]:.1e}")
     assert worst[0] < 2e-6 and worst[1] < 5e-7, worst          # measured 8.7e-7 / 1.7e-7
+
+
+@pytest.mark.parametrize("kind", ["geq", "biquad_lowpass", "biquad_bandpass", "svf", "peq"])
+def test_cascade_float_evaluation_plain_response(gpu, kind):
+    """fl_sos_response_f32eval_c64 (1 -+ w basis, section pairs) against the double evaluation for the cascade-type
+    modules: graphic / parametric equalisers (shelving sections at 31 Hz), biquads whose numerator vanishes at DC or
+    Nyquist, state-variable filters.  Forward-only calls take the float evaluation for every kind; with gradients only the
+    graphic equaliser does (its gradient must then agree with the double evaluation's), the others stay in double."""
+    from flamo_amd import _lib, ops
+    from flamo_amd.processor import dsp
+    nfft, N = 48000, 4
+    torch.manual_seed(3)
+    kw = dict(nfft=nfft, alias_decay_db=20.0, device=gpu, dtype=torch.float32, requires_grad=True)
+    if kind == "geq":
+        mod = dsp.parallelGEQ(size=(N,), **kw)
+    elif kind == "peq":
+        mod = dsp.PEQ(size=(N, N), n_bands=6, **kw)
+    elif kind == "svf":
+        mod = dsp.SVF(size=(N, N), n_sections=3, **kw)
+    else:
+        mod = dsp.Biquad(size=(N, N), n_sections=2, filter_type=kind.split("_")[1], **kw)
+    out, names = {}, {}
+    for fast in (1, 0):
+        _lib.lib().fl_debug_set_rc_fast(fast)
+        try:
+            with torch.no_grad():
+                ops.kernel_timer.reset(True)
+                Hn = mod.freq_response(mod.param)
+                torch.cuda.synchronize()
+                ops.kernel_timer.enabled = False
+            mod.param.grad = None
+            H = mod.freq_response(mod.param)
+            c = torch.randn(H.shape, device=gpu, dtype=H.dtype, generator=torch.Generator(device=gpu).manual_seed(5))
+            (H * c.conj()).real.sum().backward()
+            out[fast] = (Hn.clone(), H.detach().clone(), mod.param.grad.clone())
+        finally:
+            _lib.lib().fl_debug_set_rc_fast(1)
+    scale = out[0][0].abs().max()
+    assert ((out[1][0] - out[0][0]).abs().max() / scale).item() < 2e-6       # forward-only: float against double
+    assert relerr(out[1][0], out[0][0]) < 1e-6
+    assert 1e-9 < relerr(out[1][0], out[0][0]), "the float evaluation did not run"
+    if kind == "geq":
+        # a random cotangent makes the gradient a sum with heavy cancellation: the mixed-precision backward itself is a few
+        # 1e-6 from the float64 module either way; the float forward must not be the worse of the two by more than noise
+        m64 = dsp.parallelGEQ(size=(N,), nfft=nfft, alias_decay_db=20.0, device=gpu, dtype=torch.float64, requires_grad=True)
+        with torch.no_grad():
+            m64.param.copy_(mod.param.double())
+        (m64.freq_response(m64.param) * c.to(torch.complex128).conj()).real.sum().backward()
+        e_float, e_double = relerr(out[1][2], m64.param.grad), relerr(out[0][2], m64.param.grad)
+        print(f"\nparallelGEQ gradient against the float64 module: float forward {e_float:.1e}, double forward {e_double:.1e}")
+        assert e_float < 1.5e-5 and e_double < 1.5e-5 and e_float < 2 * e_double + 2e-6
+    else:       # with gradients these modules evaluate in double whatever the hook says
+        assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][2], out[0][2])
