@@ -27,15 +27,21 @@ constexpr int EXPM_SLOTS = EXPM_ORDER + EXPM_SQ + 1;   // stash: A_s, P_2..P_{OR
 // All LDS matrices have rows of NP = N | 1 doubles (odd pitch: transposed reads hit distinct banks).
 // C = alpha * op(A) op(B) [+ C] [+ I];  every thread of the workgroup takes outputs idx, idx+nthreads, ...
 // (pa: row pitch of A -- NP for an LDS matrix, N for a dense one read straight from global memory)
+// NT > 0: the size as a compile-time constant (4, 8, 16, 32 -- the mixing matrices in use): the dot products unroll and
+// the index arithmetic folds; with a runtime N each of the ~15-30 products of a launch spent most of its ~1.4 us in
+// integer divisions and address multiplies of a 16-term loop.
+template <int NT = 0>
 __device__ inline void mm_small(const double* __restrict__ A, bool tA, const double* __restrict__ B, bool tB,
-                                double* __restrict__ C, double alpha, int N, bool add_identity, bool accumulate,
+                                double* __restrict__ C, double alpha, int Nrt, bool add_identity, bool accumulate,
                                 int pa = 0) {
+    const int N = NT > 0 ? NT : Nrt;
     const int NP = N | 1;
     if (pa == 0) pa = NP;
     for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) {
         const int i = idx / N, j = idx - i * N;
         double s0 = 0.0, s1 = 0.0;
         int l = 0;
+#pragma unroll
         for (; l + 1 < N; l += 2) {
             s0 += (tA ? A[l * pa + i] : A[i * pa + l]) * (tB ? B[j * NP + l] : B[l * NP + j]);
             s1 += (tA ? A[(l + 1) * pa + i] : A[i * pa + l + 1]) * (tB ? B[j * NP + l + 1] : B[(l + 1) * NP + j]);
@@ -48,33 +54,48 @@ __device__ inline void mm_small(const double* __restrict__ A, bool tA, const dou
 }
 
 // dense (N x N) global <-> padded LDS
-__device__ inline void lds_load(double* __restrict__ dst, const double* __restrict__ src, int N) {
+template <int NT = 0>
+__device__ inline void lds_load(double* __restrict__ dst, const double* __restrict__ src, int Nrt) {
+    const int N = NT > 0 ? NT : Nrt;
     const int NP = N | 1;
     for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) dst[(idx / N) * NP + idx % N] = src[idx];
 }
-__device__ inline void lds_store(double* __restrict__ dst, const double* __restrict__ src, int N) {
+template <int NT = 0>
+__device__ inline void lds_store(double* __restrict__ dst, const double* __restrict__ src, int Nrt) {
+    const int N = NT > 0 ? NT : Nrt;
     const int NP = N | 1;
     for (int idx = threadIdx.x; idx < N * N; idx += blockDim.x) dst[idx] = src[(idx / N) * NP + idx % N];
 }
 
-template <typename T>
-__global__ void __launch_bounds__(1024) expm_fwd_kernel(const T* __restrict__ X, int N, int skew, T* __restrict__ E,
+template <typename T, int NT>
+__global__ void __launch_bounds__(1024) expm_fwd_kernel(const T* __restrict__ X, int Nrt, int skew, T* __restrict__ E,
                                                        double* __restrict__ stash) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = NT > 0 ? NT : Nrt;
     const int NN = N * N, NP = N | 1;
     double* A = reinterpret_cast<double*>(smem);
     double* P = A + N * NP;
     double* Q = P + N * NP;
-    auto entry = [&](int i, int j) -> double {
-        if (skew) return (j > i) ? (double)X[i * N + j] : ((j < i) ? -(double)X[j * N + i] : 0.0);
-        return (double)X[i * N + j];
-    };
+    // A (unscaled) into LDS with one load per entry, branch-free (a per-column loop over global memory with the skew
+    // test inside was N dependent round trips: 10 of the forward's 21 us at N = 16)
+    for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
+        const int i = idx / N, j = idx - i * N;
+        double v;
+        if (skew) {
+            const double x = (double)X[j > i ? idx : j * N + i];
+            v = (j > i) ? x : ((j < i) ? -x : 0.0);
+        } else {
+            v = (double)X[idx];
+        }
+        A[i * NP + j] = v;
+    }
+    __syncthreads();
     // |A|_1 = largest column sum: one thread per column, then thread 0 picks the squaring count
     __shared__ double colsum[64];
     __shared__ int sq_sh;
     if (threadIdx.x < N) {
         double cs = 0.0;
-        for (int i = 0; i < N; ++i) cs += fabs(entry(i, threadIdx.x));
+        for (int i = 0; i < N; ++i) cs += fabs(A[i * NP + threadIdx.x]);
         colsum[threadIdx.x] = cs;
     }
     __syncthreads();
@@ -96,31 +117,32 @@ __global__ void __launch_bounds__(1024) expm_fwd_kernel(const T* __restrict__ X,
     const double scale = ldexp(1.0, -SQ);
     for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
         const int i = idx / N, j = idx - i * N;
-        const double v = entry(i, j) * scale;
+        const double v = A[i * NP + j] * scale;
         A[i * NP + j] = v;
         stash[idx] = v;
         P[i * NP + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
     for (int k = EXPM_ORDER; k >= 1; --k) {
-        lds_store(stash + (size_t)k * NN, P, N);                    // P_{k+1}
-        mm_small(A, false, P, false, Q, 1.0 / k, N, true, false);   // P_k = I + A P_{k+1} / k
+        lds_store<NT>(stash + (size_t)k * NN, P, N);                    // P_{k+1}
+        mm_small<NT>(A, false, P, false, Q, 1.0 / k, N, true, false);   // P_k = I + A P_{k+1} / k
         __syncthreads();
         double* t = P; P = Q; Q = t;
     }
     for (int i = 0; i < SQ; ++i) {
-        lds_store(stash + (size_t)(EXPM_ORDER + 1 + i) * NN, P, N);  // E_i
-        mm_small(P, false, P, false, Q, 1.0, N, false, false);
+        lds_store<NT>(stash + (size_t)(EXPM_ORDER + 1 + i) * NN, P, N);  // E_i
+        mm_small<NT>(P, false, P, false, Q, 1.0, N, false, false);
         __syncthreads();
         double* t = P; P = Q; Q = t;
     }
     for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) E[idx] = (T)P[(idx / N) * NP + idx % N];
 }
 
-template <typename T>
-__global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE, int N, int skew,
+template <typename T, int NT>
+__global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE, int Nrt, int skew,
                                                        const double* __restrict__ stash, T* __restrict__ gX) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = NT > 0 ? NT : Nrt;
     const int NN = N * N, NP = N | 1;
     double* G = reinterpret_cast<double*>(smem);
     double* Q = G + N * NP;
@@ -135,24 +157,46 @@ __global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE
         G[o] = (double)gE[idx];
         dA[o] = 0.0;
     }
-    if (as_lds) lds_load(S0 + N * NP, stash, N);
+    if (as_lds) lds_load<NT>(S0 + N * NP, stash, N);
     const int SQ = (int)stash[(size_t)EXPM_SLOTS * NN];            // the forward pass's squaring count
-    for (int i = SQ - 1; i >= 0; --i) {                            // E_{i+1} = E_i^2
-        lds_load(S0, stash + (size_t)(EXPM_ORDER + 1 + i) * NN, N);
+    // The stashed matrix of step t+1 is requested while step t multiplies (at most 4 entries per thread: N <= 64,
+    // 1024 threads): the steps are a dependent chain, and a global round trip in front of each was most of this kernel.
+    // step t = 0..SQ-1: E_{SQ-1-t};  t = SQ..SQ+ORDER-1: P_{t-SQ+2}
+    const int steps = SQ + EXPM_ORDER;
+    auto slot_of = [&](int t) { return t < SQ ? EXPM_ORDER + 1 + (SQ - 1 - t) : t - SQ + 1; };
+    double nxt[4];
+    auto fetch = [&](int t) {
+        const double* src = stash + (size_t)slot_of(t) * NN;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = threadIdx.x + u * blockDim.x;
+            nxt[u] = (t < steps && idx < NN) ? src[idx] : 0.0;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = threadIdx.x + u * blockDim.x;
+            if (idx < NN) S0[(idx / N) * NP + idx % N] = nxt[u];
+        }
+    };
+    fetch(0);
+    for (int t = 0; t < steps; ++t) {
+        __syncthreads();           // the previous step's readers of S0 are done
+        commit();
+        fetch(t + 1);
         __syncthreads();
-        mm_small(G, false, S0, true, Q, 1.0, N, false, false);      // G E_i^T
-        mm_small(S0, true, G, false, Q, 1.0, N, false, true);       // + E_i^T G  (a thread re-reads only its own Q entries)
-        __syncthreads();
-        double* t = G; G = Q; Q = t;
+        if (t < SQ) {                                                  // E_{i+1} = E_i^2
+            mm_small<NT>(G, false, S0, true, Q, 1.0, N, false, false);      // G E_i^T
+            mm_small<NT>(S0, true, G, false, Q, 1.0, N, false, true);       // + E_i^T G  (a thread re-reads only its own Q entries)
+        } else {                                                       // P_k = I + A_s P_{k+1} / k
+            const int k = t - SQ + 1;
+            mm_small<NT>(G, false, S0, true, dA, 1.0 / k, N, false, true);  // dA_s += G P_{k+1}^T / k
+            mm_small<NT>(S1, true, G, false, Q, 1.0 / k, N, false, false, p1);  // G <- A_s^T G / k
+        }
+        double* tt = G; G = Q; Q = tt;
     }
-    for (int k = 1; k <= EXPM_ORDER; ++k) {                        // P_k = I + A_s P_{k+1} / k
-        lds_load(S0, stash + (size_t)k * NN, N);
-        __syncthreads();
-        mm_small(G, false, S0, true, dA, 1.0 / k, N, false, true);  // dA_s += G P_{k+1}^T / k
-        mm_small(S1, true, G, false, Q, 1.0 / k, N, false, false, p1);  // G <- A_s^T G / k
-        __syncthreads();
-        double* t = G; G = Q; Q = t;
-    }
+    __syncthreads();
     const double scale = ldexp(1.0, -SQ);
     for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
         const int i = idx / N, j = idx - i * N;
@@ -174,12 +218,21 @@ static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* stash, v
     FL_REQUIRE(N >= 1 && N <= 64, "matrix_exp: 1 <= N <= 64 (one workgroup, matrices in LDS)");
     const size_t lds = (size_t)3 * N * (N | 1) * sizeof(double);
     if (lds > 64 * 1024) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_fwd_kernel<T>),
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_fwd_kernel<T, 0>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "matrix_exp LDS size");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((expm_fwd_kernel<T>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)X, N, skew,
-                       (T*)E, (double*)stash);
+#define FL_EXPM_FWD(NT_)                                                                                                   \
+    hipLaunchKernelGGL((expm_fwd_kernel<T, NT_>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)X, N, \
+                       skew, (T*)E, (double*)stash)
+    switch (N) {        // (the fixed sizes all fit the default 64 KB of dynamic LDS)
+        case 4: FL_EXPM_FWD(4); break;
+        case 8: FL_EXPM_FWD(8); break;
+        case 16: FL_EXPM_FWD(16); break;
+        case 32: FL_EXPM_FWD(32); break;
+        default: FL_EXPM_FWD(0);
+    }
+#undef FL_EXPM_FWD
     FL_CHECK_LAUNCH("matrix_exp");
     return FL_OK;
 }
@@ -191,12 +244,21 @@ static int expm_bwd_impl(const void* gE, int N, int skew, const void* stash, voi
     size_t lds = (size_t)5 * N * (N | 1) * sizeof(double);
     if (lds > 160 * 1024) lds = (size_t)4 * N * (N | 1) * sizeof(double);
     if (lds > 64 * 1024) {
-        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_bwd_kernel<T>),
+        int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_bwd_kernel<T, 0>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "matrix_exp_bwd LDS size");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((expm_bwd_kernel<T>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)gE, N, skew,
-                       (const double*)stash, (T*)gX);
+#define FL_EXPM_BWD(NT_)                                                                                                     \
+    hipLaunchKernelGGL((expm_bwd_kernel<T, NT_>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)gE, N, \
+                       skew, (const double*)stash, (T*)gX)
+    switch (N) {
+        case 4: FL_EXPM_BWD(4); break;
+        case 8: FL_EXPM_BWD(8); break;
+        case 16: FL_EXPM_BWD(16); break;
+        case 32: FL_EXPM_BWD(32); break;
+        default: FL_EXPM_BWD(0);
+    }
+#undef FL_EXPM_BWD
     FL_CHECK_LAUNCH("matrix_exp_bwd");
     return FL_OK;
 }
