@@ -60,6 +60,8 @@ _SIGNATURES = {
     "fl_debug_set_mimo_variant": (_i, [_i, _i]),
     "fl_mimo_gradw_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fl_mimo_gradw_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradw_re_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradw_re_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fl_delay_response_c64": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _l, _vp]),
     "fl_delay_response_c128": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _l, _vp]),
     "fl_sos_response_c64": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _l, _vp]),
@@ -93,6 +95,10 @@ _SIGNATURES = {
     "fl_matrix_exp_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "fl_matrix_exp_bwd_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "fl_matrix_exp_bwd_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "fl_matrix_exp_cplx_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "fl_matrix_exp_cplx_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "fl_matrix_exp_bwd_cplx_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "fl_matrix_exp_bwd_cplx_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "fl_eig_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
     "fl_eig_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
 }

@@ -69,7 +69,7 @@ __device__ inline void lds_store(double* __restrict__ dst, const double* __restr
 
 template <typename T, int NT>
 __global__ void __launch_bounds__(1024) expm_fwd_kernel(const T* __restrict__ X, int Nrt, int skew, T* __restrict__ E,
-                                                       double* __restrict__ stash) {
+                                                       double* __restrict__ stash, int cplx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = NT > 0 ? NT : Nrt;
     const int NN = N * N, NP = N | 1;
@@ -135,12 +135,21 @@ __global__ void __launch_bounds__(1024) expm_fwd_kernel(const T* __restrict__ X,
         __syncthreads();
         double* t = P; P = Q; Q = t;
     }
-    for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) E[idx] = (T)P[(idx / N) * NP + idx % N];
+    // cplx: E is stored as the complex matrix (re, 0) the per-bin kernels take (no real -> complex pass afterwards)
+    for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
+        const T v = (T)P[(idx / N) * NP + idx % N];
+        if (cplx) {
+            E[2 * idx] = v;
+            E[2 * idx + 1] = (T)0;
+        } else {
+            E[idx] = v;
+        }
+    }
 }
 
 template <typename T, int NT>
 __global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE, int Nrt, int skew,
-                                                       const double* __restrict__ stash, T* __restrict__ gX) {
+                                                       const double* __restrict__ stash, T* __restrict__ gX, int cplx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = NT > 0 ? NT : Nrt;
     const int NN = N * N, NP = N | 1;
@@ -154,7 +163,7 @@ __global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE
     const int p1 = as_lds ? NP : N;
     for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
         const int o = (idx / N) * NP + idx % N;
-        G[o] = (double)gE[idx];
+        G[o] = (double)gE[cplx ? 2 * idx : idx];      // cplx: the real part of a complex gradient
         dA[o] = 0.0;
     }
     if (as_lds) lds_load<NT>(S0 + N * NP, stash, N);
@@ -213,7 +222,7 @@ static int expm_threads(int N) {
 }
 
 template <typename T>
-static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* stash, void* stream) {
+static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* stash, void* stream, int cplx = 0) {
     FL_REQUIRE(X && E && stash, "matrix_exp: null pointer");
     FL_REQUIRE(N >= 1 && N <= 64, "matrix_exp: 1 <= N <= 64 (one workgroup, matrices in LDS)");
     const size_t lds = (size_t)3 * N * (N | 1) * sizeof(double);
@@ -224,7 +233,7 @@ static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* stash, v
     }
 #define FL_EXPM_FWD(NT_)                                                                                                   \
     hipLaunchKernelGGL((expm_fwd_kernel<T, NT_>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)X, N, \
-                       skew, (T*)E, (double*)stash)
+                       skew, (T*)E, (double*)stash, cplx)
     switch (N) {        // (the fixed sizes all fit the default 64 KB of dynamic LDS)
         case 4: FL_EXPM_FWD(4); break;
         case 8: FL_EXPM_FWD(8); break;
@@ -238,7 +247,7 @@ static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* stash, v
 }
 
 template <typename T>
-static int expm_bwd_impl(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
+static int expm_bwd_impl(const void* gE, int N, int skew, const void* stash, void* gX, void* stream, int cplx = 0) {
     FL_REQUIRE(gE && stash && gX, "matrix_exp_bwd: null pointer");
     FL_REQUIRE(N >= 1 && N <= 64, "matrix_exp_bwd: 1 <= N <= 64");
     size_t lds = (size_t)5 * N * (N | 1) * sizeof(double);
@@ -250,7 +259,7 @@ static int expm_bwd_impl(const void* gE, int N, int skew, const void* stash, voi
     }
 #define FL_EXPM_BWD(NT_)                                                                                                     \
     hipLaunchKernelGGL((expm_bwd_kernel<T, NT_>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)gE, N, \
-                       skew, (const double*)stash, (T*)gX)
+                       skew, (const double*)stash, (T*)gX, cplx)
     switch (N) {
         case 4: FL_EXPM_BWD(4); break;
         case 8: FL_EXPM_BWD(8); break;
@@ -280,5 +289,17 @@ int fl_matrix_exp_bwd_f32(const void* gE, int N, int skew, const void* stash, vo
 }
 int fl_matrix_exp_bwd_f64(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
     return expm_bwd_impl<double>(gE, N, skew, stash, gX, stream);
+}
+int fl_matrix_exp_cplx_f32(const void* X, int N, int skew, void* E, void* stash, void* stream) {
+    return expm_fwd_impl<float>(X, N, skew, E, stash, stream, 1);
+}
+int fl_matrix_exp_cplx_f64(const void* X, int N, int skew, void* E, void* stash, void* stream) {
+    return expm_fwd_impl<double>(X, N, skew, E, stash, stream, 1);
+}
+int fl_matrix_exp_bwd_cplx_f32(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
+    return expm_bwd_impl<float>(gE, N, skew, stash, gX, stream, 1);
+}
+int fl_matrix_exp_bwd_cplx_f64(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
+    return expm_bwd_impl<double>(gE, N, skew, stash, gX, stream, 1);
 }
 }

@@ -60,8 +60,12 @@ __global__ void __launch_bounds__(256) mimo_full_kernel(
 #pragma unroll
             for (int mm = 0; mm < MT; ++mm) {
                 const int m = m0 + mm;
-                h[u][mm] = (nv && m < No) ? Hf[(long)m * hs_m + (long)n * hs_n] : cx<T>(0, 0);
-                if (conj_h) h[u][mm].y = -h[u][mm].y;
+                if (HC && (conj_h & 2)) {     // real constant matrix (strides in real elements): no complex copy of it exists
+                    h[u][mm] = (nv && m < No) ? cx<T>(reinterpret_cast<const T*>(H)[(long)m * hs_m + (long)n * hs_n], 0) : cx<T>(0, 0);
+                } else {
+                    h[u][mm] = (nv && m < No) ? Hf[(long)m * hs_m + (long)n * hs_n] : cx<T>(0, 0);
+                    if (conj_h & 1) h[u][mm].y = -h[u][mm].y;
+                }
             }
 #pragma unroll
             for (int c = 0; c < BT; ++c) x[u][c] = (nv && cv[c]) ? X[xoff[c] + (long)n * xs_n] : cx<T>(0, 0);
@@ -512,7 +516,7 @@ template <typename T, int MT, int BT, int NU>
 static void launch_full_one(dim3 grid, int nct, int nmt, hipStream_t st, const cx<T>* H, long hs_f, long hs_m, long hs_n, int conj_h,
                             const cx<T>* X, long xs_b, long xs_n, long xs_k, cx<T>* Y, long ys_b, long ys_m, long ys_k,
                             int B, int M, int No, int Ni, int K) {
-    if (NU == 1 && hs_f == 0 && g_mimo_hc)
+    if (NU == 1 && hs_f == 0 && (g_mimo_hc || (conj_h & 2)))
         hipLaunchKernelGGL((mimo_full_kernel<T, MT, BT, 1, true>), grid, dim3(256), 0, st, H, hs_f, hs_m, hs_n, conj_h, X, xs_b, xs_n,
                            xs_k, Y, ys_b, ys_m, ys_k, B, M, No, Ni, K, nct, nmt);
     else
@@ -528,8 +532,10 @@ static int mimo_impl(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
     FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo: bad sizes");
     if (B == 0 || M == 0) return FL_OK;
     const int ncols = B * K;
+    const bool h_real = (conj_h & 2) != 0;
+    FL_REQUIRE(!h_real || (hs_f == 0 && g_mimo_variant == 0), "mimo: a real matrix must be frequency independent (hs_f = 0)");
     if constexpr (sizeof(T) == 4) {
-        if (g_mimo_variant == 0 && mfma_applies(No, ncols, Ni)) {
+        if (g_mimo_variant == 0 && !h_real && mfma_applies(No, ncols, Ni)) {
             MmaArgs a = {};
             a.A = (const cx<float>*)H; a.sa_f = hs_f; a.sa_i = hs_m; a.sa_t1 = 0; a.sa_t2 = hs_n; a.conj_a = conj_h;
             a.B = (const cx<float>*)X; a.sb_j1 = xs_b; a.sb_j2 = xs_k; a.sb_t1 = 0; a.sb_t2 = xs_n; a.conj_b = 0;
@@ -540,7 +546,7 @@ static int mimo_impl(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
     }
     if constexpr (sizeof(T) == 4) {
         // 8 x 8 per-bin responses on vector signals with 16-byte-aligned planes: the streaming kernel
-        if (g_mimo_stream && g_mimo_variant == 0 && hs_f == 1 && K == 1 && No == 8 && Ni == 8 && B >= 4 &&
+        if (g_mimo_stream && g_mimo_variant == 0 && !h_real && hs_f == 1 && K == 1 && No == 8 && Ni == 8 && B >= 4 &&
             reinterpret_cast<uintptr_t>(X) % 16 == 0 && xs_n % 2 == 0 && xs_b % 2 == 0) {
             const long x_rows_end = (long)(Ni - 1) * xs_n + (xs_n < M + 2 ? xs_n : ((M + 1) & ~1L));   // elements addressable in a column
             const int bs = g_mimo_stream_split > 0 ? g_mimo_stream_split : 1;
@@ -729,7 +735,7 @@ __global__ void __launch_bounds__(256) mimo_gradw_kernel(
 // dependent L2 latency)
 template <typename T>
 __global__ void __launch_bounds__(256) mimo_gradw_final_kernel(const cx<T>* __restrict__ part, int nblk, int count,
-                                                              cx<T>* __restrict__ dW) {
+                                                              cx<T>* __restrict__ dW, int real_out) {
     const int lane = threadIdx.x & 63;
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= count) return;
@@ -744,7 +750,11 @@ __global__ void __launch_bounds__(256) mimo_gradw_final_kernel(const cx<T>* __re
         vr += __shfl_xor(vr, off, 64);
         vi += __shfl_xor(vi, off, 64);
     }
-    if (lane == 0) dW[e] = cx<T>(vr, vi);
+    // real_out: the matrix is real (its complex cast never existed): its gradient is the real part, stored as a real array
+    if (lane == 0) {
+        if (real_out) reinterpret_cast<T*>(dW)[e] = vr;
+        else dW[e] = cx<T>(vr, vi);
+    }
 }
 
 static int g_gradw_cap = 0;
@@ -758,7 +768,7 @@ static int gradw_blocks(int M) {
 
 template <typename T>
 static int gradw_impl(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                      void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream) {
+                      void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream, int real_out = 0) {
     FL_REQUIRE(G && X && part && dW, "mimo_gradw: null pointer");
     FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo_gradw: bad sizes");
     // 8x8 tiles where the matrix allows: every element of G and X is then read No/8 (Ni/8) times
@@ -775,7 +785,7 @@ static int gradw_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
             int rc = launch_mfma(a, (hipStream_t)stream, gradw_blocks(M), &slots);
             if (rc) return rc;
             hipLaunchKernelGGL((mimo_gradw_final_kernel<T>), dim3(cdiv_i((long)No * Ni, 4)), dim3(256), 0, (hipStream_t)stream,
-                               (const cx<T>*)part, slots, No * Ni, (cx<T>*)dW);
+                               (const cx<T>*)part, slots, No * Ni, (cx<T>*)dW, real_out);
             FL_CHECK_LAUNCH("mimo_gradw_final");
             return FL_OK;
         }
@@ -794,7 +804,7 @@ static int gradw_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
                            gs_k, (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)part, B, M, No, Ni, K);
     FL_CHECK_LAUNCH("mimo_gradw");
     hipLaunchKernelGGL((mimo_gradw_final_kernel<T>), dim3(cdiv_i((long)No * Ni, 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const cx<T>*)part, (int)grid.x, No * Ni, (cx<T>*)dW);
+                       (const cx<T>*)part, (int)grid.x, No * Ni, (cx<T>*)dW, real_out);
     FL_CHECK_LAUNCH("mimo_gradw_final");
     return FL_OK;
 }
@@ -830,6 +840,15 @@ int fl_mimo_gradw_c64(const void* G, long gs_b, long gs_m, long gs_k, const void
 int fl_mimo_gradw_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
                        void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream) {
     return gradw_impl<double>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, part, dW, B, M, No, Ni, K, stream);
+}
+
+int fl_mimo_gradw_re_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                         void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream) {
+    return gradw_impl<float>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, part, dW, B, M, No, Ni, K, stream, 1);
+}
+int fl_mimo_gradw_re_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                          void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream) {
+    return gradw_impl<double>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, part, dW, B, M, No, Ni, K, stream, 1);
 }
 
 int fl_mimo_c64(const void* H, long hs_f, long hs_m, long hs_n, int conj_h, const void* X, long xs_b, long xs_n, long xs_k,

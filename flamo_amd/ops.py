@@ -781,10 +781,81 @@ class _Mimo(torch.autograd.Function):
         return gH, gX, None
 
 
+# A real frequency-independent matrix (Gain, Matrix) is applied as it is (fl_mimo_* with conj_h bit 1, real gradient from
+# fl_mimo_gradw_re_*): the real -> complex cast of the reference (dsp.py:466-468) and its backward are three tiny launches
+# per module and step, which at batch 1 is what a feedback delay network's input and output gains cost.  False = cast.
+REAL_CONST_MIMO = True
+
+
+def _mimo_real_launch(W, conj_t, X):
+    """Y = W X or W^T X for a real (No, Ni) matrix W of X's precision."""
+    real = _rdtype(X)
+    B, M, Nx, K, xs_b, xs_n, xs_k = _bnk(X)
+    hs_m, hs_n = W.stride(0), W.stride(1)
+    No, Ni = W.shape
+    if conj_t:
+        No, Ni, hs_m, hs_n = Ni, No, hs_n, hs_m
+    if Ni != Nx:
+        raise ValueError(f"response expects {Ni} input channels, signal has {Nx}")
+    Y = _empty_planar((B, M, No, *X.shape[3:]), X.dtype, X.device)
+    _, _, _, _, ys_b, ys_m, ys_k = _bnk(Y)
+    L = _lib.lib()
+    fn = L.fl_mimo_c64 if real == torch.float32 else L.fl_mimo_c128
+    with kernel_timer.span("mimo_const_real" + ("_adj" if conj_t else "_fwd") + f"[cols={B * K},{No}x{Ni}]"):
+        _lib.check(fn(W.data_ptr(), 0, hs_m, hs_n, 2, X.data_ptr(), xs_b, xs_n, xs_k, Y.data_ptr(), ys_b, ys_m, ys_k, B, M, No, Ni,
+                      K, _stream()), "mimo")
+    return Y
+
+
+class _MimoRealConst(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, X):
+        _require_gpu(W, X)
+        Xp = to_planar(X.resolve_conj())
+        ctx.save_for_backward(W, Xp)
+        return _mimo_real_launch(W, False, Xp)
+
+    @staticmethod
+    def backward(ctx, gY):
+        W, Xp = ctx.saved_tensors
+        gY = to_planar(gY.resolve_conj())
+        gW = gX = None
+        if ctx.needs_input_grad[1]:
+            gX = _mimo_real_launch(W, True, gY)
+        if ctx.needs_input_grad[0]:
+            real = _rdtype(Xp)
+            B, M, Ni, K, xs_b, xs_n, xs_k = _bnk(Xp)
+            _, _, No, _, gs_b, gs_m, gs_k = _bnk(gY)
+            L = _lib.lib()
+            part = torch.empty((L.fl_mimo_gradw_blocks(M), No, Ni), dtype=Xp.dtype, device=Xp.device)
+            gW = torch.empty((No, Ni), dtype=real, device=Xp.device)
+            fn = L.fl_mimo_gradw_re_c64 if real == torch.float32 else L.fl_mimo_gradw_re_c128
+            with kernel_timer.span(f"mimo_gradw[cols={B * K},{No}x{Ni}]"):
+                _lib.check(fn(gY.data_ptr(), gs_b, gs_m, gs_k, Xp.data_ptr(), xs_b, xs_n, xs_k, part.data_ptr(), gW.data_ptr(), B, M,
+                              No, Ni, K, _stream()), "mimo_gradw")
+        return gW, gX
+
+
+def _real_const_applies(H, X, diag) -> bool:
+    """a real (No, Ni) matrix of the signal's precision, small enough that the lane-per-bin kernel (the one with the real
+    path) is the kernel the product would take anyway (the matrix-core kernels start at 16 rows x 8 columns x 8 deep)"""
+    if diag or H.is_complex() or H.dim() != 2 or not X.is_complex() or not X.is_cuda or not REAL_CONST_MIMO:
+        return False
+    if H.dtype != _rdtype(X):
+        return False
+    cols = X.shape[0] * _prod(X.shape[3:])
+    return not (X.dtype == torch.complex64 and H.shape[0] >= 16 and cols >= 8 and H.shape[1] >= 8)
+
+
 def mimo(H: torch.Tensor, X: torch.Tensor, diag: bool = False) -> torch.Tensor:
     """Per-bin complex product.  ``H``: (M,No,Ni) | (No,Ni) for ``diag=False``; (M,N) | (N,) for
     ``diag=True``.  ``X``: (B, M, Ni, ...).  Implements the four flamo einsum patterns
-    "fmn,bfn...->bfm...", "mn,bfn...->bfm...", "fn,bfn...->bfn...", "n,bfn...->bfn..."."""
+    "fmn,bfn...->bfm...", "mn,bfn...->bfm...", "fn,bfn...->bfn...", "n,bfn...->bfn...".
+    A real frequency-independent ``H`` is accepted as it is (no complex cast is formed for small matrices)."""
+    if _real_const_applies(H, X, diag):
+        if H.shape[-1] != X.shape[2]:
+            raise ValueError(f"response expects {H.shape[-1]} input channels, signal has {X.shape[2]}")
+        return _MimoRealConst.apply(H, X)
     if H.dtype != X.dtype:
         H = H.to(X.dtype)  # differentiable cast (real -> complex, or precision)
     return _Mimo.apply(H, X, bool(diag))
@@ -1324,7 +1395,7 @@ EXPM_MAX_N = 64
 
 class _MatrixExp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, skew):
+    def forward(ctx, X, skew, cplx=False):
         dev = _require_gpu(X)
         if X.dim() != 2 or X.shape[0] != X.shape[1]:
             raise ValueError("matrix_exp expects one square matrix")
@@ -1335,31 +1406,39 @@ class _MatrixExp(torch.autograd.Function):
             raise ValueError(f"matrix_exp: N={N} exceeds the single-workgroup limit {EXPM_MAX_N}")
         Xc = X.contiguous()
         L = _lib.lib()
-        E = torch.empty_like(Xc)
+        E = torch.empty((N, N), dtype=_cdtype(X.dtype) if cplx else X.dtype, device=dev)
         stash = torch.empty(L.fl_matrix_exp_stash_elems(N), dtype=torch.float64, device=dev)
-        fn = L.fl_matrix_exp_f32 if X.dtype == torch.float32 else L.fl_matrix_exp_f64
+        if cplx:
+            fn = L.fl_matrix_exp_cplx_f32 if X.dtype == torch.float32 else L.fl_matrix_exp_cplx_f64
+        else:
+            fn = L.fl_matrix_exp_f32 if X.dtype == torch.float32 else L.fl_matrix_exp_f64
         _lib.check(fn(Xc.data_ptr(), N, int(skew), E.data_ptr(), stash.data_ptr(), _stream()), "matrix_exp")
         ctx.save_for_backward(stash)
-        ctx.cfg = (N, int(skew), X.dtype)
+        ctx.cfg = (N, int(skew), X.dtype, bool(cplx))
         return E
 
     @staticmethod
     def backward(ctx, gE):
         (stash,) = ctx.saved_tensors
-        N, skew, dt = ctx.cfg
-        g = gE.to(dt).contiguous()
-        gX = torch.empty_like(g)
+        N, skew, dt, cplx = ctx.cfg
         L = _lib.lib()
-        fn = L.fl_matrix_exp_bwd_f32 if dt == torch.float32 else L.fl_matrix_exp_bwd_f64
+        if cplx:      # the kernel takes the real part of the complex gradient
+            g = gE.resolve_conj().to(_cdtype(dt)).contiguous()
+            fn = L.fl_matrix_exp_bwd_cplx_f32 if dt == torch.float32 else L.fl_matrix_exp_bwd_cplx_f64
+        else:
+            g = gE.to(dt).contiguous()
+            fn = L.fl_matrix_exp_bwd_f32 if dt == torch.float32 else L.fl_matrix_exp_bwd_f64
+        gX = torch.empty((N, N), dtype=dt, device=g.device)
         _lib.check(fn(g.data_ptr(), N, skew, stash.data_ptr(), gX.data_ptr(), _stream()), "matrix_exp_bwd")
-        return gX, None
+        return gX, None, None
 
 
-def matrix_exp(X: torch.Tensor, skew: bool = False) -> torch.Tensor:
+def matrix_exp(X: torch.Tensor, skew: bool = False, complex_out: bool = False) -> torch.Tensor:
     """exp(X), or exp(triu(X,1) - triu(X,1)^T) with skew=True, of one (N, N) parameter matrix
     (N <= 64) in one launch each way: float64 arithmetic, fixed scaling-and-squaring schedule, no
-    host synchronisation (capturable)."""
-    return _MatrixExp.apply(X, bool(skew))
+    host synchronisation (capturable).  ``complex_out``: the result as the complex matrix (re, 0) the per-bin kernels
+    take, written by the same launch (and the real part of a complex gradient read by the backward launch)."""
+    return _MatrixExp.apply(X, bool(skew), bool(complex_out))
 
 
 # ----------------------------------------------------------------------------- per-bin eigenvalues

@@ -303,11 +303,23 @@ class Gain(DSP):
         assert len(self.size) == 2, "gains must be 2D. For 1D (parallel) gains use parallelGain module."
 
     def get_freq_convolve(self):
-        self.freq_convolve = lambda x, param: ops.mimo(to_complex(self.map(param)), x, diag=self._diag)
+        # (a real matrix goes to ops.mimo as it is: small ones are applied without forming their complex cast)
+        self.freq_convolve = lambda x, param: ops.mimo(self._mapped(param), x, diag=self._diag)
         self._own_convolve = self.freq_convolve
 
+    def _mapped(self, param):
+        W = self.map(param)
+        return W if (not self._diag and torch.is_tensor(W) and W.dim() == 2 and W.is_cuda) else to_complex(W)
+
+    def _complex_mapped(self, param):
+        """to_complex(map(param)) (dsp.py:466-468); the orthogonal map writes the complex matrix itself"""
+        if (self.map is _orthogonal_map and param.is_cuda and param.dim() == 2 and param.shape[0] <= ops.EXPM_MAX_N
+                and param.dtype in (torch.float32, torch.float64)):
+            return ops.matrix_exp(param, skew=True, complex_out=True)
+        return to_complex(self.map(param))
+
     def _bin_response(self, param):
-        return to_complex(self.map(param)), self._diag
+        return self._complex_mapped(param), self._diag
 
     def _real_matrix(self, param):
         """the mapped parameter as the real matrix it is (the response is its complex cast, dsp.py:466-468)"""

@@ -157,8 +157,10 @@ int fl_permute_bins_c64(const void* src, long src_pitch, void* dst, long dst_pit
  * einsum("n,bfn...->bfn...") (parallelGain, dsp.py:552-554) with hs_f = 0, plus their
  * autograd backward.
  *
- * Y[b,m,k,f] = sum_n op(H[f,m,n]) X[b,n,k,f];  op = conj if conj_h.
+ * Y[b,m,k,f] = sum_n op(H[f,m,n]) X[b,n,k,f];  op = conj if conj_h & 1.
  * H element address: f*hs_f + m*hs_m + n*hs_n (hs_f = 0: frequency-independent matrix).
+ * conj_h & 2 (fl_mimo_* only, hs_f = 0): H is a REAL matrix of the signal's precision, strides in real elements -- the
+ * Gain / Matrix parameter as it is, without the real -> complex cast of dsp.py:466-468.
  * X/Y addresses: b*s_b + ch*s_n + k*s_k + f. */
 int fl_mimo_c64(const void* H, long hs_f, long hs_m, long hs_n, int conj_h,
                 const void* X, long xs_b, long xs_n, long xs_k,
@@ -210,6 +212,12 @@ int fl_mimo_gradw_c64(const void* G, long gs_b, long gs_m, long gs_k, const void
                       void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream);
 int fl_mimo_gradw_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
                        void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream);
+/* The same reduction for a REAL frequency-independent matrix (a Gain whose complex cast is never formed, see conj_h bit 1
+ * of fl_mimo_*): dW is a real (No, Ni) array holding the real part of the sum. */
+int fl_mimo_gradw_re_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                         void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream);
+int fl_mimo_gradw_re_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                          void* part, void* dW, int B, int M, int No, int Ni, int K, void* stream);
 
 /* ------------------------------------------------------------------ frequency responses
  * Integer delay lines, Delay/parallelDelay.get_freq_response with isint=True
@@ -374,6 +382,13 @@ int fl_matrix_exp_f32(const void* X, int N, int skew, void* E, void* stash, void
 int fl_matrix_exp_f64(const void* X, int N, int skew, void* E, void* stash, void* stream);
 int fl_matrix_exp_bwd_f32(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);
 int fl_matrix_exp_bwd_f64(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);
+/* The same pair with the result stored as the complex matrix (re, 0) that the per-bin kernels take -- E: 2 N^2 values --
+ * and the backward reading the real part of a complex gradient gE (2 N^2 values): the real <-> complex passes between
+ * the parameter map and the solve / product kernels (dsp.py:466-468's cast and its backward) never run. */
+int fl_matrix_exp_cplx_f32(const void* X, int N, int skew, void* E, void* stash, void* stream);
+int fl_matrix_exp_cplx_f64(const void* X, int N, int skew, void* E, void* stash, void* stream);
+int fl_matrix_exp_bwd_cplx_f32(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);
+int fl_matrix_exp_bwd_cplx_f64(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-bin eigenvalues of small general complex matrices: torch.linalg.eigvals in

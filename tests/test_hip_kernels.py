@@ -576,3 +576,64 @@ def test_factored_solve_one_pass_gradients(gpu, N, have):
                 assert relerr(a.cpu().to(torch.complex128), b) < tol, (name, fused, cd)
         for a, b in zip(got[True], got[False]):
             assert relerr(a, b) < (1e-12 if cd == torch.complex128 else 3e-6)
+
+
+@pytest.mark.parametrize("shape", [(16, 1), (1, 16), (8, 8), (5, 3), (32, 32)])
+def test_real_constant_matrix_product_without_complex_cast(gpu, shape):
+    """ops.mimo with a real frequency-independent matrix (fl_mimo_* conj_h bit 1, fl_mimo_gradw_re_*) against the cast
+    path (to_complex, complex kernels, real part of the gradient): forward, input gradient, real parameter gradient;
+    float32 / float64, contiguous and transposed storage, vector and matrix-valued signals."""
+    from flamo_amd import ops
+    No, Ni = shape
+    M = 1001
+    for rd, cd, tol in ((torch.float32, torch.complex64, 2e-6), (torch.float64, torch.complex128, 1e-12)):
+        for tail in ((), (3,)):
+            for transposed in (False, True):
+                torch.manual_seed(No * 7 + Ni)
+                W0 = torch.randn(Ni, No, device=gpu, dtype=rd).t() if transposed else torch.randn(No, Ni, device=gpu, dtype=rd)
+                X0 = torch.randn(2, M, Ni, *tail, device=gpu, dtype=cd)
+                C = torch.randn(2, M, No, *tail, device=gpu, dtype=cd)
+                res = {}
+                try:
+                    for fast in (True, False):
+                        ops.REAL_CONST_MIMO = fast
+                        W = W0.clone().requires_grad_(True) if not transposed else W0.detach().requires_grad_(True)
+                        X = X0.clone().requires_grad_(True)
+                        ops.kernel_timer.reset(True)
+                        Y = ops.mimo(W, X)
+                        gW, gX = torch.autograd.grad((Y * C.conj()).real.sum(), [W, X])
+                        torch.cuda.synchronize()
+                        ops.kernel_timer.enabled = False
+                        names = set(ops.kernel_timer.summary())
+                        res[fast] = (Y.detach(), gW, gX, names)
+                finally:
+                    ops.REAL_CONST_MIMO = True
+                    ops.kernel_timer.enabled = False
+                big = rd == torch.float32 and No >= 16 and Ni >= 8 and 2 * (3 if tail else 1) >= 8
+                assert any("mimo_const_real" in n for n in res[True][3]) == (not big)
+                assert not any("mimo_const_real" in n for n in res[False][3])
+                assert res[True][1].dtype == rd and res[True][1].shape == (No, Ni)
+                for a, b in zip(res[True][:3], res[False][:3]):
+                    assert relerr(a, b) < tol
+                ref = torch.einsum("mn,bfn...->bfm...", W0.to(torch.complex128).cpu(), X0.to(torch.complex128).cpu())
+                assert relerr(res[True][0].cpu().to(torch.complex128), ref) < (1e-6 if rd == torch.float32 else 1e-13)
+
+
+@pytest.mark.parametrize("N", [4, 6, 16, 32])
+def test_matrix_exp_complex_output_matches_real(gpu, N):
+    """ops.matrix_exp(..., complex_out=True): the complex matrix (re, 0) written by the same launch, and the backward reading
+    the real part of a complex gradient, against the real pair followed by a cast"""
+    from flamo_amd import ops
+    for dt in (torch.float32, torch.float64):
+        torch.manual_seed(N)
+        X0 = torch.randn(N, N, device=gpu, dtype=dt)
+        cd = torch.complex64 if dt == torch.float32 else torch.complex128
+        C = torch.randn(N, N, device=gpu, dtype=cd)
+        Xa = X0.clone().requires_grad_(True)
+        Ea = ops.matrix_exp(Xa, skew=True, complex_out=True)
+        (ga,) = torch.autograd.grad((Ea * C.conj()).real.sum(), [Xa])
+        Xb = X0.clone().requires_grad_(True)
+        Eb = ops.matrix_exp(Xb, skew=True).to(cd)
+        (gb,) = torch.autograd.grad((Eb * C.conj()).real.sum(), [Xb])
+        assert Ea.dtype == cd and torch.equal(Ea.real, Eb.real) and float(Ea.detach().imag.abs().max()) == 0.0
+        assert torch.equal(ga, gb)
