@@ -113,6 +113,8 @@ __global__ void __launch_bounds__(256) solve_kernel(
             cx<T> v(0, 0);
             if (gi < N && j < N) {
                 v = adjoint ? conj(P[((long)j * N + gi) * p_pitch + f]) : P[((long)gi * N + j) * p_pitch + f];
+                // constant row scale of the materialised matrix: A = I - diag(l) P (the row of P is j for the adjoint)
+                if (dud.l) v = v * (adjoint ? conj(dud.l[(long)j * dud.l_sn]) : dud.l[(long)gi * dud.l_sn]);
                 if (one_minus) v = cx<T>(-v.x, -v.y);
             }
             if (one_minus ? (j == gi) : (j == gi && gi >= N)) v.x += (T)1;
@@ -367,6 +369,7 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
                     cx<T> x(0, 0);
                     if (ri < N && pj < N) {
                         x = P[(adjoint ? (long)pj * N + ri : (long)ri * N + pj) * p_pitch + fl];
+                        if (dud.l) x = x * dud.l[(long)(adjoint ? pj : ri) * dud.l_sn];      // row scale (row of P)
                         x = cx<T>(sgn * x.x, (adjoint ? -sgn : sgn) * x.y);
                     }
                     if (one_minus ? (pj == ri) : (pj == ri && ri >= N)) x.x += (T)1;
@@ -407,6 +410,7 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
                 cx<T> v(0, 0);
                 if (j < N) {                                 // uniform
                     v = p[(long)j * step];
+                    if (dud.l) v = v * dud.l[(long)(adjoint ? j : gr) * dud.l_sn];           // row scale (row of P)
                     v = cx<T>(sgn * v.x, (adjoint ? -sgn : sgn) * v.y);
                     v.x = ri < N ? v.x : (T)0;
                     v.y = ri < N ? v.y : (T)0;
@@ -933,6 +937,18 @@ int fl_solve_c128(const void* P, long p_pitch, int one_minus, int adjoint, const
                   long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
     Dud<double> none = {};
     return solve_impl<double>(P, p_pitch, none, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+int fl_solve_scaled_c64(const void* P, long p_pitch, const void* l, long l_sn, int adjoint, const void* R, long rs_b, long rs_n,
+                        long rs_k, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+    FL_REQUIRE(P && l, "solve_scaled: null pointer");
+    Dud<float> d = {(const cx<float>*)l, l_sn, 0, nullptr, nullptr, 0, 0};
+    return solve_impl<float>(P, p_pitch, d, 1, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+int fl_solve_scaled_c128(const void* P, long p_pitch, const void* l, long l_sn, int adjoint, const void* R, long rs_b, long rs_n,
+                         long rs_k, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+    FL_REQUIRE(P && l, "solve_scaled: null pointer");
+    Dud<double> d = {(const cx<double>*)l, l_sn, 0, nullptr, nullptr, 0, 0};
+    return solve_impl<double>(P, p_pitch, d, 1, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
 }
 int fl_solve_dud_c64(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, int adjoint,
                      const void* R, long rs_b, long rs_n, long rs_k, void* OUT, long os_b, long os_n, long os_k,

@@ -1010,6 +1010,67 @@ class _SolveDUD(torch.autograd.Function):
         return gl, gU, gr, (gR if ctx.needs_input_grad[3] else None)
 
 
+def _solve_scaled_launch(DU, g, adjoint, R):
+    real = _rdtype(R)
+    B, M, N, K, rs_b, rs_n, rs_k = _bnk(R)
+    OUT = _empty_planar(R.shape, R.dtype, R.device)
+    _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
+    L = _lib.lib()
+    fn = L.fl_solve_scaled_c64 if real == torch.float32 else L.fl_solve_scaled_c128
+    with kernel_timer.span("solve_adj" if adjoint else "solve"):
+        _lib.check(fn(DU.data_ptr(), _lead_pitch(DU.movedim(0, -1)), g.data_ptr(), g.stride(0), int(adjoint), R.data_ptr(), rs_b,
+                      rs_n, rs_k, OUT.data_ptr(), os_b, os_n, os_k, B, M, N, K, _stream()), "solve_scaled")
+    return OUT
+
+
+class _SolveScaledLoop(torch.autograd.Function):
+    """OUT = (I - diag(g) D[f] U)^-1 R per bin; D: per-bin (M, N, N) WITHOUT gradient, g: (N,), U: (N, N) constants.
+    P' = D U is formed once; the gains scale its rows inside the solve.  Backward without the (M, N, N) gradient of the
+    loop matrix: dP = gR (x) conj(out) is an outer product per bin, so
+        g_g = sum_f gR . conj(P' out),      g_U = sum_f (D^H (conj(g) . gR)) (x) conj(out)
+    are two per-bin matrix-vector passes and two small reductions."""
+
+    @staticmethod
+    def forward(ctx, g, D, U, R):
+        _require_gpu(g, D, U, R)
+        N = U.shape[0]
+        if D.dim() != 3 or D.shape[1:] != (N, N) or U.shape != (N, N) or g.shape != (N,) or R.shape[2] != N:
+            raise ValueError("solve_scaled_loop: expected g (N,), D (M, N, N), U (N, N), R (B, M, N, ...)")
+        Dp = _h_planar(D.resolve_conj(), True)
+        gc, Uc = g.resolve_conj().contiguous(), U.resolve_conj().contiguous()
+        Rp = to_planar(R.resolve_conj())
+        # P'[f] = D[f] U: rows of D as batch items of a signal, U^T as the constant matrix (planar memory of the result IS
+        # the per-bin matrix (M, N, N))
+        DU = _mimo_launch(Uc.transpose(-1, -2), False, False, False, to_planar(Dp.permute(1, 0, 2))).permute(1, 0, 2)
+        OUT = _solve_scaled_launch(DU, gc, False, Rp)
+        ctx.save_for_backward(gc, Dp, Uc, DU, OUT)
+        return OUT
+
+    @staticmethod
+    def backward(ctx, gOUT):
+        gc, Dp, Uc, DU, OUT = ctx.saved_tensors
+        gR = _solve_scaled_launch(DU, gc, True, to_planar(gOUT.resolve_conj()))        # A^-H g
+        g_g = g_U = None
+        if ctx.needs_input_grad[0]:
+            v = _mimo_launch(DU, True, False, False, OUT)                             # P' out
+            g_g = _gradh_launch(gR, v, True).sum(dim=-1)                              # (N,): sum_f,b gR conj(v)
+        if ctx.needs_input_grad[2]:
+            t = _mimo_launch(gc, False, True, True, gR)                               # conj(g) . gR
+            w = _mimo_launch(Dp, True, False, True, t)                                # D^H (conj(g) . gR)
+            g_U = _gradw_launch(w, OUT)                                               # sum_f,b w (x) conj(out)
+        return g_g, None, g_U, (gR if ctx.needs_input_grad[3] else None)
+
+
+def solve_scaled_loop(g: torch.Tensor, D: torch.Tensor, U: torch.Tensor, R: torch.Tensor) -> torch.Tensor:
+    """Per bin f: (I - diag(g) D[f] U)^-1 R[:, f] -- a loop whose feedforward path is a per-bin matrix of delays followed
+    by per-channel gains, around a constant mixing matrix.  D must not require a gradient."""
+    if D.requires_grad:
+        raise ValueError("solve_scaled_loop: the per-bin factor must not require a gradient (use ops.solve)")
+    cd = R.dtype
+    conv = lambda t: t if t.dtype == cd else t.to(cd)  # noqa: E731
+    return _SolveScaledLoop.apply(conv(g), conv(D), conv(U), R)
+
+
 def solve_dud(l: Optional[torch.Tensor], U: torch.Tensor, r: Optional[torch.Tensor], R: torch.Tensor) -> torch.Tensor:
     """Per bin f: (I - diag(l[f]) U diag(r[f]))^-1 R[:, f] -- the closed loop of a feedback delay
     network, with the loop matrix kept in factored form (never materialised)."""

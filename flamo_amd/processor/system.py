@@ -35,6 +35,9 @@ OVERLAP_RESPONSES = True
 FUSE_SHELL = True
 # Series(Matrix, cascade-type filter, ...): response and gradients of the pair from one fused operator (ops.*_rc)
 FUSE_MATRIX_CASCADE = True
+# Recursion whose loop is diag(g) D[f] U (per-bin delay matrix, per-channel gains, mixing matrix): the gains scale rows
+# inside the solve and the backward pass forms no (M, N, N) gradient (ops.solve_scaled_loop)
+SCALED_LOOP = True
 # Gradients of the parameters are then produced on the side stream while their AccumulateGrad
 # nodes live on the main one; autograd synchronises the two correctly and merely warns about it.
 _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -348,6 +351,9 @@ class Recursion(nn.Module):
             if dud is not None:
                 # FDN structure: P = diag(l) U diag(r) stays factored, A = I - P is built in registers
                 return ops.solve_dud(dud[0], dud[1], dud[2], R)
+            sl = self.__scaled_loop(R)
+            if sl is not None:
+                return ops.solve_scaled_loop(sl[0], sl[1], sl[2], R)
             P = self.__composed_loop(R)
             if P is not None:
                 return ops.solve(P, R, one_minus=True)
@@ -385,6 +391,33 @@ class Recursion(nn.Module):
             shape[2] = m.output_channels
             acc = resp if acc is None else _compose(acc, resp, M)
         return _as_signal(acc[0], acc[1], M)
+
+    def __scaled_loop(self, R):
+        """If the loop is  diag(g) D[f] U  -- feedback = one constant full matrix U, feedforward = one per-bin full matrix D
+        that carries no gradient (a matrix of integer delays) followed by constant per-channel gains g (the structure of
+        the active-acoustics chain: Recursion(fF=Series(Delay((N,N)), parallelGain(N)), fB=Matrix)) -- return (g, D, U):
+        P' = D U is formed once, the gains scale its rows inside the solve, and the backward pass needs no (M, N, N)
+        gradient tensor (ops.solve_scaled_loop).  Else None."""
+        if not SCALED_LOOP:
+            return None
+        chain = self.__loop_chain()
+        if chain is None or len(chain) != 3:
+            return None
+        M = R.shape[1]
+        shape = [1, M, self.output_channels, self.output_channels]
+        resp = []
+        for m in chain:
+            resp.append(m._response_for_fusion(shape, None))
+            shape[2] = m.output_channels
+        (U, dU), (D, dD), (g, dg) = resp
+        N = self.output_channels
+        if dU or dD or not dg:
+            return None
+        if U.dim() != 2 or tuple(U.shape) != (N, N) or D.dim() != 3 or tuple(D.shape[1:]) != (N, N) or g.dim() != 1:
+            return None
+        if D.requires_grad:
+            return None
+        return g, D, U
 
     def __factored_loop(self, R):
         """If feedback-then-feedforward is a chain of per-bin modules with exactly one full,

@@ -323,6 +323,15 @@ int fl_solve_c128(const void* P, long p_pitch, int one_minus, int adjoint,
                   void* OUT, long os_b, long os_n, long os_k,
                   int B, int M, int N, int K, void* stream);
 
+/* fl_solve_* (one_minus) with a constant row scale of the materialised matrix: A_f = I - diag(l) P[f], l: N complex values
+ * l_sn apart.  For loops whose feedforward path ends in per-channel gains (Series(Delay((N,N)), parallelGain(N)) around a
+ * mixing matrix, the active-acoustics structure): P = D[f] U is formed once and the gains never make a pass over the
+ * (M, N, N) tensor, forward or backward. */
+int fl_solve_scaled_c64(const void* P, long p_pitch, const void* l, long l_sn, int adjoint, const void* R, long rs_b, long rs_n,
+                        long rs_k, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream);
+int fl_solve_scaled_c128(const void* P, long p_pitch, const void* l, long l_sn, int adjoint, const void* R, long rs_b, long rs_n,
+                         long rs_k, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream);
+
 /* Same solve with the loop matrix given in the factored form every feedback delay network has
  * (reverb.py:117-199, e8_fdn.py:60-100: delays and attenuation filters are diagonal, only the
  * mixing matrix is full):  A_f = I - diag(l[:,f]) U diag(r[:,f]),  U frequency independent (N x N,

@@ -637,3 +637,59 @@ def test_matrix_exp_complex_output_matches_real(gpu, N):
         (gb,) = torch.autograd.grad((Eb * C.conj()).real.sum(), [Xb])
         assert Ea.dtype == cd and torch.equal(Ea.real, Eb.real) and float(Ea.detach().imag.abs().max()) == 0.0
         assert torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("N", [4, 13, 16, 32])
+def test_scaled_loop_solve_matches_composed_loop(gpu, N):
+    """ops.solve_scaled_loop -- (I - diag(g) D[f] U)^-1 R with P' = D U formed once, the gains applied as a row scale
+    inside the solve (fl_solve_scaled_*), gradients from two per-bin matrix-vector passes -- against LAPACK autograd in
+    float64 on the materialised loop, and (Recursion level) against the composed-loop route it replaces."""
+    from collections import OrderedDict
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    torch.manual_seed(N)
+    M, B = 257, 2
+    for cd, tol in ((torch.complex128, 1e-11), (torch.complex64, 3e-5)):
+        D64 = torch.exp(2j * torch.pi * torch.rand(M, N, N, dtype=torch.float64))
+        U64 = torch.linalg.qr(torch.randn(N, N, dtype=torch.float64))[0].to(torch.complex128)
+        g64 = ((0.2 + 0.5 * torch.rand(N, dtype=torch.float64)) / N ** 0.5).to(torch.complex128)
+        R64 = torch.randn(B, M, N, dtype=torch.complex128)
+        C64 = torch.randn(B, M, N, dtype=torch.complex128)
+        gr, Ur, Rr = (t.clone().requires_grad_(True) for t in (g64, U64, R64))
+        A = torch.eye(N, dtype=torch.complex128) - gr.unsqueeze(-1) * (D64 @ Ur)
+        Yr = torch.linalg.solve(A.unsqueeze(0), Rr.unsqueeze(-1)).squeeze(-1)
+        want = torch.autograd.grad(torch.sum(torch.real(Yr * torch.conj(C64))), [gr, Ur, Rr])
+        gd, Ud, Rd = (t.detach().to(gpu, cd).requires_grad_(True) for t in (g64, U64, R64))
+        Y = ops.solve_scaled_loop(gd, D64.to(gpu, cd), Ud, Rd)
+        got = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C64.to(gpu, cd)))), [gd, Ud, Rd])
+        assert relerr(Y.detach().cpu().to(torch.complex128), Yr.detach()) < tol
+        for a, b in zip(got, want):
+            assert relerr(a.cpu().to(torch.complex128), b) < tol
+    # the planner: Recursion(fF=Series(Delay((N,N)), parallelGain(N)), fB=Matrix orthogonal) with and without the route
+    nfft = 960
+    kw = dict(nfft=nfft, alias_decay_db=20.0, device=gpu, dtype=torch.float64)
+    dly = dsp.Delay(size=(N, N), max_len=200, isint=True, **kw)
+    gain = dsp.parallelGain(size=(N,), requires_grad=True, **kw)
+    with torch.no_grad():
+        gain.param.copy_(torch.rand_like(gain.param) * 0.5 / N ** 0.5 + 0.01)
+    mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+    loop = system.Recursion(fF=system.Series(OrderedDict(d=dly, g=gain)), fB=mix)
+    X = torch.randn(2, nfft // 2 + 1, N, device=gpu, dtype=torch.complex128)
+    Cw = torch.randn(2, nfft // 2 + 1, N, device=gpu, dtype=torch.complex128)
+    res = {}
+    try:
+        for on in (True, False):
+            system.SCALED_LOOP = on
+            ops.kernel_timer.reset(True)
+            Y = loop(X)
+            g = torch.autograd.grad(torch.sum(torch.real(Y * Cw.conj())), [gain.param, mix.param])
+            torch.cuda.synchronize()
+            ops.kernel_timer.enabled = False
+            res[on] = (Y.detach(), *g, set(ops.kernel_timer.summary()))
+    finally:
+        system.SCALED_LOOP = True
+        ops.kernel_timer.enabled = False
+    for a, b in zip(res[True][:3], res[False][:3]):
+        assert relerr(a, b) < 1e-10
+    assert not any(n.startswith("mimo_gradh[") for n in res[True][3]), res[True][3]     # no (M, N, N) gradient tensor
+    assert any(n.startswith("mimo_gradh[") for n in res[False][3])
