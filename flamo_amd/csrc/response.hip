@@ -435,6 +435,14 @@ struct SosRC {
     int Nmid, nbx;       // nbx: bin blocks (the grid is 1-D in this mode)
     const float* Wr;     // (Nmid, NIW) row-major
     float* partW;        // (gridDim.x, C, NIW)
+    // "outer" mode (NIW == 0, oG != null): the response was applied to a signal with few columns, Y[b] = H X[b], and its
+    // gradient dL/dH[m][n][f] = sum_b gY[b][m][f] conj(X[b][n][f]) is formed here from the two signals instead of being
+    // read from an (M, No, Ni) tensor nobody else needs (1.6 GB written and re-read for a 32 x 32 equaliser at
+    // nfft = 384000).  Channel pair c = m * oNi + n.
+    const cx<float>* oG = nullptr;   // gY planes: b * o_gb + m * o_gn + f
+    const cx<float>* oX = nullptr;   // X planes:  b * o_xb + n * o_xn + f
+    long o_gb = 0, o_gn = 0, o_xb = 0, o_xn = 0;
+    int oB = 0, oNi = 1;
 };
 
 template <int SCH, int NIW>
@@ -506,8 +514,11 @@ __global__ void __launch_bounds__(256, 3) sos_response_bwd_mixed_kernel(
     for (int f = bx * 256 + threadIdx.x; f < m_local; f += fstride) {
         const cx<float> h = H[(size_t)c * h_pitch + f];
         cx<float> gv[NW];
+        const bool outer = NIW == 0 && rc.oG != nullptr;
+        if (!outer) {
 #pragma unroll
-        for (int n = 0; n < NW; ++n) gv[n] = gbase[(size_t)n * g_pitch + f];
+            for (int n = 0; n < NW; ++n) gv[n] = gbase[(size_t)n * g_pitch + f];
+        }
         cx<float> gin;
         if (NIW > 0) {
             gin = cx<float>(0.f, 0.f);
@@ -517,6 +528,11 @@ __global__ void __launch_bounds__(256, 3) sos_response_bwd_mixed_kernel(
                 gin.y += wrow[n] * gv[n].y;
                 if (blockIdx.z == 0) accw[n] += h.x * gv[n].x + h.y * gv[n].y;
             }
+        } else if (outer) {
+            const int mo = c / rc.oNi, no = c - mo * rc.oNi;
+            gin = cx<float>(0.f, 0.f);
+            for (int bb = 0; bb < rc.oB; ++bb)
+                fma_cxc(gin, rc.oG[(size_t)bb * rc.o_gb + (size_t)mo * rc.o_gn + f], rc.oX[(size_t)bb * rc.o_xb + (size_t)no * rc.o_xn + f]);
         } else {
             gin = gv[0];
         }
@@ -839,7 +855,7 @@ template <typename T>
 static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S, int C,
                         double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream,
                         int rc_ni = 0, SosRC rc = SosRC{0, 0, nullptr, nullptr}) {
-    FL_REQUIRE(gH && b && a && part && Wd, "sos_response_bwd: null pointer");
+    FL_REQUIRE((gH || rc.oG) && b && a && part && Wd, "sos_response_bwd: null pointer");
     FL_REQUIRE(g_pitch >= m_local && (!H || h_pitch >= m_local), "sos_response_bwd: g_pitch / h_pitch must be >= m_local");
     FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) && m_local > 0, "sos_response_bwd: bad sizes");
     if constexpr (sizeof(T) == 4) {
@@ -874,7 +890,7 @@ static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitc
             return FL_OK;
         }
     }
-    FL_REQUIRE(rc_ni == 0, "sos_response_bwd: the constant-factor mode needs float32 and the saved forward response");
+    FL_REQUIRE(rc_ni == 0 && !rc.oG, "sos_response_bwd: the constant-factor and outer-product modes need float32 and the saved forward response");
     const int sch = (g_sos_chunk == 3 || g_sos_chunk == 4 || g_sos_chunk == 6 || g_sos_chunk == 12) ? g_sos_chunk : 6;
 #define FL_SOS_BWD(SC)                                                                                              \
     {                                                                                                               \
@@ -1003,6 +1019,15 @@ int fl_sos_response_bwd_rc_c64(const void* gHfull, long g_pitch, const void* G, 
     SosRC rc{Nmid, 0, (const float*)Wr, (float*)partW};
     return sos_bwd_impl<float>(gHfull, g_pitch, G, h_pitch, b, a, S, No * Nmid, gamma, Wd, nfft, bin0, m_local, part, stream,
                                Ni, rc);
+}
+int fl_sos_response_bwd_outer_c64(const void* gY, long gy_sb, long gy_sn, const void* X, long x_sb, long x_sn, int B, int No, int Ni,
+                                  const void* H, long h_pitch, const void* b, const void* a, int S, double gamma, const void* Wd,
+                                  int nfft, int bin0, int m_local, void* part, void* stream) {
+    FL_REQUIRE(gY && X && H && B > 0 && No > 0 && Ni > 0, "sos_response_bwd_outer: bad arguments");
+    SosRC rc{0, 0, nullptr, nullptr};
+    rc.oG = (const cx<float>*)gY; rc.oX = (const cx<float>*)X;
+    rc.o_gb = gy_sb; rc.o_gn = gy_sn; rc.o_xb = x_sb; rc.o_xn = x_sn; rc.oB = B; rc.oNi = Ni;
+    return sos_bwd_impl<float>(nullptr, m_local, H, h_pitch, b, a, S, No * Ni, gamma, Wd, nfft, bin0, m_local, part, stream, 0, rc);
 }
 int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
                              int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {

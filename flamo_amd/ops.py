@@ -273,9 +273,26 @@ class _PerThread(threading.local):
         self.fork = {"event": None, "memo": None}
         self.shard = {"bin0": 0, "m_local": None, "order": None}
         self.side_streams = {}
+        self.loop_depth = 0
 
 
 _tls = _PerThread()
+
+
+class loop_scope:
+    """Marks the forward pass of a Recursion's paths: modules inside keep their responses as tensors (the loop matrix needs
+    them), so the apply-without-the-gradient-tensor route of the cascade filters stays off there."""
+
+    def __enter__(self):
+        _tls.loop_depth += 1
+
+    def __exit__(self, *exc):
+        _tls.loop_depth -= 1
+        return False
+
+
+def in_loop() -> bool:
+    return _tls.loop_depth > 0
 
 
 def fork_event():
@@ -1244,6 +1261,108 @@ class _GeqCascade(torch.autograd.Function):
                                                   part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
                                                   out.data_ptr(), _stream()), "geq_sections_bwd")
         return out, None, None, None, None
+
+
+# ---- cascade response applied to a signal with few columns: Y = H X with dL/dH formed inside the cascade backward
+def cascade_apply_supported(real: torch.dtype, X: torch.Tensor) -> bool:
+    """float32 modules with the mixed-precision backward, vector signals (B, M, N)"""
+    return real == torch.float32 and SOS_BWD_MIXED and X.dim() == 3 and X.dtype == torch.complex64 and X.is_cuda
+
+
+def _sos_backward_outer_launch(gY, Xp, Hf, bc, ac, cfg, No, Ni):
+    """part (nblk, 2, 3, S, C) with dL/dH[m][n] = sum_b gY[b][m] conj(X[b][n]) formed in the kernel"""
+    gamma, nfft, S, C_, bin0, m_local, real = cfg
+    B, M, _, K, xs_b, xs_n, _ = _bnk(Xp)
+    _, _, _, _, gs_b, gs_n, _ = _bnk(gY)
+    assert K == 1 and C_ == No * Ni and M == m_local
+    L = _lib.lib()
+    part = torch.empty((L.fl_sos_bwd_blocks(m_local), 2, 3, S, C_), dtype=torch.float64, device=bc.device)
+    with kernel_timer.span("sos_response_bwd"):
+        _lib.check(L.fl_sos_response_bwd_outer_c64(gY.data_ptr(), gs_b, gs_n, Xp.data_ptr(), xs_b, xs_n, B, No, Ni, Hf.data_ptr(),
+                                                   _pitch(m_local), bc.data_ptr(), ac.data_ptr(), S, gamma,
+                                                   twiddles(nfft, torch.float64, bc.device).data_ptr(), nfft, bin0, m_local,
+                                                   part.data_ptr(), _stream()), "sos_response_bwd_outer")
+    return part
+
+
+class _SosApply(torch.autograd.Function):
+    """Y[b,:,f] = sos_response(b, a)[f] X[b,:,f] for a full (N_out, N_in) cascade and a vector signal"""
+
+    @staticmethod
+    def forward(ctx, b, a, X, gamma, nfft, real):
+        _require_gpu(b, a, X)
+        if b.shape != a.shape or b.shape[0] != 3 or b.dim() != 4:
+            raise ValueError("sos_response_apply: b and a must both be (3, n_sections, N_out, N_in)")
+        bc, ac = b.contiguous(), a.contiguous()
+        Xp = to_planar(X.resolve_conj())
+        H, ctx.cfg = _sos_forward_launch(bc, ac, gamma, nfft, real, not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
+        ctx.save_for_backward(bc, ac, H, Xp)
+        return _mimo_launch(H.movedim(-1, 0), True, False, False, Xp)
+
+    @staticmethod
+    def backward(ctx, gY):
+        bc, ac, H, Xp = ctx.saved_tensors
+        gY = to_planar(gY.resolve_conj())
+        gb = ga = gX = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            tot = _sos_backward_outer_launch(gY, Xp, H, bc, ac, ctx.cfg, bc.shape[2], bc.shape[3]).sum(dim=0)
+            gb, ga = tot[0].view(bc.shape), tot[1].view(ac.shape)
+        if ctx.needs_input_grad[2]:
+            gX = _mimo_launch(H.movedim(-1, 0), True, False, True, gY)
+        return gb, ga, gX, None, None, None
+
+
+class _GeqCascadeApply(torch.autograd.Function):
+    """Y = geq_cascade(x)[f] X[b,:,f]: design + cascade + product forward; cascade backward (outer product formed in the
+    kernel) + design backward."""
+
+    @staticmethod
+    def forward(ctx, x, consts, X, gamma, nfft, real):
+        dev = _require_gpu(x, consts, X)
+        xc = x.contiguous()
+        if xc.dim() != 3:
+            raise ValueError("geq_cascade_apply expects full (n_bands, N_out, N_in) parameters")
+        nb = xc.shape[0]
+        chan = tuple(xc.shape[1:])
+        C_ = _prod(chan)
+        b = torch.empty((3, nb, *chan), dtype=torch.float64, device=dev)
+        a = torch.empty_like(b)
+        _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), _geq_in_kind(xc, True), nb, C_, consts.data_ptr(), b.data_ptr(),
+                                              a.data_ptr(), _stream()), "geq_sections")
+        Xp = to_planar(X.resolve_conj())
+        H, ctx.cfg = _sos_forward_launch(b, a, gamma, nfft, real, True)
+        ctx.save_for_backward(xc, consts, b, a, H, Xp)
+        return _mimo_launch(H.movedim(-1, 0), True, False, False, Xp)
+
+    @staticmethod
+    def backward(ctx, gY):
+        xc, consts, b, a, H, Xp = ctx.saved_tensors
+        gY = to_planar(gY.resolve_conj())
+        out = gX = None
+        if ctx.needs_input_grad[0]:
+            part = _sos_backward_outer_launch(gY, Xp, H, b, a, ctx.cfg, xc.shape[1], xc.shape[2])
+            nblk, nb = part.shape[0], xc.shape[0]
+            C_ = _prod(xc.shape[1:])
+            st = nb * C_
+            out = torch.empty_like(xc)
+            esz = part.element_size()
+            _lib.check(_lib.lib().fl_geq_sections_bwd(xc.data_ptr(), _geq_in_kind(xc, True), part.data_ptr(),
+                                                      part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
+                                                      out.data_ptr(), _stream()), "geq_sections_bwd")
+        if ctx.needs_input_grad[2]:
+            gX = _mimo_launch(H.movedim(-1, 0), True, False, True, gY)
+        return out, None, gX, None, None, None
+
+
+def sos_response_apply(b, a, X, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
+    """sos_response(b, a)[f] @ X[b, f] for a vector signal X (B, M, N_in): the response's gradient never exists as a
+    tensor (cascade_apply_supported)."""
+    return _SosApply.apply(b.to(torch.float64), a.to(torch.float64), X, float(gamma), int(nfft), dtype)
+
+
+def geq_cascade_apply(x, consts, X, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
+    """geq_cascade(x, consts)[f] @ X[b, f] for a vector signal X (B, M, N_in)"""
+    return _GeqCascadeApply.apply(x, consts, X, float(gamma), int(nfft), dtype)
 
 
 def cascade_rc_supported(real: torch.dtype, n_in: int) -> bool:

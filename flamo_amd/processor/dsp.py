@@ -526,6 +526,10 @@ class parallelFilter(Filter):
         return torch.diag(self._probe_fir(z))
 
 
+# cascade-type filters applied to few columns: see _SOSMixin._apply_narrow
+NARROW_APPLY = True
+
+
 class _SOSMixin:
     """Second-order-section cascades share one tail: weight the 3 taps by gamma^[0,1,2] and
     evaluate prod B / prod A per bin (dsp.py:1520-1526) -- here directly in ``ops.sos_response``,
@@ -550,6 +554,33 @@ class _SOSMixin:
 
     def _cascade_spec(self, param):
         return ("sos", *self._sos_coeffs(self.map(param.double())))
+
+    # A full cascade applied to a signal with this many columns or fewer, outside a loop: the product and the response's
+    # gradient go through ops.*_apply (dL/dH = gY (x) conj(X) formed inside the cascade backward; an (M, N_out, N_in)
+    # gradient tensor is 1.6 GB for a 32 x 32 equaliser at nfft = 384000)
+    NARROW_APPLY_MAX_COLUMNS = 2
+    NARROW_APPLY_MIN_PAIRS = 64
+
+    def get_freq_convolve(self):
+        def convolve(x, param):
+            Y = self._apply_narrow(x, param)
+            return Y if Y is not None else ops.mimo(self._response_once(param), x, diag=self._diag)
+        self.freq_convolve = convolve
+        self._own_convolve = self.freq_convolve
+
+    def _apply_narrow(self, x, param):
+        if (self._diag or not NARROW_APPLY or not torch.is_tensor(param) or not param.is_cuda or x.dim() != 3
+                or x.shape[0] > self.NARROW_APPLY_MAX_COLUMNS or ops.in_loop() or ops.bin_order(self.nfft) is not None
+                or self.input_channels * self.output_channels < self.NARROW_APPLY_MIN_PAIRS
+                or not ops.cascade_apply_supported(self.dtype, x)
+                or getattr(self, "_own_response", None) is not self.freq_response):
+            return None
+        spec = self._cascade_spec(param)
+        if spec[0] == "geq":
+            return ops.geq_cascade_apply(spec[1], spec[2], x, self._gamma_f, self.nfft, dtype=self.dtype)
+        if spec[1].dim() != 4:
+            return None
+        return ops.sos_response_apply(spec[1], spec[2], x, self._gamma_f, self.nfft, dtype=self.dtype)
 
     def _sections_spectra(self, b, a):
         """B, A as the reference returns them from get_poly_coeff: rfft of the weighted taps."""

@@ -345,6 +345,10 @@ class Recursion(nn.Module):
                     ext_fb = param
                 elif "feedforward" in key:
                     ext_ff = param
+        with ops.loop_scope():
+            return self.__forward_in_loop(X, ext_param, ext_fb, ext_ff)
+
+    def __forward_in_loop(self, X, ext_param, ext_fb, ext_ff):
         R = self.feedforward(X, ext_ff)
         if FUSE_SERIES and ext_param is None and torch.is_tensor(R) and R.is_cuda:
             dud = self.__factored_loop(R)

@@ -267,6 +267,13 @@ int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_
                             int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
 int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
                              int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
+/* fl_sos_response_bwd_c64 (mixed-precision route) when the response was applied to a signal with few columns,
+ * Y[b,:,f] = H[f] X[b,:,f] (dsp.py:922-924): dL/dH[m][n][f] = sum_b gY[b][m][f] conj(X[b][n][f]) is formed inside the
+ * kernel from the two signals (planes b*s_b + channel*s_n + f) instead of being read from an (M, No, Ni) tensor.
+ * H: the saved forward response, planes c = m*Ni + n of pitch h_pitch.  part as above. */
+int fl_sos_response_bwd_outer_c64(const void* gY, long gy_sb, long gy_sn, const void* X, long x_sb, long x_sn, int B, int No, int Ni,
+                                  const void* H, long h_pitch, const void* b, const void* a, int S, double gamma, const void* Wd,
+                                  int nfft, int bin0, int m_local, void* part, void* stream);
 /* Cascade response times a real constant matrix on the right -- Series(Matrix, <cascade-type filter>), system.py:299-300
  * over dsp.py:466-468 and dsp.py:922-924 (the reference applies the two modules one after the other):
  *   G[m*Nmid + j, f] as fl_sos_response_c64 (planes of pitch g_pitch; kept for the backward pass),

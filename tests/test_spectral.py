@@ -421,3 +421,49 @@ def test_cascade_float_evaluation_plain_response(gpu, kind):
         assert e_float < 1.5e-5 and e_double < 1.5e-5 and e_float < 2 * e_double + 2e-6
     else:       # with gradients these modules evaluate in double whatever the hook says
         assert torch.equal(out[1][1], out[0][1]) and torch.equal(out[1][2], out[0][2])
+
+
+@pytest.mark.parametrize("kind", ["geq", "biquad", "svf", "peq"])
+@pytest.mark.parametrize("B", [1, 2, 3])
+def test_cascade_applied_to_few_columns_without_gradient_tensor(gpu, kind, B):
+    """A full cascade-type filter applied to a vector signal with few columns: product through ops.*_apply, whose backward
+    forms dL/dH = gY (x) conj(X) inside the cascade kernel (fl_sos_response_bwd_outer_c64) -- against the layered route
+    (response tensor, per-bin product, (M, N, N) gradient tensor): output, parameter gradient, input gradient.  Three
+    columns are above the module's threshold and must take the layered route."""
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp
+    nfft, N = 9600, 8
+    torch.manual_seed(11)
+    kw = dict(nfft=nfft, alias_decay_db=20.0, device=gpu, dtype=torch.float32, requires_grad=True)
+    if kind == "geq":
+        mod = dsp.GEQ(size=(N, N), **kw)
+    elif kind == "peq":
+        mod = dsp.PEQ(size=(N, N), n_bands=5, **kw)
+    elif kind == "svf":
+        mod = dsp.SVF(size=(N, N), n_sections=3, **kw)
+    else:
+        mod = dsp.Biquad(size=(N, N), n_sections=2, filter_type="bandpass", **kw)
+    X0 = torch.randn(B, nfft // 2 + 1, N, device=gpu, dtype=torch.complex64)
+    C = torch.randn(B, nfft // 2 + 1, N, device=gpu, dtype=torch.complex64)
+    res = {}
+    try:
+        for narrow in (True, False):
+            dsp.NARROW_APPLY = narrow
+            mod.param.grad = None
+            X = X0.clone().requires_grad_(True)
+            ops.kernel_timer.reset(True)
+            Y = mod(X)
+            (Y * C.conj()).real.sum().backward()
+            torch.cuda.synchronize()
+            ops.kernel_timer.enabled = False
+            res[narrow] = (Y.detach().clone(), mod.param.grad.clone(), X.grad.clone(), set(ops.kernel_timer.summary()))
+    finally:
+        dsp.NARROW_APPLY = True
+        ops.kernel_timer.enabled = False
+    took = not any(n.startswith("mimo_gradh[") for n in res[True][3])
+    assert took == (B <= 2), res[True][3]
+    assert any(n.startswith("mimo_gradh[") for n in res[False][3])
+    assert relerr(res[True][0], res[False][0]) < 1e-6
+    assert relerr(res[True][2], res[False][2]) < 1e-6
+    # (the layered route rounds dL/dH to float32 before the cascade backward reads it; the fused one does not)
+    assert relerr(res[True][1], res[False][1]) < (5e-5 if kind == "peq" else 1e-5)
