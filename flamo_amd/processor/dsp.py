@@ -319,7 +319,17 @@ class Gain(DSP):
         return to_complex(self.map(param))
 
     def _bin_response(self, param):
-        return self._complex_mapped(param), self._diag
+        # once per Shell.forward: a Recursion asks for its modules' responses once per loop structure it tries, and the
+        # orthogonal map is a launch of its own (the memo entry keeps `param` alive, see DSP._response_once)
+        memo = ops.forward_memo()
+        if memo is None or not torch.is_tensor(param):
+            return self._complex_mapped(param), self._diag
+        key = (id(self), id(param), param._version, "mapped", torch.is_grad_enabled())
+        hit = memo.get(key)
+        if hit is None:
+            hit = (self._complex_mapped(param), param)
+            memo[key] = hit
+        return hit[0], self._diag
 
     def _real_matrix(self, param):
         """the mapped parameter as the real matrix it is (the response is its complex cast, dsp.py:466-468)"""
