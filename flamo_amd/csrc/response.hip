@@ -561,15 +561,18 @@ __global__ void __launch_bounds__(256, 3) sos_response_bwd_mixed_kernel(
                 const f2 Br = b0 + tbr * xr - tbi * xi, Bi = tbr * xi + tbi * xr;
                 const f2 Ar = a0 + tar * xr - tai * xi, Ai = tar * xi + tai * xr;
                 const f2 nb = Br * Br + Bi * Bi, na = Ar * Ar + Ai * Ai;
-                const bool ok0 = (nb.x > 1e-30f) & (nb.x < 1e30f) & (na.x > 1e-30f) & (na.x < 1e30f);
+                // one reciprocal per section for both quotients (v_rcp_f32 is a quarter-rate instruction: four of them were
+                // a quarter of this loop): 1/|B|^2 = |A|^2 / (|B|^2 |A|^2).  Both norms inside [1e-18, 1e18] keeps the
+                // product inside the float range; anything else is flagged for the double route as before.
+                const bool ok0 = (fminf(nb.x, na.x) > 1e-18f) && (fmaxf(nb.x, na.x) < 1e18f);
                 const bool pad1 = s + 1 >= S;
-                const bool ok1 = (nb.y > 1e-30f) & (nb.y < 1e30f) & (na.y > 1e-30f) & (na.y < 1e30f) & !pad1;
+                const bool ok1 = (fminf(nb.y, na.y) > 1e-18f) && (fmaxf(nb.y, na.y) < 1e18f) && !pad1;
                 slow |= (ok0 ? 0u : (1u << (2 * u))) | ((ok1 | pad1) ? 0u : (2u << (2 * u)));
-                f2 ib, ia;
-                ib.x = ok0 ? __builtin_amdgcn_rcpf(nb.x) : 0.f;
-                ib.y = ok1 ? __builtin_amdgcn_rcpf(nb.y) : 0.f;
-                ia.x = ok0 ? __builtin_amdgcn_rcpf(na.x) : 0.f;
-                ia.y = ok1 ? __builtin_amdgcn_rcpf(na.y) : 0.f;
+                const f2 nn = nb * na;
+                f2 inv;
+                inv.x = ok0 ? __builtin_amdgcn_rcpf(nn.x) : 0.f;
+                inv.y = ok1 ? __builtin_amdgcn_rcpf(nn.y) : 0.f;
+                const f2 ib = inv * na, ia = inv * nb;
                 // t = gh * conj(value) / |value|^2
                 const f2 tbR = (Br * gh.x + Bi * gh.y) * ib, tbI = (Br * gh.y - Bi * gh.x) * ib;
                 const f2 taR = (Ar * gh.x + Ai * gh.y) * ia, taI = (Ar * gh.y - Ai * gh.x) * ia;
