@@ -36,6 +36,13 @@ struct Dud {
     const cx<T>* U;   // row-major N x N
     const cx<T>* r;
     long r_sn, r_sf;
+    // A second left factor, l = l (.) l2 (the feedforward path's diagonal -- the delays of a feedback delay network --
+    // beside the feedback path's attenuation: their product is never formed), and with rhs_l2 the right-hand side is
+    // l2 (.) R as well (R = feedforward(X) is that same diagonal applied to the input): both as loads in the kernel
+    // instead of two launches forward and two backward.  Forward system only for rhs_l2 (the adjoint's RHS is a gradient).
+    const cx<T>* l2;
+    long l2_sn, l2_sf;
+    int rhs_l2;
 };
 
 // ---------------------------------------------------------------- DPP exchanges inside a 16-lane row
@@ -126,6 +133,7 @@ __global__ void __launch_bounds__(256) solve_kernel(
         cx<T> lv = one, rv = one;
         if (gi < N) {
             if (dud.l) lv = dud.l[(long)gi * dud.l_sn + (long)f * dud.l_sf];
+            if (dud.l2) lv = lv * dud.l2[(long)gi * dud.l2_sn + (long)f * dud.l2_sf];
             if (dud.r) rv = dud.r[(long)gi * dud.r_sn + (long)f * dud.r_sf];
         }
         const cx<T> own = adjoint ? rv : lv;       // the factor indexed by this lane's row
@@ -186,7 +194,10 @@ __global__ void __launch_bounds__(256) solve_kernel(
     for (int col = 0; col < ncols; ++col) {
         const int b = col / K, kk = col - b * K;
         cx<T> y(0, 0);
-        if (gi < N) y = R[(long)b * rs_b + (long)gi * rs_n + (long)kk * rs_k + f];
+        if (gi < N) {
+            y = R[(long)b * rs_b + (long)gi * rs_n + (long)kk * rs_k + f];
+            if (dud.rhs_l2 && !adjoint) y = y * dud.l2[(long)gi * dud.l2_sn + (long)f * dud.l2_sf];
+        }
         // forward substitution with the stored multipliers
 #pragma unroll
         for (int k = 0; k < NMAX; ++k) {
@@ -430,6 +441,7 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
             cx<T> lv = one, rv = one;
             if (ri < N) {
                 if (dud.l) lv = dud.l[(long)ri * dud.l_sn + (long)f * dud.l_sf];
+                if (dud.l2) lv = lv * dud.l2[(long)ri * dud.l2_sn + (long)f * dud.l2_sf];
                 if (dud.r) rv = dud.r[(long)ri * dud.r_sn + (long)f * dud.r_sf];
             }
             own[s] = adjoint ? conj(rv) : lv;
@@ -575,7 +587,10 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
             y[s] = cx<T>(0, 0);
-            if (s * LANES + gi < N) y[s] = R[(long)b * rs_b + (long)orig[s] * rs_n + (long)kk * rs_k + f];
+            if (s * LANES + gi < N) {
+                y[s] = R[(long)b * rs_b + (long)orig[s] * rs_n + (long)kk * rs_k + f];
+                if (dud.rhs_l2 && !(adjoint & 1)) y[s] = y[s] * dud.l2[(long)orig[s] * dud.l2_sn + (long)f * dud.l2_sf];
+            }
         }
         static_for<0, NMAX - 1>([&](auto kc) {          // forward: y_i -= L[i][k] y_k, i > k
             constexpr int KK = decltype(kc)::value;
@@ -692,7 +707,7 @@ template <typename T, int NP, bool WR>
 __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud_grads_kernel(Dud<T> d, const cx<T>* __restrict__ gR, const cx<T>* __restrict__ OUT, long s_b,
                                                         long s_n, long s_k, int B, int M, int N, int K, int bins_per_block,
                                                         cx<T>* __restrict__ gl, long gl_sn, cx<T>* __restrict__ gr, long gr_sn,
-                                                        cx<T>* __restrict__ partU) {
+                                                        cx<T>* __restrict__ partU, cx<T>* __restrict__ gR0) {
     constexpr int BPI = 256 / NP, LDT = NP + 2;      // rows 16-byte aligned and conflict-free for 16-byte reads
     extern __shared__ __attribute__((aligned(32))) char smem_dg[];
     cx<T>* Us = reinterpret_cast<cx<T>*>(smem_dg);   // [NP][LDT]
@@ -714,7 +729,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
     // pointers, 16-byte LDS reads -- and PF rounds of operands are in flight per thread.
     const int BK = B * K;
     const int rounds = f_begin < f_end ? ((f_end - f_begin + BPI - 1) / BPI) * BK : 0;
-    struct Ops { cx<T> g, o, l, r; };
+    struct Ops { cx<T> g, o, l, r, l2; };
     // Loads are unconditional, from clamped addresses (lanes outside the problem re-read the last valid element and are
     // zeroed when consumed; an absent factor reads a constant 1 with stride 0): loads under divergent control flow get an
     // s_waitcnt vmcnt(0) at the join, which would serialise every round on the memory latency.
@@ -726,6 +741,10 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
     const long l_sf = d.l ? d.l_sf : 0, r_sf = d.r ? d.r_sf : 0;
     const cx<T>* lp = d.l ? d.l + (long)ic * d.l_sn + (long)f_begin * d.l_sf : one;
     const cx<T>* rp = d.r ? d.r + (long)ic * d.r_sn + (long)f_begin * d.r_sf : one;
+    // second left factor (Dud::l2): l = l (.) l2; then gl is the gradient of the FIRST factor, gl (.) conj(l2), and gR0
+    // (when asked for) the gradient of the unscaled right-hand side, conj(l2) (.) gR
+    const long l2_sf = d.l2 ? d.l2_sf : 0;
+    const cx<T>* l2p = d.l2 ? d.l2 + (long)ic * d.l2_sn + (long)f_begin * d.l2_sf : one;
     int fit = 0, fb = 0, fk = 0;               // fetch side (uniform)
     auto fetch = [&]() {
         Ops x;
@@ -735,6 +754,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
         x.o = OUTp[off];
         x.l = lp[(long)fl * l_sf];
         x.r = rp[(long)fl * r_sf];
+        x.l2 = l2p[(long)fl * l2_sf];
         if (++fk == K) {
             fk = 0;
             if (++fb == B) {
@@ -749,7 +769,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
 #pragma unroll
     for (int u = 0; u < PF; ++u) ring[u] = fetch();
     cx<T> gl_acc(0, 0), gr_acc(0, 0);
-    int cit = 0, cbk = 0;                        // consume side (uniform)
+    int cit = 0, cbk = 0, cb = 0, ck = 0;        // consume side (uniform)
     __syncthreads();                             // U is in LDS
     // (rounds past the end run on zeros -- no early exit inside the unrolled body, whose phi moves cost more than the
     // arithmetic they skip)
@@ -762,7 +782,13 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
             if (!(row && cit * BPI + bl <= span)) x.g = x.o = cx<T>(0, 0);
             cx<T>* t1b = t1s + (q & 1) * BPI * LDT;     // double-buffered: one barrier per round
             cx<T>* t2b = t2s + (q & 1) * BPI * LDT;
-            const cx<T> t2 = mulc(x.g, x.l);            // conj(l) gR
+            if (gR0 && row && cit * BPI + bl <= span)
+                gR0[(long)i * s_n + f_begin + cit * BPI + bl + (long)cb * s_b + (long)ck * s_k] = mulc(x.g, x.l2);
+            if (++ck == K) {
+                ck = 0;
+                if (++cb == B) cb = 0;
+            }
+            const cx<T> t2 = mulc(x.g, x.l * x.l2);     // conj(l) gR
             t1b[bl * LDT + i] = x.r * x.o;
             if (WR) t2b[bl * LDT + i] = t2;
             __syncthreads();
@@ -791,7 +817,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
             if (++cbk == BK) {
                 const int f = f_begin + cit * BPI + bl;
                 if (row && f < f_end) {
-                    if (gl) gl[(long)i * gl_sn + f] = gl_acc;
+                    if (gl) gl[(long)i * gl_sn + f] = mulc(gl_acc, x.l2);
                     if (WR) gr[(long)i * gr_sn + f] = gr_acc;
                 }
                 gl_acc = cx<T>(0, 0);
@@ -866,7 +892,7 @@ static int dud_grads_blocks(int M, int N) {
 
 template <typename T>
 static int dud_grads_impl(const Dud<T>& d, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N, int K,
-                          void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* stream) {
+                          void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* stream, void* gR0 = nullptr) {
     FL_REQUIRE(d.U && gR && OUT, "solve_dud_grads: null pointer");
     FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0, "solve_dud_grads: bad sizes");
     FL_REQUIRE((partU == nullptr) == (gU == nullptr), "solve_dud_grads: partU and gU go together");
@@ -893,11 +919,11 @@ static int dud_grads_impl(const Dud<T>& d, const void* gR, const void* OUT, long
         if (gr)                                                                                                                 \
             hipLaunchKernelGGL((dud_grads_kernel<T, NP_, true>), dim3(nblk), dim3(256), lds, st, d, (const cx<T>*)gR,           \
                                (const cx<T>*)OUT, s_b, s_n, s_k, B, M, N, K, per, (cx<T>*)gl, gl_sn, (cx<T>*)gr, gr_sn,         \
-                               (cx<T>*)partU);                                                                                  \
+                               (cx<T>*)partU, (cx<T>*)gR0);                                                                     \
         else                                                                                                                    \
             hipLaunchKernelGGL((dud_grads_kernel<T, NP_, false>), dim3(nblk), dim3(256), lds, st, d, (const cx<T>*)gR,          \
                                (const cx<T>*)OUT, s_b, s_n, s_k, B, M, N, K, per, (cx<T>*)gl, gl_sn, (cx<T>*)gr, gr_sn,         \
-                               (cx<T>*)partU);                                                                                  \
+                               (cx<T>*)partU, (cx<T>*)gR0);                                                                     \
     }
     if (N <= 4) FL_DG(4) else if (N <= 8) FL_DG(8) else if (N <= 16) FL_DG(16) else if (N <= 32) FL_DG(32) else {
         if constexpr (sizeof(T) == 4) FL_DG(64) else return FL_ERR_UNSUPPORTED;
@@ -976,5 +1002,38 @@ int fl_solve_dud_grads_c128(const void* l, long l_sn, long l_sf, const void* U, 
                             long gr_sn, void* partU, void* gU, void* stream) {
     Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf};
     return dud_grads_impl<double>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream);
+}
+/* two left factors: A_f = I - diag(l (.) l2) U diag(r); rhs_l2: the right-hand side is l2 (.) R (forward system) */
+int fl_solve_dud2_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, int rhs_l2, const void* U,
+                      const void* r, long r_sn, long r_sf, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+                      long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+    FL_REQUIRE(U && l2, "solve_dud2: null pointer");
+    Dud<float> d = {(const cx<float>*)l, l_sn, l_sf, (const cx<float>*)U, (const cx<float>*)r, r_sn, r_sf,
+                    (const cx<float>*)l2, l2_sn, l2_sf, rhs_l2};
+    return solve_impl<float>(nullptr, 0, d, 1, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+int fl_solve_dud2_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, int rhs_l2, const void* U,
+                       const void* r, long r_sn, long r_sf, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+                       long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+    FL_REQUIRE(U && l2, "solve_dud2: null pointer");
+    Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf,
+                     (const cx<double>*)l2, l2_sn, l2_sf, rhs_l2};
+    return solve_impl<double>(nullptr, 0, d, 1, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+int fl_solve_dud2_grads_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                            long r_sn, long r_sf, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N,
+                            int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, void* stream) {
+    FL_REQUIRE(l2, "solve_dud2_grads: null pointer");
+    Dud<float> d = {(const cx<float>*)l, l_sn, l_sf, (const cx<float>*)U, (const cx<float>*)r, r_sn, r_sf,
+                    (const cx<float>*)l2, l2_sn, l2_sf, 0};
+    return dud_grads_impl<float>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream, gR0);
+}
+int fl_solve_dud2_grads_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                             long r_sn, long r_sf, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N,
+                             int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, void* stream) {
+    FL_REQUIRE(l2, "solve_dud2_grads: null pointer");
+    Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf,
+                     (const cx<double>*)l2, l2_sn, l2_sf, 0};
+    return dud_grads_impl<double>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream, gR0);
 }
 }

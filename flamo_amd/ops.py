@@ -1027,6 +1027,82 @@ class _SolveDUD(torch.autograd.Function):
         return gl, gU, gr, (gR if ctx.needs_input_grad[3] else None)
 
 
+class _SolveDUD2(torch.autograd.Function):
+    """OUT = (I - diag(l . l2) U diag(r))^-1 (l2 . R0) per bin: the loop of a feedback delay network with the feedforward
+    path's diagonal l2 (no gradient) applied where the kernels load l and the right-hand side (fl_solve_dud2_*).
+    l, r: per-bin (M, N) or None; l2: per-bin (M, N)."""
+
+    @staticmethod
+    def forward(ctx, l, l2, U, r, R0):
+        _require_gpu(l2, U, R0)
+        Rp = to_planar(R0.resolve_conj())
+        Uc = U.resolve_conj().contiguous()
+        pl = lambda t: None if t is None else _h_planar(t.resolve_conj(), True)  # noqa: E731
+        lp, l2p, rp = pl(l), pl(l2), pl(r)
+        OUT = _solve_dud2_launch(lp, l2p, True, Uc, rp, False, Rp)
+        ctx.have = (l is not None, r is not None)
+        ctx.save_for_backward(*([t for t in (lp, rp) if t is not None] + [l2p, Uc, OUT]))
+        return OUT
+
+    @staticmethod
+    def backward(ctx, gOUT):
+        saved = list(ctx.saved_tensors)
+        lp = saved.pop(0) if ctx.have[0] else None
+        rp = saved.pop(0) if ctx.have[1] else None
+        l2p, Uc, OUT = saved
+        gR = _solve_dud2_launch(lp, l2p, False, Uc, rp, True, to_planar(gOUT.resolve_conj()))     # A^-H g
+        need_l, need_U, need_r, need_R = (ctx.needs_input_grad[0] and lp is not None, ctx.needs_input_grad[2],
+                                          ctx.needs_input_grad[3] and rp is not None, ctx.needs_input_grad[4])
+        real = _rdtype(OUT)
+        B, M, N, K, s_b, s_n, s_k = _bnk(OUT)
+        dev = OUT.device
+        L = _lib.lib()
+        gl = _empty_rows((N,), M, OUT.dtype, dev) if need_l else None
+        gr = _empty_rows((N,), M, OUT.dtype, dev) if need_r else None
+        gR0 = _empty_planar(OUT.shape, OUT.dtype, dev) if need_R else None
+        part = gU = None
+        if need_U:
+            part = torch.empty((L.fl_solve_dud_grads_blocks(M, N), N, N), dtype=OUT.dtype, device=dev)
+            gU = torch.empty((N, N), dtype=OUT.dtype, device=dev)
+        if need_l or need_U or need_r or need_R:
+            lptr, l_sn, l_sf = _diag_args(lp)
+            l2ptr, l2_sn, l2_sf = _diag_args(l2p)
+            rptr, r_sn, r_sf = _diag_args(rp)
+            fn = L.fl_solve_dud2_grads_c64 if real == torch.float32 else L.fl_solve_dud2_grads_c128
+            ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+            with kernel_timer.span("solve_dud_grads"):
+                _lib.check(fn(lptr, l_sn, l_sf, l2ptr, l2_sn, l2_sf, Uc.data_ptr(), rptr, r_sn, r_sf, gR.data_ptr(), OUT.data_ptr(),
+                              s_b, s_n, s_k, B, M, N, K, ptr(gl), _pitch(M), ptr(gr), _pitch(M), ptr(part), ptr(gU), ptr(gR0),
+                              _stream()), "solve_dud2_grads")
+        return (None if gl is None else gl.movedim(-1, 0)), None, gU, (None if gr is None else gr.movedim(-1, 0)), gR0
+
+
+def _solve_dud2_launch(l, l2, rhs_l2, U, r, adjoint, R):
+    real = _rdtype(R)
+    B, M, N, K, rs_b, rs_n, rs_k = _bnk(R)
+    OUT = _empty_planar(R.shape, R.dtype, R.device)
+    _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
+    L = _lib.lib()
+    fn = L.fl_solve_dud2_c64 if real == torch.float32 else L.fl_solve_dud2_c128
+    lp, l_sn, l_sf = _diag_args(l)
+    l2p, l2_sn, l2_sf = _diag_args(l2)
+    rp, r_sn, r_sf = _diag_args(r)
+    with kernel_timer.span("solve_dud_adj" if adjoint else "solve_dud"):
+        _lib.check(fn(lp, l_sn, l_sf, l2p, l2_sn, l2_sf, int(rhs_l2), U.data_ptr(), rp, r_sn, r_sf, int(adjoint), R.data_ptr(),
+                      rs_b, rs_n, rs_k, OUT.data_ptr(), os_b, os_n, os_k, B, M, N, K, _stream()), "solve_dud2")
+    return OUT
+
+
+def solve_dud2(l: Optional[torch.Tensor], l2: torch.Tensor, U: torch.Tensor, r: Optional[torch.Tensor], R0: torch.Tensor) -> torch.Tensor:
+    """Per bin f: (I - diag(l[f] . l2[f]) U diag(r[f]))^-1 (l2[f] . R0[:, f]); l, r: per-bin (M, N) or None, l2: per-bin
+    (M, N) without gradient (the diagonal of the feedforward path, which also scales the right-hand side)."""
+    if l2.requires_grad:
+        raise ValueError("solve_dud2: the feedforward diagonal must not require a gradient (use solve_dud)")
+    cd = R0.dtype
+    conv = lambda t: None if t is None else (t if t.dtype == cd else t.to(cd))  # noqa: E731
+    return _SolveDUD2.apply(conv(l), conv(l2), conv(U), conv(r), R0)
+
+
 def _solve_scaled_launch(DU, g, adjoint, R):
     real = _rdtype(R)
     B, M, N, K, rs_b, rs_n, rs_k = _bnk(R)

@@ -38,6 +38,9 @@ FUSE_MATRIX_CASCADE = True
 # Recursion whose loop is diag(g) D[f] U (per-bin delay matrix, per-channel gains, mixing matrix): the gains scale rows
 # inside the solve and the backward pass forms no (M, N, N) gradient (ops.solve_scaled_loop)
 SCALED_LOOP = True
+# FDN loops whose feedforward path is one diagonal module without gradient (the delays): applied inside the factored solve
+# and its one-pass backward (ops.solve_dud2) instead of as launches of its own
+FDN_DIAGONAL_IN_SOLVE = True
 # Gradients of the parameters are then produced on the side stream while their AccumulateGrad
 # nodes live on the main one; autograd synchronises the two correctly and merely warns about it.
 _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -349,6 +352,12 @@ class Recursion(nn.Module):
             return self.__forward_in_loop(X, ext_param, ext_fb, ext_ff)
 
     def __forward_in_loop(self, X, ext_param, ext_fb, ext_ff):
+        if FUSE_SERIES and FDN_DIAGONAL_IN_SOLVE and ext_param is None and torch.is_tensor(X) and X.is_cuda and X.is_complex():
+            d2 = self.__factored_loop_with_feedforward(X)
+            if d2 is not None:
+                # FDN structure with a diagonal feedforward path (the delays): that diagonal scales l and the right-hand
+                # side where the solve kernels load them (ops.solve_dud2) instead of in launches of its own
+                return ops.solve_dud2(d2[0], d2[1], d2[2], d2[3], X)
         R = self.feedforward(X, ext_ff)
         if FUSE_SERIES and ext_param is None and torch.is_tensor(R) and R.is_cuda:
             dud = self.__factored_loop(R)
@@ -422,6 +431,41 @@ class Recursion(nn.Module):
         if D.requires_grad:
             return None
         return g, D, U
+
+    def __factored_loop_with_feedforward(self, X):
+        """(l, l2, U, r) when the feedforward path is ONE diagonal per-bin module without gradient (l2: parallelDelay in
+        every FDN of the reference) and the feedback path is one constant full matrix with per-bin diagonal factors around
+        it (l: those applied after it, r: before); else None.  P = diag(l . l2) U diag(r),  R = l2 . X."""
+        ff = list(self.feedforward) if isinstance(self.feedforward, Series) else [self.feedforward]
+        if len(ff) != 1 or isinstance(ff[0], Series) or not (hasattr(ff[0], "_fusable") and ff[0]._fusable()):
+            return None
+        fb = list(self.feedback) if isinstance(self.feedback, Series) else [self.feedback]
+        for m in fb:
+            if isinstance(m, Series) or not (hasattr(m, "_fusable") and m._fusable()):
+                return None
+        N, M = self.output_channels, X.shape[1]
+        if X.dim() < 3 or X.shape[2] != N or ff[0].input_channels != N:
+            return None
+        shape = [1, M, N, N]
+        l2, d2 = ff[0]._response_for_fusion(shape, None)
+        if not d2 or l2.dim() != 2 or l2.requires_grad or not l2.is_complex():
+            return None
+        l = r = U = None
+        for m in fb:
+            H, diag = m._response_for_fusion(shape, None)
+            shape[2] = m.output_channels
+            if diag:
+                if H.dim() != 2:
+                    return None                                    # constant diagonals keep the generic factored route
+                if U is None:
+                    r = H if r is None else _diag_mul(H, r)
+                else:
+                    l = H if l is None else _diag_mul(H, l)
+            else:
+                if U is not None or H.dim() != 2 or tuple(H.shape) != (N, N):
+                    return None
+                U = H
+        return None if U is None else (l, l2, U, r)
 
     def __factored_loop(self, R):
         """If feedback-then-feedforward is a chain of per-bin modules with exactly one full,

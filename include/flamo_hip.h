@@ -365,6 +365,24 @@ int fl_solve_dud_grads_c64(const void* l, long l_sn, long l_sf, const void* U, c
 int fl_solve_dud_grads_c128(const void* l, long l_sn, long l_sf, const void* U, const void* r, long r_sn, long r_sf, const void* gR,
                             const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N, int K, void* gl, long gl_sn, void* gr,
                             long gr_sn, void* partU, void* gU, void* stream);
+/* The factored solve and its one-pass backward with TWO left factors, l = l (.) l2 (l may be NULL), and optionally the
+ * right-hand side scaled by l2 as well (rhs_l2, forward system): the loop of a feedback delay network has
+ * P = diag(delays (.) attenuation) U and R = delays (.) (input gains x) (system.py:417-424 over reverb.py:117-199) -- the
+ * delay factor is applied by the kernels where they load l and R instead of two diagonal-product launches forward and two
+ * backward.  l2 carries no gradient.  In the backward: gl is the gradient of the FIRST factor (sum gR conj(U(r.out)) times
+ * conj(l2)), and gR0 (NULL = not wanted; same layout as gR) = conj(l2) (.) gR, the gradient of the unscaled R. */
+int fl_solve_dud2_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, int rhs_l2, const void* U,
+                      const void* r, long r_sn, long r_sf, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+                      long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream);
+int fl_solve_dud2_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, int rhs_l2, const void* U,
+                       const void* r, long r_sn, long r_sf, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+                       long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream);
+int fl_solve_dud2_grads_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                            long r_sn, long r_sf, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N,
+                            int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, void* stream);
+int fl_solve_dud2_grads_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                             long r_sn, long r_sf, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N,
+                             int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, void* stream);
 /* tuning/test hook: 0 (default) = N <= 16 factor with rows exchanged in place (compile-time DPP broadcasts,
  * threshold pivoting); 1 = the shuffle kernel with implicit partial pivoting for every N */
 int fl_debug_set_solve_variant(int variant);

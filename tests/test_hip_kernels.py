@@ -693,3 +693,74 @@ def test_scaled_loop_solve_matches_composed_loop(gpu, N):
         assert relerr(a, b) < 1e-10
     assert not any(n.startswith("mimo_gradh[") for n in res[True][3]), res[True][3]     # no (M, N, N) gradient tensor
     assert any(n.startswith("mimo_gradh[") for n in res[False][3])
+
+
+@pytest.mark.parametrize("N", [4, 6, 16, 24])
+@pytest.mark.parametrize("have", [(True, False), (False, False), (True, True)])
+def test_factored_solve_with_feedforward_diagonal(gpu, N, have):
+    """ops.solve_dud2: (I - diag(l . l2) U diag(r))^-1 (l2 . R0) with l2 applied inside the kernels (fl_solve_dud2_*,
+    fl_solve_dud2_grads_*) against ops.solve_dud on explicitly formed l . l2 and l2 . R0, and against LAPACK autograd in
+    float64: output and the gradients of l, U, r, R0."""
+    from flamo_amd import ops
+    torch.manual_seed(3 * N + have[0] + 2 * have[1])
+    M, B, K = 203, 2, 2
+    for cd, tol in ((torch.complex128, 1e-11), (torch.complex64, 3e-5)):
+        U64 = torch.linalg.qr(torch.randn(N, N, dtype=torch.float64))[0].to(torch.complex128)
+        l64 = 0.95 * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64)) if have[0] else None
+        r64 = (0.8 + 0.15 * torch.rand(M, N, dtype=torch.float64)) * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64)) \
+            if have[1] else None
+        l2_64 = (0.97 if have[0] else 0.9) * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64))
+        R64 = torch.randn(B, M, N, K, dtype=torch.complex128)
+        C64 = torch.randn(B, M, N, K, dtype=torch.complex128)
+        ref_in = [None if t is None else t.clone().requires_grad_(True) for t in (l64, U64, r64, R64)]
+        P = ref_in[1].unsqueeze(0).expand(M, N, N) * l2_64.unsqueeze(-1)
+        if have[0]:
+            P = ref_in[0].unsqueeze(-1) * P
+        if have[1]:
+            P = P * ref_in[2].unsqueeze(-2)
+        A = torch.eye(N, dtype=torch.complex128) - P
+        Yr = torch.linalg.solve(A.unsqueeze(0), l2_64.unsqueeze(-1) * ref_in[3])
+        live = [i for i, t in enumerate(ref_in) if t is not None]
+        gref = torch.autograd.grad(torch.sum(torch.real(Yr * torch.conj(C64))), [ref_in[i] for i in live])
+        dev_in = [None if t is None else t.detach().to(gpu, cd).requires_grad_(True) for t in (l64, U64, r64, R64)]
+        Y = ops.solve_dud2(dev_in[0], l2_64.to(gpu, cd), dev_in[1], dev_in[2], dev_in[3])
+        g = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C64.to(gpu, cd)))), [dev_in[i] for i in live])
+        for name, a, b in zip(["Y"] + [["l", "U", "r", "R"][i] for i in live], [Y.detach()] + list(g), [Yr.detach()] + list(gref)):
+            assert relerr(a.cpu().to(torch.complex128), b) < tol, (name, cd)
+
+
+def test_fdn_feedforward_diagonal_inside_the_solve(gpu):
+    """Recursion(fF=parallelDelay, fB=Series(Matrix orthogonal, parallelGEQ)) with and without FDN_DIAGONAL_IN_SOLVE:
+    same output and parameter gradients, four diagonal-product launches fewer."""
+    from collections import OrderedDict
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    torch.manual_seed(5)
+    nfft, N = 4800, 6
+    for dt, tol in ((torch.float64, 1e-10), (torch.float32, 2e-5)):
+        kw = dict(nfft=nfft, alias_decay_db=30.0, device=gpu, dtype=dt)
+        dl = dsp.parallelDelay(size=(N,), max_len=300, isint=True, **kw)
+        mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+        att = dsp.parallelGEQ(size=(N,), requires_grad=True, **kw)
+        with torch.no_grad():
+            att.param.copy_(0.5 + 0.4 * torch.rand_like(att.param))
+        loop = system.Recursion(fF=dl, fB=system.Series(OrderedDict(mixing_matrix=mix, attenuation=att)))
+        cd = torch.complex128 if dt == torch.float64 else torch.complex64
+        X0 = torch.randn(2, nfft // 2 + 1, N, device=gpu, dtype=cd)
+        C = torch.randn(2, nfft // 2 + 1, N, device=gpu, dtype=cd)
+        res = {}
+        try:
+            for on in (True, False):
+                system.FDN_DIAGONAL_IN_SOLVE = on
+                X = X0.clone().requires_grad_(True)
+                ops.kernel_timer.reset(True)
+                Y = loop(X)
+                g = torch.autograd.grad(torch.sum(torch.real(Y * C.conj())), [mix.param, att.param, X])
+                torch.cuda.synchronize()
+                ops.kernel_timer.enabled = False
+                res[on] = (Y.detach(), *g)
+        finally:
+            system.FDN_DIAGONAL_IN_SOLVE = True
+            ops.kernel_timer.enabled = False
+        for a, b in zip(res[True], res[False]):
+            assert relerr(a, b) < tol
