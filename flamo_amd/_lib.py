@@ -106,6 +106,10 @@ _SIGNATURES = {
     "fl_matrix_exp_cplx_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "fl_matrix_exp_bwd_cplx_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "fl_matrix_exp_bwd_cplx_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "fl_matrix_exp_both_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "fl_matrix_exp_both_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "fl_matrix_exp_bwd_both_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "fl_matrix_exp_bwd_both_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "fl_eig_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
     "fl_eig_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
 }

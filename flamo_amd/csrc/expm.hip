@@ -69,7 +69,7 @@ __device__ inline void lds_store(double* __restrict__ dst, const double* __restr
 
 template <typename T, int NT>
 __global__ void __launch_bounds__(1024) expm_fwd_kernel(const T* __restrict__ X, int Nrt, int skew, T* __restrict__ E,
-                                                       double* __restrict__ stash, int cplx) {
+                                                       T* __restrict__ Ec, double* __restrict__ stash) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = NT > 0 ? NT : Nrt;
     const int NN = N * N, NP = N | 1;
@@ -135,21 +135,21 @@ __global__ void __launch_bounds__(1024) expm_fwd_kernel(const T* __restrict__ X,
         __syncthreads();
         double* t = P; P = Q; Q = t;
     }
-    // cplx: E is stored as the complex matrix (re, 0) the per-bin kernels take (no real -> complex pass afterwards)
+    // E: the real matrix; Ec: the same as the complex matrix (re, 0) the per-bin kernels take (no real -> complex pass
+    // afterwards); either may be null
     for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
         const T v = (T)P[(idx / N) * NP + idx % N];
-        if (cplx) {
-            E[2 * idx] = v;
-            E[2 * idx + 1] = (T)0;
-        } else {
-            E[idx] = v;
+        if (Ec) {
+            Ec[2 * idx] = v;
+            Ec[2 * idx + 1] = (T)0;
         }
+        if (E) E[idx] = v;
     }
 }
 
 template <typename T, int NT>
-__global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE, int Nrt, int skew,
-                                                       const double* __restrict__ stash, T* __restrict__ gX, int cplx) {
+__global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE, const T* __restrict__ gEc, int Nrt, int skew,
+                                                       const double* __restrict__ stash, T* __restrict__ gX) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = NT > 0 ? NT : Nrt;
     const int NN = N * N, NP = N | 1;
@@ -163,7 +163,8 @@ __global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE
     const int p1 = as_lds ? NP : N;
     for (int idx = threadIdx.x; idx < NN; idx += blockDim.x) {
         const int o = (idx / N) * NP + idx % N;
-        G[o] = (double)gE[cplx ? 2 * idx : idx];      // cplx: the real part of a complex gradient
+        // gradient of the real output plus the real part of the complex output's gradient (either may be null)
+        G[o] = (gE ? (double)gE[idx] : 0.0) + (gEc ? (double)gEc[2 * idx] : 0.0);
         dA[o] = 0.0;
     }
     if (as_lds) lds_load<NT>(S0 + N * NP, stash, N);
@@ -222,8 +223,8 @@ static int expm_threads(int N) {
 }
 
 template <typename T>
-static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* stash, void* stream, int cplx = 0) {
-    FL_REQUIRE(X && E && stash, "matrix_exp: null pointer");
+static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* Ec, void* stash, void* stream) {
+    FL_REQUIRE(X && (E || Ec) && stash, "matrix_exp: null pointer");
     FL_REQUIRE(N >= 1 && N <= 64, "matrix_exp: 1 <= N <= 64 (one workgroup, matrices in LDS)");
     const size_t lds = (size_t)3 * N * (N | 1) * sizeof(double);
     if (lds > 64 * 1024) {
@@ -233,7 +234,7 @@ static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* stash, v
     }
 #define FL_EXPM_FWD(NT_)                                                                                                   \
     hipLaunchKernelGGL((expm_fwd_kernel<T, NT_>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)X, N, \
-                       skew, (T*)E, (double*)stash, cplx)
+                       skew, (T*)E, (T*)Ec, (double*)stash)
     switch (N) {        // (the fixed sizes all fit the default 64 KB of dynamic LDS)
         case 4: FL_EXPM_FWD(4); break;
         case 8: FL_EXPM_FWD(8); break;
@@ -247,8 +248,8 @@ static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* stash, v
 }
 
 template <typename T>
-static int expm_bwd_impl(const void* gE, int N, int skew, const void* stash, void* gX, void* stream, int cplx = 0) {
-    FL_REQUIRE(gE && stash && gX, "matrix_exp_bwd: null pointer");
+static int expm_bwd_impl(const void* gE, const void* gEc, int N, int skew, const void* stash, void* gX, void* stream) {
+    FL_REQUIRE((gE || gEc) && stash && gX, "matrix_exp_bwd: null pointer");
     FL_REQUIRE(N >= 1 && N <= 64, "matrix_exp_bwd: 1 <= N <= 64");
     size_t lds = (size_t)5 * N * (N | 1) * sizeof(double);
     if (lds > 160 * 1024) lds = (size_t)4 * N * (N | 1) * sizeof(double);
@@ -258,8 +259,8 @@ static int expm_bwd_impl(const void* gE, int N, int skew, const void* stash, voi
         if (rc) return rc;
     }
 #define FL_EXPM_BWD(NT_)                                                                                                     \
-    hipLaunchKernelGGL((expm_bwd_kernel<T, NT_>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)gE, N, \
-                       skew, (const double*)stash, (T*)gX, cplx)
+    hipLaunchKernelGGL((expm_bwd_kernel<T, NT_>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)gE,    \
+                       (const T*)gEc, N, skew, (const double*)stash, (T*)gX)
     switch (N) {
         case 4: FL_EXPM_BWD(4); break;
         case 8: FL_EXPM_BWD(8); break;
@@ -279,27 +280,39 @@ using namespace fl;
 extern "C" {
 size_t fl_matrix_exp_stash_elems(int N) { return (size_t)EXPM_SLOTS * N * N + 1; }
 int fl_matrix_exp_f32(const void* X, int N, int skew, void* E, void* stash, void* stream) {
-    return expm_fwd_impl<float>(X, N, skew, E, stash, stream);
+    return expm_fwd_impl<float>(X, N, skew, E, nullptr, stash, stream);
 }
 int fl_matrix_exp_f64(const void* X, int N, int skew, void* E, void* stash, void* stream) {
-    return expm_fwd_impl<double>(X, N, skew, E, stash, stream);
+    return expm_fwd_impl<double>(X, N, skew, E, nullptr, stash, stream);
 }
 int fl_matrix_exp_bwd_f32(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
-    return expm_bwd_impl<float>(gE, N, skew, stash, gX, stream);
+    return expm_bwd_impl<float>(gE, nullptr, N, skew, stash, gX, stream);
 }
 int fl_matrix_exp_bwd_f64(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
-    return expm_bwd_impl<double>(gE, N, skew, stash, gX, stream);
+    return expm_bwd_impl<double>(gE, nullptr, N, skew, stash, gX, stream);
 }
 int fl_matrix_exp_cplx_f32(const void* X, int N, int skew, void* E, void* stash, void* stream) {
-    return expm_fwd_impl<float>(X, N, skew, E, stash, stream, 1);
+    return expm_fwd_impl<float>(X, N, skew, nullptr, E, stash, stream);
 }
 int fl_matrix_exp_cplx_f64(const void* X, int N, int skew, void* E, void* stash, void* stream) {
-    return expm_fwd_impl<double>(X, N, skew, E, stash, stream, 1);
+    return expm_fwd_impl<double>(X, N, skew, nullptr, E, stash, stream);
 }
 int fl_matrix_exp_bwd_cplx_f32(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
-    return expm_bwd_impl<float>(gE, N, skew, stash, gX, stream, 1);
+    return expm_bwd_impl<float>(nullptr, gE, N, skew, stash, gX, stream);
 }
 int fl_matrix_exp_bwd_cplx_f64(const void* gE, int N, int skew, const void* stash, void* gX, void* stream) {
-    return expm_bwd_impl<double>(gE, N, skew, stash, gX, stream, 1);
+    return expm_bwd_impl<double>(nullptr, gE, N, skew, stash, gX, stream);
+}
+int fl_matrix_exp_both_f32(const void* X, int N, int skew, void* E, void* Ec, void* stash, void* stream) {
+    return expm_fwd_impl<float>(X, N, skew, E, Ec, stash, stream);
+}
+int fl_matrix_exp_both_f64(const void* X, int N, int skew, void* E, void* Ec, void* stash, void* stream) {
+    return expm_fwd_impl<double>(X, N, skew, E, Ec, stash, stream);
+}
+int fl_matrix_exp_bwd_both_f32(const void* gE, const void* gEc, int N, int skew, const void* stash, void* gX, void* stream) {
+    return expm_bwd_impl<float>(gE, gEc, N, skew, stash, gX, stream);
+}
+int fl_matrix_exp_bwd_both_f64(const void* gE, const void* gEc, int N, int skew, const void* stash, void* gX, void* stream) {
+    return expm_bwd_impl<double>(gE, gEc, N, skew, stash, gX, stream);
 }
 }

@@ -44,19 +44,23 @@ class GraphedStep:
                 p.grad = g
 
     def _run_eager(self):
+        from . import ops
         for p in self.params:
             p.grad = None
-        out = self._fn(*self.static_inputs)
-        out.backward()
+        with ops.step_scope():
+            out = self._fn(*self.static_inputs)
+            out.backward()
         # the all-ones gradient seed of the captured backward: allocated once here instead of being
         # filled by a launch in every replay
         self._seed = torch.ones_like(out)
         return out.detach()
 
     def _run_captured(self):
-        out = self._fn(*self.static_inputs)
-        seed = self._seed if (self._seed is not None and self._seed.shape == out.shape and self._seed.dtype == out.dtype) else None
-        grads = torch.autograd.grad(out, self.params, grad_outputs=seed, allow_unused=True) if self.params else ()
+        from . import ops
+        with ops.step_scope():
+            out = self._fn(*self.static_inputs)
+            seed = self._seed if (self._seed is not None and self._seed.shape == out.shape and self._seed.dtype == out.dtype) else None
+            grads = torch.autograd.grad(out, self.params, grad_outputs=seed, allow_unused=True) if self.params else ()
         self._static_grads = [None if g is None else (g if g.is_contiguous() else g.contiguous()) for g in grads]
         return out.detach()
 

@@ -274,6 +274,7 @@ class _PerThread(threading.local):
         self.shard = {"bin0": 0, "m_local": None, "order": None}
         self.side_streams = {}
         self.loop_depth = 0
+        self.step_memo = None
 
 
 _tls = _PerThread()
@@ -293,6 +294,27 @@ class loop_scope:
 
 def in_loop() -> bool:
     return _tls.loop_depth > 0
+
+
+class step_scope:
+    """One training / evaluation step (forward, criteria, backward): inside it a parameter map that is a launch of its own
+    -- the orthogonal map exp(skew(x)) -- is evaluated once per parameter version, however many callers ask for it (the
+    model and a sparsity criterion on the same mixing matrix, as in the reference's colorless-FDN training, each evaluate
+    it).  The memo dies with the scope, so nothing outlives a parameter update or a graph capture
+    (flamo_amd.graph.GraphedStep opens one scope per captured call)."""
+
+    def __enter__(self):
+        self._prev = _tls.step_memo
+        _tls.step_memo = {}
+        return self
+
+    def __exit__(self, *exc):
+        _tls.step_memo = self._prev
+        return False
+
+
+def step_memo():
+    return _tls.step_memo
 
 
 def fork_event():
@@ -1687,6 +1709,48 @@ class _MatrixExp(torch.autograd.Function):
         gX = torch.empty((N, N), dtype=dt, device=g.device)
         _lib.check(fn(g.data_ptr(), N, skew, stash.data_ptr(), gX.data_ptr(), _stream()), "matrix_exp_bwd")
         return gX, None, None
+
+
+class _MatrixExpBoth(torch.autograd.Function):
+    """(E real, E as the complex matrix (re, 0)) from one launch; one backward launch for both gradients"""
+
+    @staticmethod
+    def forward(ctx, X, skew):
+        dev = _require_gpu(X)
+        if X.dim() != 2 or X.shape[0] != X.shape[1] or X.dtype not in (torch.float32, torch.float64):
+            raise ValueError("matrix_exp expects one square float32 / float64 matrix")
+        N = X.shape[0]
+        if N > EXPM_MAX_N:
+            raise ValueError(f"matrix_exp: N={N} exceeds the single-workgroup limit {EXPM_MAX_N}")
+        Xc = X.contiguous()
+        L = _lib.lib()
+        E = torch.empty((N, N), dtype=X.dtype, device=dev)
+        Ec = torch.empty((N, N), dtype=_cdtype(X.dtype), device=dev)
+        stash = torch.empty(L.fl_matrix_exp_stash_elems(N), dtype=torch.float64, device=dev)
+        fn = L.fl_matrix_exp_both_f32 if X.dtype == torch.float32 else L.fl_matrix_exp_both_f64
+        _lib.check(fn(Xc.data_ptr(), N, int(skew), E.data_ptr(), Ec.data_ptr(), stash.data_ptr(), _stream()), "matrix_exp")
+        ctx.save_for_backward(stash)
+        ctx.cfg = (N, int(skew), X.dtype)
+        return E, Ec
+
+    @staticmethod
+    def backward(ctx, gE, gEc):
+        (stash,) = ctx.saved_tensors
+        N, skew, dt = ctx.cfg
+        L = _lib.lib()
+        g = None if gE is None else gE.to(dt).contiguous()
+        gc = None if gEc is None else gEc.resolve_conj().to(_cdtype(dt)).contiguous()
+        gX = torch.empty((N, N), dtype=dt, device=stash.device)
+        fn = L.fl_matrix_exp_bwd_both_f32 if dt == torch.float32 else L.fl_matrix_exp_bwd_both_f64
+        _lib.check(fn(None if g is None else g.data_ptr(), None if gc is None else gc.data_ptr(), N, skew, stash.data_ptr(),
+                      gX.data_ptr(), _stream()), "matrix_exp_bwd")
+        return gX, None
+
+
+def matrix_exp_both(X: torch.Tensor, skew: bool = False):
+    """(exp as a real matrix, the same as a complex matrix) from one launch each way -- for a step in which the model
+    takes the complex form and a criterion the real one."""
+    return _MatrixExpBoth.apply(X, bool(skew))
 
 
 def matrix_exp(X: torch.Tensor, skew: bool = False, complex_out: bool = False) -> torch.Tensor:

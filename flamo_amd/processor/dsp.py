@@ -315,7 +315,8 @@ class Gain(DSP):
         """to_complex(map(param)) (dsp.py:466-468); the orthogonal map writes the complex matrix itself"""
         if (self.map is _orthogonal_map and param.is_cuda and param.dim() == 2 and param.shape[0] <= ops.EXPM_MAX_N
                 and param.dtype in (torch.float32, torch.float64)):
-            return ops.matrix_exp(param, skew=True, complex_out=True)
+            pair = _orthogonal_pair(param)
+            return pair[1] if pair is not None else ops.matrix_exp(param, skew=True, complex_out=True)
         return to_complex(self.map(param))
 
     def _bin_response(self, param):
@@ -370,12 +371,27 @@ class parallelGain(Gain):
         return torch.diag(to_complex(self.map(self.param)))
 
 
+def _orthogonal_pair(x):
+    """(real, complex) exp(skew(x)) shared by everybody who asks inside one ops.step_scope() -- the model (complex form, for
+    the per-bin kernels) and e.g. a sparsity criterion on the same mixing matrix (real form); None outside a scope."""
+    memo = ops.step_memo()
+    if memo is None:
+        return None
+    key = ("orthogonal_map", id(x), x._version, torch.is_grad_enabled())
+    hit = memo.get(key)
+    if hit is None:
+        hit = (*ops.matrix_exp_both(x, skew=True), x)       # the entry keeps x alive: its id() is in the key
+        memo[key] = hit
+    return hit
+
+
 def _orthogonal_map(x):
     """exp of the skew part (dsp.py:649).  On the GPU: one fused launch each way (ops.matrix_exp);
     otherwise the same fixed schedule written with torch ops (torch.matrix_exp synchronises with
     the host and cannot be captured in a HIP graph)."""
     if x.is_cuda and x.dim() == 2 and x.shape[0] <= ops.EXPM_MAX_N and x.dtype in (torch.float32, torch.float64):
-        return ops.matrix_exp(x, skew=True)
+        pair = _orthogonal_pair(x)      # inside ops.step_scope(): once per parameter version, real and complex forms
+        return pair[0] if pair is not None else ops.matrix_exp(x, skew=True)
     return matrix_exp_capturable(skew_matrix(x))
 
 

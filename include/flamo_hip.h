@@ -423,6 +423,13 @@ int fl_matrix_exp_cplx_f32(const void* X, int N, int skew, void* E, void* stash,
 int fl_matrix_exp_cplx_f64(const void* X, int N, int skew, void* E, void* stash, void* stream);
 int fl_matrix_exp_bwd_cplx_f32(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);
 int fl_matrix_exp_bwd_cplx_f64(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);
+/* Both forms from one launch (E real N^2, Ec complex 2 N^2; either may be NULL), and the backward of both (gE real, gEc
+ * complex, either may be NULL: dL/dX from gE + Re gEc): a step in which the model takes the complex matrix and a criterion
+ * the real one (sparsity of the mixing matrix, optimize/loss.py:36-63) evaluates the map once each way. */
+int fl_matrix_exp_both_f32(const void* X, int N, int skew, void* E, void* Ec, void* stash, void* stream);
+int fl_matrix_exp_both_f64(const void* X, int N, int skew, void* E, void* Ec, void* stash, void* stream);
+int fl_matrix_exp_bwd_both_f32(const void* gE, const void* gEc, int N, int skew, const void* stash, void* gX, void* stream);
+int fl_matrix_exp_bwd_both_f64(const void* gE, const void* gEc, int N, int skew, const void* stash, void* gX, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-bin eigenvalues of small general complex matrices: torch.linalg.eigvals in

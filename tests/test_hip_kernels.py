@@ -764,3 +764,49 @@ def test_fdn_feedforward_diagonal_inside_the_solve(gpu):
             ops.kernel_timer.enabled = False
         for a, b in zip(res[True], res[False]):
             assert relerr(a, b) < tol
+
+
+@pytest.mark.parametrize("N", [4, 7, 16])
+def test_matrix_exp_both_forms_and_step_scope(gpu, N):
+    """ops.matrix_exp_both (real and complex forms from one launch, one backward launch for both gradients) against the two
+    single-form calls; and ops.step_scope(): a Matrix module's complex response and the real map asked for by a criterion
+    come from ONE evaluation, with the same gradient as two."""
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp
+    for dt in (torch.float32, torch.float64):
+        cd = torch.complex64 if dt == torch.float32 else torch.complex128
+        torch.manual_seed(N)
+        X0 = torch.randn(N, N, device=gpu, dtype=dt)
+        Cr = torch.randn(N, N, device=gpu, dtype=dt)
+        Cc = torch.randn(N, N, device=gpu, dtype=cd)
+        Xa = X0.clone().requires_grad_(True)
+        E, Ec = ops.matrix_exp_both(Xa, skew=True)
+        (ga,) = torch.autograd.grad((E * Cr).sum() + (Ec * Cc.conj()).real.sum(), [Xa])
+        Xb = X0.clone().requires_grad_(True)
+        E1, E2 = ops.matrix_exp(Xb, skew=True), ops.matrix_exp(Xb, skew=True, complex_out=True)
+        (gb,) = torch.autograd.grad((E1 * Cr).sum() + (E2 * Cc.conj()).real.sum(), [Xb])
+        assert torch.equal(E.detach(), E1.detach()) and torch.equal(Ec.detach(), E2.detach())
+        assert relerr(ga, gb) < (1e-6 if dt == torch.float32 else 1e-13)
+        # only one of the two forms used
+        Xc = X0.clone().requires_grad_(True)
+        E, Ec = ops.matrix_exp_both(Xc, skew=True)
+        (gc,) = torch.autograd.grad((E * Cr).sum(), [Xc])
+        Xd = X0.clone().requires_grad_(True)
+        (gd,) = torch.autograd.grad((ops.matrix_exp(Xd, skew=True) * Cr).sum(), [Xd])
+        assert relerr(gc, gd) < (1e-6 if dt == torch.float32 else 1e-13)
+        # module level
+        mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, nfft=480, device=gpu, dtype=dt)
+        grads = {}
+        for scoped in (True, False):
+            mix.param.grad = None
+            ctx = ops.step_scope() if scoped else torch.enable_grad()
+            with ctx:
+                H, _ = mix._bin_response(mix.param)
+                A = mix.map(mix.param)
+                if scoped:
+                    H2, _ = mix._bin_response(mix.param)
+                    assert H2 is H and mix.map(mix.param) is A        # one evaluation, shared
+                ((H * Cc.conj()).real.sum() + (A.abs()).sum()).backward()
+            grads[scoped] = mix.param.grad.clone()
+        assert ops.step_memo() is None
+        assert relerr(grads[True], grads[False]) < (1e-6 if dt == torch.float32 else 1e-13)

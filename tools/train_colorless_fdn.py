@@ -98,16 +98,18 @@ def train(model, x, target, steps, lr, group=None, log=None, graphed=False, on_r
         return log
     if on_ready is not None:
         on_ready()
+    from flamo_amd import ops
     for _ in range(steps):
         opt.zero_grad(set_to_none=True)
-        est = fd.sharded_forward(model, x, group) if sharded else model(x)
-        mse = mse_criterion(est, target)
-        sp = sparsity_criterion(model)
-        loss = mse + 0.2 * sp
-        # every rank holds the whole gathered spectrum and evaluates the same criteria; its backward reaches only
-        # its own bins, so the data term's parameter gradients are partial sums -- the sparsity term acts on the
-        # replicated matrix directly and is counted once
-        (mse + (0.2 * sp if rank == 0 else 0.0 * sp)).backward()
+        with ops.step_scope():      # the model and the sparsity criterion share one evaluation of the orthogonal map
+            est = fd.sharded_forward(model, x, group) if sharded else model(x)
+            mse = mse_criterion(est, target)
+            sp = sparsity_criterion(model)
+            loss = mse + 0.2 * sp
+            # every rank holds the whole gathered spectrum and evaluates the same criteria; its backward reaches only
+            # its own bins, so the data term's parameter gradients are partial sums -- the sparsity term acts on the
+            # replicated matrix directly and is counted once
+            (mse + (0.2 * sp if rank == 0 else 0.0 * sp)).backward()
         if sharded:
             fd.all_reduce_grads(params, group)
         opt.step()
