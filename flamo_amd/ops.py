@@ -827,7 +827,8 @@ REAL_CONST_MIMO = True
 
 
 def _mimo_real_launch(W, conj_t, X):
-    """Y = W X or W^T X for a real (No, Ni) matrix W of X's precision."""
+    """Y = W X or W^T X for a real (No, Ni) matrix W of X's precision: einsum("mn,bfn...->bfm...", to_complex(W), X) of
+    dsp.py:466-468 without forming to_complex(W)."""
     real = _rdtype(X)
     B, M, Nx, K, xs_b, xs_n, xs_k = _bnk(X)
     hs_m, hs_n = W.stride(0), W.stride(1)
@@ -1117,7 +1118,9 @@ def _solve_dud2_launch(l, l2, rhs_l2, U, r, adjoint, R):
 
 def solve_dud2(l: Optional[torch.Tensor], l2: torch.Tensor, U: torch.Tensor, r: Optional[torch.Tensor], R0: torch.Tensor) -> torch.Tensor:
     """Per bin f: (I - diag(l[f] . l2[f]) U diag(r[f]))^-1 (l2[f] . R0[:, f]); l, r: per-bin (M, N) or None, l2: per-bin
-    (M, N) without gradient (the diagonal of the feedforward path, which also scales the right-hand side)."""
+    (M, N) without gradient (the diagonal of the feedforward path, which also scales the right-hand side).
+    Replaces system.py:417-424 (Recursion.forward: A = I - fF(fB(I)), solve(A, fF(X))) for the FDN structure of
+    reverb.py:117-199 / e8_fdn.py:60-100, where fF is the delay line alone."""
     if l2.requires_grad:
         raise ValueError("solve_dud2: the feedforward diagonal must not require a gradient (use solve_dud)")
     cd = R0.dtype
@@ -1178,7 +1181,8 @@ class _SolveScaledLoop(torch.autograd.Function):
 
 def solve_scaled_loop(g: torch.Tensor, D: torch.Tensor, U: torch.Tensor, R: torch.Tensor) -> torch.Tensor:
     """Per bin f: (I - diag(g) D[f] U)^-1 R[:, f] -- a loop whose feedforward path is a per-bin matrix of delays followed
-    by per-channel gains, around a constant mixing matrix.  D must not require a gradient."""
+    by per-channel gains, around a constant mixing matrix (system.py:417-424 with fF = Series(Delay((N,N)), parallelGain(N)),
+    fB = Matrix: the active-acoustics structure, e8_active_acoustics.py).  D must not require a gradient."""
     if D.requires_grad:
         raise ValueError("solve_scaled_loop: the per-bin factor must not require a gradient (use ops.solve)")
     cd = R.dtype
@@ -1453,13 +1457,13 @@ class _GeqCascadeApply(torch.autograd.Function):
 
 
 def sos_response_apply(b, a, X, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
-    """sos_response(b, a)[f] @ X[b, f] for a vector signal X (B, M, N_in): the response's gradient never exists as a
-    tensor (cascade_apply_supported)."""
+    """sos_response(b, a)[f] @ X[b, f] for a vector signal X (B, M, N_in) -- dsp.py:922-924 over the cascade tail
+    dsp.py:1520-1526: the response's gradient never exists as a tensor (cascade_apply_supported)."""
     return _SosApply.apply(b.to(torch.float64), a.to(torch.float64), X, float(gamma), int(nfft), dtype)
 
 
 def geq_cascade_apply(x, consts, X, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
-    """geq_cascade(x, consts)[f] @ X[b, f] for a vector signal X (B, M, N_in)"""
+    """geq_cascade(x, consts)[f] @ X[b, f] for a vector signal X (B, M, N_in) (dsp.py:922-924 over dsp.py:2573-2593)"""
     return _GeqCascadeApply.apply(x, consts, X, float(gamma), int(nfft), dtype)
 
 
@@ -1749,7 +1753,8 @@ class _MatrixExpBoth(torch.autograd.Function):
 
 def matrix_exp_both(X: torch.Tensor, skew: bool = False):
     """(exp as a real matrix, the same as a complex matrix) from one launch each way -- for a step in which the model
-    takes the complex form and a criterion the real one."""
+    takes the complex form (dsp.py:649 then the cast of dsp.py:466-468) and a criterion the real one
+    (optimize/loss.py:36-63)."""
     return _MatrixExpBoth.apply(X, bool(skew))
 
 
