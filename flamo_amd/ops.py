@@ -1735,6 +1735,7 @@ class _MatrixExpBoth(torch.autograd.Function):
         _lib.check(fn(Xc.data_ptr(), N, int(skew), E.data_ptr(), Ec.data_ptr(), stash.data_ptr(), _stream()), "matrix_exp")
         ctx.save_for_backward(stash)
         ctx.cfg = (N, int(skew), X.dtype)
+        ctx.set_materialize_grads(False)        # an unused form's gradient arrives as None, not as a zero-filled tensor
         return E, Ec
 
     @staticmethod
@@ -1742,6 +1743,8 @@ class _MatrixExpBoth(torch.autograd.Function):
         (stash,) = ctx.saved_tensors
         N, skew, dt = ctx.cfg
         L = _lib.lib()
+        if gE is None and gEc is None:
+            return None, None
         g = None if gE is None else gE.to(dt).contiguous()
         gc = None if gEc is None else gEc.resolve_conj().to(_cdtype(dt)).contiguous()
         gX = torch.empty((N, N), dtype=dt, device=stash.device)
