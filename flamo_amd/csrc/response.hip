@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(256, 3) sos_response_bwd_mixed_kernel(
 // One thread per (band, channel): ~1 KB of work replaces ~150 tiny elementwise launches per step.
 __device__ inline double f32r(double x) { return (double)(float)x; }
 
-// in_kind: 0 = command gains in dB (double); 1 / 2 = LINEAR command gains x (double / float),
+// in_kind: 0 = command gains in dB (double); 1 / 2 (and 3 / 4, see below) = LINEAR command gains x (double / float),
 // i.e. the module's raw parameters under its default map 20 log10|x| -- then g = 10^(map/20) = |x|
 // and the map, its backward and the dtype casts (ten tiny launches per step) fold into these two.
 __device__ inline double geq_linear_gain(const void* gain, int in_kind, int idx, double* raw) {
@@ -677,8 +677,11 @@ __device__ inline double geq_linear_gain(const void* gain, int in_kind, int idx,
         *raw = v;
         return pow(10.0, v / 20.0);
     }
-    const double v = in_kind == 2 ? (double)reinterpret_cast<const float*>(gain)[idx] : reinterpret_cast<const double*>(gain)[idx];
+    const double v = (in_kind == 2 || in_kind == 4) ? (double)reinterpret_cast<const float*>(gain)[idx]
+                                                    : reinterpret_cast<const double*>(gain)[idx];
     *raw = v;
+    // 3 / 4: raw parameters under the map 20 log10(sigmoid(x)) (the attenuation filters of e8_fdn.py:97): g = sigmoid(x)
+    if (in_kind >= 3) return 1.0 / (1.0 + exp(-v));
     return fabs(v);
 }
 
@@ -798,8 +801,9 @@ __global__ void __launch_bounds__(256) geq_sections_bwd_kernel(const void* __res
     if (in_kind == 0) {
         reinterpret_cast<double*>(ggain)[idx] = dg * g * (2.302585092994045684 / 20.0);   // dg/dgain_db = g ln(10) / 20
     } else {
-        const double v = dg * (raw > 0 ? 1.0 : (raw < 0 ? -1.0 : 0.0));                   // g = |x|
-        if (in_kind == 2) reinterpret_cast<float*>(ggain)[idx] = (float)v;
+        const double v = in_kind >= 3 ? dg * g * (1.0 - g)                                 // g = sigmoid(x)
+                                      : dg * (raw > 0 ? 1.0 : (raw < 0 ? -1.0 : 0.0));     // g = |x|
+        if (in_kind == 2 || in_kind == 4) reinterpret_cast<float*>(ggain)[idx] = (float)v;
         else reinterpret_cast<double*>(ggain)[idx] = v;
     }
 }
@@ -950,7 +954,7 @@ int fl_debug_set_sos_chunk(int sections_per_thread) {
 
 int fl_geq_sections(const void* gain, int in_kind, int nb, int C, const void* consts, void* b, void* a, void* stream) {
     FL_REQUIRE(gain && consts && b && a, "geq_sections: null pointer");
-    FL_REQUIRE(in_kind >= 0 && in_kind <= 2, "geq_sections: in_kind must be 0 (dB, f64), 1 (linear, f64) or 2 (linear, f32)");
+    FL_REQUIRE(in_kind >= 0 && in_kind <= 4, "geq_sections: in_kind must be 0 (dB, f64), 1 / 2 (|x|, f64 / f32) or 3 / 4 (sigmoid(x), f64 / f32)");
     FL_REQUIRE(nb >= 4 && C > 0, "geq_sections: need >= 4 bands (gain, two shelves, one peak) and C > 0");
     hipLaunchKernelGGL(geq_sections_kernel, dim3(cdiv_i((long)nb * C, 256)), dim3(256), 0, (hipStream_t)stream,
                        gain, in_kind, nb, C, (const double*)consts, (double*)b, (double*)a);
@@ -960,7 +964,7 @@ int fl_geq_sections(const void* gain, int in_kind, int nb, int C, const void* co
 int fl_geq_sections_bwd(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
                         int C, const void* consts, void* ggain, void* stream) {
     FL_REQUIRE(gain && gb && ga && consts && ggain, "geq_sections_bwd: null pointer");
-    FL_REQUIRE(in_kind >= 0 && in_kind <= 2, "geq_sections_bwd: bad in_kind");
+    FL_REQUIRE(in_kind >= 0 && in_kind <= 4, "geq_sections_bwd: bad in_kind");
     FL_REQUIRE(nb >= 4 && C > 0 && nblk >= 1 && blk_stride >= 0, "geq_sections_bwd: bad sizes");
     const int mb = cdiv_i((long)nb * C, 256);
     hipLaunchKernelGGL(geq_sections_bwd_kernel, dim3(mb), dim3(256), 0, (hipStream_t)stream,
@@ -972,7 +976,7 @@ int fl_geq_sections_bwd(const void* gain, int in_kind, const void* gb, const voi
 int fl_geq_sections_bwd_w(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
                           int C, const void* consts, void* ggain, const void* partW, int wrows, int wn, void* gW, void* stream) {
     FL_REQUIRE(gain && gb && ga && consts && ggain && partW && gW, "geq_sections_bwd_w: null pointer");
-    FL_REQUIRE(nb >= 4 && C > 0 && nblk > 0 && in_kind >= 0 && in_kind <= 2 && wrows > 0 && wn > 0, "geq_sections_bwd_w: bad sizes");
+    FL_REQUIRE(nb >= 4 && C > 0 && nblk > 0 && in_kind >= 0 && in_kind <= 4 && wrows > 0 && wn > 0, "geq_sections_bwd_w: bad sizes");
     const int mb = cdiv_i((long)nb * C, 256);
     hipLaunchKernelGGL(geq_sections_bwd_kernel, dim3(mb + cdiv_i(wn, 4)), dim3(256), 0, (hipStream_t)stream,
                        gain, in_kind, (const double*)gb, (const double*)ga, blk_stride, nblk, nb, C,

@@ -1290,10 +1290,12 @@ class _Sos(torch.autograd.Function):
         return tot[0].view(bc.shape), tot[1].view(ac.shape), None, None, None
 
 
-def _geq_in_kind(t: torch.Tensor, linear: bool) -> int:
+def _geq_in_kind(t: torch.Tensor, linear: bool, sig: bool = False) -> int:
+    """fl_geq_sections' in_kind: 0 dB gains; 1 / 2 raw parameters under 20 log10|x| (f64 / f32); 3 / 4 raw parameters under
+    20 log10(sigmoid(x))"""
     if not linear:
         return 0
-    return 2 if t.dtype == torch.float32 else 1
+    return (4 if sig else 2) if t.dtype == torch.float32 else (3 if sig else 1)
 
 
 class _GeqSections(torch.autograd.Function):
@@ -1331,15 +1333,16 @@ class _GeqCascade(torch.autograd.Function):
     bin-block partials)."""
 
     @staticmethod
-    def forward(ctx, x, consts, gamma, nfft, real):
+    def forward(ctx, x, consts, gamma, nfft, real, sig=False):
         dev = _require_gpu(x, consts)
+        ctx.sig = bool(sig)
         if x.dtype not in (torch.float32, torch.float64):
             raise TypeError("geq_cascade expects float32 / float64 parameters")
         xc = x.contiguous()
         nb = xc.shape[0]
         chan = tuple(xc.shape[1:])
         C_ = max(_prod(chan), 1)
-        kind = _geq_in_kind(xc, True)
+        kind = _geq_in_kind(xc, True, sig)
         b = torch.empty((3, nb, *chan), dtype=torch.float64, device=dev)
         a = torch.empty_like(b)
         _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), kind, nb, C_, consts.data_ptr(), b.data_ptr(), a.data_ptr(),
@@ -1359,10 +1362,10 @@ class _GeqCascade(torch.autograd.Function):
         st = nb * C_
         out = torch.empty_like(xc)
         esz = part.element_size()
-        _lib.check(_lib.lib().fl_geq_sections_bwd(xc.data_ptr(), _geq_in_kind(xc, True), part.data_ptr(),
+        _lib.check(_lib.lib().fl_geq_sections_bwd(xc.data_ptr(), _geq_in_kind(xc, True, ctx.sig), part.data_ptr(),
                                                   part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
                                                   out.data_ptr(), _stream()), "geq_sections_bwd")
-        return out, None, None, None, None
+        return out, None, None, None, None, None
 
 
 # ---- cascade response applied to a signal with few columns: Y = H X with dL/dH formed inside the cascade backward
@@ -1419,8 +1422,9 @@ class _GeqCascadeApply(torch.autograd.Function):
     kernel) + design backward."""
 
     @staticmethod
-    def forward(ctx, x, consts, X, gamma, nfft, real):
+    def forward(ctx, x, consts, X, gamma, nfft, real, sig=False):
         dev = _require_gpu(x, consts, X)
+        ctx.sig = bool(sig)
         xc = x.contiguous()
         if xc.dim() != 3:
             raise ValueError("geq_cascade_apply expects full (n_bands, N_out, N_in) parameters")
@@ -1429,7 +1433,7 @@ class _GeqCascadeApply(torch.autograd.Function):
         C_ = _prod(chan)
         b = torch.empty((3, nb, *chan), dtype=torch.float64, device=dev)
         a = torch.empty_like(b)
-        _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), _geq_in_kind(xc, True), nb, C_, consts.data_ptr(), b.data_ptr(),
+        _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), _geq_in_kind(xc, True, sig), nb, C_, consts.data_ptr(), b.data_ptr(),
                                               a.data_ptr(), _stream()), "geq_sections")
         Xp = to_planar(X.resolve_conj())
         H, ctx.cfg = _sos_forward_launch(b, a, gamma, nfft, real, True)
@@ -1448,12 +1452,12 @@ class _GeqCascadeApply(torch.autograd.Function):
             st = nb * C_
             out = torch.empty_like(xc)
             esz = part.element_size()
-            _lib.check(_lib.lib().fl_geq_sections_bwd(xc.data_ptr(), _geq_in_kind(xc, True), part.data_ptr(),
+            _lib.check(_lib.lib().fl_geq_sections_bwd(xc.data_ptr(), _geq_in_kind(xc, True, ctx.sig), part.data_ptr(),
                                                       part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
                                                       out.data_ptr(), _stream()), "geq_sections_bwd")
         if ctx.needs_input_grad[2]:
             gX = _mimo_launch(H.movedim(-1, 0), True, False, True, gY)
-        return out, None, gX, None, None, None
+        return out, None, gX, None, None, None, None
 
 
 def sos_response_apply(b, a, X, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
@@ -1462,9 +1466,9 @@ def sos_response_apply(b, a, X, gamma: float, nfft: int, dtype=torch.float32) ->
     return _SosApply.apply(b.to(torch.float64), a.to(torch.float64), X, float(gamma), int(nfft), dtype)
 
 
-def geq_cascade_apply(x, consts, X, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
+def geq_cascade_apply(x, consts, X, gamma: float, nfft: int, dtype=torch.float32, gain_map: str = "abs") -> torch.Tensor:
     """geq_cascade(x, consts)[f] @ X[b, f] for a vector signal X (B, M, N_in) (dsp.py:922-924 over dsp.py:2573-2593)"""
-    return _GeqCascadeApply.apply(x, consts, X, float(gamma), int(nfft), dtype)
+    return _GeqCascadeApply.apply(x, consts, X, float(gamma), int(nfft), dtype, gain_map == "sigmoid")
 
 
 def cascade_rc_supported(real: torch.dtype, n_in: int) -> bool:
@@ -1540,15 +1544,16 @@ class _GeqCascadeRC(torch.autograd.Function):
     design backward."""
 
     @staticmethod
-    def forward(ctx, x, consts, Wr, gamma, nfft, real):
+    def forward(ctx, x, consts, Wr, gamma, nfft, real, sig=False):
         dev = _require_gpu(x, consts, Wr)
+        ctx.sig = bool(sig)
         xc = x.contiguous()
         nb = xc.shape[0]
         chan = tuple(xc.shape[1:])
         C_ = max(_prod(chan), 1)
         b = torch.empty((3, nb, *chan), dtype=torch.float64, device=dev)
         a = torch.empty_like(b)
-        _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), _geq_in_kind(xc, True), nb, C_, consts.data_ptr(), b.data_ptr(),
+        _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), _geq_in_kind(xc, True, sig), nb, C_, consts.data_ptr(), b.data_ptr(),
                                               a.data_ptr(), _stream()), "geq_sections")
         H, G, ctx.cfg = _cascade_rc_forward(b, a, Wr, gamma, nfft, real, True)
         ctx.save_for_backward(xc, consts, b, a, G, Wr)
@@ -1566,11 +1571,11 @@ class _GeqCascadeRC(torch.autograd.Function):
         gW = torch.empty_like(Wr, memory_format=torch.contiguous_format)
         esz = part.element_size()
         # design backward (sums the bin-block partials) + the constant factor's partials, one launch
-        _lib.check(_lib.lib().fl_geq_sections_bwd_w(xc.data_ptr(), _geq_in_kind(xc, True), part.data_ptr(),
+        _lib.check(_lib.lib().fl_geq_sections_bwd_w(xc.data_ptr(), _geq_in_kind(xc, True, ctx.sig), part.data_ptr(),
                                                     part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
                                                     out.data_ptr(), partW.data_ptr(), partW.shape[0] * partW.shape[1],
                                                     partW.shape[2] * partW.shape[3], gW.data_ptr(), _stream()), "geq_sections_bwd_w")
-        return out, None, gW, None, None, None
+        return out, None, gW, None, None, None, None
 
 
 def sos_response_rc(b, a, Wr, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
@@ -1578,16 +1583,23 @@ def sos_response_rc(b, a, Wr, gamma: float, nfft: int, dtype=torch.float32) -> t
     return _SosRC.apply(b.to(torch.float64), a.to(torch.float64), Wr.to(torch.float32), float(gamma), int(nfft), dtype)
 
 
-def geq_cascade_rc(x, consts, Wr, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
+def geq_cascade_rc(x, consts, Wr, gamma: float, nfft: int, dtype=torch.float32, gain_map: str = "abs") -> torch.Tensor:
     """geq_cascade(x, ...) (M, N_out, N_mid) times the real constant matrix Wr (N_mid, N_in) on the right, per bin."""
-    return _GeqCascadeRC.apply(x, consts, Wr.to(torch.float32), float(gamma), int(nfft), dtype)
+    return _GeqCascadeRC.apply(x, consts, Wr.to(torch.float32), float(gamma), int(nfft), dtype, _is_sigmoid(gain_map))
 
 
-def geq_cascade(x: torch.Tensor, consts: torch.Tensor, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
+def _is_sigmoid(gain_map: str) -> bool:
+    if gain_map not in ("abs", "sigmoid"):
+        raise ValueError("gain_map: 'abs' (20 log10|x|, the module default) or 'sigmoid' (20 log10(sigmoid(x)))")
+    return gain_map == "sigmoid"
+
+
+def geq_cascade(x: torch.Tensor, consts: torch.Tensor, gamma: float, nfft: int, dtype=torch.float32, gain_map: str = "abs") -> torch.Tensor:
     """Response (M, ...) of the graphic equaliser whose raw parameters x (n_bands, ...) go through
     the default map 20 log10|x| -- same result as sos_response(*geq_sections(20 log10|x|)), with
-    the map and its backward folded into the design kernels."""
-    return _GeqCascade.apply(x, consts, float(gamma), int(nfft), dtype)
+    the map and its backward folded into the design kernels.  gain_map="sigmoid": the map 20 log10(sigmoid(x)) of the
+    FDN attenuation filters (e8_fdn.py:97) folded the same way."""
+    return _GeqCascade.apply(x, consts, float(gamma), int(nfft), dtype, _is_sigmoid(gain_map))
 
 
 def geq_sections(gain_db: torch.Tensor, consts: torch.Tensor):

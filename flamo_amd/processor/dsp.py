@@ -575,7 +575,7 @@ class _SOSMixin:
             return None
         spec = self._cascade_spec(param)
         if spec[0] == "geq":
-            return ops.geq_cascade_rc(spec[1], spec[2], Wr, self._gamma_f, self.nfft, dtype=self.dtype)
+            return ops.geq_cascade_rc(spec[1], spec[2], Wr, self._gamma_f, self.nfft, dtype=self.dtype, gain_map=spec[3])
         return ops.sos_response_rc(spec[1], spec[2], Wr, self._gamma_f, self.nfft, dtype=self.dtype)
 
     def _cascade_spec(self, param):
@@ -603,7 +603,7 @@ class _SOSMixin:
             return None
         spec = self._cascade_spec(param)
         if spec[0] == "geq":
-            return ops.geq_cascade_apply(spec[1], spec[2], x, self._gamma_f, self.nfft, dtype=self.dtype)
+            return ops.geq_cascade_apply(spec[1], spec[2], x, self._gamma_f, self.nfft, dtype=self.dtype, gain_map=spec[3])
         if spec[1].dim() != 4:
             return None
         return ops.sos_response_apply(spec[1], spec[2], x, self._gamma_f, self.nfft, dtype=self.dtype)
@@ -712,6 +712,16 @@ def _db_of_magnitude(x):
     return 20 * torch.log10(torch.abs(x))
 
 
+def db_of_sigmoid(x):
+    """20 log10(sigmoid(x)): the map the reference's FDN examples give their attenuation filters as a lambda
+    (e8_fdn.py:97).  Passed as THIS function, the graphic equalisers fold it into the design kernel with its backward
+    (fl_geq_sections in_kind 3 / 4) as they do their default map; any other callable runs as torch ops."""
+    return 20 * torch.log10(torch.sigmoid(x))
+
+
+_FOLDED_GAIN_MAPS = {_db_of_magnitude: "abs", db_of_sigmoid: "sigmoid"}
+
+
 class GEQ(_SOSMixin, Filter):
     """Graphic equaliser: param (n_bands+3 command gains, N_out, N_in), default map 20 log10|x|
     (dsp.py:2467-2611).  Sections: flat gain, low shelf, octave peaks (R = 2.7), high shelf."""
@@ -737,17 +747,19 @@ class GEQ(_SOSMixin, Filter):
 
     def get_freq_response(self):
         def response(param):
-            if self.map is _db_of_magnitude and param.is_cuda and param.dtype in (torch.float32, torch.float64):
-                # default map: 10^(map(x)/20) = |x|, folded into the design kernel with its backward
+            gm = _FOLDED_GAIN_MAPS.get(self.map)
+            if gm is not None and param.is_cuda and param.dtype in (torch.float32, torch.float64):
+                # default map: 10^(map(x)/20) = |x| (or sigmoid(x)), folded into the design kernel with its backward
                 return ops.geq_cascade(param, self._design.device_consts(param.device), self._gamma_f, self.nfft,
-                                       dtype=self.dtype)
+                                       dtype=self.dtype, gain_map=gm)
             return self._sos_to_response(*self._sos_coeffs(self.map(param.double())))
         self.freq_response = response
         self._own_response = response
 
     def _cascade_spec(self, param):
-        if self.map is _db_of_magnitude and param.is_cuda and param.dtype in (torch.float32, torch.float64):
-            return ("geq", param, self._design.device_consts(param.device))
+        gm = _FOLDED_GAIN_MAPS.get(self.map)
+        if gm is not None and param.is_cuda and param.dtype in (torch.float32, torch.float64):
+            return ("geq", param, self._design.device_consts(param.device), gm)
         return ("sos", *self._sos_coeffs(self.map(param.double())))
 
     def _sos_coeffs(self, gain_db):

@@ -300,6 +300,8 @@ int fl_sos_response_bwd_rc_c64(const void* gHfull, long g_pitch, const void* G, 
  *                  in_kind 1 / 2: the module's RAW parameters x (double / float) under its default
  *                  map 20 log10|x| (dsp.py:2526) -- the linear gain is then |x| and the map, its
  *                  backward and the dtype casts fold into these two launches;
+ *                  in_kind 3 / 4: RAW parameters x (double / float) under the map 20 log10(sigmoid(x)) that the
+ *                  reference's FDN examples give their attenuation filters (e8_fdn.py:97): linear gain sigmoid(x);
  *   b, a: double (3, nb, C) holding float32-representable values;
  *   consts: double [t_lo, t_hi, t2_lo, t2_hi, st_lo, st_hi, pk_t[nb-3], pk_c[nb-3]] -- tan/cos of
  *   the float32 band frequencies as the host evaluates them (flamo/functional.py:555-675).

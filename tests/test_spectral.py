@@ -467,3 +467,58 @@ def test_cascade_applied_to_few_columns_without_gradient_tensor(gpu, kind, B):
     assert relerr(res[True][2], res[False][2]) < 1e-6
     # (the layered route rounds dL/dH to float32 before the cascade backward reads it; the fused one does not)
     assert relerr(res[True][1], res[False][1]) < (5e-5 if kind == "peq" else 1e-5)
+
+
+@pytest.mark.parametrize("parallel", [True, False])
+def test_geq_sigmoid_map_folded_into_the_design_kernel(gpu, parallel):
+    """dsp.db_of_sigmoid (20 log10(sigmoid(x)), the attenuation map of e8_fdn.py:97) passed by name is folded into
+    fl_geq_sections (in_kind 3 / 4) like the default map; the same math as a lambda runs as torch ops.  Response and
+    parameter gradient must agree, float32 and float64; for the full matrix also through the Matrix-then-cascade operator
+    and the few-columns route."""
+    from collections import OrderedDict
+    from flamo_amd.processor import dsp, system
+    nfft, N = 9600, 8
+    for dt, tol_h, tol_g in ((torch.float64, 1e-12, 1e-9), (torch.float32, 2e-6, 2e-5)):
+        torch.manual_seed(4)
+        kw = dict(nfft=nfft, alias_decay_db=30.0, device=gpu, dtype=dt, requires_grad=True)
+        mods = []
+        for named in (True, False):
+            m = dsp.parallelGEQ(size=(N,), **kw) if parallel else dsp.GEQ(size=(N, N), **kw)
+            m.map = dsp.db_of_sigmoid if named else (lambda x: 20 * torch.log10(torch.sigmoid(x)))
+            mods.append(m)
+        with torch.no_grad():
+            mods[0].param.copy_(torch.randn_like(mods[0].param) * 0.5 + 1.5)
+            mods[1].param.copy_(mods[0].param)
+        cd = torch.complex128 if dt == torch.float64 else torch.complex64
+        out = []
+        for m in mods:
+            H = m.freq_response(m.param)
+            c = torch.randn(H.shape, device=gpu, dtype=cd, generator=torch.Generator(device=gpu).manual_seed(9))
+            (H * c.conj()).real.sum().backward()
+            out.append((H.detach(), m.param.grad.clone()))
+        assert relerr(out[0][0], out[1][0]) < tol_h
+        assert relerr(out[0][1], out[1][1]) < tol_g
+        if parallel or dt != torch.float32:
+            continue
+        # few columns (ops.geq_cascade_apply) and Matrix-then-cascade (ops.geq_cascade_rc) with the named map
+        X = torch.randn(1, nfft // 2 + 1, N, device=gpu, dtype=cd)
+        res = []
+        for m in mods:
+            m.param.grad = None
+            Y = m(X)
+            (Y.abs() ** 2).sum().backward()
+            res.append((Y.detach(), m.param.grad.clone()))
+        assert relerr(res[0][0], res[1][0]) < 2e-6 and relerr(res[0][1], res[1][1]) < 5e-5
+        res = []
+        for m in mods:
+            m.param.grad = None
+            mat = dsp.Matrix(size=(N, N), nfft=nfft, alias_decay_db=30.0, device=gpu, dtype=dt)
+            torch.manual_seed(2)
+            with torch.no_grad():
+                mat.param.copy_(torch.randn(N, N, device=gpu))
+            ser = system.Series(OrderedDict(mix=mat, eq=m))
+            Xb = torch.randn(6, nfft // 2 + 1, N, device=gpu, dtype=cd, generator=torch.Generator(device=gpu).manual_seed(1))
+            Y = ser(Xb)
+            (Y.abs() ** 2).sum().backward()
+            res.append((Y.detach(), m.param.grad.clone()))
+        assert relerr(res[0][0], res[1][0]) < 2e-6 and relerr(res[0][1], res[1][1]) < 5e-5

@@ -30,7 +30,7 @@ def build(dev, dtype, N=16, nfft=192000, db=30.0):
     dl.assign_value(dl.sample2s(delays.to(dev, dtype)))
     mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
     att = dsp.parallelGEQ(size=(N,), requires_grad=True, **kw)
-    att.map = lambda x: 20 * torch.log10(torch.sigmoid(x))
+    att.map = dsp.db_of_sigmoid        # 20 log10(sigmoid(x)) as in e8_fdn.py:97, by name: folded into the design kernel
     with torch.no_grad():
         att.param.copy_(torch.randn_like(att.param) * 0.3 + 2.0)
     fb = system.Series(OrderedDict(mixing_matrix=mix, attenuation=att))
