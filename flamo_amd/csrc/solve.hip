@@ -627,6 +627,7 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
     }
 }
 
+static int g_solve_rpl2_16 = 0;   // factored loop, N in (4, 16]: 0 = two rows per lane (default), 1 = one row per lane (variant 4)
 static int g_solve_rpl2_p = 0;    // tuning: variant 3 = two-rows-per-lane kernel also for a materialised P
 static int g_solve_thr = 1;       // pivot threshold 2^-thr (tuning: variant 10 + thr)
 static int g_solve_variant = 0;   // tuning hook: 1 forces the shuffle kernel for every N
@@ -637,6 +638,28 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
     constexpr int BPB = 256 / NMAX;
     dim3 grid(cdiv_i(M, BPB));
     if (g_solve_variant == 0) {
+        if constexpr (NMAX == 16) {
+            // N in (8, 16], factored loop: 8 lanes x 2 rows per lane -- 8 bins per wavefront, every broadcast of a pivot-row
+            // element feeds two row updates: 86 -> 73 us at N = 16 (c64), 131 -> 108 us (c128), 82 -> 63 us at N = 9
+            // (tools/dbg/solve_rpl2_16.py; 4 lanes x 4 rows: 80 us, and it spills).  fl_debug_set_solve_variant(4): the
+            // one-row-per-lane kernels.
+            if (!P && g_solve_rpl2_16 != 1) {
+                hipLaunchKernelGGL((solve_inplace_kernel<T, 8, 2>), dim3(cdiv_i(M, 32)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
+                                   dud, one_minus, adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
+                                   os_b, os_n, os_k, B, M, N, K);
+                FL_CHECK_LAUNCH("solve");
+                return FL_OK;
+            }
+        }
+        if constexpr (NMAX == 8) {
+            if (!P && g_solve_rpl2_16 != 1) {      // N in (4, 8] on 4 lanes x 2 rows (16 bins per wavefront): 29 -> 23 us at N = 8
+                hipLaunchKernelGGL((solve_inplace_kernel<T, 4, 2>), dim3(cdiv_i(M, 64)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
+                                   dud, one_minus, adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
+                                   os_b, os_n, os_k, B, M, N, K);
+                FL_CHECK_LAUNCH("solve");
+                return FL_OK;
+            }
+        }
         if constexpr (NMAX <= 16) {
             hipLaunchKernelGGL((solve_inplace_kernel<T, NMAX, 1>), grid, dim3(256), 0, st, (const cx<T>*)P, p_pitch, dud, one_minus,
                                adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);
@@ -946,7 +969,8 @@ extern "C" {
 int fl_debug_set_solve_variant(int variant) {
     g_solve_thr = 1;
     g_solve_rpl2_p = variant == 3;
-    if (variant == 3) variant = 0;
+    g_solve_rpl2_16 = variant == 4 ? 1 : 0;
+    if (variant == 3 || variant == 4) variant = 0;
     if (variant >= 10) {          // 10 + t: in-place kernels with pivot threshold 2^-t
         g_solve_thr = variant - 10;
         variant = 0;

@@ -386,7 +386,8 @@ int fl_solve_dud2_grads_c128(const void* l, long l_sn, long l_sf, const void* l2
                              long r_sn, long r_sf, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N,
                              int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, void* stream);
 /* tuning/test hook: 0 (default) = N <= 16 factor with rows exchanged in place (compile-time DPP broadcasts,
- * threshold pivoting); 1 = the shuffle kernel with implicit partial pivoting for every N */
+ * threshold pivoting; two rows per lane for the factored loop at N in (4, 16]); 1 = the shuffle kernel with implicit
+ * partial pivoting for every N; 4 = the in-place kernels with one row per lane */
 int fl_debug_set_solve_variant(int variant);
 
 /* ------------------------------------------------------------------------------------------------

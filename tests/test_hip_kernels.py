@@ -489,7 +489,7 @@ def test_mimo_mfma_matches_lane_kernels(gpu):
         assert relerr(gw[0].cpu(), ref) < 2e-6 and relerr(gw[-1].cpu(), ref) < 2e-6
 
 
-@pytest.mark.parametrize("N", [3, 8, 13, 16, 17, 24, 32])
+@pytest.mark.parametrize("N", [3, 5, 8, 9, 13, 16, 17, 24, 32])
 def test_factored_solve_all_sizes_and_row_exchanges(gpu, N):
     """(I - diag(l) U diag(r))^-1 R through fl_solve_dud_* for every kernel shape (4/8/16 lanes per bin, two rows per
     lane above 16), with loops that never exchange rows (damped orthogonal) and loops that must (U = 3 x a
@@ -517,7 +517,7 @@ def test_factored_solve_all_sizes_and_row_exchanges(gpu, N):
             dev_in = [t.detach().to(gpu, cd).requires_grad_(True) for t in (l64, U64, r64, R64)]
             outs = {}
             try:
-                for variant in (0, 1):      # in-place kernels / shuffle kernel
+                for variant in (0, 1, 4):      # in-place kernels (two rows per lane up to N = 16) / shuffle kernel / one row per lane
                     _lib.lib().fl_debug_set_solve_variant(variant)
                     Y = ops.solve_dud(dev_in[0], dev_in[1], dev_in[2], dev_in[3])
                     g = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C64.to(gpu, cd)))), dev_in)
@@ -525,7 +525,7 @@ def test_factored_solve_all_sizes_and_row_exchanges(gpu, N):
             finally:
                 _lib.lib().fl_debug_set_solve_variant(0)
             scale = 30.0 if kind == "permutation" else 1.0      # conditioning of the exchanged systems
-            for variant in (0, 1):
+            for variant in (0, 1, 4):
                 for got, want in zip(outs[variant], [Yr.detach()] + list(gr)):
                     assert relerr(got.cpu().to(torch.complex128), want) < tol * scale, (kind, variant)
 
