@@ -87,8 +87,8 @@ _SIGNATURES = {
     "fl_solve_dud_grads_blocks": (_i, [_i, _i]),
     "fl_solve_dud2_c64": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_dud2_c128": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
-    "fl_solve_dud2_grads_c64": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp]),
-    "fl_solve_dud2_grads_c128": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp]),
+    "fl_solve_dud2_grads_c64": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp]),
+    "fl_solve_dud2_grads_c128": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp]),
     "fl_solve_dud_grads_c64": (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp]),
     "fl_solve_dud_grads_c128": (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp]),
     "fl_debug_set_solve_variant": (_i, [_i]),

@@ -717,6 +717,19 @@ static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_mi
 // through LDS; a lane keeps row i of the gU sum in registers across its block's bins; the lanes of a row are combined
 // with a fixed butterfly and the per-block partials summed by a final launch (deterministic).
 template <typename T> struct alignas(2 * sizeof(cx<T>)) cx2 { cx<T> a, b; };
+
+// Side reductions of the one-pass backward for a loop that sits between an input-gain column b (R0 = b x, x a scalar
+// spectrum) and an output-gain row c (y = c . OUT): with sx = x and sy = gy (element (b, f) at b * s_b + f, one column),
+//   g_b[i] = sum_{f,b} conj(l2_i) gR_i conj(x)      g_c[i] = sum_{f,b} gy conj(out_i)
+// -- the two gains' gradients, otherwise two bin-reduction launches with a final each.  part: (blocks, 2, N).
+template <typename T>
+struct DudSide {
+    const cx<T>* sx;
+    const cx<T>* sy;
+    long sx_b, sy_b;
+    int on;          // partials then have N*N + 2N entries per block: [gU | g_b | g_c]
+    T* real_out;     // non-null: Re g_b, Re g_c as a real (2N) array (real gain vectors) instead of the tail of gU
+};
 // 1 + 0i in memory, deliberately not const: a constant the compiler can see through turns the loads of an absent factor
 // back into a branch
 __device__ double kOneRe[2] = {1.0, 0.0};
@@ -730,7 +743,7 @@ template <typename T, int NP, bool WR>
 __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud_grads_kernel(Dud<T> d, const cx<T>* __restrict__ gR, const cx<T>* __restrict__ OUT, long s_b,
                                                         long s_n, long s_k, int B, int M, int N, int K, int bins_per_block,
                                                         cx<T>* __restrict__ gl, long gl_sn, cx<T>* __restrict__ gr, long gr_sn,
-                                                        cx<T>* __restrict__ partU, cx<T>* __restrict__ gR0) {
+                                                        cx<T>* __restrict__ partU, cx<T>* __restrict__ gR0, DudSide<T> side) {
     constexpr int BPI = 256 / NP, LDT = NP + 2;      // rows 16-byte aligned and conflict-free for 16-byte reads
     extern __shared__ __attribute__((aligned(32))) char smem_dg[];
     cx<T>* Us = reinterpret_cast<cx<T>*>(smem_dg);   // [NP][LDT]
@@ -752,7 +765,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
     // pointers, 16-byte LDS reads -- and PF rounds of operands are in flight per thread.
     const int BK = B * K;
     const int rounds = f_begin < f_end ? ((f_end - f_begin + BPI - 1) / BPI) * BK : 0;
-    struct Ops { cx<T> g, o, l, r, l2; };
+    struct Ops { cx<T> g, o, l, r, l2, sx, sy; };
     // Loads are unconditional, from clamped addresses (lanes outside the problem re-read the last valid element and are
     // zeroed when consumed; an absent factor reads a constant 1 with stride 0): loads under divergent control flow get an
     // s_waitcnt vmcnt(0) at the join, which would serialise every round on the memory latency.
@@ -778,6 +791,10 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
         x.l = lp[(long)fl * l_sf];
         x.r = rp[(long)fl * r_sf];
         x.l2 = l2p[(long)fl * l2_sf];
+        if (side.on) {                                     // (K == 1: host-checked)
+            x.sx = side.sx[(long)fb * side.sx_b + f_begin + fl];
+            x.sy = side.sy[(long)fb * side.sy_b + f_begin + fl];
+        }
         if (++fk == K) {
             fk = 0;
             if (++fb == B) {
@@ -791,7 +808,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
     Ops ring[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) ring[u] = fetch();
-    cx<T> gl_acc(0, 0), gr_acc(0, 0);
+    cx<T> gl_acc(0, 0), gr_acc(0, 0), sb_acc(0, 0), sc_acc(0, 0);
     int cit = 0, cbk = 0, cb = 0, ck = 0;        // consume side (uniform)
     __syncthreads();                             // U is in LDS
     // (rounds past the end run on zeros -- no early exit inside the unrolled body, whose phi moves cost more than the
@@ -810,6 +827,10 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
             if (++ck == K) {
                 ck = 0;
                 if (++cb == B) cb = 0;
+            }
+            if (side.on) {
+                fma_cxc(sb_acc, mulc(x.g, x.l2), x.sx);  // conj(l2) gR conj(x)     (x.g, x.o are zero outside the problem)
+                fma_cxc(sc_acc, x.sy, x.o);              // gy conj(out)
             }
             const cx<T> t2 = mulc(x.g, x.l * x.l2);     // conj(l) gR
             t1b[bl * LDT + i] = x.r * x.o;
@@ -852,9 +873,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
     }
     if (!partU) return;
     // the BPI lanes of a row are consecutive threads: butterfly inside the wavefront (BPI <= 64)
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        T vr = accU[j].x, vi = accU[j].y;
+    auto row_sum = [&](T& vr, T& vi) {
         if constexpr (BPI <= 16) {      // the lanes of a row sit inside one DPP row: register moves, no LDS round trips
             vr += dpp_mov<0xB1>(vr);    // quad_perm [1,0,3,2]
             vi += dpp_mov<0xB1>(vi);
@@ -875,14 +894,31 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
                 vi += __shfl_xor(vi, off, 64);
             }
         }
-        if (bl == 0 && row && j < N) partU[((size_t)blockIdx.x * N + i) * N + j] = cx<T>(vr, vi);
+    };
+    const size_t pstride = (size_t)N * N + (side.on ? 2 * (size_t)N : 0);
+    cx<T>* pblk = partU + (size_t)blockIdx.x * pstride;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        T vr = accU[j].x, vi = accU[j].y;
+        row_sum(vr, vi);
+        if (bl == 0 && row && j < N) pblk[(size_t)i * N + j] = cx<T>(vr, vi);
+    }
+    if (side.on) {
+        T br = sb_acc.x, bi = sb_acc.y, cr = sc_acc.x, ci = sc_acc.y;
+        row_sum(br, bi);
+        row_sum(cr, ci);
+        if (bl == 0 && row) {
+            pblk[(size_t)N * N + i] = cx<T>(br, bi);
+            pblk[(size_t)N * N + N + i] = cx<T>(cr, ci);
+        }
     }
 }
 
 // per-block partials -> gU.  Thread (pg, e): element e0 + e, partials pg, pg + 16, ...: 128-byte coalesced reads, 16
 // independent chains per element, combined in a fixed order
 template <typename T>
-__global__ void __launch_bounds__(256) dud_grads_final_kernel(const cx<T>* __restrict__ part, int nblk, int count, cx<T>* __restrict__ gU) {
+__global__ void __launch_bounds__(256) dud_grads_final_kernel(const cx<T>* __restrict__ part, int nblk, int count, cx<T>* __restrict__ gU,
+                                                              int tail_from, T* __restrict__ tail_real) {
     __shared__ cx<T> red[16][17];
     const int e = threadIdx.x & 15, pg = threadIdx.x >> 4;
     const int el = blockIdx.x * 16 + e;
@@ -901,7 +937,9 @@ __global__ void __launch_bounds__(256) dud_grads_final_kernel(const cx<T>* __res
         cx<T> a = red[0][e];
 #pragma unroll
         for (int p = 1; p < 16; ++p) a = a + red[p][e];
-        gU[el] = a;
+        // (tail_real: the entries from tail_from on are gradients of REAL gain vectors: their real parts, as a real array)
+        if (tail_real && el >= tail_from) tail_real[el - tail_from] = a.x;
+        else gU[el] = a;
     }
 }
 
@@ -915,7 +953,8 @@ static int dud_grads_blocks(int M, int N) {
 
 template <typename T>
 static int dud_grads_impl(const Dud<T>& d, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N, int K,
-                          void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* stream, void* gR0 = nullptr) {
+                          void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* stream, void* gR0 = nullptr,
+                          DudSide<T> side = DudSide<T>{nullptr, nullptr, 0, 0, 0, nullptr}) {
     FL_REQUIRE(d.U && gR && OUT, "solve_dud_grads: null pointer");
     FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0, "solve_dud_grads: bad sizes");
     FL_REQUIRE((partU == nullptr) == (gU == nullptr), "solve_dud_grads: partU and gU go together");
@@ -929,7 +968,7 @@ static int dud_grads_impl(const Dud<T>& d, const void* gR, const void* OUT, long
     const int nblk = dud_grads_blocks(M, N);
     if (B == 0 || M == 0) {
         if (gU) {
-            int rc = check_hip(hipMemsetAsync(gU, 0, sizeof(cx<T>) * N * N, st), "solve_dud_grads: memset");
+            int rc = check_hip(hipMemsetAsync(gU, 0, sizeof(cx<T>) * (N * N + (side.on ? 2 * N : 0)), st), "solve_dud_grads: memset");
             if (rc) return rc;
         }
         return FL_OK;
@@ -942,11 +981,11 @@ static int dud_grads_impl(const Dud<T>& d, const void* gR, const void* OUT, long
         if (gr)                                                                                                                 \
             hipLaunchKernelGGL((dud_grads_kernel<T, NP_, true>), dim3(nblk), dim3(256), lds, st, d, (const cx<T>*)gR,           \
                                (const cx<T>*)OUT, s_b, s_n, s_k, B, M, N, K, per, (cx<T>*)gl, gl_sn, (cx<T>*)gr, gr_sn,         \
-                               (cx<T>*)partU, (cx<T>*)gR0);                                                                     \
+                               (cx<T>*)partU, (cx<T>*)gR0, side);                                                               \
         else                                                                                                                    \
             hipLaunchKernelGGL((dud_grads_kernel<T, NP_, false>), dim3(nblk), dim3(256), lds, st, d, (const cx<T>*)gR,          \
                                (const cx<T>*)OUT, s_b, s_n, s_k, B, M, N, K, per, (cx<T>*)gl, gl_sn, (cx<T>*)gr, gr_sn,         \
-                               (cx<T>*)partU, (cx<T>*)gR0);                                                                     \
+                               (cx<T>*)partU, (cx<T>*)gR0, side);                                                               \
     }
     if (N <= 4) FL_DG(4) else if (N <= 8) FL_DG(8) else if (N <= 16) FL_DG(16) else if (N <= 32) FL_DG(32) else {
         if constexpr (sizeof(T) == 4) FL_DG(64) else return FL_ERR_UNSUPPORTED;
@@ -954,8 +993,9 @@ static int dud_grads_impl(const Dud<T>& d, const void* gR, const void* OUT, long
 #undef FL_DG
     FL_CHECK_LAUNCH("solve_dud_grads");
     if (gU) {
-        hipLaunchKernelGGL((dud_grads_final_kernel<T>), dim3(cdiv_i(N * N, 16)), dim3(256), 0, st, (const cx<T>*)partU, nblk, N * N,
-                           (cx<T>*)gU);
+        const int count = N * N + (side.on ? 2 * N : 0);       // gU is then (N*N + 2N): [gU | g_b | g_c]
+        hipLaunchKernelGGL((dud_grads_final_kernel<T>), dim3(cdiv_i(count, 16)), dim3(256), 0, st, (const cx<T>*)partU, nblk, count,
+                           (cx<T>*)gU, N * N, side.on ? side.real_out : (T*)nullptr);
         FL_CHECK_LAUNCH("solve_dud_grads_final");
     }
     return FL_OK;
@@ -1046,18 +1086,24 @@ int fl_solve_dud2_c128(const void* l, long l_sn, long l_sf, const void* l2, long
 }
 int fl_solve_dud2_grads_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
                             long r_sn, long r_sf, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N,
-                            int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, void* stream) {
+                            int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, const void* sx,
+                            long sx_b, const void* sy, long sy_b, void* g_side_real, void* stream) {
     FL_REQUIRE(l2, "solve_dud2_grads: null pointer");
+    FL_REQUIRE((sx == nullptr) == (sy == nullptr) && (!sx || (K == 1 && partU && gU)), "solve_dud2_grads: side reductions need sx, sy, one column per batch item and the partial buffers");
     Dud<float> d = {(const cx<float>*)l, l_sn, l_sf, (const cx<float>*)U, (const cx<float>*)r, r_sn, r_sf,
                     (const cx<float>*)l2, l2_sn, l2_sf, 0};
-    return dud_grads_impl<float>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream, gR0);
+    DudSide<float> side = {(const cx<float>*)sx, (const cx<float>*)sy, sx_b, sy_b, sx ? 1 : 0, (float*)g_side_real};
+    return dud_grads_impl<float>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream, gR0, side);
 }
 int fl_solve_dud2_grads_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
                              long r_sn, long r_sf, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N,
-                             int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, void* stream) {
+                             int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, const void* sx,
+                             long sx_b, const void* sy, long sy_b, void* g_side_real, void* stream) {
     FL_REQUIRE(l2, "solve_dud2_grads: null pointer");
+    FL_REQUIRE((sx == nullptr) == (sy == nullptr) && (!sx || (K == 1 && partU && gU)), "solve_dud2_grads: side reductions need sx, sy, one column per batch item and the partial buffers");
     Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf,
                      (const cx<double>*)l2, l2_sn, l2_sf, 0};
-    return dud_grads_impl<double>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream, gR0);
+    DudSide<double> side = {(const cx<double>*)sx, (const cx<double>*)sy, sx_b, sy_b, sx ? 1 : 0, (double*)g_side_real};
+    return dud_grads_impl<double>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream, gR0, side);
 }
 }

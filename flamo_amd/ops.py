@@ -1096,8 +1096,109 @@ class _SolveDUD2(torch.autograd.Function):
             with kernel_timer.span("solve_dud_grads"):
                 _lib.check(fn(lptr, l_sn, l_sf, l2ptr, l2_sn, l2_sf, Uc.data_ptr(), rptr, r_sn, r_sf, gR.data_ptr(), OUT.data_ptr(),
                               s_b, s_n, s_k, B, M, N, K, ptr(gl), _pitch(M), ptr(gr), _pitch(M), ptr(part), ptr(gU), ptr(gR0),
-                              _stream()), "solve_dud2_grads")
+                              None, 0, None, 0, None, _stream()), "solve_dud2_grads")
         return (None if gl is None else gl.movedim(-1, 0)), None, gU, (None if gr is None else gr.movedim(-1, 0)), gR0
+
+
+def _apply_const(W, transpose, X):
+    """W X or W^T X (W^H for a complex W) for a frequency-independent (No, Ni) matrix, real or complex"""
+    if not W.is_complex():
+        return _mimo_real_launch(W, transpose, X)
+    return _mimo_launch(W, False, False, transpose, X)
+
+
+class _FdnCore(torch.autograd.Function):
+    """y = c (I - diag(l . l2) U diag(r))^-1 (l2 . (b x)) per bin: a feedback delay network between its input-gain column
+    b (N, 1) and output-gain row c (1, N) (Series(Gain(N,1), Recursion, Gain(1,N)), reverb.py:117-199 / e8_fdn.py:60-100).
+    Forward: the three launches the modules would make.  Backward: c^H gy, the adjoint solve, and ONE pass that returns the
+    gradients of l, U, r, b and c (fl_solve_dud2_grads_* with its side reductions) -- the two gains' gradients are sums over
+    bins of products the pass already holds."""
+
+    @staticmethod
+    def forward(ctx, b, c, l, l2, U, r, X):
+        _require_gpu(b, c, l2, U, X)
+        N = U.shape[0]
+        if b.shape != (N, 1) or c.shape != (1, N) or X.dim() != 3 or X.shape[2] != 1:
+            raise ValueError("fdn_core: expected b (N, 1), c (1, N) and a one-channel spectrum X (B, M, 1)")
+        Xp = to_planar(X.resolve_conj())
+        Uc = U.resolve_conj().contiguous()
+        pl = lambda t: None if t is None else _h_planar(t.resolve_conj(), True)  # noqa: E731
+        lp, l2p, rp = pl(l), pl(l2), pl(r)
+        bc, cc = b.resolve_conj().contiguous(), c.resolve_conj().contiguous()
+        R0 = _apply_const(bc, False, Xp)
+        OUT = _solve_dud2_launch(lp, l2p, True, Uc, rp, False, R0)
+        y = _apply_const(cc, False, OUT)
+        ctx.have = (l is not None, r is not None)
+        ctx.save_for_backward(*([t for t in (lp, rp) if t is not None] + [l2p, Uc, OUT, Xp, bc, cc]))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        saved = list(ctx.saved_tensors)
+        lp = saved.pop(0) if ctx.have[0] else None
+        rp = saved.pop(0) if ctx.have[1] else None
+        l2p, Uc, OUT, Xp, bc, cc = saved
+        gyp = to_planar(gy.resolve_conj())
+        gR = _solve_dud2_launch(lp, l2p, False, Uc, rp, True, _apply_const(cc, True, gyp))           # A^-H c^H gy
+        need_b, need_c, need_l, need_U, need_r, need_X = (ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                                          ctx.needs_input_grad[2] and lp is not None, ctx.needs_input_grad[4],
+                                                          ctx.needs_input_grad[5] and rp is not None, ctx.needs_input_grad[6])
+        real = _rdtype(OUT)
+        B, M, N, K, s_b, s_n, s_k = _bnk(OUT)
+        dev = OUT.device
+        L = _lib.lib()
+        gl = _empty_rows((N,), M, OUT.dtype, dev) if need_l else None
+        gr = _empty_rows((N,), M, OUT.dtype, dev) if need_r else None
+        gR0 = _empty_planar(OUT.shape, OUT.dtype, dev) if need_X else None
+        side = need_b or need_c
+        real_gains = not bc.is_complex() and not cc.is_complex()
+        part = gUS = side_real = None
+        if need_U or side:
+            cnt = N * N + (2 * N if side else 0)
+            part = torch.empty((L.fl_solve_dud_grads_blocks(M, N), cnt), dtype=OUT.dtype, device=dev)
+            gUS = torch.empty((cnt,), dtype=OUT.dtype, device=dev)
+            if side and real_gains:
+                side_real = torch.empty((2 * N,), dtype=real, device=dev)
+        g_b = g_c = gU = gX = None
+        if need_l or need_U or need_r or need_X or side:
+            lptr, l_sn, l_sf = _diag_args(lp)
+            l2ptr, l2_sn, l2_sf = _diag_args(l2p)
+            rptr, r_sn, r_sf = _diag_args(rp)
+            _, _, _, _, xs_b, _, _ = _bnk(Xp)
+            _, _, _, _, gs_b, _, _ = _bnk(gyp)
+            fn = L.fl_solve_dud2_grads_c64 if real == torch.float32 else L.fl_solve_dud2_grads_c128
+            ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+            with kernel_timer.span("solve_dud_grads"):
+                _lib.check(fn(lptr, l_sn, l_sf, l2ptr, l2_sn, l2_sf, Uc.data_ptr(), rptr, r_sn, r_sf, gR.data_ptr(), OUT.data_ptr(),
+                              s_b, s_n, s_k, B, M, N, K, ptr(gl), _pitch(M), ptr(gr), _pitch(M), ptr(part), ptr(gUS), ptr(gR0),
+                              Xp.data_ptr() if side else None, xs_b, gyp.data_ptr() if side else None, gs_b, ptr(side_real),
+                              _stream()), "solve_dud2_grads")
+            if need_U:
+                gU = gUS[:N * N].view(N, N)
+            if side:
+                tail = side_real if side_real is not None else gUS[N * N:]
+                gb_full, gc_full = tail[:N].view(N, 1), tail[N:].view(1, N)
+                if side_real is None:        # mixed real / complex gains: the real one takes the real part
+                    gb_full = gb_full if bc.is_complex() else gb_full.real
+                    gc_full = gc_full if cc.is_complex() else gc_full.real
+                g_b = gb_full if need_b else None
+                g_c = gc_full if need_c else None
+            if need_X:
+                gX = _apply_const(bc, True, gR0)
+        return (g_b, g_c, (None if gl is None else gl.movedim(-1, 0)), None, gU, (None if gr is None else gr.movedim(-1, 0)), gX)
+
+
+def fdn_core(b, c, l, l2, U, r, X):
+    """One-channel spectrum X (B, M, 1) through  c (I - diag(l . l2) U diag(r))^-1 (l2 . (b X))  per bin -- see _FdnCore.
+    b (N, 1), c (1, N): real (of X's precision) or complex constants; l, r: per-bin (M, N) or None; l2: per-bin (M, N) without
+    gradient; U (N, N)."""
+    if l2.requires_grad:
+        raise ValueError("fdn_core: the feedforward diagonal must not require a gradient")
+    cd = X.dtype
+    rd = _rdtype(X)
+    conv = lambda t: None if t is None else (t if t.dtype == cd else t.to(cd))  # noqa: E731
+    gain = lambda t: t if (t.dtype == rd or t.dtype == cd) else t.to(cd if t.is_complex() else rd)  # noqa: E731
+    return _FdnCore.apply(gain(b), gain(c), conv(l), conv(l2), conv(U), conv(r), X)
 
 
 def _solve_dud2_launch(l, l2, rhs_l2, U, r, adjoint, R):

@@ -41,6 +41,9 @@ SCALED_LOOP = True
 # FDN loops whose feedforward path is one diagonal module without gradient (the delays): applied inside the factored solve
 # and its one-pass backward (ops.solve_dud2) instead of as launches of its own
 FDN_DIAGONAL_IN_SOLVE = True
+# Series(Gain(N,1), Recursion, Gain(1,N)) on a one-channel spectrum as one operator (ops.fdn_core): the gains' gradients come
+# out of the loop's one-pass backward
+FDN_CORE = True
 # Gradients of the parameters are then produced on the side stream while their AccumulateGrad
 # nodes live on the main one; autograd synchronises the two correctly and merely warns about it.
 _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
@@ -219,6 +222,12 @@ class Series(nn.Sequential):
         while i < len(items):
             key, module = items[i]
             j = i
+            if FDN_CORE and FDN_DIAGONAL_IN_SOLVE and ext_param is None and i + 2 < len(items) and isinstance(items[i + 1][1], Recursion):
+                out = self.__fdn_core(items[i][1], items[i + 1][1], items[i + 2][1], input)
+                if out is not None:
+                    input = out
+                    i += 3
+                    continue
             if FUSE_SERIES and torch.is_tensor(input) and input.is_complex() and input.is_cuda and input.dim() >= 3:
                 cols = input.shape[0]
                 for d in input.shape[3:]:
@@ -236,6 +245,31 @@ class Series(nn.Sequential):
                 input = module(input)
             i += 1
         return input
+
+    @staticmethod
+    def __fdn_core(ig, rec, og, x):
+        """Gain(N, 1) -> Recursion (FDN loop with a diagonal feedforward path) -> Gain(1, N) on a one-channel spectrum: one
+        operator (ops.fdn_core) whose backward returns both gains' gradients from the loop's one-pass backward; None when
+        the three modules are not that."""
+        if not (torch.is_tensor(x) and x.is_cuda and x.is_complex() and x.dim() == 3 and x.shape[2] == 1):
+            return None
+        for g in (ig, og):
+            if not (hasattr(g, "_mapped") and not g._diag and hasattr(g, "_fusable") and g._fusable()):
+                return None
+        N = rec.output_channels
+        if (ig.input_channels, ig.output_channels, og.input_channels, og.output_channels) != (1, N, N, 1) or rec.input_channels != N:
+            return None
+        for m in (ig, rec, og):              # the modules' own input checks would have run
+            if m.nfft // 2 + 1 != x.shape[1] and ops.bin_shard(m.nfft)[1] != x.shape[1]:
+                return None
+        b, c = ig._mapped(ig.param), og._mapped(og.param)
+        if not (torch.is_tensor(b) and torch.is_tensor(c) and b.dim() == 2 and c.dim() == 2 and b.is_cuda and c.is_cuda):
+            return None
+        with ops.loop_scope():
+            f = rec._fdn_factors(x.shape[1])
+        if f is None:
+            return None
+        return ops.fdn_core(b, c, f[0], f[1], f[2], f[3], x)
 
     @staticmethod
     def _run_response(run, shape, ext_param, device):
@@ -353,7 +387,7 @@ class Recursion(nn.Module):
 
     def __forward_in_loop(self, X, ext_param, ext_fb, ext_ff):
         if FUSE_SERIES and FDN_DIAGONAL_IN_SOLVE and ext_param is None and torch.is_tensor(X) and X.is_cuda and X.is_complex():
-            d2 = self.__factored_loop_with_feedforward(X)
+            d2 = self._fdn_factors(X.shape[1]) if (X.dim() >= 3 and X.shape[2] == self.output_channels) else None
             if d2 is not None:
                 # FDN structure with a diagonal feedforward path (the delays): that diagonal scales l and the right-hand
                 # side where the solve kernels load them (ops.solve_dud2) instead of in launches of its own
@@ -432,7 +466,7 @@ class Recursion(nn.Module):
             return None
         return g, D, U
 
-    def __factored_loop_with_feedforward(self, X):
+    def _fdn_factors(self, M: int):
         """(l, l2, U, r) when the feedforward path is ONE diagonal per-bin module without gradient (l2: parallelDelay in
         every FDN of the reference) and the feedback path is one constant full matrix with per-bin diagonal factors around
         it (l: those applied after it, r: before); else None.  P = diag(l . l2) U diag(r),  R = l2 . X."""
@@ -443,8 +477,8 @@ class Recursion(nn.Module):
         for m in fb:
             if isinstance(m, Series) or not (hasattr(m, "_fusable") and m._fusable()):
                 return None
-        N, M = self.output_channels, X.shape[1]
-        if X.dim() < 3 or X.shape[2] != N or ff[0].input_channels != N:
+        N = self.output_channels
+        if ff[0].input_channels != N:
             return None
         shape = [1, M, N, N]
         l2, d2 = ff[0]._response_for_fusion(shape, None)

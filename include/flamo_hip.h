@@ -379,12 +379,20 @@ int fl_solve_dud2_c64(const void* l, long l_sn, long l_sf, const void* l2, long 
 int fl_solve_dud2_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, int rhs_l2, const void* U,
                        const void* r, long r_sn, long r_sf, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
                        long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream);
+/* Side reductions (sx, sy non-NULL; K = 1): when the loop sits between an input-gain column b (R0 = b x) and an output-gain row
+ * c (y = c . OUT) -- Series(Gain(N,1), Recursion, Gain(1,N)), reverb.py:117-199 -- pass x as sx and gy as sy (element (b, f)
+ * at b*s_b + f): partU is then (blocks, N*N + 2N) and gU (N*N + 2N) = [gU | g_b | g_c] with
+ *   g_b[i] = sum conj(l2_i) gR_i conj(x),   g_c[i] = sum gy conj(out_i)
+ * -- the two gains' gradients without their own bin-reduction launches.  g_side_real (may be NULL): for REAL gain vectors,
+ * a real (2N) array that receives (Re g_b, Re g_c) instead of the tail of gU. */
 int fl_solve_dud2_grads_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
                             long r_sn, long r_sf, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N,
-                            int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, void* stream);
+                            int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, const void* sx,
+                            long sx_b, const void* sy, long sy_b, void* g_side_real, void* stream);
 int fl_solve_dud2_grads_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
                              long r_sn, long r_sf, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N,
-                             int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, void* stream);
+                             int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, const void* sx,
+                             long sx_b, const void* sy, long sy_b, void* g_side_real, void* stream);
 /* tuning/test hook: 0 (default) = N <= 16 factor with rows exchanged in place (compile-time DPP broadcasts,
  * threshold pivoting; two rows per lane for the factored loop at N in (4, 16]); 1 = the shuffle kernel with implicit
  * partial pivoting for every N; 4 = the in-place kernels with one row per lane */

@@ -810,3 +810,50 @@ def test_matrix_exp_both_forms_and_step_scope(gpu, N):
             grads[scoped] = mix.param.grad.clone()
         assert ops.step_memo() is None
         assert relerr(grads[True], grads[False]) < (1e-6 if dt == torch.float32 else 1e-13)
+
+
+@pytest.mark.parametrize("N", [4, 6, 16])
+def test_fdn_between_its_gains_as_one_operator(gpu, N):
+    """Series(Gain(N,1), Recursion(fF=parallelDelay, fB=Series(Matrix orthogonal, parallelGEQ)), Gain(1,N)) on a one-channel
+    spectrum: ops.fdn_core (both gains' gradients from the side reductions of fl_solve_dud2_grads_*) against the
+    module-by-module route; output, every parameter gradient and the input gradient, float64 and float32, batch 1 and 3."""
+    from collections import OrderedDict
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    nfft = 4800
+    for dt, tol in ((torch.float64, 1e-10), (torch.float32, 3e-5)):
+        torch.manual_seed(N)
+        kw = dict(nfft=nfft, alias_decay_db=30.0, device=gpu, dtype=dt)
+        ig = dsp.Gain(size=(N, 1), requires_grad=True, **kw)
+        og = dsp.Gain(size=(1, N), requires_grad=True, **kw)
+        dl = dsp.parallelDelay(size=(N,), max_len=300, isint=True, **kw)
+        mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+        att = dsp.parallelGEQ(size=(N,), requires_grad=True, **kw)
+        with torch.no_grad():
+            att.param.copy_(0.5 + 0.4 * torch.rand_like(att.param))
+        core = system.Series(OrderedDict(input_gain=ig, feedback_loop=system.Recursion(
+            fF=dl, fB=system.Series(OrderedDict(mixing_matrix=mix, attenuation=att))), output_gain=og))
+        cd = torch.complex128 if dt == torch.float64 else torch.complex64
+        params = [ig.param, og.param, mix.param, att.param]
+        for B in (1, 3):
+            X0 = torch.randn(B, nfft // 2 + 1, 1, device=gpu, dtype=cd)
+            C = torch.randn(B, nfft // 2 + 1, 1, device=gpu, dtype=cd)
+            res = {}
+            try:
+                for on in (True, False):
+                    system.FDN_CORE = on
+                    X = X0.clone().requires_grad_(True)
+                    ops.kernel_timer.reset(True)
+                    Y = core(X)
+                    g = torch.autograd.grad(torch.sum(torch.real(Y * C.conj())), params + [X])
+                    torch.cuda.synchronize()
+                    ops.kernel_timer.enabled = False
+                    res[on] = ([Y.detach()] + list(g), set(ops.kernel_timer.summary()))
+            finally:
+                system.FDN_CORE = True
+                ops.kernel_timer.enabled = False
+            assert not any(n.startswith("mimo_gradw") for n in res[True][1]), res[True][1]
+            assert any(n.startswith("mimo_gradw") for n in res[False][1])
+            assert res[True][0][1].dtype == dt and res[True][0][1].shape == ig.param.shape
+            for a, b in zip(res[True][0], res[False][0]):
+                assert relerr(a, b) < tol
