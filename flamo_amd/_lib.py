@@ -85,6 +85,8 @@ _SIGNATURES = {
     "fl_solve_dud_c64": (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_dud_c128": (_i, [_vp, _l, _l, _vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_dud_grads_blocks": (_i, [_i, _i]),
+    "fl_solve_fdn_c64": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _i, _vp, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _l, _l, _i, _i, _i, _vp]),
+    "fl_solve_fdn_c128": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _i, _vp, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _l, _l, _i, _i, _i, _vp]),
     "fl_solve_dud2_c64": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_dud2_c128": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_dud2_grads_c64": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp]),

@@ -43,7 +43,19 @@ struct Dud {
     const cx<T>* l2;
     long l2_sn, l2_sf;
     int rhs_l2;
+    // Rank-one right-hand side and contracted output (ops.fdn_core; one column per batch item, in-place kernels only):
+    // R_i[b][f] = rv_i rs[b][f] (rv conjugated for the adjoint system) -- the input-gain column times the scalar input
+    // spectrum, or conj(output-gain row) times the output's gradient -- and, forward system, z[b][f] = sum_i cw_i OUT_i
+    // beside OUT (the output-gain row applied in the wavefront).  rv / cw: N values, real (T) or complex.
+    const void* rv;
+    const cx<T>* rs;
+    long rs_sb;
+    const void* cw;
+    cx<T>* cz;
+    long cz_sb;
+    int rv_real, cw_real;
 };
+
 
 // ---------------------------------------------------------------- DPP exchanges inside a 16-lane row
 // The pivot search is a chain of dependent exchanges; through ds_bpermute each one is an LDS round
@@ -64,6 +76,20 @@ __device__ inline double dpp_mov(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, true);
     const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned int)lo);
+}
+
+template <typename T>
+__device__ inline cx<T> gain_at(const void* v, int is_real, int i) {
+    return is_real ? cx<T>(reinterpret_cast<const T*>(v)[i], 0) : reinterpret_cast<const cx<T>*>(v)[i];
+}
+// sum over the LANES consecutive lanes of a group (4, 8 or 16: inside one DPP row)
+template <int LANES, typename T>
+__device__ inline T group_sum(T v) {
+    v += dpp_mov<0xB1>(v);                                   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                                   // quad_perm [2,3,0,1]
+    if constexpr (LANES >= 8) v += dpp_mov<0x141>(v);        // row_half_mirror
+    if constexpr (LANES >= 16) v += dpp_mov<0x140>(v);       // row_mirror
+    return v;
 }
 constexpr int DPP_QUAD_XOR1 = 0xB1;       // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_XOR2 = 0x4E;       // quad_perm:[2,3,0,1]
@@ -588,7 +614,12 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
         for (int s = 0; s < RPL; ++s) {
             y[s] = cx<T>(0, 0);
             if (s * LANES + gi < N) {
-                y[s] = R[(long)b * rs_b + (long)orig[s] * rs_n + (long)kk * rs_k + f];
+                if (dud.rv) {           // rank-one right-hand side (K == 1): gain vector entry times the scalar signal
+                    const cx<T> gv = gain_at<T>(dud.rv, dud.rv_real, orig[s]);
+                    y[s] = (adjoint ? conj(gv) : gv) * dud.rs[(long)b * dud.rs_sb + f];
+                } else {
+                    y[s] = R[(long)b * rs_b + (long)orig[s] * rs_n + (long)kk * rs_k + f];
+                }
                 if (dud.rhs_l2 && !(adjoint & 1)) y[s] = y[s] * dud.l2[(long)orig[s] * dud.l2_sn + (long)f * dud.l2_sf];
             }
         }
@@ -619,10 +650,19 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
                 }
             }
         });
+        cx<T> z(0, 0);
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
             const int ri = s * LANES + gi;
-            if (ri < N) OUT[(long)b * os_b + (long)ri * os_n + (long)kk * os_k + f] = y[s];
+            if (ri < N) {
+                OUT[(long)b * os_b + (long)ri * os_n + (long)kk * os_k + f] = y[s];
+                if (dud.cz) fma_cx(z, gain_at<T>(dud.cw, dud.cw_real, ri), y[s]);
+            }
+        }
+        if (dud.cz && !adjoint) {      // uniform: the output-gain row applied in the wavefront
+            z.x = group_sum<LANES>(z.x);
+            z.y = group_sum<LANES>(z.y);
+            if (gi == 0) dud.cz[(long)b * dud.cz_sb + f] = z;
         }
     }
 }
@@ -685,7 +725,15 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
 template <typename T>
 static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
                       void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
-    FL_REQUIRE((P || dud.U) && R && OUT, "solve: null pointer");
+    FL_REQUIRE((P || dud.U) && (R || dud.rv) && OUT, "solve: null pointer");
+    if (dud.rv || dud.cz) {
+        FL_REQUIRE(dud.rv && dud.rs && K == 1 && !P, "solve: the rank-one right-hand side needs its scalar signal, one column per batch item and the factored loop");
+        if (g_solve_variant != 0 || N > (sizeof(T) == 4 ? 32 : 16)) {
+            set_error("solve: the rank-one right-hand side / contracted output exist in the in-place kernels only (N <= %d here)",
+                      sizeof(T) == 4 ? 32 : 16);
+            return FL_ERR_UNSUPPORTED;
+        }
+    }
     FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0 && (!P || p_pitch >= M), "solve: bad sizes (p_pitch >= M)");
     const int nmax_lim = sizeof(T) == 8 ? 32 : 64;
     if (N > nmax_lim) {
@@ -1105,5 +1153,25 @@ int fl_solve_dud2_grads_c128(const void* l, long l_sn, long l_sf, const void* l2
                      (const cx<double>*)l2, l2_sn, l2_sf, 0};
     DudSide<double> side = {(const cx<double>*)sx, (const cx<double>*)sy, sx_b, sy_b, sx ? 1 : 0, (double*)g_side_real};
     return dud_grads_impl<double>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream, gR0, side);
+}
+/* fl_solve_dud2 with the right-hand side built in the kernel, R_i = rv_i rs (rv conjugated for the adjoint system; scaled by
+ * l2 for the forward one), and -- forward system, cz non-NULL -- the contracted output z = sum_i cw_i OUT_i beside OUT */
+int fl_solve_fdn_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                     long r_sn, long r_sf, int adjoint, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw,
+                     int cw_real, void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* stream) {
+    FL_REQUIRE(U && l2 && rv && rs && (!cz || cw), "solve_fdn: null pointer");
+    Dud<float> d = {(const cx<float>*)l, l_sn, l_sf, (const cx<float>*)U, (const cx<float>*)r, r_sn, r_sf,
+                    (const cx<float>*)l2, l2_sn, l2_sf, adjoint ? 0 : 1, rv, (const cx<float>*)rs, rs_sb, cw, (cx<float>*)cz, cz_sb,
+                    rv_real, cw_real};
+    return solve_impl<float>(nullptr, 0, d, 1, adjoint, nullptr, 0, 0, 0, OUT, os_b, os_n, os_k, B, M, N, 1, stream);
+}
+int fl_solve_fdn_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                      long r_sn, long r_sf, int adjoint, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw,
+                      int cw_real, void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* stream) {
+    FL_REQUIRE(U && l2 && rv && rs && (!cz || cw), "solve_fdn: null pointer");
+    Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf,
+                     (const cx<double>*)l2, l2_sn, l2_sf, adjoint ? 0 : 1, rv, (const cx<double>*)rs, rs_sb, cw, (cx<double>*)cz, cz_sb,
+                     rv_real, cw_real};
+    return solve_impl<double>(nullptr, 0, d, 1, adjoint, nullptr, 0, 0, 0, OUT, os_b, os_n, os_k, B, M, N, 1, stream);
 }
 }

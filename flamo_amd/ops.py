@@ -1107,6 +1107,39 @@ def _apply_const(W, transpose, X):
     return _mimo_launch(W, False, False, transpose, X)
 
 
+# ops.fdn_core: build the right-hand side b x and apply the output-gain row inside the solve kernels (fl_solve_fdn_*; the
+# in-place kernels: N <= 32 in float32, 16 in float64).  False = separate launches for b x, c OUT and c^H gy.
+FDN_GAINS_IN_SOLVE = True
+
+
+def _fdn_in_solve(real, N) -> bool:
+    return FDN_GAINS_IN_SOLVE and N <= (32 if real == torch.float32 else 16)
+
+
+def _solve_fdn_launch(l, l2, U, r, adjoint, gain, sig, cw):
+    """OUT = A^-1 (l2 . (gain sig)) [forward] or A^-H (conj(gain) sig) [adjoint]; with cw (forward) also z = cw . OUT.
+    gain, cw: contiguous N-vectors, real or complex; sig: planar one-channel signal (B, M, 1).  -> (OUT, z | None)"""
+    real = _rdtype(sig)
+    B, M, _, K, ss_b, _, _ = _bnk(sig)
+    assert K == 1
+    N = U.shape[0]
+    OUT = _empty_planar((B, M, N), sig.dtype, sig.device)
+    _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
+    z = _empty_planar((B, M, 1), sig.dtype, sig.device) if cw is not None else None
+    zs_b = _bnk(z)[4] if z is not None else 0
+    L = _lib.lib()
+    fn = L.fl_solve_fdn_c64 if real == torch.float32 else L.fl_solve_fdn_c128
+    lp, l_sn, l_sf = _diag_args(l)
+    l2p, l2_sn, l2_sf = _diag_args(l2)
+    rp, r_sn, r_sf = _diag_args(r)
+    with kernel_timer.span("solve_dud_adj" if adjoint else "solve_dud"):
+        _lib.check(fn(lp, l_sn, l_sf, l2p, l2_sn, l2_sf, U.data_ptr(), rp, r_sn, r_sf, int(adjoint), gain.data_ptr(),
+                      int(not gain.is_complex()), sig.data_ptr(), ss_b, None if cw is None else cw.data_ptr(),
+                      int(cw is not None and not cw.is_complex()), None if z is None else z.data_ptr(), zs_b, OUT.data_ptr(), os_b,
+                      os_n, os_k, B, M, N, _stream()), "solve_fdn")
+    return OUT, z
+
+
 class _FdnCore(torch.autograd.Function):
     """y = c (I - diag(l . l2) U diag(r))^-1 (l2 . (b x)) per bin: a feedback delay network between its input-gain column
     b (N, 1) and output-gain row c (1, N) (Series(Gain(N,1), Recursion, Gain(1,N)), reverb.py:117-199 / e8_fdn.py:60-100).
@@ -1125,9 +1158,13 @@ class _FdnCore(torch.autograd.Function):
         pl = lambda t: None if t is None else _h_planar(t.resolve_conj(), True)  # noqa: E731
         lp, l2p, rp = pl(l), pl(l2), pl(r)
         bc, cc = b.resolve_conj().contiguous(), c.resolve_conj().contiguous()
-        R0 = _apply_const(bc, False, Xp)
-        OUT = _solve_dud2_launch(lp, l2p, True, Uc, rp, False, R0)
-        y = _apply_const(cc, False, OUT)
+        ctx.in_solve = _fdn_in_solve(_rdtype(Xp), N)
+        if ctx.in_solve:
+            OUT, y = _solve_fdn_launch(lp, l2p, Uc, rp, False, bc, Xp, cc)
+        else:
+            R0 = _apply_const(bc, False, Xp)
+            OUT = _solve_dud2_launch(lp, l2p, True, Uc, rp, False, R0)
+            y = _apply_const(cc, False, OUT)
         ctx.have = (l is not None, r is not None)
         ctx.save_for_backward(*([t for t in (lp, rp) if t is not None] + [l2p, Uc, OUT, Xp, bc, cc]))
         return y
@@ -1139,7 +1176,10 @@ class _FdnCore(torch.autograd.Function):
         rp = saved.pop(0) if ctx.have[1] else None
         l2p, Uc, OUT, Xp, bc, cc = saved
         gyp = to_planar(gy.resolve_conj())
-        gR = _solve_dud2_launch(lp, l2p, False, Uc, rp, True, _apply_const(cc, True, gyp))           # A^-H c^H gy
+        if ctx.in_solve:
+            gR, _ = _solve_fdn_launch(lp, l2p, Uc, rp, True, cc, gyp, None)                           # A^-H c^H gy
+        else:
+            gR = _solve_dud2_launch(lp, l2p, False, Uc, rp, True, _apply_const(cc, True, gyp))
         need_b, need_c, need_l, need_U, need_r, need_X = (ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                                           ctx.needs_input_grad[2] and lp is not None, ctx.needs_input_grad[4],
                                                           ctx.needs_input_grad[5] and rp is not None, ctx.needs_input_grad[6])

@@ -393,6 +393,17 @@ int fl_solve_dud2_grads_c128(const void* l, long l_sn, long l_sf, const void* l2
                              long r_sn, long r_sf, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N,
                              int K, void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* gR0, const void* sx,
                              long sx_b, const void* sy, long sy_b, void* g_side_real, void* stream);
+/* The FDN loop between an input-gain column and an output-gain row (Series(Gain(N,1), Recursion, Gain(1,N)),
+ * reverb.py:117-199): fl_solve_dud2 with the right-hand side built in the kernel, R_i = rv_i rs[b][f] (rs: the one-channel
+ * spectrum, element (b, f) at b*rs_sb + f; rv: N gains, real values of the signal's precision if rv_real else complex;
+ * conjugated for the adjoint system, scaled by l2 for the forward one), and -- forward system, cz non-NULL -- the contracted
+ * output z[b][f] = sum_i cw_i OUT_i written beside OUT.  In-place kernels only: N <= 32 (c64) / 16 (c128). */
+int fl_solve_fdn_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                     long r_sn, long r_sf, int adjoint, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw,
+                     int cw_real, void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* stream);
+int fl_solve_fdn_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                      long r_sn, long r_sf, int adjoint, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw,
+                      int cw_real, void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* stream);
 /* tuning/test hook: 0 (default) = N <= 16 factor with rows exchanged in place (compile-time DPP broadcasts,
  * threshold pivoting; two rows per lane for the factored loop at N in (4, 16]); 1 = the shuffle kernel with implicit
  * partial pivoting for every N; 4 = the in-place kernels with one row per lane */

@@ -812,7 +812,7 @@ def test_matrix_exp_both_forms_and_step_scope(gpu, N):
         assert relerr(grads[True], grads[False]) < (1e-6 if dt == torch.float32 else 1e-13)
 
 
-@pytest.mark.parametrize("N", [4, 6, 16])
+@pytest.mark.parametrize("N", [4, 6, 16, 24])
 def test_fdn_between_its_gains_as_one_operator(gpu, N):
     """Series(Gain(N,1), Recursion(fF=parallelDelay, fB=Series(Matrix orthogonal, parallelGEQ)), Gain(1,N)) on a one-channel
     spectrum: ops.fdn_core (both gains' gradients from the side reductions of fl_solve_dud2_grads_*) against the
@@ -840,8 +840,9 @@ def test_fdn_between_its_gains_as_one_operator(gpu, N):
             C = torch.randn(B, nfft // 2 + 1, 1, device=gpu, dtype=cd)
             res = {}
             try:
-                for on in (True, False):
-                    system.FDN_CORE = on
+                for on in (True, "launches", False):        # gains inside the solve / as launches of their own / module by module
+                    system.FDN_CORE = bool(on)
+                    ops.FDN_GAINS_IN_SOLVE = on is True
                     X = X0.clone().requires_grad_(True)
                     ops.kernel_timer.reset(True)
                     Y = core(X)
@@ -851,9 +852,14 @@ def test_fdn_between_its_gains_as_one_operator(gpu, N):
                     res[on] = ([Y.detach()] + list(g), set(ops.kernel_timer.summary()))
             finally:
                 system.FDN_CORE = True
+                ops.FDN_GAINS_IN_SOLVE = True
                 ops.kernel_timer.enabled = False
             assert not any(n.startswith("mimo_gradw") for n in res[True][1]), res[True][1]
+            in_solve = N <= (32 if dt == torch.float32 else 16)          # the in-place kernels' range
+            assert any(n.startswith("mimo_const_real_fwd") for n in res[True][1]) == (not in_solve), res[True][1]
+            assert any(n.startswith("mimo_const_real_fwd") for n in res["launches"][1])
             assert any(n.startswith("mimo_gradw") for n in res[False][1])
             assert res[True][0][1].dtype == dt and res[True][0][1].shape == ig.param.shape
-            for a, b in zip(res[True][0], res[False][0]):
-                assert relerr(a, b) < tol
+            for k in (True, "launches"):
+                for a, b in zip(res[k][0], res[False][0]):
+                    assert relerr(a, b) < tol, k
