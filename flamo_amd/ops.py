@@ -1515,6 +1515,30 @@ def cascade_apply_supported(real: torch.dtype, X: torch.Tensor) -> bool:
     return real == torch.float32 and SOS_BWD_MIXED and X.dim() == 3 and X.dtype == torch.complex64 and X.is_cuda
 
 
+def _sos_apply_forward(bc, ac, Xp, gamma, nfft, real, float_eval):
+    """(H rows buffer (No, Ni, pitch)[..., :m_local], Y planar (B, M, No), cfg): cascade response and its product with the
+    signal -- one launch when the float evaluation applies and the coefficient tables fit (fl_sos_response_apply_c64), else
+    the response launch followed by the per-bin product"""
+    S, No, Ni = bc.shape[1], bc.shape[2], bc.shape[3]
+    B = Xp.shape[0]
+    L = _lib.lib()
+    if not (float_eval and FLOAT_CASCADE_EVAL and real == torch.float32 and B <= 2 and Ni <= L.fl_sos_response_apply_max_ni(S)):
+        H, cfg = _sos_forward_launch(bc, ac, gamma, nfft, real, float_eval)
+        return H, _mimo_launch(H.movedim(-1, 0), True, False, False, Xp), cfg
+    dev = bc.device
+    bin0, m_local = _bin0_arg(nfft)
+    _, M, Nx, K, xs_b, xs_n, _ = _bnk(Xp)
+    assert K == 1 and Nx == Ni and M == m_local
+    H = _empty_rows((No, Ni), m_local, torch.complex64, dev)
+    Y = _empty_planar((B, m_local, No), torch.complex64, dev)
+    _, _, _, _, ys_b, ys_m, _ = _bnk(Y)
+    with kernel_timer.span("sos_response"):
+        _lib.check(L.fl_sos_response_apply_c64(bc.data_ptr(), ac.data_ptr(), S, No, Ni, Xp.data_ptr(), xs_b, xs_n, B, float(gamma),
+                                               twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local, H.data_ptr(),
+                                               _pitch(m_local), Y.data_ptr(), ys_b, ys_m, _stream()), "sos_response_apply")
+    return H, Y, (float(gamma), nfft, S, No * Ni, bin0, m_local, real)
+
+
 def _sos_backward_outer_launch(gY, Xp, Hf, bc, ac, cfg, No, Ni):
     """part (nblk, 2, 3, S, C) with dL/dH[m][n] = sum_b gY[b][m] conj(X[b][n]) formed in the kernel"""
     gamma, nfft, S, C_, bin0, m_local, real = cfg
@@ -1541,9 +1565,10 @@ class _SosApply(torch.autograd.Function):
             raise ValueError("sos_response_apply: b and a must both be (3, n_sections, N_out, N_in)")
         bc, ac = b.contiguous(), a.contiguous()
         Xp = to_planar(X.resolve_conj())
-        H, ctx.cfg = _sos_forward_launch(bc, ac, gamma, nfft, real, not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
+        H, Y, ctx.cfg = _sos_apply_forward(bc, ac, Xp, gamma, nfft, real,
+                                           not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
         ctx.save_for_backward(bc, ac, H, Xp)
-        return _mimo_launch(H.movedim(-1, 0), True, False, False, Xp)
+        return Y
 
     @staticmethod
     def backward(ctx, gY):
@@ -1577,9 +1602,9 @@ class _GeqCascadeApply(torch.autograd.Function):
         _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), _geq_in_kind(xc, True, sig), nb, C_, consts.data_ptr(), b.data_ptr(),
                                               a.data_ptr(), _stream()), "geq_sections")
         Xp = to_planar(X.resolve_conj())
-        H, ctx.cfg = _sos_forward_launch(b, a, gamma, nfft, real, True)
+        H, Y, ctx.cfg = _sos_apply_forward(b, a, Xp, gamma, nfft, real, True)
         ctx.save_for_backward(xc, consts, b, a, H, Xp)
-        return _mimo_launch(H.movedim(-1, 0), True, False, False, Xp)
+        return Y
 
     @staticmethod
     def backward(ctx, gY):

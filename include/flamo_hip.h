@@ -267,6 +267,14 @@ int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_
                             int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
 int fl_sos_response_bwd_c128(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
                              int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream);
+/* A full (No, Ni) cascade applied to a signal with BX = 1 or 2 columns in one launch (float evaluation as
+ * fl_sos_response_f32eval_c64): G[m*Ni + j, f] (planes of pitch g_pitch, kept for the backward pass) and
+ * Y[b][m][f] = sum_j G[m][j][f] X[b][j][f]  (X planes b*xs_b + j*xs_n + f, Y planes b*ys_b + m*ys_m + f) -- dsp.py:922-924 over
+ * the cascade tail dsp.py:1520-1526 without the product's own pass over the response.  Ni <= fl_sos_response_apply_max_ni(S). */
+int fl_sos_response_apply_max_ni(int S);
+int fl_sos_response_apply_c64(const void* b, const void* a, int S, int No, int Ni, const void* X, long xs_b, long xs_n, int BX,
+                              double gamma, const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* Y, long ys_b,
+                              long ys_m, void* stream);
 /* fl_sos_response_bwd_c64 (mixed-precision route) when the response was applied to a signal with few columns,
  * Y[b,:,f] = H[f] X[b,:,f] (dsp.py:922-924): dL/dH[m][n][f] = sum_b gY[b][m][f] conj(X[b][n][f]) is formed inside the
  * kernel from the two signals (planes b*s_b + channel*s_n + f) instead of being read from an (M, No, Ni) tensor.
