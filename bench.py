@@ -24,6 +24,9 @@ fused pipeline's own count against the step time), `input_grad` (the same step w
 `secondary` (BASELINE configs[2..4] on one GPU: bin-solves/s, solve TFLOP/s), `device` (what rocminfo / a copy probe say)
 and `cpu_baseline` (the oracle's torch-CPU graph on the host cores).
 """
+import os as _os_env
+_os_env.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # see flamo_amd/__init__.py: must precede HIP runtime init
+
 import argparse
 import json
 import os

@@ -1,3 +1,6 @@
+import os as _os_env
+_os_env.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # see flamo_amd/__init__.py: must precede HIP runtime init
+
 import json
 import os
 import sys

@@ -863,3 +863,39 @@ def test_fdn_between_its_gains_as_one_operator(gpu, N):
             for k in (True, "launches"):
                 for a, b in zip(res[k][0], res[False][0]):
                     assert relerr(a, b) < tol, k
+
+
+def test_replayed_step_is_stable_under_eager_launches(gpu):
+    """A captured step (Shell(FFT -> Gain(16,1) -> Gain(1,16) -> iFFTAntiAlias), torch's own `sum` as the loss) replayed with a
+    tiny eager tensor created and filled between replays: loss and gradients stay bit-identical.  With ROCm's pre-built graph
+    packets the captured memset + reduction pair of `sum()` returned a different value after the first eager launch
+    (flamo_amd/__init__.py turns DEBUG_CLR_GRAPH_PACKET_CAPTURE off for that reason; tools/dbg/soak_ops.py, soak_fdn15.py)."""
+    import os
+    from collections import OrderedDict
+    from flamo_amd.graph import GraphedStep
+    from flamo_amd.processor import dsp, system
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+    torch.manual_seed(1)
+    nfft, N = 192000, 16
+    kw = dict(nfft=nfft, alias_decay_db=30.0, device=gpu, dtype=torch.float32)
+    ig = dsp.Gain(size=(N, 1), requires_grad=True, **kw)
+    og = dsp.Gain(size=(1, N), requires_grad=True, **kw)
+    model = system.Shell(system.Series(OrderedDict(input_gain=ig, output_gain=og)), dsp.FFT(nfft),
+                         dsp.iFFTAntiAlias(nfft, alias_decay_db=30.0, device=gpu))
+    x = torch.randn(1, nfft, 1, device=gpu)
+    c = torch.randn(1, nfft, 1, device=gpu)
+    params = [ig.param, og.param]
+    gs = GraphedStep(lambda xx: (model(xx) * c).sum(), (x,), params, warmup=2)
+    out0 = gs.replay().clone()
+    g0 = [p.grad.clone() for p in params]
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = (model(x) * c).sum()
+    assert relerr(out0, want) < 1e-5
+    for i in range(6):
+        out = gs.replay()
+        torch.cuda.synchronize()
+        junk = torch.full((1,), float(i), device=gpu)
+        del junk
+        assert torch.equal(out, out0), (i, out.item(), out0.item())
+        assert all(torch.equal(p.grad, g) for p, g in zip(params, g0))

@@ -7,6 +7,9 @@ Prints bin-solves/s (B*M / time) for float32 and float64.   python tools/bench_f
 --workload config5: BASELINE configs[4] on one GPU -- the active-acoustics structure:
 FFTAntiAlias(384000, 30 dB) -> Series(GEQ((32,32)), Recursion(fF=Series(Delay((32,32), isint), parallelGain(32)),
 fB=Matrix(32,32, orthogonal))) -> iFFTAntiAlias, impulse-like input (1, 384000, 32), gradients for GEQ, gain, matrix."""
+import os as _os_env
+_os_env.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # see flamo_amd/__init__.py: must precede HIP runtime init
+
 import argparse
 import json
 import os

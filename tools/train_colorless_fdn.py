@@ -14,6 +14,9 @@ N GPUs:    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --maste
            matrices and solves for its own bins, ONE all-gather reassembles the (B, M, 1) spectrum in front of the
            output layer / criteria, and one small all-reduce sums the replicated parameters' gradients.
 Rank 0 prints one JSON line (bin-solves/s = B*M*steps / time, the loss trajectory's ends)."""
+import os as _os_env
+_os_env.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # see flamo_amd/__init__.py: must precede HIP runtime init
+
 import argparse
 import json
 import math
