@@ -17,7 +17,20 @@ import os as _os
 # measurably slower without the pre-built packets (0.541 vs 0.545 ms at config 2, 0.3725 vs 0.3709 ms at config 3), so the
 # switch is turned off unless the user has set it; it has to be in the environment before the HIP runtime initialises,
 # i.e. before the first CUDA call of the process (importing this package before touching the GPU is enough).
+_user_setting = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
 _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
+
+def _graph_packets_off() -> bool:
+    """True when the switch above can be relied on: set by the user, or set here before the HIP runtime came up"""
+    return _user_setting == "0" or (_user_setting is None and not _RUNTIME_WAS_UP)
+
+
+try:
+    import torch as _torch
+    _RUNTIME_WAS_UP = bool(_torch.cuda.is_initialized())
+except Exception:       # pragma: no cover
+    _RUNTIME_WAS_UP = False
 
 from . import _lib, functional, ops, utils  # noqa: F401
 from .processor import dsp, system  # noqa: F401

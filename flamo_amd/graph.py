@@ -22,6 +22,14 @@ import torch
 class GraphedStep:
     def __init__(self, fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor],
                  params: Iterable[torch.nn.Parameter] = (), warmup: int = 3):
+        import flamo_amd
+        if not flamo_amd._graph_packets_off():
+            import warnings
+            warnings.warn("flamo_amd was imported after the HIP runtime had been initialised (or DEBUG_CLR_GRAPH_PACKET_CAPTURE is "
+                          "set to something other than 0): with ROCm's pre-built graph packets, torch reductions captured behind "
+                          "this library's kernels have returned wrong values after eager launches between replays "
+                          "(DESIGN.md, section 4.5).  Export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before starting the process.",
+                          RuntimeWarning, stacklevel=2)
         self.params = [p for p in params if p.requires_grad]
         self.static_inputs = [t.clone() for t in example_inputs]
         self._fn = fn
