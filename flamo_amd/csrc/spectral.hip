@@ -20,54 +20,9 @@
 // Against the layered route (layout conversion, two FFT passes, product, two inverse passes) the (B, M, N)
 // spectrum is never written and re-read between the transforms and the product: 6 passes over the data
 // instead of 11.  The same three kernels run the backward pass (irfft' = weighted rfft, rfft' = weighted irfft).
-#define FL_PACKED_COMPLEX 1
-#include "common.h"
-#include "regfft.h"
-#include <type_traits>
+#include "spectral_common.h"
 
 namespace fl {
-
-typedef cx<float> cf;
-
-// lane <-> lane^1 exchange of one dword (DPP quad_perm [1,0,3,2])
-__device__ __forceinline__ float swap1(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-}
-
-struct ColsArgs {
-    const float* x;       // forward: real (Bn, t_len, G)
-    float* y;             // inverse: real (Bn, t_len, G)
-    cf* S;                // (Bn, L1, L2, G)
-    const cf* W;          // W_n^j, j < n
-    int n, L, L1, L2, G, cgs /* log2 CG */, CT, nct /* L2 / CT */, ngt /* G / CG */;
-    int t_len, t_lim;
-    float scale;
-    double env_log2;
-};
-
-// Global accesses as (workgroup-uniform base pointer) + (32-bit byte offset per lane): the address then costs one
-// VGPR per access (scalar base + vector offset form) instead of a 64-bit pair -- with 16..50 accesses in flight per
-// thread that is a wavefront per SIMD.  Every array addressed this way spans < 4 GB per batch item.
-template <typename P>
-__device__ __forceinline__ P& at(P* base, unsigned byte_off) {
-    return *reinterpret_cast<P*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(base)) + byte_off);
-}
-
-// streaming data (read once / written once): non-temporal, so that it does not evict the response slices the batch
-// items of a row pair share in the XCD's L2
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ cf ld_nt(const cf* base, unsigned byte_off) {
-    const v2f q = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(base) + byte_off));
-    return cf(q.x, q.y);
-}
-__device__ __forceinline__ void st_nt(cf* base, unsigned byte_off, cf v) {
-    v2f q;
-    q.x = v.x;
-    q.y = v.y;
-    __builtin_nontemporal_store(q, reinterpret_cast<v2f*>(reinterpret_cast<char*>(base) + byte_off));
-}
-
-__device__ __forceinline__ float env_at(double env_log2, int t) { return exp2f((float)(env_log2 * (double)t)); }
 
 // ---------------------------------------------------------------- K1: forward column pass
 // Workgroup = (batch item, tile of CT columns, tile of CG channels): VT = CT*CG "virtual columns" v = cl*CG + gl,
@@ -264,25 +219,6 @@ struct MidArgs {
     int dbg_hfake;        // tuning: every bin reads the first 64 bins' response (cache-resident) -- isolates the fetch cost
     long long* dbg_times; // tuning: per-workgroup cycle stamps at the phase boundaries (8 per workgroup), or null
 };
-
-// bin pair (k, L-k) number p of primary row r: where the partner sits (slot, column); false when p owns no pair
-__device__ __forceinline__ bool pair_of(int r, bool selfm, int p, int LEN, int& slotB, int& colB, bool& dc) {
-    dc = false;
-    if (r == 0) {
-        if (2 * p > LEN) return false;
-        dc = p == 0;
-        slotB = 0;
-        colB = (2 * p == LEN || p == 0) ? p : LEN - p;
-    } else if (selfm) {
-        if (2 * p >= LEN) return false;
-        slotB = 0;
-        colB = LEN - 1 - p;
-    } else {
-        slotB = 1;
-        colB = LEN - 1 - p;
-    }
-    return true;
-}
 
 // BG batch items per workgroup (256*BG threads): a response row fetched for a bin pair is applied to the BG spectra in
 // registers, so the response's trips through the TA/L2 shrink by BG (at one item per workgroup they are 8x the
@@ -710,7 +646,7 @@ static const Split* split_of(int len) {
     return nullptr;
 }
 
-static int spec_plan(int nfft, int& L1, int& L2) {
+int spec_plan(int nfft, int& L1, int& L2) {
     // (L1, L2): column length x row length; both must be fast-split lengths and L2 >= L1 so a row pair of all channels
     // stays small
     static const int pairs[][2] = {{200, 240}, {300, 320}, {400, 480}};

@@ -1,0 +1,77 @@
+// Device helpers shared by the fused Shell pipeline's kernels (spectral.hip, specwalk.hip); gfx950 only.
+#pragma once
+#ifndef FL_PACKED_COMPLEX
+#define FL_PACKED_COMPLEX 1
+#endif
+#include "common.h"
+#include "regfft.h"
+#include <type_traits>
+
+namespace fl {
+
+typedef cx<float> cf;
+
+// lane <-> lane^1 exchange of one dword (DPP quad_perm [1,0,3,2])
+__device__ __forceinline__ float swap1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+
+struct ColsArgs {
+    const float* x;       // forward: real (Bn, t_len, G)
+    float* y;             // inverse: real (Bn, t_len, G)
+    cf* S;                // (Bn, L1, L2, G)
+    const cf* W;          // W_n^j, j < n
+    int n, L, L1, L2, G, cgs /* log2 CG */, CT, nct /* L2 / CT */, ngt /* G / CG */;
+    int t_len, t_lim;
+    float scale;
+    double env_log2;
+};
+
+// Global accesses as (workgroup-uniform base pointer) + (32-bit byte offset per lane): the address then costs one
+// VGPR per access (scalar base + vector offset form) instead of a 64-bit pair -- with 16..50 accesses in flight per
+// thread that is a wavefront per SIMD.  Every array addressed this way spans < 4 GB per batch item.
+template <typename P>
+__device__ __forceinline__ P& at(P* base, unsigned byte_off) {
+    return *reinterpret_cast<P*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<P>::type*>(base)) + byte_off);
+}
+
+// streaming data (read once / written once): non-temporal, so that it does not evict the response slices the batch
+// items of a row pair share in the XCD's L2
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf ld_nt(const cf* base, unsigned byte_off) {
+    const v2f q = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(base) + byte_off));
+    return cf(q.x, q.y);
+}
+__device__ __forceinline__ void st_nt(cf* base, unsigned byte_off, cf v) {
+    v2f q;
+    q.x = v.x;
+    q.y = v.y;
+    __builtin_nontemporal_store(q, reinterpret_cast<v2f*>(reinterpret_cast<char*>(base) + byte_off));
+}
+
+__device__ __forceinline__ float env_at(double env_log2, int t) { return exp2f((float)(env_log2 * (double)t)); }
+
+// bin pair (k, L-k) number p of primary row r: where the partner sits (slot, column); false when p owns no pair
+__device__ __forceinline__ bool pair_of(int r, bool selfm, int p, int LEN, int& slotB, int& colB, bool& dc) {
+    dc = false;
+    if (r == 0) {
+        if (2 * p > LEN) return false;
+        dc = p == 0;
+        slotB = 0;
+        colB = (2 * p == LEN || p == 0) ? p : LEN - p;
+    } else if (selfm) {
+        if (2 * p >= LEN) return false;
+        slotB = 0;
+        colB = LEN - 1 - p;
+    } else {
+        slotB = 1;
+        colB = LEN - 1 - p;
+    }
+    return true;
+}
+
+
+// the fused plan of a transform length (spectral.hip)
+int spec_plan(int nfft, int& L1, int& L2);
+
+}  // namespace fl

@@ -1,0 +1,738 @@
+// Row kernels of the fused Shell pipeline that WALK THE BATCH (gfx950, MI355X).
+//
+// spectral.hip's spec_mid gives one workgroup one (row pair, batch item): the 2*L2*NO*NI response values of the row
+// pair (245 KB at 8x8 channels, L2 = 240) then cross the L2 -> L1 path once per batch item -- 8x the signal's bytes,
+// the largest single cost of that kernel.  Here ONE workgroup per CU is resident for the whole launch and
+// owns a contiguous range of (row pair, batch item) units; the response of its current row pair sits in REGISTERS
+// (thread (pair p, ms) holds H[2 bins][NO/MS][NI]: 128 VGPRs at 8x8 with MS = 2 -- half of the CU's register file holds
+// the slice) and is fetched once per row pair and workgroup.  A round takes BG = 2 units through the five phases of
+// spec_mid (row FFTs, split step, per-bin product, Hermitian pre-step, inverse row FFTs); the scratch rows of the NEXT
+// round are requested right after the current round's have been consumed and stay in flight under phases 2-5, so the
+// HBM round trip that is 20 % of a spec_mid workgroup's life is hidden.  Two LDS buffers (123 KB) alternate between
+// the phases, which leaves four barriers per round and none between rounds.
+//
+//   forward  (spec_mid_walk):   S (B, L1, L2, NI) -> Y[f] = op(H[f]) X[f] -> S2 (B, L1, L2, NO);  the spectrum is NOT
+//                               stored: the backward pass re-derives it from S (kept instead: same bytes, no extra pass)
+//   backward (spec_gradh_walk): Sg, Sx -> dL/dH[m][n][f] = sum_b gY[b,m,f] conj(X[b,n,f]) accumulated in the same
+//                               registers over the workgroup's batch slice; the row FFTs + split step of both operands
+//                               happen in the kernel, so neither spectrum ever exists in HBM and the separate
+//                               mimo_gradh pass (1.47x over-fetch) is gone.  Batch slices of a row pair are summed from
+//                               per-slice partial planes (deterministic: no atomics).
+#include "spectral_common.h"
+
+namespace fl {
+
+struct WalkArgs {
+    const cf* S;          // (Bn, L1, L2, NI)
+    cf* S2;               // (Bn, L1, L2, NO)
+    const cf* H;          // H[m*hs_m + n*hs_n + i], row-major bin order
+    long hs_m, hs_n;
+    int conj_h;
+    const cf* W;
+    int n, L, L1, L2, Bn;
+    float spec_scale;     // scale of the forward transform
+    int spec_interior2;   // double the interior bins of the spectrum (irfft backward)
+    int pre_half;         // halve the interior bins in front of the inverse transform (rfft backward)
+    long long* dbg_times; // tuning: per-workgroup cycle stamps, or null
+};
+
+// LDS-DMA of 16 bytes per lane: 64 lanes' pieces land at lds_byte_addr + 16*lane (wave-uniform base in M0), straight from
+// the per-lane global address -- no VGPR round trip.  Written as inline assembly ON PURPOSE: issued through the builtin,
+// the compiler orders every later LDS read of the kernel behind the transfer (it cannot tell the staging buffer from the
+// row buffers: s_waitcnt vmcnt(0) in front of the next ds_read), which is exactly the overlap this kernel exists for.
+// The kernel waits for its transfers itself (vmcnt(0) in front of the barrier that precedes their first read).
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+// workgroup barrier that orders LDS traffic only (a plain __syncthreads() also drains the vector-memory queue: the
+// prefetch in flight and the previous unit's stores)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// a copy of a per-lane value the optimiser cannot see through: what is derived from it is recomputed where it is used
+// instead of being hoisted out of the unit loop and kept in registers across all five phases (the response slice takes
+// half of the register budget; per-thread LDS addresses of five phases would take a fifth of the rest)
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // s_waitcnt vmcnt(0)
+
+// ---------------------------------------------------------------- packed complex pieces (two floats per lane and instruction)
+// Written out with 2-vectors: every line below is ONE v_pk_* instruction with the swaps / sign flips of complex arithmetic
+// as operand selectors.  The kernels of this file are bound by instruction issue (a wavefront issues one instruction per
+// four cycles whatever it is), so the count is what is optimised.
+__device__ __forceinline__ f2 cj(f2 a) { return f2{a.x, -a.y}; }
+__device__ __forceinline__ f2 rot_i(f2 a) { return f2{-a.y, a.x}; }       // i a
+__device__ __forceinline__ f2 pfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 cmul2(f2 a, f2 b) { return pfma(f2{a.y, a.y}, rot_i(b), f2{a.x, a.x} * b); }      // a b
+// acc + a b, with ib = i b at hand (shared by every a that multiplies this b)
+__device__ __forceinline__ f2 cmac2(f2 acc, f2 a, f2 b, f2 ib) { return pfma(f2{a.y, a.y}, ib, pfma(f2{a.x, a.x}, b, acc)); }
+
+// Real-FFT split step of the bin pair (k, L-k):  zk = Z[k], zm = Z[L-k] of the packed half-length transform, wk = W_n^k.
+//   X[k] = sc (P - i t),  X[L-k] = sc conj(P + i t),  P = zk + conj(zm),  t = wk (zk - conj(zm))
+// For the pair (0, L) pass zm = zk, wk = 1: the same lines give X[0] = 2 sc (re + im), X[L] = 2 sc (re - im).
+// The constant factor is taken as the two vectors iw = i wk and niw = i iw = -wk, the variable one by broadcast halves: no
+// rotation of a variable (a swap AND a sign flip of one half is not something the compiler folds into operand selectors).
+__device__ __forceinline__ f2 cmulc(f2 b, f2 a, f2 ia) { return pfma(f2{b.y, b.y}, ia, f2{b.x, b.x} * a); }      // a b, ia = i a
+__device__ __forceinline__ void split_pair(f2 zk, f2 zm, f2 iw, f2 niw, f2 sck, f2 scm, f2& xk, f2& xm) {
+    const f2 Pp = f2{zk.x + zm.x, zk.y - zm.y}, D = f2{zk.x - zm.x, zk.y + zm.y};
+    const f2 it = cmulc(D, iw, niw);            // i wk D
+    xk = sck * (Pp - it);                       // sck = (sc, sc)
+    xm = scm * (Pp + it);                       // scm = (sc, -sc): the conjugate
+}
+// Hermitian pre-step of the inverse real FFT for the pair (k, L-k): from Y[k], Y[L-k] to Zf[k], Zf[L-k];
+// cwk = conj(W_n^k).  For the pair (0, L) pass yk, ym with zeroed imaginary parts (cwk = 1 there).
+__device__ __forceinline__ void pre_pair(f2 yk, f2 ym, f2 icw, f2 nicw, f2& zk, f2& zm) {      // icw = i conj(wk), nicw = -conj(wk)
+    const f2 s_ = f2{yk.x + ym.x, yk.y - ym.y}, d_ = f2{yk.x - ym.x, yk.y + ym.y};
+    const f2 t_ = cmulc(d_, icw, nicw);         // i conj(wk) d
+    zk = s_ + t_;
+    zm = f2{s_.x - t_.x, t_.y - s_.y};          // conj(s - t)
+}
+
+// ---------------------------------------------------------------- forward: rows + split + product + pre-step + inverse rows
+// One unit = rows r and L1 - r of all channels of one batch item.  512 threads in two groups of four wavefronts:
+//   step A  all:  P3(u)   split step, product with the registers' response, Hermitian pre-step        Y  -> XI
+//   step B  G0:   P4(u)   first stage of the inverse row FFTs, in place in XI
+//           G1:   P1(u+1) first stage of the NEXT unit's forward row FFTs                           stage -> XF
+//   step C  G0:   P5(u)   second stage, twiddle, store                                               XI -> S2
+//           G1:   P2(u+1) second stage of the next unit's forward rows                               XF -> Y
+// with one barrier behind each step; the scratch rows of unit u+2 are requested by LDS-DMA at the start of step C (the
+// staging buffer is free once P1(u+1) has read it) and waited for at the end of step A.  Every SIMD always has one
+// wavefront of each group: the FFT stages (work for 240..256 threads only) of two different units run side by side
+// instead of leaving half of the wavefronts idle.  The pipeline drains at a row-pair boundary (new response).
+// Row pitch of the LDS row buffers, in complex elements: = 4 (mod 32), so that the FFT stages' lane patterns (8 channels x 4
+// consecutive columns, or 8 channels x 4 column groups 15 apart) fall on 32 different 8-byte banks
+constexpr int walk_pitch(int len) { return len + ((4 - len % 32) + 32) % 32; }
+
+template <int A, int B, int NI, int NO, int OCC, bool DBG = false>
+__global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LEN = A * B, LENP = walk_pitch(LEN), NCH = NI > NO ? NI : NO, NW = 8, MS = 2;
+    constexpr int MO = NO / MS;                    // output channels per thread
+    constexpr int UB = 2 * NCH * LENP;             // one row buffer: [2][NCH][LENP]
+    constexpr int SB = 2 * LEN * NI;               // staging: [2][LEN][NI], the scratch rows as they lie in memory
+    constexpr int PPR = LEN * NI * 8 / 1024;       // 1-KB DMA pieces per row
+    constexpr int NI1 = 2 * B * NI, NI4 = 2 * B * NO, NI2 = 2 * NI * A, NI5 = 2 * NO * A;
+    static_assert(LEN <= 256, "one bin pair per thread");
+    static_assert(NO % MS == 0, "output channels split over two threads");
+    static_assert((LEN * NI * 8) % 1024 == 0, "a scratch row is a whole number of 1-KB DMA pieces");
+    static_assert(NI1 <= 256 && NI2 <= 256 && NI4 <= 256 && NI5 <= 256, "an FFT stage of one unit fits one group");
+    cf* XF = reinterpret_cast<cf*>(smem);
+    cf* Yb = XF + UB;
+    cf* XI = Yb + UB;
+    cf* stage = XI + UB;                           // [SB]
+    cf* tw = stage + SB;                           // W_LEN^m
+    cf* ws = tw + LEN;                             // W_n^(L1*k2)
+    cf* wtab = ws + LEN;                           // [2][LEN]: conj(W_L^(row * c)) of the current row pair
+    cf* dummy = wtab + 2 * LEN;                    // [64]: where lanes without a partner bin store
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int grp = wave >> 2;                     // 0: inverse side, 1: forward side; also ms of the product
+    const int P = a.L1 / 2 + 1;
+    const int Utot = P * a.Bn;
+    // XCD-aware order: logically consecutive workgroups (which share a row pair's response) sit on one XCD (block q runs
+    // on XCD q % 8), so the slice comes from HBM once and from that L2 afterwards
+    const int G = gridDim.x;
+    const int w = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    int u = (int)((long)Utot * w / G);
+    const int u_hi = (int)((long)Utot * (w + 1) / G);
+    if (u >= u_hi) return;
+    const size_t bstride_i = (size_t)a.L1 * a.L2 * NI, bstride_o = (size_t)a.L1 * a.L2 * NO;
+    const unsigned stage_lds = lds_addr_of(stage);
+
+    // the scratch rows of unit uu -> staging: piece j = wave + NW*i is 1 KB of row (j / PPR)
+    auto prefetch = [&](int uu) {
+        const int r = uu / a.Bn, b = uu - r * a.Bn;
+        const int rm = (a.L1 - r) % a.L1;
+        const int npc = (rm == r ? 1 : 2) * PPR;
+        const cf* Sb = a.S + (size_t)b * bstride_i;
+#pragma unroll
+        for (int i = 0; i < (2 * PPR + NW - 1) / NW; ++i) {
+            const int j = wave + NW * i;
+            if (j < npc) {
+                const int slot = j >= PPR, jj = j - slot * PPR;
+                const cf* src = Sb + (size_t)(slot ? rm : r) * (a.L2 * NI) + jj * 128 + lane * 2;
+                dma16(src, stage_lds + (unsigned)((slot * (LEN * NI) + jj * 128) * 8));
+            }
+        }
+    };
+    // ---- the FFT stages, each for the 256 threads of one group
+    auto P1 = [&](bool selfm) {          // first stage of the forward rows, staging -> XF.  item = (slot, tb, n), n fastest
+        const int item = opaque(tid) & 255;
+        const int nn = item % NI, tb = (item / NI) % B, slot = item / (NI * B);
+        if (item >= NI1 || (slot && selfm)) return;
+        cf v[A], t[A];
+        const cf* sp = stage + slot * (LEN * NI) + tb * NI + nn;
+#pragma unroll
+        for (int ta = 0; ta < A; ++ta) v[ta] = sp[ta * (B * NI)];
+        // the twiddles are read with the data: behind the first LDS store the compiler cannot move a read any more (it
+        // cannot tell the table from the row buffers), and 15 dependent read -> multiply -> store round trips would follow
+#pragma unroll
+        for (int ka = 1; ka < A; ++ka) t[ka] = tw[ka * tb];
+        RegFFT<float, A, false>::run(v);
+        cf* uu = XF + (slot * NCH + nn) * LENP + tb;
+        uu[0] = v[0];
+#pragma unroll
+        for (int ka = 1; ka < A; ++ka) uu[ka * B] = v[ka] * t[ka];
+    };
+    auto P2 = [&](bool selfm) {          // second stage XF -> Y, natural order.  item = (n fastest, ka, slot)
+        const int item = opaque(tid) & 255;
+        const int nn = item % NI, ka = (item / NI) % A, slot = item / (NI * A);
+        if (item >= NI2 || (slot && selfm)) return;
+        cf v[B];
+        const cf* xr = XF + (slot * NCH + nn) * LENP + ka * B;
+#pragma unroll
+        for (int tb = 0; tb < B; ++tb) v[tb] = xr[tb];
+        RegFFT<float, B, false>::run(v);
+        cf* yr = Yb + (slot * NCH + nn) * LENP + ka;
+#pragma unroll
+        for (int kb = 0; kb < B; ++kb) yr[A * kb] = v[kb];
+    };
+    auto P4 = [&](bool selfm) {          // first stage of the inverse rows, in place in XI
+        const int item = opaque(tid) & 255;
+        const int m = item % NO, tb = (item / NO) % B, slot = item / (NO * B);
+        if (item >= NI4 || (slot && selfm)) return;
+        cf* uu = XI + (slot * NCH + m) * LENP + tb;
+        cf v[A], t[A];
+#pragma unroll
+        for (int ta = 0; ta < A; ++ta) v[ta] = uu[ta * B];
+#pragma unroll
+        for (int ka = 1; ka < A; ++ka) t[ka] = tw[ka * tb];
+        RegFFT<float, A, true>::run(v);
+        uu[0] = v[0];
+#pragma unroll
+        for (int ka = 1; ka < A; ++ka) uu[ka * B] = mulc(v[ka], t[ka]);
+    };
+    auto P5 = [&](bool selfm, int r, int rm, int b) {     // second stage, twiddle conj(W_L^(row*c)), store
+        // item = (m fastest, ka, slot): the lanes of a store cover runs of (c = ka + A kb, m): 512 contiguous bytes per kb
+        const int item = opaque(tid) & 255;
+        const int m = item % NO, ka = (item / NO) % A, slot = item / (NO * A);
+        if (item >= NI5 || (slot && selfm)) return;
+        cf v[B], t[B];
+        const cf* uu = XI + (slot * NCH + m) * LENP + ka * B;
+        const cf* wt = wtab + slot * LEN + ka;
+#pragma unroll
+        for (int tb = 0; tb < B; ++tb) v[tb] = uu[tb];
+#pragma unroll
+        for (int kb = 0; kb < B; ++kb) t[kb] = wt[A * kb];
+        RegFFT<float, B, true>::run(v);
+        cf* S2b = a.S2 + (size_t)b * bstride_o;
+        const unsigned dst0 = (unsigned)(slot ? rm : r) * (unsigned)a.L2 * NO + (unsigned)(ka * NO + m);
+#pragma unroll
+        for (int kb = 0; kb < B; ++kb) st_nt(S2b, 8u * (dst0 + (unsigned)(A * kb * NO)), v[kb] * t[kb]);
+    };
+
+    prefetch(u);
+    for (int j = tid; j < LEN; j += 512) {         // contiguous copies behind the master table (fl_spec_aux_fill_f32)
+        tw[j] = a.W[a.n + a.L1 + j];
+        ws[j] = a.W[a.n + a.L1 + a.L2 + j];
+    }
+    const float hs = 0.5f * a.spec_scale, wi = a.spec_interior2 ? 2.f : 1.f;
+    const float ph = a.pre_half ? 0.5f : 1.f;
+    long long t_ph[4] = {0, 0, 0, 0}, t_last = 0;
+    if (DBG) t_last = clock64();
+    const long long t_begin = t_last;
+#define FL_STAMP(i)                         \
+    if (DBG) {                              \
+        const long long t_now = clock64();  \
+        t_ph[i] += t_now - t_last;          \
+        t_last = t_now;                     \
+    }
+    wait_vm0();                                     // the first unit's rows have landed, the tables are visible
+    lds_barrier();
+
+    while (u < u_hi) {
+        // ================= a row pair: its response into registers, its tables into LDS, the pipeline filled
+        const int r = u / a.Bn;
+        const int rm = (a.L1 - r) % a.L1;
+        const bool selfm = rm == r;
+        const int seg_end = (r + 1) * a.Bn < u_hi ? (r + 1) * a.Bn : u_hi;
+        // the product's thread: bin pair p of the row pair, output channels [grp MO, (grp + 1) MO)
+        const int p = tid & 255;
+        int slotB = 0, colB = 0;
+        bool dc = false;
+        const bool valid = p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
+        const bool twin = valid && !dc && !(slotB == 0 && colB == p);    // the partner bin has a place of its own in the rows
+        const int pc = p < LEN ? p : 0;
+        f2 h[2][MO][NI];
+        {
+            const unsigned ik = (unsigned)r * LEN + (unsigned)pc;
+            unsigned im = dc ? (unsigned)a.L : (unsigned)(slotB ? rm : r) * LEN + colB;
+            if (!valid) im = ik;
+#pragma unroll
+            for (int m2 = 0; m2 < MO; ++m2) {
+                // one base + 32-bit lane offsets stepped from plane to plane (a scalar base or offset per plane is loop
+                // invariant: the compiler would pin one or two SGPRs per plane for the whole kernel)
+                unsigned ok = 8u * ((unsigned)(grp * MO + m2) * (unsigned)a.hs_m + ik), om = ok + 8u * (im - ik);
+                const unsigned step = 8u * (unsigned)a.hs_n;
+#pragma unroll
+                for (int nn = 0; nn < NI; ++nn) {
+                    h[0][m2][nn] = v2(at(a.H, ok));
+                    h[1][m2][nn] = v2(at(a.H, om));
+                    ok += step;
+                    om += step;
+                }
+            }
+        }
+        // conj(W_L^(row c)) = conj(W_n^(2 row c)), 2 row c < n: row r from group 0's threads, row L1 - r from group 1's
+        // (the previous pair's last P5 read the table in its last step, a barrier ago)
+        const cf wt_mine = conj(a.W[2 * (grp ? rm : r) * pc]);
+        const f2 wk = v2(a.W[r] * ws[pc]);                      // W_n^k of the pair's first bin, k = r + L1 p
+        const f2 iw = rot_i(wk), niw = f2{-wk.x, -wk.y}, icw = f2{wk.y, wk.x}, nicw = f2{-wk.x, wk.y};
+        const float sc = dc ? hs : hs * wi;                     // the pair (0, L) is not interior
+        const f2 sck = f2{sc, sc}, scm = f2{sc, -sc};
+        const f2 phv = dc ? f2{1.f, 0.f} : f2{ph, ph};          // ... and only its real parts enter the inverse transform
+        const int yk_o = pc, ym_o = slotB * NCH * LENP + colB;  // where the pair's bins sit in a row buffer
+        cf* zm_dst = twin ? XI + ym_o : dummy + lane;           // lanes without a partner bin of their own store aside
+        if (grp == 1) P1(selfm);
+        if (p < LEN) wtab[grp * LEN + p] = wt_mine;
+        lds_barrier();
+        if (grp == 1) P2(selfm);
+        if (a.conj_h) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int m2 = 0; m2 < MO; ++m2)
+#pragma unroll
+                    for (int nn = 0; nn < NI; ++nn) h[e][m2][nn].y = -h[e][m2][nn].y;
+        }
+        // every load above has landed: the compiler's own waits end here, outside the unit loop.  The next unit's rows are
+        // requested only now (the staging buffer has been free since the barrier above): waiting for the response must
+        // not mean waiting for them; they have the whole of step A to arrive
+        wait_vm0();
+        if (u + 1 < u_hi) prefetch(u + 1);
+        lds_barrier();
+        FL_STAMP(0)
+
+#pragma unroll 1
+        for (; u < seg_end; ++u) {
+            const bool next = u + 1 < seg_end;      // the forward side works on the next unit of this row pair
+            // ---- step A / P3: split step, product, Hermitian pre-step: Y -> XI
+            // (the response registers are made opaque once per unit: whatever the product derives from them -- the broadcast
+            // halves a packed multiply takes as operand selectors for free -- is then formed here, per use, instead of being
+            // hoisted out of the unit loop as a second, twice as large, copy of the slice)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int m2 = 0; m2 < MO; ++m2)
+#pragma unroll
+                    for (int nn = 0; nn < NI; ++nn) asm volatile("" : "+v"(h[e][m2][nn]));
+            if (valid) {
+                const cf* yk_p = Yb + yk_o;
+                const cf* ym_p = Yb + ym_o;
+                f2 xk[NI], xm[NI];
+#pragma unroll
+                for (int nn = 0; nn < NI; ++nn) split_pair(v2(yk_p[nn * LENP]), v2(ym_p[nn * LENP]), iw, niw, sck, scm, xk[nn], xm[nn]);
+                cf* zk_p = XI + yk_o + grp * MO * LENP;
+                cf* zm_p = zm_dst + (twin ? grp * MO * LENP : 0);
+#pragma unroll
+                for (int m2 = 0; m2 < MO; ++m2) {
+                    // sum_n h x = sum_n Re(h) x + i sum_n Im(h) x: two plain packed chains per bin, one rotation at the end
+                    f2 ka_ = {0.f, 0.f}, kb_ = {0.f, 0.f}, ma_ = {0.f, 0.f}, mb_ = {0.f, 0.f};
+#pragma unroll
+                    for (int nn = 0; nn < NI; ++nn) {
+                        ka_ = pfma(f2{h[0][m2][nn].x, h[0][m2][nn].x}, xk[nn], ka_);
+                        kb_ = pfma(f2{h[0][m2][nn].y, h[0][m2][nn].y}, xk[nn], kb_);
+                        ma_ = pfma(f2{h[1][m2][nn].x, h[1][m2][nn].x}, xm[nn], ma_);
+                        mb_ = pfma(f2{h[1][m2][nn].y, h[1][m2][nn].y}, xm[nn], mb_);
+                    }
+                    const f2 yk = f2{ka_.x - kb_.y, ka_.y + kb_.x}, ym = f2{ma_.x - mb_.y, ma_.y + mb_.x};
+                    f2 zk, zm;
+                    pre_pair(phv * yk, phv * ym, icw, nicw, zk, zm);
+                    zk_p[m2 * LENP] = c2(zk);
+                    zm_p[twin ? m2 * LENP : 0] = c2(zm);
+                }
+            }
+            wait_vm0();                              // the next unit's rows have landed before anyone passes this barrier
+            lds_barrier();
+            FL_STAMP(1)
+            // ---- step B
+            if (grp == 0) P4(selfm);
+            else if (next) P1(selfm);
+            lds_barrier();
+            FL_STAMP(2)
+            // ---- step C
+            if (next && u + 2 < u_hi) prefetch(u + 2);
+            if (grp == 0) P5(selfm, r, rm, u - r * a.Bn);
+            else if (next) P2(selfm);
+            lds_barrier();
+            FL_STAMP(3)
+        }
+    }
+    if (DBG && a.dbg_times && tid == 0) {
+        long long* o = a.dbg_times + (size_t)blockIdx.x * 8;
+        o[0] = t_begin;
+        o[1] = clock64();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[2 + i] = t_ph[i];
+    }
+#undef FL_STAMP
+}
+
+// ---------------------------------------------------------------- backward: dL/dH accumulated over a batch slice
+// dH[m][n][f] = sum_b gY[b,m,f] conj(X[b,n,f]),  gY = weighted spectrum of the rows in Sg (K1 of the output's gradient),
+// X = spectrum of the rows in Sx (K1 of the input, kept from the forward pass).  Workgroup (row pair r, batch slice s) walks
+// its items; thread (pair p, ms) keeps dH[2 bins][NO/MS][NI] in registers and writes it once, into partial plane set s.
+struct GradhArgs {
+    const cf* Sg;         // (Bn, L1, L2, NO)
+    const cf* Sx;         // (Bn, L1, L2, NI)
+    cf* dH;               // dH[s*ds_s + m*ds_m + n*ds_n + i], row-major bin order, s < NS
+    long ds_s, ds_m, ds_n;
+    const cf* W;
+    int n, L, L1, L2, Bn, NS;
+    float scale_g;        // scale of the gradient's forward transform (the inverse transform's scale)
+    int interior2_g;      // double its interior bins (irfft backward)
+    float scale_x;        // scale of the input's forward transform
+};
+
+template <int A, int B, int NI, int NO, int MS, int OCC>
+__global__ void __launch_bounds__(256 * MS, OCC) spec_gradh_walk(GradhArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LEN = A * B, LENP = LEN | 1, NC = NI + NO, NT = 256 * MS, NW = NT / 64;
+    constexpr int NPP = (LEN + 255) / 256;
+    constexpr int MO = NO / MS;
+    constexpr int UB = 2 * NC * LENP;              // row buffer: [2 slots][NO gradient rows, then NI input rows][LENP]
+    constexpr int SBG = 2 * LEN * NO, SBX = 2 * LEN * NI;     // staging: the gradient's two rows, then the input's
+    constexpr int PPRG = LEN * NO * 8 / 1024, PPRX = LEN * NI * 8 / 1024;
+    constexpr int NI1 = 2 * B * NC, NI2 = 2 * NC * A;
+    static_assert(NO % MS == 0, "output channels split over MS threads");
+    static_assert((LEN * NI * 8) % 1024 == 0 && (LEN * NO * 8) % 1024 == 0, "a scratch row is a whole number of 1-KB DMA pieces");
+    cf* U = reinterpret_cast<cf*>(smem);
+    cf* stage = U + UB;                            // [SBG + SBX]
+    cf* tw = stage + SBG + SBX;
+    cf* ws = tw + LEN;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int P = a.L1 / 2 + 1;
+    // XCD-aware order: the slices of a row pair on one XCD (nothing is shared but the twiddles; it keeps a pair's partial
+    // planes' lines in one L2)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int r = (q / a.NS) * 8 + xcd, sl = q % a.NS;
+    if (r >= P) return;
+    const int rm = (a.L1 - r) % a.L1;
+    const bool selfm = rm == r;
+    const int b_lo = (int)((long)a.Bn * sl / a.NS), b_hi = (int)((long)a.Bn * (sl + 1) / a.NS);
+    const size_t bstride_g = (size_t)a.L1 * a.L2 * NO, bstride_x = (size_t)a.L1 * a.L2 * NI;
+    const unsigned stage_lds = lds_addr_of(stage);
+
+    auto prefetch = [&](int b) {
+        const int nslot = selfm ? 1 : 2;
+        const cf* Gb = a.Sg + (size_t)b * bstride_g;
+        const cf* Xb = a.Sx + (size_t)b * bstride_x;
+#pragma unroll
+        for (int i = 0; i < (2 * (PPRG + PPRX) + NW - 1) / NW; ++i) {
+            const int j = wave + NW * i;
+            if (j < 2 * PPRG) {
+                const int slot = j >= PPRG, jj = j - slot * PPRG;
+                if (slot < nslot)
+                    dma16(Gb + (size_t)(slot ? rm : r) * (a.L2 * NO) + jj * 128 + lane * 2,
+                          stage_lds + (unsigned)((slot * (LEN * NO) + jj * 128) * 8));
+            } else if (j < 2 * (PPRG + PPRX)) {
+                const int j2 = j - 2 * PPRG;
+                const int slot = j2 >= PPRX, jj = j2 - slot * PPRX;
+                if (slot < nslot)
+                    dma16(Xb + (size_t)(slot ? rm : r) * (a.L2 * NI) + jj * 128 + lane * 2,
+                          stage_lds + (unsigned)((SBG + slot * (LEN * NI) + jj * 128) * 8));
+            }
+        }
+    };
+
+    cf acc[NPP][2][MO][NI];
+#pragma unroll
+    for (int pp = 0; pp < NPP; ++pp)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int m2 = 0; m2 < MO; ++m2)
+#pragma unroll
+                for (int nn = 0; nn < NI; ++nn) acc[pp][e][m2][nn] = cf(0.f, 0.f);
+    if (b_lo < b_hi) prefetch(b_lo);
+    for (int j = tid; j < LEN; j += NT) {
+        tw[j] = a.W[a.n + a.L1 + j];
+        ws[j] = a.W[a.n + a.L1 + a.L2 + j];
+    }
+    const int ms = __builtin_amdgcn_readfirstlane(tid >> 8);
+    const cf wr = a.W[r];
+    const float hg = 0.5f * a.scale_g * (a.interior2_g ? 2.f : 1.f), hx = 0.5f * a.scale_x;
+    wait_vm0();
+    lds_barrier();
+
+#pragma unroll 1
+    for (int b = b_lo; b < b_hi; ++b) {
+        // ---- P1: first stage of the row FFTs of both operands, staging -> U.  item = (slot, tb, channel), channel fastest:
+        // channels [0, NO) are the gradient's rows, [NO, NO + NI) the input's
+        for (int item = opaque(tid); item < NI1; item += NT) {
+            const int ch = item % NC, tb = (item / NC) % B, slot = item / (NC * B);
+            if (slot && selfm) continue;
+            cf v[A];
+            const bool isx = ch >= NO;
+            const cf* sp = isx ? stage + SBG + slot * (LEN * NI) + tb * NI + (ch - NO) : stage + slot * (LEN * NO) + tb * NO + ch;
+            const int st = isx ? B * NI : B * NO;
+#pragma unroll
+            for (int ta = 0; ta < A; ++ta) v[ta] = sp[ta * st];
+            RegFFT<float, A, false>::run(v);
+            __builtin_amdgcn_sched_barrier(0);
+            cf* uu = U + (slot * NC + ch) * LENP + tb;
+            uu[0] = v[0];
+#pragma unroll
+            for (int ka = 1; ka < A; ++ka) uu[ka * B] = v[ka] * tw[ka * tb];
+        }
+        lds_barrier();
+        // staging is consumed: the next item's rows take its place while this one is transformed and accumulated
+        if (b + 1 < b_hi) prefetch(b + 1);
+        // ---- P2: second stage in place (read all, barrier, write all): natural order
+        {
+            cf v[(NI2 + NT - 1) / NT][B];
+#pragma unroll
+            for (int ps = 0; ps < (NI2 + NT - 1) / NT; ++ps) {
+                const int item = opaque(tid) + ps * NT;
+                const int rl = item % (2 * NC), ka = item / (2 * NC);
+                const int slot = rl / NC;
+                if (item < NI2 && !(slot && selfm)) {
+                    const cf* xr = U + rl * LENP + ka * B;
+#pragma unroll
+                    for (int tb = 0; tb < B; ++tb) v[ps][tb] = xr[tb];
+                    RegFFT<float, B, false>::run(v[ps]);
+                }
+            }
+            lds_barrier();
+#pragma unroll
+            for (int ps = 0; ps < (NI2 + NT - 1) / NT; ++ps) {
+                const int item = opaque(tid) + ps * NT;
+                const int rl = item % (2 * NC), ka = item / (2 * NC);
+                const int slot = rl / NC;
+                if (item < NI2 && !(slot && selfm)) {
+                    cf* yr = U + rl * LENP + ka;
+#pragma unroll
+                    for (int kb = 0; kb < B; ++kb) yr[A * kb] = v[ps][kb];
+                }
+            }
+        }
+        lds_barrier();
+        // ---- P3: split step of the thread's gradient channels and of all input channels, accumulate
+#pragma unroll
+        for (int pp = 0; pp < NPP; ++pp) {
+            const int p = pp * 256 + (opaque(tid) & 255);
+            int slotB = 0, colB = 0;
+            bool dc = false;
+            const bool valid = p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
+            if (!valid) continue;
+            const cf wk = wr * ws[p];
+            const cf wm(-wk.x, wk.y);                               // W_n^(L-k) = -conj(W_n^k)
+            auto split = [&](int ch, float hsc, float dsc, cf& ok_, cf& om_) {
+                const cf zk = U[ch * LENP + p];
+                const cf zm = U[(slotB * NC + ch) * LENP + colB];
+                if (dc) {
+                    ok_ = cf(dsc * (zk.x + zk.y), 0.f);             // bin 0
+                    om_ = cf(dsc * (zk.x - zk.y), 0.f);             // bin L
+                } else {
+                    const cf pk = zk + conj(zm), dk = zk - conj(zm);
+                    const cf pm = zm + conj(zk), dm = zm - conj(zk);
+                    ok_ = hsc * (pk + mul_mi(wk * dk));
+                    om_ = hsc * (pm + mul_mi(wm * dm));
+                }
+            };
+            cf xk[NI], xm[NI];
+#pragma unroll
+            for (int nn = 0; nn < NI; ++nn) split(NO + nn, hx, a.scale_x, xk[nn], xm[nn]);
+#pragma unroll
+            for (int m2 = 0; m2 < MO; ++m2) {
+                cf gk, gm;
+                split(ms * MO + m2, hg, a.scale_g, gk, gm);
+#pragma unroll
+                for (int nn = 0; nn < NI; ++nn) {
+                    fma_cxc(acc[pp][0][m2][nn], gk, xk[nn]);
+                    fma_cxc(acc[pp][1][m2][nn], gm, xm[nn]);
+                }
+            }
+        }
+        // the next item's rows have landed before anyone passes this barrier; behind it the next P1 may overwrite U
+        wait_vm0();
+        lds_barrier();
+    }
+    // ---- the slice's sums -> partial plane set sl
+    {
+        cf* out = a.dH + (size_t)sl * a.ds_s;
+#pragma unroll
+        for (int pp = 0; pp < NPP; ++pp) {
+            const int p = pp * 256 + (tid & 255);
+            int slotB = 0, colB = 0;
+            bool dc = false;
+            const bool valid = p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
+            if (!valid) continue;
+            const unsigned ik = (unsigned)r * LEN + p;
+            const unsigned im = dc ? (unsigned)a.L : (unsigned)(slotB ? rm : r) * LEN + colB;
+#pragma unroll
+            for (int m2 = 0; m2 < MO; ++m2) {
+                unsigned ok = 8u * ((unsigned)(ms * MO + m2) * (unsigned)a.ds_m + ik), om = 8u * ((unsigned)(ms * MO + m2) * (unsigned)a.ds_m + im);
+                const unsigned step = 8u * (unsigned)a.ds_n;
+#pragma unroll
+                for (int nn = 0; nn < NI; ++nn) {
+                    at(out, ok) = acc[pp][0][m2][nn];
+                    if (im != ik) at(out, om) = acc[pp][1][m2][nn];
+                    ok += step;
+                    om += step;
+                }
+            }
+        }
+    }
+}
+
+// out[j] = sum_s parts[s*stride + j]  (the batch slices' partial planes; fixed order: deterministic)
+__global__ void __launch_bounds__(256) sum_parts_kernel(const float4* __restrict__ parts, long stride4, int ns, float4* __restrict__ out, long n4) {
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n4) return;
+    float4 s = parts[j];
+    for (int k = 1; k < ns; ++k) {
+        const float4 v = parts[(long)k * stride4 + j];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    out[j] = s;
+}
+
+static int g_walk = 1;            // 0: off (spec_mid only); 1: on for the shapes below
+static int g_walk_wgs = 0;        // workgroups of the forward walking kernel (0: one per CU)
+static int g_walk_slices = 0;     // batch slices of the backward walking kernel (0: CUs / row pairs)
+static long long* g_walk_times = nullptr;
+
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <int A, int B, int NI, int NO, int OCC>
+static int launch_walk(const WalkArgs& a, hipStream_t st) {
+    constexpr int LEN = A * B, LENP = walk_pitch(LEN), NCH = NI > NO ? NI : NO;
+    constexpr size_t lds = ((size_t)3 * 2 * NCH * LENP + 2 * LEN * NI + 4 * LEN + 64) * sizeof(cf);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    auto kern = spec_mid_walk<A, B, NI, NO, OCC>;
+    auto kern_dbg = spec_mid_walk<A, B, NI, NO, OCC, true>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_dbg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long units = (long)(a.L1 / 2 + 1) * a.Bn;
+    long g = g_walk_wgs > 0 ? g_walk_wgs : device_cus();
+    if (g > units) g = units;
+    if (g >= 8) g -= g % 8;
+    if (a.dbg_times) hipLaunchKernelGGL(kern_dbg, dim3((unsigned)g), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(512), lds, st, a);
+    return FL_OK;
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+extern "C" {
+
+int fl_debug_set_walk(int mode, int wgs, int slices, void* times) {
+    g_walk = mode;
+    g_walk_wgs = wgs;
+    g_walk_slices = slices;
+    g_walk_times = (long long*)times;
+    return FL_OK;
+}
+
+int fl_spec_walk_supports(int nfft, int n_in, int n_out) {
+    int l1, l2;
+    if (!g_walk || spec_plan(nfft, l1, l2) != FL_OK) return 0;
+    return l2 == 240 && n_in == 8 && n_out == 8;
+}
+
+int fl_spec_gradh_slices(int nfft, int Bn) {
+    int l1, l2;
+    if (spec_plan(nfft, l1, l2) != FL_OK || Bn <= 0) return 0;
+    if (g_walk_slices > 0) return g_walk_slices < Bn ? g_walk_slices : Bn;
+    const int P = l1 / 2 + 1;
+    int ns = device_cus() / P;              // whole workgroups per CU: one
+    if (ns < 1) ns = 1;
+    return ns < Bn ? ns : Bn;
+}
+
+int fl_spec_gradh_walk_f32(const void* Sg, const void* Sx, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices, const void* W,
+                           int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g, double scale_x, void* stream) {
+    FL_REQUIRE(Sg && Sx && dH_parts && W, "spec_gradh_walk: null pointer");
+    FL_REQUIRE(n_slices >= 1 && n_slices <= (Bn > 0 ? Bn : 1), "spec_gradh_walk: slices must be in [1, batch]");
+    FL_REQUIRE(reinterpret_cast<uintptr_t>(Sg) % 16 == 0 && reinterpret_cast<uintptr_t>(Sx) % 16 == 0, "spec_gradh_walk: scratch arrays must be 16-byte aligned");
+    if (Bn == 0) return FL_OK;
+    GradhArgs a = {};
+    int rc = spec_plan(nfft, a.L1, a.L2);
+    if (rc) return rc;
+    a.Sg = (const cf*)Sg; a.Sx = (const cf*)Sx; a.dH = (cf*)dH_parts; a.ds_s = ds_s; a.ds_m = ds_m; a.ds_n = ds_n;
+    a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn; a.NS = n_slices;
+    a.scale_g = (float)scale_g; a.interior2_g = interior2_g; a.scale_x = (float)scale_x;
+    FL_REQUIRE((size_t)NO * (size_t)ds_m * 8ull < (1ull << 32), "spec_gradh_walk: a partial plane set exceeds 32-bit offsets");
+    const int P = a.L1 / 2 + 1;
+    const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * n_slices);
+    hipStream_t st = (hipStream_t)stream;
+    if (a.L2 == 240 && NI == 8 && NO == 8) {
+        constexpr int A = 16, B = 15, LEN = A * B, LENP = LEN | 1, NC = 16;
+        constexpr size_t lds = ((size_t)2 * NC * LENP + 2 * LEN * NC + 2 * LEN) * sizeof(cf);
+        static_assert(lds <= 160 * 1024, "LDS budget");
+        auto kern = spec_gradh_walk<16, 15, 8, 8, 2, 2>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, a);
+    } else {
+        set_error("spec_gradh_walk: no kernel for nfft=%d, %d -> %d channels", nfft, NI, NO);
+        return FL_ERR_UNSUPPORTED;
+    }
+    FL_CHECK_LAUNCH("spec_gradh_walk");
+    return FL_OK;
+}
+
+int fl_sum_parts_c64(const void* parts, long part_stride, int n_parts, void* out, long n, void* stream) {
+    FL_REQUIRE(parts && out && n_parts >= 1 && n >= 0, "sum_parts: bad arguments");
+    FL_REQUIRE(n % 2 == 0 && part_stride % 2 == 0 && reinterpret_cast<uintptr_t>(parts) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0,
+               "sum_parts: 16-byte granularity");
+    if (n == 0) return FL_OK;
+    const long n4 = n / 2;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)parts,
+                       part_stride / 2, n_parts, (float4*)out, n4);
+    FL_CHECK_LAUNCH("sum_parts");
+    return FL_OK;
+}
+
+int fl_spec_mid_walk_f32(const void* S, void* S2, const void* H, long hs_m, long hs_n, int conj_h, const void* W, int nfft, int Bn,
+                         int NI, int NO, double spec_scale, int spec_interior2, int pre_half, void* stream) {
+    FL_REQUIRE(S && S2 && H && W, "spec_mid_walk: null pointer");
+    FL_REQUIRE(S != S2, "spec_mid_walk: not an in-place kernel (the rows of a round are read while earlier rounds' are stored)");
+    if (Bn == 0) return FL_OK;
+    WalkArgs a = {};
+    int rc = spec_plan(nfft, a.L1, a.L2);
+    if (rc) return rc;
+    a.S = (const cf*)S; a.S2 = (cf*)S2; a.H = (const cf*)H; a.hs_m = hs_m; a.hs_n = hs_n; a.conj_h = conj_h;
+    a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn;
+    a.spec_scale = (float)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half; a.dbg_times = g_walk_times;
+    FL_REQUIRE((size_t)a.L1 * a.L2 * (NI > NO ? NI : NO) * 8ull < (1ull << 32), "spec_mid_walk: a batch item exceeds 32-bit offsets");
+    FL_REQUIRE(reinterpret_cast<uintptr_t>(S) % 16 == 0, "spec_mid_walk: S must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    if (a.L2 == 240 && NI == 8 && NO == 8) rc = launch_walk<16, 15, 8, 8, 2>(a, st);
+    else {
+        set_error("spec_mid_walk: no kernel for nfft=%d, %d -> %d channels", nfft, NI, NO);
+        return FL_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+    FL_CHECK_LAUNCH("spec_mid_walk");
+    return FL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,133 @@
+"""Batch-walking row kernels (csrc/specwalk.hip) against spec_mid + mimo_gradh: equality and launch times.
+    python tools/dbg/walk_bench.py [--batch 32] [--wgs 0,256,248] [--slices 0,2,3]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from flamo_amd import _lib, ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nfft", type=int, default=96000)
+ap.add_argument("--n", type=int, default=8)
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--wgs", default="0")
+ap.add_argument("--slices", default="0")
+ap.add_argument("--reps", type=int, default=20)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+nfft, N, B = args.nfft, args.n, args.batch
+M = nfft // 2 + 1
+L = _lib.lib()
+torch.manual_seed(0)
+x = torch.randn(B, nfft, N, device=dev)
+g = torch.randn(B, nfft, N, device=dev)
+H = ops.permute_bins(torch.randn(M, N, N, device=dev, dtype=torch.complex64) / N ** 0.5, nfft)
+Hp = ops._h_planar(H, True)
+hp = ops._lead_pitch(Hp.movedim(0, -1))
+W = ops.twiddles(nfft, torch.float32, dev)
+S = ops._spec_cols_fwd(x, nfft, 0.0)
+Sg = ops._spec_cols_fwd(g, nfft, 0.0)
+P = ops._pitch(M)
+rel = lambda a, b: (torch.linalg.vector_norm((a - b).float()) / torch.linalg.vector_norm(b.float())).item()  # noqa: E731
+
+
+def timeit(fn, reps=args.reps, flush=True):
+    junk = torch.empty(64 * 1024 * 1024, device=dev)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        if flush:
+            junk.add_(1.0)          # 256 MB touched: the infinity cache holds nothing of the operands
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+# ---------------------------------------------------------------- forward
+for conj_t, scale, i2, ph in ((False, 1.0, 0, 0), (True, 1.0 / nfft, 1, 1)):
+    L.fl_debug_set_walk(0, 0, 0, None)
+    S2_ref, _ = ops._spec_mid(S.clone(), B, N, N, nfft, Hp, conj_t, False, True, scale, i2, ph)
+    hs_m, hs_n = (hp, N * hp) if conj_t else (N * hp, hp)
+    for wgs in [int(v) for v in args.wgs.split(",")]:
+        L.fl_debug_set_walk(1, wgs, 0, None)
+        S2 = torch.full_like(S, float("nan"))
+        _lib.check(L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Hp.data_ptr(), hs_m, hs_n, int(conj_t), W.data_ptr(), nfft, B, N, N,
+                                          scale, i2, ph, ops._stream()), "walk")
+        torch.cuda.synchronize()
+        print(f"forward conj_t={conj_t} wgs={wgs}: rel err vs spec_mid {rel(torch.view_as_real(S2), torch.view_as_real(S2_ref)):.3e}"
+              f"  nan={torch.isnan(torch.view_as_real(S2)).any().item()}")
+
+S2 = torch.empty_like(S)
+for wgs in [int(v) for v in args.wgs.split(",")]:
+    L.fl_debug_set_walk(1, wgs, 0, None)
+    t = timeit(lambda: L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0,
+                                              ops._stream()))
+    print(f"spec_mid_walk wgs={wgs}: median {t[0]:.1f} us, min {t[1]:.1f} us")
+Xs = ops._empty_rows((B, N), M, torch.complex64, dev)
+t = timeit(lambda: L.fl_spec_mid_f32(S.data_ptr(), S2.data_ptr(), Xs.data_ptr(), N * P, P, Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N,
+                                     1.0, 0, 0, ops._stream()))
+print(f"spec_mid (spectrum stored, separate output): median {t[0]:.1f} us, min {t[1]:.1f} us")
+t = timeit(lambda: L.fl_spec_mid_f32(S.data_ptr(), S2.data_ptr(), None, 0, 0, Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N,
+                                     1.0, 0, 0, ops._stream()))
+print(f"spec_mid (no spectrum): median {t[0]:.1f} us, min {t[1]:.1f} us")
+
+# phase picture of the walking kernel: span per workgroup
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+buf = torch.zeros(cus * 8, dtype=torch.int64, device=dev)
+L.fl_debug_set_walk(1, 0, 0, buf.data_ptr())
+L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0, ops._stream())
+torch.cuda.synchronize()
+L.fl_debug_set_walk(1, 0, 0, None)
+tt = buf.view(-1, 8).cpu().double()
+tt = tt[tt[:, 1] > 0]
+if len(tt):
+    d = tt[:, 1] - tt[:, 0]
+    print(f"walk: {len(tt)} workgroups, body cycles mean {d.mean():.0f} min {d.min():.0f} max {d.max():.0f}; span {(tt[:, 1].max() - tt[:, 0].min()):.0f}")
+    names = ["row-pair fill (H, tables, P1, P2)", "step A: P3 split/product/pre", "step B: P4 | P1(next)", "step C: P5 + store | P2(next)"]
+    for i, nm in enumerate(names):
+        print(f"   {nm:34s} {tt[:, 2 + i].mean():9.0f} cycles per workgroup ({100 * tt[:, 2 + i].mean() / d.mean():4.1f} %)")
+
+# ---------------------------------------------------------------- backward
+L.fl_debug_set_walk(0, 0, 0, None)
+_, Xs_ref = ops._spec_mid(S.clone(), B, N, N, nfft, None, False, True, False, 1.0, 0, 0)
+_, gY_ref = ops._spec_mid(Sg.clone(), B, N, N, nfft, None, False, True, False, 1.0 / nfft, 1, 0)
+gH_ref = ops._gradh_launch(gY_ref.movedim(-1, 1), Xs_ref.movedim(-1, 1), False).movedim(-1, 0)
+gH_ref_p = ops._h_planar(gH_ref, True)
+for ns in [int(v) for v in args.slices.split(",")]:
+    L.fl_debug_set_walk(1, 0, ns, None)
+    nsl = L.fl_spec_gradh_slices(nfft, B)
+    parts = torch.full((nsl, N, N, P), float("nan"), dtype=torch.complex64, device=dev)
+    out = torch.empty((N, N, P), dtype=torch.complex64, device=dev)
+
+    def run():
+        _lib.check(L.fl_spec_gradh_walk_f32(Sg.data_ptr(), S.data_ptr(), parts.data_ptr(), N * N * P, N * P, P, nsl, W.data_ptr(), nfft, B, N, N,
+                                            1.0 / nfft, 1, 1.0, ops._stream()), "gradh_walk")
+
+    def run_sum():
+        _lib.check(L.fl_sum_parts_c64(parts.data_ptr(), N * N * P, nsl, out.data_ptr(), N * N * P, ops._stream()), "sum_parts")
+
+    run()
+    run_sum()
+    torch.cuda.synchronize()
+    got = out[..., :M]
+    ref = gH_ref_p.movedim(0, -1)
+    print(f"gradh_walk slices={nsl}: rel err vs spec_mid+mimo_gradh {rel(torch.view_as_real(got), torch.view_as_real(ref)):.3e}"
+          f"  nan={torch.isnan(torch.view_as_real(got)).any().item()}")
+    t = timeit(run)
+    t2 = timeit(run_sum)
+    print(f"   gradh_walk: median {t[0]:.1f} us, min {t[1]:.1f} us; sum_parts: median {t2[0]:.1f} us")
+gYs = ops._empty_rows((B, N), M, torch.complex64, dev)
+t = timeit(lambda: L.fl_spec_mid_f32(Sg.data_ptr(), None, gYs.data_ptr(), N * P, P, None, 0, 0, 0, W.data_ptr(), nfft, B, N, N, 1.0 / nfft, 1, 0,
+                                     ops._stream()))
+t2 = timeit(lambda: ops._gradh_launch(gY_ref.movedim(-1, 1), Xs_ref.movedim(-1, 1), False))
+print(f"spec_mid (spectrum only): median {t[0]:.1f} us; mimo_gradh: median {t2[0]:.1f} us")
