@@ -47,9 +47,10 @@ _SIGNATURES = {
     "fl_spec_cols_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _vp]),
     "fl_spec_mid_f32": (_i, [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "fl_spec_walk_supports": (_i, [_i, _i, _i]),
-    "fl_spec_mid_walk_f32": (_i, [_vp, _vp, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
+    "fl_spec_walk_spectrum_elems": (_sz, [_i, _i, _i]),
+    "fl_spec_mid_walk_f32": (_i, [_vp, _vp, _vp, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "fl_spec_gradh_slices": (_i, [_i, _i]),
-    "fl_spec_gradh_walk_f32": (_i, [_vp, _vp, _vp, _l, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _d, _vp]),
+    "fl_spec_gradh_walk_f32": (_i, [_vp, _vp, _vp, _l, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _vp]),
     "fl_sum_parts_c64": (_i, [_vp, _l, _i, _vp, _l, _vp]),
     "fl_debug_set_walk": (_i, [_i, _i, _i, _vp]),
     "fl_spec_cols_inv_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp]),

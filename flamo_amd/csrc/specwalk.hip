@@ -11,13 +11,17 @@
 // HBM round trip that is 20 % of a spec_mid workgroup's life is hidden.  Two LDS buffers (123 KB) alternate between
 // the phases, which leaves four barriers per round and none between rounds.
 //
-//   forward  (spec_mid_walk):   S (B, L1, L2, NI) -> Y[f] = op(H[f]) X[f] -> S2 (B, L1, L2, NO);  the spectrum is NOT
-//                               stored: the backward pass re-derives it from S (kept instead: same bytes, no extra pass)
-//   backward (spec_gradh_walk): Sg, Sx -> dL/dH[m][n][f] = sum_b gY[b,m,f] conj(X[b,n,f]) accumulated in the same
-//                               registers over the workgroup's batch slice; the row FFTs + split step of both operands
-//                               happen in the kernel, so neither spectrum ever exists in HBM and the separate
-//                               mimo_gradh pass (1.47x over-fetch) is gone.  Batch slices of a row pair are summed from
-//                               per-slice partial planes (deterministic: no atomics).
+//   forward  (spec_mid_walk):   S (B, L1, L2, NI) -> Y[f] = op(H[f]) X[f] -> S2 (B, L1, L2, NO).  If the backward pass will
+//                               need the spectrum it is kept PAIR-MAJOR, Xp[unit][k | L-k][n][pair]: exactly what the
+//                               product's thread holds, written and read back as whole 512-byte runs
+//   backward (spec_gradh_walk): Sg, Xp -> dL/dH[m][n][f] = sum_b gY[b,m,f] conj(X[b,n,f]) accumulated in registers over the
+//                               workgroup's batch slice: the gradient's row FFTs + split step happen in the kernel (its
+//                               spectrum never exists in HBM) and the separate mimo_gradh pass (1.47x over-fetch) is
+//                               gone.  Batch slices of a row pair are summed from per-slice partial planes
+//                               (deterministic: no atomics).
+// All of these kernels are bound by instruction issue, not by HBM (PMC: VALU busy 45 %, 36 % of wavefront cycles parked at
+// barriers / waits, HBM at a third of its rate): the spectrum is kept rather than recomputed because eight row FFTs per
+// unit cost more issue slots than 31 KB of coalesced traffic.
 #include "spectral_common.h"
 
 namespace fl {
@@ -33,6 +37,7 @@ struct WalkArgs {
     float spec_scale;     // scale of the forward transform
     int spec_interior2;   // double the interior bins of the spectrum (irfft backward)
     int pre_half;         // halve the interior bins in front of the inverse transform (rfft backward)
+    cf* Xp;               // spectrum out, pair-major: Xp[(u*2 + e)*NI*LEN + n*LEN + p], u = r*Bn + b, e = 0: bin k, 1: bin L-k; or null
     long long* dbg_times; // tuning: per-workgroup cycle stamps, or null
 };
 
@@ -62,6 +67,7 @@ __device__ __forceinline__ int opaque(int v) {
     return v;
 }
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // s_waitcnt vmcnt(0)
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }    // s_waitcnt lgkmcnt(0)
 
 // ---------------------------------------------------------------- packed complex pieces (two floats per lane and instruction)
 // Written out with 2-vectors: every line below is ONE v_pk_* instruction with the swaps / sign flips of complex arithmetic
@@ -106,9 +112,13 @@ __device__ __forceinline__ void pre_pair(f2 yk, f2 ym, f2 icw, f2 nicw, f2& zk, 
 // staging buffer is free once P1(u+1) has read it) and waited for at the end of step A.  Every SIMD always has one
 // wavefront of each group: the FFT stages (work for 240..256 threads only) of two different units run side by side
 // instead of leaving half of the wavefronts idle.  The pipeline drains at a row-pair boundary (new response).
-// Row pitch of the LDS row buffers, in complex elements: = 4 (mod 32), so that the FFT stages' lane patterns (8 channels x 4
-// consecutive columns, or 8 channels x 4 column groups 15 apart) fall on 32 different 8-byte banks
-constexpr int walk_pitch(int len) { return len + ((4 - len % 32) + 32) % 32; }
+// Row pitch of the LDS row buffers, in complex elements: 4 times an odd number (mod 32), so that the FFT stages' lane
+// patterns (8 channels x 4 consecutive columns, or 8 channels x 4 column groups 15 apart) fall on 32 different 8-byte banks
+constexpr int walk_pitch(int len) {
+    int p = len;
+    while (p % 8 != 4) ++p;
+    return p;
+}
 
 template <int A, int B, int NI, int NO, int OCC, bool DBG = false>
 __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
@@ -116,12 +126,11 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
     constexpr int LEN = A * B, LENP = walk_pitch(LEN), NCH = NI > NO ? NI : NO, NW = 8, MS = 2;
     constexpr int MO = NO / MS;                    // output channels per thread
     constexpr int UB = 2 * NCH * LENP;             // one row buffer: [2][NCH][LENP]
-    constexpr int SB = 2 * LEN * NI;               // staging: [2][LEN][NI], the scratch rows as they lie in memory
-    constexpr int PPR = LEN * NI * 8 / 1024;       // 1-KB DMA pieces per row
+    constexpr int SB = 4 * A * 64;                 // staging: [forward-side wavefront][ta][lane]: see fetch()
     constexpr int NI1 = 2 * B * NI, NI4 = 2 * B * NO, NI2 = 2 * NI * A, NI5 = 2 * NO * A;
     static_assert(LEN <= 256, "one bin pair per thread");
     static_assert(NO % MS == 0, "output channels split over two threads");
-    static_assert((LEN * NI * 8) % 1024 == 0, "a scratch row is a whole number of 1-KB DMA pieces");
+    static_assert(NI % 2 == 0 && A % 2 == 0, "16-byte DMA granules are channel pairs; a 1-KB piece is two first-stage inputs of 64 items");
     static_assert(NI1 <= 256 && NI2 <= 256 && NI4 <= 256 && NI5 <= 256, "an FFT stage of one unit fits one group");
     cf* XF = reinterpret_cast<cf*>(smem);
     cf* Yb = XF + UB;
@@ -146,35 +155,42 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
     const size_t bstride_i = (size_t)a.L1 * a.L2 * NI, bstride_o = (size_t)a.L1 * a.L2 * NO;
     const unsigned stage_lds = lds_addr_of(stage);
 
-    // the scratch rows of unit uu -> staging: piece j = wave + NW*i is 1 KB of row (j / PPR)
-    auto prefetch = [&](int uu) {
+    // The scratch rows of unit uu -> staging, by the forward-side wavefronts, each for ITSELF: wavefront wv fetches
+    // exactly the A x 64 values its own 64 first-stage items will read, laid out [ta][lane], so that no other wavefront ever
+    // touches its region: the transfer is issued as soon as the wavefront's own reads of the previous unit have returned
+    // and awaited (vmcnt) just before its next reads -- no barrier is involved, and the rows have a whole pipeline cycle
+    // to arrive.  One 1-KB piece = first-stage inputs ta = 2q, 2q+1 of the 64 items; a lane's 16 bytes = channels (n, n+1)
+    // of one column.
+    auto fetch = [&](int uu) {
         const int r = uu / a.Bn, b = uu - r * a.Bn;
         const int rm = (a.L1 - r) % a.L1;
-        const int npc = (rm == r ? 1 : 2) * PPR;
-        const cf* Sb = a.S + (size_t)b * bstride_i;
+        const int wv = wave & 3, hi = lane >> 5;
+        int item0 = 64 * wv + 2 * (lane & 31);
+        if (item0 >= NI1 || (item0 >= B * NI && rm == r)) item0 = 0;          // no such item: any valid address
+        const int nn0 = item0 % NI, tb = (item0 / NI) % B, slot = item0 / (NI * B);
+        const cf* src = a.S + (size_t)b * bstride_i + (size_t)(slot ? rm : r) * (a.L2 * NI) + ((hi * B + tb) * NI + nn0);
 #pragma unroll
-        for (int i = 0; i < (2 * PPR + NW - 1) / NW; ++i) {
-            const int j = wave + NW * i;
-            if (j < npc) {
-                const int slot = j >= PPR, jj = j - slot * PPR;
-                const cf* src = Sb + (size_t)(slot ? rm : r) * (a.L2 * NI) + jj * 128 + lane * 2;
-                dma16(src, stage_lds + (unsigned)((slot * (LEN * NI) + jj * 128) * 8));
-            }
-        }
+        for (int q = 0; q < A / 2; ++q) dma16(src + q * (2 * B * NI), stage_lds + (unsigned)(((wv * A + 2 * q) * 64) * 8));
     };
     // ---- the FFT stages, each for the 256 threads of one group
-    auto P1 = [&](bool selfm) {          // first stage of the forward rows, staging -> XF.  item = (slot, tb, n), n fastest
+    auto P1 = [&](bool selfm, int fetch_next) {      // first stage of the forward rows, staging -> XF.  item = (slot, tb, n), n fastest
         const int item = opaque(tid) & 255;
         const int nn = item % NI, tb = (item / NI) % B, slot = item / (NI * B);
-        if (item >= NI1 || (slot && selfm)) return;
+        const bool have = item < NI1 && !(slot && selfm);
         cf v[A], t[A];
-        const cf* sp = stage + slot * (LEN * NI) + tb * NI + nn;
+        wait_vm0();                              // this wavefront's own transfer (fetch) has landed
+        const cf* sp = stage + (item >> 6) * (A * 64) + (item & 63);
 #pragma unroll
-        for (int ta = 0; ta < A; ++ta) v[ta] = sp[ta * (B * NI)];
+        for (int ta = 0; ta < A; ++ta) v[ta] = sp[ta * 64];
         // the twiddles are read with the data: behind the first LDS store the compiler cannot move a read any more (it
         // cannot tell the table from the row buffers), and 15 dependent read -> multiply -> store round trips would follow
 #pragma unroll
-        for (int ka = 1; ka < A; ++ka) t[ka] = tw[ka * tb];
+        for (int ka = 1; ka < A; ++ka) t[ka] = tw[ka * (have ? tb : 0)];
+        if (fetch_next >= 0) {
+            wait_lgkm0();                        // the reads above have returned: the region may be refilled
+            fetch(fetch_next);
+        }
+        if (!have) return;
         RegFFT<float, A, false>::run(v);
         cf* uu = XF + (slot * NCH + nn) * LENP + tb;
         uu[0] = v[0];
@@ -228,7 +244,7 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         for (int kb = 0; kb < B; ++kb) st_nt(S2b, 8u * (dst0 + (unsigned)(A * kb * NO)), v[kb] * t[kb]);
     };
 
-    prefetch(u);
+    if (grp == 1) fetch(u);
     for (int j = tid; j < LEN; j += 512) {         // contiguous copies behind the master table (fl_spec_aux_fill_f32)
         tw[j] = a.W[a.n + a.L1 + j];
         ws[j] = a.W[a.n + a.L1 + a.L2 + j];
@@ -244,8 +260,7 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         t_ph[i] += t_now - t_last;          \
         t_last = t_now;                     \
     }
-    wait_vm0();                                     // the first unit's rows have landed, the tables are visible
-    lds_barrier();
+    lds_barrier();                                  // the tables are visible
 
     while (u < u_hi) {
         // ================= a row pair: its response into registers, its tables into LDS, the pipeline filled
@@ -290,7 +305,7 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         const f2 phv = dc ? f2{1.f, 0.f} : f2{ph, ph};          // ... and only its real parts enter the inverse transform
         const int yk_o = pc, ym_o = slotB * NCH * LENP + colB;  // where the pair's bins sit in a row buffer
         cf* zm_dst = twin ? XI + ym_o : dummy + lane;           // lanes without a partner bin of their own store aside
-        if (grp == 1) P1(selfm);
+        if (grp == 1) P1(selfm, -1);
         if (p < LEN) wtab[grp * LEN + p] = wt_mine;
         lds_barrier();
         if (grp == 1) P2(selfm);
@@ -303,10 +318,9 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
                     for (int nn = 0; nn < NI; ++nn) h[e][m2][nn].y = -h[e][m2][nn].y;
         }
         // every load above has landed: the compiler's own waits end here, outside the unit loop.  The next unit's rows are
-        // requested only now (the staging buffer has been free since the barrier above): waiting for the response must
-        // not mean waiting for them; they have the whole of step A to arrive
+        // requested only now: waiting for the response must not mean waiting for them
         wait_vm0();
-        if (u + 1 < u_hi) prefetch(u + 1);
+        if (grp == 1 && u + 1 < u_hi) fetch(u + 1);
         lds_barrier();
         FL_STAMP(0)
 
@@ -329,6 +343,11 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
                 f2 xk[NI], xm[NI];
 #pragma unroll
                 for (int nn = 0; nn < NI; ++nn) split_pair(v2(yk_p[nn * LENP]), v2(ym_p[nn * LENP]), iw, niw, sck, scm, xk[nn], xm[nn]);
+                if (a.Xp) {      // group 0 keeps the bins k, group 1 the bins L-k (both hold both)
+                    cf* xo = a.Xp + ((size_t)u * 2 + grp) * (NI * LEN) + p;
+#pragma unroll
+                    for (int nn = 0; nn < NI; ++nn) st_nt(xo, 8u * (unsigned)(nn * LEN), c2(grp ? xm[nn] : xk[nn]));
+                }
                 cf* zk_p = XI + yk_o + grp * MO * LENP;
                 cf* zm_p = zm_dst + (twin ? grp * MO * LENP : 0);
 #pragma unroll
@@ -349,16 +368,14 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
                     zm_p[twin ? m2 * LENP : 0] = c2(zm);
                 }
             }
-            wait_vm0();                              // the next unit's rows have landed before anyone passes this barrier
             lds_barrier();
             FL_STAMP(1)
             // ---- step B
             if (grp == 0) P4(selfm);
-            else if (next) P1(selfm);
+            else if (next) P1(selfm, u + 2 < u_hi ? u + 2 : -1);
             lds_barrier();
             FL_STAMP(2)
             // ---- step C
-            if (next && u + 2 < u_hi) prefetch(u + 2);
             if (grp == 0) P5(selfm, r, rm, u - r * a.Bn);
             else if (next) P2(selfm);
             lds_barrier();
@@ -377,207 +394,195 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
 
 // ---------------------------------------------------------------- backward: dL/dH accumulated over a batch slice
 // dH[m][n][f] = sum_b gY[b,m,f] conj(X[b,n,f]),  gY = weighted spectrum of the rows in Sg (K1 of the output's gradient),
-// X = spectrum of the rows in Sx (K1 of the input, kept from the forward pass).  Workgroup (row pair r, batch slice s) walks
-// its items; thread (pair p, ms) keeps dH[2 bins][NO/MS][NI] in registers and writes it once, into partial plane set s.
+// X = the spectrum the forward kernel kept pair-major.  Workgroup (row pair r, batch slice s) walks its items; thread
+// (pair p, e) owns ONE bin -- k of the pair if e = 0 (group 0), L-k if e = 1 (group 1) -- and keeps dH[NO][NI] of it in
+// registers, written once into partial plane set s.  Software pipeline over the items, two barriers per item:
+//   step 1  all:  P3(b-2)  split step of the gradient (the thread's side of the pair), X from staging, accumulate
+//   step 2  G0:   P1(b)    first stage of the gradient's row FFTs                                  stage_g -> XF[b & 1]
+//           G1:   P2(b-1)  second stage                                                            XF[(b-1) & 1] -> Y
+// Staging is owner-wave (see spec_mid_walk's fetch): a group-0 wavefront transfers the gradient rows its own P1 items
+// read, every wavefront the 4 KB of spectrum its own P3 threads read (with one bin per thread the two groups read
+// different halves of a unit's block) -- each transfer issued right after the owner's reads of the previous item and
+// awaited just before its next ones, a full pipeline cycle later.
 struct GradhArgs {
     const cf* Sg;         // (Bn, L1, L2, NO)
-    const cf* Sx;         // (Bn, L1, L2, NI)
+    const cf* Xp;         // pair-major spectrum of the forward kernel
     cf* dH;               // dH[s*ds_s + m*ds_m + n*ds_n + i], row-major bin order, s < NS
     long ds_s, ds_m, ds_n;
     const cf* W;
     int n, L, L1, L2, Bn, NS;
     float scale_g;        // scale of the gradient's forward transform (the inverse transform's scale)
     int interior2_g;      // double its interior bins (irfft backward)
-    float scale_x;        // scale of the input's forward transform
 };
 
-template <int A, int B, int NI, int NO, int MS, int OCC>
-__global__ void __launch_bounds__(256 * MS, OCC) spec_gradh_walk(GradhArgs a) {
+template <int A, int B, int NI, int NO, int OCC>
+__global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LEN = A * B, LENP = LEN | 1, NC = NI + NO, NT = 256 * MS, NW = NT / 64;
-    constexpr int NPP = (LEN + 255) / 256;
-    constexpr int MO = NO / MS;
-    constexpr int UB = 2 * NC * LENP;              // row buffer: [2 slots][NO gradient rows, then NI input rows][LENP]
-    constexpr int SBG = 2 * LEN * NO, SBX = 2 * LEN * NI;     // staging: the gradient's two rows, then the input's
-    constexpr int PPRG = LEN * NO * 8 / 1024, PPRX = LEN * NI * 8 / 1024;
-    constexpr int NI1 = 2 * B * NC, NI2 = 2 * NC * A;
-    static_assert(NO % MS == 0, "output channels split over MS threads");
-    static_assert((LEN * NI * 8) % 1024 == 0 && (LEN * NO * 8) % 1024 == 0, "a scratch row is a whole number of 1-KB DMA pieces");
-    cf* U = reinterpret_cast<cf*>(smem);
-    cf* stage = U + UB;                            // [SBG + SBX]
-    cf* tw = stage + SBG + SBX;
+    constexpr int LEN = A * B, LENP = walk_pitch(LEN);
+    constexpr int UB = 2 * NO * LENP;              // a row buffer of the gradient: [2][NO][LENP]
+    constexpr int SBG = 4 * A * 64;                // gradient staging: [group-0 wavefront][ta][lane]
+    constexpr int SBX = 8 * NI * 64;               // spectrum staging: [wavefront][n][lane]
+    constexpr int NI1 = 2 * B * NO, NI2 = 2 * NO * A;
+    static_assert(LEN <= 256, "one bin pair per thread pair");
+    static_assert(NO % 2 == 0 && NI % 2 == 0 && A % 2 == 0, "16-byte DMA granules");
+    static_assert(NI1 <= 256 && NI2 <= 256, "an FFT stage of one unit fits one group");
+    cf* XF = reinterpret_cast<cf*>(smem);          // [2][UB]
+    cf* Yb = XF + 2 * UB;
+    cf* stage_g = Yb + UB;
+    cf* stage_x = stage_g + SBG;
+    cf* tw = stage_x + SBX;
     cf* ws = tw + LEN;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int grp = wave >> 2;
     const int P = a.L1 / 2 + 1;
-    // XCD-aware order: the slices of a row pair on one XCD (nothing is shared but the twiddles; it keeps a pair's partial
-    // planes' lines in one L2)
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int r = (q / a.NS) * 8 + xcd, sl = q % a.NS;
+    // XCD-aware order: the slices of a row pair on one XCD (it keeps a pair's partial planes' lines in one L2)
+    const int xcd = blockIdx.x & 7, q_ = blockIdx.x >> 3;
+    const int r = (q_ / a.NS) * 8 + xcd, sl = q_ % a.NS;
     if (r >= P) return;
     const int rm = (a.L1 - r) % a.L1;
     const bool selfm = rm == r;
-    const int b_lo = (int)((long)a.Bn * sl / a.NS), b_hi = (int)((long)a.Bn * (sl + 1) / a.NS);
-    const size_t bstride_g = (size_t)a.L1 * a.L2 * NO, bstride_x = (size_t)a.L1 * a.L2 * NI;
-    const unsigned stage_lds = lds_addr_of(stage);
+    const int b_lo = (int)((long)a.Bn * sl / a.NS), n_it = (int)((long)a.Bn * (sl + 1) / a.NS) - b_lo;
+    const size_t bstride_g = (size_t)a.L1 * a.L2 * NO;
+    const unsigned sg_lds = lds_addr_of(stage_g), sx_lds = lds_addr_of(stage_x);
 
-    auto prefetch = [&](int b) {
-        const int nslot = selfm ? 1 : 2;
-        const cf* Gb = a.Sg + (size_t)b * bstride_g;
-        const cf* Xb = a.Sx + (size_t)b * bstride_x;
+    auto fetch_g = [&](int b) {          // group 0: the A x 64 first-stage inputs of this wavefront's own items
+        const int wv = wave & 3, hi = lane >> 5;
+        int item0 = 64 * wv + 2 * (lane & 31);
+        if (item0 >= NI1 || (item0 >= B * NO && selfm)) item0 = 0;
+        const int m0 = item0 % NO, tb = (item0 / NO) % B, slot = item0 / (NO * B);
+        const cf* src = a.Sg + (size_t)b * bstride_g + (size_t)(slot ? rm : r) * (a.L2 * NO) + ((hi * B + tb) * NO + m0);
 #pragma unroll
-        for (int i = 0; i < (2 * (PPRG + PPRX) + NW - 1) / NW; ++i) {
-            const int j = wave + NW * i;
-            if (j < 2 * PPRG) {
-                const int slot = j >= PPRG, jj = j - slot * PPRG;
-                if (slot < nslot)
-                    dma16(Gb + (size_t)(slot ? rm : r) * (a.L2 * NO) + jj * 128 + lane * 2,
-                          stage_lds + (unsigned)((slot * (LEN * NO) + jj * 128) * 8));
-            } else if (j < 2 * (PPRG + PPRX)) {
-                const int j2 = j - 2 * PPRG;
-                const int slot = j2 >= PPRX, jj = j2 - slot * PPRX;
-                if (slot < nslot)
-                    dma16(Xb + (size_t)(slot ? rm : r) * (a.L2 * NI) + jj * 128 + lane * 2,
-                          stage_lds + (unsigned)((SBG + slot * (LEN * NI) + jj * 128) * 8));
-            }
-        }
+        for (int q = 0; q < A / 2; ++q) dma16(src + q * (2 * B * NO), sg_lds + (unsigned)(((wv * A + 2 * q) * 64) * 8));
+    };
+    auto fetch_x = [&](int b) {          // every wavefront: X[n][its own 64 pairs] of its side of the unit's block
+        int pp = 64 * (wave & 3) + 2 * (lane & 31);
+        if (pp > LEN - 2) pp = LEN - 2;
+        const cf* src = a.Xp + (((size_t)r * a.Bn + b) * 2 + grp) * (NI * LEN) + (lane >> 5) * LEN + pp;
+#pragma unroll
+        for (int q = 0; q < NI / 2; ++q) dma16(src + q * (2 * LEN), sx_lds + (unsigned)(((wave * NI + 2 * q) * 64) * 8));
     };
 
-    cf acc[NPP][2][MO][NI];
+    // the product's thread
+    const int p = tid & 255;
+    int slotB = 0, colB = 0;
+    bool dc = false;
+    const bool valid = p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
+    const int pc = p < LEN ? p : 0;
+    f2 acc[NO][NI];
 #pragma unroll
-    for (int pp = 0; pp < NPP; ++pp)
+    for (int m = 0; m < NO; ++m)
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int m2 = 0; m2 < MO; ++m2)
-#pragma unroll
-                for (int nn = 0; nn < NI; ++nn) acc[pp][e][m2][nn] = cf(0.f, 0.f);
-    if (b_lo < b_hi) prefetch(b_lo);
-    for (int j = tid; j < LEN; j += NT) {
+        for (int nn = 0; nn < NI; ++nn) acc[m][nn] = f2{0.f, 0.f};
+    if (grp == 0 && n_it > 0) fetch_g(b_lo);
+    for (int j = tid; j < LEN; j += 512) {
         tw[j] = a.W[a.n + a.L1 + j];
         ws[j] = a.W[a.n + a.L1 + a.L2 + j];
     }
-    const int ms = __builtin_amdgcn_readfirstlane(tid >> 8);
     const cf wr = a.W[r];
-    const float hg = 0.5f * a.scale_g * (a.interior2_g ? 2.f : 1.f), hx = 0.5f * a.scale_x;
-    wait_vm0();
     lds_barrier();
+    const f2 wk = v2(wr * ws[pc]);
+    // i wk D enters with + for the bin L-k, with - for the bin k; the bin L-k takes the conjugate (see split_pair)
+    const f2 iws = grp ? rot_i(wk) : f2{wk.y, -wk.x}, niws = grp ? f2{-wk.x, -wk.y} : wk;
+    const float hg = 0.5f * a.scale_g;
+    const float sc = dc ? hg : hg * (a.interior2_g ? 2.f : 1.f);
+    const f2 scv = grp ? f2{sc, -sc} : f2{sc, sc};
+    const int yk_o = pc, ym_o = slotB * NO * LENP + colB;
 
 #pragma unroll 1
-    for (int b = b_lo; b < b_hi; ++b) {
-        // ---- P1: first stage of the row FFTs of both operands, staging -> U.  item = (slot, tb, channel), channel fastest:
-        // channels [0, NO) are the gradient's rows, [NO, NO + NI) the input's
-        for (int item = opaque(tid); item < NI1; item += NT) {
-            const int ch = item % NC, tb = (item / NC) % B, slot = item / (NC * B);
-            if (slot && selfm) continue;
-            cf v[A];
-            const bool isx = ch >= NO;
-            const cf* sp = isx ? stage + SBG + slot * (LEN * NI) + tb * NI + (ch - NO) : stage + slot * (LEN * NO) + tb * NO + ch;
-            const int st = isx ? B * NI : B * NO;
+    for (int t = 0; t < n_it + 2; ++t) {
+        const bool g_pending = t >= 1 && t < n_it;              // group 0 issued the rows of item t in the previous step 2
+        const bool x_now = t >= 1 && t <= n_it;                 // the spectrum block of item t-1 is requested in this step 1
+        // ---- step 1
+        if (t >= 2) {
 #pragma unroll
-            for (int ta = 0; ta < A; ++ta) v[ta] = sp[ta * st];
-            RegFFT<float, A, false>::run(v);
-            __builtin_amdgcn_sched_barrier(0);
-            cf* uu = U + (slot * NC + ch) * LENP + tb;
-            uu[0] = v[0];
+            for (int m = 0; m < NO; ++m)
 #pragma unroll
-            for (int ka = 1; ka < A; ++ka) uu[ka * B] = v[ka] * tw[ka * tb];
+                for (int nn = 0; nn < NI; ++nn) asm volatile("" : "+v"(acc[m][nn]));
+            // this wavefront's spectrum block of item t-2 has landed (behind it in the queue: group 0's newer row pieces)
+            if (grp == 0 && g_pending) __builtin_amdgcn_s_waitcnt(0x0F70 | (A / 2));
+            else wait_vm0();
         }
-        lds_barrier();
-        // staging is consumed: the next item's rows take its place while this one is transformed and accumulated
-        if (b + 1 < b_hi) prefetch(b + 1);
-        // ---- P2: second stage in place (read all, barrier, write all): natural order
+        f2 x[NI];
         {
-            cf v[(NI2 + NT - 1) / NT][B];
+            const cf* xs = stage_x + (wave * NI) * 64 + lane;
 #pragma unroll
-            for (int ps = 0; ps < (NI2 + NT - 1) / NT; ++ps) {
-                const int item = opaque(tid) + ps * NT;
-                const int rl = item % (2 * NC), ka = item / (2 * NC);
-                const int slot = rl / NC;
-                if (item < NI2 && !(slot && selfm)) {
-                    const cf* xr = U + rl * LENP + ka * B;
+            for (int nn = 0; nn < NI; ++nn) x[nn] = v2(xs[nn * 64]);
+        }
+        if (x_now) {
+            wait_lgkm0();                                        // the reads above have returned: the region may be refilled
+            fetch_x(b_lo + t - 1);
+        }
+        if (t >= 2 && valid) {
 #pragma unroll
-                    for (int tb = 0; tb < B; ++tb) v[ps][tb] = xr[tb];
-                    RegFFT<float, B, false>::run(v[ps]);
-                }
-            }
-            lds_barrier();
+            for (int m = 0; m < NO; ++m) {
+                const f2 zk = v2(Yb[yk_o + m * LENP]), zm = v2(Yb[ym_o + m * LENP]);
+                const f2 Pp = f2{zk.x + zm.x, zk.y - zm.y}, D = f2{zk.x - zm.x, zk.y + zm.y};
+                const f2 g = scv * (Pp + cmulc(D, iws, niws));
+                const f2 mg = f2{g.y, -g.x};                     // g conj(x) = Re(x) g + Im(x) (-i g)
 #pragma unroll
-            for (int ps = 0; ps < (NI2 + NT - 1) / NT; ++ps) {
-                const int item = opaque(tid) + ps * NT;
-                const int rl = item % (2 * NC), ka = item / (2 * NC);
-                const int slot = rl / NC;
-                if (item < NI2 && !(slot && selfm)) {
-                    cf* yr = U + rl * LENP + ka;
-#pragma unroll
-                    for (int kb = 0; kb < B; ++kb) yr[A * kb] = v[ps][kb];
-                }
+                for (int nn = 0; nn < NI; ++nn) acc[m][nn] = pfma(f2{x[nn].y, x[nn].y}, mg, pfma(f2{x[nn].x, x[nn].x}, g, acc[m][nn]));
             }
         }
         lds_barrier();
-        // ---- P3: split step of the thread's gradient channels and of all input channels, accumulate
+        // ---- step 2
+        if (grp == 0) {
+            if (t < n_it) {              // P1(t): first stage of the gradient rows, staging -> XF[t & 1].  item = (m fastest, tb, slot)
+                const int item = opaque(tid) & 255;
+                const int m = item % NO, tb = (item / NO) % B, slot = item / (NO * B);
+                const bool have = item < NI1 && !(slot && selfm);
+                cf v[A], tt[A];
+                // this wavefront's rows of item t have landed (behind them in the queue: the spectrum pieces just requested)
+                if (x_now) __builtin_amdgcn_s_waitcnt(0x0F70 | (NI / 2));
+                else wait_vm0();
+                const cf* sp = stage_g + (item >> 6) * (A * 64) + (item & 63);
 #pragma unroll
-        for (int pp = 0; pp < NPP; ++pp) {
-            const int p = pp * 256 + (opaque(tid) & 255);
-            int slotB = 0, colB = 0;
-            bool dc = false;
-            const bool valid = p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
-            if (!valid) continue;
-            const cf wk = wr * ws[p];
-            const cf wm(-wk.x, wk.y);                               // W_n^(L-k) = -conj(W_n^k)
-            auto split = [&](int ch, float hsc, float dsc, cf& ok_, cf& om_) {
-                const cf zk = U[ch * LENP + p];
-                const cf zm = U[(slotB * NC + ch) * LENP + colB];
-                if (dc) {
-                    ok_ = cf(dsc * (zk.x + zk.y), 0.f);             // bin 0
-                    om_ = cf(dsc * (zk.x - zk.y), 0.f);             // bin L
-                } else {
-                    const cf pk = zk + conj(zm), dk = zk - conj(zm);
-                    const cf pm = zm + conj(zk), dm = zm - conj(zk);
-                    ok_ = hsc * (pk + mul_mi(wk * dk));
-                    om_ = hsc * (pm + mul_mi(wm * dm));
+                for (int ta = 0; ta < A; ++ta) v[ta] = sp[ta * 64];
+#pragma unroll
+                for (int ka = 1; ka < A; ++ka) tt[ka] = tw[ka * (have ? tb : 0)];
+                if (t + 1 < n_it) {
+                    wait_lgkm0();
+                    fetch_g(b_lo + t + 1);
                 }
-            };
-            cf xk[NI], xm[NI];
+                if (have) {
+                    RegFFT<float, A, false>::run(v);
+                    cf* uu = XF + (t & 1) * UB + (slot * NO + m) * LENP + tb;
+                    uu[0] = v[0];
 #pragma unroll
-            for (int nn = 0; nn < NI; ++nn) split(NO + nn, hx, a.scale_x, xk[nn], xm[nn]);
-#pragma unroll
-            for (int m2 = 0; m2 < MO; ++m2) {
-                cf gk, gm;
-                split(ms * MO + m2, hg, a.scale_g, gk, gm);
-#pragma unroll
-                for (int nn = 0; nn < NI; ++nn) {
-                    fma_cxc(acc[pp][0][m2][nn], gk, xk[nn]);
-                    fma_cxc(acc[pp][1][m2][nn], gm, xm[nn]);
+                    for (int ka = 1; ka < A; ++ka) uu[ka * B] = v[ka] * tt[ka];
                 }
             }
+        } else if (t >= 1 && t <= n_it) {     // P2(t-1): second stage XF[(t-1) & 1] -> Y.  item = (m fastest, ka, slot)
+            const int item = opaque(tid) & 255;
+            const int m = item % NO, ka = (item / NO) % A, slot = item / (NO * A);
+            if (item < NI2 && !(slot && selfm)) {
+                cf v[B];
+                const cf* xr = XF + ((t - 1) & 1) * UB + (slot * NO + m) * LENP + ka * B;
+#pragma unroll
+                for (int tb = 0; tb < B; ++tb) v[tb] = xr[tb];
+                RegFFT<float, B, false>::run(v);
+                cf* yr = Yb + (slot * NO + m) * LENP + ka;
+#pragma unroll
+                for (int kb = 0; kb < B; ++kb) yr[A * kb] = v[kb];
+            }
         }
-        // the next item's rows have landed before anyone passes this barrier; behind it the next P1 may overwrite U
-        wait_vm0();
         lds_barrier();
     }
     // ---- the slice's sums -> partial plane set sl
     {
-        cf* out = a.dH + (size_t)sl * a.ds_s;
+        const unsigned ik = (unsigned)r * LEN + p;
+        const unsigned im = dc ? (unsigned)a.L : (unsigned)(slotB ? rm : r) * LEN + colB;
+        if (valid && !(grp && im == ik)) {
+            cf* out = a.dH + (size_t)sl * a.ds_s;
+            const unsigned bin = grp ? im : ik;
 #pragma unroll
-        for (int pp = 0; pp < NPP; ++pp) {
-            const int p = pp * 256 + (tid & 255);
-            int slotB = 0, colB = 0;
-            bool dc = false;
-            const bool valid = p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
-            if (!valid) continue;
-            const unsigned ik = (unsigned)r * LEN + p;
-            const unsigned im = dc ? (unsigned)a.L : (unsigned)(slotB ? rm : r) * LEN + colB;
-#pragma unroll
-            for (int m2 = 0; m2 < MO; ++m2) {
-                unsigned ok = 8u * ((unsigned)(ms * MO + m2) * (unsigned)a.ds_m + ik), om = 8u * ((unsigned)(ms * MO + m2) * (unsigned)a.ds_m + im);
+            for (int m = 0; m < NO; ++m) {
+                unsigned o = 8u * ((unsigned)m * (unsigned)a.ds_m + bin);
                 const unsigned step = 8u * (unsigned)a.ds_n;
 #pragma unroll
                 for (int nn = 0; nn < NI; ++nn) {
-                    at(out, ok) = acc[pp][0][m2][nn];
-                    if (im != ik) at(out, om) = acc[pp][1][m2][nn];
-                    ok += step;
-                    om += step;
+                    at(out, o) = c2(acc[m][nn]);
+                    o += step;
                 }
             }
         }
@@ -615,7 +620,7 @@ static int device_cus() {
 template <int A, int B, int NI, int NO, int OCC>
 static int launch_walk(const WalkArgs& a, hipStream_t st) {
     constexpr int LEN = A * B, LENP = walk_pitch(LEN), NCH = NI > NO ? NI : NO;
-    constexpr size_t lds = ((size_t)3 * 2 * NCH * LENP + 2 * LEN * NI + 4 * LEN + 64) * sizeof(cf);
+    constexpr size_t lds = ((size_t)3 * 2 * NCH * LENP + 4 * A * 64 + 4 * LEN + 64) * sizeof(cf);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     auto kern = spec_mid_walk<A, B, NI, NO, OCC>;
@@ -664,27 +669,27 @@ int fl_spec_gradh_slices(int nfft, int Bn) {
     return ns < Bn ? ns : Bn;
 }
 
-int fl_spec_gradh_walk_f32(const void* Sg, const void* Sx, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices, const void* W,
-                           int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g, double scale_x, void* stream) {
-    FL_REQUIRE(Sg && Sx && dH_parts && W, "spec_gradh_walk: null pointer");
+int fl_spec_gradh_walk_f32(const void* Sg, const void* Xp, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices, const void* W,
+                           int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g, void* stream) {
+    FL_REQUIRE(Sg && Xp && dH_parts && W, "spec_gradh_walk: null pointer");
     FL_REQUIRE(n_slices >= 1 && n_slices <= (Bn > 0 ? Bn : 1), "spec_gradh_walk: slices must be in [1, batch]");
-    FL_REQUIRE(reinterpret_cast<uintptr_t>(Sg) % 16 == 0 && reinterpret_cast<uintptr_t>(Sx) % 16 == 0, "spec_gradh_walk: scratch arrays must be 16-byte aligned");
+    FL_REQUIRE(reinterpret_cast<uintptr_t>(Sg) % 16 == 0 && reinterpret_cast<uintptr_t>(Xp) % 16 == 0, "spec_gradh_walk: scratch arrays must be 16-byte aligned");
     if (Bn == 0) return FL_OK;
     GradhArgs a = {};
     int rc = spec_plan(nfft, a.L1, a.L2);
     if (rc) return rc;
-    a.Sg = (const cf*)Sg; a.Sx = (const cf*)Sx; a.dH = (cf*)dH_parts; a.ds_s = ds_s; a.ds_m = ds_m; a.ds_n = ds_n;
+    a.Sg = (const cf*)Sg; a.Xp = (const cf*)Xp; a.dH = (cf*)dH_parts; a.ds_s = ds_s; a.ds_m = ds_m; a.ds_n = ds_n;
     a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn; a.NS = n_slices;
-    a.scale_g = (float)scale_g; a.interior2_g = interior2_g; a.scale_x = (float)scale_x;
+    a.scale_g = (float)scale_g; a.interior2_g = interior2_g;
     FL_REQUIRE((size_t)NO * (size_t)ds_m * 8ull < (1ull << 32), "spec_gradh_walk: a partial plane set exceeds 32-bit offsets");
     const int P = a.L1 / 2 + 1;
     const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * n_slices);
     hipStream_t st = (hipStream_t)stream;
     if (a.L2 == 240 && NI == 8 && NO == 8) {
-        constexpr int A = 16, B = 15, LEN = A * B, LENP = LEN | 1, NC = 16;
-        constexpr size_t lds = ((size_t)2 * NC * LENP + 2 * LEN * NC + 2 * LEN) * sizeof(cf);
+        constexpr int A = 16, B = 15, LEN = A * B, LENP = walk_pitch(LEN);
+        constexpr size_t lds = ((size_t)3 * 2 * 8 * LENP + 4 * A * 64 + 8 * 8 * 64 + 2 * LEN) * sizeof(cf);
         static_assert(lds <= 160 * 1024, "LDS budget");
-        auto kern = spec_gradh_walk<16, 15, 8, 8, 2, 2>;
+        auto kern = spec_gradh_walk<16, 15, 8, 8, 2>;
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -711,7 +716,13 @@ int fl_sum_parts_c64(const void* parts, long part_stride, int n_parts, void* out
     return FL_OK;
 }
 
-int fl_spec_mid_walk_f32(const void* S, void* S2, const void* H, long hs_m, long hs_n, int conj_h, const void* W, int nfft, int Bn,
+size_t fl_spec_walk_spectrum_elems(int nfft, int Bn, int NI) {
+    int l1, l2;
+    if (spec_plan(nfft, l1, l2) != FL_OK || Bn < 0) return 0;
+    return (size_t)(l1 / 2 + 1) * Bn * 2 * NI * l2;
+}
+
+int fl_spec_mid_walk_f32(const void* S, void* S2, void* Xp, const void* H, long hs_m, long hs_n, int conj_h, const void* W, int nfft, int Bn,
                          int NI, int NO, double spec_scale, int spec_interior2, int pre_half, void* stream) {
     FL_REQUIRE(S && S2 && H && W, "spec_mid_walk: null pointer");
     FL_REQUIRE(S != S2, "spec_mid_walk: not an in-place kernel (the rows of a round are read while earlier rounds' are stored)");
@@ -722,6 +733,7 @@ int fl_spec_mid_walk_f32(const void* S, void* S2, const void* H, long hs_m, long
     a.S = (const cf*)S; a.S2 = (cf*)S2; a.H = (const cf*)H; a.hs_m = hs_m; a.hs_n = hs_n; a.conj_h = conj_h;
     a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn;
     a.spec_scale = (float)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half; a.dbg_times = g_walk_times;
+    a.Xp = (cf*)Xp;
     FL_REQUIRE((size_t)a.L1 * a.L2 * (NI > NO ? NI : NO) * 8ull < (1ull << 32), "spec_mid_walk: a batch item exceeds 32-bit offsets");
     FL_REQUIRE(reinterpret_cast<uintptr_t>(S) % 16 == 0, "spec_mid_walk: S must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;

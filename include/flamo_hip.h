@@ -143,24 +143,28 @@ int fl_spec_cols_fwd_f32(const void* x, int Bn, int t_len, int G, void* S, const
 int fl_spec_mid_f32(const void* S, void* S2, void* Xs, long xs_b, long xs_n, const void* H, long hs_m, long hs_n, int conj_h,
                     const void* W, int nfft, int Bn, int NI, int NO, double spec_scale, int spec_interior2, int pre_half,
                     void* stream);
-/* mid, batch-walking form (csrc/specwalk.hip): the same operator as fl_spec_mid_f32 with H present and S2 != S, no spectrum
- * output.  One workgroup per CU owns a contiguous range of (row pair, batch item) units and keeps the row pair's response
- * slice in registers, so H (the "fmn" operand of einsum("fmn,bfn...->bfm...") at dsp.py:922-924) crosses the L2 -> L1 path
- * once per row pair and workgroup instead of once per batch item; the next unit's scratch rows arrive by LDS-DMA under the
- * current unit's phases.  fl_spec_walk_supports: 1 when (nfft, channels) has this kernel (else use fl_spec_mid_f32). */
+/* mid, batch-walking form (csrc/specwalk.hip): the same operator as fl_spec_mid_f32 with H present and S2 != S.
+ * One workgroup per CU owns a contiguous range of (row pair, batch item) units and keeps the row pair's response slice in
+ * registers, so H (the "fmn" operand of einsum("fmn,bfn...->bfm...") at dsp.py:922-924) crosses the L2 -> L1 path once per
+ * row pair and workgroup instead of once per batch item; the next unit's scratch rows arrive by LDS-DMA under the current
+ * unit's phases, and the inverse-side FFT stages of a unit run beside the forward-side stages of the next on the other
+ * half of the wavefronts.  Xp (or null): the spectrum for the backward pass, PAIR-MAJOR and private to these two kernels:
+ *   Xp[((r*Bn + b)*2 + e)*NI*L2 + n*L2 + p] = X[b][n][bin], bin = k (e = 0) or nfft/2 - k (e = 1) of pair p of row pair r
+ * (fl_spec_walk_spectrum_elems complex values).  fl_spec_walk_supports: 1 when (nfft, channels) has this kernel. */
 int fl_spec_walk_supports(int nfft, int n_in, int n_out);
-int fl_spec_mid_walk_f32(const void* S, void* S2, const void* H, long hs_m, long hs_n, int conj_h, const void* W, int nfft, int Bn,
+size_t fl_spec_walk_spectrum_elems(int nfft, int Bn, int NI);
+int fl_spec_mid_walk_f32(const void* S, void* S2, void* Xp, const void* H, long hs_m, long hs_n, int conj_h, const void* W, int nfft, int Bn,
                          int NI, int NO, double spec_scale, int spec_interior2, int pre_half, void* stream);
 /* Backward of the product inside the row kernel -- the autograd of dsp.py:922-924 w.r.t. the response:
  *   dH[m][n][i] = sum_b gY[b,m,i] conj(X[b,n,i]),   gY = scale_g * w_k * rfft-spectrum of the rows in Sg (K1 of the output
- *   gradient; w_k = 2 on interior bins if interior2_g), X = scale_x * spectrum of the rows in Sx (K1 of the input, kept from the
- *   forward pass), both (Bn, L1, L2, channels).  Neither spectrum goes through HBM.  Workgroup (row pair, batch slice) sums its
- *   slice in registers and writes partial plane set s < n_slices: dH_parts[s*ds_s + m*ds_m + n*ds_n + i], row-major bin order
- *   (every element of every set is written; fl_sum_parts_c64 or the consumer adds the sets -- fixed order, no atomics).
+ *   gradient, (Bn, L1, L2, NO); w_k = 2 on interior bins if interior2_g), X = the pair-major spectrum fl_spec_mid_walk_f32
+ *   kept.  gY never goes through HBM.  Workgroup (row pair, batch slice) sums its slice in registers and writes partial
+ *   plane set s < n_slices: dH_parts[s*ds_s + m*ds_m + n*ds_n + i], row-major bin order (every element of every set is
+ *   written; fl_sum_parts_c64 or the consumer adds the sets -- fixed order, no atomics).
  *   fl_spec_gradh_slices: the slice count that fills the device (1 <= . <= Bn). */
 int fl_spec_gradh_slices(int nfft, int Bn);
-int fl_spec_gradh_walk_f32(const void* Sg, const void* Sx, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices, const void* W,
-                           int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g, double scale_x, void* stream);
+int fl_spec_gradh_walk_f32(const void* Sg, const void* Xp, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices, const void* W,
+                           int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g, void* stream);
 /* out[j] = sum_{s < n_parts} parts[s*part_stride + j], j < n complex values (16-byte aligned, n and part_stride even) */
 int fl_sum_parts_c64(const void* parts, long part_stride, int n_parts, void* out, long n, void* stream);
 /* tuning hook: mode 0 switches the walking kernels off (fl_spec_walk_supports -> 0); wgs / slices override the forward

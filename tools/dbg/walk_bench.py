@@ -61,18 +61,22 @@ for conj_t, scale, i2, ph in ((False, 1.0, 0, 0), (True, 1.0 / nfft, 1, 1)):
     for wgs in [int(v) for v in args.wgs.split(",")]:
         L.fl_debug_set_walk(1, wgs, 0, None)
         S2 = torch.full_like(S, float("nan"))
-        _lib.check(L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Hp.data_ptr(), hs_m, hs_n, int(conj_t), W.data_ptr(), nfft, B, N, N,
+        _lib.check(L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), None, Hp.data_ptr(), hs_m, hs_n, int(conj_t), W.data_ptr(), nfft, B, N, N,
                                           scale, i2, ph, ops._stream()), "walk")
         torch.cuda.synchronize()
         print(f"forward conj_t={conj_t} wgs={wgs}: rel err vs spec_mid {rel(torch.view_as_real(S2), torch.view_as_real(S2_ref)):.3e}"
               f"  nan={torch.isnan(torch.view_as_real(S2)).any().item()}")
 
 S2 = torch.empty_like(S)
+Xp = torch.zeros(L.fl_spec_walk_spectrum_elems(nfft, B, N), dtype=torch.complex64, device=dev)
 for wgs in [int(v) for v in args.wgs.split(",")]:
     L.fl_debug_set_walk(1, wgs, 0, None)
-    t = timeit(lambda: L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0,
+    t = timeit(lambda: L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), None, Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0,
                                               ops._stream()))
     print(f"spec_mid_walk wgs={wgs}: median {t[0]:.1f} us, min {t[1]:.1f} us")
+    t = timeit(lambda: L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Xp.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0,
+                                              ops._stream()))
+    print(f"spec_mid_walk wgs={wgs} + pair-major spectrum: median {t[0]:.1f} us, min {t[1]:.1f} us")
 Xs = ops._empty_rows((B, N), M, torch.complex64, dev)
 t = timeit(lambda: L.fl_spec_mid_f32(S.data_ptr(), S2.data_ptr(), Xs.data_ptr(), N * P, P, Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N,
                                      1.0, 0, 0, ops._stream()))
@@ -85,7 +89,7 @@ print(f"spec_mid (no spectrum): median {t[0]:.1f} us, min {t[1]:.1f} us")
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 buf = torch.zeros(cus * 8, dtype=torch.int64, device=dev)
 L.fl_debug_set_walk(1, 0, 0, buf.data_ptr())
-L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0, ops._stream())
+L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Xp.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0, ops._stream())
 torch.cuda.synchronize()
 L.fl_debug_set_walk(1, 0, 0, None)
 tt = buf.view(-1, 8).cpu().double()
@@ -103,6 +107,16 @@ _, Xs_ref = ops._spec_mid(S.clone(), B, N, N, nfft, None, False, True, False, 1.
 _, gY_ref = ops._spec_mid(Sg.clone(), B, N, N, nfft, None, False, True, False, 1.0 / nfft, 1, 0)
 gH_ref = ops._gradh_launch(gY_ref.movedim(-1, 1), Xs_ref.movedim(-1, 1), False).movedim(-1, 0)
 gH_ref_p = ops._h_planar(gH_ref, True)
+# the pair-major spectrum against the stored one: unit (r, b), e = 0 -> bins r*L2 + p (row-major order)
+L1, L2 = nfft // 2 // 240, 240
+Xpv = Xp.view(L1 // 2 + 1, B, 2, N, L2)
+Xs_rm = Xs_ref            # (B, N, M) row-major bin order
+for r in (1, 7, 57, 99):
+    want = Xs_rm[:, :, r * L2:(r + 1) * L2]
+    got = Xpv[r, :, 0].reshape(B, N, L2)
+    wantm = Xs_rm[:, :, (L1 - r) * L2:(L1 - r + 1) * L2].flip(-1)
+    gotm = Xpv[r, :, 1].reshape(B, N, L2)
+    print(f"pair-major spectrum row pair {r}: k {rel(torch.view_as_real(got), torch.view_as_real(want)):.2e}  L-k {rel(torch.view_as_real(gotm), torch.view_as_real(wantm)):.2e}")
 for ns in [int(v) for v in args.slices.split(",")]:
     L.fl_debug_set_walk(1, 0, ns, None)
     nsl = L.fl_spec_gradh_slices(nfft, B)
@@ -110,8 +124,8 @@ for ns in [int(v) for v in args.slices.split(",")]:
     out = torch.empty((N, N, P), dtype=torch.complex64, device=dev)
 
     def run():
-        _lib.check(L.fl_spec_gradh_walk_f32(Sg.data_ptr(), S.data_ptr(), parts.data_ptr(), N * N * P, N * P, P, nsl, W.data_ptr(), nfft, B, N, N,
-                                            1.0 / nfft, 1, 1.0, ops._stream()), "gradh_walk")
+        _lib.check(L.fl_spec_gradh_walk_f32(Sg.data_ptr(), Xp.data_ptr(), parts.data_ptr(), N * N * P, N * P, P, nsl, W.data_ptr(), nfft, B, N, N,
+                                            1.0 / nfft, 1, ops._stream()), "gradh_walk")
 
     def run_sum():
         _lib.check(L.fl_sum_parts_c64(parts.data_ptr(), N * N * P, nsl, out.data_ptr(), N * N * P, ops._stream()), "sum_parts")
