@@ -647,6 +647,55 @@ def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2):
     return y
 
 
+# Batch-walking row kernels (csrc/specwalk.hip): one workgroup per CU keeps the row pair's response slice in registers and
+# walks (row pair, batch item) units; the spectrum the backward pass needs is kept pair-major (private to the two kernels) and
+# dL/dH is accumulated in registers from it -- no (B, M, N) spectrum, no separate gradient pass over two of them.
+_WALK_MIN_BATCH = 4        # below this a workgroup's range is a unit or two: the fill (response into registers) dominates
+
+
+def _walk_applies(nfft: int, B: int, NI: int, NO: int) -> bool:
+    return B >= _WALK_MIN_BATCH and bool(_lib.lib().fl_spec_walk_supports(int(nfft), int(NI), int(NO)))
+
+
+def _spec_mid_walk(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, spec_scale, interior2, pre_half):
+    """-> (S2, pair-major spectrum or None) through fl_spec_mid_walk_f32"""
+    dev = S.device
+    L = _lib.lib()
+    S2 = torch.empty(B * (nfft // 2) * NO, dtype=torch.complex64, device=dev)
+    Xp = torch.empty(int(L.fl_spec_walk_spectrum_elems(nfft, B, NI)), dtype=torch.complex64, device=dev) if want_spec else None
+    hp = _lead_pitch(Hrm.movedim(0, -1))
+    hs_m, hs_n = Hrm.shape[2] * hp, hp
+    if conj_t:
+        hs_m, hs_n = hs_n, hs_m
+    tag = f"spec_mid_walk[{NI}->{NO}" + (",spec" if want_spec else "") + "]"
+    with kernel_timer.span(tag):
+        _lib.check(L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), None if Xp is None else Xp.data_ptr(), Hrm.data_ptr(), hs_m, hs_n,
+                                          int(bool(conj_t)), twiddles(nfft, torch.float32, dev).data_ptr(), nfft, B, NI, NO, spec_scale,
+                                          int(interior2), int(pre_half), _stream()), "spec_mid_walk")
+    return S2, Xp
+
+
+def _spec_gradh_walk(Sg, Xp, B, NI, NO, nfft, scale_g):
+    """dL/dH (M, NO, NI) view, row-major bin order, from the gradient's scratch rows and the pair-major spectrum"""
+    dev = Sg.device
+    L = _lib.lib()
+    M = nfft // 2 + 1
+    P = _pitch(M)
+    ns = int(L.fl_spec_gradh_slices(nfft, B))
+    parts = torch.empty((ns, NO, NI, P), dtype=torch.complex64, device=dev)
+    with kernel_timer.span("spec_gradh_walk"):
+        _lib.check(L.fl_spec_gradh_walk_f32(Sg.data_ptr(), Xp.data_ptr(), parts.data_ptr(), NO * NI * P, NI * P, P, ns,
+                                            twiddles(nfft, torch.float32, dev).data_ptr(), nfft, B, NI, NO, scale_g, 1, _stream()),
+                   "spec_gradh_walk")
+    if ns == 1:
+        out = parts[0]
+    else:
+        out = torch.empty((NO, NI, P), dtype=torch.complex64, device=dev)
+        with kernel_timer.span("sum_parts"):
+            _lib.check(L.fl_sum_parts_c64(parts.data_ptr(), NO * NI * P, ns, out.data_ptr(), NO * NI * P, _stream()), "sum_parts")
+    return out[..., :M].movedim(-1, 0)
+
+
 class _SpectralApply(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Hrm, nfft, scale_f, env_f, scale_i, env_i):
@@ -665,16 +714,20 @@ class _SpectralApply(torch.autograd.Function):
         Hp = _h_planar(Hrm.resolve_conj(), True)
         B, T = xc.shape[0], xc.shape[1]
         S = _spec_cols_fwd(xc, nfft, env_f)
-        S2, Xs = _spec_mid(S, B, NI, NO, nfft, Hp, False, ctx.needs_input_grad[1], True, scale_f, 0, 0)
+        walk = _walk_applies(nfft, B, NI, NO)
+        if walk:
+            S2, Xs = _spec_mid_walk(S, B, NI, NO, nfft, Hp, False, ctx.needs_input_grad[1], scale_f, 0, 0)
+        else:
+            S2, Xs = _spec_mid(S, B, NI, NO, nfft, Hp, False, ctx.needs_input_grad[1], True, scale_f, 0, 0)
         y = _spec_cols_inv(S2, B, nfft, nfft, NO, nfft, scale_i, env_i)
         ctx.save_for_backward(Hp, *([Xs] if Xs is not None else []))
-        ctx.cfg = (nfft, scale_f, env_f, scale_i, env_i, T, NI, NO)
+        ctx.cfg = (nfft, scale_f, env_f, scale_i, env_i, T, NI, NO, walk)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         Hp, *kept = ctx.saved_tensors
-        nfft, scale_f, env_f, scale_i, env_i, T, NI, NO = ctx.cfg
+        nfft, scale_f, env_f, scale_i, env_i, T, NI, NO, walk = ctx.cfg
         need_x, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g = gy.contiguous()
         if g.data_ptr() % 8:
@@ -682,9 +735,20 @@ class _SpectralApply(torch.autograd.Function):
         B = g.shape[0]
         # irfft' : g_Y[k] = w_k scale_i sum_t g_y[t] e_i(t) exp(-j w_k t) -- a forward transform with doubled interior bins
         Sg = _spec_cols_fwd(g, nfft, env_i)
+        gx = gH = None
+        if walk:
+            if need_h:
+                gH = _spec_gradh_walk(Sg, kept[0], B, NI, NO, nfft, scale_i)
+            if need_x:
+                # rfft' : g_x[t] = scale_f e_f(t) Re sum_k g_X[k] exp(+j w_k t), g_X = H^H g_Y
+                if _walk_applies(nfft, B, NO, NI):
+                    S3, _ = _spec_mid_walk(Sg, B, NO, NI, nfft, Hp, True, False, scale_i, 1, 1)
+                else:
+                    S3, _ = _spec_mid(Sg, B, NO, NI, nfft, Hp, True, False, True, scale_i, 1, 1)
+                gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f, env_f)
+            return gx, gH, None, None, None, None, None
         # rfft' : g_x[t] = scale_f e_f(t) Re sum_k g_X[k] exp(+j w_k t), g_X = H^H g_Y -- an inverse transform with halved interior bins
         S3, gYs = _spec_mid(Sg, B, NO, NI if need_x else NO, nfft, Hp if need_x else None, True, need_h, need_x, scale_i, 1, 1)
-        gx = gH = None
         if need_x:
             gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f, env_f)
         if need_h:
