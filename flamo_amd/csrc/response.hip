@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) sos_response_rc_kernel(const double* __re
 // frequency (shelving sections at 44 Hz) happens in exact arithmetic, what is left is a well-conditioned Horner step.
 // (The backward kernel's float stage uses the same basis.)  The 2 x S/2 running products are two independent chains per
 // packed register.  Measured against the double kernel: response 3e-7 relative, 49 -> ~30 us at config 2.
-template <int NIW>
+template <int NIW, int UNR = 1>
 __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double* __restrict__ b, const double* __restrict__ a, int S,
                                                                   int C, int Nmid, const float* __restrict__ Wr, double g,
                                                                   const cx<double>* __restrict__ Wd, int nfft, int bin0,
@@ -207,6 +207,8 @@ __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double*
         const float* cb = cf + ((size_t)j * 4 + (low ? 0 : 2)) * 3 * SP;
         const float* ca = cb + 3 * SP;
         f2 pbr = (f2)(1.f), pbi = (f2)(0.f), par = (f2)(1.f), pai = (f2)(0.f);
+        // (UNR section pairs per trip: their 6 UNR table reads are issued together -- one LDS latency per trip, not per pair)
+#pragma unroll UNR
         for (int s = 0; s < SP; s += 2) {
             const f2 b0 = *reinterpret_cast<const f2*>(cb + s), b1 = *reinterpret_cast<const f2*>(cb + SP + s),
                      b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
@@ -882,7 +884,7 @@ __global__ void __launch_bounds__(256) geq_sections_bwd_kernel(const void* __res
 }
 
 static int g_sos_chunk = 0;
-static int g_rc_fast = 1;   // cascade-times-matrix forward: float evaluation in the 1 -+ w basis (0: the double kernel)
+static int g_rc_fast = 6;   // cascade-times-matrix forward: float evaluation in the 1 -+ w basis, section pairs per loop trip (1 | 2 | 3 | 6; 0: the double kernel)
 static int g_sos_blocks = 0;
 
 static int sos_blocks(int m_local) {
@@ -1015,7 +1017,7 @@ int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamm
 }
 int fl_sos_bwd_blocks(int m_local) { return sos_blocks(m_local); }
 int fl_debug_set_rc_fast(int on) {
-    g_rc_fast = on != 0;
+    g_rc_fast = on;
     return FL_OK;
 }
 int fl_debug_set_sos_chunk(int sections_per_thread) {
@@ -1074,9 +1076,22 @@ int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid
     const size_t lds_fast = ((size_t)Nmid * 12 * ((S + 1) & ~1) + (size_t)Nmid * Ni) * sizeof(float);
 #define FL_RC_FWD(NIW_)                                                                                                      \
     if (Ni == NIW_ && g_rc_fast && float_eval) {                                                                             \
-        hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_>), grid, dim3(256), lds_fast, (hipStream_t)stream,              \
-                           (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,                  \
-                           (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);      \
+        if (g_rc_fast == 2)                                                                                                  \
+            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 2>), grid, dim3(256), lds_fast, (hipStream_t)stream,       \
+                               (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
+                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
+        else if (g_rc_fast == 3)                                                                                             \
+            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 3>), grid, dim3(256), lds_fast, (hipStream_t)stream,       \
+                               (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
+                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
+        else if (g_rc_fast == 6)                                                                                             \
+            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 6>), grid, dim3(256), lds_fast, (hipStream_t)stream,       \
+                               (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
+                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_>), grid, dim3(256), lds_fast, (hipStream_t)stream,          \
+                               (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
+                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
         FL_CHECK_LAUNCH("sos_response_rc_fast");                                                                             \
         return FL_OK;                                                                                                        \
     }                                                                                                                        \

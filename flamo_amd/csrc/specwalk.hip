@@ -415,16 +415,18 @@ struct GradhArgs {
     int interior2_g;      // double its interior bins (irfft backward)
 };
 
-template <int A, int B, int NI, int NO, int OCC>
+template <int A, int B, int NI, int NO, int NSC, int OCC>
 __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LEN = A * B, LENP = walk_pitch(LEN);
-    constexpr int UB = 2 * NO * LENP;              // a row buffer of the gradient: [2][NO][LENP]
-    constexpr int SBG = 4 * A * 64;                // gradient staging: [group-0 wavefront][ta][lane]
+    constexpr int NOL = NO / NSC;                  // gradient channels of this workgroup: [mo, mo + NOL)
+    constexpr int UB = 2 * NOL * LENP;             // a row buffer of the gradient: [2][NOL][LENP]
+    constexpr int NI1 = 2 * B * NOL, NI2 = 2 * NOL * A;
+    constexpr int NW1 = (NI1 + 63) / 64;           // group-0 wavefronts that have first-stage items
+    constexpr int SBG = NW1 * A * 64;              // gradient staging: [group-0 wavefront][ta][lane]
     constexpr int SBX = 8 * NI * 64;               // spectrum staging: [wavefront][n][lane]
-    constexpr int NI1 = 2 * B * NO, NI2 = 2 * NO * A;
     static_assert(LEN <= 256, "one bin pair per thread pair");
-    static_assert(NO % 2 == 0 && NI % 2 == 0 && A % 2 == 0, "16-byte DMA granules");
+    static_assert(NO % NSC == 0 && NOL % 2 == 0 && NI % 2 == 0 && A % 2 == 0, "16-byte DMA granules");
     static_assert(NI1 <= 256 && NI2 <= 256, "an FFT stage of one unit fits one group");
     cf* XF = reinterpret_cast<cf*>(smem);          // [2][UB]
     cf* Yb = XF + 2 * UB;
@@ -438,7 +440,7 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     const int P = a.L1 / 2 + 1;
     // XCD-aware order: the slices of a row pair on one XCD (it keeps a pair's partial planes' lines in one L2)
     const int xcd = blockIdx.x & 7, q_ = blockIdx.x >> 3;
-    const int r = (q_ / a.NS) * 8 + xcd, sl = q_ % a.NS;
+    const int r = (q_ / (a.NS * NSC)) * 8 + xcd, sl = (q_ / NSC) % a.NS, mo = (q_ % NSC) * NOL;
     if (r >= P) return;
     const int rm = (a.L1 - r) % a.L1;
     const bool selfm = rm == r;
@@ -449,9 +451,9 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     auto fetch_g = [&](int b) {          // group 0: the A x 64 first-stage inputs of this wavefront's own items
         const int wv = wave & 3, hi = lane >> 5;
         int item0 = 64 * wv + 2 * (lane & 31);
-        if (item0 >= NI1 || (item0 >= B * NO && selfm)) item0 = 0;
-        const int m0 = item0 % NO, tb = (item0 / NO) % B, slot = item0 / (NO * B);
-        const cf* src = a.Sg + (size_t)b * bstride_g + (size_t)(slot ? rm : r) * (a.L2 * NO) + ((hi * B + tb) * NO + m0);
+        if (item0 >= NI1 || (item0 >= B * NOL && selfm)) item0 = 0;
+        const int m0 = item0 % NOL, tb = (item0 / NOL) % B, slot = item0 / (NOL * B);
+        const cf* src = a.Sg + (size_t)b * bstride_g + (size_t)(slot ? rm : r) * (a.L2 * NO) + ((hi * B + tb) * NO + mo + m0);
 #pragma unroll
         for (int q = 0; q < A / 2; ++q) dma16(src + q * (2 * B * NO), sg_lds + (unsigned)(((wv * A + 2 * q) * 64) * 8));
     };
@@ -469,12 +471,13 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     bool dc = false;
     const bool valid = p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
     const int pc = p < LEN ? p : 0;
-    f2 acc[NO][NI];
+    f2 acc[NOL][NI];
 #pragma unroll
-    for (int m = 0; m < NO; ++m)
+    for (int m = 0; m < NOL; ++m)
 #pragma unroll
         for (int nn = 0; nn < NI; ++nn) acc[m][nn] = f2{0.f, 0.f};
-    if (grp == 0 && n_it > 0) fetch_g(b_lo);
+    const bool has_g = grp == 0 && (wave & 3) < NW1;             // this wavefront has first-stage items (and transfers their rows)
+    if (has_g && n_it > 0) fetch_g(b_lo);
     for (int j = tid; j < LEN; j += 512) {
         tw[j] = a.W[a.n + a.L1 + j];
         ws[j] = a.W[a.n + a.L1 + a.L2 + j];
@@ -487,7 +490,7 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     const float hg = 0.5f * a.scale_g;
     const float sc = dc ? hg : hg * (a.interior2_g ? 2.f : 1.f);
     const f2 scv = grp ? f2{sc, -sc} : f2{sc, sc};
-    const int yk_o = pc, ym_o = slotB * NO * LENP + colB;
+    const int yk_o = pc, ym_o = slotB * NOL * LENP + colB;
 
 #pragma unroll 1
     for (int t = 0; t < n_it + 2; ++t) {
@@ -496,11 +499,11 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
         // ---- step 1
         if (t >= 2) {
 #pragma unroll
-            for (int m = 0; m < NO; ++m)
+            for (int m = 0; m < NOL; ++m)
 #pragma unroll
                 for (int nn = 0; nn < NI; ++nn) asm volatile("" : "+v"(acc[m][nn]));
-            // this wavefront's spectrum block of item t-2 has landed (behind it in the queue: group 0's newer row pieces)
-            if (grp == 0 && g_pending) __builtin_amdgcn_s_waitcnt(0x0F70 | (A / 2));
+            // this wavefront's spectrum block of item t-2 has landed (behind it in the queue: its own newer row pieces)
+            if (has_g && g_pending) __builtin_amdgcn_s_waitcnt(0x0F70 | (A / 2));
             else wait_vm0();
         }
         f2 x[NI];
@@ -515,7 +518,7 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
         }
         if (t >= 2 && valid) {
 #pragma unroll
-            for (int m = 0; m < NO; ++m) {
+            for (int m = 0; m < NOL; ++m) {
                 const f2 zk = v2(Yb[yk_o + m * LENP]), zm = v2(Yb[ym_o + m * LENP]);
                 const f2 Pp = f2{zk.x + zm.x, zk.y - zm.y}, D = f2{zk.x - zm.x, zk.y + zm.y};
                 const f2 g = scv * (Pp + cmulc(D, iws, niws));
@@ -527,9 +530,9 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
         lds_barrier();
         // ---- step 2
         if (grp == 0) {
-            if (t < n_it) {              // P1(t): first stage of the gradient rows, staging -> XF[t & 1].  item = (m fastest, tb, slot)
+            if (t < n_it && has_g) {     // P1(t): first stage of the gradient rows, staging -> XF[t & 1].  item = (m fastest, tb, slot)
                 const int item = opaque(tid) & 255;
-                const int m = item % NO, tb = (item / NO) % B, slot = item / (NO * B);
+                const int m = item % NOL, tb = (item / NOL) % B, slot = item / (NOL * B);
                 const bool have = item < NI1 && !(slot && selfm);
                 cf v[A], tt[A];
                 // this wavefront's rows of item t have landed (behind them in the queue: the spectrum pieces just requested)
@@ -546,7 +549,7 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
                 }
                 if (have) {
                     RegFFT<float, A, false>::run(v);
-                    cf* uu = XF + (t & 1) * UB + (slot * NO + m) * LENP + tb;
+                    cf* uu = XF + (t & 1) * UB + (slot * NOL + m) * LENP + tb;
                     uu[0] = v[0];
 #pragma unroll
                     for (int ka = 1; ka < A; ++ka) uu[ka * B] = v[ka] * tt[ka];
@@ -554,14 +557,14 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
             }
         } else if (t >= 1 && t <= n_it) {     // P2(t-1): second stage XF[(t-1) & 1] -> Y.  item = (m fastest, ka, slot)
             const int item = opaque(tid) & 255;
-            const int m = item % NO, ka = (item / NO) % A, slot = item / (NO * A);
+            const int m = item % NOL, ka = (item / NOL) % A, slot = item / (NOL * A);
             if (item < NI2 && !(slot && selfm)) {
                 cf v[B];
-                const cf* xr = XF + ((t - 1) & 1) * UB + (slot * NO + m) * LENP + ka * B;
+                const cf* xr = XF + ((t - 1) & 1) * UB + (slot * NOL + m) * LENP + ka * B;
 #pragma unroll
                 for (int tb = 0; tb < B; ++tb) v[tb] = xr[tb];
                 RegFFT<float, B, false>::run(v);
-                cf* yr = Yb + (slot * NO + m) * LENP + ka;
+                cf* yr = Yb + (slot * NOL + m) * LENP + ka;
 #pragma unroll
                 for (int kb = 0; kb < B; ++kb) yr[A * kb] = v[kb];
             }
@@ -576,8 +579,8 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
             cf* out = a.dH + (size_t)sl * a.ds_s;
             const unsigned bin = grp ? im : ik;
 #pragma unroll
-            for (int m = 0; m < NO; ++m) {
-                unsigned o = 8u * ((unsigned)m * (unsigned)a.ds_m + bin);
+            for (int m = 0; m < NOL; ++m) {
+                unsigned o = 8u * ((unsigned)(mo + m) * (unsigned)a.ds_m + bin);
                 const unsigned step = 8u * (unsigned)a.ds_n;
 #pragma unroll
                 for (int nn = 0; nn < NI; ++nn) {
@@ -605,6 +608,7 @@ static int g_walk = 1;            // 0: off (spec_mid only); 1: on for the shape
 static int g_walk_wgs = 0;        // workgroups of the forward walking kernel (0: one per CU)
 static int g_walk_slices = 0;     // batch slices of the backward walking kernel (0: CUs / row pairs)
 static long long* g_walk_times = nullptr;
+static int g_walk_nsc = 2;        // output-channel groups of the backward kernel (tuning: fl_debug_set_walk mode 14 -> 4)
 
 static int device_cus() {
     static int cus = 0;
@@ -646,6 +650,7 @@ using namespace fl;
 extern "C" {
 
 int fl_debug_set_walk(int mode, int wgs, int slices, void* times) {
+    g_walk_nsc = mode == 14 ? 4 : 2;
     g_walk = mode;
     g_walk_wgs = wgs;
     g_walk_slices = slices;
@@ -663,8 +668,11 @@ int fl_spec_gradh_slices(int nfft, int Bn) {
     int l1, l2;
     if (spec_plan(nfft, l1, l2) != FL_OK || Bn <= 0) return 0;
     if (g_walk_slices > 0) return g_walk_slices < Bn ? g_walk_slices : Bn;
+    // the gradient kernel splits a row pair's work over the output channels first (two workgroups per row pair, no
+    // partial sums); batch slices only beyond that
     const int P = l1 / 2 + 1;
-    int ns = device_cus() / P;              // whole workgroups per CU: one
+    int ns = device_cus() / (2 * P);
+    if (g_walk_nsc == 4) ns = 1;
     if (ns < 1) ns = 1;
     return ns < Bn ? ns : Bn;
 }
@@ -683,19 +691,25 @@ int fl_spec_gradh_walk_f32(const void* Sg, const void* Xp, void* dH_parts, long 
     a.scale_g = (float)scale_g; a.interior2_g = interior2_g;
     FL_REQUIRE((size_t)NO * (size_t)ds_m * 8ull < (1ull << 32), "spec_gradh_walk: a partial plane set exceeds 32-bit offsets");
     const int P = a.L1 / 2 + 1;
-    const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * n_slices);
     hipStream_t st = (hipStream_t)stream;
     if (a.L2 == 240 && NI == 8 && NO == 8) {
-        constexpr int A = 16, B = 15, LEN = A * B, LENP = walk_pitch(LEN);
-        constexpr size_t lds = ((size_t)3 * 2 * 8 * LENP + 4 * A * 64 + 8 * 8 * 64 + 2 * LEN) * sizeof(cf);
-        static_assert(lds <= 160 * 1024, "LDS budget");
-        auto kern = spec_gradh_walk<16, 15, 8, 8, 2>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, a);
+#define FL_GRADH(NSC_, OCC_)                                                                                                     \
+    {                                                                                                                            \
+        constexpr int A = 16, B = 15, LEN = A * B, LENP = walk_pitch(LEN), NOL = 8 / NSC_;                                       \
+        constexpr size_t lds = ((size_t)3 * 2 * NOL * LENP + ((2 * B * NOL + 63) / 64) * A * 64 + 8 * 8 * 64 + 2 * LEN) * sizeof(cf); \
+        static_assert(lds <= 160 * 1024, "LDS budget");                                                                          \
+        const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * n_slices * NSC_);                                                    \
+        auto kern = spec_gradh_walk<16, 15, 8, 8, NSC_, OCC_>;                                                                   \
+        static bool attr_set = false;                                                                                            \
+        if (!attr_set) {                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                                     \
+        }                                                                                                                        \
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, a);                                                             \
+    }
+        // output channels of a row pair over 2 workgroups (one per CU) or, tuning, over 4 (two per CU)
+        if (g_walk_nsc == 4) FL_GRADH(4, 4) else FL_GRADH(2, 2)
+#undef FL_GRADH
     } else {
         set_error("spec_gradh_walk: no kernel for nfft=%d, %d -> %d channels", nfft, NI, NO);
         return FL_ERR_UNSUPPORTED;

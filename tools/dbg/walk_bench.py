@@ -118,7 +118,7 @@ for r in (1, 7, 57, 99):
     gotm = Xpv[r, :, 1].reshape(B, N, L2)
     print(f"pair-major spectrum row pair {r}: k {rel(torch.view_as_real(got), torch.view_as_real(want)):.2e}  L-k {rel(torch.view_as_real(gotm), torch.view_as_real(wantm)):.2e}")
 for ns in [int(v) for v in args.slices.split(",")]:
-    L.fl_debug_set_walk(1, 0, ns, None)
+    L.fl_debug_set_walk(14 if ns == 4 else 1, 0, 0 if ns == 4 else ns, None)      # "4": four output-channel groups per row pair
     nsl = L.fl_spec_gradh_slices(nfft, B)
     parts = torch.full((nsl, N, N, P), float("nan"), dtype=torch.complex64, device=dev)
     out = torch.empty((N, N, P), dtype=torch.complex64, device=dev)
