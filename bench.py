@@ -313,7 +313,7 @@ def main():
         inside the timed region's closing fence."""
         from flamo_amd import dist as fd
         pending.append(fd.all_reduce_grads(params, async_op=True))
-        while len(pending) > 2:                         # the flat buffer is shared: keep the queue short
+        while len(pending) > 1:                         # one collective in flight per parameter set (dist.all_reduce_grads)
             pending.pop(0)()
 
     step = eager_step

@@ -26,11 +26,37 @@ def _graph_packets_off() -> bool:
     return _user_setting == "0" or (_user_setting is None and not _RUNTIME_WAS_UP)
 
 
-try:
-    import torch as _torch
-    _RUNTIME_WAS_UP = bool(_torch.cuda.is_initialized())
-except Exception:       # pragma: no cover
-    _RUNTIME_WAS_UP = False
+def _hip_runtime_loaded_and_used() -> bool:
+    """Has this process already initialised the HIP runtime?  torch.cuda.is_initialized() misses torch.cuda.is_available() /
+    device_count(), which call hipGetDeviceCount -- that brings the runtime up (and parses the DEBUG_CLR_* switches) without
+    setting torch's lazy-init flag.  The runtime opens the compute driver's device node when it comes up and never closes
+    it: an open /dev/kfd among this process's descriptors is the tell-tale."""
+    try:
+        import torch
+        if torch.cuda.is_initialized():
+            return True
+    except Exception:       # pragma: no cover
+        pass
+    try:
+        for fd in _os.listdir("/proc/self/fd"):
+            try:
+                if _os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                    return True
+            except OSError:
+                continue
+    except OSError:         # pragma: no cover
+        pass
+    return False
+
+
+_RUNTIME_WAS_UP = _hip_runtime_loaded_and_used()
+if _RUNTIME_WAS_UP and _user_setting is None:
+    import warnings as _warnings
+    _warnings.warn("flamo_amd was imported after the HIP runtime came up (a torch.cuda call ran first): "
+                   "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 can no longer take effect in this process, and replayed HIP graphs that "
+                   "mix this library's kernels with torch reductions may return wrong reduction values after eager launches "
+                   "between replays.  Import flamo_amd before the first torch.cuda call, or export the variable.",
+                   RuntimeWarning, stacklevel=2)
 
 from . import _lib, functional, ops, utils  # noqa: F401
 from .processor import dsp, system  # noqa: F401

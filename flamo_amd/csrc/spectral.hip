@@ -829,7 +829,18 @@ int fl_spec_supports(int nfft, int n_in, int n_out) {
     auto ok = [](int c) { return c == 2 || c == 4 || c == 8 || c == 16; };
     if (!ok(n_in) || !ok(n_out)) return 0;
     if (n_in != n_out && (n_in > 8 || n_out > 8)) return 0;
-    return 1;
+    // the row kernel holds a row pair of all channels in LDS: (2 max(n_in, n_out) (L2 | 1) + 2 L2 + ...) complex values --
+    // 131 KB at 16 channels, nfft = 384000; a part with less LDS per workgroup than that takes the layered route
+    static int lds_limit = 0;
+    if (!lds_limit) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+            v = 64 * 1024;
+        lds_limit = v;
+    }
+    const int nch = n_in > n_out ? n_in : n_out;
+    const size_t need = ((size_t)2 * nch * (l2 | 1) + 2 * (size_t)l2 + 64 + nch) * sizeof(cf);
+    return need <= (size_t)lds_limit ? 1 : 0;
 }
 
 int fl_debug_set_spec_times(void* buf) {

@@ -132,8 +132,13 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
             for n in key[2]:
                 views.append(flat[off:off + n])
                 off += n
-            ent = _flat_cache[key] = (flat, views)
-        flat, views = ent
+            ent = _flat_cache[key] = [flat, views, None]
+        flat, views, outstanding = ent
+        if outstanding is not None:
+            # an earlier asynchronous call on this buffer has not been finished: its collective may still be reading and
+            # writing the buffer this call is about to refill.  Finish it first (sums back into ITS gradients) -- at most
+            # one collective per parameter set is ever in flight.
+            outstanding()
         grads = [p.grad.reshape(-1) for p in plist]
         torch._foreach_copy_(views, grads)
         if _host_staged(flat, group):
@@ -143,10 +148,17 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
             work = None
         else:
             work = dist.all_reduce(flat, group=group, async_op=async_op)
-        pending.append((work, views, plist))
+        pending.append((work, views, plist, ent))
+
+    done = [False]
 
     def finish():
-        for work, views, plist in pending:
+        if done[0]:
+            return
+        done[0] = True
+        for work, views, plist, ent in pending:
+            if ent[2] is finish:
+                ent[2] = None
             if work is not None:
                 work.wait()
             dst, src = [], []
@@ -160,6 +172,8 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
                 torch._foreach_copy_(dst, src)
 
     if async_op:
+        for _, _, _, ent in pending:
+            ent[2] = finish
         return finish
     finish()
     return None

@@ -1709,9 +1709,16 @@ def geq_cascade_apply(x, consts, X, gamma: float, nfft: int, dtype=torch.float32
     return _GeqCascadeApply.apply(x, consts, X, float(gamma), int(nfft), dtype, gain_map == "sigmoid")
 
 
-def cascade_rc_supported(real: torch.dtype, n_in: int) -> bool:
-    """cascade response times a real constant matrix with n_in columns: fused backward available"""
-    return real == torch.float32 and SOS_BWD_MIXED and int(n_in) in (2, 4, 8, 16)
+def cascade_rc_supported(real: torch.dtype, n_in: int, n_mid: int = 1, n_sections: int = 1) -> bool:
+    """cascade response (n_mid cascades of n_sections per output row) times a real constant matrix with n_in columns: the
+    fused operator exists -- float32, 2/4/8/16 columns, and fl_sos_response_rc_c64's own limits (n_mid <= 32, <= 64 sections,
+    coefficient tables of one output row within the default 64 KB of dynamic LDS: n_mid * 6 * sections doubles)."""
+    if not (real == torch.float32 and SOS_BWD_MIXED and int(n_in) in (2, 4, 8, 16)):
+        return False
+    n_mid, n_sections = int(n_mid), int(n_sections)
+    if n_mid < 1 or n_mid > 32 or n_sections < 1 or n_sections > 64:
+        return False
+    return n_mid * 6 * n_sections * 8 + n_mid * int(n_in) * 4 <= 64 * 1024
 
 
 def _cascade_rc_forward(b, a, Wr, gamma, nfft, real, float_eval):

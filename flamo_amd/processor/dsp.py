@@ -125,15 +125,21 @@ def _cached_integer_delay(module, param, samples_fn):
     eight parameter-sized launches in front of the kernel (cast, round, pow, casts) were a tenth of a batch-1 FDN step.
     (In-place edits through `param.data` do not move the version counter; use assign_value / copy_ under no_grad.)"""
     import weakref
+    # While a HIP graph is being captured the cache is neither read nor written: a hit would record NO kernel, so the graph
+    # would read an eager-pool tensor that the next eager call with another key (bin order, shard, bumped version) frees --
+    # and its replays would ignore a later assign_value.  Inside a capture the kernel is launched, recorded, and its
+    # output lives in the graph's own pool.
+    capturing = param.is_cuda and torch.cuda.is_current_stream_capturing()
     key = (param._version, ops.bin_shard(module.nfft), ops.bin_order(module.nfft), param.device, param.dtype)
     hit = module.__dict__.get("_int_delay_cache")
-    if hit is not None and hit[0]() is param and hit[1] == key:
+    if not capturing and hit is not None and hit[0]() is param and hit[1] == key:
         return hit[2]
     with torch.no_grad():
         mi = samples_fn().round()             # half-to-even, as torch.round in the reference
         amp = (module._gamma_f ** mi).to(module.dtype)
         H = ops.delay_response(mi.to(torch.int64), amp, module.nfft)
-    module.__dict__["_int_delay_cache"] = (weakref.ref(param), key, H)
+    if not capturing:
+        module.__dict__["_int_delay_cache"] = (weakref.ref(param), key, H)
     return H
 
 
@@ -569,11 +575,15 @@ class _SOSMixin:
     def _response_times_matrix(self, param, Wr):
         """freq_response(param) @ Wr (a real constant matrix on the right) as one operator whose backward folds the
         composition into the cascade kernel; None when this module / dtype has no such path."""
-        if self._diag or not param.is_cuda or not ops.cascade_rc_supported(self.dtype, Wr.shape[1]):
+        if self._diag or not param.is_cuda:
             return None
         if getattr(self, "_own_response", None) is not self.freq_response:
             return None
         spec = self._cascade_spec(param)
+        # sections, cascades per output row, columns of the constant factor: the fused operator's kernel limits (LDS tables)
+        n_sections = spec[1].shape[0] if spec[0] == "geq" else spec[1].shape[1]
+        if not ops.cascade_rc_supported(self.dtype, Wr.shape[1], Wr.shape[0], n_sections):
+            return None
         if spec[0] == "geq":
             return ops.geq_cascade_rc(spec[1], spec[2], Wr, self._gamma_f, self.nfft, dtype=self.dtype, gain_map=spec[3])
         return ops.sos_response_rc(spec[1], spec[2], Wr, self._gamma_f, self.nfft, dtype=self.dtype)

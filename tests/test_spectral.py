@@ -71,7 +71,10 @@ def test_transform_round_trip_and_spectrum(gpu, N, vt):
 
 
 @pytest.mark.parametrize("nfft,N,B", [(96000, 8, 3), (96000, 4, 2), (96000, 2, 5), (96000, 16, 2), (192000, 8, 2), (384000, 4, 2),
-                                      (192000, 16, 1), (384000, 2, 1)])
+                                      (192000, 16, 1), (384000, 2, 1), (384000, 16, 1),
+                                      # the batch-walking row kernels (csrc/specwalk.hip): 8 x 8 channels at nfft = 96000 from 4 items
+                                      # on -- a unit or two per workgroup (4, 7), row-pair changes inside a workgroup's range (33)
+                                      (96000, 8, 4), (96000, 8, 7), (96000, 8, 33)])
 def test_spectral_apply_against_torch_fft(gpu, nfft, N, B):
     from flamo_amd import ops
     torch.manual_seed(nfft + N)
@@ -95,29 +98,32 @@ def test_spectral_apply_against_torch_fft(gpu, nfft, N, B):
 @pytest.mark.parametrize("norm_f,norm_i,db_f,db_i,T", [("backward", "backward", 0.0, 30.0, 96000), ("ortho", "ortho", 30.0, 30.0, 96000),
                                                         ("forward", "forward", 30.0, 0.0, 96000), ("backward", "backward", 0.0, 0.0, 50001),
                                                         ("backward", "backward", 0.0, 0.0, 96017)])
-def test_spectral_apply_norms_envelopes_lengths(gpu, norm_f, norm_i, db_f, db_i, T):
+@pytest.mark.parametrize("N,B", [(4, 2), (8, 6)])        # (8, 6): through the batch-walking row kernels
+def test_spectral_apply_norms_envelopes_lengths(gpu, norm_f, norm_i, db_f, db_i, T, N, B):
     from flamo_amd import ops
-    nfft, N, B = 96000, 4, 2
+    nfft = 96000
     torch.manual_seed(T)
     M = nfft // 2 + 1
     x = torch.randn(B, T, N, device=gpu, requires_grad=True)
-    H = (torch.randn(M, N, N, device=gpu, dtype=torch.complex64) / N ** 0.5)
+    H = (torch.randn(M, N, N, device=gpu, dtype=torch.complex64) / N ** 0.5).requires_grad_(True)
     y = ops.spectral_apply(x, ops.permute_bins(H, nfft), nfft, norm_f, norm_i, db_f or None, db_i or None)
     c = torch.randn(B, nfft, N, device=gpu)
-    (gx,) = torch.autograd.grad((y * c).sum(), [x])
+    gx, gH = torch.autograd.grad((y * c).sum(), [x, H])
     assert gx.shape == x.shape
     xr = x.detach().cpu().double().requires_grad_(True)
+    Hr = H.detach().cpu().to(torch.complex128).requires_grad_(True)
     t = torch.arange(nfft, dtype=torch.float64)
     xx = xr[:, :nfft]
     if db_f:
         xx = xx * (10.0 ** (db_f / (20.0 * nfft) * t))[: xx.shape[1], None]
-    Y = torch.einsum("fmn,bfn->bfm", H.cpu().to(torch.complex128), torch.fft.rfft(xx, n=nfft, dim=1, norm=norm_f))
+    Y = torch.einsum("fmn,bfn->bfm", Hr, torch.fft.rfft(xx, n=nfft, dim=1, norm=norm_f))
     yr = torch.fft.irfft(Y, n=nfft, dim=1, norm=norm_i)
     if db_i:
         yr = yr * (10.0 ** (db_i / (20.0 * nfft) * t))[:, None]
-    (gxr,) = torch.autograd.grad((yr * c.cpu().double()).sum(), [xr])
+    gxr, gHr = torch.autograd.grad((yr * c.cpu().double()).sum(), [xr, Hr])
     assert relerr(y.detach().cpu(), yr.detach()) < TOL
     assert relerr(gx.cpu(), gxr) < TOL
+    assert relerr(gH.cpu(), gHr) < TOL
 
 
 def _config2(gpu, N, nfft, db=0.0):
