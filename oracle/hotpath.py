@@ -350,3 +350,44 @@ def fdn_forward(x, in_gain, out_gain, U_param, delays_s, nfft, alias_decay_db, f
     if output == "abs":
         return torch.abs(Y)
     return Y
+
+
+# --------------------------------------------------------------------------- the same responses on a subset of the bins
+# (full-size checks: at nfft = 384000 a 32 x 32 chain has 192001 loop matrices -- minutes and tens of GB on the CPU -- while
+# its bins are independent, so the oracle evaluates a sample of them.  The formulas are the ones above with the rfft of the
+# three taps / the phase ramp written out for the chosen bins k: sum_p c_p gamma^p exp(-j 2 pi k p / nfft).)
+
+
+def sos_response_at(b: torch.Tensor, a: torch.Tensor, nfft: int, gamma: torch.Tensor, bins: torch.Tensor) -> torch.Tensor:
+    """sos_response (dsp.py:1520-1526, 2587-2593) at the bins `bins` (int64, (nb,)): (nb, ...)."""
+    w = torch.exp(-2j * torch.pi * bins.to(torch.float64) / nfft).to(cdtype(gamma.dtype))       # (nb,)
+    zp = torch.stack([torch.ones_like(w), gamma * w, (gamma * w) ** 2], 0)                       # (3, nb): (gamma w)^p
+    shape = [3, -1] + [1] * (b.dim() - 1)
+    B = (b.to(gamma.dtype).unsqueeze(1) * zp.view(shape)).sum(0)                                 # (nb, n_sections, ...)
+    A = (a.to(gamma.dtype).unsqueeze(1) * zp.view(shape)).sum(0)
+    Bp, Ap = torch.prod(B, dim=1), torch.prod(A, dim=1)
+    H = Bp / Ap
+    return torch.where(torch.abs(Ap) != 0, H, torch.finfo(H.dtype).eps * torch.ones_like(H))
+
+
+def geq_response_at(param: torch.Tensor, nfft: int, gamma: torch.Tensor, bins: torch.Tensor, fs: int = 48000,
+                    octave_interval: int = 1, map_fn=None) -> torch.Tensor:
+    """geq_response (dsp.py:2563-2593) at the bins `bins`."""
+    cf, sc = eq_freqs(octave_interval)
+    gain_db = (20 * torch.log10(torch.abs(param))) if map_fn is None else map_fn(param)
+    b, a = geq_sos(gain_db, cf, sc, fs)
+    return sos_response_at(b, a, nfft, gamma, bins)
+
+
+def delay_response_at(m: torch.Tensor, nfft: int, gamma: torch.Tensor, bins: torch.Tensor) -> torch.Tensor:
+    """delay_response (dsp.py:3352-3374) at the bins `bins`, phase reduced exactly for integer m (delay_response_exact)."""
+    k = bins.to(torch.int64).view(-1, *([1] * m.dim()))
+    idx = (k * m.to(torch.int64).unsqueeze(0)) % nfft
+    ang = -2 * math.pi * idx.to(torch.float64) / nfft
+    g = gamma.to(torch.float64) ** m.to(torch.float64)
+    return torch.polar(g.expand_as(ang).contiguous(), ang)
+
+
+def recursion_at(F: torch.Tensor, Bk: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
+    """recursion (system.py:397-425) for responses already restricted to a subset of bins: F, Bk (nb, N, N), X (B, nb, N[, K])."""
+    return recursion(F, Bk, X)

@@ -230,3 +230,18 @@ def test_e7_biquad_training_oracle():
         losses.append(loss.item())
     assert relerr(torch.tensor(losses, dtype=torch.float64), a["losses"]) < 1e-9
     assert relerr(p.detach(), a["param"]) < 1e-8
+
+
+def test_sampled_bin_responses_equal_the_full_ones():
+    """The oracle's per-bin evaluators (used by the full-size config-5 check) against the golden-pinned full-length ones."""
+    torch.manual_seed(3)
+    nfft = 1500
+    gamma = O.gamma_of(30.0, nfft, torch.float64)
+    bins = torch.tensor([0, 1, 7, 333, 749, 750])
+    p = torch.rand(12, 3, 2, dtype=torch.float64) + 0.5
+    assert relerr(O.geq_response_at(p, nfft, gamma, bins), O.geq_response(p, nfft, gamma)[bins]) < 1e-10
+    m = torch.randint(1, 400, (3, 2)).double()
+    assert relerr(O.delay_response_at(m, nfft, gamma, bins), O.delay_response(m, nfft, gamma)[bins]) < 1e-12
+    b = torch.randn(3, 4, 2, dtype=torch.float64)
+    a = torch.randn(3, 4, 2, dtype=torch.float64) + torch.tensor([3.0, 0, 0]).view(3, 1, 1)
+    assert relerr(O.sos_response_at(b, a, nfft, gamma, bins), O.sos_response(b, a, nfft, gamma)[bins]) < 1e-10
