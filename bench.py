@@ -49,12 +49,33 @@ FP32_PEAK_TFLOPS = 157.3    # vector FP32, spec
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")   # written by tools/summarize_profiles.py from the two PMC passes
 
 
-def build_model(dev, dtype):
+FIXTURE = os.path.join(ROOT, "tests", "golden", "bench_params.npz")   # parameters drawn once by the reference's constructors, seed 130709
+
+
+def fixture_params():
+    """name -> float32 tensor (tools/gen_bench_fixture.py); {} when the fixture is missing (seeded draws are used then)."""
+    try:
+        import numpy as np
+        z = np.load(FIXTURE, allow_pickle=False)
+        return {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+    except Exception:           # noqa: BLE001
+        return {}
+
+
+def build_model(dev, dtype, db=0.0):
+    """BASELINE configs[1]; db > 0: the anti-aliased variant (FFTAntiAlias / iFFTAntiAlias, dsp.py:141-206)."""
     from flamo_amd.processor import dsp, system
-    kw = dict(nfft=NFFT, alias_decay_db=0.0, device=dev, dtype=dtype)
+    kw = dict(nfft=NFFT, alias_decay_db=db, device=dev, dtype=dtype)
     mat = dsp.Matrix(size=(NCH, NCH), matrix_type="random", requires_grad=True, **kw)
     geq = dsp.GEQ(size=(NCH, NCH), requires_grad=True, **kw)
+    fx = fixture_params()
+    if "c2_W" in fx:
+        mat.assign_value(fx["c2_W"].to(dev, dtype))
+        geq.assign_value(fx["c2_geq"].to(dev, dtype))
     core = system.Series(OrderedDict(mix=mat, eq=geq))
+    if db:
+        return system.Shell(core, dsp.FFTAntiAlias(NFFT, alias_decay_db=db, device=dev, dtype=dtype),
+                            dsp.iFFTAntiAlias(NFFT, alias_decay_db=db, device=dev, dtype=dtype)), [mat.param, geq.param]
     return system.Shell(core, dsp.FFT(NFFT, dtype=dtype), dsp.iFFT(NFFT, dtype=dtype)), [mat.param, geq.param]
 
 
@@ -135,6 +156,93 @@ def cpu_baseline(W, G, budget_s=45.0):
             "threads_probe_s_per_batch1_step": {str(k): round(v, 3) for k, v in probe.items()}, "os_cpu_count": ncpu,
             "sample": f"config 2 graph (nfft={NFFT}, {NCH}x{NCH}, float32) at batch {b} of {BATCH}, 1 warm-up + 3 timed steps, "
                       f"{dt:.2f} s/step, {cores} threads (fastest of the probe; os.cpu_count() = {ncpu}), torch {torch.__version__} CPU ops"}
+
+
+def cpu_baseline_fdn(budget_steps=3):
+    """BASELINE configs[2] on the host cores at FULL size (16 channels, nfft = 192000, batch 1, 30 dB, attenuation equaliser):
+    the oracle's torch-CPU graph, forward + backward, 1 warm-up + `budget_steps` timed steps (anchor 2.0 s/step)."""
+    from oracle import hotpath as O
+    fx = fixture_params()
+    N, nfft, db = 16, 192000, 30.0
+    g = torch.Generator().manual_seed(130709)
+    f32 = torch.float32
+    ps = [fx.get("c3_in_gain", torch.randn(N, 1, generator=g)), fx.get("c3_out_gain", torch.randn(1, N, generator=g)),
+          fx.get("c3_U", torch.randn(N, N, generator=g)), fx.get("c3_attn", torch.randn(12, N, generator=g) * 0.3 + 2)]
+    ps = [p.to(f32).requires_grad_(True) for p in ps]
+    delays_s = (fx.get("c3_delays", torch.tensor([503.0 + 140 * i for i in range(N)])) / 48000 * 100).to(f32)
+    x = torch.zeros(1, nfft, 1, dtype=f32)
+    x[:, 0] = 1
+    c = torch.randn(1, nfft, 1, generator=g)
+    amap = lambda p: 20 * torch.log10(torch.sigmoid(p))      # noqa: E731
+
+    def step():
+        y = O.fdn_forward(x, ps[0], ps[1], ps[2], delays_s, nfft, db, attn_param=ps[3], attn_map=amap)
+        torch.autograd.grad(torch.sum(y * c), ps)
+    step()
+    t0 = time.perf_counter()
+    for _ in range(budget_steps):
+        step()
+    dt = (time.perf_counter() - t0) / budget_steps
+    return {"value": (nfft // 2 + 1) / dt, "unit": "bin-solves/s", "s_per_step": round(dt, 3), "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"config 3 at full size (N=16, nfft={nfft}, batch 1, float32), 1 warm-up + {budget_steps} timed steps"}
+
+
+def cpu_baseline_config5(scale=20, budget_steps=1):
+    """The configs[4] structure on the host cores at nfft = 384000 / `scale` (the full size needs >= 56 GB and minutes
+    on the CPU; per-bin work is independent of nfft, so bin-solves/s carries over and s/step scales by `scale`).  The survey
+    suggests 38400 (scale 10): that is 37 s per step on 8 cores, over this command's time budget -- 19200 (scale 20) is timed."""
+    from oracle import hotpath as O
+    fx = fixture_params()
+    N, nfft, db = 32, 384000 // scale, 30.0
+    g = torch.Generator().manual_seed(130709)
+    f32 = torch.float32
+    geq = fx.get("c5_geq", torch.rand(12, N, N, generator=g) + 0.5).to(f32).requires_grad_(True)
+    gain = fx.get("c5_gain", torch.rand(N, generator=g) * 0.05 + 0.01).to(f32).requires_grad_(True)
+    U = fx.get("c5_U", torch.randn(N, N, generator=g)).to(f32).requires_grad_(True)
+    delay_s = fx.get("c5_delay_s", torch.randint(1, 2000, (N, N), generator=g).float() / 48000 * 100).to(f32)
+    x = torch.randn(1, nfft, N, generator=g) * 0.1
+    x[:, 0] += 1
+    c = torch.randn(1, nfft, N, generator=g)
+
+    def step():
+        gamma = O.gamma_of(db, nfft, f32)
+        X = O.mimo_full(O.geq_response(geq, nfft, gamma).to(torch.complex64), O.rfft(x, nfft, alias_decay_db=db))
+        m = O.delay_samples(delay_s, 48000, 100, True)
+        F = O.to_complex(gain).view(1, N, 1) * O.delay_response(m, nfft, gamma).to(torch.complex64)
+        Bk = O.to_complex(O.orthogonal(U)).unsqueeze(0).expand(F.shape[0], N, N)
+        y = O.irfft(O.recursion(F, Bk, X), nfft, alias_decay_db=db)
+        torch.autograd.grad(torch.sum(y * c), [geq, gain, U])
+    step()
+    t0 = time.perf_counter()
+    for _ in range(budget_steps):
+        step()
+    dt = (time.perf_counter() - t0) / budget_steps
+    return {"value": (nfft // 2 + 1) / dt, "unit": "bin-solves/s", "s_per_step": round(dt, 3), "scale_factor_to_full_size": scale,
+            "s_per_step_extrapolated_full_size": round(dt * scale, 2), "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"config-5 structure (32x32, anti-aliasing 30 dB, float32) at nfft={nfft} = 384000/{scale}, 1 warm-up + "
+                      f"{budget_steps} timed steps"}
+
+
+def config2_variants(dev, x, steps):
+    """configs[1] with impulse input (its spectrum is all ones: nothing may special-case it) and with 30 dB of
+    anti-aliasing (FFTAntiAlias / iFFTAntiAlias: the envelopes ride in the column passes) -- ms/step from graph replays."""
+    from flamo_amd import ops
+    out = {}
+    M = NFFT // 2 + 1
+    prod = 2 * BATCH * M * NCH * NCH
+    imp = torch.zeros_like(x)
+    imp[:, 0] = 1
+    torch.manual_seed(130709)
+    model, params = build_model(dev, torch.float32)
+    ms = _graph_ms(lambda xx: ops.mean_square(model(xx)), (imp,), params, steps)
+    out["impulse"] = {"ms_per_step": round(ms, 4), "products_per_s": prod / (ms * 1e-3)}
+    torch.manual_seed(130709)
+    model30, params30 = build_model(dev, torch.float32, db=30.0)
+    ms = _graph_ms(lambda xx: ops.mean_square(model30(xx)), (x,), params30, steps)
+    out["alias30_wgn"] = {"ms_per_step": round(ms, 4), "products_per_s": prod / (ms * 1e-3)}
+    ms = _graph_ms(lambda xx: ops.mean_square(model30(xx)), (imp,), params30, steps)
+    out["alias30_impulse"] = {"ms_per_step": round(ms, 4), "products_per_s": prod / (ms * 1e-3)}
+    return out
 
 
 # ----------------------------------------------------------------------------- secondary workloads (one GPU)
@@ -264,9 +372,30 @@ def bin_sharded(dev, model, params, x, steps):
                                                                                   "(49 MB), 1 flat gradient all-reduce"}}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_plan(gpus, argv, env=None, port=None):
+    """What `bench.py --gpus N` does when it is NOT already running under a launcher: the command it re-executes itself
+    with (one rank per GPU over RCCL, rendezvous on 127.0.0.1) and the rank-specific environment every rank will see."""
+    env = os.environ if env is None else env
+    port = int(env.get("MASTER_PORT") or port or _free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in argv if a != "--dry-launch"]
+    ranks = [{"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+              "device": f"cuda:{r}"} for r in range(gpus)]
+    return {"cmd": cmd, "ranks": ranks, "backend": "nccl (RCCL)", "env_common": {"HSA_ENABLE_IPC_MODE_LEGACY": env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="print the multi-rank launch (command, per-rank environment) as JSON and exit; nothing is run")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -278,9 +407,31 @@ def main():
     args = ap.parse_args()
     warnings.simplefilter("ignore")
 
+    # ---- one rank per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE) this process IS a rank; started bare with
+    # --gpus N > 1 it launches the N ranks itself and becomes their launcher.  Either way the line printed carries
+    # n_gpus == --gpus, or nothing is printed at all.
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if args.dry_launch:
+        plan = launch_plan(args.gpus, sys.argv[1:]) if (args.gpus > 1 and not launched) else \
+            {"cmd": None, "ranks": [{"RANK": os.environ.get("RANK", "0"), "LOCAL_RANK": os.environ.get("LOCAL_RANK", "0"),
+                                     "WORLD_SIZE": os.environ.get("WORLD_SIZE", "1")}], "note": "runs in this process"}
+        print(json.dumps(plan))
+        return
+    if not launched and args.gpus > 1:
+        plan = launch_plan(args.gpus, sys.argv[1:])
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+        sys.exit(subprocess.call(plan["cmd"], env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); refusing to report a line "
+                 f"whose n_gpus differs from --gpus")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and torch.cuda.device_count() < world and os.environ.get("BENCH_ALLOW_SHARED_GPU") != "1":
+        sys.exit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()}")
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the env hook runs the collective path with one rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -404,6 +555,9 @@ def main():
             f"spec_mid[{NCH}->{NCH},H,inv,spec]": 3 * sig + hb,               # scratch in; spectrum (kept for backward), scratch out; H
             f"spec_mid[{NCH}->{NCH},spec]": 2 * sig,                          # backward: scratch in, dL/dY out
             "spec_cols_inv": 2 * sig,
+            f"spec_mid_walk[{NCH}->{NCH},spec]": 3 * sig + hb,                # scratch in; scratch out, spectrum kept for backward; H
+            f"spec_mid_walk[{NCH}->{NCH}]": 2 * sig + hb,
+            "spec_gradh_walk": 2 * sig + hb,                                 # gradient scratch in, kept spectrum in, dL/dH out
             f"mimo_gradh[cols={BATCH},{NCH}x{NCH}]": 2 * sig + hb,
             "mean_square": sig, "mean_square_bwd": 2 * sig,
             "sos_response_rc": 2 * hb, "sos_response_bwd_rc": 2 * hb,
@@ -423,7 +577,10 @@ def main():
         except Exception:           # noqa: BLE001 -- no profile committed yet
             pass
         roof = None
-        key = f"spec_mid[{NCH}->{NCH},H,inv,spec]"
+        key = f"spec_mid_walk[{NCH}->{NCH},spec]"
+        walk = key in timers
+        if not walk:
+            key = f"spec_mid[{NCH}->{NCH},H,inv,spec]"
         fused = key in timers
         if not fused:
             key = f"mimo_bin_fwd[cols={BATCH},{NCH}x{NCH}]"
@@ -434,7 +591,10 @@ def main():
             # per-bin product (2 sig + H), pre-step/column pass of the inverse (2 sig)
             layered = 6 * sig + hb
             roof = {"bound": "hbm",
-                    "kernel": ("spec_mid<16,15,8,8>: forward row FFTs + real-FFT split step + per-bin complex einsum Y[b,f,:] = H[f] X[b,f,:] "
+                    "kernel": ("spec_mid_walk<16,15,8,8>: forward row FFTs + real-FFT split step + per-bin complex einsum Y[b,f,:] = H[f] X[b,f,:] "
+                               "(H = GEQ[f] @ Matrix, the row pair's slice held in registers while one workgroup per CU walks the batch) + "
+                               "Hermitian pre-step + inverse row FFTs, in one kernel" if walk else
+                               "spec_mid<16,15,8,8>: forward row FFTs + real-FFT split step + per-bin complex einsum Y[b,f,:] = H[f] X[b,f,:] "
                                "(H = GEQ[f] @ Matrix) + Hermitian pre-step + inverse row FFTs of one batch item's row pair, in one kernel"
                                if fused else "mimo_full_kernel<float,8,4>: Y[b,f,:] = H[f] X[b,f,:] over the whole batch"),
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -444,7 +604,8 @@ def main():
                     "layered_route_equivalent_GBs": (layered / (mean_ms * 1e-3) / 1e9) if fused else None,
                     "events": f"HIP events on the launch stream, {roof_steps} eager steps run by this command right after the timed graph "
                               "replays, each timed launch queued behind ~0.2 ms of streaming copies (busy queue, cold infinity cache)",
-                    "traffic_source": (traffic or {}).get("source", "no PMC profile committed for this kernel yet")}
+                    "traffic_source": (traffic or {}).get("source", "no PMC profile committed for this kernel yet"),
+                    "traffic_profile_commit": (traffic or {}).get("commit")}
         unfused_bytes = (2 * sig + hb) + (3 * sig + 2 * hb) + (2 * sig) + (3 * sig)      # GEQ fwd/bwd + Matrix fwd/bwd
         fused_bytes = sum(alg.get(k, 0) * v["launches_per_step"] for k, v in kernels.items())
         out = {"metric": "freq-bin*channel products/sec (fwd+bwd), nfft=96000 8x8ch", "value": products_per_step / (ms * 1e-3),
@@ -473,12 +634,24 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["input_grad"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             try:
+                out["variants"] = config2_variants(dev, x, args.steps)
+            except Exception as e:  # noqa: BLE001
+                out["variants"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:
                 out["secondary"] = secondary(dev)
             except Exception as e:  # noqa: BLE001
                 out["secondary"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             out["device"] = device_info(dev)
+        out["params"] = "tests/golden/bench_params.npz (reference constructors, seed 130709)" if fixture_params() else "seeded draws (fixture missing)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(params[0], params[1])
+            if isinstance(out.get("secondary"), dict) and "error" not in out["secondary"]:
+                try:        # configs[2] at full size and the configs[4] structure at 1/10 length, same thread count
+                    torch.set_num_threads(out["cpu_baseline"]["cores"])
+                    out["secondary"]["config3_fdn16_batch1"]["cpu_baseline"] = cpu_baseline_fdn()
+                    out["secondary"]["config5_chain_32x32"]["cpu_baseline"] = cpu_baseline_config5()
+                except Exception as e:  # noqa: BLE001
+                    out["secondary"]["cpu_baseline_error"] = f"{type(e).__name__}: {e}"[:300]
         print(json.dumps(out))
     if dist_on:
         dist.barrier()

@@ -75,11 +75,19 @@ def main():
         c = [r for r in rows if pat in r[0]]
         c.sort(key=lambda r: -r[5])
         return c[0] if c else None
-    tags = {"spec_mid[8->8,H,inv,spec]": "spec_mid<16, 15, 8, 8, true, true", "spec_mid[8->8,spec]": "spec_mid<16, 15, 8, 8, false, false",
+    tags = {"spec_mid_walk[8->8,spec]": "spec_mid_walk<16, 15, 8, 8", "spec_gradh_walk": "spec_gradh_walk<16, 15, 8, 8",
+            "spec_mid[8->8,H,inv,spec]": "spec_mid<16, 15, 8, 8, true, true", "spec_mid[8->8,spec]": "spec_mid<16, 15, 8, 8, false, false",
             "spec_cols_fwd": "spec_cols_fwd<", "spec_cols_inv": "spec_cols_inv<", "mimo_gradh[cols=32,8x8]": "mimo_gradh_kernel<float, 4, 4>",
             "sos_response_rc": "sos_response_rc_kernel", "sos_response_bwd_rc": "sos_response_bwd_mixed_kernel", "mimo_full": "mimo_full_kernel<float, 8, 4, 1, false>"}
     traffic = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 3`, FETCH_SIZE doubled per "
                          f"MI355X_MICROARCH.md; profiles/{tag}_pmc_hbm_traffic.csv"}
+    try:        # which code the counters were taken on: the hash and whether the tree was clean when this summary was written
+        import subprocess
+        head = subprocess.run(["git", "rev-parse", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "flamo_amd", "bench.py"], cwd=ROOT, capture_output=True, text=True).stdout.strip())
+        traffic["commit"] = head + ("+uncommitted changes" if dirty else "")
+    except Exception:           # noqa: BLE001
+        traffic["commit"] = None
     for k, pat in tags.items():
         r = largest(pat)
         if r:
@@ -100,7 +108,7 @@ def main():
                 m = {c: (sum(v.get(c, [0])) / max(len(v.get(c, [1])), 1)) for c in names}
                 wr.writerow([k[:120], n] + ["%.0f" % m[c] for c in names] +
                             ["%.3f" % (m["SQ_ACTIVE_INST_VALU"] / max(m["SQ_WAVE_CYCLES"], 1)), "%.3f" % (m["SQ_LDS_BANK_CONFLICT"] / max(m["SQ_LDS_IDX_ACTIVE"], 1))])
-    big = [r for r in rows if "spec_mid<" in r[0]]
+    big = [r for r in rows if "spec_mid" in r[0]]
     big.sort(key=lambda r: -r[5])
     if big:
         print("dominant kernel traffic (largest spec_mid launch):", big[0][0][:60], "grid", big[0][1], "bytes %.4g" % big[0][5])
