@@ -638,24 +638,27 @@ __global__ void __launch_bounds__(256) permute_bins_kernel(const cf* __restrict_
 }
 
 // ---------------------------------------------------------------- host side
-struct Split { int len, A, B; };
-static const Split kSplits[] = {{200, 8, 25}, {240, 16, 15}, {300, 12, 25}, {320, 16, 20}, {400, 16, 25}, {480, 32, 15}};
-static const Split* split_of(int len) {
-    for (const Split& s : kSplits)
-        if (s.len == len) return &s;
+// (nfft, L1, L2): nfft/2 = L1 L2, column length x row length, both products of two in-register FFT sizes with factors 2, 3,
+// 5 (launch_cols / launch_mid below), L2 >= L1 so that a row pair of all channels stays small.  The three BASELINE lengths
+// carry every channel combination and the tuning variants; the others -- the reference's default 2^11 (dsp.py:84), the
+// powers of two up to 2^17, 48000 and 144000 (one and three seconds at 48 kHz) -- the equal-channel kernels.
+struct PlanEntry { int nfft, L1, L2, lean; };
+static const PlanEntry kPlans[] = {{96000, 200, 240, 0}, {192000, 300, 320, 0}, {384000, 400, 480, 0},
+                                   {2048, 32, 32, 1},    {4096, 32, 64, 1},     {8192, 64, 64, 1},     {16384, 64, 128, 1},
+                                   {32768, 128, 128, 1}, {65536, 128, 256, 1},  {131072, 256, 256, 1}, {48000, 150, 160, 1},
+                                   {144000, 225, 320, 1}};
+static const PlanEntry* plan_of(int nfft) {
+    for (const PlanEntry& p : kPlans)
+        if (p.nfft == nfft) return &p;
     return nullptr;
 }
 
 int spec_plan(int nfft, int& L1, int& L2) {
-    // (L1, L2): column length x row length; both must be fast-split lengths and L2 >= L1 so a row pair of all channels
-    // stays small
-    static const int pairs[][2] = {{200, 240}, {300, 320}, {400, 480}};
-    for (auto& p : pairs)
-        if (2L * p[0] * p[1] == nfft) {
-            L1 = p[0];
-            L2 = p[1];
-            return FL_OK;
-        }
+    if (const PlanEntry* p = plan_of(nfft)) {
+        L1 = p->L1;
+        L2 = p->L2;
+        return FL_OK;
+    }
     set_error("spectral: nfft=%d has no fused plan", nfft);
     return FL_ERR_UNSUPPORTED;
 }
@@ -686,7 +689,7 @@ static int cols_setup(ColsArgs& a, int nfft, int Bn, int t_len, int t_lim, int G
     return FL_OK;
 }
 
-template <int A, int B>
+template <int A, int B, bool LEAN = false>
 static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStream_t st) {
     constexpr int LEN = A * B, LENP = LEN | 1;
 #define FL_COLS(VT_, RG_)                                                                                        \
@@ -698,11 +701,15 @@ static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStrea
         else hipLaunchKernelGGL((spec_cols_fwd<A, B, VT_, RG_, false>), dim3(nblk), dim3(256), lds, st, a);      \
     }
     const int vt = a.CT << a.cgs;
-    if (vt == 32) {
-        const int rg = cols_rg(32, a.L1);
-        if (rg == 1) FL_COLS(32, 1) else if (rg == 4) FL_COLS(32, 4) else FL_COLS(32, 2)
+    if constexpr (LEAN) {      // one load-group choice per tile width
+        if (vt == 32) FL_COLS(32, 2) else FL_COLS(16, 2)
     } else {
-        if (cols_rg(16, a.L1) == 1) FL_COLS(16, 1) else FL_COLS(16, 2)
+        if (vt == 32) {
+            const int rg = cols_rg(32, a.L1);
+            if (rg == 1) FL_COLS(32, 1) else if (rg == 4) FL_COLS(32, 4) else FL_COLS(32, 2)
+        } else {
+            if (cols_rg(16, a.L1) == 1) FL_COLS(16, 1) else FL_COLS(16, 2)
+        }
     }
 #undef FL_COLS
 }
@@ -714,6 +721,12 @@ static int cols_launch(bool inverse, const ColsArgs& a, int Bn, hipStream_t st) 
         case 200: launch_cols<8, 25>(inverse, a, (unsigned)nblk, st); break;
         case 300: launch_cols<12, 25>(inverse, a, (unsigned)nblk, st); break;
         case 400: launch_cols<16, 25>(inverse, a, (unsigned)nblk, st); break;
+        case 32: launch_cols<8, 4, true>(inverse, a, (unsigned)nblk, st); break;
+        case 64: launch_cols<8, 8, true>(inverse, a, (unsigned)nblk, st); break;
+        case 128: launch_cols<16, 8, true>(inverse, a, (unsigned)nblk, st); break;
+        case 150: launch_cols<10, 15, true>(inverse, a, (unsigned)nblk, st); break;
+        case 225: launch_cols<15, 15, true>(inverse, a, (unsigned)nblk, st); break;
+        case 256: launch_cols<16, 16, true>(inverse, a, (unsigned)nblk, st); break;
         default: set_error("spectral cols: unsupported column length %d", a.L1); return FL_ERR_UNSUPPORTED;
     }
     FL_CHECK_LAUNCH(inverse ? "spec_cols_inv" : "spec_cols_fwd");
@@ -778,6 +791,35 @@ static void launch_mid_n(const MidArgs& a, unsigned, hipStream_t st) {
     launch_mid_bg<A, B, NI, NO, 1, 1>(a, st);
 }
 
+// equal channel counts, one batch item per workgroup, no tuning variants (the lengths beyond the three BASELINE ones)
+template <int A, int B, int N>
+static void launch_mid_lean_n(const MidArgs& a, hipStream_t st) {
+    constexpr int LEN = A * B, LENP = LEN | 1;
+    const size_t lds = ((size_t)2 * N * LENP + 2 * LEN + 2 * B + N) * sizeof(cf);
+    const int P = a.L1 / 2 + 1;
+    const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * a.Bn);
+    if (a.S2) {
+        if (a.H) hipLaunchKernelGGL((spec_mid<A, B, N, N, true, true, 1, 1, 0>), dim3(nblk), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((spec_mid<A, B, N, N, false, true, 1, 1>), dim3(nblk), dim3(256), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((spec_mid<A, B, N, N, false, false, 1, 1>), dim3(nblk), dim3(256), lds, st, a);
+    }
+}
+
+template <int A, int B>
+static int launch_mid_lean(const MidArgs& a, int NI, int NO, hipStream_t st) {
+    if (NI == NO) {
+        switch (NI) {
+            case 2: launch_mid_lean_n<A, B, 2>(a, st); return FL_OK;
+            case 4: launch_mid_lean_n<A, B, 4>(a, st); return FL_OK;
+            case 8: launch_mid_lean_n<A, B, 8>(a, st); return FL_OK;
+            case 16: launch_mid_lean_n<A, B, 16>(a, st); return FL_OK;
+        }
+    }
+    set_error("spectral mid: no kernel for %d -> %d channels at this transform length (2, 4, 8 or 16 channels, equal in and out)", NI, NO);
+    return FL_ERR_UNSUPPORTED;
+}
+
 template <int A, int B>
 static int launch_mid(const MidArgs& a, int NI, int NO, unsigned nblk, hipStream_t st) {
 #define FL_MID(NI_, NO_)                              \
@@ -829,6 +871,7 @@ int fl_spec_supports(int nfft, int n_in, int n_out) {
     auto ok = [](int c) { return c == 2 || c == 4 || c == 8 || c == 16; };
     if (!ok(n_in) || !ok(n_out)) return 0;
     if (n_in != n_out && (n_in > 8 || n_out > 8)) return 0;
+    if (n_in != n_out && plan_of(nfft)->lean) return 0;
     // the row kernel holds a row pair of all channels in LDS: (2 max(n_in, n_out) (L2 | 1) + 2 L2 + ...) complex values --
     // 131 KB at 16 channels, nfft = 384000; a part with less LDS per workgroup than that takes the layered route
     static int lds_limit = 0;
@@ -910,6 +953,11 @@ int fl_spec_mid_f32(const void* S, void* S2, void* Xs, long xs_b, long xs_n, con
         case 240: rc = launch_mid<16, 15>(a, NI, NO, (unsigned)nblk, st); break;
         case 320: rc = launch_mid<16, 20>(a, NI, NO, (unsigned)nblk, st); break;
         case 480: rc = launch_mid<32, 15>(a, NI, NO, (unsigned)nblk, st); break;
+        case 32: rc = launch_mid_lean<8, 4>(a, NI, NO, st); break;
+        case 64: rc = launch_mid_lean<8, 8>(a, NI, NO, st); break;
+        case 128: rc = launch_mid_lean<16, 8>(a, NI, NO, st); break;
+        case 160: rc = launch_mid_lean<16, 10>(a, NI, NO, st); break;
+        case 256: rc = launch_mid_lean<16, 16>(a, NI, NO, st); break;
         default: set_error("spec_mid: unsupported row length %d", a.L2); return FL_ERR_UNSUPPORTED;
     }
     if (rc) return rc;

@@ -123,7 +123,7 @@ constexpr int walk_pitch(int len) {
 template <int A, int B, int NI, int NO, int OCC, bool DBG = false>
 __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LEN = A * B, LENP = walk_pitch(LEN), NCH = NI > NO ? NI : NO, NW = 8, MS = 2;
+    constexpr int LEN = A * B, LENP = walk_pitch(LEN), NCH = NI > NO ? NI : NO, MS = 2;
     constexpr int MO = NO / MS;                    // output channels per thread
     constexpr int UB = 2 * NCH * LENP;             // one row buffer: [2][NCH][LENP]
     constexpr int SB = 4 * A * 64;                 // staging: [forward-side wavefront][ta][lane]: see fetch()

@@ -74,7 +74,11 @@ def test_transform_round_trip_and_spectrum(gpu, N, vt):
                                       (192000, 16, 1), (384000, 2, 1), (384000, 16, 1),
                                       # the batch-walking row kernels (csrc/specwalk.hip): 8 x 8 channels at nfft = 96000 from 4 items
                                       # on -- a unit or two per workgroup (4, 7), row-pair changes inside a workgroup's range (33)
-                                      (96000, 8, 4), (96000, 8, 7), (96000, 8, 33)])
+                                      (96000, 8, 4), (96000, 8, 7), (96000, 8, 33),
+                                      # the other planned lengths (csrc/spectral.hip kPlans): the reference's default 2^11, powers of
+                                      # two to 2^17, one and three seconds at 48 kHz
+                                      (2048, 2, 3), (2048, 16, 2), (4096, 8, 3), (8192, 4, 2), (16384, 16, 1), (32768, 2, 2), (65536, 8, 2),
+                                      (131072, 4, 1), (48000, 8, 3), (48000, 16, 1), (144000, 8, 2), (144000, 2, 1)])
 def test_spectral_apply_against_torch_fft(gpu, nfft, N, B):
     from flamo_amd import ops
     torch.manual_seed(nfft + N)
