@@ -726,9 +726,12 @@ def test_bench_contract_line(gpu):
     sr = d["step_roofline"]
     assert abs(sr["unfused_bytes_per_step"] - 1.057e9) < 2e6 and 0 < sr["frac_of_unfused_floor"] < 1
     assert sr["pipeline_bytes_per_step"] > sr["unfused_bytes_per_step"]
-    for k in ("spec_cols_fwd", "spec_cols_inv", "spec_mid[8->8,H,inv,spec]", "mimo_gradh[cols=32,8x8]"):
+    for k in ("spec_cols_fwd", "spec_cols_inv", "spec_mid_walk[8->8,spec]", "spec_gradh_walk"):
         assert 0.1 < d["kernels"][k]["frac_hbm_peak"] < 1.0, k
+    assert "spec_mid_walk" in r["kernel"] and d["params"].startswith("tests/golden/bench_params.npz")
     assert d["input_grad"]["ms_per_step"] > d["ms_per_step"]
+    for k in ("impulse", "alias30_wgn", "alias30_impulse"):
+        assert d["variants"][k]["ms_per_step"] > 0, k
     sec = d["secondary"]
     for k in ("config3_fdn16_batch1", "config3_fdn16_batch8", "config4_colorless_training", "config5_chain_32x32"):
         assert sec[k]["ms_per_step"] > 0 and sec[k]["bin_solves_per_s"] > 0, k
