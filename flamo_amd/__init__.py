@@ -9,14 +9,18 @@ C ABI in include/flamo_hip.h) is required -- there is no CPU or eager fallback.
 """
 import os as _os
 
-# ROCm 7.x replays a captured HIP graph from pre-built AQL packets ("graph packet capture").  With this library's kernels in a
-# captured step, some of PyTorch's own nodes in the same graph -- the memset + reduction pair behind a captured
-# `tensor.sum()` / `.max()` -- returned different (deterministic, wrong) values after ANY tiny eager launch between two
-# replays, while every output of this library's kernels and all gradients stayed bit-identical (tools/dbg/soak_ops.py,
-# soak_fdn15.py; not reproducible with torch kernels alone, gone with the packets rebuilt at launch).  Replays are not
-# measurably slower without the pre-built packets (0.541 vs 0.545 ms at config 2, 0.3725 vs 0.3709 ms at config 3), so the
-# switch is turned off unless the user has set it; it has to be in the environment before the HIP runtime initialises,
-# i.e. before the first CUDA call of the process (importing this package before touching the GPU is enough).
+# ROCm 7.x replays a captured HIP graph from pre-built AQL packets ("graph packet capture").  With that switch on, a captured
+# torch reduction (`tensor.sum()` / `.max()`: a memset node + a kernel node) that follows MB-sized temporaries allocated INSIDE
+# the capture returns different -- deterministic, wrong -- values after ANY tiny eager launch between two replays.  It is a
+# hazard of the platform, not of this library: tools/dbg/replay_min.py reproduces it with torch kernels alone ("torch only,
+# MB-sized temporaries in the capture": 6 of 6 replays differ), while this library's kernels on preallocated buffers, and
+# trivial kernels with large by-value arguments or 100 KB of dynamic LDS, replay bit-identically; the library's operators hit
+# it only because they allocate their scratch arrays from the graph's pool like any torch op (padding those allocations moves
+# it away).  Every tensor this library's kernels write, and every gradient, stayed bit-identical over thousands of replays
+# either way (tools/dbg/soak_fdn2.py).  Replays are not measurably slower without the pre-built packets (0.541 vs 0.545 ms at
+# config 2, 0.3725 vs 0.3709 ms at config 3), so the switch is turned off unless the user has set it; it has to be in the
+# environment before the HIP runtime initialises, i.e. before the first CUDA call of the process (importing this package
+# before touching the GPU is enough).
 _user_setting = _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")
 _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 

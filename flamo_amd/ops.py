@@ -106,15 +106,27 @@ def twiddles(nfft: int, real: torch.dtype, device: torch.device) -> torch.Tensor
                     _lib.check(L.fl_spec_aux_fill_f32(W.data_ptr(), nfft, cur.cuda_stream), "spec_aux_fill")
                 ev = torch.cuda.Event()
                 ev.record(cur)
+                if not torch.cuda.is_current_stream_capturing():
+                    # The host waits for the fill here, once per (length, precision, device): from now on the table is
+                    # plain read-only memory and NO consumer on any stream ever waits for an event of it.  It used to keep
+                    # the event, and a consumer on a capturing stream waited for it: that records, inside the graph, a wait
+                    # on an event that lives OUTSIDE it -- and with ROCm 7.2's pre-built graph packets the torch nodes that
+                    # follow in the graph (the memset + reduction pair of a captured sum() / max()) then return wrong
+                    # values after any eager launch between two replays.  tools/dbg/replay_min.py: the hazard of DESIGN
+                    # 4.5 reproduced with exactly the producers that went through that wait, and with no others.
+                    ev.synchronize()
+                    ev = None
                 ent = _twiddles[key] = [W, ev, cur.cuda_stream]
     W, ev, filled_on = ent
     if ev is not None:
+        # a table first built INSIDE a capture: its fill and this event are nodes of that graph; other streams of the same
+        # capture order themselves behind it
         cur = torch.cuda.current_stream(device)
         if cur.cuda_stream != filled_on:
             if torch.cuda.is_current_stream_capturing():
                 cur.wait_event(ev)
             elif ev.query():
-                ent[1] = None           # the fill has completed: no ordering needed any more
+                ent[1] = None
             else:
                 cur.wait_event(ev)
     return W

@@ -30,6 +30,16 @@ def producers():
     yield "tiny plain", lambda out: tiny.tiny_plain(x.data_ptr(), out.data_ptr(), n, stream())
     yield "tiny 240-byte by-value arg", lambda out: tiny.tiny_big(x.data_ptr(), out.data_ptr(), n, stream())
     yield "tiny 100 KB dynamic LDS", lambda out: tiny.tiny_lds(x.data_ptr(), out.data_ptr(), n, stream())
+    def rep(f, k):
+        def run(out):
+            for _ in range(k):
+                f(out)
+        return run
+    yield "tiny plain x12", rep(lambda out: tiny.tiny_plain(x.data_ptr(), out.data_ptr(), n, stream()), 12)
+    yield "tiny 240-byte arg x12", rep(lambda out: tiny.tiny_big(x.data_ptr(), out.data_ptr(), n, stream()), 12)
+    yield "tiny 100 KB LDS x12", rep(lambda out: tiny.tiny_lds(x.data_ptr(), out.data_ptr(), n, stream()), 12)
+    yield "torch mul x12 + complex temporaries", lambda out: out.copy_(torch.view_as_real(torch.fft.rfft(x * 1.5)).reshape(-1)[:n])
+    yield "torch.empty temporaries in the capture", lambda out: out.copy_((torch.empty_like(x).copy_(x) * 1.5 + torch.empty_like(x).fill_(0.0)))
     if os.environ.get("REPLAY_MIN_LIB", "1") == "1":
         sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
         # importing flamo_amd sets the switch for *later* processes only; the runtime of this one is already up
@@ -42,6 +52,26 @@ def producers():
         yield "fused Shell pipeline (3 fl_spec_* launches)", lambda out: out.copy_(ops.spectral_apply(
             xs, ops.permute_bins(torch.ones(24001, 2, 2, device=dev, dtype=torch.complex64), 48000), 48000).reshape(-1)[:n])
         yield "fl_rfft layered", lambda out: out.copy_(torch.view_as_real(ops.rfft(x.view(1, n, 1), n)).reshape(-1)[:n])
+        yield "fl_transpose x12", rep(lambda out: L.fl_transpose(x.data_ptr(), out.data_ptr(), 1, 375, 512, 375, 4, stream()), 12)
+        S = torch.empty(4 * 24000 * 2, dtype=torch.complex64, device=dev)
+        W48 = ops.twiddles(48000, torch.float32, dev)
+        yield "fl_spec_cols_fwd alone (preallocated)", lambda out: (L.fl_spec_cols_fwd_f32(xs.data_ptr(), 4, 24000 * 2, 2, S.data_ptr(), W48.data_ptr(), 48000, 0.0, stream()), out.copy_(torch.view_as_real(S).reshape(-1)[:n]))[1]
+        sc = torch.empty(n, dtype=torch.complex64, device=dev)
+        Xo = torch.empty(n // 2 + 32, dtype=torch.complex64, device=dev)
+        Wn = ops.twiddles(n, torch.float32, dev)
+        def raw_rfft_alloc(pad):
+            def run(out):
+                n_scr = L.fl_fft_scratch_elems(n, 0, 1)
+                scr = torch.empty(max(n_scr, 1) + pad, dtype=torch.complex64, device=dev)
+                P = ops._pitch(n // 2 + 1)
+                Xn = torch.empty(P + pad, dtype=torch.complex64, device=dev)
+                L.fl_rfft_f32(x.data_ptr(), n, n, Xn.data_ptr(), P, scr.data_ptr(), Wn.data_ptr(), 1, n, 1.0, 0.0, 0, stream())
+                out.copy_(torch.view_as_real(Xn).reshape(-1)[:n])
+            return run
+        yield "fl_rfft_f32, buffers allocated in the capture", raw_rfft_alloc(0)
+        yield "fl_rfft_f32, in-capture buffers padded by 64K elements", raw_rfft_alloc(65536)
+        yield "torch only, MB-sized temporaries in the capture", lambda out: out.copy_((torch.empty(n * 4, device=dev).fill_(1.0)[:n] * x + torch.empty(n * 2, dtype=torch.complex64, device=dev).fill_(0)[:n].real))
+        yield "fl_rfft_f32 alone (preallocated)", lambda out: (L.fl_rfft_f32(x.data_ptr(), n, n, Xo.data_ptr(), n // 2 + 32, sc.data_ptr(), Wn.data_ptr(), 1, n, 1.0, 0.0, 0, stream()), out.copy_(torch.view_as_real(Xo).reshape(-1)[:n]))[1]
 
 
 for name, prod in producers():
