@@ -48,7 +48,9 @@ _SIGNATURES = {
     "fl_spec_mid_f32": (_i, [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "fl_spec_walk_supports": (_i, [_i, _i, _i]),
     "fl_spec_walk_spectrum_elems": (_sz, [_i, _i, _i]),
-    "fl_spec_mid_walk_f32": (_i, [_vp, _vp, _vp, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
+    "fl_spec_walk_workgroups": (_i, [_i, _i]),
+    "fl_spec_walk_partition": (_i, [_i, _i, _i, C.POINTER(_i)]),
+    "fl_spec_mid_walk_f32": (_i, [_vp, _vp, _vp, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp, _vp]),
     "fl_spec_gradh_slices": (_i, [_i, _i]),
     "fl_spec_gradh_walk_f32": (_i, [_vp, _vp, _vp, _l, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _vp]),
     "fl_sum_parts_c64": (_i, [_vp, _l, _i, _vp, _l, _vp]),

@@ -37,6 +37,7 @@ struct WalkArgs {
     float spec_scale;     // scale of the forward transform
     int spec_interior2;   // double the interior bins of the spectrum (irfft backward)
     int pre_half;         // halve the interior bins in front of the inverse transform (rfft backward)
+    const int* bounds;    // work partition: workgroup w takes units [bounds[w], bounds[w+1]) (fl_spec_walk_partition), or null: equal counts
     cf* Xp;               // spectrum out, pair-major: Xp[(u*2 + e)*NI*LEN + n*LEN + p], u = r*Bn + b, e = 0: bin k, 1: bin L-k; or null
     long long* dbg_times; // tuning: per-workgroup cycle stamps, or null
 };
@@ -149,8 +150,8 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
     // on XCD q % 8), so the slice comes from HBM once and from that L2 afterwards
     const int G = gridDim.x;
     const int w = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    int u = (int)((long)Utot * w / G);
-    const int u_hi = (int)((long)Utot * (w + 1) / G);
+    int u = a.bounds ? a.bounds[w] : (int)((long)Utot * w / G);
+    const int u_hi = a.bounds ? a.bounds[w + 1] : (int)((long)Utot * (w + 1) / G);
     if (u >= u_hi) return;
     const size_t bstride_i = (size_t)a.L1 * a.L2 * NI, bstride_o = (size_t)a.L1 * a.L2 * NO;
     const unsigned stage_lds = lds_addr_of(stage);
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         for (int q = 0; q < A / 2; ++q) dma16(src + q * (2 * B * NI), stage_lds + (unsigned)(((wv * A + 2 * q) * 64) * 8));
     };
     // ---- the FFT stages, each for the 256 threads of one group
-    auto P1 = [&](bool selfm, int fetch_next) {      // first stage of the forward rows, staging -> XF.  item = (slot, tb, n), n fastest
+    auto P1 = [&](bool selfm) {          // first stage of the forward rows, staging -> XF.  item = (slot, tb, n), n fastest
         const int item = opaque(tid) & 255;
         const int nn = item % NI, tb = (item / NI) % B, slot = item / (NI * B);
         const bool have = item < NI1 && !(slot && selfm);
@@ -186,10 +187,6 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         // cannot tell the table from the row buffers), and 15 dependent read -> multiply -> store round trips would follow
 #pragma unroll
         for (int ka = 1; ka < A; ++ka) t[ka] = tw[ka * (have ? tb : 0)];
-        if (fetch_next >= 0) {
-            wait_lgkm0();                        // the reads above have returned: the region may be refilled
-            fetch(fetch_next);
-        }
         if (!have) return;
         RegFFT<float, A, false>::run(v);
         cf* uu = XF + (slot * NCH + nn) * LENP + tb;
@@ -305,7 +302,7 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         const f2 phv = dc ? f2{1.f, 0.f} : f2{ph, ph};          // ... and only its real parts enter the inverse transform
         const int yk_o = pc, ym_o = slotB * NCH * LENP + colB;  // where the pair's bins sit in a row buffer
         cf* zm_dst = twin ? XI + ym_o : dummy + lane;           // lanes without a partner bin of their own store aside
-        if (grp == 1) P1(selfm, -1);
+        if (grp == 1) P1(selfm);
         if (p < LEN) wtab[grp * LEN + p] = wt_mine;
         lds_barrier();
         if (grp == 1) P2(selfm);
@@ -372,12 +369,17 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
             FL_STAMP(1)
             // ---- step B
             if (grp == 0) P4(selfm);
-            else if (next) P1(selfm, u + 2 < u_hi ? u + 2 : -1);
+            else if (next) P1(selfm);
             lds_barrier();
             FL_STAMP(2)
-            // ---- step C
+            // ---- step C.  The forward side's own staging regions are free (its reads of step B are behind the barrier): the rows
+            // of unit u+2 are requested here, beside the LIGHTER of the two second stages (the transfer's issue costs ~100
+            // cycles per 1-KB piece: in step B it made the forward side the slower half)
             if (grp == 0) P5(selfm, r, rm, u - r * a.Bn);
-            else if (next) P2(selfm);
+            else if (next) {
+                if (u + 2 < u_hi) fetch(u + 2);
+                P2(selfm);
+            }
             lds_barrier();
             FL_STAMP(3)
         }
@@ -621,6 +623,15 @@ static int device_cus() {
     return cus;
 }
 
+// workgroups of the forward walking kernel: one per CU (a multiple of 8: XCD-aware order), never more than units
+static long walk_wgs(int L1, int Bn) {
+    const long units = (long)(L1 / 2 + 1) * Bn;
+    long g = g_walk_wgs > 0 ? g_walk_wgs : device_cus();
+    if (g > units) g = units;
+    if (g >= 8) g -= g % 8;
+    return g;
+}
+
 template <int A, int B, int NI, int NO, int OCC>
 static int launch_walk(const WalkArgs& a, hipStream_t st) {
     constexpr int LEN = A * B, LENP = walk_pitch(LEN), NCH = NI > NO ? NI : NO;
@@ -634,10 +645,7 @@ static int launch_walk(const WalkArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_dbg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    const long units = (long)(a.L1 / 2 + 1) * a.Bn;
-    long g = g_walk_wgs > 0 ? g_walk_wgs : device_cus();
-    if (g > units) g = units;
-    if (g >= 8) g -= g % 8;
+    const long g = walk_wgs(a.L1, a.Bn);
     if (a.dbg_times) hipLaunchKernelGGL(kern_dbg, dim3((unsigned)g), dim3(512), lds, st, a);
     else hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(512), lds, st, a);
     return FL_OK;
@@ -730,6 +738,55 @@ int fl_sum_parts_c64(const void* parts, long part_stride, int n_parts, void* out
     return FL_OK;
 }
 
+int fl_spec_walk_workgroups(int nfft, int Bn) {
+    int l1, l2;
+    if (spec_plan(nfft, l1, l2) != FL_OK || Bn <= 0) return 0;
+    return (int)walk_wgs(l1, Bn);
+}
+
+int fl_spec_walk_partition(int nfft, int Bn, int n_wg, int* bounds) {
+    FL_REQUIRE(bounds && n_wg > 0 && Bn > 0, "spec_walk_partition: bad arguments");
+    int L1, L2;
+    int rc = spec_plan(nfft, L1, L2);
+    if (rc) return rc;
+    // Contiguous unit ranges of minimal maximum COST.  A unit of a self-mirrored row pair (k1 = 0, and L1/2 for even L1) has
+    // one row instead of two; entering a row pair costs a fill (the response slice into registers, tables, the pipeline's
+    // first two stages with nothing beside them).  Fitted to per-workgroup cycle counts (tools/dbg/walk_fit.py): 9.8 k cycles
+    // per unit, 15.4 k per row pair entered, 8.3 k per self-mirrored unit.  Equal unit COUNTS left the slowest workgroup
+    // 13-19 % above the mean.  Costs in twentieths of a unit; the smallest cap for which a greedy sweep needs no more than
+    // n_wg ranges (binary search), then the sweep's cuts.
+    const int P = L1 / 2 + 1, U = P * Bn, UC = 20, US = 17, FC = 31;
+    auto ucost = [&](int u) { const int r = u / Bn; return (r == 0 || 2 * r == L1) ? US : UC; };
+    auto sweep = [&](long cap, int* out) {       // number of ranges used; out[i] = first unit of range i
+        int n = 0, u = 0;
+        while (u < U) {
+            if (out) out[n] = u;
+            ++n;
+            long c = FC + ucost(u);
+            int last_r = u / Bn;
+            ++u;
+            while (u < U) {
+                const int r = u / Bn;
+                const long add = ucost(u) + (r != last_r ? FC : 0);
+                if (c + add > cap) break;
+                c += add;
+                last_r = r;
+                ++u;
+            }
+        }
+        return n;
+    };
+    long lo = FC + UC, hi = (long)U * UC + (long)P * FC;
+    while (lo < hi) {
+        const long mid = (lo + hi) / 2;
+        if (sweep(mid, nullptr) <= n_wg) hi = mid;
+        else lo = mid + 1;
+    }
+    const int used = sweep(lo, bounds);
+    for (int i = used; i <= n_wg; ++i) bounds[i] = U;      // surplus workgroups get empty ranges
+    return FL_OK;
+}
+
 size_t fl_spec_walk_spectrum_elems(int nfft, int Bn, int NI) {
     int l1, l2;
     if (spec_plan(nfft, l1, l2) != FL_OK || Bn < 0) return 0;
@@ -737,7 +794,7 @@ size_t fl_spec_walk_spectrum_elems(int nfft, int Bn, int NI) {
 }
 
 int fl_spec_mid_walk_f32(const void* S, void* S2, void* Xp, const void* H, long hs_m, long hs_n, int conj_h, const void* W, int nfft, int Bn,
-                         int NI, int NO, double spec_scale, int spec_interior2, int pre_half, void* stream) {
+                         int NI, int NO, double spec_scale, int spec_interior2, int pre_half, const void* bounds, void* stream) {
     FL_REQUIRE(S && S2 && H && W, "spec_mid_walk: null pointer");
     FL_REQUIRE(S != S2, "spec_mid_walk: not an in-place kernel (the rows of a round are read while earlier rounds' are stored)");
     if (Bn == 0) return FL_OK;
@@ -748,6 +805,7 @@ int fl_spec_mid_walk_f32(const void* S, void* S2, void* Xp, const void* H, long 
     a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn;
     a.spec_scale = (float)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half; a.dbg_times = g_walk_times;
     a.Xp = (cf*)Xp;
+    a.bounds = (const int*)bounds;
     FL_REQUIRE((size_t)a.L1 * a.L2 * (NI > NO ? NI : NO) * 8ull < (1ull << 32), "spec_mid_walk: a batch item exceeds 32-bit offsets");
     FL_REQUIRE(reinterpret_cast<uintptr_t>(S) % 16 == 0, "spec_mid_walk: S must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;

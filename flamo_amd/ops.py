@@ -669,10 +669,32 @@ def _walk_applies(nfft: int, B: int, NI: int, NO: int) -> bool:
     return B >= _WALK_MIN_BATCH and bool(_lib.lib().fl_spec_walk_supports(int(nfft), int(NI), int(NO)))
 
 
+_walk_bounds = {}
+
+
+def _walk_partition(nfft: int, B: int, dev: torch.device) -> torch.Tensor:
+    """Device copy of the forward walking kernel's work partition (fl_spec_walk_partition), cached per (nfft, batch, device)."""
+    L = _lib.lib()
+    n_wg = int(L.fl_spec_walk_workgroups(nfft, B))
+    key = (int(nfft), int(B), n_wg, dev.index if dev.index is not None else torch.cuda.current_device())
+    t = _walk_bounds.get(key)
+    if t is None:
+        import ctypes
+        host = (ctypes.c_int * (n_wg + 1))()
+        _lib.check(L.fl_spec_walk_partition(nfft, B, n_wg, host), "spec_walk_partition")
+        if torch.cuda.is_current_stream_capturing():
+            return None          # no host-to-device copy inside a capture: this call runs on equal counts; the warm-up before it filled the cache
+        t = torch.tensor(list(host), dtype=torch.int32).to(dev)
+        torch.cuda.current_stream(dev).synchronize()
+        _walk_bounds[key] = t
+    return t
+
+
 def _spec_mid_walk(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, spec_scale, interior2, pre_half):
     """-> (S2, pair-major spectrum or None) through fl_spec_mid_walk_f32"""
     dev = S.device
     L = _lib.lib()
+    bounds = _walk_partition(nfft, B, dev)
     S2 = torch.empty(B * (nfft // 2) * NO, dtype=torch.complex64, device=dev)
     Xp = torch.empty(int(L.fl_spec_walk_spectrum_elems(nfft, B, NI)), dtype=torch.complex64, device=dev) if want_spec else None
     hp = _lead_pitch(Hrm.movedim(0, -1))
@@ -683,7 +705,8 @@ def _spec_mid_walk(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, spec_scale, inter
     with kernel_timer.span(tag):
         _lib.check(L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), None if Xp is None else Xp.data_ptr(), Hrm.data_ptr(), hs_m, hs_n,
                                           int(bool(conj_t)), twiddles(nfft, torch.float32, dev).data_ptr(), nfft, B, NI, NO, spec_scale,
-                                          int(interior2), int(pre_half), _stream()), "spec_mid_walk")
+                                          int(interior2), int(pre_half), None if bounds is None else bounds.data_ptr(), _stream()),
+                   "spec_mid_walk")
     return S2, Xp
 
 

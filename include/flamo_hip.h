@@ -153,8 +153,14 @@ int fl_spec_mid_f32(const void* S, void* S2, void* Xs, long xs_b, long xs_n, con
  * (fl_spec_walk_spectrum_elems complex values).  fl_spec_walk_supports: 1 when (nfft, channels) has this kernel. */
 int fl_spec_walk_supports(int nfft, int n_in, int n_out);
 size_t fl_spec_walk_spectrum_elems(int nfft, int Bn, int NI);
+/* Work partition of the forward kernel: fl_spec_walk_workgroups = its grid size; fl_spec_walk_partition fills the HOST array
+ * bounds[n_wg + 1] with contiguous unit ranges of about equal cost (a unit = (row pair, batch item), r * Bn + b; entering a row
+ * pair costs a fill, self-mirrored row pairs are half units).  The caller keeps a DEVICE copy and passes it as `bounds`
+ * (null: equal unit counts). */
+int fl_spec_walk_workgroups(int nfft, int Bn);
+int fl_spec_walk_partition(int nfft, int Bn, int n_wg, int* bounds);
 int fl_spec_mid_walk_f32(const void* S, void* S2, void* Xp, const void* H, long hs_m, long hs_n, int conj_h, const void* W, int nfft, int Bn,
-                         int NI, int NO, double spec_scale, int spec_interior2, int pre_half, void* stream);
+                         int NI, int NO, double spec_scale, int spec_interior2, int pre_half, const void* bounds, void* stream);
 /* Backward of the product inside the row kernel -- the autograd of dsp.py:922-924 w.r.t. the response:
  *   dH[m][n][i] = sum_b gY[b,m,i] conj(X[b,n,i]),   gY = scale_g * w_k * rfft-spectrum of the rows in Sg (K1 of the output
  *   gradient, (Bn, L1, L2, NO); w_k = 2 on interior bins if interior2_g), X = the pair-major spectrum fl_spec_mid_walk_f32

@@ -31,6 +31,10 @@ W = ops.twiddles(nfft, torch.float32, dev)
 S = ops._spec_cols_fwd(x, nfft, 0.0)
 Sg = ops._spec_cols_fwd(g, nfft, 0.0)
 P = ops._pitch(M)
+bnd = ops._walk_partition(nfft, B, dev)
+BND = None if os.environ.get("WALK_EQUAL_COUNTS") == "1" else bnd.data_ptr()
+bl = bnd.cpu().tolist()
+print("partition: units per workgroup min", min(b - a for a, b in zip(bl, bl[1:])), "max", max(b - a for a, b in zip(bl, bl[1:])))
 rel = lambda a, b: (torch.linalg.vector_norm((a - b).float()) / torch.linalg.vector_norm(b.float())).item()  # noqa: E731
 
 
@@ -62,7 +66,7 @@ for conj_t, scale, i2, ph in ((False, 1.0, 0, 0), (True, 1.0 / nfft, 1, 1)):
         L.fl_debug_set_walk(1, wgs, 0, None)
         S2 = torch.full_like(S, float("nan"))
         _lib.check(L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), None, Hp.data_ptr(), hs_m, hs_n, int(conj_t), W.data_ptr(), nfft, B, N, N,
-                                          scale, i2, ph, ops._stream()), "walk")
+                                          scale, i2, ph, BND, ops._stream()), "walk")
         torch.cuda.synchronize()
         print(f"forward conj_t={conj_t} wgs={wgs}: rel err vs spec_mid {rel(torch.view_as_real(S2), torch.view_as_real(S2_ref)):.3e}"
               f"  nan={torch.isnan(torch.view_as_real(S2)).any().item()}")
@@ -72,10 +76,10 @@ Xp = torch.zeros(L.fl_spec_walk_spectrum_elems(nfft, B, N), dtype=torch.complex6
 for wgs in [int(v) for v in args.wgs.split(",")]:
     L.fl_debug_set_walk(1, wgs, 0, None)
     t = timeit(lambda: L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), None, Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0,
-                                              ops._stream()))
+                                              BND, ops._stream()))
     print(f"spec_mid_walk wgs={wgs}: median {t[0]:.1f} us, min {t[1]:.1f} us")
     t = timeit(lambda: L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Xp.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0,
-                                              ops._stream()))
+                                              BND, ops._stream()))
     print(f"spec_mid_walk wgs={wgs} + pair-major spectrum: median {t[0]:.1f} us, min {t[1]:.1f} us")
 Xs = ops._empty_rows((B, N), M, torch.complex64, dev)
 t = timeit(lambda: L.fl_spec_mid_f32(S.data_ptr(), S2.data_ptr(), Xs.data_ptr(), N * P, P, Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N,
@@ -89,7 +93,7 @@ print(f"spec_mid (no spectrum): median {t[0]:.1f} us, min {t[1]:.1f} us")
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 buf = torch.zeros(cus * 8, dtype=torch.int64, device=dev)
 L.fl_debug_set_walk(1, 0, 0, buf.data_ptr())
-L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Xp.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0, ops._stream())
+L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Xp.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0, BND, ops._stream())
 torch.cuda.synchronize()
 L.fl_debug_set_walk(1, 0, 0, None)
 tt = buf.view(-1, 8).cpu().double()
