@@ -722,6 +722,137 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
     return FL_OK;
 }
 
+
+// ---------------------------------------------------------------- loops beyond the register-resident sizes
+// N > 64 (float) / 32 (double): one workgroup per bin, the matrix in LDS (pitch N + 1), LU with partial pivoting by the
+// whole workgroup (pivot search = a block reduction of |re| + |im| as in the register kernels, row exchange, multipliers,
+// rank-one update of the trailing block), then the right-hand sides in blocks of CB columns (forward and back substitution
+// with the columns of a block side by side).  A correctness path for sizes the reference's torch.linalg.solve
+// (system.py:425) accepts and feedback delay networks rarely use: ~4 N + 2 N (B K / CB) barriers per bin, not tuned.
+template <typename T>
+__global__ void __launch_bounds__(256) solve_lds_kernel(const cx<T>* __restrict__ P, long p_pitch, int one_minus, int adjoint,
+                                                        const cx<T>* __restrict__ R, long rs_b, long rs_n, long rs_k,
+                                                        cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
+                                                        int B, int M, int N, int K, int CB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NP = N + 1;
+    cx<T>* Am = reinterpret_cast<cx<T>*>(smem);             // [N][NP]
+    cx<T>* Y = Am + (size_t)N * NP;                          // [N][CB]
+    int* piv = reinterpret_cast<int*>(Y + (size_t)N * CB);   // [N]
+    __shared__ T red_v[256];
+    __shared__ int red_i[256];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    for (int e = tid; e < N * N; e += 256) {
+        const int i = e / N, j = e - i * N;
+        cx<T> v = adjoint ? conj(P[(size_t)(j * N + i) * p_pitch + f]) : P[(size_t)(i * N + j) * p_pitch + f];
+        if (one_minus) v = cx<T>((i == j ? (T)1 : (T)0) - v.x, -v.y);
+        Am[i * NP + j] = v;
+    }
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        // pivot: largest |re| + |im| in column k at or below the diagonal (LAPACK icamax)
+        T best = (T)-1;
+        int bi = k;
+        for (int i = k + tid; i < N; i += 256) {
+            const cx<T> v = Am[i * NP + k];
+            const T m = fabs(v.x) + fabs(v.y);
+            if (m > best) { best = m; bi = i; }
+        }
+        red_v[tid] = best;
+        red_i[tid] = bi;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s && (red_v[tid + s] > red_v[tid] || (red_v[tid + s] == red_v[tid] && red_i[tid + s] < red_i[tid]))) {
+                red_v[tid] = red_v[tid + s];
+                red_i[tid] = red_i[tid + s];
+            }
+            __syncthreads();
+        }
+        const int p = red_i[0];
+        if (tid == 0) piv[k] = p;
+        if (p != k)
+            for (int j = tid; j < N; j += 256) {
+                const cx<T> t = Am[k * NP + j];
+                Am[k * NP + j] = Am[p * NP + j];
+                Am[p * NP + j] = t;
+            }
+        __syncthreads();
+        const cx<T> ip = crecip(Am[k * NP + k]);
+        for (int i = k + 1 + tid; i < N; i += 256) Am[i * NP + k] = Am[i * NP + k] * ip;
+        __syncthreads();
+        const int nt = N - k - 1;
+        for (int e = tid; e < nt * nt; e += 256) {
+            const int i = k + 1 + e / nt, j = k + 1 + e % nt;
+            const cx<T> l = Am[i * NP + k], u = Am[k * NP + j];
+            cx<T> a = Am[i * NP + j];
+            a.x -= l.x * u.x - l.y * u.y;
+            a.y -= l.x * u.y + l.y * u.x;
+            Am[i * NP + j] = a;
+        }
+        __syncthreads();
+    }
+    // right-hand sides, CB columns (b, kk) at a time
+    const int ncol = B * K;
+    for (int c0 = 0; c0 < ncol; c0 += CB) {
+        const int nc = min(CB, ncol - c0);
+        for (int e = tid; e < N * nc; e += 256) {
+            const int i = e / nc, c = e - i * nc, col = c0 + c;
+            const int b = col / K, kk = col - b * K;
+            Y[i * CB + c] = R[(size_t)b * rs_b + (size_t)i * rs_n + (size_t)kk * rs_k + f];
+        }
+        __syncthreads();
+        for (int k = 0; k < N; ++k) {           // the factorisation's row exchanges, in order
+            const int p = piv[k];
+            if (p != k && tid < nc) {
+                const cx<T> t = Y[k * CB + tid];
+                Y[k * CB + tid] = Y[p * CB + tid];
+                Y[p * CB + tid] = t;
+            }
+            __syncthreads();
+        }
+        for (int k = 0; k < N; ++k) {           // L y = b (unit lower)
+            const int nr = N - k - 1;
+            for (int e = tid; e < nr * nc; e += 256) {
+                const int i = k + 1 + e / nc, c = e % nc;
+                const cx<T> l = Am[i * NP + k], y = Y[k * CB + c];
+                cx<T> a = Y[i * CB + c];
+                a.x -= l.x * y.x - l.y * y.y;
+                a.y -= l.x * y.y + l.y * y.x;
+                Y[i * CB + c] = a;
+            }
+            __syncthreads();
+        }
+        for (int k = N - 1; k >= 0; --k) {      // U x = y
+            const cx<T> ip = crecip(Am[k * NP + k]);
+            if (tid < nc) Y[k * CB + tid] = Y[k * CB + tid] * ip;
+            __syncthreads();
+            for (int e = tid; e < k * nc; e += 256) {
+                const int i = e / nc, c = e % nc;
+                const cx<T> u = Am[i * NP + k], x = Y[k * CB + c];
+                cx<T> a = Y[i * CB + c];
+                a.x -= u.x * x.x - u.y * x.y;
+                a.y -= u.x * x.y + u.y * x.x;
+                Y[i * CB + c] = a;
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < N * nc; e += 256) {
+            const int i = e / nc, c = e - i * nc, col = c0 + c;
+            const int b = col / K, kk = col - b * K;
+            OUT[(size_t)b * os_b + (size_t)i * os_n + (size_t)kk * os_k + f] = Y[i * CB + c];
+        }
+        __syncthreads();
+    }
+}
+
+// largest loop the LDS kernel takes: the matrix (pitch N + 1) plus at least four right-hand-side columns in 160 KB
+template <typename T>
+static int solve_lds_max_n() {
+    int n = 0;
+    while (((size_t)(n + 1) * (n + 2) + 4 * (size_t)(n + 1)) * sizeof(cx<T>) + (size_t)(n + 1) * sizeof(int) <= 160 * 1024 - 4096) ++n;
+    return n;
+}
+
 template <typename T>
 static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
                       void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
@@ -737,8 +868,25 @@ static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_mi
     FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0 && (!P || p_pitch >= M), "solve: bad sizes (p_pitch >= M)");
     const int nmax_lim = sizeof(T) == 8 ? 32 : 64;
     if (N > nmax_lim) {
-        set_error("solve: N=%d exceeds the register-resident limit (%d) for this precision", N, nmax_lim);
-        return FL_ERR_UNSUPPORTED;
+        const int big = solve_lds_max_n<T>();
+        if (!P || N > big) {
+            set_error("solve: N=%d exceeds %s (%d for this precision)", N, P ? "what one workgroup's LDS holds" : "the register-resident limit of the factored forms",
+                      P ? big : nmax_lim);
+            return FL_ERR_UNSUPPORTED;
+        }
+        if (B == 0 || M == 0) return FL_OK;
+        int cb = 16;
+        while (cb > 4 && ((size_t)N * (N + 1) + (size_t)N * cb) * sizeof(cx<T>) + (size_t)N * sizeof(int) > 160 * 1024 - 4096) cb >>= 1;
+        const size_t lds = ((size_t)N * (N + 1) + (size_t)N * cb) * sizeof(cx<T>) + (size_t)N * sizeof(int);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(solve_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((solve_lds_kernel<T>), dim3(M), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)P, p_pitch, one_minus, adjoint,
+                           (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K, cb);
+        FL_CHECK_LAUNCH("solve_lds");
+        return FL_OK;
     }
     if (B == 0 || M == 0) return FL_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -1054,6 +1202,8 @@ static int dud_grads_impl(const Dud<T>& d, const void* gR, const void* OUT, long
 using namespace fl;
 
 extern "C" {
+int fl_solve_max_n(int f64) { return f64 ? solve_lds_max_n<double>() : solve_lds_max_n<float>(); }
+
 int fl_debug_set_solve_variant(int variant) {
     g_solve_thr = 1;
     g_solve_rpl2_p = variant == 3;

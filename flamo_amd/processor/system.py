@@ -360,11 +360,13 @@ class Recursion(nn.Module):
         self.alias_decay_db = self.__check_attribute("alias_decay_db")
         self.dtype = self.__check_attribute("dtype")
         self.input_channels, self.output_channels = self.__check_io()
-        # the closed-loop solve keeps a loop-matrix row per lane: one wavefront per bin bounds the loop size (the
-        # reference's torch.linalg.solve has no such bound; there is deliberately no torch fallback on this path)
-        limit = 32 if self.dtype == torch.float64 else 64
+        # The closed-loop solve keeps a loop-matrix row per lane up to 64 (float32) / 32 (float64) channels -- the sizes with
+        # the fused loop forms; above that one workgroup per bin factors the materialised matrix in LDS (fl_solve_max_n: 138 /
+        # 97).  The reference's torch.linalg.solve has no bound; there is deliberately no torch fallback on this path.
+        self._register_loop = self.output_channels <= (32 if self.dtype == torch.float64 else 64)
+        limit = 97 if self.dtype == torch.float64 else 138
         assert self.output_channels <= limit, (
-            f"Recursion: {self.output_channels} loop channels exceed the HIP solve kernel's limit of {limit} "
+            f"Recursion: {self.output_channels} loop channels exceed the HIP solve kernels' limit of {limit} "
             f"({'float64' if self.dtype == torch.float64 else 'float32'}); see INTEGRATION.md")
 
     @staticmethod
@@ -386,7 +388,7 @@ class Recursion(nn.Module):
             return self.__forward_in_loop(X, ext_param, ext_fb, ext_ff)
 
     def __forward_in_loop(self, X, ext_param, ext_fb, ext_ff):
-        if FUSE_SERIES and FDN_DIAGONAL_IN_SOLVE and ext_param is None and torch.is_tensor(X) and X.is_cuda and X.is_complex():
+        if FUSE_SERIES and FDN_DIAGONAL_IN_SOLVE and self._register_loop and ext_param is None and torch.is_tensor(X) and X.is_cuda and X.is_complex():
             d2 = self._fdn_factors(X.shape[1]) if (X.dim() >= 3 and X.shape[2] == self.output_channels) else None
             if d2 is not None:
                 # FDN structure with a diagonal feedforward path (the delays): that diagonal scales l and the right-hand
@@ -394,11 +396,11 @@ class Recursion(nn.Module):
                 return ops.solve_dud2(d2[0], d2[1], d2[2], d2[3], X)
         R = self.feedforward(X, ext_ff)
         if FUSE_SERIES and ext_param is None and torch.is_tensor(R) and R.is_cuda:
-            dud = self.__factored_loop(R)
+            dud = self.__factored_loop(R) if self._register_loop else None
             if dud is not None:
                 # FDN structure: P = diag(l) U diag(r) stays factored, A = I - P is built in registers
                 return ops.solve_dud(dud[0], dud[1], dud[2], R)
-            sl = self.__scaled_loop(R)
+            sl = self.__scaled_loop(R) if self._register_loop else None
             if sl is not None:
                 return ops.solve_scaled_loop(sl[0], sl[1], sl[2], R)
             P = self.__composed_loop(R)

@@ -363,7 +363,10 @@ int fl_geq_sections_bwd_w(const void* gain, int in_kind, const void* gb, const v
  * Per bin f:  A_f = (one_minus ? I - P[:,:,f] : P[:,:,f]);  if adjoint, A_f := A_f^H;
  *             OUT[b,:,k,f] = A_f^{-1} R[b,:,k,f]
  * LU with partial pivoting, factored ONCE per bin and applied to all B*K right-hand sides
- * (the reference factors the same matrix B times).  P planar: (i*N + j)*p_pitch + f.  N <= 64. */
+ * (the reference factors the same matrix B times).  P planar: (i*N + j)*p_pitch + f.  N <= 64 (c64) / 32 (c128) in
+ * registers (one matrix row per lane); above that one workgroup per bin with the matrix in LDS, up to fl_solve_max_n
+ * (138 / 97): a correctness path for sizes torch.linalg.solve accepts and delay networks rarely use. */
+int fl_solve_max_n(int f64);
 int fl_solve_c64(const void* P, long p_pitch, int one_minus, int adjoint,
                  const void* R, long rs_b, long rs_n, long rs_k,
                  void* OUT, long os_b, long os_n, long os_k,

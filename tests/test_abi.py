@@ -100,3 +100,30 @@ def test_operator_api_host_logic():
     b, a = geq._sos_coeffs(geq.map(geq.param))
     bo, ao = O.geq_sos(geq.map(geq.param), geq.center_freq, geq.shelving_crossover)
     assert b.dtype == torch.float32 and torch.equal(b, bo) and torch.equal(a, ao)
+
+
+def test_walk_partition_covers_every_unit_once():
+    """fl_spec_walk_partition (host side, no GPU): contiguous, monotone unit ranges that cover [0, row pairs * batch) exactly,
+    with a smaller maximum cost than equal unit counts under the kernel's fitted cost model."""
+    import ctypes
+    from flamo_amd import _lib
+    L = _lib.lib()
+    for B, n_wg in ((32, 256), (4, 256), (7, 104), (33, 256), (1, 96)):
+        host = (ctypes.c_int * (n_wg + 1))()
+        assert L.fl_spec_walk_partition(96000, B, n_wg, host) == 0
+        b = list(host)
+        U = 101 * B
+        assert b[0] == 0 and b[-1] == U and all(x <= y for x, y in zip(b, b[1:]))
+
+        def cost(lo, hi):
+            c, last = 0, None
+            for u in range(lo, hi):
+                r = u // B
+                if r != last:
+                    c, last = c + 31, r
+                c += 17 if (r == 0 or 2 * r == 200) else 20
+            return c
+        got = max(cost(x, y) for x, y in zip(b, b[1:]))
+        eq = max(cost(U * i // n_wg, U * (i + 1) // n_wg) for i in range(n_wg))
+        assert got <= eq, (B, got, eq)
+    assert L.fl_spec_walk_partition(12345, 4, 8, (ctypes.c_int * 9)()) != 0          # no plan for this length

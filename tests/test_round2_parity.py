@@ -88,9 +88,12 @@ def test_parallel_probe_and_peq_coeff_api():
 def test_recursion_channel_limit_is_checked_at_construction():
     from flamo_amd.processor import dsp, system
     kw = dict(nfft=64, dtype=torch.float32)
-    with pytest.raises(AssertionError, match="limit of 64"):
-        system.Recursion(fF=dsp.parallelGain(size=(65,), **kw), fB=dsp.Matrix(size=(65, 65), **kw))
-    system.Recursion(fF=dsp.parallelGain(size=(64,), **kw), fB=dsp.Matrix(size=(64, 64), **kw))
+    with pytest.raises(AssertionError, match="limit of 138"):
+        system.Recursion(fF=dsp.parallelGain(size=(139,), **kw), fB=dsp.Matrix(size=(139, 139), **kw))
+    system.Recursion(fF=dsp.parallelGain(size=(138,), **kw), fB=dsp.Matrix(size=(138, 138), **kw))
+    kw = dict(nfft=64, dtype=torch.float64)
+    with pytest.raises(AssertionError, match="limit of 97"):
+        system.Recursion(fF=dsp.parallelGain(size=(98,), **kw), fB=dsp.Matrix(size=(98, 98), **kw))
 
 
 def test_fusability_follows_forward_overrides_and_hooks():

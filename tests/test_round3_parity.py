@@ -144,3 +144,39 @@ def test_config5_core_full_size_on_sampled_bins(gpu):
     for gi, gr, k in zip(g, gref, ("g_geq", "g_gain", "g_U")):
         lim = 1e-3 if k == "g_geq" else 3e-5             # equaliser gains: float32 section buffers in the reference (and the oracle)
         assert relerr(gi.cpu(), gr) < lim, (k, relerr(gi.cpu(), gr))
+
+
+@gpu_only
+@pytest.mark.parametrize("dt,N", [(torch.float32, 80), (torch.float32, 138), (torch.float64, 40), (torch.float64, 97)])
+def test_recursion_beyond_the_register_resident_sizes(gpu, dt, N):
+    """Loops larger than a wavefront's lanes (64 channels in float32, 32 in float64) go through the LDS solve kernel: output and
+    gradients of Recursion(parallelDelay * parallelGain, orthogonal Matrix) against torch.linalg.solve in float64 (system.py:397-425)."""
+    from flamo_amd.processor import dsp, system
+    from oracle import hotpath as O
+    nfft, db = 240, 30.0
+    M = nfft // 2 + 1
+    torch.manual_seed(N)
+    kw = dict(nfft=nfft, alias_decay_db=db, device=gpu, dtype=dt)
+    dl = dsp.parallelDelay(size=(N,), max_len=40, isint=True, **kw)
+    gn = dsp.parallelGain(size=(N,), requires_grad=True, **kw)
+    mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+    with torch.no_grad():
+        gn.param.copy_(torch.rand(N, device=gpu, dtype=dt) * 0.5 + 0.2)
+    rec = system.Recursion(fF=system.Series(OrderedDict(d=dl, g=gn)), fB=mix)
+    cd = torch.complex64 if dt == torch.float32 else torch.complex128
+    X = torch.randn(2, M, N, device=gpu, dtype=cd)
+    C = torch.randn(2, M, N, device=gpu, dtype=cd)
+    Y = rec(X)
+    g = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C))), [gn.param, mix.param])
+    # oracle
+    lv = [gn.param.detach().cpu().double().requires_grad_(True), mix.param.detach().cpu().double().requires_grad_(True)]
+    gamma = O.gamma_of(db, nfft, F64)
+    m = O.delay_samples(dl.param.detach().cpu().double(), 48000, 100, True)
+    F = torch.diag_embed(O.to_complex(lv[0]).view(1, N) * O.delay_response(m, nfft, gamma))
+    Bk = O.to_complex(O.orthogonal(lv[1])).unsqueeze(0).expand(M, N, N)
+    Yr = O.recursion(F, Bk, X.cpu().to(torch.complex128))
+    gr = torch.autograd.grad(torch.sum(torch.real(Yr * torch.conj(C.cpu().to(torch.complex128)))), lv)
+    tol = 1e-9 if dt == torch.float64 else 2e-5
+    assert relerr(Y.detach().cpu(), Yr.detach()) < tol
+    for gi, gj, k in zip(g, gr, ("g_gain", "g_U")):
+        assert relerr(gi.cpu(), gj) < 10 * tol, (k, relerr(gi.cpu(), gj))
