@@ -388,22 +388,23 @@ class Recursion(nn.Module):
             return self.__forward_in_loop(X, ext_param, ext_fb, ext_ff)
 
     def __forward_in_loop(self, X, ext_param, ext_fb, ext_ff):
-        if FUSE_SERIES and FDN_DIAGONAL_IN_SOLVE and self._register_loop and ext_param is None and torch.is_tensor(X) and X.is_cuda and X.is_complex():
-            d2 = self._fdn_factors(X.shape[1]) if (X.dim() >= 3 and X.shape[2] == self.output_channels) else None
+        # (external parameters -- system.py:409-415 -- take the same fused routes: every helper below hands each module its own entry)
+        if FUSE_SERIES and FDN_DIAGONAL_IN_SOLVE and self._register_loop and torch.is_tensor(X) and X.is_cuda and X.is_complex():
+            d2 = self._fdn_factors(X.shape[1], ext_fb, ext_ff) if (X.dim() >= 3 and X.shape[2] == self.output_channels) else None
             if d2 is not None:
                 # FDN structure with a diagonal feedforward path (the delays): that diagonal scales l and the right-hand
                 # side where the solve kernels load them (ops.solve_dud2) instead of in launches of its own
                 return ops.solve_dud2(d2[0], d2[1], d2[2], d2[3], X)
         R = self.feedforward(X, ext_ff)
-        if FUSE_SERIES and ext_param is None and torch.is_tensor(R) and R.is_cuda:
-            dud = self.__factored_loop(R) if self._register_loop else None
+        if FUSE_SERIES and torch.is_tensor(R) and R.is_cuda:
+            dud = self.__factored_loop(R, ext_fb, ext_ff) if self._register_loop else None
             if dud is not None:
                 # FDN structure: P = diag(l) U diag(r) stays factored, A = I - P is built in registers
                 return ops.solve_dud(dud[0], dud[1], dud[2], R)
-            sl = self.__scaled_loop(R) if self._register_loop else None
+            sl = self.__scaled_loop(R, ext_fb, ext_ff) if self._register_loop else None
             if sl is not None:
                 return ops.solve_scaled_loop(sl[0], sl[1], sl[2], R)
-            P = self.__composed_loop(R)
+            P = self.__composed_loop(R, ext_fb, ext_ff)
             if P is not None:
                 return ops.solve(P, R, one_minus=True)
         # generic loop: P = F(B(I)) for ONE batch element (it does not depend on the batch)
@@ -411,37 +412,44 @@ class Recursion(nn.Module):
         P = self.feedforward(self.feedback(I, ext_fb), ext_ff)
         return ops.solve(P, R, one_minus=True)
 
-    def __loop_chain(self):
-        """The per-bin modules of feedback-then-feedforward in the order they act on the identity, or None if
-        some module is not a plain per-bin product."""
+    @staticmethod
+    def __path_items(path, ext):
+        """[(module, its external parameter or None)] of a loop path, with the reference's routing (system.py:409-415 hands a
+        path its `ext_param` entry: a dict keyed by module name for a Series, the tensor itself for a single module)."""
+        if isinstance(path, Series):
+            return [(m, (ext[k] if (isinstance(ext, dict) and k in ext) else None)) for k, m in path._modules.items()]
+        return [(path, ext)]
+
+    def __loop_chain(self, ext_fb=None, ext_ff=None):
+        """The per-bin modules of feedback-then-feedforward in the order they act on the identity, each with its external
+        parameter, or None if some module is not a plain per-bin product."""
         chain = []
-        for path in (self.feedback, self.feedforward):
-            mods = list(path) if isinstance(path, Series) else [path]
-            for m in mods:
+        for path, ext in ((self.feedback, ext_fb), (self.feedforward, ext_ff)):
+            for m, e in self.__path_items(path, ext):
                 if isinstance(m, Series):
                     return None
                 if not (hasattr(m, "_fusable") and m._fusable()):
                     return None
-                chain.append(m)
+                chain.append((m, e))
         return chain
 
-    def __composed_loop(self, R):
+    def __composed_loop(self, R, ext_fb=None, ext_ff=None):
         """P[f] = F[f] B[f] from the modules' responses (the Series planner's composition) instead of pushing a
         (1, M, N, N) identity through them: the first module's product with the identity is its own response --
         one 1.6 GB product and its backward less at N = 32, nfft = 384000."""
-        chain = self.__loop_chain()
+        chain = self.__loop_chain(ext_fb, ext_ff)
         if chain is None:
             return None
         M = R.shape[1]
         shape = [1, M, self.output_channels, self.output_channels]
         acc = None
-        for m in chain:
-            resp = m._response_for_fusion(shape, None)
+        for m, e in chain:
+            resp = m._response_for_fusion(shape, e)
             shape[2] = m.output_channels
             acc = resp if acc is None else _compose(acc, resp, M)
         return _as_signal(acc[0], acc[1], M)
 
-    def __scaled_loop(self, R):
+    def __scaled_loop(self, R, ext_fb=None, ext_ff=None):
         """If the loop is  diag(g) D[f] U  -- feedback = one constant full matrix U, feedforward = one per-bin full matrix D
         that carries no gradient (a matrix of integer delays) followed by constant per-channel gains g (the structure of
         the active-acoustics chain: Recursion(fF=Series(Delay((N,N)), parallelGain(N)), fB=Matrix)) -- return (g, D, U):
@@ -449,14 +457,14 @@ class Recursion(nn.Module):
         gradient tensor (ops.solve_scaled_loop).  Else None."""
         if not SCALED_LOOP:
             return None
-        chain = self.__loop_chain()
+        chain = self.__loop_chain(ext_fb, ext_ff)
         if chain is None or len(chain) != 3:
             return None
         M = R.shape[1]
         shape = [1, M, self.output_channels, self.output_channels]
         resp = []
-        for m in chain:
-            resp.append(m._response_for_fusion(shape, None))
+        for m, e in chain:
+            resp.append(m._response_for_fusion(shape, e))
             shape[2] = m.output_channels
         (U, dU), (D, dD), (g, dg) = resp
         N = self.output_channels
@@ -468,27 +476,28 @@ class Recursion(nn.Module):
             return None
         return g, D, U
 
-    def _fdn_factors(self, M: int):
+    def _fdn_factors(self, M: int, ext_fb=None, ext_ff=None):
         """(l, l2, U, r) when the feedforward path is ONE diagonal per-bin module without gradient (l2: parallelDelay in
         every FDN of the reference) and the feedback path is one constant full matrix with per-bin diagonal factors around
         it (l: those applied after it, r: before); else None.  P = diag(l . l2) U diag(r),  R = l2 . X."""
-        ff = list(self.feedforward) if isinstance(self.feedforward, Series) else [self.feedforward]
+        ffi = self.__path_items(self.feedforward, ext_ff)
+        ff = [m for m, _ in ffi]
         if len(ff) != 1 or isinstance(ff[0], Series) or not (hasattr(ff[0], "_fusable") and ff[0]._fusable()):
             return None
-        fb = list(self.feedback) if isinstance(self.feedback, Series) else [self.feedback]
-        for m in fb:
+        fbi = self.__path_items(self.feedback, ext_fb)
+        for m, _ in fbi:
             if isinstance(m, Series) or not (hasattr(m, "_fusable") and m._fusable()):
                 return None
         N = self.output_channels
         if ff[0].input_channels != N:
             return None
         shape = [1, M, N, N]
-        l2, d2 = ff[0]._response_for_fusion(shape, None)
+        l2, d2 = ff[0]._response_for_fusion(shape, ffi[0][1])
         if not d2 or l2.dim() != 2 or l2.requires_grad or not l2.is_complex():
             return None
         l = r = U = None
-        for m in fb:
-            H, diag = m._response_for_fusion(shape, None)
+        for m, e in fbi:
+            H, diag = m._response_for_fusion(shape, e)
             shape[2] = m.output_channels
             if diag:
                 if H.dim() != 2:
@@ -503,23 +512,22 @@ class Recursion(nn.Module):
                 U = H
         return None if U is None else (l, l2, U, r)
 
-    def __factored_loop(self, R):
+    def __factored_loop(self, R, ext_fb=None, ext_ff=None):
         """If feedback-then-feedforward is a chain of per-bin modules with exactly one full,
         frequency-independent matrix U and otherwise diagonal factors (the structure of every FDN
         in flamo: delays and attenuation are diagonal, only the mixing matrix is full), return
         (l, U, r) with P = diag(l) U diag(r); else None."""
         chain = []
-        for path in (self.feedback, self.feedforward):        # applied in this order to the identity
-            mods = list(path) if isinstance(path, Series) else [path]
-            for m in mods:
+        for path, ext in ((self.feedback, ext_fb), (self.feedforward, ext_ff)):        # applied in this order to the identity
+            for m, e in self.__path_items(path, ext):
                 if not (hasattr(m, "_fusable") and m._fusable()):
                     return None
-                chain.append(m)
+                chain.append((m, e))
         M = R.shape[1]
         shape = [1, M, self.output_channels, self.output_channels]
         l = r = U = None
-        for m in chain:
-            H, diag = m._response_for_fusion(shape, None)
+        for m, e in chain:
+            H, diag = m._response_for_fusion(shape, e)
             shape[2] = m.output_channels
             if diag:
                 if U is None:

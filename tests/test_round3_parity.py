@@ -180,3 +180,65 @@ def test_recursion_beyond_the_register_resident_sizes(gpu, dt, N):
     assert relerr(Y.detach().cpu(), Yr.detach()) < tol
     for gi, gj, k in zip(g, gr, ("g_gain", "g_U")):
         assert relerr(gi.cpu(), gj) < 10 * tol, (k, relerr(gi.cpu(), gj))
+
+
+@gpu_only
+@pytest.mark.parametrize("structure", ["fdn", "chain"])
+def test_recursion_external_parameters_take_the_fused_loop_routes(gpu, structure):
+    """`ext_param` routing of Recursion (system.py:409-415: keys containing "feedback" / "feedforward") through the fused loop forms:
+    the result and the gradients w.r.t. the external tensors equal those of a twin model that owns the same values as parameters,
+    and equal the generic identity-probing route (FUSE_SERIES off)."""
+    from flamo_amd.processor import dsp, system
+    N, nfft, db = 8, 480, 30.0
+    M = nfft // 2 + 1
+    dt = torch.float64
+    kw = dict(nfft=nfft, alias_decay_db=db, device=gpu, dtype=dt)
+
+    def build():
+        torch.manual_seed(7)
+        mix = dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)
+        att = dsp.parallelGain(size=(N,), requires_grad=True, **kw)
+        with torch.no_grad():
+            att.param.copy_(torch.rand(N, device=gpu, dtype=dt) * 0.4 + 0.3)
+        if structure == "fdn":
+            dl = dsp.parallelDelay(size=(N,), max_len=60, isint=True, **kw)
+            ff = dl
+        else:
+            dl = dsp.Delay(size=(N, N), max_len=60, isint=True, **kw)
+            g = dsp.parallelGain(size=(N,), requires_grad=True, **kw)
+            with torch.no_grad():
+                g.param.copy_(torch.rand(N, device=gpu, dtype=dt) * 0.2 / N ** 0.5 + 0.01)
+            ff = system.Series(OrderedDict(d=dl, g=g))
+        return system.Recursion(fF=ff, fB=system.Series(OrderedDict(mixing_matrix=mix, attenuation=att))), mix, att
+
+    torch.manual_seed(11)
+    U_ext = torch.randn(N, N, device=gpu, dtype=dt, requires_grad=True)
+    a_ext = (torch.rand(N, device=gpu, dtype=dt) * 0.4 + 0.3).requires_grad_(True)
+    X = torch.randn(2, M, N, device=gpu, dtype=torch.complex128)
+    C = torch.randn(2, M, N, device=gpu, dtype=torch.complex128)
+    obj = lambda Y: torch.sum(torch.real(Y * torch.conj(C)))      # noqa: E731
+    # twin: owns the values
+    twin, mix_t, att_t = build()
+    mix_t.assign_value(U_ext.detach())
+    att_t.assign_value(a_ext.detach())
+    Yt = twin(X)
+    gt = torch.autograd.grad(obj(Yt), [mix_t.param, att_t.param])
+    # external parameters, fused routes
+    rec, _, _ = build()
+    ext = {"feedback": {"mixing_matrix": U_ext, "attenuation": a_ext}}
+    Y = rec(X, ext)
+    g = torch.autograd.grad(obj(Y), [U_ext, a_ext])
+    assert relerr(Y.detach(), Yt.detach()) < 1e-12
+    for gi, gj in zip(g, gt):
+        assert relerr(gi, gj) < 1e-10
+    # and the generic route
+    system.FUSE_SERIES = False
+    try:
+        rec2, _, _ = build()
+        Yg = rec2(X, ext)
+        gg = torch.autograd.grad(obj(Yg), [U_ext, a_ext])
+    finally:
+        system.FUSE_SERIES = True
+    assert relerr(Y.detach(), Yg.detach()) < 1e-10
+    for gi, gj in zip(g, gg):
+        assert relerr(gi, gj) < 1e-9
