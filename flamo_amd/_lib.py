@@ -40,12 +40,16 @@ _SIGNATURES = {
     "fl_transpose": (_i, [_vp, _vp, _i, _i, _i, _l, _i, _vp]),
     "fl_spec_plan": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     "fl_spec_supports": (_i, [_i, _i, _i]),
+    "fl_spec_supports_f64": (_i, [_i, _i, _i]),
     "fl_spec_aux_elems": (_sz, [_i]),
     "fl_spec_aux_fill_f32": (_i, [_vp, _i, _vp]),
+    "fl_spec_aux_fill_f64": (_i, [_vp, _i, _vp]),
     "fl_debug_set_spec": (_i, [_i, _i]),
     "fl_debug_set_spec_times": (_i, [_vp]),
     "fl_spec_cols_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _vp]),
+    "fl_spec_cols_fwd_f64": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _vp]),
     "fl_spec_mid_f32": (_i, [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
+    "fl_spec_mid_f64": (_i, [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "fl_spec_walk_supports": (_i, [_i, _i, _i]),
     "fl_spec_walk_spectrum_elems": (_sz, [_i, _i, _i]),
     "fl_spec_walk_workgroups": (_i, [_i, _i]),
@@ -56,7 +60,9 @@ _SIGNATURES = {
     "fl_sum_parts_c64": (_i, [_vp, _l, _i, _vp, _l, _vp]),
     "fl_debug_set_walk": (_i, [_i, _i, _i, _vp]),
     "fl_spec_cols_inv_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp]),
+    "fl_spec_cols_inv_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp]),
     "fl_permute_bins_c64": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp]),
+    "fl_permute_bins_c128": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp]),
     "fl_mimo_c64": (_i, [_vp, _l, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _i, _vp]),
     "fl_mimo_c128": (_i, [_vp, _l, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _i, _vp]),
     "fl_mimo_diag_c64": (_i, [_vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),

@@ -23,6 +23,7 @@
 #include "spectral_common.h"
 
 namespace fl {
+namespace FL_SPEC_NS {
 
 // ---------------------------------------------------------------- K1: forward column pass
 // Workgroup = (batch item, tile of CT columns, tile of CG channels): VT = CT*CG "virtual columns" v = cl*CG + gl,
@@ -31,7 +32,7 @@ namespace fl {
 // odd one x[2j+1][g..g+1] (8-byte loads, the VT lanes cover one contiguous run of both sample rows), and one
 // DPP exchange turns that into (re, im) per channel.
 template <int A, int B, int VT, int RG, bool PLAIN>
-__global__ void __launch_bounds__(256, 3) spec_cols_fwd(ColsArgs a) {
+__global__ void __launch_bounds__(256, sizeof(real_t) == 8 ? 2 : 3) spec_cols_fwd(ColsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LEN = A * B, LENP = LEN | 1;
     cf* U = reinterpret_cast<cf*>(smem);   // [VT][LENP]
@@ -44,7 +45,7 @@ __global__ void __launch_bounds__(256, 3) spec_cols_fwd(ColsArgs a) {
     const int CG = 1 << a.cgs;
     const int c0 = ct * a.CT, g0 = gt * CG;
     constexpr int NIT = B * VT, NR = (NIT + 255) / 256;
-    const float* xb = a.x + (size_t)b * a.t_len * a.G + g0;
+    const real_t* xb = a.x + (size_t)b * a.t_len * a.G + g0;
     cf v[RG][A];
     auto load_group = [&](int r0) {
 #pragma unroll
@@ -58,8 +59,8 @@ __global__ void __launch_bounds__(256, 3) spec_cols_fwd(ColsArgs a) {
                 for (int ta = 0; ta < A; ++ta) {
                     const int j = c0 + cl + a.L2 * (ta * B + tb);
                     const int t = 2 * j + par;
-                    float2 q = make_float2(0.f, 0.f);
-                    if (PLAIN || t < a.t_lim) q = at(reinterpret_cast<const float2*>(xb), 4u * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par)));
+                    real2 q = make_real2(0, 0);
+                    if (PLAIN || t < a.t_lim) q = at(reinterpret_cast<const real2*>(xb), RSZ * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par)));
                     v[rr][ta] = cf(q.x, q.y);
                 }
             }
@@ -90,15 +91,15 @@ __global__ void __launch_bounds__(256, 3) spec_cols_fwd(ColsArgs a) {
                     cf q = v[rr][ta];
                     if (!PLAIN && a.env_log2 != 0.0) {
                         const int t = 2 * (c0 + cl + a.L2 * (ta * B + tb)) + par;
-                        const float e = env_at(a.env_log2, t);
+                        const real_t e = env_at(a.env_log2, t);
                         q.x *= e;
                         q.y *= e;
                     }
                     // even lane holds (re_g, re_g+1), odd lane (im_g-1, im_g)
-                    const float got = swap1(par ? q.x : q.y);
+                    const real_t got = swap1(par ? q.x : q.y);
                     v[rr][ta] = par ? cf(got, q.y) : cf(q.x, got);
                 }
-                RegFFT<float, A, false>::run(v[rr]);
+                RegFFT<real_t, A, false>::run(v[rr]);
                 cf* u = U + vv * LENP + tb;
                 u[0] = v[rr][0];
 #pragma unroll
@@ -116,13 +117,13 @@ __global__ void __launch_bounds__(256, 3) spec_cols_fwd(ColsArgs a) {
         const cf* u = U + vv * LENP + ka * B;
 #pragma unroll
         for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
-        RegFFT<float, B, false>::run(v);
+        RegFFT<real_t, B, false>::run(v);
         const cf w1 = a.W[2 * c * ka];
         const cf* w2 = t2 + cl * B;
 #pragma unroll
         for (int kb = 0; kb < B; ++kb) {
             const int k1 = ka + A * kb;
-            at(out, 8u * (((unsigned)k1 * (unsigned)a.L2 + (unsigned)c) * (unsigned)a.G + (unsigned)gl)) = v[kb] * (w1 * w2[kb]);
+            at(out, ESZ * (((unsigned)k1 * (unsigned)a.L2 + (unsigned)c) * (unsigned)a.G + (unsigned)gl)) = v[kb] * (w1 * w2[kb]);
         }
     }
 }
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
                 const int cl = vv >> a.cgs, gl = vv & (CG - 1);
 #pragma unroll
                 for (int ta = 0; ta < A; ++ta)
-                    v[rr][ta] = at(in, 8u * (((unsigned)(ta * B + tb) * (unsigned)a.L2 + (unsigned)(c0 + cl)) * (unsigned)a.G + (unsigned)gl));
+                    v[rr][ta] = at(in, ESZ * (((unsigned)(ta * B + tb) * (unsigned)a.L2 + (unsigned)(c0 + cl)) * (unsigned)a.G + (unsigned)gl));
             }
         }
     };
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
             const int item = threadIdx.x + (r0 + rr) * 256;
             if (r0 + rr < NR && item < NIT) {
                 const int tb = item / VT, vv = item % VT;
-                RegFFT<float, A, true>::run(v[rr]);
+                RegFFT<real_t, A, true>::run(v[rr]);
                 cf* u = U + vv * LENP + tb;
                 u[0] = v[rr][0];
 #pragma unroll
@@ -176,7 +177,7 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
         }
     }
     __syncthreads();
-    float* yb = a.y + (size_t)b * a.t_len * a.G + g0;
+    real_t* yb = a.y + (size_t)b * a.t_len * a.G + g0;
     for (int item = threadIdx.x; item < A * VT; item += 256) {
         const int ka = item / VT, vv = item % VT;
         const int cl = vv >> a.cgs, gl = vv & (CG - 1);
@@ -185,19 +186,19 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
         const cf* u = U + vv * LENP + ka * B;
 #pragma unroll
         for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
-        RegFFT<float, B, true>::run(v);
+        RegFFT<real_t, B, true>::run(v);
 #pragma unroll
         for (int kb = 0; kb < B; ++kb) {
             const int t1 = ka + A * kb;
             const int t = 2 * (c0 + cl + a.L2 * t1) + par;
             // (re_g, im_g) per lane -> even lane (re_g, re_g+1) at sample 2j, odd lane (im_g-1, im_g) at 2j+1
-            const float got = swap1(par ? v[kb].x : v[kb].y);
-            float2 q = par ? make_float2(got, v[kb].y) : make_float2(v[kb].x, got);
-            float s = a.scale;
+            const real_t got = swap1(par ? v[kb].x : v[kb].y);
+            real2 q = par ? make_real2(got, v[kb].y) : make_real2(v[kb].x, got);
+            real_t s = a.scale;
             if (a.env_log2 != 0.0) s *= env_at(a.env_log2, t);
             q.x *= s;
             q.y *= s;
-            if (t < a.t_lim) at(reinterpret_cast<float2*>(yb), 4u * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par))) = q;
+            if (t < a.t_lim) at(reinterpret_cast<real2*>(yb), RSZ * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par))) = q;
         }
     }
 }
@@ -213,7 +214,7 @@ struct MidArgs {
     int conj_h;
     const cf* W;
     int n, L, L1, L2, Bn;
-    float spec_scale;     // scale of the forward transform
+    real_t spec_scale;    // scale of the forward transform
     int spec_interior2;   // double the interior bins of the spectrum (irfft backward)
     int pre_half;         // halve the interior bins in front of the inverse transform (rfft backward)
     int dbg_hfake;        // tuning: every bin reads the first 64 bins' response (cache-resident) -- isolates the fetch cost
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
         if (item >= BG * 2 * B * NI || (slot && selfm) || bb >= nb) return false;
         const unsigned src0 = (unsigned)bb * bstride_i + (unsigned)(slot ? rm : r) * (unsigned)a.L2 * NI + nn;
 #pragma unroll
-        for (int ta = 0; ta < A; ++ta) v[ta] = ld_nt(Sb, 8u * (src0 + (unsigned)(ta * B + tb) * NI));
+        for (int ta = 0; ta < A; ++ta) v[ta] = ld_nt(Sb, ESZ * (src0 + (unsigned)(ta * B + tb) * NI));
         return true;
     };
     const bool have0 = p1_load(tid, v0);
@@ -287,7 +288,7 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
                 have = p1_load(item, v);
             }
             if (!have) continue;
-            RegFFT<float, A, false>::run(v);
+            RegFFT<real_t, A, false>::run(v);
             cf* u = U + (bs * NCH + nn) * LENP + tb;
             u[0] = v[0];
 #pragma unroll
@@ -306,7 +307,7 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
         if (act) {
 #pragma unroll
             for (int tb = 0; tb < B; ++tb) v[tb] = urow[ka * B + tb];
-            RegFFT<float, B, false>::run(v);
+            RegFFT<real_t, B, false>::run(v);
         }
         __syncthreads();
         if (act) {
@@ -322,8 +323,8 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
     // (all input channels) and write their own output channels back into them: one barrier between the two.
     {
         const cf wr = a.W[r];
-        const float hs = 0.5f * a.spec_scale, wi = a.spec_interior2 ? 2.f : 1.f;
-        const float ph = a.pre_half ? 0.5f : 1.f;
+        const real_t hs = (real_t)0.5 * a.spec_scale, wi = a.spec_interior2 ? (real_t)2 : (real_t)1;
+        const real_t ph = a.pre_half ? (real_t)0.5 : (real_t)1;
         const int ms = tid / 256;
         for (int p0 = 0; p0 < LEN; p0 += 256) {
             const int p = p0 + (tid & 255);
@@ -333,7 +334,7 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
             const unsigned ik = (unsigned)r * LEN + p;
             const unsigned im = dc ? (unsigned)a.L : (unsigned)(slotB ? rm : r) * LEN + colB;
             cf xk[BG][NI], xm[BG][NI];
-            cf wk(1.f, 0.f);
+            cf wk(1, 0);
             if (valid) {
                 wk = wr * ws[p];
 #pragma unroll
@@ -343,8 +344,8 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
                         const cf zk = U[((2 * bb) * NCH + nn) * LENP + p];
                         const cf zm = U[((2 * bb + slotB) * NCH + nn) * LENP + colB];
                         if (dc) {
-                            xk[bb][nn] = cf(a.spec_scale * (zk.x + zk.y), 0.f);     // X[0]
-                            xm[bb][nn] = cf(a.spec_scale * (zk.x - zk.y), 0.f);     // X[L]
+                            xk[bb][nn] = cf(a.spec_scale * (zk.x + zk.y), 0);     // X[0]
+                            xm[bb][nn] = cf(a.spec_scale * (zk.x - zk.y), 0);     // X[L]
                         } else {
                             const cf pk = zk + conj(zm), dk = zk - conj(zm);
                             const cf ok = pk + mul_mi(wk * dk);
@@ -368,8 +369,8 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
 #pragma unroll
                             for (int e = 1; e < NI; ++e)
                                 if (e == nn) { vk = xk[bb][e]; vm = xm[bb][e]; }
-                            st_nt(xo, 8u * ((unsigned)nn * (unsigned)a.xs_n + ik), vk);
-                            if (im != ik) st_nt(xo, 8u * ((unsigned)nn * (unsigned)a.xs_n + im), vm);
+                            st_nt(xo, ESZ * ((unsigned)nn * (unsigned)a.xs_n + ik), vk);
+                            if (im != ik) st_nt(xo, ESZ * ((unsigned)nn * (unsigned)a.xs_n + im), vm);
                         }
                     }
                 }
@@ -383,7 +384,7 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
             // plane (m, n) is a workgroup-uniform base (scalar arithmetic), the bin the lane's 32-bit offset
             constexpr int NB = PFD + 1;
             cf hrows[NB][2 * NI];
-            const unsigned hoff_k = a.dbg_hfake ? 8u * (ik & 63u) : 8u * ik, hoff_m = a.dbg_hfake ? 8u * (im & 63u) : 8u * im;
+            const unsigned hoff_k = a.dbg_hfake ? ESZ * (ik & 63u) : ESZ * ik, hoff_m = a.dbg_hfake ? ESZ * (im & 63u) : ESZ * im;
             auto load_row = [&](int m2, cf* dst) {
                 const cf* Hm = a.H + (size_t)__builtin_amdgcn_readfirstlane(ms * (NO / MS) + m2) * a.hs_m;
 #pragma unroll
@@ -417,8 +418,8 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
                 for (int bb = 0; bb < BG; ++bb) {
                     cf yk, ym;
                     if (HAS_H) {
-                        yk = cf(0.f, 0.f);
-                        ym = cf(0.f, 0.f);
+                        yk = cf(0, 0);
+                        ym = cf(0, 0);
 #pragma unroll
                         for (int nn = 0; nn < NI; ++nn) {
                             fma_cx(yk, hkv[nn], xk[bb][nn]);
@@ -458,8 +459,8 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
         //   c) Hermitian pre-step per (item, pair), in place
         static_assert(HAS_H && DO_INV && NTH == BG, "three-sweep product: response + inverse half, 256 threads per item");
         const cf wr = a.W[r];
-        const float hs = 0.5f * a.spec_scale, wi = a.spec_interior2 ? 2.f : 1.f;
-        const float ph = a.pre_half ? 0.5f : 1.f;
+        const real_t hs = (real_t)0.5 * a.spec_scale, wi = a.spec_interior2 ? (real_t)2 : (real_t)1;
+        const real_t ph = a.pre_half ? (real_t)0.5 : (real_t)1;
         const int bbt = tid / 256;                      // the batch item this thread serves in sweeps a and c
         for (int p0 = 0; p0 < LEN; p0 += 256) {        // ---- a
             const int p = p0 + (tid & 255);
@@ -477,8 +478,8 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
                 const cf zk = *pk, zm = *pm;
                 cf xk, xm;
                 if (dc) {
-                    xk = cf(a.spec_scale * (zk.x + zk.y), 0.f);     // X[0]
-                    xm = cf(a.spec_scale * (zk.x - zk.y), 0.f);     // X[L]
+                    xk = cf(a.spec_scale * (zk.x + zk.y), 0);     // X[0]
+                    xm = cf(a.spec_scale * (zk.x - zk.y), 0);     // X[L]
                     nyq[bbt * NCH + nn] = xm;
                 } else {
                     const cf pk_ = zk + conj(zm), dk = zk - conj(zm);
@@ -492,8 +493,8 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
                 }
                 *pk = xk;
                 if (xo) {
-                    st_nt(xo, 8u * ((unsigned)nn * (unsigned)a.xs_n + ik), xk);
-                    if (im != ik) st_nt(xo, 8u * ((unsigned)nn * (unsigned)a.xs_n + im), xm);
+                    st_nt(xo, ESZ * ((unsigned)nn * (unsigned)a.xs_n + ik), xk);
+                    if (im != ik) st_nt(xo, ESZ * ((unsigned)nn * (unsigned)a.xs_n + im), xm);
                 }
             }
         }
@@ -510,7 +511,7 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
 #pragma unroll
                     for (int nn = 0; nn < NI; ++nn)
                         x[bb][nn] = isnyq ? nyq[bb * NCH + nn] : U[((2 * bb + slot) * NCH + nn) * LENP + col];
-                const unsigned hoff = 8u * ib;
+                const unsigned hoff = ESZ * ib;
                 // MC response rows requested together (MC*NI loads in flight per thread): the sweep is a chain of
                 // NO/MC load round trips, each ~3.5k cycles under the kernel's own traffic -- not NO of them
                 // (MC = 4 rows in flight spills under the 128-register cap of this form and measured slower: 109 us against 95)
@@ -532,7 +533,7 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
                         }
 #pragma unroll
                         for (int bb = 0; bb < BG; ++bb) {
-                            cf y(0.f, 0.f);
+                            cf y(0, 0);
 #pragma unroll
                             for (int nn = 0; nn < NI; ++nn) fma_cx(y, h[mc][nn], x[bb][nn]);
                             if (isnyq) nyq[bb * NCH + m0 + mc] = y;
@@ -577,7 +578,7 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
         cf v[A];
 #pragma unroll
         for (int ta = 0; ta < A; ++ta) v[ta] = u[ta * B];
-        RegFFT<float, A, true>::run(v);
+        RegFFT<real_t, A, true>::run(v);
         u[0] = v[0];
 #pragma unroll
         for (int ka = 1; ka < A; ++ka) u[ka * B] = v[ka] * conj(tw[ka * tb]);
@@ -597,13 +598,13 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
             const cf* u = U + (bs * NCH + m) * LENP + ka * B;
 #pragma unroll
             for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
-            RegFFT<float, B, true>::run(v);
+            RegFFT<real_t, B, true>::run(v);
             const cf w1 = a.W[2 * row * ka];
             const unsigned dst0 = (unsigned)bb * bstride_o + (unsigned)row * (unsigned)a.L2 * NO + m;
 #pragma unroll
             for (int kb = 0; kb < B; ++kb) {
                 const int c = ka + A * kb;
-                st_nt(S2b, 8u * (dst0 + (unsigned)c * NO), v[kb] * conj(w1 * wi2[slot * B + kb]));
+                st_nt(S2b, ESZ * (dst0 + (unsigned)c * NO), v[kb] * conj(w1 * wi2[slot * B + kb]));
             }
         }
     }
@@ -642,6 +643,8 @@ __global__ void __launch_bounds__(256) permute_bins_kernel(const cf* __restrict_
 // 5 (launch_cols / launch_mid below), L2 >= L1 so that a row pair of all channels stays small.  The three BASELINE lengths
 // carry every channel combination and the tuning variants; the others -- the reference's default 2^11 (dsp.py:84), the
 // powers of two up to 2^17, 48000 and 144000 (one and three seconds at 48 kHz) -- the equal-channel kernels.
+}  // namespace FL_SPEC_NS
+#ifndef FL_F64
 struct PlanEntry { int nfft, L1, L2, lean; };
 static const PlanEntry kPlans[] = {{96000, 200, 240, 0}, {192000, 300, 320, 0}, {384000, 400, 480, 0},
                                    {2048, 32, 32, 1},    {4096, 32, 64, 1},     {8192, 64, 64, 1},     {16384, 64, 128, 1},
@@ -663,14 +666,22 @@ int spec_plan(int nfft, int& L1, int& L2) {
     return FL_ERR_UNSUPPORTED;
 }
 
+int spec_plan_lean(int nfft) {
+    const PlanEntry* p = plan_of(nfft);
+    return p ? p->lean : 1;
+}
+#endif
+namespace FL_SPEC_NS {
+
 static int g_spec_vt = 0, g_spec_rg = 0;      // 0 = pick per shape (below); fl_debug_set_spec overrides
 
 // Column-pass tile: virtual columns per workgroup and loads in flight per thread group. Measured under graph replay on
 // the whole training step (tools/dbg/graph_ab.py): 16 virtual columns (27 KB of LDS, five workgroups per CU) win for
 // up to 8 channels at every plan length (3 % at nfft=96000, 11 % at 192000); with 16 channels a 16-wide tile would be a
 // single column of 128-byte segments and the 32-wide tile with all loads in flight is ahead.
-static int cols_vt(int G) { return g_spec_vt ? g_spec_vt : (G <= 8 ? 16 : 32); }
-static int cols_rg(int vt, int L1) { return g_spec_rg ? g_spec_rg : (vt == 32 ? 4 : (L1 <= 200 ? 1 : 2)); }
+// (float64: always the 16-wide tile -- its LDS is twice the float32 tile's)
+static int cols_vt(int G) { return sizeof(real_t) == 8 ? 16 : g_spec_vt ? g_spec_vt : (G <= 8 ? 16 : 32); }
+static int cols_rg(int vt, int L1) { return sizeof(real_t) == 8 ? 1 : g_spec_rg ? g_spec_rg : (vt == 32 ? 4 : (L1 <= 200 ? 1 : 2)); }
 
 static int cols_setup(ColsArgs& a, int nfft, int Bn, int t_len, int t_lim, int G, const void* W, int vt) {
     int L1, L2;
@@ -701,7 +712,9 @@ static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStrea
         else hipLaunchKernelGGL((spec_cols_fwd<A, B, VT_, RG_, false>), dim3(nblk), dim3(256), lds, st, a);      \
     }
     const int vt = a.CT << a.cgs;
-    if constexpr (LEAN) {      // one load-group choice per tile width
+    if constexpr (sizeof(real_t) == 8) {      // float64: the 16-wide tile, one load group (its values are four registers each)
+        FL_COLS(16, 1)
+    } else if constexpr (LEAN) {              // one load-group choice per tile width
         if (vt == 32) FL_COLS(32, 2) else FL_COLS(16, 2)
     } else {
         if (vt == 32) {
@@ -834,12 +847,29 @@ static int launch_mid(const MidArgs& a, int NI, int NO, unsigned nblk, hipStream
     return FL_ERR_UNSUPPORTED;
 }
 
+}  // namespace FL_SPEC_NS
 }  // namespace fl
 
 using namespace fl;
+using namespace fl::FL_SPEC_NS;
+
+#ifdef FL_F64
+#define FL_SPEC_FN(base) base##_f64
+#define FL_SPEC_CFN(base) base##_c128
+#else
+#define FL_SPEC_FN(base) base##_f32
+#define FL_SPEC_CFN(base) base##_c64
+#endif
+
+// LDS of the column kernels for G channels: (VT (L1 | 1) + L1 + VT B) complex values, B <= 25
+static size_t cols_lds_need(int L1, int G) {
+    const int vt = cols_vt(G);
+    return ((size_t)vt * (L1 | 1) + L1 + (size_t)vt * 25) * sizeof(cf);
+}
 
 extern "C" {
 
+#ifndef FL_F64
 int fl_spec_plan(int nfft, int* L1, int* L2) {
     int l1 = 0, l2 = 0;
     int rc = spec_plan(nfft, l1, l2);
@@ -855,7 +885,9 @@ size_t fl_spec_aux_elems(int nfft) {
     return (size_t)l1 + 2 * (size_t)l2;
 }
 
-int fl_spec_aux_fill_f32(void* W, int nfft, void* stream) {
+#endif
+
+int FL_SPEC_FN(fl_spec_aux_fill)(void* W, int nfft, void* stream) {
     FL_REQUIRE(W, "spec_aux_fill: null pointer");
     int l1, l2;
     int rc = spec_plan(nfft, l1, l2);
@@ -865,13 +897,17 @@ int fl_spec_aux_fill_f32(void* W, int nfft, void* stream) {
     return FL_OK;
 }
 
+#ifdef FL_F64
+int fl_spec_supports_f64(int nfft, int n_in, int n_out) {
+#else
 int fl_spec_supports(int nfft, int n_in, int n_out) {
+#endif
     int l1, l2;
     if (spec_plan(nfft, l1, l2) != FL_OK) return 0;
     auto ok = [](int c) { return c == 2 || c == 4 || c == 8 || c == 16; };
     if (!ok(n_in) || !ok(n_out)) return 0;
     if (n_in != n_out && (n_in > 8 || n_out > 8)) return 0;
-    if (n_in != n_out && plan_of(nfft)->lean) return 0;
+    if (n_in != n_out && (spec_plan_lean(nfft) || sizeof(real_t) == 8)) return 0;
     // the row kernel holds a row pair of all channels in LDS: (2 max(n_in, n_out) (L2 | 1) + 2 L2 + ...) complex values --
     // 131 KB at 16 channels, nfft = 384000; a part with less LDS per workgroup than that takes the layered route
     static int lds_limit = 0;
@@ -883,9 +919,11 @@ int fl_spec_supports(int nfft, int n_in, int n_out) {
     }
     const int nch = n_in > n_out ? n_in : n_out;
     const size_t need = ((size_t)2 * nch * (l2 | 1) + 2 * (size_t)l2 + 64 + nch) * sizeof(cf);
-    return need <= (size_t)lds_limit ? 1 : 0;
+    if (need > (size_t)lds_limit) return 0;
+    return cols_lds_need(l1, n_in) <= (size_t)lds_limit && cols_lds_need(l1, n_out) <= (size_t)lds_limit ? 1 : 0;
 }
 
+#ifndef FL_F64
 int fl_debug_set_spec_times(void* buf) {
     g_mid_times = (long long*)buf;
     return FL_OK;
@@ -896,41 +934,42 @@ int fl_debug_set_spec(int vt, int rg) {
     g_spec_rg = (rg % 100 == 1 || rg % 100 == 4 || rg % 100 == 2) ? rg % 100 : 0;
     g_mid_bg = (rg >= 100) ? (rg / 100) % 10 : 1;
     g_mid_hfake = (rg / 1000) % 10 == 1;
-    g_mid_pfd = (rg / 10000) % 10;       // rg = 10000*prefetch depth + 1000*fake + 100*bg + load group     // rg = 100*(2: two batch items per workgroup) + load group
+    g_mid_pfd = (rg / 10000) % 10;       // rg = 10000*prefetch depth + 1000*fake + 100*bg + load group
     return FL_OK;
 }
+#endif
 
-int fl_spec_cols_fwd_f32(const void* x, int Bn, int t_len, int G, void* S, const void* W, int nfft, double env_log2,
+int FL_SPEC_FN(fl_spec_cols_fwd)(const void* x, int Bn, int t_len, int G, void* S, const void* W, int nfft, double env_log2,
                          void* stream) {
     FL_REQUIRE(x && S, "spec_cols_fwd: null pointer");
-    FL_REQUIRE(reinterpret_cast<uintptr_t>(x) % 8 == 0, "spec_cols_fwd: x must be 8-byte aligned");
+    FL_REQUIRE(reinterpret_cast<uintptr_t>(x) % (2 * RSZ) == 0, "spec_cols_fwd: x must be aligned to two samples");
     if (Bn == 0) return FL_OK;
     ColsArgs a = {};
     int rc = cols_setup(a, nfft, Bn, t_len, t_len, G, W, cols_vt(G));
     if (rc) return rc;
-    a.x = (const float*)x;
+    a.x = (const real_t*)x;
     a.S = (cf*)S;
     a.env_log2 = env_log2;
     return cols_launch(false, a, Bn, (hipStream_t)stream);
 }
 
-int fl_spec_cols_inv_f32(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+int FL_SPEC_FN(fl_spec_cols_inv)(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                          double env_log2, void* stream) {
     FL_REQUIRE(S2 && y, "spec_cols_inv: null pointer");
-    FL_REQUIRE(reinterpret_cast<uintptr_t>(y) % 8 == 0, "spec_cols_inv: y must be 8-byte aligned");
+    FL_REQUIRE(reinterpret_cast<uintptr_t>(y) % (2 * RSZ) == 0, "spec_cols_inv: y must be aligned to two samples");
     FL_REQUIRE(t_out >= 0 && t_out <= t_len, "spec_cols_inv: t_out must be in [0, t_len]");
     if (Bn == 0) return FL_OK;
     ColsArgs a = {};
     int rc = cols_setup(a, nfft, Bn, t_len, t_out, G, W, cols_vt(G));
     if (rc) return rc;
-    a.y = (float*)y;
+    a.y = (real_t*)y;
     a.S = (cf*)S2;
-    a.scale = (float)scale;
+    a.scale = (real_t)scale;
     a.env_log2 = env_log2;
     return cols_launch(true, a, Bn, (hipStream_t)stream);
 }
 
-int fl_spec_mid_f32(const void* S, void* S2, void* Xs, long xs_b, long xs_n, const void* H, long hs_m, long hs_n, int conj_h,
+int FL_SPEC_FN(fl_spec_mid)(const void* S, void* S2, void* Xs, long xs_b, long xs_n, const void* H, long hs_m, long hs_n, int conj_h,
                     const void* W, int nfft, int Bn, int NI, int NO, double spec_scale, int spec_interior2, int pre_half,
                     void* stream) {
     FL_REQUIRE(S && W, "spec_mid: null pointer");
@@ -944,15 +983,21 @@ int fl_spec_mid_f32(const void* S, void* S2, void* Xs, long xs_b, long xs_n, con
     a.S = (const cf*)S; a.S2 = (cf*)S2; a.Xs = (cf*)Xs; a.xs_b = xs_b; a.xs_n = xs_n;
     a.H = (const cf*)H; a.hs_m = hs_m; a.hs_n = hs_n; a.conj_h = conj_h;
     a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn;
-    a.spec_scale = (float)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half; a.dbg_hfake = g_mid_hfake; a.dbg_times = g_mid_times;
+    a.spec_scale = (real_t)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half; a.dbg_hfake = g_mid_hfake; a.dbg_times = g_mid_times;
     const int P = a.L1 / 2 + 1;
     const size_t nblk = (size_t)cdiv_i(P, 8) * 8 * Bn;
     FL_REQUIRE(nblk < (1ull << 31), "spec_mid: grid too large");
     hipStream_t st = (hipStream_t)stream;
     switch (a.L2) {
+#ifdef FL_F64       // float64: one workgroup per (row pair, batch item), equal channel counts, at every plan length
+        case 240: rc = launch_mid_lean<16, 15>(a, NI, NO, st); break;
+        case 320: rc = launch_mid_lean<16, 20>(a, NI, NO, st); break;
+        case 480: rc = launch_mid_lean<32, 15>(a, NI, NO, st); break;
+#else
         case 240: rc = launch_mid<16, 15>(a, NI, NO, (unsigned)nblk, st); break;
         case 320: rc = launch_mid<16, 20>(a, NI, NO, (unsigned)nblk, st); break;
         case 480: rc = launch_mid<32, 15>(a, NI, NO, (unsigned)nblk, st); break;
+#endif
         case 32: rc = launch_mid_lean<8, 4>(a, NI, NO, st); break;
         case 64: rc = launch_mid_lean<8, 8>(a, NI, NO, st); break;
         case 128: rc = launch_mid_lean<16, 8>(a, NI, NO, st); break;
@@ -965,7 +1010,7 @@ int fl_spec_mid_f32(const void* S, void* S2, void* Xs, long xs_b, long xs_n, con
     return FL_OK;
 }
 
-int fl_permute_bins_c64(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
+int FL_SPEC_CFN(fl_permute_bins)(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
                         void* stream) {
     FL_REQUIRE(src && dst && nplanes >= 0 && nplanes <= 65535, "permute_bins: bad arguments");
     int L1, L2;

@@ -7,23 +7,48 @@
 #include "regfft.h"
 #include <type_traits>
 
+// The pipeline's kernels exist in float32 and float64: spectral.hip is compiled twice (the Makefile's second rule adds
+// -DFL_F64: real_t = double, exports *_f64 / *_c128), each build in a namespace of its own so that the two sets of kernels
+// and argument structs do not collide.  specwalk.hip (float32 only) sees the float32 names.
+#ifdef FL_F64
+#define FL_SPEC_NS sp64
+#else
+#define FL_SPEC_NS sp32
+#endif
+
 namespace fl {
+namespace FL_SPEC_NS {
 
-typedef cx<float> cf;
+#ifdef FL_F64
+typedef double real_t;
+typedef double2 real2;
+__device__ __forceinline__ real2 make_real2(double a, double b) { return make_double2(a, b); }
+#else
+typedef float real_t;
+typedef float2 real2;
+__device__ __forceinline__ real2 make_real2(float a, float b) { return make_float2(a, b); }
+#endif
+typedef cx<real_t> cf;
+constexpr unsigned ESZ = sizeof(cf), RSZ = sizeof(real_t);      // bytes per complex / real element (32-bit lane offsets)
 
-// lane <-> lane^1 exchange of one dword (DPP quad_perm [1,0,3,2])
+// lane <-> lane^1 exchange (DPP quad_perm [1,0,3,2]), one dword at a time
 __device__ __forceinline__ float swap1(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
 }
+__device__ __forceinline__ double swap1(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 
 struct ColsArgs {
-    const float* x;       // forward: real (Bn, t_len, G)
-    float* y;             // inverse: real (Bn, t_len, G)
+    const real_t* x;      // forward: real (Bn, t_len, G)
+    real_t* y;            // inverse: real (Bn, t_len, G)
     cf* S;                // (Bn, L1, L2, G)
     const cf* W;          // W_n^j, j < n
     int n, L, L1, L2, G, cgs /* log2 CG */, CT, nct /* L2 / CT */, ngt /* G / CG */;
     int t_len, t_lim;
-    float scale;
+    real_t scale;
     double env_log2;
 };
 
@@ -37,7 +62,7 @@ __device__ __forceinline__ P& at(P* base, unsigned byte_off) {
 
 // streaming data (read once / written once): non-temporal, so that it does not evict the response slices the batch
 // items of a row pair share in the XCD's L2
-typedef float v2f __attribute__((ext_vector_type(2)));
+typedef real_t v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ cf ld_nt(const cf* base, unsigned byte_off) {
     const v2f q = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(base) + byte_off));
     return cf(q.x, q.y);
@@ -49,7 +74,11 @@ __device__ __forceinline__ void st_nt(cf* base, unsigned byte_off, cf v) {
     __builtin_nontemporal_store(q, reinterpret_cast<v2f*>(reinterpret_cast<char*>(base) + byte_off));
 }
 
+#ifdef FL_F64
+__device__ __forceinline__ double env_at(double env_log2, int t) { return exp2(env_log2 * (double)t); }
+#else
 __device__ __forceinline__ float env_at(double env_log2, int t) { return exp2f((float)(env_log2 * (double)t)); }
+#endif
 
 // bin pair (k, L-k) number p of primary row r: where the partner sits (slot, column); false when p owns no pair
 __device__ __forceinline__ bool pair_of(int r, bool selfm, int p, int LEN, int& slotB, int& colB, bool& dc) {
@@ -71,7 +100,10 @@ __device__ __forceinline__ bool pair_of(int r, bool selfm, int p, int LEN, int& 
 }
 
 
-// the fused plan of a transform length (spectral.hip)
+}  // namespace FL_SPEC_NS
+
+// the fused plan of a transform length (spectral.hip, float32 build)
 int spec_plan(int nfft, int& L1, int& L2);
+int spec_plan_lean(int nfft);
 
 }  // namespace fl

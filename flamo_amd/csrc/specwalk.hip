@@ -25,6 +25,7 @@
 #include "spectral_common.h"
 
 namespace fl {
+using namespace sp32;      // these kernels exist in float32 only (spectral_common.h)
 
 struct WalkArgs {
     const cf* S;          // (Bn, L1, L2, NI)

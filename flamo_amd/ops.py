@@ -96,14 +96,15 @@ def twiddles(nfft: int, real: torch.dtype, device: torch.device) -> torch.Tensor
             ent = _twiddles.get(key)
             if ent is None:
                 L = _lib.lib()
-                # float32 tables of the fused pipeline's lengths carry its contiguous copies behind the nfft entries
-                aux = int(L.fl_spec_aux_elems(int(nfft))) if real == torch.float32 else 0
+                # tables of the fused pipeline's lengths carry its contiguous copies behind the nfft entries
+                aux = int(L.fl_spec_aux_elems(int(nfft)))
                 W = torch.empty(nfft + aux, dtype=_cdtype(real), device=device)
                 fn = L.fl_twiddle_fill_f32 if real == torch.float32 else L.fl_twiddle_fill_f64
                 cur = torch.cuda.current_stream(device)
                 _lib.check(fn(W.data_ptr(), nfft, cur.cuda_stream), "twiddle_fill")
                 if aux:
-                    _lib.check(L.fl_spec_aux_fill_f32(W.data_ptr(), nfft, cur.cuda_stream), "spec_aux_fill")
+                    fill = L.fl_spec_aux_fill_f32 if real == torch.float32 else L.fl_spec_aux_fill_f64
+                    _lib.check(fill(W.data_ptr(), nfft, cur.cuda_stream), "spec_aux_fill")
                 ev = torch.cuda.Event()
                 ev.record(cur)
                 if not torch.cuda.is_current_stream_capturing():
@@ -578,9 +579,16 @@ def irfft(X: torch.Tensor, nfft: int, norm: str = "backward", alias_decay_db: Op
 # y = irfft(H[f] . rfft(x)) in three launches (csrc/spectral.hip): time-domain tensors stay channel-innermost
 # (B, T, G), the spectrum between the transforms and the product never goes through HBM, and what does cross the
 # boundary (the spectrum kept for the backward pass, H, dL/dH) is bin-planar in ROW-MAJOR BIN ORDER
-# (bin k = k1 + L1 k2 at element k1 L2 + k2).  float32 only; everything else takes the layered operators above.
-def spectral_supported(nfft: int, n_in: int, n_out: int) -> bool:
-    return bool(_lib.lib().fl_spec_supports(int(nfft), int(n_in), int(n_out)))
+# (bin k = k1 + L1 k2 at element k1 L2 + k2).  float32 and float64 (the same kernels compiled for double, one workgroup per
+# (row pair, batch item) and equal channel counts only); everything else takes the layered operators above.
+def spectral_supported(nfft: int, n_in: int, n_out: int, real: torch.dtype = torch.float32) -> bool:
+    L = _lib.lib()
+    fn = L.fl_spec_supports if real == torch.float32 else L.fl_spec_supports_f64
+    return bool(fn(int(nfft), int(n_in), int(n_out)))
+
+
+def _spec_fn(name: str, real: torch.dtype):
+    return getattr(_lib.lib(), name + ("_f32" if real == torch.float32 else "_f64"))
 
 
 class _PermuteBins(torch.autograd.Function):
@@ -589,16 +597,17 @@ class _PermuteBins(torch.autograd.Function):
     @staticmethod
     def forward(ctx, H, nfft, inverse):
         _require_gpu(H)
-        if H.dtype != torch.complex64:
-            raise TypeError("permute_bins expects a complex64 tensor")
+        if H.dtype not in (torch.complex64, torch.complex128):
+            raise TypeError("permute_bins expects a complex64 / complex128 tensor")
         M = nfft // 2 + 1
         if H.shape[0] != M:
             raise ValueError(f"permute_bins: expected {M} bins along dim 0, got {H.shape[0]}")
         Hp = _h_planar(H.resolve_conj(), True)
         rest = tuple(H.shape[1:])
         out = _empty_rows(rest, M, H.dtype, H.device)
-        _lib.check(_lib.lib().fl_permute_bins_c64(Hp.data_ptr(), _lead_pitch(Hp.movedim(0, -1)), out.data_ptr(), _pitch(M),
-                                                  max(_prod(rest), 1), nfft, int(inverse), _stream()), "permute_bins")
+        fn = _lib.lib().fl_permute_bins_c64 if H.dtype == torch.complex64 else _lib.lib().fl_permute_bins_c128
+        _lib.check(fn(Hp.data_ptr(), _lead_pitch(Hp.movedim(0, -1)), out.data_ptr(), _pitch(M),
+                      max(_prod(rest), 1), nfft, int(inverse), _stream()), "permute_bins")
         ctx.cfg = (nfft, inverse)
         return out.movedim(-1, 0)
 
@@ -614,12 +623,12 @@ def permute_bins(H: torch.Tensor, nfft: int, inverse: bool = False) -> torch.Ten
 
 
 def _spec_cols_fwd(x, nfft, env_log2):
-    """x: contiguous real float32 (B, T, G) -> scratch (B*L*G,) complex64"""
+    """x: contiguous real (B, T, G) -> scratch (B*L*G,) complex"""
     B, T, G = x.shape
-    S = torch.empty(B * (nfft // 2) * G, dtype=torch.complex64, device=x.device)
+    S = torch.empty(B * (nfft // 2) * G, dtype=_cdtype(x.dtype), device=x.device)
     with kernel_timer.span("spec_cols_fwd"):
-        _lib.check(_lib.lib().fl_spec_cols_fwd_f32(x.data_ptr(), B, T, G, S.data_ptr(),
-                                                   twiddles(nfft, torch.float32, x.device).data_ptr(), nfft, env_log2, _stream()),
+        _lib.check(_spec_fn("fl_spec_cols_fwd", x.dtype)(x.data_ptr(), B, T, G, S.data_ptr(),
+                                                         twiddles(nfft, x.dtype, x.device).data_ptr(), nfft, env_log2, _stream()),
                    "spec_cols_fwd")
     return S
 
@@ -628,10 +637,11 @@ def _spec_mid(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, want_inverse, spec_sca
     """-> (S2 or None, spectrum rows (B, NI, M) or None).  Hrm: (M, NO_h, NI_h) row-major-order response view or None."""
     dev = S.device
     M = nfft // 2 + 1
-    Xs = _empty_rows((B, NI), M, torch.complex64, dev) if want_spec else None
+    real = _rdtype(S)
+    Xs = _empty_rows((B, NI), M, S.dtype, dev) if want_spec else None
     S2 = None
     if want_inverse:
-        S2 = S if NI == NO else torch.empty(B * (nfft // 2) * NO, dtype=torch.complex64, device=dev)   # row pairs are private: in place
+        S2 = S if NI == NO else torch.empty(B * (nfft // 2) * NO, dtype=S.dtype, device=dev)   # row pairs are private: in place
     hp = hs_m = hs_n = 0
     if Hrm is not None:
         hp = _lead_pitch(Hrm.movedim(0, -1))
@@ -641,21 +651,22 @@ def _spec_mid(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, want_inverse, spec_sca
     P = _pitch(M)
     tag = f"spec_mid[{NI}->{NO}" + (",H" if Hrm is not None else "") + (",inv" if want_inverse else "") + (",spec" if want_spec else "") + "]"
     with kernel_timer.span(tag):
-        _lib.check(_lib.lib().fl_spec_mid_f32(S.data_ptr(), None if S2 is None else S2.data_ptr(),
-                                              None if Xs is None else Xs.data_ptr(), NI * P, P,
-                                              None if Hrm is None else Hrm.data_ptr(), hs_m, hs_n, int(bool(conj_t)),
-                                              twiddles(nfft, torch.float32, dev).data_ptr(), nfft, B, NI, NO, spec_scale,
-                                              int(interior2), int(pre_half), _stream()), "spec_mid")
+        _lib.check(_spec_fn("fl_spec_mid", real)(S.data_ptr(), None if S2 is None else S2.data_ptr(),
+                                                 None if Xs is None else Xs.data_ptr(), NI * P, P,
+                                                 None if Hrm is None else Hrm.data_ptr(), hs_m, hs_n, int(bool(conj_t)),
+                                                 twiddles(nfft, real, dev).data_ptr(), nfft, B, NI, NO, spec_scale,
+                                                 int(interior2), int(pre_half), _stream()), "spec_mid")
     return S2, Xs
 
 
 def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2):
     alloc = torch.zeros if t_len > t_out else torch.empty
-    y = alloc((B, t_len, G), dtype=torch.float32, device=S2.device)
+    real = _rdtype(S2)
+    y = alloc((B, t_len, G), dtype=real, device=S2.device)
     with kernel_timer.span("spec_cols_inv"):
-        _lib.check(_lib.lib().fl_spec_cols_inv_f32(S2.data_ptr(), y.data_ptr(), B, t_len, t_out, G,
-                                                   twiddles(nfft, torch.float32, S2.device).data_ptr(), nfft, scale, env_log2,
-                                                   _stream()), "spec_cols_inv")
+        _lib.check(_spec_fn("fl_spec_cols_inv", real)(S2.data_ptr(), y.data_ptr(), B, t_len, t_out, G,
+                                                      twiddles(nfft, real, S2.device).data_ptr(), nfft, scale, env_log2,
+                                                      _stream()), "spec_cols_inv")
     return y
 
 
@@ -735,21 +746,21 @@ class _SpectralApply(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Hrm, nfft, scale_f, env_f, scale_i, env_i):
         _require_gpu(x, Hrm)
-        if x.dtype != torch.float32 or x.dim() != 3:
-            raise TypeError("spectral_apply expects a real float32 (B, T, N) signal")
+        if x.dtype not in (torch.float32, torch.float64) or x.dim() != 3:
+            raise TypeError("spectral_apply expects a real float32 / float64 (B, T, N) signal")
         M = nfft // 2 + 1
-        if Hrm.dim() != 3 or Hrm.shape[0] != M or Hrm.dtype != torch.complex64:
-            raise ValueError(f"spectral_apply: the response must be complex64 ({M}, N_out, N_in)")
+        if Hrm.dim() != 3 or Hrm.shape[0] != M or Hrm.dtype != _cdtype(x.dtype):
+            raise ValueError(f"spectral_apply: the response must be {_cdtype(x.dtype)} ({M}, N_out, N_in)")
         NO, NI = Hrm.shape[1], Hrm.shape[2]
         if x.shape[2] != NI:
             raise ValueError(f"response expects {NI} input channels, signal has {x.shape[2]}")
         xc = x.contiguous()
-        if xc.data_ptr() % 8:
+        if xc.data_ptr() % (2 * xc.element_size()):
             xc = xc.clone()
         Hp = _h_planar(Hrm.resolve_conj(), True)
         B, T = xc.shape[0], xc.shape[1]
         S = _spec_cols_fwd(xc, nfft, env_f)
-        walk = _walk_applies(nfft, B, NI, NO)
+        walk = x.dtype == torch.float32 and _walk_applies(nfft, B, NI, NO)
         if walk:
             S2, Xs = _spec_mid_walk(S, B, NI, NO, nfft, Hp, False, ctx.needs_input_grad[1], scale_f, 0, 0)
         else:
@@ -765,7 +776,7 @@ class _SpectralApply(torch.autograd.Function):
         nfft, scale_f, env_f, scale_i, env_i, T, NI, NO, walk = ctx.cfg
         need_x, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g = gy.contiguous()
-        if g.data_ptr() % 8:
+        if g.data_ptr() % (2 * g.element_size()):
             g = g.clone()
         B = g.shape[0]
         # irfft' : g_Y[k] = w_k scale_i sum_t g_y[t] e_i(t) exp(-j w_k t) -- a forward transform with doubled interior bins
@@ -794,7 +805,7 @@ class _SpectralApply(torch.autograd.Function):
 
 def spectral_apply(x: torch.Tensor, Hrm: torch.Tensor, nfft: int, norm_f: str = "backward", norm_i: str = "backward",
                    db_f: Optional[float] = None, db_i: Optional[float] = None) -> torch.Tensor:
-    """irfft(H[f] . rfft(x [* gamma_f^-t], n=nfft, norm_f), n=nfft, norm_i) [* gamma_i^-t] along dim 1 of a real float32
+    """irfft(H[f] . rfft(x [* gamma_f^-t], n=nfft, norm_f), n=nfft, norm_i) [* gamma_i^-t] along dim 1 of a real float32 / float64
     (B, T, N_in) signal, with ``Hrm`` the (M, N_out, N_in) per-bin response in ROW-MAJOR bin order
     (``permute_bins``).  Returns (B, nfft, N_out), contiguous."""
     if norm_f not in _NORM_FWD or norm_i not in _NORM_INV:

@@ -245,8 +245,6 @@ class DSP(nn.Module):
         per_bin = torch.is_tensor(H) and H.dim() >= 1 and H.shape[0] == self.nfft // 2 + 1 and H.dim() == (2 if getattr(self, "_diag", False) else 3)
         if not per_bin or (self._native_bin_order and self._native_now(param)):
             return H
-        if H.dtype != torch.complex64:
-            raise RuntimeError("row-major bin order is a float32 path")
         return ops.permute_bins(H, self.nfft)
 
     def _native_now(self, param) -> bool:

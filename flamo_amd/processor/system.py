@@ -704,7 +704,7 @@ class Shell(nn.Module):
         fin, fout, core = self.__input_layer, self.__output_layer, self.__core
         if not (type(fin) in (FFT, FFTAntiAlias) and type(fout) in (iFFT, iFFTAntiAlias)):
             return None
-        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and x.shape[0] > 0):
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype in (torch.float32, torch.float64) and x.dim() == 3 and x.shape[0] > 0):
             return None
         if fin.transform is not fin._own_transform or fout.transform is not fout._own_transform:
             return None
@@ -721,7 +721,7 @@ class Shell(nn.Module):
         else:
             return None
         n_in, n_out = run[0][1].input_channels, run[-1][1].output_channels
-        if x.shape[2] != n_in or not ops.spectral_supported(self.nfft, n_in, n_out):
+        if x.shape[2] != n_in or not ops.spectral_supported(self.nfft, n_in, n_out, x.dtype):
             return None
         if ops.bin_shard(self.nfft) != (0, self.nfft // 2 + 1):
             return None
@@ -734,8 +734,9 @@ class Shell(nn.Module):
             H = torch.diag_embed(H)
         if H.dim() == 2:
             H = H.unsqueeze(0).expand(M, *H.shape)
-        if H.dtype != torch.complex64:
-            H = H.to(torch.complex64)
+        cdt = torch.complex64 if x.dtype == torch.float32 else torch.complex128
+        if H.dtype != cdt:
+            H = H.to(cdt)
         return ops.spectral_apply(x, H, nfft, fin.norm, fout.norm, getattr(fin, "_alias_db", None),
                                   getattr(fout, "_alias_db", None))
 

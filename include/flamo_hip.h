@@ -182,6 +182,20 @@ int fl_spec_cols_inv_f32(const void* S2, void* y, int Bn, int t_len, int t_out, 
 /* per plane: dst[i] = src[k(i)] (inverse = 0, natural -> row-major bin order) or dst[k(i)] = src[i] (inverse = 1) */
 int fl_permute_bins_c64(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
                         void* stream);
+/* The same pipeline in float64 / complex128 (spectral.hip compiled a second time with real_t = double): same arguments, same
+ * layouts, W from fl_twiddle_fill_f64 + fl_spec_aux_fill_f64.  One workgroup per (row pair, batch item) at every plan length,
+ * equal channel counts only (fl_spec_supports_f64 also accounts for the doubled LDS of the row and column tiles). */
+int fl_spec_supports_f64(int nfft, int n_in, int n_out);
+int fl_spec_aux_fill_f64(void* W, int nfft, void* stream);
+int fl_spec_cols_fwd_f64(const void* x, int Bn, int t_len, int G, void* S, const void* W, int nfft, double env_log2,
+                         void* stream);
+int fl_spec_mid_f64(const void* S, void* S2, void* Xs, long xs_b, long xs_n, const void* H, long hs_m, long hs_n, int conj_h,
+                    const void* W, int nfft, int Bn, int NI, int NO, double spec_scale, int spec_interior2, int pre_half,
+                    void* stream);
+int fl_spec_cols_inv_f64(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                         double env_log2, void* stream);
+int fl_permute_bins_c128(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
+                         void* stream);
 
 /* ------------------------------------------------------------------ per-bin complex MIMO product
  * Replace torch.einsum("fmn,bfn...->bfm...") (dsp.py:922-924, 3406-3408 and every Filter

@@ -99,6 +99,73 @@ def test_spectral_apply_against_torch_fft(gpu, nfft, N, B):
     assert relerr(gH.cpu(), gHr) < TOL
 
 
+TOL64 = 1e-12     # float64 kernels against torch.fft in float64 on the CPU
+
+
+@pytest.mark.parametrize("nfft,N,B", [(96000, 8, 3), (96000, 2, 2), (96000, 16, 2), (192000, 4, 2), (192000, 8, 1), (384000, 8, 1), (384000, 2, 2),
+                                      (2048, 16, 3), (4096, 8, 2), (65536, 4, 2), (131072, 2, 1), (48000, 8, 2), (144000, 4, 1)])
+def test_spectral_apply_float64(gpu, nfft, N, B):
+    """The same three launches compiled for double (fl_spec_*_f64): forward and both gradients"""
+    from flamo_amd import ops
+    assert ops.spectral_supported(nfft, N, N, torch.float64)
+    torch.manual_seed(nfft + N)
+    M = nfft // 2 + 1
+    x = torch.randn(B, nfft - 5, N, device=gpu, dtype=torch.float64, requires_grad=True)
+    H = (torch.randn(M, N, N, device=gpu, dtype=torch.complex128) / N ** 0.5).requires_grad_(True)
+    ops.kernel_timer.reset(True)
+    y = ops.spectral_apply(x, ops.permute_bins(H, nfft), nfft, "ortho", "backward", 20.0, 10.0)
+    c = torch.randn(B, nfft, N, device=gpu, dtype=torch.float64)
+    gx, gH = torch.autograd.grad((y * c).sum(), [x, H])
+    torch.cuda.synchronize()
+    used = set(ops.kernel_timer.records)
+    ops.kernel_timer.enabled = False
+    assert {"spec_cols_fwd", "spec_cols_inv"} <= used and any(k.startswith("spec_mid[") for k in used)
+    assert y.dtype == torch.float64 and gx.shape == x.shape and gH.dtype == torch.complex128
+    xr = x.detach().cpu().requires_grad_(True)
+    Hr = H.detach().cpu().requires_grad_(True)
+    t = torch.arange(nfft, dtype=torch.float64)
+    xx = xr * (10.0 ** (20.0 / (20.0 * nfft) * t))[: nfft - 5, None]
+    Y = torch.einsum("fmn,bfn->bfm", Hr, torch.fft.rfft(xx, n=nfft, dim=1, norm="ortho"))
+    yr = torch.fft.irfft(Y, n=nfft, dim=1) * (10.0 ** (10.0 / (20.0 * nfft) * t))[:, None]
+    gxr, gHr = torch.autograd.grad((yr * c.cpu()).sum(), [xr, Hr])
+    assert relerr(y.detach().cpu(), yr.detach()) < TOL64
+    assert relerr(gx.cpu(), gxr) < TOL64
+    assert relerr(gH.cpu(), gHr) < TOL64
+
+
+def test_shell_float64_fused_equals_layered(gpu):
+    """A float64 Shell (FFT -> Series(Gain, parallelDelay, Matrix) -> iFFT) takes the fused route and agrees with the layered one"""
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    nfft, N, dt = 96000, 8, torch.float64
+    kw = dict(nfft=nfft, device=gpu, dtype=dt)
+    torch.manual_seed(5)
+    core = system.Series(OrderedDict(g=dsp.Gain(size=(N, N), requires_grad=True, **kw),
+                                     d=dsp.parallelDelay(size=(N,), max_len=1500, isint=True, requires_grad=False, **kw),
+                                     m=dsp.Matrix(size=(N, N), matrix_type="orthogonal", requires_grad=True, **kw)))
+    shell = system.Shell(core, dsp.FFT(nfft, dtype=dt), dsp.iFFT(nfft, dtype=dt))
+    x = torch.randn(2, nfft, N, device=gpu, dtype=dt)
+    params = [p for p in shell.parameters() if p.requires_grad]
+    c = torch.randn(2, nfft, N, device=gpu, dtype=dt)      # (a plain energy loss does not depend on the orthogonal matrix)
+    ops.kernel_timer.reset(True)
+    y = shell(x)
+    g1 = torch.autograd.grad((y * c).sum(), params)
+    torch.cuda.synchronize()
+    used = set(ops.kernel_timer.records)
+    ops.kernel_timer.enabled = False
+    assert any(k.startswith("spec_mid[") for k in used)
+    old = ops.spectral_supported
+    ops.spectral_supported = lambda *a, **k: False
+    try:
+        y2 = shell(x)
+        g2 = torch.autograd.grad((y2 * c).sum(), params)
+    finally:
+        ops.spectral_supported = old
+    assert relerr(y, y2) < TOL64
+    for a, b in zip(g1, g2):
+        assert relerr(a, b) < 1e-10
+
+
 @pytest.mark.parametrize("norm_f,norm_i,db_f,db_i,T", [("backward", "backward", 0.0, 30.0, 96000), ("ortho", "ortho", 30.0, 30.0, 96000),
                                                         ("forward", "forward", 30.0, 0.0, 96000), ("backward", "backward", 0.0, 0.0, 50001),
                                                         ("backward", "backward", 0.0, 0.0, 96017)])
@@ -207,14 +274,14 @@ def test_shell_fused_under_graph_capture(gpu):
 
 
 def test_unsupported_shapes_take_the_layered_path(gpu):
-    """odd channel counts, float64, 4-D signals and other transform lengths fall back to the layered operators, silently
-    and with the same results"""
+    """odd channel counts, other transform lengths and float64 shapes whose tiles exceed the LDS fall back to the layered
+    operators, silently and with the same results"""
     from flamo_amd import ops
     from flamo_amd.processor import dsp, system
-    for nfft, N, dt in ((96000, 3, torch.float32), (96000, 4, torch.float64), (4800, 4, torch.float32)):
+    for nfft, N, dt in ((96000, 3, torch.float32), (96000, 6, torch.float64), (4800, 4, torch.float32), (384000, 16, torch.float64)):
         kw = dict(nfft=nfft, device=gpu, dtype=dt)
         shell = system.Shell(system.Series(dsp.Matrix(size=(N, N), **kw)), dsp.FFT(nfft, dtype=dt), dsp.iFFT(nfft, dtype=dt))
-        x = torch.randn(2, nfft, N, device=gpu, dtype=dt)
+        x = torch.randn(1 if N == 16 else 2, nfft, N, device=gpu, dtype=dt)
         ops.kernel_timer.reset(True)
         with torch.no_grad():
             y = shell(x)
