@@ -82,7 +82,7 @@ _SIGNATURES = {
     "fl_sos_response_c64": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _l, _vp]),
     "fl_sos_response_f32eval_c64": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _l, _vp]),
     "fl_sos_response_c128": (_i, [_vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _l, _vp]),
-    "fl_sos_bwd_blocks": (_i, [_i]),
+    "fl_sos_bwd_blocks": (_i, [_i, _i, _i, _i]),
     "fl_debug_set_sos_chunk": (_i, [_i]),
     "fl_debug_set_rc_fast": (_i, [_i]),
     "fl_sos_response_bwd_c64": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _d, _vp, _i, _i, _i, _vp, _vp]),

@@ -193,54 +193,118 @@ __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double*
     }
     for (int i = threadIdx.x; i < Nmid * NIW; i += 256) lw[i] = Wr[i];
     __syncthreads();
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= m_local) return;
-    const int k = bin_of(f, bin0, nfft);
-    const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
-    const cx<double> z1(g * w1.x, g * w1.y);
-    const bool low = 4 * (long)k < nfft;
-    const float xr = low ? (float)(1.0 - z1.x) : (float)(1.0 + z1.x), xi = low ? (float)(-z1.y) : (float)z1.y;
-    cx<float> acc[NIW];
-#pragma unroll
-    for (int n = 0; n < NIW; ++n) acc[n] = cx<float>(0.f, 0.f);
-    for (int j = 0; j < Nmid; ++j) {
-        const float* cb = cf + ((size_t)j * 4 + (low ? 0 : 2)) * 3 * SP;
-        const float* ca = cb + 3 * SP;
-        f2 pbr = (f2)(1.f), pbi = (f2)(0.f), par = (f2)(1.f), pai = (f2)(0.f);
-        // (UNR section pairs per trip: their 6 UNR table reads are issued together -- one LDS latency per trip, not per pair)
-#pragma unroll UNR
-        for (int s = 0; s < SP; s += 2) {
-            const f2 b0 = *reinterpret_cast<const f2*>(cb + s), b1 = *reinterpret_cast<const f2*>(cb + SP + s),
-                     b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
-            const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
-                     a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
-            const f2 tbr = b1 + b2 * xr, tbi = b2 * xi, tar = a1 + a2 * xr, tai = a2 * xi;
-            const f2 Br = b0 + tbr * xr - tbi * xi, Bi = tbr * xi + tbi * xr;
-            const f2 Ar = a0 + tar * xr - tai * xi, Ai = tar * xi + tai * xr;
-            const f2 nbr = pbr * Br - pbi * Bi, nbi = pbr * Bi + pbi * Br;
-            const f2 nar = par * Ar - pai * Ai, nai = par * Ai + pai * Ar;
-            pbr = nbr; pbi = nbi; par = nar; pai = nai;
-        }
-        // the two chains (even / odd sections) of each product
-        const float Bx = pbr.x * pbr.y - pbi.x * pbi.y, By = pbr.x * pbi.y + pbi.x * pbr.y;
-        const float Ax = par.x * par.y - pai.x * pai.y, Ay = par.x * pai.y + pai.x * par.y;
-        cx<float> hf;
-        if (Ax != 0.f || Ay != 0.f) {
-            const float inv = 1.0f / (Ax * Ax + Ay * Ay);
-            hf = cx<float>((Bx * Ax + By * Ay) * inv, (By * Ax - Bx * Ay) * inv);
+    // A thread takes TWO ADJACENT BINS (k, k + 1) through the cascades: the twelve table reads of a section pair serve both
+    // (one bin per thread had the LDS return path as busy as the vector ALU: 48 bytes per lane and section pair against 16
+    // packed instructions).  Adjacent bins share the expansion point except for the one pair that straddles nfft/4, which
+    // walks the tables twice.  Natural order: elements 2p, 2p + 1; row-major order: (row 2r, column c) and the element one
+    // row below it (bin + 1); the Nyquist element is a pair of its own.
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    int e[2];
+    bool two;
+    if (bin0 >= 0) {
+        e[0] = 2 * p;
+        if (e[0] >= m_local) return;
+        two = e[0] + 1 < m_local;
+        e[1] = two ? e[0] + 1 : e[0];
+    } else {
+        const int L2 = -bin0, L = nfft >> 1, L1 = L / L2, main = ((L1 + 1) >> 1) * L2;
+        if (p > main) return;
+        if (p == main) {
+            e[0] = e[1] = L;
+            two = false;
         } else {
-            hf = cx<float>(eps_of<float>(), 0.f);
+            const int r = p / L2, c2 = p - r * L2;
+            e[0] = 2 * r * L2 + c2;
+            two = 2 * r + 1 < L1;
+            e[1] = two ? e[0] + L2 : e[0];
         }
-        G[(size_t)(m * Nmid + j) * g_pitch + f] = hf;
+    }
+    bool low[2];
+    float xr[2], xi[2], x2r[2], x2i[2];
 #pragma unroll
-        for (int n = 0; n < NIW; ++n) {
-            const float w = lw[j * NIW + n];
-            acc[n].x += w * hf.x;
-            acc[n].y += w * hf.y;
+    for (int q = 0; q < 2; ++q) {
+        const int k = bin_of(e[q], bin0, nfft);
+        const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
+        const cx<double> z1(g * w1.x, g * w1.y);
+        low[q] = 4 * (long)k < nfft;
+        const double xrd = low[q] ? 1.0 - z1.x : 1.0 + z1.x, xid = low[q] ? -z1.y : z1.y;
+        xr[q] = (float)xrd; xi[q] = (float)xid;
+        x2r[q] = (float)(xrd * xrd - xid * xid); x2i[q] = (float)(2.0 * xrd * xid);
+    }
+    const bool same = low[0] == low[1];
+    cx<float> acc[2][NIW];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) acc[q][n] = cx<float>(0.f, 0.f);
+    for (int j = 0; j < Nmid; ++j) {
+        f2 pbr[2], pbi[2], par[2], pai[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            pbr[q] = (f2)(1.f); pbi[q] = (f2)(0.f); par[q] = (f2)(1.f); pai[q] = (f2)(0.f);
+        }
+        // one section pair of bin q: c0 + c1 x + c2 x^2 (x^2 shared by all sections) times the running products
+        auto step = [&](int q, f2 b0, f2 b1, f2 b2, f2 a0, f2 a1, f2 a2) {
+            const f2 Br = b0 + b1 * xr[q] + b2 * x2r[q], Bi = b1 * xi[q] + b2 * x2i[q];
+            const f2 Ar = a0 + a1 * xr[q] + a2 * x2r[q], Ai = a1 * xi[q] + a2 * x2i[q];
+            const f2 nbr = pbr[q] * Br - pbi[q] * Bi, nbi = pbr[q] * Bi + pbi[q] * Br;
+            const f2 nar = par[q] * Ar - pai[q] * Ai, nai = par[q] * Ai + pai[q] * Ar;
+            pbr[q] = nbr; pbi[q] = nbi; par[q] = nar; pai[q] = nai;
+        };
+        if (same) {
+            const float* cb = cf + ((size_t)j * 4 + (low[0] ? 0 : 2)) * 3 * SP;
+            const float* ca = cb + 3 * SP;
+            // (UNR section pairs per trip: their 6 UNR table reads are issued together -- one LDS latency per trip, not per pair)
+#pragma unroll UNR
+            for (int s = 0; s < SP; s += 2) {
+                const f2 b0 = *reinterpret_cast<const f2*>(cb + s), b1 = *reinterpret_cast<const f2*>(cb + SP + s),
+                         b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
+                const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
+                         a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
+                step(0, b0, b1, b2, a0, a1, a2);
+                step(1, b0, b1, b2, a0, a1, a2);
+            }
+        } else {
+            for (int q = 0; q < 2; ++q) {
+                const float* cb = cf + ((size_t)j * 4 + (low[q] ? 0 : 2)) * 3 * SP;
+                const float* ca = cb + 3 * SP;
+                for (int s = 0; s < SP; s += 2) {
+                    const f2 b0 = *reinterpret_cast<const f2*>(cb + s), b1 = *reinterpret_cast<const f2*>(cb + SP + s),
+                             b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
+                    const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
+                             a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
+                    if (q == 0) step(0, b0, b1, b2, a0, a1, a2);
+                    else step(1, b0, b1, b2, a0, a1, a2);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            // the two chains (even / odd sections) of each product
+            const float Bx = pbr[q].x * pbr[q].y - pbi[q].x * pbi[q].y, By = pbr[q].x * pbi[q].y + pbi[q].x * pbr[q].y;
+            const float Ax = par[q].x * par[q].y - pai[q].x * pai[q].y, Ay = par[q].x * pai[q].y + pai[q].x * par[q].y;
+            cx<float> hf;
+            if (Ax != 0.f || Ay != 0.f) {
+                const float inv = 1.0f / (Ax * Ax + Ay * Ay);
+                hf = cx<float>((Bx * Ax + By * Ay) * inv, (By * Ax - Bx * Ay) * inv);
+            } else {
+                hf = cx<float>(eps_of<float>(), 0.f);
+            }
+            if (q == 0 || two) G[(size_t)(m * Nmid + j) * g_pitch + e[q]] = hf;
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) {
+                const float w = lw[j * NIW + n];
+                acc[q][n].x += w * hf.x;
+                acc[q][n].y += w * hf.y;
+            }
         }
     }
 #pragma unroll
-    for (int n = 0; n < NIW; ++n) H[(size_t)(m * NIW + n) * h_pitch + f] = acc[n];
+    for (int q = 0; q < 2; ++q)
+        if (q == 0 || two) {
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) H[(size_t)(m * NIW + n) * h_pitch + e[q]] = acc[q][n];
+        }
 }
 
 // The cascade applied to a signal with BX <= 2 columns in the same launch: thread (output channel m, bin) walks the Ni
@@ -276,7 +340,8 @@ __global__ void __launch_bounds__(256) sos_response_apply_fast_kernel(const doub
     const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
     const cx<double> z1(g * w1.x, g * w1.y);
     const bool low = 4 * (long)k < nfft;
-    const float xr = low ? (float)(1.0 - z1.x) : (float)(1.0 + z1.x), xi = low ? (float)(-z1.y) : (float)z1.y;
+    const double xrd = low ? 1.0 - z1.x : 1.0 + z1.x, xid = low ? -z1.y : z1.y;
+    const float xr = (float)xrd, xi = (float)xid, x2r = (float)(xrd * xrd - xid * xid), x2i = (float)(2.0 * xrd * xid);
     cx<float> acc[BX];
 #pragma unroll
     for (int n = 0; n < BX; ++n) acc[n] = cx<float>(0.f, 0.f);
@@ -292,9 +357,8 @@ __global__ void __launch_bounds__(256) sos_response_apply_fast_kernel(const doub
                      b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
             const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
                      a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
-            const f2 tbr = b1 + b2 * xr, tbi = b2 * xi, tar = a1 + a2 * xr, tai = a2 * xi;
-            const f2 Br = b0 + tbr * xr - tbi * xi, Bi = tbr * xi + tbi * xr;
-            const f2 Ar = a0 + tar * xr - tai * xi, Ai = tar * xi + tai * xr;
+            const f2 Br = b0 + b1 * xr + b2 * x2r, Bi = b1 * xi + b2 * x2i;      // c0 + c1 x + c2 x^2, x^2 shared by all sections
+            const f2 Ar = a0 + a1 * xr + a2 * x2r, Ai = a1 * xi + a2 * x2i;
             const f2 nbr = pbr * Br - pbi * Bi, nbi = pbr * Bi + pbi * Br;
             const f2 nar = par * Ar - pai * Ai, nai = par * Ai + pai * Ar;
             pbr = nbr; pbi = nbi; par = nar; pai = nai;
@@ -345,7 +409,8 @@ __global__ void __launch_bounds__(256) sos_response_fast_kernel(const double* __
         const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
         const cx<double> z1(g * w1.x, g * w1.y);
         const bool low = 4 * (long)k < nfft;
-        const float xr = low ? (float)(1.0 - z1.x) : (float)(1.0 + z1.x), xi = low ? (float)(-z1.y) : (float)z1.y;
+        const double xrd = low ? 1.0 - z1.x : 1.0 + z1.x, xid = low ? -z1.y : z1.y;
+    const float xr = (float)xrd, xi = (float)xid, x2r = (float)(xrd * xrd - xid * xid), x2i = (float)(2.0 * xrd * xid);
         const float* cb = cf + (low ? 0 : 6 * SP);
         const float* ca = cb + 3 * SP;
         f2 pbr = (f2)(1.f), pbi = (f2)(0.f), par = (f2)(1.f), pai = (f2)(0.f);
@@ -354,9 +419,8 @@ __global__ void __launch_bounds__(256) sos_response_fast_kernel(const double* __
                      b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
             const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
                      a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
-            const f2 tbr = b1 + b2 * xr, tbi = b2 * xi, tar = a1 + a2 * xr, tai = a2 * xi;
-            const f2 Br = b0 + tbr * xr - tbi * xi, Bi = tbr * xi + tbi * xr;
-            const f2 Ar = a0 + tar * xr - tai * xi, Ai = tar * xi + tai * xr;
+            const f2 Br = b0 + b1 * xr + b2 * x2r, Bi = b1 * xi + b2 * x2i;      // c0 + c1 x + c2 x^2, x^2 shared by all sections
+            const f2 Ar = a0 + a1 * xr + a2 * x2r, Ai = a1 * xi + a2 * x2i;
             const f2 nbr = pbr * Br - pbi * Bi, nbi = pbr * Bi + pbi * Br;
             const f2 nar = par * Ar - pai * Ai, nai = par * Ai + pai * Ar;
             pbr = nbr; pbi = nbi; par = nar; pai = nai;
@@ -521,16 +585,17 @@ struct SosRC {
 };
 
 template <int SCH, int NIW>
-__global__ void __launch_bounds__(256, 3) sos_response_bwd_mixed_kernel(
+__global__ void __launch_bounds__(256, 2) sos_response_bwd_mixed_kernel(
     const cx<float>* __restrict__ gH, long g_pitch, const cx<float>* __restrict__ H, long h_pitch,
     const double* __restrict__ b, const double* __restrict__ a, int S, int C, double g,
     const cx<double>* __restrict__ Wd, int nfft, int bin0, int m_local, double* __restrict__ part, SosRC rc) {
     static_assert(SCH % 2 == 0, "sections are processed in pairs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int SP = (S + 1) & ~1;                            // table pitch: even, so a pair is one 8-byte read
     double* lb = reinterpret_cast<double*>(smem);
     double* la = lb + 3 * S;
-    float* cf = reinterpret_cast<float*>(la + 3 * S + (S & 1));   // [basis][b|a][3][SP], 8-byte aligned
+    // float tables of THIS block's section chunk, [basis][b|a][3][SCH]: the pitch is a compile-time constant, so the
+    // twelve reads of a section pair are one base register (basis chosen per bin) plus immediate offsets
+    float* cf = reinterpret_cast<float*>(la + 3 * S + (S & 1));   // 8-byte aligned
     // block -> (bin block bx, channel pair c).  Constant-factor mode: the Nmid pairs (m, j) of one output channel m read
     // the same NIW gradient planes; their blocks get ids 8 apart (block q runs on XCD q % 8), i.e. consecutive slots
     // of ONE XCD, so those planes cross the fabric once and come from that L2 for the other Nmid - 1 blocks
@@ -550,19 +615,20 @@ __global__ void __launch_bounds__(256, 3) sos_response_bwd_mixed_kernel(
     stage_taps(b, a, S, C, c, lb, la);
     // B(w) = b0 + b1 w + b2 w^2 re-expanded about w = +1 (x = 1 - w) and about w = -1 (x = 1 + w):
     //   B = (b0+b1+b2) - (b1+2 b2) x + b2 x^2      |      B = (b0-b1+b2) + (b1-2 b2) x + b2 x^2
-    // sums formed in double, stored in float (see the kernel comment for why this form is float-safe)
-    for (int i = threadIdx.x; i < 2 * SP; i += blockDim.x) {
-        const int poly = i / SP, sidx = i - poly * SP;
+    // sums formed in double, stored in float (see the kernel comment for why this form is float-safe).  Sections past
+    // the cascade's end are padding, b = a = (1, 0, 0): their sums are computed and never written
+    const int s0 = blockIdx.z * SCH;
+    for (int i = threadIdx.x; i < 2 * SCH; i += blockDim.x) {
+        const int poly = i / SCH, q = i - poly * SCH, sidx = s0 + q;
         const double* t = poly ? la : lb;
         const bool real = sidx < S;
         const double t0 = real ? t[sidx] : 1.0, t1 = real ? t[S + sidx] : 0.0, t2 = real ? t[2 * S + sidx] : 0.0;
-        float* lo = cf + (0 * 2 + poly) * 3 * SP;
-        float* hi = cf + (1 * 2 + poly) * 3 * SP;
-        lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
-        hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+        float* lo = cf + (0 * 2 + poly) * 3 * SCH;
+        float* hi = cf + (1 * 2 + poly) * 3 * SCH;
+        lo[q] = (float)(t0 + t1 + t2); lo[SCH + q] = (float)(-(t1 + 2 * t2)); lo[2 * SCH + q] = (float)t2;
+        hi[q] = (float)(t0 - t1 + t2); hi[SCH + q] = (float)(t1 - 2 * t2);    hi[2 * SCH + q] = (float)t2;
     }
     __syncthreads();
-    const int s0 = blockIdx.z * SCH;
     // running sums of section PAIRS (x: section s0+2u, y: section s0+2u+1): every operation below is a
     // packed-float instruction (v_pk_*), the only kind that issues two lanes' worth per cycle slot --
     // unpacked FP32 and FP64 FMAs issue at the same rate, so "float instead of double" alone buys nothing
@@ -573,7 +639,8 @@ __global__ void __launch_bounds__(256, 3) sos_response_bwd_mixed_kernel(
         for (int u = 0; u < SCH / 2; ++u) acc[p][u] = (f2)(0.f);
     const float eps = eps_of<float>();
     constexpr int NW = NIW > 0 ? NIW : 1;
-    float wrow[NW], accw[NW];
+    float wrow[NW];
+    f2 accw[NW];
     const cx<float>* gbase = gH + (size_t)c * g_pitch;
     if (NIW > 0) {
         const int mrow = c / rc.Nmid, j = c - mrow * rc.Nmid;
@@ -581,97 +648,128 @@ __global__ void __launch_bounds__(256, 3) sos_response_bwd_mixed_kernel(
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
             wrow[n] = rc.Wr[j * NIW + n];
-            accw[n] = 0.f;
+            accw[n] = (f2)(0.f);
         }
     }
 
     const int fstride = nbx * 256;
-    for (int f = bx * 256 + threadIdx.x; f < m_local; f += fstride) {
-        const cx<float> h = H[(size_t)c * h_pitch + f];
-        cx<float> gv[NW];
-        const bool outer = NIW == 0 && rc.oG != nullptr;
-        if (!outer) {
-#pragma unroll
-            for (int n = 0; n < NW; ++n) gv[n] = gbase[(size_t)n * g_pitch + f];
-        }
-        cx<float> gin;
+    const bool outer = NIW == 0 && rc.oG != nullptr;
+    // The operands of bin f + fstride are requested before bin f is worked on (two wavefronts per SIMD: nothing else would
+    // cover the round trip -- the twiddle's address depends on the bin number, its load used to sit alone in front of the
+    // arithmetic).  Row-major bin order: the (row, column) pair of the element advances incrementally instead of by a
+    // division per bin.
+    struct Operands {
+        cx<float> h;
+        f2 gv[NW];
+        cx<double> w1;
+        int k;
+    };
+    int fn = bx * 256 + threadIdx.x;                 // element the next fetch is for
+    const int L2r = bin0 < 0 ? -bin0 : 1, Lh = nfft >> 1, L1r = Lh / L2r;
+    int k1 = fn / L2r, k2 = fn - k1 * L2r;
+    const int dk1 = fstride / L2r, dk2 = fstride - dk1 * L2r;
+    auto fetch = [&](Operands& o) {
+        const int f = fn < m_local ? fn : m_local - 1;        // (past the end: a valid address, the values are not used)
+        o.k = bin0 >= 0 ? bin0 + f : (fn >= Lh ? Lh : k1 + L1r * k2);
+        o.w1 = Wd[o.k < nfft ? o.k : o.k - nfft];
+        o.h = H[(size_t)c * h_pitch + f];
         if (NIW > 0) {
-            gin = cx<float>(0.f, 0.f);
 #pragma unroll
             for (int n = 0; n < NW; ++n) {
-                gin.x += wrow[n] * gv[n].x;
-                gin.y += wrow[n] * gv[n].y;
-                if (blockIdx.z == 0) accw[n] += h.x * gv[n].x + h.y * gv[n].y;
+                const cx<float> t = gbase[(size_t)n * g_pitch + f];
+                o.gv[n] = f2{t.x, t.y};
             }
+        } else if (!outer) {
+            const cx<float> t = gbase[f];
+            o.gv[0] = f2{t.x, t.y};
+        }
+        fn += fstride;
+        k1 += dk1;
+        k2 += dk2;
+        if (k2 >= L2r) {
+            k2 -= L2r;
+            ++k1;
+        }
+    };
+    Operands cur, nxt;
+    fetch(cur);
+    for (int f = bx * 256 + threadIdx.x; f < m_local; f += fstride, cur = nxt) {
+        fetch(nxt);
+        const cx<float> h = cur.h;
+        cx<float> gin;
+        if (NIW > 0) {
+            // dL/dG = sum_n W[j][n] dL/dH[m][n] and the dL/dW sums, one packed instruction per plane each
+            f2 gi = (f2)(0.f);
+            const f2 hv = {h.x, h.y};
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                gi += cur.gv[n] * wrow[n];
+                if (blockIdx.z == 0) accw[n] += hv * cur.gv[n];     // (Re, Im halves; added after the loop)
+            }
+            gin = cx<float>(gi.x, gi.y);
         } else if (outer) {
             const int mo = c / rc.oNi, no = c - mo * rc.oNi;
             gin = cx<float>(0.f, 0.f);
             for (int bb = 0; bb < rc.oB; ++bb)
                 fma_cxc(gin, rc.oG[(size_t)bb * rc.o_gb + (size_t)mo * rc.o_gn + f], rc.oX[(size_t)bb * rc.o_xb + (size_t)no * rc.o_xn + f]);
         } else {
-            gin = gv[0];
+            gin = cx<float>(cur.gv[0].x, cur.gv[0].y);
         }
         if (h.x == eps && h.y == 0.f) continue;   // guarded bin (prod A == 0): constant, zero gradient
-        const int k = bin_of(f, bin0, nfft);
-        const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
+        const int k = cur.k;
+        const cx<double> w1 = cur.w1;
         const cx<double> z1(g * w1.x, g * w1.y);
         const cx<float> d((float)(1.0 - z1.x), (float)(-z1.y));
-        const cx<float> d2 = d * d;
         const bool low = 4 * (long)k < nfft;      // w nearer to +1 than to -1
-        const float xr = low ? d.x : (float)(1.0 + z1.x), xi = low ? d.y : (float)z1.y;
-        const float* cb = cf + (low ? 0 : 6 * SP);
-        const float* ca = cb + 3 * SP;
+        const double xrd = low ? 1.0 - z1.x : 1.0 + z1.x, xid = low ? -z1.y : z1.y;
+        const float xr = (float)xrd, xi = (float)xid;
+        const float x2r = (float)(xrd * xrd - xid * xid), x2i = (float)(2.0 * xrd * xid);      // the sections share x and x^2: B = c0 + c1 x + c2 x^2
+        const f2* tb = reinterpret_cast<const f2*>(cf + (low ? 0 : 6 * SCH));      // [b|a][3][SCH / 2] section pairs
         const cx<float> gc(gin.x, -gin.y);
-        const cx<float> gh = gc * h;              // conj(gH) * H
+        // q_p = conj(gH) H d^p, shared by all sections: Re(q_p / B_s) = (q_p.x Br + q_p.y Bi) / |B_s|^2
+        const cx<float> q0 = gc * h, q1 = q0 * d, q2 = q1 * d;
         unsigned slow = 0;
 #pragma unroll
         for (int u = 0; u < SCH / 2; ++u) {
-            const int s = s0 + 2 * u;
-            if (s < S) {   // uniform; the odd member of the last pair may be padding (b = a = 1: weight 1/1, masked below)
-                const f2 b0 = *reinterpret_cast<const f2*>(cb + s), b1 = *reinterpret_cast<const f2*>(cb + SP + s),
-                         b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
-                const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
-                         a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
-                const f2 tbr = b1 + b2 * xr, tbi = b2 * xi, tar = a1 + a2 * xr, tai = a2 * xi;
-                const f2 Br = b0 + tbr * xr - tbi * xi, Bi = tbr * xi + tbi * xr;
-                const f2 Ar = a0 + tar * xr - tai * xi, Ai = tar * xi + tai * xr;
-                const f2 nb = Br * Br + Bi * Bi, na = Ar * Ar + Ai * Ai;
-                // one reciprocal per section for both quotients (v_rcp_f32 is a quarter-rate instruction: four of them were
-                // a quarter of this loop): 1/|B|^2 = |A|^2 / (|B|^2 |A|^2).  Both norms inside [1e-18, 1e18] keeps the
-                // product inside the float range; anything else is flagged for the double route as before.
-                const bool ok0 = (fminf(nb.x, na.x) > 1e-18f) && (fmaxf(nb.x, na.x) < 1e18f);
-                const bool pad1 = s + 1 >= S;
-                const bool ok1 = (fminf(nb.y, na.y) > 1e-18f) && (fmaxf(nb.y, na.y) < 1e18f) && !pad1;
-                slow |= (ok0 ? 0u : (1u << (2 * u))) | ((ok1 | pad1) ? 0u : (2u << (2 * u)));
-                const f2 nn = nb * na;
-                f2 inv;
-                inv.x = ok0 ? __builtin_amdgcn_rcpf(nn.x) : 0.f;
-                inv.y = ok1 ? __builtin_amdgcn_rcpf(nn.y) : 0.f;
-                const f2 ib = inv * na, ia = inv * nb;
-                // t = gh * conj(value) / |value|^2
-                const f2 tbR = (Br * gh.x + Bi * gh.y) * ib, tbI = (Br * gh.y - Bi * gh.x) * ib;
-                const f2 taR = (Ar * gh.x + Ai * gh.y) * ia, taI = (Ar * gh.y - Ai * gh.x) * ia;
-                acc[0][u] += tbR;
-                acc[1][u] += tbR * d.x - tbI * d.y;
-                acc[2][u] += tbR * d2.x - tbI * d2.y;
-                acc[3][u] -= taR;
-                acc[4][u] -= taR * d.x - taI * d.y;
-                acc[5][u] -= taR * d2.x - taI * d2.y;
-            }
+            const f2 b0 = tb[u], b1 = tb[SCH / 2 + u], b2 = tb[SCH + u];
+            const f2 a0 = tb[3 * SCH / 2 + u], a1 = tb[2 * SCH + u], a2 = tb[5 * SCH / 2 + u];
+            const f2 Br = b0 + b1 * xr + b2 * x2r, Bi = b1 * xi + b2 * x2i;
+            const f2 Ar = a0 + a1 * xr + a2 * x2r, Ai = a1 * xi + a2 * x2i;
+            const f2 nb = Br * Br + Bi * Bi, na = Ar * Ar + Ai * Ai;
+            // one reciprocal per section for both quotients (v_rcp_f32 is a quarter-rate instruction):
+            // 1/|B|^2 = |A|^2 / (|B|^2 |A|^2).  A product that is not a normal number (a norm vanished, or left the float
+            // range) is flagged for the double route
+            const f2 nn = nb * na;
+            const bool ok0 = __builtin_amdgcn_classf(nn.x, 0x100);             // +normal
+            const bool ok1 = __builtin_amdgcn_classf(nn.y, 0x100);
+            slow |= (ok0 ? 0u : (1u << (2 * u))) | (ok1 ? 0u : (2u << (2 * u)));
+            f2 inv;
+            inv.x = ok0 ? __builtin_amdgcn_rcpf(nn.x) : 0.f;
+            inv.y = ok1 ? __builtin_amdgcn_rcpf(nn.y) : 0.f;
+            const f2 ib = inv * na, ia = -(inv * nb);
+            const f2 Brs = Br * ib, Bis = Bi * ib, Ars = Ar * ia, Ais = Ai * ia;
+            // (one fused multiply-add per statement: "acc += x + y" would be a multiply, an fma and an add)
+            acc[0][u] = Brs * q0.x + acc[0][u]; acc[0][u] = Bis * q0.y + acc[0][u];
+            acc[1][u] = Brs * q1.x + acc[1][u]; acc[1][u] = Bis * q1.y + acc[1][u];
+            acc[2][u] = Brs * q2.x + acc[2][u]; acc[2][u] = Bis * q2.y + acc[2][u];
+            acc[3][u] = Ars * q0.x + acc[3][u]; acc[3][u] = Ais * q0.y + acc[3][u];
+            acc[4][u] = Ars * q1.x + acc[4][u]; acc[4][u] = Ais * q1.y + acc[4][u];
+            acc[5][u] = Ars * q2.x + acc[5][u]; acc[5][u] = Ais * q2.y + acc[5][u];
         }
         if (slow) {   // rare: redo the flagged sections in double
             SosEval e;
             e.z1 = z1;
             e.z2 = z1 * z1;
+            const cx<float> d2 = d * d;
 #pragma unroll
             for (int q = 0; q < SCH; ++q) {
-                if ((slow >> q) & 1u) {
+                if (((slow >> q) & 1u) && s0 + q < S) {
                     const int s = s0 + q;
                     const cx<double> Bs = e.poly(lb, S, s), As = e.poly(la, S, s);
-                    cx<float> tb, ta;
-                    sos_bwd_slow_section(e, lb, la, S, s, gc, Bs, As, tb, ta);
-                    const float v[6] = {tb.x, tb.x * d.x - tb.y * d.y, tb.x * d2.x - tb.y * d2.y,
-                                        -ta.x, -(ta.x * d.x - ta.y * d.y), -(ta.x * d2.x - ta.y * d2.y)};
+                    cx<float> tb2, ta2;
+                    sos_bwd_slow_section(e, lb, la, S, s, gc, Bs, As, tb2, ta2);
+                    const float v[6] = {tb2.x, tb2.x * d.x - tb2.y * d.y, tb2.x * d2.x - tb2.y * d2.y,
+                                        -ta2.x, -(ta2.x * d.x - ta2.y * d.y), -(ta2.x * d2.x - ta2.y * d2.y)};
 #pragma unroll
                     for (int p = 0; p < 6; ++p) {
                         if (q & 1) acc[p][q / 2].y += v[p];
@@ -719,7 +817,7 @@ __global__ void __launch_bounds__(256, 3) sos_response_bwd_mixed_kernel(
         __shared__ float redw[4][NW];
 #pragma unroll
         for (int n = 0; n < NW; ++n) {
-            float v = accw[n];
+            float v = accw[n].x + accw[n].y;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
             if (lane == 0) redw[wave][n] = v;
@@ -887,9 +985,30 @@ static int g_sos_chunk = 0;
 static int g_rc_fast = 6;   // cascade-times-matrix forward: float evaluation in the 1 -+ w basis, section pairs per loop trip (1 | 2 | 3 | 6; 0: the double kernel)
 static int g_sos_blocks = 0;
 
-static int sos_blocks(int m_local) {
-    int nb = cdiv_i(m_local, 256);
-    const int cap = g_sos_blocks > 0 ? g_sos_blocks : 32;
+// Bin blocks per channel pair of the backward kernels: the whole grid (blocks x C channel pairs x section chunks) is ONE
+// round of resident workgroups when the channel count allows it (two workgroups of 256 threads per CU: the kernels run at
+// two wavefronts per SIMD), so that every thread walks many bins and the prologue / reduction of a workgroup is paid once
+// per CU slot -- at config 2 (64 pairs, 48001 bins) 8 blocks per pair (512 workgroups, 24 bins per thread) run in 57 us,
+// the 32 blocks of before (2048 workgroups, 2.7 rounds) in 72.
+static int sos_chunk_of(int S, bool mixed) {
+    if (mixed) {
+        const int want = g_sos_chunk > 0 ? g_sos_chunk : 12;
+        return (S <= 4 || want <= 4) ? 4 : (S <= 6 || want <= 6) ? 6 : (S <= 8 || want <= 8) ? 8 : 12;
+    }
+    const int sch = (g_sos_chunk == 3 || g_sos_chunk == 4 || g_sos_chunk == 6 || g_sos_chunk == 12) ? g_sos_chunk : 6;
+    return S > 4 ? sch : 4;
+}
+
+static int sos_blocks(int m_local, int C, int S, bool mixed) {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus = v;
+    }
+    const int nz = cdiv_i(S, sos_chunk_of(S, mixed));
+    int nb = g_sos_blocks > 0 ? g_sos_blocks : (2 * cus) / (C * nz > 0 ? C * nz : 1);
+    const int cap = cdiv_i(m_local, 256);
     if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
     return nb;
@@ -944,12 +1063,12 @@ static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitc
         if (H) {
 #define FL_SOS_MIX(SC)                                                                                              \
     {                                                                                                               \
-        dim3 grid(sos_blocks(m_local), C, cdiv_i(S, SC));                                                           \
+        dim3 grid(sos_blocks(m_local, C, S, true), C, cdiv_i(S, SC));                                               \
         if (rc_ni > 0) {                                                                                           \
-            rc.nbx = sos_blocks(m_local);                                                                          \
+            rc.nbx = sos_blocks(m_local, C, S, true);                                                              \
             grid = dim3(cdiv_i((C / rc.Nmid) * rc.nbx, 8) * 8 * rc.Nmid, 1, cdiv_i(S, SC));                        \
         }                                                                                                          \
-        const size_t lds = (size_t)(6 * S + 2) * sizeof(double) + (size_t)12 * ((S + 1) & ~1) * sizeof(float);    \
+        const size_t lds = (size_t)(6 * S + 2) * sizeof(double) + (size_t)12 * SC * sizeof(float);    \
         FL_SOS_MIX_N(SC, 0) else FL_SOS_MIX_N(SC, 2) else FL_SOS_MIX_N(SC, 4) else FL_SOS_MIX_N(SC, 8)            \
         else FL_SOS_MIX_N(SC, 16) else {                                                                          \
             set_error("sos_response_bwd: no kernel for %d input channels of the constant factor", rc_ni);          \
@@ -961,10 +1080,10 @@ static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitc
         hipLaunchKernelGGL((sos_response_bwd_mixed_kernel<SC, NIW_>), grid, dim3(256), lds, (hipStream_t)stream,   \
                            (const cx<float>*)gH, g_pitch, (const cx<float>*)H, h_pitch, (const double*)b,           \
                            (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0, m_local, (double*)part, rc);
-            const int want = g_sos_chunk > 0 ? g_sos_chunk : 12;
-            if (S <= 4 || want <= 4) FL_SOS_MIX(4)
-            else if (S <= 6 || want <= 6) FL_SOS_MIX(6)
-            else if (S <= 8 || want <= 8) FL_SOS_MIX(8)
+            const int sc = sos_chunk_of(S, true);
+            if (sc == 4) FL_SOS_MIX(4)
+            else if (sc == 6) FL_SOS_MIX(6)
+            else if (sc == 8) FL_SOS_MIX(8)
             else FL_SOS_MIX(12)
 #undef FL_SOS_MIX
 #undef FL_SOS_MIX_N
@@ -973,17 +1092,17 @@ static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitc
         }
     }
     FL_REQUIRE(rc_ni == 0 && !rc.oG, "sos_response_bwd: the constant-factor and outer-product modes need float32 and the saved forward response");
-    const int sch = (g_sos_chunk == 3 || g_sos_chunk == 4 || g_sos_chunk == 6 || g_sos_chunk == 12) ? g_sos_chunk : 6;
+    const int sch = sos_chunk_of(S, false);
 #define FL_SOS_BWD(SC)                                                                                              \
     {                                                                                                               \
-        dim3 grid(sos_blocks(m_local), C, cdiv_i(S, SC));                                                           \
+        dim3 grid(sos_blocks(m_local, C, S, false), C, cdiv_i(S, SC));                                              \
         hipLaunchKernelGGL((sos_response_bwd_kernel<T, SC>), grid, dim3(256), (size_t)6 * S * sizeof(double),      \
                            (hipStream_t)stream, (const cx<T>*)gH, g_pitch, (const double*)b, (const double*)a, S, C, gamma, \
                            (const cx<double>*)Wd, nfft, bin0, m_local, (double*)part);                              \
     }
-    if (S > 4 && sch == 12) FL_SOS_BWD(12)
-    else if (S > 4 && sch == 6) FL_SOS_BWD(6)
-    else if (S > 4 && sch == 3) FL_SOS_BWD(3)
+    if (sch == 12) FL_SOS_BWD(12)
+    else if (sch == 6) FL_SOS_BWD(6)
+    else if (sch == 3) FL_SOS_BWD(3)
     else FL_SOS_BWD(4)
 #undef FL_SOS_BWD
     FL_CHECK_LAUNCH("sos_response_bwd");
@@ -1015,7 +1134,7 @@ int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamm
                         int m_local, void* H, long h_pitch, void* stream) {
     return sos_impl<double>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, h_pitch, stream);
 }
-int fl_sos_bwd_blocks(int m_local) { return sos_blocks(m_local); }
+int fl_sos_bwd_blocks(int m_local, int C, int S, int mixed) { return sos_blocks(m_local, C, S, mixed != 0); }
 int fl_debug_set_rc_fast(int on) {
     g_rc_fast = on;
     return FL_OK;
@@ -1074,22 +1193,25 @@ int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid
     dim3 grid(cdiv_i(m_local, 256), No);
     const size_t lds = (size_t)Nmid * 6 * S * sizeof(double) + (size_t)Nmid * Ni * sizeof(float);
     const size_t lds_fast = ((size_t)Nmid * 12 * ((S + 1) & ~1) + (size_t)Nmid * Ni) * sizeof(float);
+    // the float kernel's threads take bin PAIRS: half the elements (+ the Nyquist element as a pair of its own in row-major order)
+    const int npairs = bin0 >= 0 ? cdiv_i(m_local, 2) : (((nfft / 2 / (-bin0)) + 1) / 2) * (-bin0) + 1;
+    const dim3 grid_fast(cdiv_i(npairs, 256), No);
 #define FL_RC_FWD(NIW_)                                                                                                      \
     if (Ni == NIW_ && g_rc_fast && float_eval) {                                                                             \
         if (g_rc_fast == 2)                                                                                                  \
-            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 2>), grid, dim3(256), lds_fast, (hipStream_t)stream,       \
+            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 2>), grid_fast, dim3(256), lds_fast, (hipStream_t)stream,       \
                                (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
                                (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
         else if (g_rc_fast == 3)                                                                                             \
-            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 3>), grid, dim3(256), lds_fast, (hipStream_t)stream,       \
+            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 3>), grid_fast, dim3(256), lds_fast, (hipStream_t)stream,       \
                                (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
                                (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
         else if (g_rc_fast == 6)                                                                                             \
-            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 6>), grid, dim3(256), lds_fast, (hipStream_t)stream,       \
+            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 6>), grid_fast, dim3(256), lds_fast, (hipStream_t)stream,       \
                                (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
                                (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
         else                                                                                                                 \
-            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_>), grid, dim3(256), lds_fast, (hipStream_t)stream,          \
+            hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_>), grid_fast, dim3(256), lds_fast, (hipStream_t)stream,          \
                                (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
                                (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
         FL_CHECK_LAUNCH("sos_response_rc_fast");                                                                             \

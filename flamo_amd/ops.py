@@ -1514,7 +1514,7 @@ def _sos_backward_launch(gH, Hf, bc, ac, cfg):
     g = _h_planar(gH.resolve_conj(), True)
     g_pitch = _lead_pitch(g.movedim(0, -1))
     L = _lib.lib()
-    nblk = L.fl_sos_bwd_blocks(m_local)
+    nblk = L.fl_sos_bwd_blocks(m_local, C_, S, int(real == torch.float32 and Hf is not None))
     part = torch.empty((nblk, 2, 3, S, C_), dtype=torch.float64, device=bc.device)   # every entry is written
     fn = L.fl_sos_response_bwd_c64 if real == torch.float32 else L.fl_sos_response_bwd_c128
     Wd = twiddles(nfft, torch.float64, bc.device)
@@ -1664,7 +1664,7 @@ def _sos_backward_outer_launch(gY, Xp, Hf, bc, ac, cfg, No, Ni):
     _, _, _, _, gs_b, gs_n, _ = _bnk(gY)
     assert K == 1 and C_ == No * Ni and M == m_local
     L = _lib.lib()
-    part = torch.empty((L.fl_sos_bwd_blocks(m_local), 2, 3, S, C_), dtype=torch.float64, device=bc.device)
+    part = torch.empty((L.fl_sos_bwd_blocks(m_local, C_, S, 1), 2, 3, S, C_), dtype=torch.float64, device=bc.device)
     with kernel_timer.span("sos_response_bwd"):
         _lib.check(L.fl_sos_response_bwd_outer_c64(gY.data_ptr(), gs_b, gs_n, Xp.data_ptr(), xs_b, xs_n, B, No, Ni, Hf.data_ptr(),
                                                    _pitch(m_local), bc.data_ptr(), ac.data_ptr(), S, gamma,
@@ -1796,7 +1796,7 @@ def _cascade_rc_backward(gH, G, b, a, Wr, cfg):
     Ni = Wr.shape[1]
     g = _h_planar(gH.resolve_conj(), True)
     L = _lib.lib()
-    nblk = L.fl_sos_bwd_blocks(m_local)
+    nblk = L.fl_sos_bwd_blocks(m_local, C_, S, 1)
     part = torch.empty((nblk, 2, 3, S, C_), dtype=torch.float64, device=b.device)
     partW = torch.empty((nblk, No, Nmid, Ni), dtype=torch.float32, device=b.device)
     Wc = Wr.contiguous()

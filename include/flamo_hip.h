@@ -300,12 +300,13 @@ int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamm
 int fl_sos_response_f32eval_c64(const void* b, const void* a, int S, int C, double gamma, const void* Wd,
                                 int nfft, int bin0, int m_local, void* H, long h_pitch, void* stream);
 /* Backward: partial sums over bins of dL/db, dL/da.  part: double (nblk, 2, 3, S, C) where
- * nblk = fl_sos_bwd_blocks(m_local); every entry is written (no zero-fill needed), the caller sums
- * over nblk.  H / h_pitch: the forward output.  _c64 with H != NULL takes the mixed-precision
+ * nblk = fl_sos_bwd_blocks(m_local, C, S, mixed) (mixed = 1 for the _c64 route with H, the constant-factor and the
+ * outer-product forms; the grid is sized to one round of resident workgroups); every entry is written (no zero-fill
+ * needed), the caller sums over nblk.  H / h_pitch: the forward output.  _c64 with H != NULL takes the mixed-precision
  * route (section values in double, quotients and running sums in float in the basis
  * {1, d, d^2}, d = 1 - g w, converted back in double); H == NULL, and _c128 always, evaluates
  * everything in double. */
-int fl_sos_bwd_blocks(int m_local);
+int fl_sos_bwd_blocks(int m_local, int C, int S, int mixed);
 /* tuning hook: sections whose sums one thread keeps in registers (0 = default); + 100 * blocks per channel */
 int fl_debug_set_sos_chunk(int sections_per_thread);
 /* test hook: 0 = the float evaluations (fl_sos_response_f32eval_c64, fl_sos_response_rc_c64 with float_eval) fall back to double */
@@ -342,7 +343,7 @@ int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid
  * the right by a real constant matrix W (Nmid x Ni) -- Series(Matrix, <cascade-type filter>), system.py:299-300 over
  * dsp.py:466-468 and dsp.py:922-924:  H[m][n] = sum_j G[m][j] W[j][n].  gHfull: dL/dH, planes (m*Ni + n) of pitch g_pitch;
  * G: the saved forward response of the cascade (planes c, pitch h_pitch).  part as above (for G's coefficients);
- * partW: float (fl_sos_bwd_blocks(m_local), No*Nmid, Ni), per-block partials of Re(conj(G[m][j]) dL/dH[m][n]) -- summed
+ * partW: float (fl_sos_bwd_blocks(m_local, C, S, 1), No*Nmid, Ni), per-block partials of Re(conj(G[m][j]) dL/dH[m][n]) -- summed
  * over blocks and over m they are dL/dW[j][n].  Replaces two response-sized composition-backward passes.  Ni in {2,4,8,16}. */
 int fl_sos_response_bwd_rc_c64(const void* gHfull, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
                                int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,

@@ -16,7 +16,7 @@ P = ops._pitch(M)
 st = torch.cuda.current_stream().cuda_stream
 def run(cfg, mixed):
     L.fl_debug_set_sos_chunk(cfg)
-    nblk = L.fl_sos_bwd_blocks(M)
+    nblk = L.fl_sos_bwd_blocks(M, C, S, int(mixed))
     part = torch.empty((nblk, 2, 3, S, C), dtype=torch.float64, device=dev)
     def go():
         _lib.check(L.fl_sos_response_bwd_c64(gH.data_ptr(), P, Hp.data_ptr() if mixed else None, P, b.data_ptr(), a.data_ptr(), S, C, 0.9999,
