@@ -457,8 +457,12 @@ __device__ inline cx<double> cdiv_fast(cx<double> a, cx<double> b) {
 // in registers (GEQ: 12 sections = one chunk, nothing is recomputed).  Everything stays in double:
 // the three tap sums of a section are nearly collinear at low frequency and the parameter maps
 // combine them with cancellation, so single-precision sums cost 3 digits of the final gradient.
+// Hs (or null): the forward output.  With it the cascade product is not re-evaluated per bin (24 polynomial values and 24
+// complex products for a graphic equaliser, per section chunk); the section loop shares q_p = conj(gH) H z_p between the
+// sections and takes ONE reciprocal per section for both quotients, 1/|B|^2 = |A|^2 / (|B|^2 |A|^2), as the mixed kernel does.
 template <typename T, int SCH>
-__global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __restrict__ gH, long g_pitch, const double* __restrict__ b,
+__global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __restrict__ gH, long g_pitch, const cx<T>* __restrict__ Hs,
+                                                              long h_pitch, const double* __restrict__ b,
                                                               const double* __restrict__ a, int S, int C, double g,
                                                               const cx<double>* __restrict__ Wd, int nfft, int bin0,
                                                               int m_local, double* __restrict__ part) {
@@ -471,40 +475,65 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
     double acc[6 * SCH];   // [(i*3 + p)*SCH + q]: i = b|a, p = tap, q = section of the chunk
 #pragma unroll
     for (int v = 0; v < 6 * SCH; ++v) acc[v] = 0.0;
+    const T eps = eps_of<T>();
 
     for (int f = blockIdx.x * 256 + threadIdx.x; f < m_local; f += gridDim.x * 256) {
         const SosEval e = sos_point(Wd, nfft, bin_of(f, bin0, nfft), g);
-        cx<double> Bp(1, 0), Ap(1, 0);
-        for (int s = 0; s < S; ++s) {
-            Bp = Bp * e.poly(lb, S, s);
-            Ap = Ap * e.poly(la, S, s);
-        }
-        if (Ap.x == 0 && Ap.y == 0) continue;  // guarded bins are the constant eps: zero gradient
-        const cx<double> h = cdiv_fast(Bp, Ap);
         const cx<T> gin = gH[(size_t)c * g_pitch + f];
+        cx<double> h, Ap(1, 0);
+        if (Hs) {
+            const cx<T> hv = Hs[(size_t)c * h_pitch + f];
+            if (hv.x == eps && hv.y == (T)0) continue;   // guarded bin (prod A == 0): the constant eps, zero gradient
+            h = cx<double>((double)hv.x, (double)hv.y);
+        } else {
+            cx<double> Bp(1, 0);
+            for (int s = 0; s < S; ++s) {
+                Bp = Bp * e.poly(lb, S, s);
+                Ap = Ap * e.poly(la, S, s);
+            }
+            if (Ap.x == 0 && Ap.y == 0) continue;  // guarded bins are the constant eps: zero gradient
+            h = cdiv_fast(Bp, Ap);
+        }
         const cx<double> gc((double)gin.x, -(double)gin.y);
-        const cx<double> gh = gc * h;            // conj(gH) * H
+        const cx<double> q0 = gc * h, q1 = q0 * e.z1, q2 = q0 * e.z2;      // conj(gH) H z_p
 #pragma unroll
         for (int q = 0; q < SCH; ++q) {
             const int s = s0 + q;
             if (s < S) {
                 const cx<double> Bs = e.poly(lb, S, s), As = e.poly(la, S, s);
-                cx<double> tb;
-                if (Bs.x != 0 || Bs.y != 0) {
-                    tb = cdiv_fast(gh, Bs);
-                } else {  // numerator section vanishes at this bin: product of the others
-                    cx<double> o(1, 0);
-                    for (int t = 0; t < S; ++t)
-                        if (t != s) o = o * e.poly(lb, S, t);
-                    tb = gc * cdiv_fast(o, Ap);
+                const double nb = Bs.x * Bs.x + Bs.y * Bs.y, na = As.x * As.x + As.y * As.y;
+                const double nn = nb * na;
+                if (nn > 1e-30 && nn < 1e30) {      // (the reciprocal's seed is a float: the product has to sit in its range)
+                    const double inv = fast_rcp(nn);
+                    const double ib = inv * na, ia = -(inv * nb);
+                    const double Brs = Bs.x * ib, Bis = Bs.y * ib, Ars = As.x * ia, Ais = As.y * ia;
+                    // Re(q_p / B_s) = (q_p.x Br + q_p.y Bi) / |B_s|^2
+                    acc[0 * SCH + q] = fma(Bis, q0.y, fma(Brs, q0.x, acc[0 * SCH + q]));
+                    acc[1 * SCH + q] = fma(Bis, q1.y, fma(Brs, q1.x, acc[1 * SCH + q]));
+                    acc[2 * SCH + q] = fma(Bis, q2.y, fma(Brs, q2.x, acc[2 * SCH + q]));
+                    acc[3 * SCH + q] = fma(Ais, q0.y, fma(Ars, q0.x, acc[3 * SCH + q]));
+                    acc[4 * SCH + q] = fma(Ais, q1.y, fma(Ars, q1.x, acc[4 * SCH + q]));
+                    acc[5 * SCH + q] = fma(Ais, q2.y, fma(Ars, q2.x, acc[5 * SCH + q]));
+                } else {      // a section value vanishes (or leaves the range) at this bin
+                    cx<double> tb;
+                    if (nb > 1e-290) {
+                        tb = cdiv(q0, Bs);
+                    } else {  // numerator section vanishes at this bin: product of the others
+                        cx<double> o(1, 0), Aq(1, 0);
+                        for (int t = 0; t < S; ++t) {
+                            if (t != s) o = o * e.poly(lb, S, t);
+                            Aq = Aq * e.poly(la, S, t);
+                        }
+                        tb = gc * cdiv(o, Aq);
+                    }
+                    const cx<double> ta = cdiv(q0, As);
+                    acc[0 * SCH + q] += tb.x;
+                    acc[1 * SCH + q] += tb.x * e.z1.x - tb.y * e.z1.y;     // Re(tb * z_p)
+                    acc[2 * SCH + q] += tb.x * e.z2.x - tb.y * e.z2.y;
+                    acc[3 * SCH + q] -= ta.x;
+                    acc[4 * SCH + q] -= ta.x * e.z1.x - ta.y * e.z1.y;
+                    acc[5 * SCH + q] -= ta.x * e.z2.x - ta.y * e.z2.y;
                 }
-                const cx<double> ta = cdiv_fast(gh, As);
-                acc[0 * SCH + q] += tb.x;
-                acc[1 * SCH + q] += tb.x * e.z1.x - tb.y * e.z1.y;     // Re(tb * z_p)
-                acc[2 * SCH + q] += tb.x * e.z2.x - tb.y * e.z2.y;
-                acc[3 * SCH + q] -= ta.x;
-                acc[4 * SCH + q] -= ta.x * e.z1.x - ta.y * e.z1.y;
-                acc[5 * SCH + q] -= ta.x * e.z2.x - ta.y * e.z2.y;
             }
         }
     }
@@ -1097,7 +1126,7 @@ static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitc
     {                                                                                                               \
         dim3 grid(sos_blocks(m_local, C, S, false), C, cdiv_i(S, SC));                                              \
         hipLaunchKernelGGL((sos_response_bwd_kernel<T, SC>), grid, dim3(256), (size_t)6 * S * sizeof(double),      \
-                           (hipStream_t)stream, (const cx<T>*)gH, g_pitch, (const double*)b, (const double*)a, S, C, gamma, \
+                           (hipStream_t)stream, (const cx<T>*)gH, g_pitch, (const cx<T>*)H, h_pitch, (const double*)b, (const double*)a, S, C, gamma, \
                            (const cx<double>*)Wd, nfft, bin0, m_local, (double*)part);                              \
     }
     if (sch == 12) FL_SOS_BWD(12)

@@ -1536,8 +1536,8 @@ class _Sos(torch.autograd.Function):
         bc, ac = b.contiguous(), a.contiguous()
         # raw section coefficients: float evaluation only when no gradient will reuse the saved response (see FLOAT_CASCADE_EVAL)
         H, ctx.cfg = _sos_forward_launch(bc, ac, gamma, nfft, real, not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]))
-        # the float32 backward reuses the forward output instead of re-evaluating the cascade
-        keep = H if (real == torch.float32 and SOS_BWD_MIXED) else None
+        # the backward reuses the forward output instead of re-evaluating the cascade
+        keep = H if (real == torch.float64 or SOS_BWD_MIXED) else None
         ctx.save_for_backward(bc, ac, *([keep] if keep is not None else []))
         return H.movedim(-1, 0)
 
@@ -1607,7 +1607,7 @@ class _GeqCascade(torch.autograd.Function):
         _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), kind, nb, C_, consts.data_ptr(), b.data_ptr(), a.data_ptr(),
                                               _stream()), "geq_sections")
         H, ctx.cfg = _sos_forward_launch(b, a, gamma, nfft, real, True)     # graphic-equaliser sections
-        keep = H if (real == torch.float32 and SOS_BWD_MIXED) else None
+        keep = H if (real == torch.float64 or SOS_BWD_MIXED) else None
         ctx.save_for_backward(xc, consts, b, a, *([keep] if keep is not None else []))
         return H.movedim(-1, 0)
 
