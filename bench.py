@@ -652,10 +652,21 @@ def main():
                     out["secondary"]["config5_chain_32x32"]["cpu_baseline"] = cpu_baseline_config5()
                 except Exception as e:  # noqa: BLE001
                     out["secondary"]["cpu_baseline_error"] = f"{type(e).__name__}: {e}"[:300]
-        print(json.dumps(out))
+        line = json.dumps(out)
+    else:
+        line = None
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        # RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would come out at exit, BEHIND
+        # the result: flush it first so that the JSON line is the last line of rank 0's output
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:       # noqa: BLE001
+            pass
+        print(line, flush=True)
 
 
 def input_grad_leg(model, params, x, steps, products):

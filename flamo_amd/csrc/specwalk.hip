@@ -395,6 +395,20 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
 #undef FL_STAMP
 }
 
+// s_waitcnt vmcnt(n) for a wavefront-uniform n (the count of this wavefront's NEWER transfers that may stay in flight); the
+// counter's field is split in the encoding (bits 3:0 and 15:14).  Unknown counts wait for everything: always safe.
+__device__ __forceinline__ void wait_vm_le(int n) {
+    switch (n) {
+        case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+        case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
+        case 16: __builtin_amdgcn_s_waitcnt(0x4F70); break;
+        case 20: __builtin_amdgcn_s_waitcnt(0x4F74); break;
+        case 24: __builtin_amdgcn_s_waitcnt(0x4F78); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+}
+
 // ---------------------------------------------------------------- backward: dL/dH accumulated over a batch slice
 // dH[m][n][f] = sum_b gY[b,m,f] conj(X[b,n,f]),  gY = weighted spectrum of the rows in Sg (K1 of the output's gradient),
 // X = the spectrum the forward kernel kept pair-major.  Workgroup (row pair r, batch slice s) walks its items; thread
@@ -405,8 +419,11 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
 //           G1:   P2(b-1)  second stage                                                            XF[(b-1) & 1] -> Y
 // Staging is owner-wave (see spec_mid_walk's fetch): a group-0 wavefront transfers the gradient rows its own P1 items
 // read, every wavefront the 4 KB of spectrum its own P3 threads read (with one bin per thread the two groups read
-// different halves of a unit's block) -- each transfer issued right after the owner's reads of the previous item and
-// awaited just before its next ones, a full pipeline cycle later.
+// different halves of a unit's block) -- each transfer issued right after the owner's reads of the item that used the
+// region and awaited just before its next ones, a full pipeline cycle later (DEPTH 1, the form in use).  DEPTH 2 (tuning
+// mode 17) doubles the staging regions and moves the transfers' issue to the wavefronts that have no FFT stage in step 2;
+// it measured no faster (round 3: 69.5 against 68.7 us, and 66.8 us with the barrier between the two steps removed
+// altogether), i.e. an item's 4000-cycle cycle is neither a transfer round trip nor barrier skew -- see DESIGN 4.9.
 struct GradhArgs {
     const cf* Sg;         // (Bn, L1, L2, NO)
     const cf* Xp;         // pair-major spectrum of the forward kernel
@@ -416,9 +433,10 @@ struct GradhArgs {
     int n, L, L1, L2, Bn, NS;
     float scale_g;        // scale of the gradient's forward transform (the inverse transform's scale)
     int interior2_g;      // double its interior bins (irfft backward)
+    long long* dbg_times; // tuning: 8 int64 per workgroup (begin, end, cycles in step 1, in step 2, per wavefront 0 / 1 / 4 / 7 of step 2)
 };
 
-template <int A, int B, int NI, int NO, int NSC, int OCC>
+template <int A, int B, int NI, int NO, int NSC, int OCC, int DEPTH, bool DBG = false>
 __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LEN = A * B, LENP = walk_pitch(LEN);
@@ -431,11 +449,14 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     static_assert(LEN <= 256, "one bin pair per thread pair");
     static_assert(NO % NSC == 0 && NOL % 2 == 0 && NI % 2 == 0 && A % 2 == 0, "16-byte DMA granules");
     static_assert(NI1 <= 256 && NI2 <= 256, "an FFT stage of one unit fits one group");
+    static_assert(DEPTH == 1 || DEPTH == 2, "one or two items in flight");
+    constexpr int GA = A / 2, XA = NI / 2;         // transfers (instructions) of one item's rows / spectrum block per wavefront
+    constexpr int P2_OFF = 256 - ((NI2 + 63) / 64) * 64;       // second-stage items on the last wavefronts of group 1
     cf* XF = reinterpret_cast<cf*>(smem);          // [2][UB]
     cf* Yb = XF + 2 * UB;
-    cf* stage_g = Yb + UB;
-    cf* stage_x = stage_g + SBG;
-    cf* tw = stage_x + SBX;
+    cf* stage_g = Yb + UB;                         // [DEPTH][SBG]
+    cf* stage_x = stage_g + DEPTH * SBG;           // [DEPTH][SBX]
+    cf* tw = stage_x + DEPTH * SBX;
     cf* ws = tw + LEN;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -451,21 +472,26 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     const size_t bstride_g = (size_t)a.L1 * a.L2 * NO;
     const unsigned sg_lds = lds_addr_of(stage_g), sx_lds = lds_addr_of(stage_x);
 
-    auto fetch_g = [&](int b) {          // group 0: the A x 64 first-stage inputs of this wavefront's own items
-        const int wv = wave & 3, hi = lane >> 5;
-        int item0 = 64 * wv + 2 * (lane & 31);
+    // cw: the CONSUMER wavefront whose staging region is filled (the wavefront itself when it transfers for itself)
+    auto fetch_g = [&](int i, int cw) {  // the A x 64 first-stage inputs of group-0 wavefront cw's own items, item i of the slice
+        const int b = b_lo + i;
+        const unsigned sg_buf = sg_lds + (unsigned)((i % DEPTH) * SBG * 8);
+        const int hi = lane >> 5;
+        int item0 = 64 * cw + 2 * (lane & 31);
         if (item0 >= NI1 || (item0 >= B * NOL && selfm)) item0 = 0;
         const int m0 = item0 % NOL, tb = (item0 / NOL) % B, slot = item0 / (NOL * B);
         const cf* src = a.Sg + (size_t)b * bstride_g + (size_t)(slot ? rm : r) * (a.L2 * NO) + ((hi * B + tb) * NO + mo + m0);
 #pragma unroll
-        for (int q = 0; q < A / 2; ++q) dma16(src + q * (2 * B * NO), sg_lds + (unsigned)(((wv * A + 2 * q) * 64) * 8));
+        for (int q = 0; q < A / 2; ++q) dma16(src + q * (2 * B * NO), sg_buf + (unsigned)(((cw * A + 2 * q) * 64) * 8));
     };
-    auto fetch_x = [&](int b) {          // every wavefront: X[n][its own 64 pairs] of its side of the unit's block
-        int pp = 64 * (wave & 3) + 2 * (lane & 31);
+    auto fetch_x = [&](int i, int cw) {  // X[n][the 64 pairs of wavefront cw] of its side of the unit's block
+        const int b = b_lo + i;
+        const unsigned sx_buf = sx_lds + (unsigned)((i % DEPTH) * SBX * 8);
+        int pp = 64 * (cw & 3) + 2 * (lane & 31);
         if (pp > LEN - 2) pp = LEN - 2;
-        const cf* src = a.Xp + (((size_t)r * a.Bn + b) * 2 + grp) * (NI * LEN) + (lane >> 5) * LEN + pp;
+        const cf* src = a.Xp + (((size_t)r * a.Bn + b) * 2 + (cw >> 2)) * (NI * LEN) + (lane >> 5) * LEN + pp;
 #pragma unroll
-        for (int q = 0; q < NI / 2; ++q) dma16(src + q * (2 * LEN), sx_lds + (unsigned)(((wave * NI + 2 * q) * 64) * 8));
+        for (int q = 0; q < NI / 2; ++q) dma16(src + q * (2 * LEN), sx_buf + (unsigned)(((cw * NI + 2 * q) * 64) * 8));
     };
 
     // the product's thread
@@ -479,8 +505,22 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     for (int m = 0; m < NOL; ++m)
 #pragma unroll
         for (int nn = 0; nn < NI; ++nn) acc[m][nn] = f2{0.f, 0.f};
-    const bool has_g = grp == 0 && (wave & 3) < NW1;             // this wavefront has first-stage items (and transfers their rows)
-    if (has_g && n_it > 0) fetch_g(b_lo);
+    const bool has_g = grp == 0 && (wave & 3) < NW1;             // this wavefront has first-stage items
+    // DEPTH 2: the transfers are issued by the wavefronts that have NO stage of their own in step 2 (2 .. 5: the first stage
+    // sits on wavefronts 0 .. NW1-1, the second on the last ones), for the others as well as for themselves -- issuing a
+    // 1-KB piece costs a wavefront ~100 cycles, and with every wavefront fetching for itself that sat on the two longest
+    // paths: 4 pieces per wavefront in step 1, 8 more in front of the first stage's arithmetic.  Fetcher f = wave - 2 fills
+    // the rows of first-stage wavefront f (if there is one) and the spectrum blocks of wavefronts XLO[f] .. XLO[f+1]-1.
+    const bool fetcher = DEPTH == 2 && wave >= 2 && wave <= 5;
+    const int fi = wave - 2;
+    const int xlo = NW1 >= 2 ? (fi == 0 ? 0 : fi == 1 ? 1 : fi == 2 ? 2 : 5) : (fi == 0 ? 0 : fi == 1 ? 1 : fi == 2 ? 3 : 6);
+    const int xhi = NW1 >= 2 ? (fi == 0 ? 1 : fi == 1 ? 2 : fi == 2 ? 5 : 8) : (fi == 0 ? 1 : fi == 1 ? 3 : fi == 2 ? 6 : 8);
+    int x_issued = 0;                                            // spectrum pieces this fetcher issued in the last step 2
+    if (DEPTH == 2) {
+        if (fetcher && fi < NW1 && n_it > 0) fetch_g(0, fi);
+    } else if (has_g && n_it > 0) {
+        fetch_g(0, wave & 3);
+    }
     for (int j = tid; j < LEN; j += 512) {
         tw[j] = a.W[a.n + a.L1 + j];
         ws[j] = a.W[a.n + a.L1 + a.L2 + j];
@@ -495,29 +535,37 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     const f2 scv = grp ? f2{sc, -sc} : f2{sc, sc};
     const int yk_o = pc, ym_o = slotB * NOL * LENP + colB;
 
+    long long g_ph[2] = {0, 0}, g_last = 0, g_begin = 0;
+    if (DBG) g_begin = g_last = clock64();
+#define FL_GSTAMP(i)                        \
+    if (DBG) {                              \
+        const long long t_now = clock64();  \
+        g_ph[i] += t_now - g_last;          \
+        g_last = t_now;                     \
+    }
 #pragma unroll 1
     for (int t = 0; t < n_it + 2; ++t) {
-        const bool g_pending = t >= 1 && t < n_it;              // group 0 issued the rows of item t in the previous step 2
-        const bool x_now = t >= 1 && t <= n_it;                 // the spectrum block of item t-1 is requested in this step 1
+        // DEPTH 1 (owner-wave transfers): step 1 of cycle t requests the spectrum block of item t-1, P1(t) the rows of item
+        // t+1; a wait names how many NEWER transfers of the wavefront may stay in flight.
+        const bool x_now = DEPTH == 1 && t >= 1 && t <= n_it;
         // ---- step 1
         if (t >= 2) {
 #pragma unroll
             for (int m = 0; m < NOL; ++m)
 #pragma unroll
                 for (int nn = 0; nn < NI; ++nn) asm volatile("" : "+v"(acc[m][nn]));
-            // this wavefront's spectrum block of item t-2 has landed (behind it in the queue: its own newer row pieces)
-            if (has_g && g_pending) __builtin_amdgcn_s_waitcnt(0x0F70 | (A / 2));
-            else wait_vm0();
+            // DEPTH 1: this wavefront's spectrum block of item t-2 has landed (behind it: its own newer row pieces)
+            if (DEPTH == 1) wait_vm_le((has_g && t < n_it) ? GA : 0);
         }
         f2 x[NI];
         {
-            const cf* xs = stage_x + (wave * NI) * 64 + lane;
+            const cf* xs = stage_x + (t % DEPTH) * SBX + (wave * NI) * 64 + lane;      // item t-2's region
 #pragma unroll
             for (int nn = 0; nn < NI; ++nn) x[nn] = v2(xs[nn * 64]);
         }
         if (x_now) {
             wait_lgkm0();                                        // the reads above have returned: the region may be refilled
-            fetch_x(b_lo + t - 1);
+            fetch_x(t - 1, wave);
         }
         if (t >= 2 && valid) {
 #pragma unroll
@@ -530,25 +578,35 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
                 for (int nn = 0; nn < NI; ++nn) acc[m][nn] = pfma(f2{x[nn].y, x[nn].y}, mg, pfma(f2{x[nn].x, x[nn].x}, g, acc[m][nn]));
             }
         }
+        // DEPTH 2: the rows of item t (requested in the last step 2, ahead of that step's spectrum pieces) have landed
+        if (fetcher) wait_vm_le(x_issued);
         lds_barrier();
+        FL_GSTAMP(0)
         // ---- step 2
-        if (grp == 0) {
+        if (fetcher) {
+            wait_vm0();                  // the spectrum blocks of item t-1 have landed: a whole cycle in flight
+            if (fi < NW1 && t + 1 < n_it) fetch_g(t + 1, fi);
+            x_issued = 0;
+            if (t < n_it) {
+                for (int cw = xlo; cw < xhi; ++cw) fetch_x(t, cw);
+                x_issued = XA * (xhi - xlo);
+            }
+        } else if (grp == 0) {
             if (t < n_it && has_g) {     // P1(t): first stage of the gradient rows, staging -> XF[t & 1].  item = (m fastest, tb, slot)
                 const int item = opaque(tid) & 255;
                 const int m = item % NOL, tb = (item / NOL) % B, slot = item / (NOL * B);
                 const bool have = item < NI1 && !(slot && selfm);
                 cf v[A], tt[A];
-                // this wavefront's rows of item t have landed (behind them in the queue: the spectrum pieces just requested)
-                if (x_now) __builtin_amdgcn_s_waitcnt(0x0F70 | (NI / 2));
-                else wait_vm0();
-                const cf* sp = stage_g + (item >> 6) * (A * 64) + (item & 63);
+                // DEPTH 1: this wavefront's rows of item t have landed (behind them: the spectrum pieces just requested)
+                if (DEPTH == 1) wait_vm_le(x_now ? XA : 0);
+                const cf* sp = stage_g + (t % DEPTH) * SBG + (item >> 6) * (A * 64) + (item & 63);
 #pragma unroll
                 for (int ta = 0; ta < A; ++ta) v[ta] = sp[ta * 64];
 #pragma unroll
                 for (int ka = 1; ka < A; ++ka) tt[ka] = tw[ka * (have ? tb : 0)];
-                if (t + 1 < n_it) {
+                if (DEPTH == 1 && t + 1 < n_it) {
                     wait_lgkm0();
-                    fetch_g(b_lo + t + 1);
+                    fetch_g(t + 1, wave & 3);
                 }
                 if (have) {
                     RegFFT<float, A, false>::run(v);
@@ -559,9 +617,10 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
                 }
             }
         } else if (t >= 1 && t <= n_it) {     // P2(t-1): second stage XF[(t-1) & 1] -> Y.  item = (m fastest, ka, slot)
-            const int item = opaque(tid) & 255;
+            // (DEPTH 2: the items sit on the group's last wavefronts, 4 and 5 issue transfers)
+            const int item = (opaque(tid) & 255) - (DEPTH == 2 ? P2_OFF : 0);
             const int m = item % NOL, ka = (item / NOL) % A, slot = item / (NOL * A);
-            if (item < NI2 && !(slot && selfm)) {
+            if (item >= 0 && item < NI2 && !(slot && selfm)) {
                 cf v[B];
                 const cf* xr = XF + ((t - 1) & 1) * UB + (slot * NOL + m) * LENP + ka * B;
 #pragma unroll
@@ -572,7 +631,20 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
                 for (int kb = 0; kb < B; ++kb) yr[A * kb] = v[kb];
             }
         }
+        long long t_work = 0;
+        if (DBG) t_work = clock64() - g_last;        // this wavefront's own work in step 2, before it waits at the barrier
         lds_barrier();
+        FL_GSTAMP(1)
+        if (DBG && a.dbg_times && lane == 0 && (wave == 0 || wave == 1 || wave == 4 || wave == 7))
+            atomicAdd((unsigned long long*)(a.dbg_times + (size_t)blockIdx.x * 8 + (wave == 0 ? 4 : wave == 1 ? 5 : wave == 4 ? 6 : 7)), (unsigned long long)t_work);
+    }
+#undef FL_GSTAMP
+    if (DBG && a.dbg_times && tid == 0) {
+        long long* o = a.dbg_times + (size_t)blockIdx.x * 8;
+        o[0] = g_begin;
+        o[1] = clock64();
+        o[2] = g_ph[0];
+        o[3] = g_ph[1];
     }
     // ---- the slice's sums -> partial plane set sl
     {
@@ -697,27 +769,32 @@ int fl_spec_gradh_walk_f32(const void* Sg, const void* Xp, void* dH_parts, long 
     if (rc) return rc;
     a.Sg = (const cf*)Sg; a.Xp = (const cf*)Xp; a.dH = (cf*)dH_parts; a.ds_s = ds_s; a.ds_m = ds_m; a.ds_n = ds_n;
     a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn; a.NS = n_slices;
-    a.scale_g = (float)scale_g; a.interior2_g = interior2_g;
+    a.scale_g = (float)scale_g; a.interior2_g = interior2_g; a.dbg_times = g_walk_times;
     FL_REQUIRE((size_t)NO * (size_t)ds_m * 8ull < (1ull << 32), "spec_gradh_walk: a partial plane set exceeds 32-bit offsets");
     const int P = a.L1 / 2 + 1;
     hipStream_t st = (hipStream_t)stream;
     if (a.L2 == 240 && NI == 8 && NO == 8) {
-#define FL_GRADH(NSC_, OCC_)                                                                                                     \
+#define FL_GRADH(NSC_, OCC_, DEPTH_)                                                                                             \
     {                                                                                                                            \
         constexpr int A = 16, B = 15, LEN = A * B, LENP = walk_pitch(LEN), NOL = 8 / NSC_;                                       \
-        constexpr size_t lds = ((size_t)3 * 2 * NOL * LENP + ((2 * B * NOL + 63) / 64) * A * 64 + 8 * 8 * 64 + 2 * LEN) * sizeof(cf); \
+        constexpr size_t lds = ((size_t)3 * 2 * NOL * LENP + DEPTH_ * (((2 * B * NOL + 63) / 64) * A * 64 + 8 * 8 * 64) + 2 * LEN) * sizeof(cf); \
         static_assert(lds <= 160 * 1024, "LDS budget");                                                                          \
         const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * n_slices * NSC_);                                                    \
-        auto kern = spec_gradh_walk<16, 15, 8, 8, NSC_, OCC_>;                                                                   \
+        auto kern = spec_gradh_walk<16, 15, 8, 8, NSC_, OCC_, DEPTH_>;                                                           \
+        auto kern_dbg = spec_gradh_walk<16, 15, 8, 8, NSC_, OCC_, DEPTH_, true>;                                                 \
         static bool attr_set = false;                                                                                            \
         if (!attr_set) {                                                                                                         \
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_dbg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             attr_set = true;                                                                                                     \
         }                                                                                                                        \
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, a);                                                             \
+        if (a.dbg_times) hipLaunchKernelGGL(kern_dbg, dim3(nblk), dim3(512), lds, st, a);                                        \
+        else hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, a);                                                        \
     }
         // output channels of a row pair over 2 workgroups (one per CU) or, tuning, over 4 (two per CU)
-        if (g_walk_nsc == 4) FL_GRADH(4, 4) else FL_GRADH(2, 2)
+        // (mode 17, tuning: two staging regions per kind, transfers issued by the wavefronts without a stage of their own --
+        // measured 69.5 us against 68.7 us for the owner-wave form at config 2: an item's cycle is not a transfer round trip)
+        if (g_walk_nsc == 4) FL_GRADH(4, 4, 1) else if (g_walk == 17) FL_GRADH(2, 2, 2) else FL_GRADH(2, 2, 1)
 #undef FL_GRADH
     } else {
         set_error("spec_gradh_walk: no kernel for nfft=%d, %d -> %d channels", nfft, NI, NO);

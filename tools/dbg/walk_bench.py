@@ -122,7 +122,8 @@ for r in (1, 7, 57, 99):
     gotm = Xpv[r, :, 1].reshape(B, N, L2)
     print(f"pair-major spectrum row pair {r}: k {rel(torch.view_as_real(got), torch.view_as_real(want)):.2e}  L-k {rel(torch.view_as_real(gotm), torch.view_as_real(wantm)):.2e}")
 for ns in [int(v) for v in args.slices.split(",")]:
-    L.fl_debug_set_walk(14 if ns == 4 else 1, 0, 0 if ns == 4 else ns, None)      # "4": four output-channel groups per row pair
+    # "4": four output-channel groups per row pair; "17": doubled staging regions, transfers issued by the wavefronts without an FFT stage (tuning variant)
+    L.fl_debug_set_walk(14 if ns == 4 else 17 if ns == 17 else 1, 0, 0 if ns in (4, 17) else ns, None)
     nsl = L.fl_spec_gradh_slices(nfft, B)
     parts = torch.full((nsl, N, N, P), float("nan"), dtype=torch.complex64, device=dev)
     out = torch.empty((N, N, P), dtype=torch.complex64, device=dev)
@@ -149,3 +150,19 @@ t = timeit(lambda: L.fl_spec_mid_f32(Sg.data_ptr(), None, gYs.data_ptr(), N * P,
                                      ops._stream()))
 t2 = timeit(lambda: ops._gradh_launch(gY_ref.movedim(-1, 1), Xs_ref.movedim(-1, 1), False))
 print(f"spec_mid (spectrum only): median {t[0]:.1f} us; mimo_gradh: median {t2[0]:.1f} us")
+
+# phase picture of the backward kernel
+nblk = 8 * ((L1 // 2 + 1 + 7) // 8) * 2 * 4
+bufg = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
+L.fl_debug_set_walk(1, 0, 0, bufg.data_ptr())
+nsl = L.fl_spec_gradh_slices(nfft, B)
+parts = torch.empty((nsl, N, N, P), dtype=torch.complex64, device=dev)
+_lib.check(L.fl_spec_gradh_walk_f32(Sg.data_ptr(), Xp.data_ptr(), parts.data_ptr(), N * N * P, N * P, P, nsl, W.data_ptr(), nfft, B, N, N, 1.0 / nfft, 1, ops._stream()), "gradh_walk")
+torch.cuda.synchronize()
+L.fl_debug_set_walk(1, 0, 0, None)
+tg = bufg.view(-1, 8).cpu().double()
+tg = tg[tg[:, 1] > 0]
+if len(tg):
+    d = tg[:, 1] - tg[:, 0]
+    print(f"gradh_walk: {len(tg)} workgroups, cycles mean {d.mean():.0f} min {d.min():.0f} max {d.max():.0f}; step 1 {tg[:, 2].mean():.0f}, step 2 {tg[:, 3].mean():.0f}; "
+          f"own work in step 2: wavefront 0 {tg[:, 4].mean():.0f}, 1 {tg[:, 5].mean():.0f}, 4 {tg[:, 6].mean():.0f}, 7 {tg[:, 7].mean():.0f}")
