@@ -396,6 +396,56 @@ def test_matrix_cascade_operator_equals_composition(gpu, kind):
         assert relerr(a, b) < 2e-5, kind
 
 
+@pytest.mark.parametrize("nfft,N", [(144000, 4), (48000, 8), (2048, 2), (192000, 8)])
+def test_matrix_cascade_operator_at_other_lengths(gpu, nfft, N):
+    """the bin-PAIR walk of the cascade-times-matrix forward (two adjacent bins per thread: elements one row apart in row-major
+    order) at plan lengths with an odd row count (144000: 225 rows), few bins (2048) and the longer BASELINE length, and the
+    one-round grid of its backward: fused pair operator against the generic composition, forward and both gradients"""
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    torch.manual_seed(nfft % 1000 + N)
+    kw = dict(nfft=nfft, alias_decay_db=0.0, device=gpu, dtype=torch.float32, requires_grad=True)
+    mat = dsp.Matrix(size=(N, N), matrix_type="random", **kw)
+    flt = dsp.GEQ(size=(N, N), **kw)
+    shell = system.Shell(system.Series(OrderedDict(mix=mat, flt=flt)), dsp.FFT(nfft), dsp.iFFT(nfft))
+    params = [mat.param, flt.param]
+    x = torch.randn(2, nfft, N, device=gpu)
+
+    def run():
+        ops.kernel_timer.reset(True)
+        y = shell(x)
+        g = torch.autograd.grad(ops.mean_square(y), params)
+        torch.cuda.synchronize()
+        used = set(ops.kernel_timer.records)
+        ops.kernel_timer.enabled = False
+        return y.detach(), g, used
+
+    y1, g1, used1 = run()
+    assert "sos_response_bwd_rc" in used1 and any(k.startswith("spec_mid") for k in used1), used1
+    system.FUSE_MATRIX_CASCADE = False
+    try:
+        y2, g2, _ = run()
+    finally:
+        system.FUSE_MATRIX_CASCADE = True
+    assert relerr(y1, y2) < TOL
+    for a, b in zip(g1, g2):
+        assert relerr(a, b) < 2e-5
+    # natural bin order, an odd number of bins and a bin shard that starts at an odd bin: the same kernels through ops
+    M = nfft // 2 + 1
+    b64, a64 = flt._sos_coeffs(flt.map(flt.param.detach().double()))
+    Wr = mat.map(mat.param.detach()).float()
+    Hn = ops.sos_response_rc(b64, a64, Wr, 1.0, nfft)
+    with ops.row_major_bins(nfft):
+        Hr = ops.sos_response_rc(b64, a64, Wr, 1.0, nfft)
+    assert torch.equal(ops.permute_bins(Hr, nfft, inverse=True), Hn)       # the same arithmetic per bin, whatever the order
+    ops.set_bin_shard(3, min(1001, M - 3))
+    try:
+        Hs = ops.sos_response_rc(b64, a64, Wr, 1.0, nfft)
+    finally:
+        ops.set_bin_shard(0, None)
+    assert Hs.shape[0] == min(1001, M - 3) and torch.equal(Hs, Hn[3:3 + Hs.shape[0]])
+
+
 @pytest.mark.parametrize("variant", [2, 4, 5])
 def test_mid_kernel_variants_agree(gpu, variant):
     """the row kernel's experimental forms (tuning hook: 2 / 4 batch items per workgroup with the three-sweep product, one
