@@ -167,29 +167,62 @@ __global__ void __launch_bounds__(256) sos_response_rc_kernel(const double* __re
 // frequency (shelving sections at 44 Hz) happens in exact arithmetic, what is left is a well-conditioned Horner step.
 // (The backward kernel's float stage uses the same basis.)  The 2 x S/2 running products are two independent chains per
 // packed register.  Measured against the double kernel: response 3e-7 relative, 49 -> ~30 us at config 2.
+// Graphic-equaliser mode of the kernel below (gain != null): the sections are DESIGNED in the prologue from the command
+// gains (eq.py:57-111, the arithmetic of geq_sections_kernel) instead of being read -- every workgroup needs the 12 sections
+// of its N_mid cascades, one per thread -- and the first bin block of each output channel writes them out for the backward
+// pass: the design launch in front of this one (5 us and a dispatch gap in the config-2 step) is gone.
+struct GeqDesign {
+    const void* gain;      // (nb, C) command gains / raw parameters, or null: sections are read from b, a
+    int in_kind;
+    const double* k;       // band constants
+    double* b_out;         // (3, nb, C) each
+    double* a_out;
+};
+__device__ inline void geq_section_of(const void* __restrict__ gain, int in_kind, int idx, int band, int nb,
+                                      const double* __restrict__ k, double* bb, double* aa);
+
 template <int NIW, int UNR = 1>
 __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double* __restrict__ b, const double* __restrict__ a, int S,
                                                                   int C, int Nmid, const float* __restrict__ Wr, double g,
                                                                   const cx<double>* __restrict__ Wd, int nfft, int bin0,
                                                                   int m_local, cx<float>* __restrict__ G, long g_pitch,
-                                                                  cx<float>* __restrict__ H, long h_pitch) {
+                                                                  cx<float>* __restrict__ H, long h_pitch, GeqDesign gd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int SP = (S + 1) & ~1;                               // even table pitch: a section pair is one 8-byte read
     float* cf = reinterpret_cast<float*>(smem);                // [Nmid][basis 2][poly 2][3][SP]
     float* lw = cf + (size_t)Nmid * 12 * SP;                   // [Nmid][NIW]
     const int m = blockIdx.y;
-    for (int i = threadIdx.x; i < Nmid * 2 * SP; i += 256) {
-        const int j = i / (2 * SP), rem = i - j * 2 * SP;
-        const int poly = rem / SP, sidx = rem - poly * SP;
-        const double* t = poly ? a : b;
+    for (int i = threadIdx.x; i < Nmid * SP; i += 256) {
+        const int j = i / SP, sidx = i - j * SP;
         const int c = m * Nmid + j;
         const bool real = sidx < S;                            // padding section: b = a = (1, 0, 0)
-        const double t0 = real ? t[(size_t)sidx * C + c] : 1.0, t1 = real ? t[(size_t)(S + sidx) * C + c] : 0.0,
-                     t2 = real ? t[(size_t)(2 * S + sidx) * C + c] : 0.0;
-        float* lo = cf + ((size_t)j * 4 + 0 * 2 + poly) * 3 * SP;
-        float* hi = cf + ((size_t)j * 4 + 1 * 2 + poly) * 3 * SP;
-        lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
-        hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+        double tb[3] = {1.0, 0.0, 0.0}, ta[3] = {1.0, 0.0, 0.0};
+        if (real) {
+            if (gd.gain) {
+                geq_section_of(gd.gain, gd.in_kind, sidx * C + c, sidx, S, gd.k, tb, ta);
+                if (blockIdx.x == 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        gd.b_out[(size_t)(q * S + sidx) * C + c] = tb[q];
+                        gd.a_out[(size_t)(q * S + sidx) * C + c] = ta[q];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    tb[q] = b[(size_t)(q * S + sidx) * C + c];
+                    ta[q] = a[(size_t)(q * S + sidx) * C + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int poly = 0; poly < 2; ++poly) {
+            const double t0 = poly ? ta[0] : tb[0], t1 = poly ? ta[1] : tb[1], t2 = poly ? ta[2] : tb[2];
+            float* lo = cf + ((size_t)j * 4 + 0 * 2 + poly) * 3 * SP;
+            float* hi = cf + ((size_t)j * 4 + 1 * 2 + poly) * 3 * SP;
+            lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
+            hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+        }
     }
     for (int i = threadIdx.x; i < Nmid * NIW; i += 256) lw[i] = Wr[i];
     __syncthreads();
@@ -887,13 +920,9 @@ __device__ inline double geq_linear_gain(const void* gain, int in_kind, int idx,
     return fabs(v);
 }
 
-__global__ void __launch_bounds__(256) geq_sections_kernel(const void* __restrict__ gain, int in_kind, int nb, int C,
-                                                          const double* __restrict__ k, double* __restrict__ b,
-                                                          double* __restrict__ a) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nb * C) return;
-    const int band = idx / C;
-    const int st = nb * C;
+// one section of the equaliser: band `band` of channel pair idx - band * C (idx = band * C + c), taps into bb[3], aa[3]
+__device__ inline void geq_section_of(const void* __restrict__ gain, int in_kind, int idx, int band, int nb,
+                                      const double* __restrict__ k, double* bb, double* aa) {
     double raw;
     const double g = geq_linear_gain(gain, in_kind, idx, &raw);
     double b0, b1, b2, a0, a1, a2;
@@ -919,8 +948,20 @@ __global__ void __launch_bounds__(256) geq_sections_kernel(const void* __restric
         b0 = f32r(sg + g * t); b1 = f32r(-2 * sg * c); b2 = f32r(sg - g * t);
         a0 = f32r(sg + t); a1 = b1; a2 = f32r(sg - t);
     }
-    b[idx] = b0; b[idx + st] = b1; b[idx + 2 * st] = b2;
-    a[idx] = a0; a[idx + st] = a1; a[idx + 2 * st] = a2;
+    bb[0] = b0; bb[1] = b1; bb[2] = b2;
+    aa[0] = a0; aa[1] = a1; aa[2] = a2;
+}
+
+__global__ void __launch_bounds__(256) geq_sections_kernel(const void* __restrict__ gain, int in_kind, int nb, int C,
+                                                          const double* __restrict__ k, double* __restrict__ b,
+                                                          double* __restrict__ a) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nb * C) return;
+    const int st = nb * C;
+    double bb[3], aa[3];
+    geq_section_of(gain, in_kind, idx, idx / C, nb, k, bb, aa);
+    b[idx] = bb[0]; b[idx + st] = bb[1]; b[idx + 2 * st] = bb[2];
+    a[idx] = aa[0]; a[idx + st] = aa[1]; a[idx + 2 * st] = aa[2];
 }
 
 // gb / ga: (nblk, 3, nb, C) partial sums blk_stride elements apart (nblk = 1: plain gradients);
@@ -1211,9 +1252,9 @@ int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_
                             int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
     return sos_bwd_impl<float>(gH, g_pitch, H, h_pitch, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
 }
-int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
-                           const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
-                           int float_eval, void* stream) {
+static int rc_impl(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
+                   const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
+                   int float_eval, void* stream, GeqDesign gd) {
     FL_REQUIRE(b && a && Wr && Wd && G && H, "sos_response_rc: null pointer");
     FL_REQUIRE(g_pitch >= m_local && h_pitch >= m_local, "sos_response_rc: pitches must be >= m_local");
     FL_REQUIRE(S > 0 && S <= 64 && No > 0 && No <= 65535 && Nmid > 0 && Nmid <= 32 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) &&
@@ -1230,23 +1271,28 @@ int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid
         if (g_rc_fast == 2)                                                                                                  \
             hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 2>), grid_fast, dim3(256), lds_fast, (hipStream_t)stream,       \
                                (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
-                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
+                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch, gd);  \
         else if (g_rc_fast == 3)                                                                                             \
             hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 3>), grid_fast, dim3(256), lds_fast, (hipStream_t)stream,       \
                                (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
-                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
+                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch, gd);  \
         else if (g_rc_fast == 6)                                                                                             \
             hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 6>), grid_fast, dim3(256), lds_fast, (hipStream_t)stream,       \
                                (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
-                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
+                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch, gd);  \
         else                                                                                                                 \
             hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_>), grid_fast, dim3(256), lds_fast, (hipStream_t)stream,          \
                                (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
-                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);  \
+                               (const cx<double>*)Wd, nfft, bin0, m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch, gd);  \
         FL_CHECK_LAUNCH("sos_response_rc_fast");                                                                             \
         return FL_OK;                                                                                                        \
     }                                                                                                                        \
     if (Ni == NIW_) {                                                                                                        \
+        if (gd.gain) {      /* the double kernel reads its sections: design them first */                                        \
+            hipLaunchKernelGGL(geq_sections_kernel, dim3(cdiv_i(S * No * Nmid, 256)), dim3(256), 0, (hipStream_t)stream, gd.gain, \
+                               gd.in_kind, S, No * Nmid, gd.k, gd.b_out, gd.a_out);                                              \
+            FL_CHECK_LAUNCH("geq_sections");                                                                                     \
+        }                                                                                                                        \
         hipLaunchKernelGGL((sos_response_rc_kernel<NIW_>), grid, dim3(256), lds, (hipStream_t)stream, (const double*)b,      \
                            (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma, (const cx<double>*)Wd, nfft, bin0, \
                            m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);                                         \
@@ -1257,6 +1303,26 @@ int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid
 #undef FL_RC_FWD
     set_error("sos_response_rc: no kernel for %d input channels of the constant factor", Ni);
     return FL_ERR_UNSUPPORTED;
+}
+int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
+                           const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
+                           int float_eval, void* stream) {
+    return rc_impl(b, a, S, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, G, g_pitch, H, h_pitch, float_eval, stream,
+                   GeqDesign{nullptr, 0, nullptr, nullptr, nullptr});
+}
+int fl_geq_response_rc_c64(const void* gain, int in_kind, int nb, const void* consts, void* b, void* a, int No, int Nmid, int Ni,
+                           const void* Wr, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch,
+                           void* H, long h_pitch, int float_eval, void* stream) {
+    FL_REQUIRE(gain && consts, "geq_response_rc: null pointer");
+    FL_REQUIRE(in_kind >= 0 && in_kind <= 4 && nb >= 4, "geq_response_rc: in_kind in [0, 4], at least four bands");
+    if (m_local == 0) {      // nothing to evaluate: the sections are still an output
+        hipLaunchKernelGGL(geq_sections_kernel, dim3(cdiv_i(nb * No * Nmid, 256)), dim3(256), 0, (hipStream_t)stream, gain, in_kind, nb,
+                           No * Nmid, (const double*)consts, (double*)b, (double*)a);
+        FL_CHECK_LAUNCH("geq_sections");
+        return FL_OK;
+    }
+    return rc_impl(b, a, nb, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, G, g_pitch, H, h_pitch, float_eval, stream,
+                   GeqDesign{gain, in_kind, (const double*)consts, (double*)b, (double*)a});
 }
 int fl_sos_response_apply_max_ni(int S) {      // cascades per row whose coefficient tables fit the default 64 KB of dynamic LDS
     const int SP = (S + 1) & ~1;

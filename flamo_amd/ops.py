@@ -1767,8 +1767,9 @@ def cascade_rc_supported(real: torch.dtype, n_in: int, n_mid: int = 1, n_section
     return n_mid * 6 * n_sections * 8 + n_mid * int(n_in) * 4 <= 64 * 1024
 
 
-def _cascade_rc_forward(b, a, Wr, gamma, nfft, real, float_eval):
-    """G = cascade(b, a) (No, Nmid per bin), H = G @ Wr in one launch.  Returns (H view (M, No, Ni), G rows, cfg)."""
+def _cascade_rc_forward(b, a, Wr, gamma, nfft, real, float_eval, geq=None):
+    """G = cascade(b, a) (No, Nmid per bin), H = G @ Wr in one launch.  Returns (H view (M, No, Ni), G rows, cfg).
+    geq = (raw gains, in_kind, band constants): b, a are OUTPUTS, designed by the same launch (fl_geq_response_rc_c64)."""
     if b.dim() != 4:
         raise ValueError("cascade_rc expects a full (N_out, N_mid) cascade")
     dev = b.device
@@ -1782,10 +1783,17 @@ def _cascade_rc_forward(b, a, Wr, gamma, nfft, real, float_eval):
     Wc = Wr.contiguous()
     P = _pitch(m_local)
     with kernel_timer.span("sos_response_rc"):
-        _lib.check(_lib.lib().fl_sos_response_rc_c64(b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni, Wc.data_ptr(), float(gamma),
-                                                     twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local,
-                                                     G.data_ptr(), P, H.data_ptr(), P, int(bool(float_eval and FLOAT_CASCADE_EVAL)),
-                                                     _stream()), "sos_response_rc")
+        if geq is not None:
+            xc, kind, consts = geq
+            _lib.check(_lib.lib().fl_geq_response_rc_c64(xc.data_ptr(), kind, S, consts.data_ptr(), b.data_ptr(), a.data_ptr(), No, Nmid, Ni,
+                                                         Wc.data_ptr(), float(gamma), twiddles(nfft, torch.float64, dev).data_ptr(), nfft,
+                                                         bin0, m_local, G.data_ptr(), P, H.data_ptr(), P,
+                                                         int(bool(float_eval and FLOAT_CASCADE_EVAL)), _stream()), "geq_response_rc")
+        else:
+            _lib.check(_lib.lib().fl_sos_response_rc_c64(b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni, Wc.data_ptr(), float(gamma),
+                                                         twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local,
+                                                         G.data_ptr(), P, H.data_ptr(), P, int(bool(float_eval and FLOAT_CASCADE_EVAL)),
+                                                         _stream()), "sos_response_rc")
     return H.movedim(-1, 0), G, (float(gamma), nfft, S, No * Nmid, bin0, m_local, real)
 
 
@@ -1844,9 +1852,8 @@ class _GeqCascadeRC(torch.autograd.Function):
         C_ = max(_prod(chan), 1)
         b = torch.empty((3, nb, *chan), dtype=torch.float64, device=dev)
         a = torch.empty_like(b)
-        _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), _geq_in_kind(xc, True, sig), nb, C_, consts.data_ptr(), b.data_ptr(),
-                                              a.data_ptr(), _stream()), "geq_sections")
-        H, G, ctx.cfg = _cascade_rc_forward(b, a, Wr, gamma, nfft, real, True)
+        # the sections are designed in the response kernel's prologue (and written to b, a for the backward pass)
+        H, G, ctx.cfg = _cascade_rc_forward(b, a, Wr, gamma, nfft, real, True, geq=(xc, _geq_in_kind(xc, True, sig), consts))
         ctx.save_for_backward(xc, consts, b, a, G, Wr)
         return H
 

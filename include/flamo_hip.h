@@ -339,6 +339,12 @@ int fl_sos_response_bwd_outer_c64(const void* gY, long gy_sb, long gy_sn, const 
 int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
                            const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
                            int float_eval, void* stream);
+/* The same operator for a graphic equaliser given by its command gains (eq.py:57-111; gain / in_kind / consts as in
+ * fl_geq_sections): the float kernel designs the sections in its prologue and writes them to b, a (double (3, nb, No*Nmid)
+ * each, outputs: the backward pass reads them) -- one launch for fl_geq_sections + fl_sos_response_rc_c64. */
+int fl_geq_response_rc_c64(const void* gain, int in_kind, int nb, const void* consts, void* b, void* a, int No, int Nmid, int Ni,
+                           const void* Wr, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch,
+                           void* H, long h_pitch, int float_eval, void* stream);
 /* The same backward pass when the cascade's response G (No x Nmid per bin, channel pair c = m*Nmid + j) was multiplied on
  * the right by a real constant matrix W (Nmid x Ni) -- Series(Matrix, <cascade-type filter>), system.py:299-300 over
  * dsp.py:466-468 and dsp.py:922-924:  H[m][n] = sum_j G[m][j] W[j][n].  gHfull: dL/dH, planes (m*Ni + n) of pitch g_pitch;
