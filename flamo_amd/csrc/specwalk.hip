@@ -829,11 +829,12 @@ int fl_spec_walk_partition(int nfft, int Bn, int n_wg, int* bounds) {
     if (rc) return rc;
     // Contiguous unit ranges of minimal maximum COST.  A unit of a self-mirrored row pair (k1 = 0, and L1/2 for even L1) has
     // one row instead of two; entering a row pair costs a fill (the response slice into registers, tables, the pipeline's
-    // first two stages with nothing beside them).  Fitted to per-workgroup cycle counts (tools/dbg/walk_fit.py): 9.8 k cycles
-    // per unit, 15.4 k per row pair entered, 8.3 k per self-mirrored unit.  Equal unit COUNTS left the slowest workgroup
-    // 13-19 % above the mean.  Costs in twentieths of a unit; the smallest cap for which a greedy sweep needs no more than
+    // first two stages with nothing beside them).  Fitted to per-workgroup cycle counts (tools/dbg/walk_bench.py's table by
+    // (units, entries)): 11.0 k cycles per unit, 20.7 k per row pair entered, 8.7 k per self-mirrored unit (refitted late in
+    // round 3: with the earlier 1.55 units per entry the workgroups that enter two row pairs finished 6 % behind the rest).
+    // Equal unit COUNTS left the slowest workgroup 13-19 % above the mean.  Costs in twentieths of a unit; the smallest cap for which a greedy sweep needs no more than
     // n_wg ranges (binary search), then the sweep's cuts.
-    const int P = L1 / 2 + 1, U = P * Bn, UC = 20, US = 17, FC = 31;
+    const int P = L1 / 2 + 1, U = P * Bn, UC = 20, US = 16, FC = 38;
     auto ucost = [&](int u) { const int r = u / Bn; return (r == 0 || 2 * r == L1) ? US : UC; };
     auto sweep = [&](long cap, int* out) {       // number of ranges used; out[i] = first unit of range i
         int n = 0, u = 0;

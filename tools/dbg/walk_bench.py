@@ -166,3 +166,31 @@ if len(tg):
     d = tg[:, 1] - tg[:, 0]
     print(f"gradh_walk: {len(tg)} workgroups, cycles mean {d.mean():.0f} min {d.min():.0f} max {d.max():.0f}; step 1 {tg[:, 2].mean():.0f}, step 2 {tg[:, 3].mean():.0f}; "
           f"own work in step 2: wavefront 0 {tg[:, 4].mean():.0f}, 1 {tg[:, 5].mean():.0f}, 4 {tg[:, 6].mean():.0f}, 7 {tg[:, 7].mean():.0f}")
+
+# forward kernel: per-workgroup cycles against the partition's cost model (units, row-pair entries)
+if len(tt) and BND is not None:
+    G = len(bl) - 1
+    full = buf.view(-1, 8).cpu().double()
+    rows = []
+    for blk in range(G):
+        w = (blk & 7) * (G >> 3) + (blk >> 3) if G % 8 == 0 else blk
+        lo, hi = bl[w], bl[w + 1]
+        if hi <= lo:
+            continue
+        fills = (hi - 1) // B - lo // B + 1
+        halves = sum(1 for u in range(lo, hi) if (u // B) in (0, (nfft // 2 // 240) // 2))
+        rows.append((full[blk, 1] - full[blk, 0], hi - lo, fills, halves, blk & 7))
+    rows.sort(key=lambda r: -r[0])
+    print("slowest workgroups (cycles, units, row-pair entries, self-mirrored units, XCD):", [(int(c), n, f, h, x) for c, n, f, h, x in rows[:8]])
+    print("fastest:", [(int(c), n, f, h, x) for c, n, f, h, x in rows[-4:]])
+    import collections
+    by = collections.defaultdict(list)
+    for c, n, f, h, x in rows:
+        by[(n, f, h)].append(c.item())
+    for k in sorted(by):
+        v = by[k]
+        print(f"   units {k[0]:2d} entries {k[1]} self-mirrored {k[2]:2d}: {len(v):3d} workgroups, cycles mean {sum(v) / len(v):8.0f} min {min(v):8.0f} max {max(v):8.0f}")
+    byx = collections.defaultdict(list)
+    for c, n, f, h, x in rows:
+        byx[x].append(c.item())
+    print("   mean cycles per XCD:", {x: int(sum(v) / len(v)) for x, v in sorted(byx.items())})
