@@ -91,6 +91,7 @@ _SIGNATURES = {
     "fl_sos_response_apply_c64": (_i, [_vp, _vp, _i, _i, _i, _vp, _l, _l, _i, _d, _vp, _i, _i, _i, _vp, _l, _vp, _l, _l, _vp]),
     "fl_sos_response_bwd_outer_c64": (_i, [_vp, _l, _l, _vp, _l, _l, _i, _i, _i, _vp, _l, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _vp]),
     "fl_sos_response_rc_c64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _d, _vp, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp]),
+    "fl_geq_response_c64": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _d, _vp, _i, _i, _i, _vp, _l, _i, _vp]),
     "fl_geq_response_rc_c64": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _d, _vp, _i, _i, _i, _vp, _l, _vp, _l, _i, _vp]),
     "fl_sos_response_bwd_rc_c64": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _d, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "fl_geq_sections": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),

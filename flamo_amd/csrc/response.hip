@@ -419,21 +419,40 @@ __global__ void __launch_bounds__(256) sos_response_apply_fast_kernel(const doub
 constexpr int kSosFastBins = 1024;
 __global__ void __launch_bounds__(256) sos_response_fast_kernel(const double* __restrict__ b, const double* __restrict__ a, int S, int C,
                                                                double g, const cx<double>* __restrict__ Wd, int nfft, int bin0,
-                                                               int m_local, cx<float>* __restrict__ H, long h_pitch) {
+                                                               int m_local, cx<float>* __restrict__ H, long h_pitch, GeqDesign gd) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int SP = (S + 1) & ~1;
     float* cf = reinterpret_cast<float*>(smem);                // [basis 2][poly 2][3][SP]
     const int c = blockIdx.y;
-    for (int i = threadIdx.x; i < 2 * SP; i += 256) {
-        const int poly = i / SP, sidx = i - poly * SP;
-        const double* t = poly ? a : b;
+    for (int sidx = threadIdx.x; sidx < SP; sidx += 256) {
         const bool real = sidx < S;                            // padding section: b = a = (1, 0, 0)
-        const double t0 = real ? t[(size_t)sidx * C + c] : 1.0, t1 = real ? t[(size_t)(S + sidx) * C + c] : 0.0,
-                     t2 = real ? t[(size_t)(2 * S + sidx) * C + c] : 0.0;
-        float* lo = cf + (0 * 2 + poly) * 3 * SP;
-        float* hi = cf + (1 * 2 + poly) * 3 * SP;
-        lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
-        hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+        double tb[3] = {1.0, 0.0, 0.0}, ta[3] = {1.0, 0.0, 0.0};
+        if (real) {
+            if (gd.gain) {                                     // graphic equaliser: designed here (see GeqDesign)
+                geq_section_of(gd.gain, gd.in_kind, sidx * C + c, sidx, S, gd.k, tb, ta);
+                if (blockIdx.x == 0) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        gd.b_out[(size_t)(q * S + sidx) * C + c] = tb[q];
+                        gd.a_out[(size_t)(q * S + sidx) * C + c] = ta[q];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    tb[q] = b[(size_t)(q * S + sidx) * C + c];
+                    ta[q] = a[(size_t)(q * S + sidx) * C + c];
+                }
+            }
+        }
+#pragma unroll
+        for (int poly = 0; poly < 2; ++poly) {
+            const double t0 = poly ? ta[0] : tb[0], t1 = poly ? ta[1] : tb[1], t2 = poly ? ta[2] : tb[2];
+            float* lo = cf + (0 * 2 + poly) * 3 * SP;
+            float* hi = cf + (1 * 2 + poly) * 3 * SP;
+            lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
+            hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+        }
     }
     __syncthreads();
     const int f_end = min(m_local, (int)(blockIdx.x + 1) * kSosFastBins);
@@ -1100,7 +1119,8 @@ static int delay_impl(const int32_t* m, const void* amp, int C, const void* W, i
 
 template <typename T>
 static int sos_impl(const void* b, const void* a, int S, int C, double gamma, const void* Wd, int nfft, int bin0,
-                    int m_local, void* H, long h_pitch, void* stream, bool float_eval = false) {
+                    int m_local, void* H, long h_pitch, void* stream, bool float_eval = false,
+                    GeqDesign gd = GeqDesign{nullptr, 0, nullptr, nullptr, nullptr}) {
     FL_REQUIRE(b && a && H && Wd, "sos_response: null pointer");
     FL_REQUIRE(h_pitch >= m_local, "sos_response: h_pitch must be >= m_local");
     FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) && m_local >= 0, "sos_response: bad sizes");
@@ -1110,10 +1130,15 @@ static int sos_impl(const void* b, const void* a, int S, int C, double gamma, co
             const int SP = (S + 1) & ~1;
             hipLaunchKernelGGL(sos_response_fast_kernel, dim3(cdiv_i(m_local, kSosFastBins), C), dim3(256), (size_t)12 * SP * sizeof(float),
                                (hipStream_t)stream, (const double*)b, (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0,
-                               m_local, (cx<float>*)H, h_pitch);
+                               m_local, (cx<float>*)H, h_pitch, gd);
             FL_CHECK_LAUNCH("sos_response_fast");
             return FL_OK;
         }
+    }
+    if (gd.gain) {      // the double kernel reads its sections: design them first
+        hipLaunchKernelGGL(geq_sections_kernel, dim3(cdiv_i(S * C, 256)), dim3(256), 0, (hipStream_t)stream, gd.gain, gd.in_kind, S, C, gd.k,
+                           gd.b_out, gd.a_out);
+        FL_CHECK_LAUNCH("geq_sections");
     }
     dim3 grid(cdiv_i(m_local, 256), C);
     hipLaunchKernelGGL((sos_response_kernel<T>), grid, dim3(256), (size_t)6 * S * sizeof(double), (hipStream_t)stream, (const double*)b, (const double*)a, S, C,
@@ -1199,6 +1224,19 @@ int fl_sos_response_c64(const void* b, const void* a, int S, int C, double gamma
 int fl_sos_response_f32eval_c64(const void* b, const void* a, int S, int C, double gamma, const void* Wd, int nfft, int bin0,
                                 int m_local, void* H, long h_pitch, void* stream) {
     return sos_impl<float>(b, a, S, C, gamma, Wd, nfft, bin0, m_local, H, h_pitch, stream, true);
+}
+int fl_geq_response_c64(const void* gain, int in_kind, int nb, const void* consts, void* b, void* a, int C, double gamma, const void* Wd,
+                        int nfft, int bin0, int m_local, void* H, long h_pitch, int float_eval, void* stream) {
+    FL_REQUIRE(gain && consts && b && a, "geq_response: null pointer");
+    FL_REQUIRE(in_kind >= 0 && in_kind <= 4 && nb >= 4, "geq_response: in_kind in [0, 4], at least four bands");
+    const GeqDesign gd{gain, in_kind, (const double*)consts, (double*)b, (double*)a};
+    if (m_local == 0) {
+        hipLaunchKernelGGL(geq_sections_kernel, dim3(cdiv_i(nb * C, 256)), dim3(256), 0, (hipStream_t)stream, gain, in_kind, nb, C,
+                           (const double*)consts, (double*)b, (double*)a);
+        FL_CHECK_LAUNCH("geq_sections");
+        return FL_OK;
+    }
+    return sos_impl<float>(b, a, nb, C, gamma, Wd, nfft, bin0, m_local, H, h_pitch, stream, float_eval != 0, gd);
 }
 int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamma, const void* Wd, int nfft, int bin0,
                         int m_local, void* H, long h_pitch, void* stream) {

@@ -1604,9 +1604,19 @@ class _GeqCascade(torch.autograd.Function):
         kind = _geq_in_kind(xc, True, sig)
         b = torch.empty((3, nb, *chan), dtype=torch.float64, device=dev)
         a = torch.empty_like(b)
-        _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), kind, nb, C_, consts.data_ptr(), b.data_ptr(), a.data_ptr(),
-                                              _stream()), "geq_sections")
-        H, ctx.cfg = _sos_forward_launch(b, a, gamma, nfft, real, True)     # graphic-equaliser sections
+        if real == torch.float32:
+            # design + cascade in one launch (the float kernel designs the sections in its prologue)
+            bin0, m_local = _bin0_arg(nfft)
+            H = _empty_rows(chan, m_local, torch.complex64, dev)
+            with kernel_timer.span("sos_response"):
+                _lib.check(_lib.lib().fl_geq_response_c64(xc.data_ptr(), kind, nb, consts.data_ptr(), b.data_ptr(), a.data_ptr(), C_, float(gamma),
+                                                          twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local, H.data_ptr(),
+                                                          _pitch(m_local), int(bool(FLOAT_CASCADE_EVAL)), _stream()), "geq_response")
+            ctx.cfg = (float(gamma), nfft, nb, C_, bin0, m_local, real)
+        else:
+            _lib.check(_lib.lib().fl_geq_sections(xc.data_ptr(), kind, nb, C_, consts.data_ptr(), b.data_ptr(), a.data_ptr(),
+                                                  _stream()), "geq_sections")
+            H, ctx.cfg = _sos_forward_launch(b, a, gamma, nfft, real, True)     # graphic-equaliser sections
         keep = H if (real == torch.float64 or SOS_BWD_MIXED) else None
         ctx.save_for_backward(xc, consts, b, a, *([keep] if keep is not None else []))
         return H.movedim(-1, 0)

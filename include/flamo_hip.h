@@ -299,6 +299,10 @@ int fl_sos_response_c128(const void* b, const void* a, int S, int C, double gamm
  * with cancellation (parametric equalisers) amplify the extra 2e-7 to 1e-5 .. 1e-4 in the gradient. */
 int fl_sos_response_f32eval_c64(const void* b, const void* a, int S, int C, double gamma, const void* Wd,
                                 int nfft, int bin0, int m_local, void* H, long h_pitch, void* stream);
+/* Graphic equaliser from its command gains in ONE launch (fl_geq_sections + fl_sos_response[_f32eval]_c64): the float
+ * kernel designs the sections in its prologue; b, a (double (3, nb, C) each) are outputs for the backward pass. */
+int fl_geq_response_c64(const void* gain, int in_kind, int nb, const void* consts, void* b, void* a, int C, double gamma, const void* Wd,
+                        int nfft, int bin0, int m_local, void* H, long h_pitch, int float_eval, void* stream);
 /* Backward: partial sums over bins of dL/db, dL/da.  part: double (nblk, 2, 3, S, C) where
  * nblk = fl_sos_bwd_blocks(m_local, C, S, mixed) (mixed = 1 for the _c64 route with H, the constant-factor and the
  * outer-product forms; the grid is sized to one round of resident workgroups); every entry is written (no zero-fill
