@@ -501,9 +501,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.no_graph:
-        for _ in range(12):          # allocator growth and first-launch costs belong to set-up, like the capture does
-            step()
+    # Set-up, before the W warm-up steps: the device is brought to its sustained state.  Right after the capture (host work,
+    # GPU idle) the first ~50 replays of this 0.4 ms step run 10-18 % slower than the rest (tools/dbg/replay_transient.py:
+    # 0.44, 0.48, 0.46, 0.43, 0.42, 0.41, ... 0.40 ms per replay in blocks of five -- the power management's clock ramp, not
+    # something the step does), and with W = 5 the K = 20 timed steps would sit in the middle of that ramp.  The local step
+    # (no collective: every rank does this on its own) is repeated in blocks of ten until two consecutive blocks agree
+    # within 1 %, at most 300 times (0.12 s); eager steps additionally include allocator growth and first-launch costs.
+    settle = {"steps": 0, "ms_first_block": None, "ms_last_block": None}
+    local_step = (lambda: gs.replay()) if gs is not None else (lambda: eager_step(False))
+    prev = None
+    while settle["steps"] < 300:
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(10):
+            local_step()
+        torch.cuda.synchronize()
+        cur = (time.perf_counter() - tb) / 10 * 1e3
+        settle["steps"] += 10
+        if settle["ms_first_block"] is None:
+            settle["ms_first_block"] = round(cur, 4)
+        settle["ms_last_block"] = round(cur, 4)
+        if prev is not None and settle["steps"] >= 30 and abs(cur - prev) <= 0.01 * prev:
+            break
+        prev = cur
     for _ in range(args.warmup):
         step()
     fence()
@@ -614,6 +634,10 @@ def main():
                "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
                "timed_region": ("eager steps" if args.no_graph else
                                 "HIP-graph replays of forward+backward (torch.cuda.CUDAGraph), one replay per step"),
+               "setup_before_warmup": {"what": "after the capture the local step is repeated in blocks of ten until two consecutive "
+                                               "blocks agree within 1 % (the device's clock ramp: the first ~50 replays run 10-18 % "
+                                               "slower); then the W warm-up steps, then the K timed steps",
+                                       **settle},
                "config": {"workload": "BASELINE configs[1]: Shell(FFT -> Series(Matrix 8x8, GEQ 8x8) -> iFFT), nfft=96000, "
                                       "batch 32 per GPU, fwd+bwd of (y**2).mean(), parameter grads",
                           "nfft": NFFT, "channels": NCH, "batch_per_gpu": BATCH, "parallelism": f"dp{world} (batch)",
