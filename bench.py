@@ -626,6 +626,13 @@ def main():
                               "replays, each timed launch queued behind ~0.2 ms of streaming copies (busy queue, cold infinity cache)",
                     "traffic_source": (traffic or {}).get("source", "no PMC profile committed for this kernel yet"),
                     "traffic_profile_commit": (traffic or {}).get("commit")}
+            # the same kernel inside the REPLAYED step, from the committed rocprofv3 --kernel-trace --stats run of this command
+            # (events cannot be recorded inside a captured graph on ROCm; the eager leg above starts every launch behind
+            # cache-flushing copies and reads ~10 % longer)
+            prof_us = (traffic or {}).get(key if fused else "mimo_full", {}).get("rocprofv3_avg_launch_us")
+            if prof_us:
+                roof["replayed_launch_ms_rocprofv3"] = prof_us * 1e-3
+                roof["replayed_frac_rocprofv3"] = alg[key] / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS
         unfused_bytes = (2 * sig + hb) + (3 * sig + 2 * hb) + (2 * sig) + (3 * sig)      # GEQ fwd/bwd + Matrix fwd/bwd
         fused_bytes = sum(alg.get(k, 0) * v["launches_per_step"] for k, v in kernels.items())
         out = {"metric": "freq-bin*channel products/sec (fwd+bwd), nfft=96000 8x8ch", "value": products_per_step / (ms * 1e-3),

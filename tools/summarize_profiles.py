@@ -88,10 +88,21 @@ def main():
         traffic["commit"] = head + ("+uncommitted changes" if dirty else "")
     except Exception:           # noqa: BLE001
         traffic["commit"] = None
+    # average launch duration of the same kernels in the rocprofv3 --kernel-trace --stats run of the bench command (graph replays)
+    stats = {}
+    try:
+        for r in csv.DictReader(open(os.path.join(SRC, "stats", "r_kernel_stats.csv"))):
+            stats[r["Name"]] = (float(r["AverageNs"]), int(r["Calls"]))
+    except OSError:
+        pass
     for k, pat in tags.items():
         r = largest(pat)
         if r:
             traffic[k] = {"bytes_per_launch": r[5], "fetch_bytes": r[3], "write_bytes": r[4], "launches": r[2], "kernel": r[0][:100]}
+            st = [v for n, v in stats.items() if n[:100] == r[0][:100]]
+            if st:
+                traffic[k]["rocprofv3_avg_launch_us"] = st[0][0] / 1e3
+                traffic[k]["rocprofv3_calls"] = st[0][1]
     json.dump(traffic, open(os.path.join(DST, "pmc_hbm_traffic.json"), "w"), indent=1)
     sq = os.path.join(SRC, "bench_sq", "r_counter_collection.csv")
     if os.path.exists(sq):
