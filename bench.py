@@ -246,11 +246,33 @@ def config2_variants(dev, x, steps):
 
 
 # ----------------------------------------------------------------------------- secondary workloads (one GPU)
+def settle_device(local_step, max_steps=300):
+    """Set-up in front of a timed region: repeat ``local_step`` in blocks of ten until two consecutive blocks agree within 1 %
+    (at least 30, at most ``max_steps`` repeats).  Right after a capture -- host work, GPU idle -- the first ~50 replays of a
+    sub-millisecond step run 10-18 % slower than the rest (tools/dbg/replay_transient.py: the device's clock ramp)."""
+    rep = {"steps": 0, "ms_first_block": None, "ms_last_block": None}
+    prev = None
+    while rep["steps"] < max_steps:
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for _ in range(10):
+            local_step()
+        torch.cuda.synchronize()
+        cur = (time.perf_counter() - tb) / 10 * 1e3
+        rep["steps"] += 10
+        if rep["ms_first_block"] is None:
+            rep["ms_first_block"] = round(cur, 4)
+        rep["ms_last_block"] = round(cur, 4)
+        if prev is not None and rep["steps"] >= 30 and abs(cur - prev) <= 0.01 * prev:
+            break
+        prev = cur
+    return rep
+
+
 def _graph_ms(fn, inputs, params, steps):
     from flamo_amd.graph import GraphedStep
     gs = GraphedStep(fn, inputs, params)
-    for _ in range(3):
-        gs.replay()
+    settle_device(gs.replay, max_steps=100)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -507,23 +529,8 @@ def main():
     # something the step does), and with W = 5 the K = 20 timed steps would sit in the middle of that ramp.  The local step
     # (no collective: every rank does this on its own) is repeated in blocks of ten until two consecutive blocks agree
     # within 1 %, at most 300 times (0.12 s); eager steps additionally include allocator growth and first-launch costs.
-    settle = {"steps": 0, "ms_first_block": None, "ms_last_block": None}
     local_step = (lambda: gs.replay()) if gs is not None else (lambda: eager_step(False))
-    prev = None
-    while settle["steps"] < 300:
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        for _ in range(10):
-            local_step()
-        torch.cuda.synchronize()
-        cur = (time.perf_counter() - tb) / 10 * 1e3
-        settle["steps"] += 10
-        if settle["ms_first_block"] is None:
-            settle["ms_first_block"] = round(cur, 4)
-        settle["ms_last_block"] = round(cur, 4)
-        if prev is not None and settle["steps"] >= 30 and abs(cur - prev) <= 0.01 * prev:
-            break
-        prev = cur
+    settle = settle_device(local_step)
     for _ in range(args.warmup):
         step()
     fence()
@@ -708,8 +715,7 @@ def input_grad_leg(model, params, x, steps, products):
     saved = [p.grad for p in params]
     from flamo_amd.graph import GraphedStep      # differentiates with respect to `params`: the input joins them
     gs = GraphedStep(lambda xx: ops.mean_square(model(xg)), (x,), list(params) + [xg], warmup=2)
-    for _ in range(3):
-        gs.replay()
+    settle_device(gs.replay, max_steps=100)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
