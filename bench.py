@@ -249,7 +249,7 @@ def config2_variants(dev, x, steps):
 def settle_device(local_step, max_steps=300):
     """Set-up in front of a timed region: repeat ``local_step`` in blocks of ten until two consecutive blocks agree within 1 %
     (at least 30, at most ``max_steps`` repeats).  Right after a capture -- host work, GPU idle -- the first ~50 replays of a
-    sub-millisecond step run 10-18 % slower than the rest (tools/dbg/replay_transient.py: the device's clock ramp)."""
+    sub-millisecond step run 10-18 % slower than the rest (tools/dbg/archive/replay_transient.py: the device's clock ramp)."""
     rep = {"steps": 0, "ms_first_block": None, "ms_last_block": None}
     prev = None
     while rep["steps"] < max_steps:
@@ -365,6 +365,30 @@ def secondary(dev):
     ms = _graph_ms(lambda xx: (model(xx) * c).sum(), (x,), params, 5)
     out["config5_chain_32x32"] = {"ms_per_step": round(ms, 3), "bin_solves_per_s": 192001 / (ms * 1e-3),
                                   "solve": solve_rate(model, x, c, params, 32, 384000, 32)}
+    del model, params, x, c
+    # float64: what the reference's example scripts default to (examples/e7_biquad.py:237, e8_fdn.py:515,
+    # e8_active_acoustics.py:765) -- configs[1], [2] and the configs[4] structure, the same steps in double
+    d64 = torch.float64
+    torch.manual_seed(130709)
+    model, params = build_model(dev, d64)
+    x = torch.randn(BATCH, NFFT, NCH, device=dev, dtype=d64)
+    ms = _graph_ms(lambda xx: ops.mean_square(model(xx)), (x,), params, 10)
+    out["config2_f64"] = {"ms_per_step": round(ms, 4), "products_per_s": 2 * BATCH * (NFFT // 2 + 1) * NCH * NCH / (ms * 1e-3),
+                          "dtype": "f64"}
+    del model, params, x
+    torch.manual_seed(130709)
+    model, params = bench_fdn.build(dev, d64, 16, 192000)
+    x = torch.randn(1, 192000, 1, device=dev, dtype=d64)
+    c = torch.randn(1, 192000, 1, device=dev, dtype=d64)
+    ms = _graph_ms(lambda xx: (model(xx) * c).sum(), (x,), params, 10)
+    out["config3_fdn16_batch1_f64"] = {"ms_per_step": round(ms, 4), "bin_solves_per_s": 96001 / (ms * 1e-3), "dtype": "f64"}
+    del model, params, x, c
+    torch.manual_seed(130709)
+    model, params = bench_fdn.build_config5(dev, d64, 32, 384000)
+    x = torch.randn(1, 384000, 32, device=dev, dtype=d64)
+    c = torch.randn(1, 384000, 32, device=dev, dtype=d64)
+    ms = _graph_ms(lambda xx: (model(xx) * c).sum(), (x,), params, 5)
+    out["config5_chain_32x32_f64"] = {"ms_per_step": round(ms, 3), "bin_solves_per_s": 192001 / (ms * 1e-3), "dtype": "f64"}
     return out
 
 
@@ -411,13 +435,22 @@ def bin_sharded(dev, model, params, x, steps):
             p.grad = None
         (fd.sharded_forward(m5, x5) * c5).sum().backward()
         fd.all_reduce_grads(p5)
-    ms5 = timed(step5, 5)
+    ms5 = {}
+    for algo in ("rccl", "direct"):          # the all-gather's two algorithms (flamo_amd.dist.set_all_gather_algorithm)
+        prev = fd.set_all_gather_algorithm(algo)
+        try:
+            ms5[algo] = timed(step5, 5)
+        finally:
+            fd.set_all_gather_algorithm(prev)
+    ms5_by_algo, ms5 = {k: round(v, 3) for k, v in ms5.items()}, ms5[fd.get_all_gather_algorithm()]
     return {"config2_bins_all_to_all": {"ms_per_step": round(ms2, 4), "products_per_s": 2 * BATCH * world * M * NCH * NCH / (ms2 * 1e-3),
                                         "scaling": "weak", "collectives": "2 all-to-all forward + 2 backward (98 MB per rank each), "
                                                                           "1 flat gradient all-reduce"},
             "config5_chain_bins_all_gather": {"ms_per_step": round(ms5, 3), "bin_solves_per_s": 192001 / (ms5 * 1e-3),
                                               "scaling": "strong", "collectives": "1 all-gather of the (1, 192001, 32) spectrum "
-                                                                                  "(49 MB), 1 flat gradient all-reduce"}}
+                                                                                  "(49 MB), 1 flat gradient all-reduce",
+                                              "all_gather_algorithm": fd.get_all_gather_algorithm(),
+                                              "ms_per_step_by_all_gather_algorithm": ms5_by_algo}}
 
 
 def _free_port():
@@ -495,6 +528,7 @@ def main():
     x = torch.randn(BATCH, NFFT, NCH, device=dev, dtype=dtype)   # resident in HBM before timing
 
     def eager_step(sync_grads=True):
+        finish_gradients()
         for p in params:
             p.grad = None
         y = model(x)
@@ -506,14 +540,17 @@ def main():
 
     pending = []
 
+    def finish_gradients():
+        while pending:
+            pending.pop(0)()
+
     def sync_gradients():
         """Data-parallel gradient sum: < 4 KB through one cached flat buffer and ONE RCCL all-reduce per step, issued
-        asynchronously (the next step does not wait for the collective, as in DDP); every one of them is waited for
-        inside the timed region's closing fence."""
+        asynchronously: the host goes on, and the handle is finished (stream wait + sums back into the gradients) by
+        finish_gradients() in front of the NEXT backward pass -- where an optimiser step would read them -- never after
+        it: a later finish would put the previous step's sums over fresh gradients."""
         from flamo_amd import dist as fd
         pending.append(fd.all_reduce_grads(params, async_op=True))
-        while len(pending) > 1:                         # one collective in flight per parameter set (dist.all_reduce_grads)
-            pending.pop(0)()
 
     step = eager_step
     gs = None
@@ -537,25 +574,35 @@ def main():
 
         if gs is not None:
             def step():
+                finish_gradients()          # the previous step's sums are in place before the replay rewrites the gradients
                 loss = gs.replay()
                 if dist_on:
                     sync_gradients()
                 return loss
 
     def fence():
-        while pending:
-            pending.pop(0)()
+        finish_gradients()
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     # Set-up, before the W warm-up steps: the device is brought to its sustained state.  Right after the capture (host work,
-    # GPU idle) the first ~50 replays of this 0.4 ms step run 10-18 % slower than the rest (tools/dbg/replay_transient.py:
+    # GPU idle) the first ~50 replays of this 0.4 ms step run 10-18 % slower than the rest (tools/dbg/archive/replay_transient.py:
     # 0.44, 0.48, 0.46, 0.43, 0.42, 0.41, ... 0.40 ms per replay in blocks of five -- the power management's clock ramp, not
     # something the step does), and with W = 5 the K = 20 timed steps would sit in the middle of that ramp.  The local step
     # (no collective: every rank does this on its own) is repeated in blocks of ten until two consecutive blocks agree
     # within 1 %, at most 300 times (0.12 s); eager steps additionally include allocator growth and first-launch costs.
     local_step = (lambda: gs.replay()) if gs is not None else (lambda: eager_step(False))
+    # the figure measured the way rounds 1-2 measured it (three replays + W warm-ups behind the capture, then K timed): kept in
+    # the line so that rounds stay comparable -- `value` is taken after the device has settled
+    for _ in range(3 + args.warmup):
+        local_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        local_step()
+    torch.cuda.synchronize()
+    ms_unsettled = (time.perf_counter() - t0) / args.steps * 1e3
     settle = settle_device(local_step)
     for _ in range(args.warmup):
         step()
@@ -565,10 +612,22 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    # the same step over >= 50 more iterations (SURVEY 8-d1's count), every rank: box-to-box and run-to-run noise of a timed
+    # region of K x 0.4 ms shows as the difference between the two
+    n_steady = max(50, args.steps)
+    t0 = time.perf_counter()
+    for _ in range(n_steady):
+        step()
+    fence()
+    elapsed_steady = time.perf_counter() - t0
+    ranks_seen = 1
     if dist_on:                     # max over ranks; before rank 0 goes on alone into the roofline leg
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_steady], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        elapsed, elapsed_steady = t.tolist()
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)       # how many ranks RCCL actually carried
+        ranks_seen = int(ones.item())
 
     # ---- bin-sharded forms: every rank takes part (collectives), before rank 0 goes on alone
     sharded = None
@@ -595,12 +654,26 @@ def main():
         # (profiles/).  The copies also flush the 256 MB infinity cache, so these launch times are cache-cold: up to
         # ~5 % above the replayed ones in the rocprofv3 trace.
         roof_steps = min(args.steps, 10)
-        ops.kernel_timer.reset(enabled=True, prefill_cycles=500_000)
-        for _ in range(roof_steps):
+        # (a) IN-STEP: ~2.5 ms of copies queued once in front of each eager step, no prefill per launch -- the host stays ahead
+        # of the GPU for the whole step, so every kernel runs directly behind its real predecessor, as in the replay.  These are
+        # the figures `roofline` and `kernels` carry; the rocprofv3 averages of the replayed step (profiles/) must agree.
+        ops.kernel_timer.reset(enabled=True, prefill_cycles=0)
+        for i in range(roof_steps + 2):
+            if i == 2:                           # two unrecorded steps first (allocator, clocks)
+                torch.cuda.synchronize()
+                ops.kernel_timer.records = {}
+            ops.kernel_timer.begin_step(2.5)
             eager_step(sync_grads=False)        # rank 0 only: no collective in here
         torch.cuda.synchronize()
         ops.kernel_timer.enabled = False
         timers = ops.kernel_timer.summary()
+        # (b) COLD: every timed launch behind its own ~0.2 ms of cache-flushing copies (round 1-3's eager leg)
+        ops.kernel_timer.reset(enabled=True, prefill_cycles=500_000)
+        for _ in range(roof_steps):
+            eager_step(sync_grads=False)
+        torch.cuda.synchronize()
+        ops.kernel_timer.enabled = False
+        timers_cold = ops.kernel_timer.summary()
         sig = esz * BATCH * M * NCH            # one (B, M, N) complex spectrum / scratch array, or a (B, T, N) real signal
         hb = esz * M * NCH * NCH
         alg = {   # algorithmic HBM bytes per launch
@@ -655,27 +728,25 @@ def main():
                     "algorithmic_bytes": alg[key], "launch_ms": mean_ms, "launches": n,
                     "layered_route_bytes": layered if fused else None,
                     "layered_route_equivalent_GBs": (layered / (mean_ms * 1e-3) / 1e9) if fused else None,
-                    "events": f"HIP events on the launch stream, {roof_steps} eager steps run by this command right after the timed graph "
-                              "replays, each timed launch queued behind ~0.2 ms of streaming copies (busy queue, cold infinity cache)",
+                    "events": f"HIP events on the launch stream around this kernel inside {roof_steps} eager steps run by this command right "
+                              "after the timed graph replays; each STEP (not each launch) is queued behind ~2.5 ms of copies, so its "
+                              "kernels run back to back, this one directly behind the input's column pass with the caches as that "
+                              "pass left them -- the in-step launch time (events cannot be recorded inside a captured graph on ROCm)",
                     "traffic_source": (traffic or {}).get("source", "no PMC profile committed for this kernel yet"),
                     "traffic_profile_commit": (traffic or {}).get("commit")}
             # the same kernel inside the REPLAYED step, from the committed rocprofv3 --kernel-trace --stats run of this command
             # (events cannot be recorded inside a captured graph on ROCm; the eager leg above starts every launch behind
             # cache-flushing copies and reads ~10 % longer)
+            if key in timers_cold:
+                nc, msc = timers_cold[key]
+                roof["cold_leg"] = {"launch_ms": msc, "frac": alg[key] / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches": nc,
+                                    "events": "every timed launch queued behind its own ~0.2 ms of cache-flushing copies"}
             if walk:
                 sus = sustained_walk_launch_ms(dev)
-                if sus:
-                    # the figures of the line are the sustained ones, like `value`; the eager leg's stay beside them
-                    roof["eager_leg"] = {"launch_ms": roof["launch_ms"], "achieved": roof["achieved"], "frac": roof["frac"],
-                                         "launches": roof["launches"], "events": roof["events"]}
-                    roof["launch_ms"] = sus
-                    roof["achieved"] = alg[key] / (sus * 1e-3) / 1e9
-                    roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
-                    roof["launches"] = 30
-                    roof["layered_route_equivalent_GBs"] = layered / (sus * 1e-3) / 1e9
-                    roof["events"] = ("HIP events on the launch stream around 30 launches of the kernel back to back on the step's operand "
-                                      "shapes (after 10 more), run by this command after the timed region: the device in the sustained "
-                                      "state `value` is measured in; 319 MB per launch against 256 MB of infinity cache")
+                if sus:     # side figure only (synthetic): the kernel alone, back to back -- NOT what `frac` is computed from
+                    roof["isolated_back_to_back"] = {
+                        "launch_ms": sus, "frac": alg[key] / (sus * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches": 30,
+                        "events": "HIP events around 30 launches of the kernel alone, back to back, on the step's operand shapes"}
             prof_us = (traffic or {}).get(key if fused else "mimo_full", {}).get("rocprofv3_avg_launch_us")
             if prof_us:
                 roof["replayed_launch_ms_rocprofv3"] = prof_us * 1e-3
@@ -692,6 +763,11 @@ def main():
                                                "blocks agree within 1 % (the device's clock ramp: the first ~50 replays run 10-18 % "
                                                "slower); then the W warm-up steps, then the K timed steps",
                                        **settle},
+               "ms_per_step_steady": {"ms_per_step": elapsed_steady / n_steady * 1e3, "steps": n_steady,
+                                      "what": "the same step over this many more iterations right after the timed region"},
+               "ms_per_step_unsettled": {"ms_per_step": ms_unsettled, "what": "rounds 1-2's method: 3 replays + W warm-ups right "
+                                         "behind the capture, then K timed (inside the device's clock ramp); local step, rank 0"},
+               "rccl_ranks_seen": ranks_seen if dist_on else None,
                "config": {"workload": "BASELINE configs[1]: Shell(FFT -> Series(Matrix 8x8, GEQ 8x8) -> iFFT), nfft=96000, "
                                       "batch 32 per GPU, fwd+bwd of (y**2).mean(), parameter grads",
                           "nfft": NFFT, "channels": NCH, "batch_per_gpu": BATCH, "parallelism": f"dp{world} (batch)",
@@ -709,6 +785,10 @@ def main():
         if not args.no_extras and dtype == torch.float32:
             try:
                 out["input_grad"] = input_grad_leg(model, params, x, args.steps, products_per_step // world)
+                # SURVEY 8-d1 counts the input's gradient too: the d1-conforming figure at top level, beside `value`
+                if world == 1:
+                    out["value_with_input_grad"] = out["input_grad"]["products_per_s"]
+                    out["ms_per_step_with_input_grad"] = out["input_grad"]["ms_per_step"]
             except Exception as e:  # noqa: BLE001
                 out["input_grad"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             try:

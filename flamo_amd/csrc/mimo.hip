@@ -631,7 +631,7 @@ static int gradh_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
         }
     }
     // Larger register tiles read G and X once per bin instead of once per 4x4 tile (config 2: 326 -> 221 MB of fabric
-    // traffic per launch) -- and measure SLOWER: 4x4 65 us, 8x4 68 us, 8x8 88 us (tools/dbg/gradh_tile.py, cold caches):
+    // traffic per launch) -- and measure SLOWER: 4x4 65 us, 8x4 68 us, 8x8 88 us (tools/dbg/archive/gradh_tile.py, cold caches):
     // the second read of a 4x4 tile comes from the L2, while 64 / 128 accumulator registers cost occupancy.  Kept
     // behind the tuning hook.
     if (sizeof(T) == 4 && No >= 8 && Ni >= 8 && g_gradh_tile != 4) {

@@ -681,7 +681,7 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
         if constexpr (NMAX == 16) {
             // N in (8, 16], factored loop: 8 lanes x 2 rows per lane -- 8 bins per wavefront, every broadcast of a pivot-row
             // element feeds two row updates: 86 -> 73 us at N = 16 (c64), 131 -> 108 us (c128), 82 -> 63 us at N = 9
-            // (tools/dbg/solve_rpl2_16.py; 4 lanes x 4 rows: 80 us, and it spills).  fl_debug_set_solve_variant(4): the
+            // (tools/dbg/archive/solve_rpl2_16.py; 4 lanes x 4 rows: 80 us, and it spills).  fl_debug_set_solve_variant(4): the
             // one-row-per-lane kernels.
             if (!P && g_solve_rpl2_16 != 1) {
                 hipLaunchKernelGGL((solve_inplace_kernel<T, 8, 2>), dim3(cdiv_i(M, 32)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,

@@ -20,6 +20,8 @@ rather than bucketing.
 """
 from __future__ import annotations
 
+import os
+import warnings
 from contextlib import contextmanager
 from typing import Iterable, Optional, Tuple
 
@@ -50,6 +52,49 @@ def bin_shard(nfft: int, rank: Optional[int] = None, world: Optional[int] = None
         ops.set_bin_shard(0, None)
 
 
+# ----------------------------------------------------------------------------- all-gather algorithm
+# "rccl":   one all_gather_into_tensor; RCCL picks the algorithm (ring / direct by message size and topology).
+# "direct": the full-mesh form of SURVEY 8-e1 -- every rank posts world-1 peer sends and world-1 peer receives at once
+#           (torch.distributed.batch_isend_irecv = one RCCL group call), so its slice leaves on all 7 xGMI links
+#           concurrently instead of travelling a ring that is bound by one link.  The payloads here are small (config 5:
+#           6 MB per rank), where the ring's world-1 hops of latency are what it costs.
+# Selected by FLAMO_ALLGATHER or set_all_gather_algorithm(); results are identical (data movement only).
+_AG_ALGOS = ("rccl", "direct")
+_ag_algo = os.environ.get("FLAMO_ALLGATHER", "rccl").lower()
+if _ag_algo not in _AG_ALGOS:
+    raise ValueError(f"FLAMO_ALLGATHER={_ag_algo!r}: expected one of {_AG_ALGOS}")
+
+
+def set_all_gather_algorithm(name: str) -> str:
+    """Choose how all_gather_bins moves the shards ("rccl" | "direct"); returns the previous choice."""
+    global _ag_algo
+    if name not in _AG_ALGOS:
+        raise ValueError(f"all-gather algorithm {name!r}: expected one of {_AG_ALGOS}")
+    prev, _ag_algo = _ag_algo, name
+    return prev
+
+
+def get_all_gather_algorithm() -> str:
+    return _ag_algo
+
+
+def _gather_blocks(buf: torch.Tensor, world: int, rank: int, group) -> torch.Tensor:
+    """(world, *buf.shape): block q = rank q's buf.  Equal shapes on every rank."""
+    out = torch.empty((world, *buf.shape), dtype=buf.dtype, device=buf.device)
+    if _ag_algo == "direct" and world > 1:
+        out[rank].copy_(buf)
+        p2p = []
+        for d in range(1, world):
+            to, frm = (rank + d) % world, (rank - d) % world
+            p2p.append(dist.P2POp(dist.isend, buf, dist.get_global_rank(group, to) if group is not None else to, group))
+            p2p.append(dist.P2POp(dist.irecv, out[frm], dist.get_global_rank(group, frm) if group is not None else frm, group))
+        for w in dist.batch_isend_irecv(p2p):
+            w.wait()
+    else:
+        dist.all_gather_into_tensor(out.view(world * buf.shape[0], *buf.shape[1:]), buf, group=group)
+    return out
+
+
 def _host_staged(t: torch.Tensor, group) -> bool:
     """gloo moves host memory: device tensors are staged through the host (ranks sharing one GPU on a
     test rig; RCCL refuses two ranks on one device).  Transport only -- no arithmetic moves to the CPU."""
@@ -77,13 +122,9 @@ class _AllGatherBins(torch.autograd.Function):
         cplx = send.is_complex()
         buf = torch.view_as_real(send) if cplx else send
         if _host_staged(buf, group):
-            parts = [torch.empty(buf.shape, dtype=buf.dtype) for _ in range(world)]
-            dist.all_gather(parts, buf.cpu(), group=group)
-            out = torch.stack(parts).to(buf.device)
+            out = _gather_blocks(buf.cpu(), world, rank, group).to(buf.device)
         else:
-            out = torch.empty((world * buf.shape[0], *buf.shape[1:]), dtype=buf.dtype, device=buf.device)
-            dist.all_gather_into_tensor(out, buf, group=group)     # concatenated along dim 0
-        out = out.view(world, *buf.shape)
+            out = _gather_blocks(buf, world, rank, group)
         if cplx:
             out = torch.view_as_complex(out)
         # (world, B, rest..., per) -> (B, rest..., world*per) -> trim -> logical (B, M, rest...)
@@ -114,8 +155,10 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
     """Sum the gradients of replicated parameters over ranks with ONE flat all-reduce per dtype, through a flat
     buffer that is allocated once per parameter set (no cat / cast / per-parameter temporaries per step): the gradients
     are copied into views of the buffer (one multi-tensor copy), reduced in place, and copied back.
-    async_op: returns a callable that waits for the collective and copies the sums back (call it before the
-    gradients are read); None otherwise."""
+    async_op: returns a callable that waits for the collective and copies the sums back -- call it before the
+    gradients are read AND before the next backward pass (or graph replay) rewrites them: a handle that is still
+    open when the same parameters are reduced again is waited for and its sums are dropped, with a warning.
+    None otherwise."""
     ps = [p for p in params if p.grad is not None]
     if not ps:
         return (lambda: None) if async_op else None
@@ -136,9 +179,14 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
         flat, views, outstanding = ent
         if outstanding is not None:
             # an earlier asynchronous call on this buffer has not been finished: its collective may still be reading and
-            # writing the buffer this call is about to refill.  Finish it first (sums back into ITS gradients) -- at most
-            # one collective per parameter set is ever in flight.
-            outstanding()
+            # writing the buffer this call is about to refill.  Wait for it -- at most one collective per parameter set is
+            # ever in flight -- but do NOT copy its sums back: the gradients have been rewritten since (that is why a new
+            # reduction is being asked for), and the stale sums would replace them and be reduced again.  The caller broke
+            # the contract (finish before the next backward); its earlier handle becomes a no-op.
+            warnings.warn("all_reduce_grads: the previous asynchronous reduction of these parameters was never finished; "
+                          "its sums are discarded (call the returned handle before the next backward pass)", RuntimeWarning,
+                          stacklevel=2)
+            outstanding(copy_back=False)
         grads = [p.grad.reshape(-1) for p in plist]
         torch._foreach_copy_(views, grads)
         if _host_staged(flat, group):
@@ -152,7 +200,7 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
 
     done = [False]
 
-    def finish():
+    def finish(copy_back: bool = True):
         if done[0]:
             return
         done[0] = True
@@ -161,8 +209,12 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
                 ent[2] = None
             if work is not None:
                 work.wait()
+            if not copy_back:
+                continue
             dst, src = [], []
             for p, v in zip(plist, views):
+                if p.grad is None:          # cleared since the call: nothing to hand the sum to
+                    continue
                 if p.grad.is_contiguous():
                     dst.append(p.grad.view(-1))
                     src.append(v)

@@ -21,15 +21,21 @@ import torch
 
 class GraphedStep:
     def __init__(self, fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor],
-                 params: Iterable[torch.nn.Parameter] = (), warmup: int = 3):
+                 params: Iterable[torch.nn.Parameter] = (), warmup: int = 3,
+                 allow_graph_packets: bool = False):
         import flamo_amd
         if not flamo_amd._graph_packets_off():
+            # refused, not warned about: with ROCm's pre-built graph packets a captured torch reduction behind this library's
+            # kernels has returned wrong -- deterministic, plausible -- values after eager launches between replays (DESIGN.md
+            # section 4.5).  A training loop would go on silently with a wrong loss.
+            msg = ("flamo_amd.graph.GraphedStep: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is not in effect (flamo_amd was imported after "
+                   "the HIP runtime had been initialised, or the variable is set to something else).  Export "
+                   "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before starting the process, or import flamo_amd before the first "
+                   "torch.cuda call.")
+            if not allow_graph_packets:
+                raise RuntimeError(msg + "  (GraphedStep(..., allow_graph_packets=True) captures anyway.)")
             import warnings
-            warnings.warn("flamo_amd was imported after the HIP runtime had been initialised (or DEBUG_CLR_GRAPH_PACKET_CAPTURE is "
-                          "set to something other than 0): with ROCm's pre-built graph packets, torch reductions captured behind "
-                          "this library's kernels have returned wrong values after eager launches between replays "
-                          "(DESIGN.md, section 4.5).  Export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before starting the process.",
-                          RuntimeWarning, stacklevel=2)
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
         self.params = [p for p in params if p.requires_grad]
         self.static_inputs = [t.clone() for t in example_inputs]
         self._fn = fn

@@ -113,7 +113,7 @@ def twiddles(nfft: int, real: torch.dtype, device: torch.device) -> torch.Tensor
                     # the event, and a consumer on a capturing stream waited for it: that records, inside the graph, a wait
                     # on an event that lives OUTSIDE it -- and with ROCm 7.2's pre-built graph packets the torch nodes that
                     # follow in the graph (the memset + reduction pair of a captured sum() / max()) then return wrong
-                    # values after any eager launch between two replays.  tools/dbg/replay_min.py: the hazard of DESIGN
+                    # values after any eager launch between two replays.  tools/dbg/archive/replay_min.py: the hazard of DESIGN
                     # 4.5 reproduced with exactly the producers that went through that wait, and with no others.
                     ev.synchronize()
                     ev = None
@@ -221,6 +221,20 @@ class KernelTimer:
         self.enabled = False
         self.records = {}
         self.prefill_cycles = 0
+
+    def begin_step(self, prefill_ms: float = 2.0):
+        """In-step mode: queue ~prefill_ms of streaming copies ONCE, in front of a whole eager step whose launches are
+        then timed with prefill_cycles = 0.  The host runs ahead of the GPU for the whole step, so its kernels execute
+        back to back on the stream -- each behind its real predecessor, with the caches in the state that predecessor
+        left -- as they do in a replayed graph (where events cannot be recorded on ROCm); the event pairs add only
+        their own record packets between two kernels."""
+        if not self.enabled:
+            return
+        keep, self.prefill_cycles = self.prefill_cycles, int(prefill_ms * 1e3 / 35.0) * 100_000
+        try:
+            self._prefill()
+        finally:
+            self.prefill_cycles = keep
 
     def reset(self, enabled: bool, prefill_cycles: int = 0):
         """prefill_cycles > 0: about prefill_cycles / 100k streaming copies of 96 MB (~35 us each) are
@@ -559,11 +573,125 @@ def env_log2_of(alias_decay_db: float, nfft: int) -> float:
     return abs(float(alias_decay_db)) / (20.0 * nfft) * math.log2(10.0)
 
 
+# ----------------------------------------------------------------------------- any transform length (chirp-z route)
+# The Stockham kernels take even lengths whose half is 13-smooth (fl_fft_plan).  The reference hands ANY nfft to
+# torch.fft.rfft / irfft (dsp.py:84-89, 110-115): odd lengths, or lengths with a large prime factor (34 = 2 17,
+# 2176 = 2^7 17, 95999).  Those go through Bluestein's identity  k t = (k^2 + t^2 - (k - t)^2) / 2,
+#     X[k] = c[k] sum_t (x[t] c[t]) conj(c[k - t]),      c[t] = exp(-i pi t^2 / n),
+# i.e. a circular convolution of length P >= 2n - 1 with the chirp, P a length the kernels DO take: two real transforms
+# of length P (real and imaginary part of x c), one real-coefficient mix per bin with the chirp filter's spectrum -- the
+# chirp is even in t, so its spectrum p + i q is even too and the product A B splits into the two Hermitian halves
+#     Ce = R p - I q,   Co = R q + I p          (R, I = rfft of Re / Im of x c)
+# whose inverse real transforms are the real and imaginary part of the convolution -- and two inverse real transforms,
+# all on the library's own rfft / irfft kernels; what is left in torch is elementwise.  ~8x the work of a direct transform
+# of that length: a route for lengths nobody tunes for, on the layered path only (the fused Shell pipeline plans 13-smooth
+# lengths, fl_spec_plan).  Differentiable by construction (linear ops composed of differentiable pieces).
+_fft_plan_ok_cache = {}
+_bluestein_cache = {}
+
+
+def fft_plan_ok(nfft: int, real: torch.dtype) -> bool:
+    """Do the Stockham kernels take this length directly?"""
+    key = (int(nfft), real == torch.float64)
+    ok = _fft_plan_ok_cache.get(key)
+    if ok is None:
+        import ctypes
+        l1, l2 = ctypes.c_int(0), ctypes.c_int(0)
+        ok = _fft_plan_ok_cache[key] = nfft >= 2 and _lib.lib().fl_fft_plan(int(nfft), int(key[1]), ctypes.byref(l1), ctypes.byref(l2)) == 0
+    return ok
+
+
+def _bluestein_setup(n: int, real: torch.dtype, dev: torch.device):
+    key = (n, real, dev.index if dev.index is not None else torch.cuda.current_device())
+    ent = _bluestein_cache.get(key)
+    if ent is None:
+        P = 2 * n - 1 + ((2 * n - 1) & 1)              # even candidates upwards; the filter's spectrum is formed in double
+        while not (fft_plan_ok(P, torch.float32) and fft_plan_ok(P, torch.float64)):
+            P += 2
+        # chirp phases from t^2 mod 2n in integers: exact arguments at any length
+        t = torch.arange(n, dtype=torch.int64)
+        ang = (t * t % (2 * n)).to(torch.float64) * (math.pi / n)
+        c = torch.complex(torch.cos(ang), -torch.sin(ang))                     # exp(-i pi t^2 / n)
+        b = torch.zeros(P, dtype=torch.complex128)                              # conj(c) on lags -(n-1) .. n-1, circular
+        b[:n] = c.conj()
+        if n > 1:
+            b[P - n + 1:] = c[1:].flip(0).conj()
+        bd = b.to(dev)
+        cplx = _cdtype(real)
+        # spectrum of the (even) chirp filter through the library's own transform: p + i q, both real
+        pq = _Rfft.apply(torch.stack([bd.real, bd.imag], dim=-1).view(1, P, 2), P, 1.0, 0.0)            # (1, P/2+1, 2), float64
+        p_, q_ = pq[0, :, 0].real.to(real).contiguous(), pq[0, :, 1].real.to(real).contiguous()
+        ent = _bluestein_cache[key] = (P, c.to(dev).to(cplx), p_, q_)
+    return ent
+
+
+def _chirp_convolve(a: torch.Tensor, P: int, p_: torch.Tensor, q_: torch.Tensor, t_out: int, conj_filter: bool) -> torch.Tensor:
+    """sum_t a[t] conj(c[k - t]) (conj_filter: c[k - t]) for k < t_out; a complex (B, T, rest...), T <= P."""
+    real = _rdtype(a)
+    sh = (1, -1) + (1,) * (a.dim() - 2)
+    ri = torch.stack([a.real, a.imag], dim=-1)                                 # one launch for both parts
+    RI = _Rfft.apply(ri, P, 1.0, 0.0)                                          # (B, P/2+1, rest..., 2)
+    R, I_ = RI[..., 0], RI[..., 1]
+    pp, qq = p_.view(sh), (-q_ if conj_filter else q_).view(sh)
+    C = torch.stack([R * pp - I_ * qq, R * qq + I_ * pp], dim=-1)
+    y = _Irfft.apply(C, P, 1.0 / P, 0.0)[:, :t_out]                             # (B, t_out, rest..., 2) real
+    return torch.complex(y[..., 0], y[..., 1])
+
+
+def _envelope(nfft: int, env_log2: float, real: torch.dtype, dev: torch.device, ndim: int) -> torch.Tensor:
+    e = torch.exp2(torch.arange(nfft, dtype=torch.float64, device=dev) * env_log2).to(real)
+    return e.view((1, -1) + (1,) * (ndim - 2))
+
+
+def _rfft_chirp(x: torch.Tensor, nfft: int, scale: float, env_log2: float) -> torch.Tensor:
+    real, dev, M = _rdtype(x), x.device, nfft // 2 + 1
+    if nfft == 1:
+        return (x[:, :1] * scale).to(_cdtype(real))
+    P, c, p_, q_ = _bluestein_setup(nfft, real, dev)
+    x = x[:, :nfft]
+    T = x.shape[1]
+    if env_log2:
+        x = x * _envelope(nfft, env_log2, real, dev, x.dim())[:, :T]
+    sh = (1, -1) + (1,) * (x.dim() - 2)
+    conv = _chirp_convolve(x * c[:T].view(sh), P, p_, q_, M, False)
+    return conv * (c[:M] * scale).view(sh)
+
+
+def _irfft_chirp(X: torch.Tensor, nfft: int, scale: float, env_log2: float) -> torch.Tensor:
+    real, dev, M = _rdtype(X), X.device, nfft // 2 + 1
+    if X.shape[1] != M:
+        raise ValueError(f"irfft: expected {M} bins along dim 1, got {X.shape[1]}")
+    if nfft == 1:
+        return X.real * scale
+    P, c, p_, q_ = _bluestein_setup(nfft, real, dev)
+    sh = (1, -1) + (1,) * (X.dim() - 2)
+    # y[t] = scale Re sum_{k < M} w_k X'[k] exp(+2 pi i k t / n): interior bins twice, the imaginary parts of bin 0 (and of
+    # the Nyquist bin of an even length) ignored, as torch.fft.irfft does
+    w = torch.full((M,), 2.0, dtype=real, device=dev)
+    w[0] = 1.0
+    edge = [0] + ([M - 1] if nfft % 2 == 0 else [])
+    if nfft % 2 == 0:
+        w[M - 1] = 1.0
+    mask = torch.ones(M, dtype=real, device=dev)
+    mask[edge] = 0.0
+    U = torch.complex(X.real, X.imag * mask.view(sh)) * w.view(sh)
+    conv = _chirp_convolve(U * c[:M].conj().view(sh), P, p_, q_, nfft, True)
+    y = (conv * c.conj().view(sh)).real * scale
+    if env_log2:
+        y = y * _envelope(nfft, env_log2, real, dev, y.dim())
+    return y
+
+
 def rfft(x: torch.Tensor, nfft: int, norm: str = "backward", alias_decay_db: Optional[float] = None) -> torch.Tensor:
     """torch.fft.rfft(x [* gamma^-t], n=nfft, dim=1, norm=norm) on the HIP path."""
     if norm not in _NORM_FWD:
         raise ValueError(f"Invalid normalization mode: {norm}")
     env = 0.0 if not alias_decay_db else env_log2_of(alias_decay_db, nfft)
+    if not fft_plan_ok(int(nfft), _rdtype(x)):
+        _require_gpu(x)
+        if x.is_complex():
+            raise TypeError("rfft expects a real tensor")
+        return _rfft_chirp(x, int(nfft), _NORM_FWD[norm](nfft), env)
     return _Rfft.apply(x, int(nfft), _NORM_FWD[norm](nfft), env)
 
 
@@ -572,6 +700,11 @@ def irfft(X: torch.Tensor, nfft: int, norm: str = "backward", alias_decay_db: Op
     if norm not in _NORM_INV:
         raise ValueError(f"Invalid normalization mode: {norm}")
     env = 0.0 if not alias_decay_db else env_log2_of(alias_decay_db, nfft)
+    if not fft_plan_ok(int(nfft), _rdtype(X)):
+        _require_gpu(X)
+        if not X.is_complex():
+            raise TypeError("irfft expects a complex tensor")
+        return _irfft_chirp(X.resolve_conj(), int(nfft), _NORM_INV[norm](nfft), env)
     return _Irfft.apply(X, int(nfft), _NORM_INV[norm](nfft), env)
 
 
@@ -1480,7 +1613,7 @@ def delay_response(m_int: torch.Tensor, amp: torch.Tensor, nfft: int) -> torch.T
 # evaluation rounded once, about twice as fast) where that is safe for the gradients -- always for graphic-equaliser
 # sections (benign parameter map: gradient within 2e-7 of the double evaluation's), for raw section coefficients only
 # when no gradient is taken: the backward reuses the saved response and a parametric equaliser's map amplifies the extra
-# error to 1e-5 .. 1e-4 (tools/dbg/rc_fast_grad.py).  False = double everywhere.
+# error to 1e-5 .. 1e-4 (tools/dbg/archive/rc_fast_grad.py).  False = double everywhere.
 FLOAT_CASCADE_EVAL = True
 
 # float32 modules: mixed-precision backward of the cascade (see fl_sos_response_bwd_c64); False

@@ -43,3 +43,51 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def maxerr(a, b):
+    """max |a - b| / max |b|: the max-norm companion of relerr (which is l2-relative)."""
+    a = torch.as_tensor(a)
+    b = torch.as_tensor(b)
+    wide = torch.complex128 if b.is_complex() else torch.float64
+    num = (a.to(b.device) - b).to(wide).abs().max() if b.numel() else torch.tensor(0.0)
+    den = b.to(wide).abs().max() if b.numel() else torch.tensor(1.0)
+    return (num / den.clamp_min(1e-300)).item()
+
+
+# Errors ACHIEVED on an MI355X, recorded by `FLAMO_RECORD_ERRORS=<file> pytest -m gpu` and committed: a check that is allowed a
+# loose flat tolerance for a stated reason (the reference's float32 section buffers, dsp.py:2573-2585) still fails when its
+# error grows by more than `k` over what the committed kernels achieve -- a regression from 3e-6 to 5e-4 under a 1e-3 limit.
+_ACHIEVED_FILE = os.path.join(GOLDEN, "achieved_errors.json")
+try:
+    with open(_ACHIEVED_FILE) as _f:
+        ACHIEVED = json.load(_f)
+except (OSError, ValueError):
+    ACHIEVED = {}
+_RECORDED = {}
+
+
+def check_close(name, got, ref, tol, max_tol=None, k=5.0, floor=2e-7):
+    """l2-relative error < tol AND max-norm error < max_tol (default 10 tol), both printed; and, when `name` has a recorded
+    achieved error, l2 < k x that (at least `floor`: results are deterministic, the margin is for library / box differences)."""
+    l2, mx = relerr(got, ref), maxerr(got, ref)
+    _RECORDED[name] = {"l2": l2, "max": mx, "tol": tol}
+    print(f"[parity] {name}: l2 {l2:.3e}  max {mx:.3e}  (limit {tol:g})")
+    assert l2 < tol, (name, l2, tol)
+    assert mx < (10 * tol if max_tol is None else max_tol), (name, "max-norm", mx)
+    rec = ACHIEVED.get(name)
+    if rec is not None:
+        lim = max(k * rec["l2"], floor)
+        assert l2 < lim, (name, f"l2 error {l2:.3e} is more than {k:g}x the recorded achieved error {rec['l2']:.3e}")
+        limm = max(k * rec["max"], 10 * floor)
+        assert mx < limm, (name, f"max-norm error {mx:.3e} is more than {k:g}x the recorded achieved error {rec['max']:.3e}")
+    return l2
+
+
+def pytest_sessionfinish(session, exitstatus):
+    path = os.environ.get("FLAMO_RECORD_ERRORS")
+    if path and _RECORDED:
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(dict(sorted(_RECORDED.items())), f, indent=1)
+

@@ -127,3 +127,13 @@ def test_walk_partition_covers_every_unit_once():
         eq = max(cost(U * i // n_wg, U * (i + 1) // n_wg) for i in range(n_wg))
         assert got <= eq, (B, got, eq)
     assert L.fl_spec_walk_partition(12345, 4, 8, (ctypes.c_int * 9)()) != 0          # no plan for this length
+
+
+def test_graphed_step_refuses_without_the_graph_packet_switch(monkeypatch):
+    """GraphedStep raises (it used to warn) when DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 cannot be relied on: replayed reductions have
+    returned wrong values with ROCm's pre-built graph packets.  The check comes before anything touches the GPU."""
+    import flamo_amd
+    from flamo_amd.graph import GraphedStep
+    monkeypatch.setattr(flamo_amd, "_graph_packets_off", lambda: False)
+    with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
+        GraphedStep(lambda x: x.sum(), (torch.zeros(2),), ())

@@ -29,6 +29,11 @@ def _worker(rank, world, port, M, results):
         assert local.shape[1] == m_local
         gathered = fd.all_gather_bins(local, M)
         ok_fwd = torch.equal(gathered, full)                  # data movement only: bit exact
+        prev = fd.set_all_gather_algorithm("direct")          # full-mesh peer sends: the same bits
+        try:
+            ok_fwd = ok_fwd and torch.equal(fd.all_gather_bins(local, M), full)
+        finally:
+            fd.set_all_gather_algorithm(prev)
         w = torch.randn(3, M, 4, 2, dtype=torch.complex128)
         loss = torch.sum(torch.real(gathered * torch.conj(w)))
         (g,) = torch.autograd.grad(loss, [local])
@@ -65,6 +70,16 @@ def _worker(rank, world, port, M, results):
             fin = fd.all_reduce_grads([p], async_op=True)
             fin()
             ok_red = ok_red and torch.allclose(p.grad, torch.full((5,), float(sum(r + 1 + rep for r in range(world)))))
+        # a handle left open across a "backward" is waited for, its stale sums are NOT written over the fresh gradients
+        import warnings
+        p.grad = torch.full((5,), 100.0)
+        fd.all_reduce_grads([p], async_op=True)               # never finished
+        p.grad = torch.full((5,), float(rank + 1))            # the next backward pass
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            fd.all_reduce_grads([p])
+        ok_red = ok_red and torch.allclose(p.grad, torch.full((5,), float(sum(range(1, world + 1))))) and \
+            any("never finished" in str(w.message) for w in wlist)
         results[rank] = bool(ok_fwd and ok_bwd and ok_red and ok_ctx and ok_x and torch.equal(rl, full.real))
     finally:
         dist.destroy_process_group()

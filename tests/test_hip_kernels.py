@@ -869,12 +869,12 @@ def test_replayed_step_is_stable_under_eager_launches(gpu):
     """A captured step (Shell(FFT -> Gain(16,1) -> Gain(1,16) -> iFFTAntiAlias), torch's own `sum` as the loss) replayed with a
     tiny eager tensor created and filled between replays: loss and gradients stay bit-identical.  With ROCm's pre-built graph
     packets the captured memset + reduction pair of `sum()` returned a different value after the first eager launch
-    (flamo_amd/__init__.py turns DEBUG_CLR_GRAPH_PACKET_CAPTURE off for that reason; tools/dbg/soak_ops.py, soak_fdn15.py)."""
+    (flamo_amd/__init__.py turns DEBUG_CLR_GRAPH_PACKET_CAPTURE off for that reason; tools/dbg/archive/soak_ops.py, soak_fdn15.py)."""
     import os
     from collections import OrderedDict
     from flamo_amd.graph import GraphedStep
     from flamo_amd.processor import dsp, system
-    # (the hazard is the platform's: tools/dbg/replay_min.py reproduces it with torch kernels alone -- MB-sized temporaries
+    # (the hazard is the platform's: tools/dbg/archive/replay_min.py reproduces it with torch kernels alone -- MB-sized temporaries
     # allocated inside the capture in front of a captured sum() -- and with no kernel of this library in the graph)
     assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
     torch.manual_seed(1)

@@ -15,7 +15,7 @@ from collections import OrderedDict
 import pytest
 import torch
 
-from conftest import load_golden, relerr
+from conftest import check_close, load_golden, relerr
 
 F64 = torch.float64
 
@@ -249,9 +249,9 @@ def test_config2_bench_size_batch32_against_oracle(gpu):
     model, mat, geq = _config2_model(dsp, system, nfft, 0.0, W, G, gpu, torch.float32, False)
     y = model(x.to(gpu, torch.float32))
     g = torch.autograd.grad(ops.mean_square(y), [mat.param, geq.param])
-    assert relerr(y.detach().cpu(), yref.detach()) < 1e-5
-    assert relerr(g[0].cpu(), gref[0]) < 1e-5
-    assert relerr(g[1].cpu(), gref[1]) < 1e-4
+    check_close("config2_bench_b32/y", y.detach().cpu(), yref.detach(), 1e-5)
+    check_close("config2_bench_b32/gW", g[0].cpu(), gref[0], 1e-5)
+    check_close("config2_bench_b32/gG", g[1].cpu(), gref[1], 1e-4)
 
 
 def _config5(dsp, system, N, nfft, db, a, dev, dt, max_len):
@@ -283,9 +283,9 @@ def test_config5_miniature_all_gradients_against_reference(gpu):
         x = a["x"].to(gpu, dt).requires_grad_(True)
         y = model(x)
         g = torch.autograd.grad(torch.sum(y * a["c"].to(gpu, dt)), [x] + plist)
-        assert relerr(y.detach().cpu(), _d(a["y"])) < tol, dt
-        for gi, k in zip(g, ("gx", "g_geq", "g_gain", "g_U")):
-            assert relerr(gi.cpu(), _d(a[k])) < (1e-3 if k == "g_geq" else 5 * tol), (dt, k)   # g_geq: float32 buffers in the reference
+        check_close(f"config5_mini/{str(dt)[6:]}/y", y.detach().cpu(), _d(a["y"]), tol)
+        for gi, k in zip(g, ("gx", "g_geq", "g_gain", "g_U")):     # g_geq: float32 buffers in the reference; recorded bound on top
+            check_close(f"config5_mini/{str(dt)[6:]}/{k}", gi.cpu(), _d(a[k]), 1e-3 if k == "g_geq" else 5 * tol)
 
 
 @gpu_only
@@ -316,10 +316,10 @@ def test_config5_chain_all_gradients_against_oracle(gpu):
         xg = x.to(gpu, dt).requires_grad_(True)
         y = model(xg)
         g = torch.autograd.grad(torch.sum(y * c.to(gpu, dt)), [xg] + plist)
-        assert relerr(y.detach().cpu(), yref.detach()) < tol, dt
+        check_close(f"config5_chain_9600/{str(dt)[6:]}/y", y.detach().cpu(), yref.detach(), tol)
         for gi, gr, k in zip(g, gref, ("gx", "g_geq", "g_gain", "g_U")):
-            lim = 1e-3 if k == "g_geq" else 3 * tol      # the GEQ gain gradient passes through float32 section buffers (reference and oracle)
-            assert relerr(gi.cpu(), gr) < lim, (dt, k, relerr(gi.cpu(), gr))
+            # the GEQ gain gradient passes through float32 section buffers (reference and oracle): flat limit + recorded bound
+            check_close(f"config5_chain_9600/{str(dt)[6:]}/{k}", gi.cpu(), gr, 1e-3 if k == "g_geq" else 3 * tol)
 
 
 @gpu_only
@@ -344,9 +344,9 @@ def test_fdn16_full_size_all_gradients_against_oracle(gpu):
     model, plist = _fdn(dsp, system, meta, a, gpu, torch.float32)
     y = model(x.to(gpu, torch.float32))
     g = torch.autograd.grad(torch.sum(y * c.to(gpu, torch.float32)), plist)
-    assert relerr(y.detach().cpu(), yref.detach()) < 1e-5
+    check_close("fdn16_full/y", y.detach().cpu(), yref.detach(), 1e-5)
     for gi, gr, k in zip(g, gref, keys):
-        assert relerr(gi.cpu(), gr) < 1e-5, k
+        check_close(f"fdn16_full/g_{k}", gi.cpu(), gr, 1e-5)
 
 
 @gpu_only

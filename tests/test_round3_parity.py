@@ -11,7 +11,7 @@ from collections import OrderedDict
 import pytest
 import torch
 
-from conftest import relerr
+from conftest import check_close, relerr
 
 gpu_only = pytest.mark.gpu
 F64 = torch.float64
@@ -50,10 +50,11 @@ def test_fdn16_with_attenuation_full_size_all_gradients(gpu):
     model = system.Shell(core, dsp.FFT(nfft, dtype=dt), dsp.iFFTAntiAlias(nfft, alias_decay_db=db, device=gpu, dtype=dt))
     y = model(x.to(gpu, dt))
     g = torch.autograd.grad(torch.sum(y * c.to(gpu, dt)), [ig.param, og.param, mix.param, att.param])
-    assert relerr(y.detach().cpu(), yref.detach()) < 1e-5
+    check_close("fdn16_attn_full/y", y.detach().cpu(), yref.detach(), 1e-5)
     for gi, gr, k in zip(g, gref, keys):
-        lim = 1e-3 if k == "attn_param" else 1e-5        # equaliser gains: float32 section buffers in the reference (and the oracle)
-        assert relerr(gi.cpu(), gr) < lim, (k, relerr(gi.cpu(), gr))
+        # equaliser gains: float32 section buffers in the reference (and the oracle) -- a flat 1e-3, and the recorded achieved
+        # error (tests/golden/achieved_errors.json) times five on top of it
+        check_close(f"fdn16_attn_full/g_{k}", gi.cpu(), gr, 1e-3 if k == "attn_param" else 1e-5)
 
 
 @gpu_only
@@ -140,10 +141,10 @@ def test_config5_core_full_size_on_sampled_bins(gpu):
     assert Y.shape == (1, M, N)
     Ysel = Y[:, bins.to(gpu)]
     g = torch.autograd.grad(torch.sum(torch.real(Ysel * torch.conj(C.to(gpu, torch.complex64)))), [geq.param, gain.param, mix.param])
-    assert relerr(Ysel.detach().cpu(), Yref.detach()) < 1e-5
+    check_close("config5_core_full/Ysel", Ysel.detach().cpu(), Yref.detach(), 1e-5)
     for gi, gr, k in zip(g, gref, ("g_geq", "g_gain", "g_U")):
-        lim = 1e-3 if k == "g_geq" else 3e-5             # equaliser gains: float32 section buffers in the reference (and the oracle)
-        assert relerr(gi.cpu(), gr) < lim, (k, relerr(gi.cpu(), gr))
+        # equaliser gains: float32 section buffers in the reference (and the oracle); see check_close for the recorded bound
+        check_close(f"config5_core_full/{k}", gi.cpu(), gr, 1e-3 if k == "g_geq" else 3e-5)
 
 
 @gpu_only

@@ -1,0 +1,92 @@
+"""Round 4: transform lengths the Stockham kernels do not take (chirp-z route, dsp.py:84-89 hands ANY nfft to torch.fft),
+fused-pipeline plans derived from the factorisation, batch-walking kernels beyond the benchmark's shape."""
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from conftest import check_close, relerr
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+TOL = {torch.float64: 1e-10, torch.float32: 1e-5}
+CD = {torch.float64: torch.complex128, torch.float32: torch.complex64}
+
+
+@pytest.fixture(params=[torch.float64, torch.float32], ids=["f64", "f32"])
+def dt(request):
+    return request.param
+
+
+# 34 = 2 17, 2176 = 2^7 17 (a prime factor > 13), 95999 (odd, = 17 5647), small odd lengths, a prime, and lengths the
+# kernels take directly (32000, 44100) as the control
+@pytest.mark.parametrize("nfft", [34, 2176, 95999, 95, 7, 3, 1, 4099, 32000, 44100])
+def test_transforms_any_length(gpu, dt, nfft):
+    """rfft / irfft at arbitrary nfft against torch.fft in float64 (the reference: dsp.py:84-89, 110-115): outputs and
+    gradients, truncated / zero-padded input, the three norms, both envelopes."""
+    from flamo_amd import ops
+    from oracle import hotpath as O
+    torch.manual_seed(nfft)
+    M = nfft // 2 + 1
+    # (the anti-aliased transforms multiply by an nfft-long envelope: like the reference's they take T == nfft only)
+    cases = [(nfft, "backward", 0.0), (M, "ortho", 0.0), (nfft + 7, "forward", 0.0), (nfft, "ortho", 30.0)] if nfft < 50000 \
+        else [(nfft, "backward", 30.0)]
+    for T, norm, db in cases:
+        x = torch.randn(2, T, 3, dtype=dt, device=gpu).requires_grad_(True)
+        C = torch.randn(2, M, 3, dtype=CD[dt], device=gpu)
+        X = ops.rfft(x, nfft, norm, db)
+        xr = x.detach().cpu().double().requires_grad_(True)
+        Xr = O.rfft(xr, nfft, norm, db or None)
+        assert X.shape == Xr.shape
+        check_close(f"any_len/{nfft}/{str(dt)[6:]}/{T}{norm}{db}/X", X.detach().cpu(), Xr.detach(), TOL[dt])
+        (gx,) = torch.autograd.grad(torch.sum(torch.real(X * torch.conj(C))), [x])
+        (gxr,) = torch.autograd.grad(torch.sum(torch.real(Xr * torch.conj(C.cpu().to(torch.complex128)))), [xr])
+        check_close(f"any_len/{nfft}/{str(dt)[6:]}/{T}{norm}{db}/gx", gx.cpu(), gxr, TOL[dt])
+        Z = torch.randn(2, M, 3, dtype=CD[dt], device=gpu).requires_grad_(True)
+        c = torch.randn(2, nfft, 3, dtype=dt, device=gpu)
+        y = ops.irfft(Z, nfft, norm, db)
+        Zr = Z.detach().cpu().to(torch.complex128).requires_grad_(True)
+        yr = O.irfft(Zr, nfft, norm, db or None)
+        assert y.shape == yr.shape
+        check_close(f"any_len/{nfft}/{str(dt)[6:]}/{T}{norm}{db}/y", y.detach().cpu(), yr.detach(), TOL[dt])
+        (gZ,) = torch.autograd.grad(torch.sum(y * c), [Z])
+        (gZr,) = torch.autograd.grad(torch.sum(yr * c.cpu().double()), [Zr])
+        check_close(f"any_len/{nfft}/{str(dt)[6:]}/{T}{norm}{db}/gZ", gZ.cpu(), gZr, TOL[dt])
+
+
+@pytest.mark.parametrize("nfft", [95, 2176])
+def test_shell_at_a_length_without_a_plan(gpu, dt, nfft):
+    """A whole model at an nfft the kernels do not plan (odd; prime factor 17): Shell(FFTAntiAlias -> Series(Matrix, parallelDelay,
+    GEQ) -> iFFTAntiAlias), output and parameter gradients against the oracle -- the response generators and the per-bin
+    product only ever see M = nfft // 2 + 1 bins and the twiddle table of that length."""
+    from flamo_amd.processor import dsp, system
+    from oracle import hotpath as O
+    N, B, db = 4, 2, 20.0
+    torch.manual_seed(nfft)
+    kw = dict(nfft=nfft, alias_decay_db=db, device=gpu, dtype=dt)
+    mat = dsp.Matrix(size=(N, N), requires_grad=True, **kw)
+    dl = dsp.parallelDelay(size=(N,), max_len=20, isint=True, **kw)
+    geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+    W = torch.randn(N, N).double()
+    G = torch.empty(12, N, N).uniform_(10 ** (-6 / 20), 10 ** (6 / 20)).float().double()
+    m = torch.tensor([3.0, 7.0, 11.0, 13.0]).double()
+    mat.assign_value(W.to(gpu, dt))
+    geq.assign_value(G.to(gpu, dt))
+    dl.assign_value(dl.sample2s(m.to(gpu, dt)))
+    model = system.Shell(system.Series(OrderedDict(mix=mat, d=dl, eq=geq)), dsp.FFTAntiAlias(nfft, alias_decay_db=db, device=gpu, dtype=dt),
+                         dsp.iFFTAntiAlias(nfft, alias_decay_db=db, device=gpu, dtype=dt))
+    x = torch.randn(B, nfft, N, dtype=dt, device=gpu)
+    y = model(x)
+    gW, gG = torch.autograd.grad((y ** 2).mean(), [mat.param, geq.param])
+    Wl, Gl = W.clone().requires_grad_(True), G.clone().requires_grad_(True)
+    gamma = O.gamma_of(db, nfft, F64)
+    X = O.rfft(x.cpu().double(), nfft, alias_decay_db=db)
+    X = O.mimo_const(O.to_complex(Wl), X)
+    X = O.mimo_diag(O.delay_response(m, nfft, gamma), X)
+    X = O.mimo_full(O.geq_response(Gl, nfft, gamma), X)
+    yr = O.irfft(X, nfft, alias_decay_db=db)
+    gWr, gGr = torch.autograd.grad((yr ** 2).mean(), [Wl, Gl])
+    tol = 1e-9 if dt == F64 else 1e-5
+    check_close(f"shell_noplan/{nfft}/{str(dt)[6:]}/y", y.detach().cpu(), yr.detach(), max(tol, 2e-6))
+    check_close(f"shell_noplan/{nfft}/{str(dt)[6:]}/gW", gW.cpu(), gWr, max(tol, 2e-6) * 5)
+    check_close(f"shell_noplan/{nfft}/{str(dt)[6:]}/gG", gG.cpu(), gGr, 1e-3)       # float32 section buffers (dsp.py:2573-2585)
