@@ -22,6 +22,7 @@ template <typename T> __host__ __device__ inline cx<T> operator*(cx<T> a, cx<T> 
     return cx<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 template <typename T> __host__ __device__ inline cx<T> operator*(T s, cx<T> a) { return cx<T>(s * a.x, s * a.y); }
+template <typename T> __host__ __device__ inline cx<T> mul_plain(cx<T> a, cx<T> b) { return cx<T>(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 template <typename T> __host__ __device__ inline cx<T> conj(cx<T> a) { return cx<T>(a.x, -a.y); }
 // a * conj(b)
 template <typename T> __host__ __device__ inline cx<T> mulc(cx<T> a, cx<T> b) {
@@ -47,14 +48,80 @@ template <typename T> __host__ __device__ inline void fma_cxc(cx<T>& acc, cx<T> 
 typedef float f2 __attribute__((ext_vector_type(2)));
 __host__ __device__ inline f2 v2(cx<float> a) { return f2{a.x, a.y}; }
 __host__ __device__ inline cx<float> c2(f2 v) { return cx<float>(v.x, v.y); }
+// ---- packed complex arithmetic with the swaps and sign flips as VOP3P operand modifiers (device code).  hipcc folds a whole-
+// vector negation into v_pk_add (a - b) and a broadcast half into op_sel, but NOT "swap the halves AND negate one": i*b, and
+// the (-y, y) / (-ti, tr) operand of a complex product, came out as v_xor + v_mov per use -- a fifth of the FFT stages'
+// instructions (32 + 19 of the 271 of a 16-point stage).  The operators below are the single instructions the hardware has:
+//   op_sel[i] / op_sel_hi[i]: which half of source i feeds the low / high result lane;  neg_lo / neg_hi: negate source i there.
+// Plain `asm` (not volatile): pure functions of their operands, free to be scheduled, merged and removed.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FL_PK_ASM 1
+__device__ __forceinline__ f2 pk_add_i(f2 a, f2 b) {      // a + i b = (a.x - b.y, a.y + b.x)
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f2 pk_sub_i(f2 a, f2 b) {      // a - i b = (a.x + b.y, a.y - b.x)
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f2 pk_cmul(f2 a, f2 t) {       // a t: two instructions
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));                                 // (x tr, x ti)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(a), "v"(t));   // (-y ti, y tr) +
+    return r;
+}
+__device__ __forceinline__ f2 pk_cmulc(f2 a, f2 t) {      // a conj(t)
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));                     // (x tr, -x ti)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(r) : "v"(a), "v"(t));             // (y ti, y tr) +
+    return r;
+}
+// the same products with a wavefront-uniform factor (a compile-time twiddle): it rides in an SGPR pair
+__device__ __forceinline__ f2 pk_cmul_s(f2 a, f2 t) {
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "s"(t));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(a), "s"(t));
+    return r;
+}
+__device__ __forceinline__ f2 pk_rot_s(f2 a, f2 k) {      // (a.y k.x, a.x k.y): i a with k = (-1, 1), -i a with k = (1, -1)
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "s"(k));
+    return r;
+}
+// a + s (i b) and a - s (i b), s real: the +-i times a real-scaled difference of the radix-3 / radix-5 butterflies
+__device__ __forceinline__ f2 pk_fma_i(float s, f2 b, f2 a) {      // a + i s b = (a.x - s b.y, a.y + s b.x)
+    f2 r;
+    const f2 sv = {s, s};       // (a compile-time constant at every call site: an SGPR pair)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "s"(sv), "v"(b), "v"(a));
+    return r;
+}
+__device__ __forceinline__ f2 pk_fms_i(float s, f2 b, f2 a) {      // a - i s b = (a.x + s b.y, a.y - s b.x)
+    f2 r;
+    const f2 sv = {s, s};
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(r) : "s"(sv), "v"(b), "v"(a));
+    return r;
+}
+#endif
 __host__ __device__ inline cx<float> operator+(cx<float> a, cx<float> b) { return c2(v2(a) + v2(b)); }
 __host__ __device__ inline cx<float> operator-(cx<float> a, cx<float> b) { return c2(v2(a) - v2(b)); }
 __host__ __device__ inline cx<float> operator*(cx<float> a, cx<float> b) {
+#if defined(FL_PK_ASM) && !defined(FL_PK_NO_OPS)
+    return c2(pk_cmul(v2(a), v2(b)));
+#endif
     f2 r = f2{a.x, a.x} * v2(b);
     return c2(__builtin_elementwise_fma(f2{-a.y, a.y}, f2{b.y, b.x}, r));
 }
 __host__ __device__ inline cx<float> operator*(float s, cx<float> a) { return c2(f2{s, s} * v2(a)); }
+__host__ __device__ inline cx<float> mul_plain(cx<float> a, cx<float> b) {     // a b in compiler-visible form (see regfft.h, PK)
+    f2 r = f2{a.x, a.x} * v2(b);
+    return c2(__builtin_elementwise_fma(f2{-a.y, a.y}, f2{b.y, b.x}, r));
+}
 __host__ __device__ inline cx<float> mulc(cx<float> a, cx<float> b) {     // a * conj(b)
+#if defined(FL_PK_ASM) && !defined(FL_PK_NO_OPS)
+    return c2(pk_cmulc(v2(a), v2(b)));
+#endif
     f2 r = f2{b.x, b.x} * v2(a);
     return c2(__builtin_elementwise_fma(f2{b.y, -b.y}, f2{a.y, a.x}, r));
 }

@@ -5,11 +5,13 @@
 namespace fl {
 
 // ---------------------------------------------------------------- radix butterflies (in registers)
-template <typename T, int R, bool INV>
+// PK: the packed-asm forms of common.h (float only).  A kernel can opt out (spec_cols_inv does: with the asm forms its
+// schedule changes and it runs 40 % slower -- measured, both for the butterflies alone and for the products alone).
+template <typename T, int R, bool INV, bool PK = true>
 struct Bfly;
 
-template <typename T, bool INV>
-struct Bfly<T, 2, INV> {
+template <typename T, bool INV, bool PK>
+struct Bfly<T, 2, INV, PK> {
     static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
         cx<T> a = v[0], b = v[1];
         v[0] = a + b;
@@ -17,10 +19,19 @@ struct Bfly<T, 2, INV> {
     }
 };
 
-template <typename T, bool INV>
-struct Bfly<T, 4, INV> {
+template <typename T, bool INV, bool PK>
+struct Bfly<T, 4, INV, PK> {
     static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
         cx<T> t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
+#if defined(FL_PK_ASM) && !defined(FL_PK_NO_BFLY)
+        if constexpr (PK && sizeof(T) == 4) {       // t1 +- i d as one packed add each (common.h)
+            v[0] = t0 + t2;
+            v[2] = t0 - t2;
+            v[1] = c2(INV ? pk_add_i(v2(t1), v2(d)) : pk_sub_i(v2(t1), v2(d)));
+            v[3] = c2(INV ? pk_sub_i(v2(t1), v2(d)) : pk_add_i(v2(t1), v2(d)));
+            return;
+        }
+#endif
         cx<T> t3 = INV ? mul_i(d) : mul_mi(d);
         v[0] = t0 + t2;
         v[1] = t1 + t3;
@@ -29,13 +40,21 @@ struct Bfly<T, 4, INV> {
     }
 };
 
-template <typename T, bool INV>
-struct Bfly<T, 3, INV> {
+template <typename T, bool INV, bool PK>
+struct Bfly<T, 3, INV, PK> {
     static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
         const T h = (T)0.86602540378443864676;  // sin(2pi/3)
         const cx<T> t = v[1] + v[2];
         const cx<T> u = axpy((T)-0.5, t, v[0]);
         const cx<T> d = v[1] - v[2];
+#if defined(FL_PK_ASM) && !defined(FL_PK_NO_BFLY)
+        if constexpr (PK && sizeof(T) == 4) {       // u +- i h d as one packed multiply-add each
+            v[0] = v[0] + t;
+            v[1] = c2(INV ? pk_fma_i((float)h, v2(d), v2(u)) : pk_fms_i((float)h, v2(d), v2(u)));
+            v[2] = c2(INV ? pk_fms_i((float)h, v2(d), v2(u)) : pk_fma_i((float)h, v2(d), v2(u)));
+            return;
+        }
+#endif
         const cx<T> w = h * (INV ? mul_i(d) : mul_mi(d));
         v[0] = v[0] + t;
         v[1] = u + w;
@@ -43,18 +62,28 @@ struct Bfly<T, 3, INV> {
     }
 };
 
-template <typename T, bool INV>
-struct Bfly<T, 5, INV> {
+template <typename T, bool INV, bool PK>
+struct Bfly<T, 5, INV, PK> {
     static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
-        const T c1 = (T)0.30901699437494742410;   // cos(2pi/5)
-        const T c2 = (T)-0.80901699437494742410;  // cos(4pi/5)
+        const T k1c = (T)0.30901699437494742410;   // cos(2pi/5)
+        const T k2c = (T)-0.80901699437494742410;  // cos(4pi/5)
         const T s1 = (T)0.95105651629515357212;   // sin(2pi/5)
         const T s2 = (T)0.58778525229247312917;   // sin(4pi/5)
         const cx<T> a1 = v[1] + v[4], a2 = v[2] + v[3], d1 = v[1] - v[4], d2 = v[2] - v[3];
-        const cx<T> m1 = axpy(c2, a2, axpy(c1, a1, v[0]));
-        const cx<T> m2 = axpy(c1, a2, axpy(c2, a1, v[0]));
+        const cx<T> m1 = axpy(k2c, a2, axpy(k1c, a1, v[0]));
+        const cx<T> m2 = axpy(k1c, a2, axpy(k2c, a1, v[0]));
         const cx<T> e1 = axpy(s2, d2, s1 * d1);
         const cx<T> e2 = axpy(-s1, d2, s2 * d1);
+#if defined(FL_PK_ASM) && !defined(FL_PK_NO_BFLY)
+        if constexpr (PK && sizeof(T) == 4) {       // m +- i e as one packed add each
+            v[0] = v[0] + a1 + a2;
+            v[1] = c2(INV ? pk_add_i(v2(m1), v2(e1)) : pk_sub_i(v2(m1), v2(e1)));
+            v[4] = c2(INV ? pk_sub_i(v2(m1), v2(e1)) : pk_add_i(v2(m1), v2(e1)));
+            v[2] = c2(INV ? pk_add_i(v2(m2), v2(e2)) : pk_sub_i(v2(m2), v2(e2)));
+            v[3] = c2(INV ? pk_sub_i(v2(m2), v2(e2)) : pk_add_i(v2(m2), v2(e2)));
+            return;
+        }
+#endif
         const cx<T> j1 = INV ? mul_i(e1) : mul_mi(e1);
         const cx<T> j2 = INV ? mul_i(e2) : mul_mi(e2);
         v[0] = v[0] + a1 + a2;
@@ -66,7 +95,7 @@ struct Bfly<T, 5, INV> {
 };
 
 // generic odd prime radix: direct O(R^2) DFT with w_R^j = tw[j * step] (forward table)
-template <typename T, int R, bool INV>
+template <typename T, int R, bool INV, bool PK>
 struct Bfly {
     static __device__ inline void run(cx<T>* v, const cx<T>* tw, int step) {
         cx<T> o[R];
@@ -161,7 +190,7 @@ constexpr int first_factor(int R) {
 }
 
 // Natural-order in-register FFT of size R: v[k] <- sum_t v[t] W_R^(+-tk)
-template <typename T, int R, bool INV>
+template <typename T, int R, bool INV, bool PK = true>
 struct RegFFT {
     static __device__ __forceinline__ void run(cx<T> (&v)[R]) {
         if constexpr (R == 1) {
@@ -183,7 +212,7 @@ struct RegFFT {
 #pragma unroll
             for (int k = 0; k < R; ++k) v[k] = o[k];
         } else if constexpr (is_base_radix(R)) {
-            Bfly<T, R, INV>::run(v, nullptr, 0);
+            Bfly<T, R, INV, PK>::run(v, nullptr, 0);
         } else {
             constexpr int R1 = first_factor(R), R2 = R / R1;
             constexpr TwTab<R> tw = TwTab<R>();
@@ -193,15 +222,29 @@ struct RegFFT {
                 cx<T> sub[R1];
 #pragma unroll
                 for (int t1 = 0; t1 < R1; ++t1) sub[t1] = v[t1 * R2 + t2];
-                RegFFT<T, R1, INV>::run(sub);
+                RegFFT<T, R1, INV, PK>::run(sub);
 #pragma unroll
                 for (int k1 = 0; k1 < R1; ++k1) {
                     const int m = (t2 * k1) % R;
                     if (m == 0) {
                         w[k1 * R2 + t2] = sub[k1];
                     } else {
+#if defined(FL_PK_ASM) && !defined(FL_PK_NO_BFLY)
+                        if constexpr (PK && sizeof(T) == 4) {
+                            // a compile-time twiddle: a quarter turn is one packed multiply by (+-1, -+1) with the halves swapped,
+                            // everything else the two-instruction product with the factor in an SGPR pair
+                            if ((4 * m) % R == 0) {
+                                const int q = ((4 * m) / R) % 4;          // W^m = (-i)^q forward, (+i)^q inverse
+                                if (q == 2) w[k1 * R2 + t2] = c2(-v2(sub[k1]));
+                                else w[k1 * R2 + t2] = c2(pk_rot_s(v2(sub[k1]), ((q == 1) != INV) ? f2{1.f, -1.f} : f2{-1.f, 1.f}));
+                            } else {
+                                w[k1 * R2 + t2] = c2(pk_cmul_s(v2(sub[k1]), f2{(float)tw.re[m], INV ? (float)(-tw.im[m]) : (float)tw.im[m]}));
+                            }
+                            continue;
+                        }
+#endif
                         const cx<T> tf((T)tw.re[m], INV ? (T)(-tw.im[m]) : (T)tw.im[m]);
-                        w[k1 * R2 + t2] = sub[k1] * tf;
+                        w[k1 * R2 + t2] = mul_plain(sub[k1], tf);
                     }
                 }
             }
@@ -210,7 +253,7 @@ struct RegFFT {
                 cx<T> sub[R2];
 #pragma unroll
                 for (int t2 = 0; t2 < R2; ++t2) sub[t2] = w[k1 * R2 + t2];
-                RegFFT<T, R2, INV>::run(sub);
+                RegFFT<T, R2, INV, PK>::run(sub);
 #pragma unroll
                 for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = sub[k2];
             }

@@ -168,11 +168,11 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
             const int item = threadIdx.x + (r0 + rr) * 256;
             if (r0 + rr < NR && item < NIT) {
                 const int tb = item / VT, vv = item % VT;
-                RegFFT<real_t, A, true>::run(v[rr]);
+                RegFFT<real_t, A, true, false>::run(v[rr]);
                 cf* u = U + vv * LENP + tb;
                 u[0] = v[rr][0];
 #pragma unroll
-                for (int ka = 1; ka < A; ++ka) u[ka * B] = v[rr][ka] * conj(tw[ka * tb]);
+                for (int ka = 1; ka < A; ++ka) u[ka * B] = mul_plain(v[rr][ka], conj(tw[ka * tb]));
             }
         }
     }
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
         const cf* u = U + vv * LENP + ka * B;
 #pragma unroll
         for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
-        RegFFT<real_t, B, true>::run(v);
+        RegFFT<real_t, B, true, false>::run(v);
 #pragma unroll
         for (int kb = 0; kb < B; ++kb) {
             const int t1 = ka + A * kb;
@@ -674,6 +674,7 @@ int spec_plan_lean(int nfft) {
 namespace FL_SPEC_NS {
 
 static int g_spec_vt = 0, g_spec_rg = 0;      // 0 = pick per shape (below); fl_debug_set_spec overrides
+static size_t g_cols_inv_min_lds = [] { const char* e = getenv("FLAMO_COLS_INV_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
 
 // Column-pass tile: virtual columns per workgroup and loads in flight per thread group. Measured under graph replay on
 // the whole training step (tools/dbg/graph_ab.py): 16 virtual columns (27 KB of LDS, five workgroups per CU) win for
@@ -705,7 +706,8 @@ static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStrea
     constexpr int LEN = A * B, LENP = LEN | 1;
 #define FL_COLS(VT_, RG_)                                                                                        \
     {                                                                                                            \
-        const size_t lds = ((size_t)VT_ * LENP + LEN + (size_t)VT_ * B) * sizeof(cf);                            \
+        size_t lds = ((size_t)VT_ * LENP + LEN + (size_t)VT_ * B) * sizeof(cf);                                  \
+        if (inverse && g_cols_inv_min_lds > lds) lds = g_cols_inv_min_lds;                                       \
         if (inverse) hipLaunchKernelGGL((spec_cols_inv<A, B, VT_, RG_>), dim3(nblk), dim3(256), lds, st, a);     \
         else if (a.env_log2 == 0.0 && a.t_lim >= a.n)                                                            \
             hipLaunchKernelGGL((spec_cols_fwd<A, B, VT_, RG_, true>), dim3(nblk), dim3(256), lds, st, a);        \
