@@ -54,60 +54,95 @@ __host__ __device__ inline cx<float> c2(f2 v) { return cx<float>(v.x, v.y); }
 // instructions (32 + 19 of the 271 of a 16-point stage).  The operators below are the single instructions the hardware has:
 //   op_sel[i] / op_sel_hi[i]: which half of source i feeds the low / high result lane;  neg_lo / neg_hi: negate source i there.
 // Plain `asm` (not volatile): pure functions of their operands, free to be scheduled, merged and removed.
-#if defined(__HIP_DEVICE_COMPILE__)
 #define FL_PK_ASM 1
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FL_PK_DEV 1
+#else
+#define FL_PK_DEV 0      // host pass: the same functions in plain C++ (never executed; device code is what runs)
+#endif
 __device__ __forceinline__ f2 pk_add_i(f2 a, f2 b) {      // a + i b = (a.x - b.y, a.y + b.x)
+#if FL_PK_DEV
     f2 r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#else
+    return f2{a.x - b.y, a.y + b.x};
+#endif
 }
 __device__ __forceinline__ f2 pk_sub_i(f2 a, f2 b) {      // a - i b = (a.x + b.y, a.y - b.x)
+#if FL_PK_DEV
     f2 r;
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#else
+    return f2{a.x + b.y, a.y - b.x};
+#endif
 }
 __device__ __forceinline__ f2 pk_cmul(f2 a, f2 t) {       // a t: two instructions
+#if FL_PK_DEV
     f2 r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));                                 // (x tr, x ti)
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(a), "v"(t));   // (-y ti, y tr) +
     return r;
+#else
+    return f2{a.x * t.x - a.y * t.y, a.x * t.y + a.y * t.x};
+#endif
 }
 __device__ __forceinline__ f2 pk_cmulc(f2 a, f2 t) {      // a conj(t)
+#if FL_PK_DEV
     f2 r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));                     // (x tr, -x ti)
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(r) : "v"(a), "v"(t));             // (y ti, y tr) +
     return r;
+#else
+    return f2{a.x * t.x + a.y * t.y, a.y * t.x - a.x * t.y};
+#endif
 }
-// the same products with a wavefront-uniform factor (a compile-time twiddle): it rides in an SGPR pair
+// the same product with a wavefront-uniform factor (a compile-time twiddle): it rides in an SGPR pair
 __device__ __forceinline__ f2 pk_cmul_s(f2 a, f2 t) {
+#if FL_PK_DEV
     f2 r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "s"(t));
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(r) : "v"(a), "s"(t));
     return r;
+#else
+    return f2{a.x * t.x - a.y * t.y, a.x * t.y + a.y * t.x};
+#endif
 }
 __device__ __forceinline__ f2 pk_rot_s(f2 a, f2 k) {      // (a.y k.x, a.x k.y): i a with k = (-1, 1), -i a with k = (1, -1)
+#if FL_PK_DEV
     f2 r;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "s"(k));
     return r;
+#else
+    return f2{a.y * k.x, a.x * k.y};
+#endif
 }
-// a + s (i b) and a - s (i b), s real: the +-i times a real-scaled difference of the radix-3 / radix-5 butterflies
+// a + s (i b) and a - s (i b), s a compile-time real: the +-i times a real-scaled difference of the radix-3 butterfly
 __device__ __forceinline__ f2 pk_fma_i(float s, f2 b, f2 a) {      // a + i s b = (a.x - s b.y, a.y + s b.x)
+#if FL_PK_DEV
     f2 r;
-    const f2 sv = {s, s};       // (a compile-time constant at every call site: an SGPR pair)
+    const f2 sv = {s, s};       // (an SGPR pair)
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "s"(sv), "v"(b), "v"(a));
     return r;
+#else
+    return f2{a.x - s * b.y, a.y + s * b.x};
+#endif
 }
 __device__ __forceinline__ f2 pk_fms_i(float s, f2 b, f2 a) {      // a - i s b = (a.x + s b.y, a.y - s b.x)
+#if FL_PK_DEV
     f2 r;
     const f2 sv = {s, s};
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(r) : "s"(sv), "v"(b), "v"(a));
     return r;
-}
+#else
+    return f2{a.x + s * b.y, a.y - s * b.x};
 #endif
+}
 __host__ __device__ inline cx<float> operator+(cx<float> a, cx<float> b) { return c2(v2(a) + v2(b)); }
 __host__ __device__ inline cx<float> operator-(cx<float> a, cx<float> b) { return c2(v2(a) - v2(b)); }
 __host__ __device__ inline cx<float> operator*(cx<float> a, cx<float> b) {
-#if defined(FL_PK_ASM) && !defined(FL_PK_NO_OPS)
+#if FL_PK_DEV
     return c2(pk_cmul(v2(a), v2(b)));
 #endif
     f2 r = f2{a.x, a.x} * v2(b);
@@ -119,7 +154,7 @@ __host__ __device__ inline cx<float> mul_plain(cx<float> a, cx<float> b) {     /
     return c2(__builtin_elementwise_fma(f2{-a.y, a.y}, f2{b.y, b.x}, r));
 }
 __host__ __device__ inline cx<float> mulc(cx<float> a, cx<float> b) {     // a * conj(b)
-#if defined(FL_PK_ASM) && !defined(FL_PK_NO_OPS)
+#if FL_PK_DEV
     return c2(pk_cmulc(v2(a), v2(b)));
 #endif
     f2 r = f2{b.x, b.x} * v2(a);

@@ -23,7 +23,7 @@ template <typename T, bool INV, bool PK>
 struct Bfly<T, 4, INV, PK> {
     static __device__ inline void run(cx<T>* v, const cx<T>*, int) {
         cx<T> t0 = v[0] + v[2], t1 = v[0] - v[2], t2 = v[1] + v[3], d = v[1] - v[3];
-#if defined(FL_PK_ASM) && !defined(FL_PK_NO_BFLY)
+#ifdef FL_PK_ASM
         if constexpr (PK && sizeof(T) == 4) {       // t1 +- i d as one packed add each (common.h)
             v[0] = t0 + t2;
             v[2] = t0 - t2;
@@ -47,7 +47,7 @@ struct Bfly<T, 3, INV, PK> {
         const cx<T> t = v[1] + v[2];
         const cx<T> u = axpy((T)-0.5, t, v[0]);
         const cx<T> d = v[1] - v[2];
-#if defined(FL_PK_ASM) && !defined(FL_PK_NO_BFLY)
+#ifdef FL_PK_ASM
         if constexpr (PK && sizeof(T) == 4) {       // u +- i h d as one packed multiply-add each
             v[0] = v[0] + t;
             v[1] = c2(INV ? pk_fma_i((float)h, v2(d), v2(u)) : pk_fms_i((float)h, v2(d), v2(u)));
@@ -74,7 +74,7 @@ struct Bfly<T, 5, INV, PK> {
         const cx<T> m2 = axpy(k1c, a2, axpy(k2c, a1, v[0]));
         const cx<T> e1 = axpy(s2, d2, s1 * d1);
         const cx<T> e2 = axpy(-s1, d2, s2 * d1);
-#if defined(FL_PK_ASM) && !defined(FL_PK_NO_BFLY)
+#ifdef FL_PK_ASM
         if constexpr (PK && sizeof(T) == 4) {       // m +- i e as one packed add each
             v[0] = v[0] + a1 + a2;
             v[1] = c2(INV ? pk_add_i(v2(m1), v2(e1)) : pk_sub_i(v2(m1), v2(e1)));
@@ -229,7 +229,7 @@ struct RegFFT {
                     if (m == 0) {
                         w[k1 * R2 + t2] = sub[k1];
                     } else {
-#if defined(FL_PK_ASM) && !defined(FL_PK_NO_BFLY)
+#ifdef FL_PK_ASM
                         if constexpr (PK && sizeof(T) == 4) {
                             // a compile-time twiddle: a quarter turn is one packed multiply by (+-1, -+1) with the halves swapped,
                             // everything else the two-instruction product with the factor in an SGPR pair

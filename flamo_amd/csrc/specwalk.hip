@@ -12,7 +12,7 @@
 // the phases, which leaves four barriers per round and none between rounds.
 //
 //   forward  (spec_mid_walk):   S (B, L1, L2, NI) -> Y[f] = op(H[f]) X[f] -> S2 (B, L1, L2, NO).  If the backward pass will
-//                               need the spectrum it is kept PAIR-MAJOR, Xp[unit][k | L-k][n][pair]: exactly what the
+//                               need the spectrum it is kept PAIR-MAJOR, Xp[unit][k | L-k][n/2][pair][n%2]: exactly what the
 //                               product's thread holds, written and read back as whole 512-byte runs
 //   backward (spec_gradh_walk): Sg, Xp -> dL/dH[m][n][f] = sum_b gY[b,m,f] conj(X[b,n,f]) accumulated in registers over the
 //                               workgroup's batch slice: the gradient's row FFTs + split step happen in the kernel (its
@@ -39,7 +39,7 @@ struct WalkArgs {
     int spec_interior2;   // double the interior bins of the spectrum (irfft backward)
     int pre_half;         // halve the interior bins in front of the inverse transform (rfft backward)
     const int* bounds;    // work partition: workgroup w takes units [bounds[w], bounds[w+1]) (fl_spec_walk_partition), or null: equal counts
-    cf* Xp;               // spectrum out, pair-major: Xp[(u*2 + e)*NI*LEN + n*LEN + p], u = r*Bn + b, e = 0: bin k, 1: bin L-k; or null
+    cf* Xp;               // spectrum out, pair-major: Xp[(u*2 + e)*NI*LEN + ((n/2)*LEN + p)*2 + n%2], u = r*Bn + b, e = 0: bin k, 1: bin L-k; or null
     long long* dbg_times; // tuning: per-workgroup cycle stamps, or null
 };
 
@@ -50,6 +50,10 @@ struct WalkArgs {
 // The kernel waits for its transfers itself (vmcnt(0) in front of the barrier that precedes their first read).
 __device__ __forceinline__ void dma16(const void* g, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_byte_addr) : "memory");
+}
+// the same with a wavefront-uniform base in an SGPR pair and a 32-bit per-lane byte offset (no 64-bit address arithmetic per piece)
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
@@ -67,6 +71,34 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ int opaque(int v) {
     asm volatile("" : "+v"(v));
     return v;
+}
+// One complex value from LDS as ONE ds_read_b64.  hipcc merges two 8-byte reads at constant offsets into a ds_read2_b64, which
+// the LDS services at half the rate (8 array cycles per wave-instruction for 1 KB against 2 for 512 B) and under the narrow
+// banking rule -- and the start of every step is exactly an LDS read burst of all eight wavefronts (a third of step C).  The
+// read is issued as inline assembly, so the compiler neither merges it nor knows it is in flight: lds_reads_done() waits for
+// the LDS counter and pins the values behind the wait.
+__device__ __forceinline__ f2 lds_rd(unsigned byte_addr, int off) {
+    f2 v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "i"(off));
+    return v;
+}
+// (the raw register pairs are pinned: any use of them ahead of the wait -- even a move into another register -- reads garbage)
+template <int N>
+__device__ __forceinline__ void lds_reads_done(f2 (&r)[N], cf (&v)[N]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        asm volatile("" : "+v"(r[i]));
+        v[i] = c2(r[i]);
+    }
+}
+#ifndef FL_XP_PAIRS
+#define FL_XP_PAIRS 1      // the kept spectrum in channel pairs (16-byte stores / LDS reads); 0: one channel plane per 8-byte access
+#endif
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_nt16(cf* base, unsigned byte_off, f2 lo, f2 hi) {
+    const f4 q = {lo.x, lo.y, hi.x, hi.y};
+    __builtin_nontemporal_store(q, reinterpret_cast<f4*>(reinterpret_cast<char*>(base) + byte_off));
 }
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // s_waitcnt vmcnt(0)
 __device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }    // s_waitcnt lgkmcnt(0)
@@ -88,19 +120,47 @@ __device__ __forceinline__ f2 cmac2(f2 acc, f2 a, f2 b, f2 ib) { return pfma(f2{
 // The constant factor is taken as the two vectors iw = i wk and niw = i iw = -wk, the variable one by broadcast halves: no
 // rotation of a variable (a swap AND a sign flip of one half is not something the compiler folds into operand selectors).
 __device__ __forceinline__ f2 cmulc(f2 b, f2 a, f2 ia) { return pfma(f2{b.y, b.y}, ia, f2{b.x, b.x} * a); }      // a b, ia = i a
-__device__ __forceinline__ void split_pair(f2 zk, f2 zm, f2 iw, f2 niw, f2 sck, f2 scm, f2& xk, f2& xm) {
-    const f2 Pp = f2{zk.x + zm.x, zk.y - zm.y}, D = f2{zk.x - zm.x, zk.y + zm.y};
-    const f2 it = cmulc(D, iw, niw);            // i wk D
-    xk = sck * (Pp - it);                       // sck = (sc, sc)
-    xm = scm * (Pp + it);                       // scm = (sc, -sc): the conjugate
+// packed adds with per-half signs as operand modifiers (one instruction each; written out, "(a.x + b.x, a.y - b.y)" costs two
+// adds and two moves)
+#if FL_PK_DEV
+#define FL_PK_ADD(name, mods, plain)                                                 \
+    __device__ __forceinline__ f2 name(f2 a, f2 b) {                                 \
+        f2 r;                                                                        \
+        asm("v_pk_add_f32 %0, %1, %2 " mods : "=v"(r) : "v"(a), "v"(b));             \
+        return r;                                                                    \
+    }
+#else
+#define FL_PK_ADD(name, mods, plain) \
+    __device__ __forceinline__ f2 name(f2 a, f2 b) { return plain; }
+#endif
+FL_PK_ADD(add_pm, "neg_hi:[0,1]", (f2{a.x + b.x, a.y - b.y}))                    // a + conj(b)
+FL_PK_ADD(add_mp, "neg_lo:[0,1]", (f2{a.x - b.x, a.y + b.y}))                    // a - conj(b)
+FL_PK_ADD(add_cj, "neg_hi:[1,1]", (f2{a.x + b.x, -a.y - b.y}))                   // conj(a + b)
+FL_PK_ADD(sub_cj, "neg_lo:[0,1] neg_hi:[1,0]", (f2{a.x - b.x, b.y - a.y}))       // conj(a - b)
+#undef FL_PK_ADD
+// acc + x.y (-i g) = (acc.x + x.y g.y, acc.y - x.y g.x)
+__device__ __forceinline__ f2 fma_mi(f2 x, f2 g, f2 acc) {
+#if FL_PK_DEV
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "+v"(acc) : "v"(x), "v"(g));
+    return acc;
+#else
+    return f2{acc.x + x.y * g.y, acc.y - x.y * g.x};
+#endif
+}
+// iws = sc i wk, niws = -sc wk (the scale rides in the constant factor), sck = (sc, sc):  xk = sc (P - i t), xm = sc conj(P + i t)
+__device__ __forceinline__ void split_pair(f2 zk, f2 zm, f2 iws, f2 niws, f2 sck, f2& xk, f2& xm) {
+    const f2 Pp = sck * add_pm(zk, zm), D = add_mp(zk, zm);
+    const f2 it = cmulc(D, iws, niws);          // sc i wk D
+    xk = Pp - it;
+    xm = add_cj(Pp, it);
 }
 // Hermitian pre-step of the inverse real FFT for the pair (k, L-k): from Y[k], Y[L-k] to Zf[k], Zf[L-k];
 // cwk = conj(W_n^k).  For the pair (0, L) pass yk, ym with zeroed imaginary parts (cwk = 1 there).
 __device__ __forceinline__ void pre_pair(f2 yk, f2 ym, f2 icw, f2 nicw, f2& zk, f2& zm) {      // icw = i conj(wk), nicw = -conj(wk)
-    const f2 s_ = f2{yk.x + ym.x, yk.y - ym.y}, d_ = f2{yk.x - ym.x, yk.y + ym.y};
+    const f2 s_ = add_pm(yk, ym), d_ = add_mp(yk, ym);
     const f2 t_ = cmulc(d_, icw, nicw);         // i conj(wk) d
     zk = s_ + t_;
-    zm = f2{s_.x - t_.x, t_.y - s_.y};          // conj(s - t)
+    zm = sub_cj(s_, t_);                        // conj(s - t)
 }
 
 // ---------------------------------------------------------------- forward: rows + split + product + pre-step + inverse rows
@@ -116,6 +176,8 @@ __device__ __forceinline__ void pre_pair(f2 yk, f2 ym, f2 icw, f2 nicw, f2& zk, 
 // instead of leaving half of the wavefronts idle.  The pipeline drains at a row-pair boundary (new response).
 // Row pitch of the LDS row buffers, in complex elements: 4 times an odd number (mod 32), so that the FFT stages' lane
 // patterns (8 channels x 4 consecutive columns, or 8 channels x 4 column groups 15 apart) fall on 32 different 8-byte banks
+// first-stage twiddle table [tb][ka] with an odd pitch: the four tb of a 32-lane group then sit on four different banks
+constexpr int tw_pitch(int A) { return A | 1; }
 constexpr int walk_pitch(int len) {
     int p = len;
     while (p % 8 != 4) ++p;
@@ -138,8 +200,9 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
     cf* Yb = XF + UB;
     cf* XI = Yb + UB;
     cf* stage = XI + UB;                           // [SB]
-    cf* tw = stage + SB;                           // W_LEN^m
-    cf* ws = tw + LEN;                             // W_n^(L1*k2)
+    constexpr int TWP = tw_pitch(A), TWL = (B * TWP + 1) & ~1;
+    cf* tw = stage + SB;                           // W_LEN^(ka tb) at [tb][ka], pitch TWP
+    cf* ws = tw + TWL;                             // W_n^(L1*k2)
     cf* wtab = ws + LEN;                           // [2][LEN]: conj(W_L^(row * c)) of the current row pair
     cf* dummy = wtab + 2 * LEN;                    // [64]: where lanes without a partner bin store
     const int tid = threadIdx.x;
@@ -163,16 +226,35 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
     // and awaited (vmcnt) just before its next reads -- no barrier is involved, and the rows have a whole pipeline cycle
     // to arrive.  One 1-KB piece = first-stage inputs ta = 2q, 2q+1 of the 64 items; a lane's 16 bytes = channels (n, n+1)
     // of one column.
-    auto fetch = [&](int uu) {
-        const int r = uu / a.Bn, b = uu - r * a.Bn;
+    // Addressing: everything per-lane -- (row r or L1 - r, column, channel pair) -- is one 32-bit byte offset, rebuilt when the
+    // row pair changes (fetch_row); the batch item enters through the wavefront-uniform base, and the fetches go through the
+    // units in order, so (row pair, batch item) of the next fetch are two scalars that count (no division per fetch).
+    unsigned fetch_voff = 0;
+    int f_r = -1, f_b = 0;
+    auto fetch_row = [&](int r) {
         const int rm = (a.L1 - r) % a.L1;
         const int wv = wave & 3, hi = lane >> 5;
         int item0 = 64 * wv + 2 * (lane & 31);
         if (item0 >= NI1 || (item0 >= B * NI && rm == r)) item0 = 0;          // no such item: any valid address
         const int nn0 = item0 % NI, tb = (item0 / NI) % B, slot = item0 / (NI * B);
-        const cf* src = a.S + (size_t)b * bstride_i + (size_t)(slot ? rm : r) * (a.L2 * NI) + ((hi * B + tb) * NI + nn0);
+        fetch_voff = 8u * ((unsigned)(slot ? rm : r) * (unsigned)(a.L2 * NI) + (unsigned)((hi * B + tb) * NI + nn0));
+    };
+    auto fetch = [&](int uu) {           // called for consecutive units uu
+        if (f_r < 0) {
+            f_r = uu / a.Bn;
+            f_b = uu - f_r * a.Bn;
+            fetch_row(f_r);
+        }
+        const char* base = reinterpret_cast<const char*>(a.S + (size_t)f_b * bstride_i);
+        const int wv = wave & 3;
 #pragma unroll
-        for (int q = 0; q < A / 2; ++q) dma16(src + q * (2 * B * NI), stage_lds + (unsigned)(((wv * A + 2 * q) * 64) * 8));
+        for (int q = 0; q < A / 2; ++q)
+            dma16s(base + (size_t)q * (2 * B * NI * 8), fetch_voff, stage_lds + (unsigned)(((wv * A + 2 * q) * 64) * 8));
+        if (++f_b == a.Bn) {             // the next fetch is for the next row pair
+            f_b = 0;
+            ++f_r;
+            fetch_row(f_r < a.L1 / 2 + 1 ? f_r : 0);
+        }
     };
     // ---- the FFT stages, each for the 256 threads of one group
     auto P1 = [&](bool selfm) {          // first stage of the forward rows, staging -> XF.  item = (slot, tb, n), n fastest
@@ -187,7 +269,7 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         // the twiddles are read with the data: behind the first LDS store the compiler cannot move a read any more (it
         // cannot tell the table from the row buffers), and 15 dependent read -> multiply -> store round trips would follow
 #pragma unroll
-        for (int ka = 1; ka < A; ++ka) t[ka] = tw[ka * (have ? tb : 0)];
+        for (int ka = 1; ka < A; ++ka) t[ka] = tw[(have ? tb : 0) * TWP + ka];
         if (!have) return;
         RegFFT<float, A, false>::run(v);
         cf* uu = XF + (slot * NCH + nn) * LENP + tb;
@@ -217,39 +299,53 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
 #pragma unroll
         for (int ta = 0; ta < A; ++ta) v[ta] = uu[ta * B];
 #pragma unroll
-        for (int ka = 1; ka < A; ++ka) t[ka] = tw[ka * tb];
+        for (int ka = 1; ka < A; ++ka) t[ka] = tw[tb * TWP + ka];
         RegFFT<float, A, true>::run(v);
         uu[0] = v[0];
 #pragma unroll
         for (int ka = 1; ka < A; ++ka) uu[ka * B] = mulc(v[ka], t[ka]);
     };
+    long long q_ph[3] = {0, 0, 0}, q_t0 = 0;
     auto P5 = [&](bool selfm, int r, int rm, int b) {     // second stage, twiddle conj(W_L^(row*c)), store
+        if (DBG) q_t0 = clock64();
         // item = (m fastest, ka, slot): the lanes of a store cover runs of (c = ka + A kb, m): 512 contiguous bytes per kb
         const int item = opaque(tid) & 255;
         const int m = item % NO, ka = (item / NO) % A, slot = item / (NO * A);
         if (item >= NI5 || (slot && selfm)) return;
         cf v[B], t[B];
-        const cf* uu = XI + (slot * NCH + m) * LENP + ka * B;
-        const cf* wt = wtab + slot * LEN + ka;
+        const unsigned uu = lds_addr_of(XI + (slot * NCH + m) * LENP + ka * B);
+        const unsigned wt = lds_addr_of(wtab + slot * LEN + ka);
+        f2 rv[B], rt[B];
 #pragma unroll
-        for (int tb = 0; tb < B; ++tb) v[tb] = uu[tb];
+        for (int tb = 0; tb < B; ++tb) rv[tb] = lds_rd(uu, tb * 8);
 #pragma unroll
-        for (int kb = 0; kb < B; ++kb) t[kb] = wt[A * kb];
+        for (int kb = 0; kb < B; ++kb) rt[kb] = lds_rd(wt, A * kb * 8);
+        lds_reads_done(rv, v);
+        lds_reads_done(rt, t);
+        long long tq0 = 0;
+        if (DBG) tq0 = clock64();
         RegFFT<float, B, true>::run(v);
+        if (DBG) {
+            const long long tq1 = clock64();
+            q_ph[0] += tq0 - q_t0;       // reads
+            q_ph[1] += tq1 - tq0;        // butterflies
+            q_t0 = tq1;
+        }
         cf* S2b = a.S2 + (size_t)b * bstride_o;
         const unsigned dst0 = (unsigned)(slot ? rm : r) * (unsigned)a.L2 * NO + (unsigned)(ka * NO + m);
 #pragma unroll
         for (int kb = 0; kb < B; ++kb) st_nt(S2b, 8u * (dst0 + (unsigned)(A * kb * NO)), v[kb] * t[kb]);
+        if (DBG) q_ph[2] += clock64() - q_t0;     // twiddles + stores
     };
 
     if (grp == 1) fetch(u);
     for (int j = tid; j < LEN; j += 512) {         // contiguous copies behind the master table (fl_spec_aux_fill_f32)
-        tw[j] = a.W[a.n + a.L1 + j];
+        tw[(j / A) * TWP + j % A] = a.W[a.n + a.L1 + (j / A) * (j % A)];      // a thread's A first-stage twiddles are one run
         ws[j] = a.W[a.n + a.L1 + a.L2 + j];
     }
     const float hs = 0.5f * a.spec_scale, wi = a.spec_interior2 ? 2.f : 1.f;
     const float ph = a.pre_half ? 0.5f : 1.f;
-    long long t_ph[4] = {0, 0, 0, 0}, t_last = 0;
+    long long t_ph[4] = {0, 0, 0, 0}, t_last = 0, w_ph[3] = {0, 0, 0};
     if (DBG) t_last = clock64();
     const long long t_begin = t_last;
 #define FL_STAMP(i)                         \
@@ -297,9 +393,9 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         // (the previous pair's last P5 read the table in its last step, a barrier ago)
         const cf wt_mine = conj(a.W[2 * (grp ? rm : r) * pc]);
         const f2 wk = v2(a.W[r] * ws[pc]);                      // W_n^k of the pair's first bin, k = r + L1 p
-        const f2 iw = rot_i(wk), niw = f2{-wk.x, -wk.y}, icw = f2{wk.y, wk.x}, nicw = f2{-wk.x, wk.y};
+        const f2 icw = f2{wk.y, wk.x}, nicw = f2{-wk.x, wk.y};
         const float sc = dc ? hs : hs * wi;                     // the pair (0, L) is not interior
-        const f2 sck = f2{sc, sc}, scm = f2{sc, -sc};
+        const f2 sck = f2{sc, sc}, iw = sc * rot_i(wk), niw = f2{-sc * wk.x, -sc * wk.y};      // the split step's scale rides in its twiddle
         const f2 phv = dc ? f2{1.f, 0.f} : f2{ph, ph};          // ... and only its real parts enter the inverse transform
         const int yk_o = pc, ym_o = slotB * NCH * LENP + colB;  // where the pair's bins sit in a row buffer
         cf* zm_dst = twin ? XI + ym_o : dummy + lane;           // lanes without a partner bin of their own store aside
@@ -340,11 +436,30 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
                 const cf* ym_p = Yb + ym_o;
                 f2 xk[NI], xm[NI];
 #pragma unroll
-                for (int nn = 0; nn < NI; ++nn) split_pair(v2(yk_p[nn * LENP]), v2(ym_p[nn * LENP]), iw, niw, sck, scm, xk[nn], xm[nn]);
-                if (a.Xp) {      // group 0 keeps the bins k, group 1 the bins L-k (both hold both)
-                    cf* xo = a.Xp + ((size_t)u * 2 + grp) * (NI * LEN) + p;
+                for (int nn = 0; nn < NI; ++nn) split_pair(v2(yk_p[nn * LENP]), v2(ym_p[nn * LENP]), iw, niw, sck, xk[nn], xm[nn]);
+                if (a.Xp) {      // group 0 keeps the bins k, group 1 the bins L-k (both hold both); grp is wavefront-uniform: a branch
+                    // channel PAIRS are the unit of the layout: one 16-byte store per pair (8-byte stores are bound by their issue
+                    // rate, not by bytes: half as many instructions for the same data), and the backward kernel reads them back
+                    // from its staging buffer as one ds_read_b128
+#if FL_XP_PAIRS
+                    cf* xo = a.Xp + ((size_t)u * 2 + grp) * (NI * LEN) + 2 * p;
+                    if (grp) {
 #pragma unroll
-                    for (int nn = 0; nn < NI; ++nn) st_nt(xo, 8u * (unsigned)(nn * LEN), c2(grp ? xm[nn] : xk[nn]));
+                        for (int j = 0; j < NI / 2; ++j) st_nt16(xo, 16u * (unsigned)(j * LEN), xm[2 * j], xm[2 * j + 1]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NI / 2; ++j) st_nt16(xo, 16u * (unsigned)(j * LEN), xk[2 * j], xk[2 * j + 1]);
+                    }
+#else
+                    cf* xo = a.Xp + ((size_t)u * 2 + grp) * (NI * LEN) + p;
+                    if (grp) {
+#pragma unroll
+                        for (int nn = 0; nn < NI; ++nn) st_nt(xo, 8u * (unsigned)(nn * LEN), c2(xm[nn]));
+                    } else {
+#pragma unroll
+                        for (int nn = 0; nn < NI; ++nn) st_nt(xo, 8u * (unsigned)(nn * LEN), c2(xk[nn]));
+                    }
+#endif
                 }
                 cf* zk_p = XI + yk_o + grp * MO * LENP;
                 cf* zm_p = zm_dst + (twin ? grp * MO * LENP : 0);
@@ -359,18 +474,20 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
                         ma_ = pfma(f2{h[1][m2][nn].x, h[1][m2][nn].x}, xm[nn], ma_);
                         mb_ = pfma(f2{h[1][m2][nn].y, h[1][m2][nn].y}, xm[nn], mb_);
                     }
-                    const f2 yk = f2{ka_.x - kb_.y, ka_.y + kb_.x}, ym = f2{ma_.x - mb_.y, ma_.y + mb_.x};
+                    const f2 yk = pk_add_i(ka_, kb_), ym = pk_add_i(ma_, mb_);
                     f2 zk, zm;
                     pre_pair(phv * yk, phv * ym, icw, nicw, zk, zm);
                     zk_p[m2 * LENP] = c2(zk);
                     zm_p[twin ? m2 * LENP : 0] = c2(zm);
                 }
             }
+            if (DBG) w_ph[0] += clock64() - t_last;     // own work of this wavefront in the step (before it waits at the barrier)
             lds_barrier();
             FL_STAMP(1)
             // ---- step B
             if (grp == 0) P4(selfm);
             else if (next) P1(selfm);
+            if (DBG) w_ph[1] += clock64() - t_last;
             lds_barrier();
             FL_STAMP(2)
             // ---- step C.  The forward side's own staging regions are free (its reads of step B are behind the barrier): the rows
@@ -381,6 +498,7 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
                 if (u + 2 < u_hi) fetch(u + 2);
                 P2(selfm);
             }
+            if (DBG) w_ph[2] += clock64() - t_last;
             lds_barrier();
             FL_STAMP(3)
         }
@@ -392,6 +510,11 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[2 + i] = t_ph[i];
     }
+    // own work per step of one wavefront of each group, three 21-bit fields (units of 16 cycles): A | B << 21 | C << 42
+    if (DBG && a.dbg_times && (tid == 0 || tid == 256))
+        a.dbg_times[(size_t)blockIdx.x * 8 + 6 + grp] = grp == 0 && a.spec_interior2 == 7
+            ? (q_ph[0] >> 4) | ((q_ph[1] >> 4) << 21) | ((q_ph[2] >> 4) << 42)       // tuning: P5's reads | butterflies | twiddles + stores
+            : (w_ph[0] >> 4) | ((w_ph[1] >> 4) << 21) | ((w_ph[2] >> 4) << 42);
 #undef FL_STAMP
 }
 
@@ -456,8 +579,9 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     cf* Yb = XF + 2 * UB;
     cf* stage_g = Yb + UB;                         // [DEPTH][SBG]
     cf* stage_x = stage_g + DEPTH * SBG;           // [DEPTH][SBX]
-    cf* tw = stage_x + DEPTH * SBX;
-    cf* ws = tw + LEN;
+    constexpr int TWP = tw_pitch(A), TWL = (B * TWP + 1) & ~1;
+    cf* tw = stage_x + DEPTH * SBX;                // W_LEN^(ka tb) at [tb][ka], pitch TWP
+    cf* ws = tw + TWL;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int grp = wave >> 2;
@@ -487,9 +611,15 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
     auto fetch_x = [&](int i, int cw) {  // X[n][the 64 pairs of wavefront cw] of its side of the unit's block
         const int b = b_lo + i;
         const unsigned sx_buf = sx_lds + (unsigned)((i % DEPTH) * SBX * 8);
+#if FL_XP_PAIRS
+        int pp = 64 * (cw & 3) + lane;           // a lane's 16 bytes: channels (2q, 2q + 1) of one bin pair
+        if (pp > LEN - 1) pp = LEN - 1;
+        const cf* src = a.Xp + (((size_t)r * a.Bn + b) * 2 + (cw >> 2)) * (NI * LEN) + 2 * pp;
+#else
         int pp = 64 * (cw & 3) + 2 * (lane & 31);
         if (pp > LEN - 2) pp = LEN - 2;
         const cf* src = a.Xp + (((size_t)r * a.Bn + b) * 2 + (cw >> 2)) * (NI * LEN) + (lane >> 5) * LEN + pp;
+#endif
 #pragma unroll
         for (int q = 0; q < NI / 2; ++q) dma16(src + q * (2 * LEN), sx_buf + (unsigned)(((cw * NI + 2 * q) * 64) * 8));
     };
@@ -522,7 +652,7 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
         fetch_g(0, wave & 3);
     }
     for (int j = tid; j < LEN; j += 512) {
-        tw[j] = a.W[a.n + a.L1 + j];
+        tw[(j / A) * TWP + j % A] = a.W[a.n + a.L1 + (j / A) * (j % A)];      // a thread's A first-stage twiddles are one run
         ws[j] = a.W[a.n + a.L1 + a.L2 + j];
     }
     const cf wr = a.W[r];
@@ -559,9 +689,19 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
         }
         f2 x[NI];
         {
+#if FL_XP_PAIRS
+            const f4* xs = reinterpret_cast<const f4*>(stage_x + (t % DEPTH) * SBX + (wave * NI) * 64) + lane;      // item t-2's region: [n/2][lane][n%2]
+#pragma unroll
+            for (int j = 0; j < NI / 2; ++j) {
+                const f4 q = xs[j * 64];
+                x[2 * j] = f2{q.x, q.y};
+                x[2 * j + 1] = f2{q.z, q.w};
+            }
+#else
             const cf* xs = stage_x + (t % DEPTH) * SBX + (wave * NI) * 64 + lane;      // item t-2's region
 #pragma unroll
             for (int nn = 0; nn < NI; ++nn) x[nn] = v2(xs[nn * 64]);
+#endif
         }
         if (x_now) {
             wait_lgkm0();                                        // the reads above have returned: the region may be refilled
@@ -571,11 +711,11 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
 #pragma unroll
             for (int m = 0; m < NOL; ++m) {
                 const f2 zk = v2(Yb[yk_o + m * LENP]), zm = v2(Yb[ym_o + m * LENP]);
-                const f2 Pp = f2{zk.x + zm.x, zk.y - zm.y}, D = f2{zk.x - zm.x, zk.y + zm.y};
+                const f2 Pp = add_pm(zk, zm), D = add_mp(zk, zm);
                 const f2 g = scv * (Pp + cmulc(D, iws, niws));
-                const f2 mg = f2{g.y, -g.x};                     // g conj(x) = Re(x) g + Im(x) (-i g)
+                // g conj(x) = Re(x) g + Im(x) (-i g): the quarter turn of g is the second multiply-add's operand selectors
 #pragma unroll
-                for (int nn = 0; nn < NI; ++nn) acc[m][nn] = pfma(f2{x[nn].y, x[nn].y}, mg, pfma(f2{x[nn].x, x[nn].x}, g, acc[m][nn]));
+                for (int nn = 0; nn < NI; ++nn) acc[m][nn] = fma_mi(x[nn], g, pfma(f2{x[nn].x, x[nn].x}, g, acc[m][nn]));
             }
         }
         // DEPTH 2: the rows of item t (requested in the last step 2, ahead of that step's spectrum pieces) have landed
@@ -603,7 +743,7 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
 #pragma unroll
                 for (int ta = 0; ta < A; ++ta) v[ta] = sp[ta * 64];
 #pragma unroll
-                for (int ka = 1; ka < A; ++ka) tt[ka] = tw[ka * (have ? tb : 0)];
+                for (int ka = 1; ka < A; ++ka) tt[ka] = tw[(have ? tb : 0) * TWP + ka];
                 if (DEPTH == 1 && t + 1 < n_it) {
                     wait_lgkm0();
                     fetch_g(t + 1, wave & 3);
@@ -708,7 +848,7 @@ static long walk_wgs(int L1, int Bn) {
 template <int A, int B, int NI, int NO, int OCC>
 static int launch_walk(const WalkArgs& a, hipStream_t st) {
     constexpr int LEN = A * B, LENP = walk_pitch(LEN), NCH = NI > NO ? NI : NO;
-    constexpr size_t lds = ((size_t)3 * 2 * NCH * LENP + 4 * A * 64 + 4 * LEN + 64) * sizeof(cf);
+    constexpr size_t lds = ((size_t)3 * 2 * NCH * LENP + 4 * A * 64 + ((B * tw_pitch(A) + 1) & ~1) + 3 * LEN + 64) * sizeof(cf);
     static_assert(lds <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     auto kern = spec_mid_walk<A, B, NI, NO, OCC>;
@@ -777,7 +917,7 @@ int fl_spec_gradh_walk_f32(const void* Sg, const void* Xp, void* dH_parts, long 
 #define FL_GRADH(NSC_, OCC_, DEPTH_)                                                                                             \
     {                                                                                                                            \
         constexpr int A = 16, B = 15, LEN = A * B, LENP = walk_pitch(LEN), NOL = 8 / NSC_;                                       \
-        constexpr size_t lds = ((size_t)3 * 2 * NOL * LENP + DEPTH_ * (((2 * B * NOL + 63) / 64) * A * 64 + 8 * 8 * 64) + 2 * LEN) * sizeof(cf); \
+        constexpr size_t lds = ((size_t)3 * 2 * NOL * LENP + DEPTH_ * (((2 * B * NOL + 63) / 64) * A * 64 + 8 * 8 * 64) + ((B * tw_pitch(A) + 1) & ~1) + LEN) * sizeof(cf); \
         static_assert(lds <= 160 * 1024, "LDS budget");                                                                          \
         const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * n_slices * NSC_);                                                    \
         auto kern = spec_gradh_walk<16, 15, 8, 8, NSC_, OCC_, DEPTH_>;                                                           \

@@ -92,12 +92,27 @@ print(f"spec_mid (no spectrum): median {t[0]:.1f} us, min {t[1]:.1f} us")
 # phase picture of the walking kernel: span per workgroup
 cus = torch.cuda.get_device_properties(0).multi_processor_count
 buf = torch.zeros(cus * 8, dtype=torch.int64, device=dev)
+buf2 = torch.zeros_like(buf)
+L.fl_debug_set_walk(1, 0, 0, buf2.data_ptr())
+L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Xp.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 7, 0, BND, ops._stream())
+torch.cuda.synchronize()
+L.fl_debug_set_walk(1, 0, 0, None)
 L.fl_debug_set_walk(1, 0, 0, buf.data_ptr())
 L.fl_spec_mid_walk_f32(S.data_ptr(), S2.data_ptr(), Xp.data_ptr(), Hp.data_ptr(), N * hp, hp, 0, W.data_ptr(), nfft, B, N, N, 1.0, 0, 0, BND, ops._stream())
 torch.cuda.synchronize()
 L.fl_debug_set_walk(1, 0, 0, None)
-tt = buf.view(-1, 8).cpu().double()
-tt = tt[tt[:, 1] > 0]
+w = buf2.view(-1, 8).cpu()
+w = w[w[:, 1] > 0][:, 6]
+print(f"   P5 of a group-0 wavefront: reads {((w & 0x1FFFFF) * 16).double().mean():8.0f}  butterflies {(((w >> 21) & 0x1FFFFF) * 16).double().mean():8.0f}"
+      f"  twiddles + stores {(((w >> 42) & 0x1FFFFF) * 16).double().mean():8.0f} cycles per workgroup")
+raw = buf.view(-1, 8).cpu()
+raw = raw[raw[:, 1] > 0]
+tt = raw.double()
+if len(tt):
+    for g, nm in ((0, "group 0 (P4, P5 + stores)"), (1, "group 1 (P1, fetch + P2)")):
+        w = raw[:, 6 + g]
+        print(f"   own work of a wavefront of {nm}: A {((w & 0x1FFFFF) * 16).double().mean():8.0f}  B {(((w >> 21) & 0x1FFFFF) * 16).double().mean():8.0f}"
+              f"  C {(((w >> 42) & 0x1FFFFF) * 16).double().mean():8.0f} cycles per workgroup")
 if len(tt):
     d = tt[:, 1] - tt[:, 0]
     print(f"walk: {len(tt)} workgroups, body cycles mean {d.mean():.0f} min {d.min():.0f} max {d.max():.0f}; span {(tt[:, 1].max() - tt[:, 0].min()):.0f}")
@@ -113,7 +128,7 @@ gH_ref = ops._gradh_launch(gY_ref.movedim(-1, 1), Xs_ref.movedim(-1, 1), False).
 gH_ref_p = ops._h_planar(gH_ref, True)
 # the pair-major spectrum against the stored one: unit (r, b), e = 0 -> bins r*L2 + p (row-major order)
 L1, L2 = nfft // 2 // 240, 240
-Xpv = Xp.view(L1 // 2 + 1, B, 2, N, L2)
+Xpv = Xp.view(L1 // 2 + 1, B, 2, N // 2, L2, 2).permute(0, 1, 2, 3, 5, 4).reshape(L1 // 2 + 1, B, 2, N, L2)     # [n/2][pair][n%2] -> [n][pair]
 Xs_rm = Xs_ref            # (B, N, M) row-major bin order
 for r in (1, 7, 57, 99):
     want = Xs_rm[:, :, r * L2:(r + 1) * L2]
