@@ -66,8 +66,19 @@ __global__ void __launch_bounds__(256) mean_square_kernel(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256) mean_square_final_kernel(const double* __restrict__ partial, int nblocks,
                                                                double inv_count, T* __restrict__ loss) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) s += partial[i];
+    // eight loads in flight per lane (a few thousand partials behind one workgroup: the round trips, not the adds, are the time);
+    // the order of the additions is fixed
+    double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < nblocks; i += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] += v[u];
+    }
+    for (int u = 0; i < nblocks; i += 256, ++u) q[u & 7] += partial[i];
+    double s = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     __shared__ double red[4];
@@ -172,6 +183,18 @@ int fl_mean_square_f32(const void* y, long rows, long cols, long pitch, void* lo
 }
 int fl_mean_square_f64(const void* y, long rows, long cols, long pitch, void* loss, void* scratch, void* stream) {
     return mean_square_impl<double>(y, rows, cols, pitch, loss, scratch, stream);
+}
+int fl_mean_square_final_f32(const void* parts, int n_parts, double inv_count, void* loss, void* stream) {
+    FL_REQUIRE(parts && loss && n_parts > 0, "mean_square_final: bad arguments");
+    hipLaunchKernelGGL((mean_square_final_kernel<float>), dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)parts, n_parts, inv_count, (float*)loss);
+    FL_CHECK_LAUNCH("mean_square_final");
+    return FL_OK;
+}
+int fl_mean_square_final_f64(const void* parts, int n_parts, double inv_count, void* loss, void* stream) {
+    FL_REQUIRE(parts && loss && n_parts > 0, "mean_square_final: bad arguments");
+    hipLaunchKernelGGL((mean_square_final_kernel<double>), dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)parts, n_parts, inv_count, (double*)loss);
+    FL_CHECK_LAUNCH("mean_square_final");
+    return FL_OK;
 }
 int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream) {
     return mean_square_bwd_impl<float>(y, gloss, gy, rows, cols, pitch, stream);

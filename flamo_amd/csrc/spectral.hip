@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
     }
     __syncthreads();
     real_t* yb = a.y + (size_t)b * a.t_len * a.G + g0;
+    real_t sq = 0;
     for (int item = threadIdx.x; item < A * VT; item += 256) {
         const int ka = item / VT, vv = item % VT;
         const int cl = vv >> a.cgs, gl = vv & (CG - 1);
@@ -198,8 +199,21 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
             if (a.env_log2 != 0.0) s *= env_at(a.env_log2, t);
             q.x *= s;
             q.y *= s;
-            if (t < a.t_lim) at(reinterpret_cast<real2*>(yb), RSZ * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par))) = q;
+            if (t < a.t_lim) {
+                at(reinterpret_cast<real2*>(yb), RSZ * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par))) = q;
+                sq += q.x * q.x + q.y * q.y;
+            }
         }
+    }
+    if (a.sumsq) {        // (workgroup-uniform) per-workgroup partial of sum y^2, combined in a fixed order by fl_mean_square_final_*
+        double d = (double)sq;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
+        __syncthreads();                          // the row buffer is free: its first words carry the four wavefront sums
+        double* red = reinterpret_cast<double*>(smem);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) a.sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -955,8 +969,27 @@ int FL_SPEC_FN(fl_spec_cols_fwd)(const void* x, int Bn, int t_len, int G, void* 
     return cols_launch(false, a, Bn, (hipStream_t)stream);
 }
 
+static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                         double env_log2, double* sumsq, void* stream);
 int FL_SPEC_FN(fl_spec_cols_inv)(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                          double env_log2, void* stream) {
+    return cols_inv_impl(S2, y, Bn, t_len, t_out, G, W, nfft, scale, env_log2, nullptr, stream);
+}
+int FL_SPEC_FN(fl_spec_cols_inv_sumsq)(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                               double env_log2, void* sumsq_parts, void* stream) {
+    FL_REQUIRE(sumsq_parts, "spec_cols_inv_sumsq: null pointer");
+    return cols_inv_impl(S2, y, Bn, t_len, t_out, G, W, nfft, scale, env_log2, (double*)sumsq_parts, stream);
+}
+int FL_SPEC_FN(fl_spec_cols_blocks)(int nfft, int Bn, int G) {      // workgroups of a column pass = entries of sumsq_parts
+    ColsArgs a = {};
+    static const real_t dummy = 0;
+    if (Bn <= 0) return 0;
+    if (cols_setup(a, nfft, Bn, 0, 0, G, &dummy, cols_vt(G))) return -1;
+    return Bn * a.nct * a.ngt;
+}
+}  // extern "C"
+static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                         double env_log2, double* sumsq, void* stream) {
     FL_REQUIRE(S2 && y, "spec_cols_inv: null pointer");
     FL_REQUIRE(reinterpret_cast<uintptr_t>(y) % (2 * RSZ) == 0, "spec_cols_inv: y must be aligned to two samples");
     FL_REQUIRE(t_out >= 0 && t_out <= t_len, "spec_cols_inv: t_out must be in [0, t_len]");
@@ -968,8 +1001,10 @@ int FL_SPEC_FN(fl_spec_cols_inv)(const void* S2, void* y, int Bn, int t_len, int
     a.S = (cf*)S2;
     a.scale = (real_t)scale;
     a.env_log2 = env_log2;
+    a.sumsq = sumsq;
     return cols_launch(true, a, Bn, (hipStream_t)stream);
 }
+extern "C" {
 
 int FL_SPEC_FN(fl_spec_mid)(const void* S, void* S2, void* Xs, long xs_b, long xs_n, const void* H, long hs_m, long hs_n, int conj_h,
                     const void* W, int nfft, int Bn, int NI, int NO, double spec_scale, int spec_interior2, int pre_half,

@@ -50,6 +50,8 @@ struct ColsArgs {
     int t_len, t_lim;
     real_t scale;
     double env_log2;
+    double* sumsq;        // inverse, optional: sumsq[workgroup] = sum of the squares of the samples this workgroup stored (the
+                          // objective's reduction rides in the pass that produces y: ops.mean_square never re-reads it)
 };
 
 // Global accesses as (workgroup-uniform base pointer) + (32-bit byte offset per lane): the address then costs one

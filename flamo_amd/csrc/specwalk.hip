@@ -555,6 +555,7 @@ struct GradhArgs {
     const cf* W;
     int n, L, L1, L2, Bn, NS;
     float scale_g;        // scale of the gradient's forward transform (the inverse transform's scale)
+    const float* out_scale;   // device scalar multiplied into dH on the way out, or null (the objective's 2 g / N: see ops.mean_square)
     int interior2_g;      // double its interior bins (irfft backward)
     long long* dbg_times; // tuning: 8 int64 per workgroup (begin, end, cycles in step 1, in step 2, per wavefront 0 / 1 / 4 / 7 of step 2)
 };
@@ -793,6 +794,13 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
         if (valid && !(grp && im == ik)) {
             cf* out = a.dH + (size_t)sl * a.ds_s;
             const unsigned bin = grp ? im : ik;
+            if (a.out_scale) {
+                const float os = *a.out_scale;
+#pragma unroll
+                for (int m = 0; m < NOL; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < NI; ++nn) acc[m][nn] *= os;
+            }
 #pragma unroll
             for (int m = 0; m < NOL; ++m) {
                 unsigned o = 8u * ((unsigned)(mo + m) * (unsigned)a.ds_m + bin);
@@ -898,8 +906,19 @@ int fl_spec_gradh_slices(int nfft, int Bn) {
     return ns < Bn ? ns : Bn;
 }
 
+static int gradh_walk_impl(const void* Sg, const void* Xp, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices, const void* W,
+                           int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g, const float* out_scale, void* stream);
 int fl_spec_gradh_walk_f32(const void* Sg, const void* Xp, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices, const void* W,
                            int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g, void* stream) {
+    return gradh_walk_impl(Sg, Xp, dH_parts, ds_s, ds_m, ds_n, n_slices, W, nfft, Bn, NI, NO, scale_g, interior2_g, nullptr, stream);
+}
+int fl_spec_gradh_walk_scaled_f32(const void* Sg, const void* Xp, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices, const void* W,
+                                  int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g, const void* out_scale, void* stream) {
+    return gradh_walk_impl(Sg, Xp, dH_parts, ds_s, ds_m, ds_n, n_slices, W, nfft, Bn, NI, NO, scale_g, interior2_g, (const float*)out_scale, stream);
+}
+}  // extern "C"
+static int gradh_walk_impl(const void* Sg, const void* Xp, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices, const void* W,
+                           int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g, const float* out_scale, void* stream) {
     FL_REQUIRE(Sg && Xp && dH_parts && W, "spec_gradh_walk: null pointer");
     FL_REQUIRE(n_slices >= 1 && n_slices <= (Bn > 0 ? Bn : 1), "spec_gradh_walk: slices must be in [1, batch]");
     FL_REQUIRE(reinterpret_cast<uintptr_t>(Sg) % 16 == 0 && reinterpret_cast<uintptr_t>(Xp) % 16 == 0, "spec_gradh_walk: scratch arrays must be 16-byte aligned");
@@ -909,7 +928,7 @@ int fl_spec_gradh_walk_f32(const void* Sg, const void* Xp, void* dH_parts, long 
     if (rc) return rc;
     a.Sg = (const cf*)Sg; a.Xp = (const cf*)Xp; a.dH = (cf*)dH_parts; a.ds_s = ds_s; a.ds_m = ds_m; a.ds_n = ds_n;
     a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn; a.NS = n_slices;
-    a.scale_g = (float)scale_g; a.interior2_g = interior2_g; a.dbg_times = g_walk_times;
+    a.scale_g = (float)scale_g; a.interior2_g = interior2_g; a.dbg_times = g_walk_times; a.out_scale = out_scale;
     FL_REQUIRE((size_t)NO * (size_t)ds_m * 8ull < (1ull << 32), "spec_gradh_walk: a partial plane set exceeds 32-bit offsets");
     const int P = a.L1 / 2 + 1;
     hipStream_t st = (hipStream_t)stream;
@@ -943,6 +962,7 @@ int fl_spec_gradh_walk_f32(const void* Sg, const void* Xp, void* dH_parts, long 
     FL_CHECK_LAUNCH("spec_gradh_walk");
     return FL_OK;
 }
+extern "C" {
 
 int fl_sum_parts_c64(const void* parts, long part_stride, int n_parts, void* out, long n, void* stream) {
     FL_REQUIRE(parts && out && n_parts >= 1 && n >= 0, "sum_parts: bad arguments");

@@ -792,15 +792,24 @@ def _spec_mid(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, want_inverse, spec_sca
     return S2, Xs
 
 
-def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2):
+def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2, want_sumsq=False):
+    """-> y (B, t_len, G); with want_sumsq also the per-workgroup partial sums of y^2 (double) the same launch leaves behind"""
     alloc = torch.zeros if t_len > t_out else torch.empty
     real = _rdtype(S2)
     y = alloc((B, t_len, G), dtype=real, device=S2.device)
+    parts = None
     with kernel_timer.span("spec_cols_inv"):
-        _lib.check(_spec_fn("fl_spec_cols_inv", real)(S2.data_ptr(), y.data_ptr(), B, t_len, t_out, G,
-                                                      twiddles(nfft, real, S2.device).data_ptr(), nfft, scale, env_log2,
-                                                      _stream()), "spec_cols_inv")
-    return y
+        if want_sumsq:
+            nblk = int(_spec_fn("fl_spec_cols_blocks", real)(nfft, B, G))
+            parts = torch.empty(max(nblk, 1), dtype=torch.float64, device=S2.device)
+            _lib.check(_spec_fn("fl_spec_cols_inv_sumsq", real)(S2.data_ptr(), y.data_ptr(), B, t_len, t_out, G,
+                                                                twiddles(nfft, real, S2.device).data_ptr(), nfft, scale, env_log2,
+                                                                parts.data_ptr(), _stream()), "spec_cols_inv_sumsq")
+        else:
+            _lib.check(_spec_fn("fl_spec_cols_inv", real)(S2.data_ptr(), y.data_ptr(), B, t_len, t_out, G,
+                                                          twiddles(nfft, real, S2.device).data_ptr(), nfft, scale, env_log2,
+                                                          _stream()), "spec_cols_inv")
+    return (y, parts) if want_sumsq else y
 
 
 # Batch-walking row kernels (csrc/specwalk.hip): one workgroup per CU keeps the row pair's response slice in registers and
@@ -854,8 +863,9 @@ def _spec_mid_walk(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, spec_scale, inter
     return S2, Xp
 
 
-def _spec_gradh_walk(Sg, Xp, B, NI, NO, nfft, scale_g):
-    """dL/dH (M, NO, NI) view, row-major bin order, from the gradient's scratch rows and the pair-major spectrum"""
+def _spec_gradh_walk(Sg, Xp, B, NI, NO, nfft, scale_g, out_scale=None):
+    """dL/dH (M, NO, NI) view, row-major bin order, from the gradient's scratch rows and the pair-major spectrum;
+    out_scale: float32 device scalar multiplied in on the way out"""
     dev = Sg.device
     L = _lib.lib()
     M = nfft // 2 + 1
@@ -863,8 +873,9 @@ def _spec_gradh_walk(Sg, Xp, B, NI, NO, nfft, scale_g):
     ns = int(L.fl_spec_gradh_slices(nfft, B))
     parts = torch.empty((ns, NO, NI, P), dtype=torch.complex64, device=dev)
     with kernel_timer.span("spec_gradh_walk"):
-        _lib.check(L.fl_spec_gradh_walk_f32(Sg.data_ptr(), Xp.data_ptr(), parts.data_ptr(), NO * NI * P, NI * P, P, ns,
-                                            twiddles(nfft, torch.float32, dev).data_ptr(), nfft, B, NI, NO, scale_g, 1, _stream()),
+        _lib.check(L.fl_spec_gradh_walk_scaled_f32(Sg.data_ptr(), Xp.data_ptr(), parts.data_ptr(), NO * NI * P, NI * P, P, ns,
+                                                   twiddles(nfft, torch.float32, dev).data_ptr(), nfft, B, NI, NO, scale_g, 1,
+                                                   None if out_scale is None else out_scale.data_ptr(), _stream()),
                    "spec_gradh_walk")
     if ns == 1:
         out = parts[0]
@@ -898,16 +909,27 @@ class _SpectralApply(torch.autograd.Function):
             S2, Xs = _spec_mid_walk(S, B, NI, NO, nfft, Hp, False, ctx.needs_input_grad[1], scale_f, 0, 0)
         else:
             S2, Xs = _spec_mid(S, B, NI, NO, nfft, Hp, False, ctx.needs_input_grad[1], True, scale_f, 0, 0)
-        y = _spec_cols_inv(S2, B, nfft, nfft, NO, nfft, scale_i, env_i)
+        y, parts = _spec_cols_inv(S2, B, nfft, nfft, NO, nfft, scale_i, env_i, want_sumsq=True)
         ctx.save_for_backward(Hp, *([Xs] if Xs is not None else []))
         ctx.cfg = (nfft, scale_f, env_f, scale_i, env_i, T, NI, NO, walk)
+        # what an objective computed from y alone can reuse (mean_square): the partial sums the inverse pass left behind, and
+        # everything the backward pass needs -- see _SpectralMeanSquare
+        y._flamo_sa = _SpectralTag(x, Hrm, Hp, Xs, ctx.cfg, parts, y._version)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         Hp, *kept = ctx.saved_tensors
-        nfft, scale_f, env_f, scale_i, env_i, T, NI, NO, walk = ctx.cfg
-        need_x, need_h = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        return _SpectralApply._backward(ctx.cfg, Hp, kept[0] if kept else None, ctx.needs_input_grad[0], ctx.needs_input_grad[1], gy, None) \
+            + (None, None, None, None, None)
+
+    @staticmethod
+    def _backward(cfg, Hp, Xkept, need_x, need_h, gy, out_scale):
+        """Gradients (gx, gH) for the output gradient gy -- or, with out_scale (a float device scalar c), for c * gy without
+        forming it: the pipeline is linear, so the factor is applied where the results are small (in the walking kernel's
+        epilogue for dL/dH)."""
+        kept = [Xkept]
+        nfft, scale_f, env_f, scale_i, env_i, T, NI, NO, walk = cfg
         g = gy.contiguous()
         if g.data_ptr() % (2 * g.element_size()):
             g = g.clone()
@@ -917,7 +939,7 @@ class _SpectralApply(torch.autograd.Function):
         gx = gH = None
         if walk:
             if need_h:
-                gH = _spec_gradh_walk(Sg, kept[0], B, NI, NO, nfft, scale_i)
+                gH = _spec_gradh_walk(Sg, kept[0], B, NI, NO, nfft, scale_i, None if out_scale is None else out_scale.float())
             if need_x:
                 # rfft' : g_x[t] = scale_f e_f(t) Re sum_k g_X[k] exp(+j w_k t), g_X = H^H g_Y
                 if _walk_applies(nfft, B, NO, NI):
@@ -925,15 +947,55 @@ class _SpectralApply(torch.autograd.Function):
                 else:
                     S3, _ = _spec_mid(Sg, B, NO, NI, nfft, Hp, True, False, True, scale_i, 1, 1)
                 gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f, env_f)
-            return gx, gH, None, None, None, None, None
+                if out_scale is not None:
+                    gx = gx * out_scale.to(gx.dtype)
+            return gx, gH
         # rfft' : g_x[t] = scale_f e_f(t) Re sum_k g_X[k] exp(+j w_k t), g_X = H^H g_Y -- an inverse transform with halved interior bins
         S3, gYs = _spec_mid(Sg, B, NO, NI if need_x else NO, nfft, Hp if need_x else None, True, need_h, need_x, scale_i, 1, 1)
         if need_x:
             gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f, env_f)
+            if out_scale is not None:
+                gx = gx * out_scale.to(gx.dtype)
         if need_h:
             Xs = kept[0]
             gH = _gradh_launch(gYs.movedim(-1, 1), Xs.movedim(-1, 1), False).movedim(-1, 0)
-        return gx, gH, None, None, None, None, None
+            if out_scale is not None:
+                gH = gH * out_scale.to(gH.real.dtype)
+        return gx, gH
+
+
+class _SpectralTag:
+    """Rides on the tensor _SpectralApply returns (attribute ``_flamo_sa``): the inputs and kept arrays of that evaluation."""
+    __slots__ = ("x", "Hrm", "Hp", "Xs", "cfg", "parts", "version")
+
+    def __init__(self, x, Hrm, Hp, Xs, cfg, parts, version):
+        self.x, self.Hrm, self.Hp, self.Xs, self.cfg, self.parts, self.version = x, Hrm, Hp, Xs, cfg, parts, version
+
+
+class _SpectralMeanSquare(torch.autograd.Function):
+    """mean(y^2) of y = spectral_apply(x, H) as ONE node over (x, H): the value comes from the partial sums the inverse column
+    pass left behind (no pass over y), and the backward pass -- g_y = (2 g / N) y, a multiple of y itself -- runs the pipeline's
+    backward ON y with the factor applied to its small results: neither the objective's read of y nor the read + write that
+    forms g_y happen (3 of the step's 15.5 signal-sized passes at BASELINE configs[1]).  The tensor y stays a normal
+    output of its own node: whatever else consumes it differentiates through that node as before."""
+
+    @staticmethod
+    def forward(ctx, x, Hrm, y, tag):
+        real = y.dtype
+        loss = torch.empty((), dtype=real, device=y.device)
+        fn = _lib.lib().fl_mean_square_final_f32 if real == torch.float32 else _lib.lib().fl_mean_square_final_f64
+        with kernel_timer.span("mean_square_final"):
+            _lib.check(fn(tag.parts.data_ptr(), tag.parts.numel(), 1.0 / y.numel(), loss.data_ptr(), _stream()), "mean_square_final")
+        ctx.save_for_backward(y, tag.Hp, *([tag.Xs] if tag.Xs is not None else []))
+        ctx.cfg = tag.cfg
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        y, Hp, *kept = ctx.saved_tensors
+        c = (gloss.to(y.dtype) * (2.0 / y.numel())).reshape(())          # device scalar in the pipeline's precision
+        gx, gH = _SpectralApply._backward(ctx.cfg, Hp, kept[0] if kept else None, ctx.needs_input_grad[0], ctx.needs_input_grad[1], y, c)
+        return gx, gH, None, None
 
 
 def spectral_apply(x: torch.Tensor, Hrm: torch.Tensor, nfft: int, norm_f: str = "backward", norm_i: str = "backward",
@@ -2121,7 +2183,14 @@ class _MeanSquare(torch.autograd.Function):
 def mean_square(y: torch.Tensor) -> torch.Tensor:
     """(y ** 2).mean() of a real tensor in one streaming pass each way (forward: one read of y;
     backward: one read + one write), in whatever layout y is stored."""
+    tag = getattr(y, "_flamo_sa", None)
+    if FUSE_OBJECTIVE and tag is not None and tag.parts is not None and y._version == tag.version and torch.is_grad_enabled() \
+            and (tag.x.requires_grad or tag.Hrm.requires_grad) and (tag.Xs is not None or not tag.Hrm.requires_grad):
+        return _SpectralMeanSquare.apply(tag.x, tag.Hrm, y.detach(), tag)
     return _MeanSquare.apply(y)
+
+
+FUSE_OBJECTIVE = True      # mean_square(spectral_apply(...)) as one node (see _SpectralMeanSquare); False: always the two streaming passes
 
 
 # ----------------------------------------------------------------------------- orthogonal parameter map

@@ -171,6 +171,11 @@ int fl_spec_mid_walk_f32(const void* S, void* S2, void* Xp, const void* H, long 
 int fl_spec_gradh_slices(int nfft, int Bn);
 int fl_spec_gradh_walk_f32(const void* Sg, const void* Xp, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices, const void* W,
                            int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g, void* stream);
+/* the same with dH multiplied by the device scalar out_scale[0] (float) on its way out: the factor 2 g / N of an objective
+ * mean(y^2) whose gradient g_y = (2 g / N) y is never materialised -- K1 runs on y itself (ops.mean_square) */
+int fl_spec_gradh_walk_scaled_f32(const void* Sg, const void* Xp, void* dH_parts, long ds_s, long ds_m, long ds_n, int n_slices,
+                                  const void* W, int nfft, int Bn, int NI, int NO, double scale_g, int interior2_g,
+                                  const void* out_scale, void* stream);
 /* out[j] = sum_{s < n_parts} parts[s*part_stride + j], j < n complex values (16-byte aligned, n and part_stride even) */
 int fl_sum_parts_c64(const void* parts, long part_stride, int n_parts, void* out, long n, void* stream);
 /* tuning hook: mode 0 switches the walking kernels off (fl_spec_walk_supports -> 0); wgs / slices override the forward
@@ -179,6 +184,12 @@ int fl_debug_set_walk(int mode, int wgs, int slices, void* times);
 /* K3: y[b][t][g] = scale * e(t) * (unnormalised inverse transform of S2), t < t_out <= t_len; y: real (Bn, t_len, G) */
 int fl_spec_cols_inv_f32(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                          double env_log2, void* stream);
+/* K3 that also leaves sumsq_parts[w] = sum of the squares of the samples workgroup w stored (double; fl_spec_cols_blocks
+ * entries, every one written): the reduction of an objective mean(y^2) -- trainer.py:177-190 with a squared-error criterion --
+ * rides in the pass that produces y; fl_mean_square_final_* combines the partials in a fixed order */
+int fl_spec_cols_inv_sumsq_f32(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                               double env_log2, void* sumsq_parts, void* stream);
+int fl_spec_cols_blocks_f32(int nfft, int Bn, int G);
 /* per plane: dst[i] = src[k(i)] (inverse = 0, natural -> row-major bin order) or dst[k(i)] = src[i] (inverse = 1) */
 int fl_permute_bins_c64(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
                         void* stream);
@@ -194,6 +205,9 @@ int fl_spec_mid_f64(const void* S, void* S2, void* Xs, long xs_b, long xs_n, con
                     void* stream);
 int fl_spec_cols_inv_f64(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                          double env_log2, void* stream);
+int fl_spec_cols_inv_sumsq_f64(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                               double env_log2, void* sumsq_parts, void* stream);
+int fl_spec_cols_blocks_f64(int nfft, int Bn, int G);
 int fl_permute_bins_c128(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
                          void* stream);
 
@@ -491,6 +505,9 @@ int fl_debug_set_solve_variant(int variant);
 size_t fl_mean_square_scratch_bytes(void);
 int fl_mean_square_f32(const void* y, long rows, long cols, long pitch, void* loss, void* scratch, void* stream);
 int fl_mean_square_f64(const void* y, long rows, long cols, long pitch, void* loss, void* scratch, void* stream);
+/* loss[0] = inv_count * sum of n_parts partial sums (double), added in a fixed order by one workgroup */
+int fl_mean_square_final_f32(const void* parts, int n_parts, double inv_count, void* loss, void* stream);
+int fl_mean_square_final_f64(const void* parts, int n_parts, double inv_count, void* loss, void* stream);
 int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
 int fl_mean_square_bwd_f64(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
 

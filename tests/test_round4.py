@@ -90,3 +90,45 @@ def test_shell_at_a_length_without_a_plan(gpu, dt, nfft):
     check_close(f"shell_noplan/{nfft}/{str(dt)[6:]}/y", y.detach().cpu(), yr.detach(), max(tol, 2e-6))
     check_close(f"shell_noplan/{nfft}/{str(dt)[6:]}/gW", gW.cpu(), gWr, max(tol, 2e-6) * 5)
     check_close(f"shell_noplan/{nfft}/{str(dt)[6:]}/gG", gG.cpu(), gGr, 1e-3)       # float32 section buffers (dsp.py:2573-2585)
+
+
+@pytest.mark.parametrize("nfft,N,B", [(96000, 8, 5), (96000, 8, 2), (4096, 4, 3), (192000, 16, 2)])
+def test_objective_rides_in_the_pipeline(gpu, dt, nfft, N, B):
+    """ops.mean_square(model(x)) as one node over (x, H) (value from the inverse column pass's partial sums, gradient by running
+    the pipeline's backward on y itself) against the two streaming passes: loss, parameter gradients and input gradient; and y
+    used a second time (its own node keeps working beside the fused one).  Walking kernels (batch 5), the one-item row kernel
+    (batch 2), a small plan, 16 channels."""
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    torch.manual_seed(nfft + N + B)
+    kw = dict(nfft=nfft, alias_decay_db=0.0, device=gpu, dtype=dt)
+    mat = dsp.Matrix(size=(N, N), requires_grad=True, **kw)
+    geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+    model = system.Shell(system.Series(OrderedDict(mix=mat, eq=geq)), dsp.FFT(nfft, dtype=dt), dsp.iFFT(nfft, dtype=dt))
+    x = torch.randn(B, nfft, N, device=gpu, dtype=dt).requires_grad_(True)
+    w = torch.randn(B, nfft, N, device=gpu, dtype=dt)
+    plist = [x, mat.param, geq.param]
+
+    def run(fuse, second_use):
+        ops.FUSE_OBJECTIVE = fuse
+        try:
+            y = model(x)
+            if getattr(y, "_flamo_sa", None) is None:               # not the three-launch route at this shape / precision
+                pytest.skip("layered route: nothing to fuse")
+            loss = 3.0 * ops.mean_square(y)
+            if second_use:
+                loss = loss + (y * w).sum() * 1e-6
+            return loss.detach(), torch.autograd.grad(loss, plist)
+        finally:
+            ops.FUSE_OBJECTIVE = True
+    tol = 1e-12 if dt == F64 else 2e-6
+    for second_use in (False, True):
+        l0, g0 = run(False, second_use)
+        l1, g1 = run(True, second_use)
+        assert relerr(l1, l0) < tol, (second_use, relerr(l1, l0))
+        for a, b, k in zip(g1, g0, ("gx", "gW", "gG")):
+            assert relerr(a, b) < 10 * tol, (second_use, k, relerr(a, b))
+    # the objective of a tensor that was modified after the pipeline produced it: the generic passes
+    y = model(x)
+    y.mul_(2.0)
+    assert relerr(ops.mean_square(y).detach(), (y.detach() ** 2).mean()) < (1e-12 if dt == F64 else 1e-6)
