@@ -660,14 +660,45 @@ __global__ void __launch_bounds__(256) permute_bins_kernel(const cf* __restrict_
 }  // namespace FL_SPEC_NS
 #ifndef FL_F64
 struct PlanEntry { int nfft, L1, L2, lean; };
+// the tuned lengths: every channel combination and the tuning variants exist for the three BASELINE lengths
 static const PlanEntry kPlans[] = {{96000, 200, 240, 0}, {192000, 300, 320, 0}, {384000, 400, 480, 0},
                                    {2048, 32, 32, 1},    {4096, 32, 64, 1},     {8192, 64, 64, 1},     {16384, 64, 128, 1},
                                    {32768, 128, 128, 1}, {65536, 128, 256, 1},  {131072, 256, 256, 1}, {48000, 150, 160, 1},
                                    {144000, 225, 320, 1}};
+// Every other length is PLANNED from the factorisation: nfft/2 = L1 L2 with L1 among the column lengths and L2 among the row
+// lengths that are instantiated (cols_launch / fl_spec_mid below; each a product of two in-register FFT sizes) -- 32000
+// (examples/e4_recursion_nn.py:349: 50 x 320), 44100 (441 x 50), 88200 (441 x 100), 64000, 24000, 16000, 160000, 256000 ...
+// (a row length is 2^k B, k <= 5: the row kernel's threads divide evenly over the k_a of its second stage)
+// Preference: the row length nearest to 256 (a row pair of all channels in LDS, 240..256 bin pairs for a workgroup's threads),
+// rows not shorter than columns.  Planned lengths take the equal-channel kernels.
+static const int kColLens[] = {32, 50, 64, 75, 100, 125, 128, 150, 200, 225, 250, 256, 300, 400, 441};
+static const int kRowLens[] = {32, 50, 64, 100, 128, 160, 200, 240, 256, 320, 400, 480};
 static const PlanEntry* plan_of(int nfft) {
     for (const PlanEntry& p : kPlans)
         if (p.nfft == nfft) return &p;
     return nullptr;
+}
+
+static bool plan_search(int nfft, int& L1, int& L2) {
+    if (nfft < 2 || (nfft & 1)) return false;
+    const int L = nfft / 2;
+    double best = 1e30;
+    bool found = false;
+    for (int l2 : kRowLens) {
+        if (L % l2) continue;
+        const int l1 = L / l2;
+        bool have = false;
+        for (int c : kColLens) have = have || c == l1;
+        if (!have) continue;
+        double cost = fabs(log2((double)l2 / 256.0)) + (l2 < l1 ? 1.0 : 0.0);
+        if (cost < best) {
+            best = cost;
+            L1 = l1;
+            L2 = l2;
+            found = true;
+        }
+    }
+    return found;
 }
 
 int spec_plan(int nfft, int& L1, int& L2) {
@@ -676,7 +707,8 @@ int spec_plan(int nfft, int& L1, int& L2) {
         L2 = p->L2;
         return FL_OK;
     }
-    set_error("spectral: nfft=%d has no fused plan", nfft);
+    if (plan_search(nfft, L1, L2)) return FL_OK;
+    set_error("spectral: nfft=%d has no fused plan (nfft/2 is not a product of an instantiated column and row length)", nfft);
     return FL_ERR_UNSUPPORTED;
 }
 
@@ -756,6 +788,12 @@ static int cols_launch(bool inverse, const ColsArgs& a, int Bn, hipStream_t st) 
         case 150: launch_cols<10, 15, true>(inverse, a, (unsigned)nblk, st); break;
         case 225: launch_cols<15, 15, true>(inverse, a, (unsigned)nblk, st); break;
         case 256: launch_cols<16, 16, true>(inverse, a, (unsigned)nblk, st); break;
+        case 50: launch_cols<2, 25, true>(inverse, a, (unsigned)nblk, st); break;
+        case 75: launch_cols<5, 15, true>(inverse, a, (unsigned)nblk, st); break;
+        case 100: launch_cols<4, 25, true>(inverse, a, (unsigned)nblk, st); break;
+        case 125: launch_cols<5, 25, true>(inverse, a, (unsigned)nblk, st); break;
+        case 250: launch_cols<10, 25, true>(inverse, a, (unsigned)nblk, st); break;
+        case 441: launch_cols<21, 21, true>(inverse, a, (unsigned)nblk, st); break;
         default: set_error("spectral cols: unsupported column length %d", a.L1); return FL_ERR_UNSUPPORTED;
     }
     FL_CHECK_LAUNCH(inverse ? "spec_cols_inv" : "spec_cols_fwd");
@@ -933,6 +971,11 @@ int fl_spec_supports(int nfft, int n_in, int n_out) {
             v = 64 * 1024;
         lds_limit = v;
     }
+    // a column-pass workgroup owns CT = VT / min(G, VT) columns of all G channels: CT must divide the row length
+    for (int G : {n_in, n_out}) {
+        const int vt = cols_vt(G), ct = vt / (G < vt ? G : vt);
+        if (l2 % ct) return 0;
+    }
     const int nch = n_in > n_out ? n_in : n_out;
     const size_t need = ((size_t)2 * nch * (l2 | 1) + 2 * (size_t)l2 + 64 + nch) * sizeof(cf);
     if (need > (size_t)lds_limit) return 0;
@@ -1040,6 +1083,10 @@ int FL_SPEC_FN(fl_spec_mid)(const void* S, void* S2, void* Xs, long xs_b, long x
         case 128: rc = launch_mid_lean<16, 8>(a, NI, NO, st); break;
         case 160: rc = launch_mid_lean<16, 10>(a, NI, NO, st); break;
         case 256: rc = launch_mid_lean<16, 16>(a, NI, NO, st); break;
+        case 50: rc = launch_mid_lean<2, 25>(a, NI, NO, st); break;
+        case 100: rc = launch_mid_lean<4, 25>(a, NI, NO, st); break;
+        case 200: rc = launch_mid_lean<8, 25>(a, NI, NO, st); break;
+        case 400: rc = launch_mid_lean<16, 25>(a, NI, NO, st); break;
         default: set_error("spec_mid: unsupported row length %d", a.L2); return FL_ERR_UNSUPPORTED;
     }
     if (rc) return rc;

@@ -853,19 +853,44 @@ static long walk_wgs(int L1, int Bn) {
     return g;
 }
 
+// The kernels of this file ask for more dynamic LDS than the default 64 KB: the attribute is per function AND per device, so
+// it is set once per (kernel, device) -- a second GPU used by the same process gets its own -- and its result is checked
+// (a part with less LDS per workgroup fails here with a message, not at the launch).
+constexpr int kMaxDevices = 64;
+static int ensure_lds(const void* kern, size_t lds, bool* done /* [kMaxDevices] */) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (done[dev]) return FL_OK;
+    const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        set_error("walking kernels: %zu bytes of LDS per workgroup are not available on device %d (%s)", lds, dev, hipGetErrorString(e));
+        return FL_ERR_UNSUPPORTED;
+    }
+    done[dev] = true;
+    return FL_OK;
+}
+static size_t device_lds_limit() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 64 * 1024;
+    return (size_t)v;
+}
+
+template <int A, int B, int NI, int NO>
+constexpr size_t walk_lds_bytes() {
+    constexpr int LEN = A * B, LENP = walk_pitch(LEN), NCH = NI > NO ? NI : NO;
+    return ((size_t)3 * 2 * NCH * LENP + 4 * A * 64 + ((B * tw_pitch(A) + 1) & ~1) + 3 * LEN + 64) * sizeof(cf);
+}
+
 template <int A, int B, int NI, int NO, int OCC>
 static int launch_walk(const WalkArgs& a, hipStream_t st) {
-    constexpr int LEN = A * B, LENP = walk_pitch(LEN), NCH = NI > NO ? NI : NO;
-    constexpr size_t lds = ((size_t)3 * 2 * NCH * LENP + 4 * A * 64 + ((B * tw_pitch(A) + 1) & ~1) + 3 * LEN + 64) * sizeof(cf);
+    constexpr size_t lds = walk_lds_bytes<A, B, NI, NO>();
     static_assert(lds <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
+    static bool done[kMaxDevices] = {}, done_dbg[kMaxDevices] = {};
     auto kern = spec_mid_walk<A, B, NI, NO, OCC>;
     auto kern_dbg = spec_mid_walk<A, B, NI, NO, OCC, true>;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_dbg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    int rc = ensure_lds(reinterpret_cast<const void*>(kern), lds, done);
+    if (rc) return rc;
+    if (a.dbg_times && (rc = ensure_lds(reinterpret_cast<const void*>(kern_dbg), lds, done_dbg))) return rc;
     const long g = walk_wgs(a.L1, a.Bn);
     if (a.dbg_times) hipLaunchKernelGGL(kern_dbg, dim3((unsigned)g), dim3(512), lds, st, a);
     else hipLaunchKernelGGL(kern, dim3((unsigned)g), dim3(512), lds, st, a);
@@ -887,10 +912,21 @@ int fl_debug_set_walk(int mode, int wgs, int slices, void* times) {
     return FL_OK;
 }
 
+// Shapes of the walking kernels: one bin pair per thread pair (row length <= 256), every FFT stage of a unit within one group
+// of 256 threads (2 B N <= 256 and 2 A N <= 256), the row pair's response slice 2 L2 N_out N_in values in half of the CU's
+// register file (<= 128 registers per thread: N_out N_in <= 64).  Instantiated: the 16 x 15 rows (nfft = 96000 and every planned
+// length with 240-bin rows) and the 16 x 16 rows (65536, 131072, 64000, 128000 ...), 2 / 4 / 8 channels on either side.  16
+// channels do not fit (the slice alone would be 512 registers); row lengths 320 / 480 (nfft = 192000 / 384000) would need two
+// bin pairs per thread pair: those stay with spec_mid.
+static bool walk_shape(int l2, int n_in, int n_out) {
+    auto ch = [](int c) { return c == 2 || c == 4 || c == 8; };
+    return (l2 == 240 || l2 == 256) && ch(n_in) && ch(n_out);
+}
 int fl_spec_walk_supports(int nfft, int n_in, int n_out) {
     int l1, l2;
     if (!g_walk || spec_plan(nfft, l1, l2) != FL_OK) return 0;
-    return l2 == 240 && n_in == 8 && n_out == 8;
+    if (!walk_shape(l2, n_in, n_out)) return 0;
+    return walk_lds_bytes<16, 16, 8, 8>() <= device_lds_limit();
 }
 
 int fl_spec_gradh_slices(int nfft, int Bn) {
@@ -932,33 +968,50 @@ static int gradh_walk_impl(const void* Sg, const void* Xp, void* dH_parts, long 
     FL_REQUIRE((size_t)NO * (size_t)ds_m * 8ull < (1ull << 32), "spec_gradh_walk: a partial plane set exceeds 32-bit offsets");
     const int P = a.L1 / 2 + 1;
     hipStream_t st = (hipStream_t)stream;
-    if (a.L2 == 240 && NI == 8 && NO == 8) {
-#define FL_GRADH(NSC_, OCC_, DEPTH_)                                                                                             \
+    int lrc = FL_ERR_UNSUPPORTED;
+#define FL_GRADH(A_, B_, NI_, NO_, NSC_, OCC_, DEPTH_)                                                                            \
     {                                                                                                                            \
-        constexpr int A = 16, B = 15, LEN = A * B, LENP = walk_pitch(LEN), NOL = 8 / NSC_;                                       \
-        constexpr size_t lds = ((size_t)3 * 2 * NOL * LENP + DEPTH_ * (((2 * B * NOL + 63) / 64) * A * 64 + 8 * 8 * 64) + ((B * tw_pitch(A) + 1) & ~1) + LEN) * sizeof(cf); \
+        constexpr int LEN = A_ * B_, LENP = walk_pitch(LEN), NOL = NO_ / NSC_;                                                   \
+        constexpr size_t lds = ((size_t)3 * 2 * NOL * LENP + DEPTH_ * (((2 * B_ * NOL + 63) / 64) * A_ * 64 + 8 * NI_ * 64) +    \
+                                ((B_ * tw_pitch(A_) + 1) & ~1) + LEN) * sizeof(cf);                                              \
         static_assert(lds <= 160 * 1024, "LDS budget");                                                                          \
         const unsigned nblk = (unsigned)(cdiv_i(P, 8) * 8 * n_slices * NSC_);                                                    \
-        auto kern = spec_gradh_walk<16, 15, 8, 8, NSC_, OCC_, DEPTH_>;                                                           \
-        auto kern_dbg = spec_gradh_walk<16, 15, 8, 8, NSC_, OCC_, DEPTH_, true>;                                                 \
-        static bool attr_set = false;                                                                                            \
-        if (!attr_set) {                                                                                                         \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_dbg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            attr_set = true;                                                                                                     \
+        auto kern = spec_gradh_walk<A_, B_, NI_, NO_, NSC_, OCC_, DEPTH_>;                                                       \
+        auto kern_dbg = spec_gradh_walk<A_, B_, NI_, NO_, NSC_, OCC_, DEPTH_, true>;                                             \
+        static bool done[kMaxDevices] = {}, done_dbg[kMaxDevices] = {};                                                          \
+        lrc = ensure_lds(reinterpret_cast<const void*>(kern), lds, done);                                                        \
+        if (!lrc && a.dbg_times) lrc = ensure_lds(reinterpret_cast<const void*>(kern_dbg), lds, done_dbg);                       \
+        if (!lrc) {                                                                                                              \
+            if (a.dbg_times) hipLaunchKernelGGL(kern_dbg, dim3(nblk), dim3(512), lds, st, a);                                    \
+            else hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, a);                                                    \
         }                                                                                                                        \
-        if (a.dbg_times) hipLaunchKernelGGL(kern_dbg, dim3(nblk), dim3(512), lds, st, a);                                        \
-        else hipLaunchKernelGGL(kern, dim3(nblk), dim3(512), lds, st, a);                                                        \
     }
-        // output channels of a row pair over 2 workgroups (one per CU) or, tuning, over 4 (two per CU)
-        // (mode 17, tuning: two staging regions per kind, transfers issued by the wavefronts without a stage of their own --
-        // measured 69.5 us against 68.7 us for the owner-wave form at config 2: an item's cycle is not a transfer round trip)
-        if (g_walk_nsc == 4) FL_GRADH(4, 4, 1) else if (g_walk == 17) FL_GRADH(2, 2, 2) else FL_GRADH(2, 2, 1)
+    // output channels of a row pair over 2 workgroups (one per CU) -- or one for 2 output channels; tuning: over 4 (two per CU);
+    // (mode 17, tuning: two staging regions per kind, transfers issued by the wavefronts without a stage of their own --
+    // measured 69.5 us against 68.7 us for the owner-wave form at config 2: an item's cycle is not a transfer round trip)
+#define FL_GRADH_ROWS(A_, B_)                                                                                                    \
+    if (NI == 8 && NO == 8) {                                                                                                    \
+        if (A_ == 16 && B_ == 15 && g_walk_nsc == 4) FL_GRADH(16, 15, 8, 8, 4, 4, 1)                                             \
+        else if (A_ == 16 && B_ == 15 && g_walk == 17) FL_GRADH(16, 15, 8, 8, 2, 2, 2)                                           \
+        else FL_GRADH(A_, B_, 8, 8, 2, 2, 1)                                                                                     \
+    }                                                                                                                            \
+    else if (NI == 4 && NO == 8) FL_GRADH(A_, B_, 4, 8, 2, 2, 1)                                                                 \
+    else if (NI == 2 && NO == 8) FL_GRADH(A_, B_, 2, 8, 2, 2, 1)                                                                 \
+    else if (NI == 8 && NO == 4) FL_GRADH(A_, B_, 8, 4, 2, 2, 1)                                                                 \
+    else if (NI == 4 && NO == 4) FL_GRADH(A_, B_, 4, 4, 2, 2, 1)                                                                 \
+    else if (NI == 2 && NO == 4) FL_GRADH(A_, B_, 2, 4, 2, 2, 1)                                                                 \
+    else if (NI == 8 && NO == 2) FL_GRADH(A_, B_, 8, 2, 1, 2, 1)                                                                 \
+    else if (NI == 4 && NO == 2) FL_GRADH(A_, B_, 4, 2, 1, 2, 1)                                                                 \
+    else if (NI == 2 && NO == 2) FL_GRADH(A_, B_, 2, 2, 1, 2, 1)
+    if (a.L2 == 240) { FL_GRADH_ROWS(16, 15) }
+    else if (a.L2 == 256) { FL_GRADH_ROWS(16, 16) }
+#undef FL_GRADH_ROWS
 #undef FL_GRADH
-    } else {
+    if (lrc == FL_ERR_UNSUPPORTED && !walk_shape(a.L2, NI, NO)) {
         set_error("spec_gradh_walk: no kernel for nfft=%d, %d -> %d channels", nfft, NI, NO);
         return FL_ERR_UNSUPPORTED;
     }
+    if (lrc) return lrc;
     FL_CHECK_LAUNCH("spec_gradh_walk");
     return FL_OK;
 }
@@ -1048,8 +1101,21 @@ int fl_spec_mid_walk_f32(const void* S, void* S2, void* Xp, const void* H, long 
     FL_REQUIRE((size_t)a.L1 * a.L2 * (NI > NO ? NI : NO) * 8ull < (1ull << 32), "spec_mid_walk: a batch item exceeds 32-bit offsets");
     FL_REQUIRE(reinterpret_cast<uintptr_t>(S) % 16 == 0, "spec_mid_walk: S must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
-    if (a.L2 == 240 && NI == 8 && NO == 8) rc = launch_walk<16, 15, 8, 8, 2>(a, st);
-    else {
+    rc = FL_ERR_UNSUPPORTED;
+#define FL_WALK_ROWS(A_, B_)                                                  \
+    if (NI == 8 && NO == 8) rc = launch_walk<A_, B_, 8, 8, 2>(a, st);         \
+    else if (NI == 4 && NO == 8) rc = launch_walk<A_, B_, 4, 8, 2>(a, st);    \
+    else if (NI == 2 && NO == 8) rc = launch_walk<A_, B_, 2, 8, 2>(a, st);    \
+    else if (NI == 8 && NO == 4) rc = launch_walk<A_, B_, 8, 4, 2>(a, st);    \
+    else if (NI == 4 && NO == 4) rc = launch_walk<A_, B_, 4, 4, 2>(a, st);    \
+    else if (NI == 2 && NO == 4) rc = launch_walk<A_, B_, 2, 4, 2>(a, st);    \
+    else if (NI == 8 && NO == 2) rc = launch_walk<A_, B_, 8, 2, 2>(a, st);    \
+    else if (NI == 4 && NO == 2) rc = launch_walk<A_, B_, 4, 2, 2>(a, st);    \
+    else if (NI == 2 && NO == 2) rc = launch_walk<A_, B_, 2, 2, 2>(a, st);
+    if (a.L2 == 240) { FL_WALK_ROWS(16, 15) }
+    else if (a.L2 == 256) { FL_WALK_ROWS(16, 16) }
+#undef FL_WALK_ROWS
+    if (rc == FL_ERR_UNSUPPORTED && !walk_shape(a.L2, NI, NO)) {
         set_error("spec_mid_walk: no kernel for nfft=%d, %d -> %d channels", nfft, NI, NO);
         return FL_ERR_UNSUPPORTED;
     }

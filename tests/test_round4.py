@@ -132,3 +132,42 @@ def test_objective_rides_in_the_pipeline(gpu, dt, nfft, N, B):
     y = model(x)
     y.mul_(2.0)
     assert relerr(ops.mean_square(y).detach(), (y.detach() ** 2).mean()) < (1e-12 if dt == F64 else 1e-6)
+
+
+@pytest.mark.parametrize("nfft,NI,NO,B", [(96000, 4, 4, 5), (96000, 2, 2, 7), (96000, 4, 8, 4), (96000, 8, 2, 5), (96000, 2, 4, 6),
+                                          (96000, 8, 4, 9), (65536, 8, 8, 5), (131072, 8, 8, 4), (131072, 4, 4, 4), (64000, 8, 8, 6),
+                                          (64000, 4, 4, 4), (96000, 8, 8, 9)])
+def test_walking_kernels_beyond_the_benchmark_shape(gpu, nfft, NI, NO, B):
+    """The batch-walking row kernels at other channel counts (2 / 4 / 8 on either side, non-square included) and at the 256-bin
+    rows (nfft = 65536, 131072, 64000): output, input gradient and response gradient against the one-item row kernel
+    (fl_debug_set_walk(0)) and against torch.fft + einsum in float64 (dsp.py:922-924); odd batch sizes, ranges that cross a row
+    pair, the adjoint product with the channel counts swapped."""
+    from flamo_amd import _lib, ops
+    L = _lib.lib()
+    assert L.fl_spec_walk_supports(nfft, NI, NO) == 1 and ops._walk_applies(nfft, B, NI, NO)
+    torch.manual_seed(nfft + 10 * NI + NO)
+    M = nfft // 2 + 1
+    x = torch.randn(B, nfft, NI, device=gpu, requires_grad=True)
+    H = (torch.randn(M, NO, NI, device=gpu, dtype=torch.complex64) / NI ** 0.5).requires_grad_(True)
+    c = torch.randn(B, nfft, NO, device=gpu)
+
+    def run():
+        y = ops.spectral_apply(x, ops.permute_bins(H, nfft), nfft)
+        return (y.detach(),) + torch.autograd.grad((y * c).sum(), [x, H])
+    yw, gxw, gHw = run()
+    L.fl_debug_set_walk(0, 0, 0, None)
+    try:
+        assert not ops._walk_applies(nfft, B, NI, NO)
+        ym, gxm, gHm = run()
+    finally:
+        L.fl_debug_set_walk(1, 0, 0, None)
+    for a, b, k in ((yw, ym, "y"), (gxw, gxm, "gx"), (gHw, gHm, "gH")):
+        assert relerr(a, b) < 2e-6, (k, relerr(a, b))
+    xr = x.detach().cpu().double().requires_grad_(True)
+    Hr = H.detach().cpu().to(torch.complex128).requires_grad_(True)
+    yr = torch.fft.irfft(torch.einsum("fmn,bfn->bfm", Hr, torch.fft.rfft(xr, n=nfft, dim=1)), n=nfft, dim=1)
+    gxr, gHr = torch.autograd.grad((yr * c.cpu().double()).sum(), [xr, Hr])
+    tag = f"walk_shapes/{nfft}/{NI}to{NO}/b{B}"
+    check_close(tag + "/y", yw.cpu(), yr.detach(), 1e-5)
+    check_close(tag + "/gx", gxw.cpu(), gxr, 1e-5)
+    check_close(tag + "/gH", gHw.cpu(), gHr, 1e-5)

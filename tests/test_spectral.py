@@ -33,6 +33,23 @@ def _ref(x, H, nfft, norm_f="backward", norm_i="backward", db_f=0.0, db_i=0.0):
     return X, y
 
 
+def test_plans_from_the_factorisation(gpu):
+    """fl_spec_plan derives (L1, L2) for lengths without a table entry; what it cannot factor over the instantiated column and
+    row lengths (odd half-lengths, large primes) reports unsupported and the operators take the layered route."""
+    import ctypes
+    from flamo_amd import _lib, ops
+    L = _lib.lib()
+    for nfft, want in ((32000, (50, 320)), (44100, (441, 50)), (88200, (441, 100)), (64000, (125, 256)), (24000, (50, 240)),
+                       (16000, (50, 160)), (160000, (250, 320)), (256000, (400, 320)), (176400, (441, 200))):
+        L1, L2 = ctypes.c_int(), ctypes.c_int()
+        assert L.fl_spec_plan(nfft, ctypes.byref(L1), ctypes.byref(L2)) == 0, nfft
+        assert L1.value * L2.value * 2 == nfft and (L1.value, L2.value) == want, (nfft, L1.value, L2.value)
+        assert ops.spectral_supported(nfft, 8, 8)
+    for nfft in (22050, 95999, 2176, 34):
+        assert L.fl_spec_plan(nfft, None, None) != 0 and not ops.spectral_supported(nfft, 8, 8)
+    assert not ops.spectral_supported(44100, 2, 2)           # 2 channels: 8-column tiles do not divide the 50-bin rows
+
+
 @pytest.mark.parametrize("nfft", sorted(PLANS))
 def test_plan_and_bin_order(gpu, nfft):
     import ctypes
@@ -78,7 +95,11 @@ def test_transform_round_trip_and_spectrum(gpu, N, vt):
                                       # the other planned lengths (csrc/spectral.hip kPlans): the reference's default 2^11, powers of
                                       # two to 2^17, one and three seconds at 48 kHz
                                       (2048, 2, 3), (2048, 16, 2), (4096, 8, 3), (8192, 4, 2), (16384, 16, 1), (32768, 2, 2), (65536, 8, 2),
-                                      (131072, 4, 1), (48000, 8, 3), (48000, 16, 1), (144000, 8, 2), (144000, 2, 1)])
+                                      (131072, 4, 1), (48000, 8, 3), (48000, 16, 1), (144000, 8, 2), (144000, 2, 1),
+                                      # lengths PLANNED from the factorisation (no table entry): examples/e4_recursion_nn.py:349's
+                                      # 32000 = 2 . 50 . 320, 44100 = 2 . 441 . 50, 88200 = 2 . 441 . 100, and multiples of 8000
+                                      (32000, 8, 3), (32000, 2, 2), (44100, 8, 2), (88200, 4, 1), (64000, 8, 2), (24000, 4, 2), (16000, 2, 2),
+                                      (160000, 8, 1), (256000, 2, 1)])
 def test_spectral_apply_against_torch_fft(gpu, nfft, N, B):
     from flamo_amd import ops
     torch.manual_seed(nfft + N)
