@@ -1089,11 +1089,10 @@ static int sos_chunk_of(int S, bool mixed) {
 }
 
 static int sos_blocks(int m_local, int C, int S, bool mixed) {
-    static int cus = 0;
-    if (!cus) {
+    int cus = 256;       // of the CURRENT device (asked per call: a few hundred nanoseconds beside a launch)
+    {
         int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cus = v;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int nz = cdiv_i(S, sos_chunk_of(S, mixed));
     int nb = g_sos_blocks > 0 ? g_sos_blocks : (2 * cus) / (C * nz > 0 ? C * nz : 1);

@@ -845,11 +845,19 @@ __global__ void __launch_bounds__(256) solve_lds_kernel(const cx<T>* __restrict_
     }
 }
 
-// largest loop the LDS kernel takes: the matrix (pitch N + 1) plus at least four right-hand-side columns in 160 KB
+// LDS one workgroup of the current device may ask for (160 KB on MI355X), less 4 KB for the kernel's static arrays
+static size_t solve_lds_budget() {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+        v = 160 * 1024;      // no device to ask (host-side construction checks): the part this library is built for
+    return (size_t)v - 4096;
+}
+// largest loop the LDS kernel takes: the matrix (pitch N + 1) plus at least four right-hand-side columns in that budget
 template <typename T>
 static int solve_lds_max_n() {
+    const size_t budget = solve_lds_budget();
     int n = 0;
-    while (((size_t)(n + 1) * (n + 2) + 4 * (size_t)(n + 1)) * sizeof(cx<T>) + (size_t)(n + 1) * sizeof(int) <= 160 * 1024 - 4096) ++n;
+    while (((size_t)(n + 1) * (n + 2) + 4 * (size_t)(n + 1)) * sizeof(cx<T>) + (size_t)(n + 1) * sizeof(int) <= budget) ++n;
     return n;
 }
 
@@ -875,13 +883,21 @@ static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_mi
             return FL_ERR_UNSUPPORTED;
         }
         if (B == 0 || M == 0) return FL_OK;
+        const size_t budget = solve_lds_budget();
         int cb = 16;
-        while (cb > 4 && ((size_t)N * (N + 1) + (size_t)N * cb) * sizeof(cx<T>) + (size_t)N * sizeof(int) > 160 * 1024 - 4096) cb >>= 1;
+        while (cb > 4 && ((size_t)N * (N + 1) + (size_t)N * cb) * sizeof(cx<T>) + (size_t)N * sizeof(int) > budget) cb >>= 1;
         const size_t lds = ((size_t)N * (N + 1) + (size_t)N * cb) * sizeof(cx<T>) + (size_t)N * sizeof(int);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(solve_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-            attr_set = true;
+        // the attribute is per device: set (and checked) once on each device this process uses
+        static bool attr_set[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+        if (!attr_set[dev]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(solve_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+            if (e != hipSuccess) {
+                set_error("solve: %zu bytes of LDS per workgroup are not available on device %d (%s)", budget, dev, hipGetErrorString(e));
+                return FL_ERR_UNSUPPORTED;
+            }
+            attr_set[dev] = true;
         }
         hipLaunchKernelGGL((solve_lds_kernel<T>), dim3(M), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)P, p_pitch, one_minus, adjoint,
                            (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K, cb);

@@ -827,21 +827,23 @@ __global__ void __launch_bounds__(256) sum_parts_kernel(const float4* __restrict
     out[j] = s;
 }
 
+constexpr int kMaxDevices = 64;
 static int g_walk = 1;            // 0: off (spec_mid only); 1: on for the shapes below
 static int g_walk_wgs = 0;        // workgroups of the forward walking kernel (0: one per CU)
 static int g_walk_slices = 0;     // batch slices of the backward walking kernel (0: CUs / row pairs)
 static long long* g_walk_times = nullptr;
 static int g_walk_nsc = 2;        // output-channel groups of the backward kernel (tuning: fl_debug_set_walk mode 14 -> 4)
 
-static int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
+static int device_cus() {       // of the current device, cached per device
+    static int cus[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
     }
-    return cus;
+    return cus[dev];
 }
 
 // workgroups of the forward walking kernel: one per CU (a multiple of 8: XCD-aware order), never more than units
@@ -856,7 +858,6 @@ static long walk_wgs(int L1, int Bn) {
 // The kernels of this file ask for more dynamic LDS than the default 64 KB: the attribute is per function AND per device, so
 // it is set once per (kernel, device) -- a second GPU used by the same process gets its own -- and its result is checked
 // (a part with less LDS per workgroup fails here with a message, not at the launch).
-constexpr int kMaxDevices = 64;
 static int ensure_lds(const void* kern, size_t lds, bool* done /* [kMaxDevices] */) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;

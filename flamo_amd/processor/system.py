@@ -364,7 +364,12 @@ class Recursion(nn.Module):
         # the fused loop forms; above that one workgroup per bin factors the materialised matrix in LDS (fl_solve_max_n: 138 /
         # 97).  The reference's torch.linalg.solve has no bound; there is deliberately no torch fallback on this path.
         self._register_loop = self.output_channels <= (32 if self.dtype == torch.float64 else 64)
-        limit = 97 if self.dtype == torch.float64 else 138
+        limit = 97 if self.dtype == torch.float64 else 138      # MI355X (160 KB of LDS per workgroup); the library is asked
+        try:                                                    # when it is there: a part with less LDS answers less
+            from .. import _lib
+            limit = int(_lib.lib().fl_solve_max_n(int(self.dtype == torch.float64)))
+        except (OSError, AttributeError, RuntimeError):         # host-logic use without the built extension
+            pass
         assert self.output_channels <= limit, (
             f"Recursion: {self.output_channels} loop channels exceed the HIP solve kernels' limit of {limit} "
             f"({'float64' if self.dtype == torch.float64 else 'float32'}); see INTEGRATION.md")
