@@ -92,9 +92,6 @@ __device__ __forceinline__ void lds_reads_done(f2 (&r)[N], cf (&v)[N]) {
         v[i] = c2(r[i]);
     }
 }
-#ifndef FL_P5_PAIR_STORES
-#define FL_P5_PAIR_STORES 1
-#endif
 #ifndef FL_XP_PAIRS
 #define FL_XP_PAIRS 1      // the kept spectrum in channel pairs (16-byte stores / LDS reads); 0: one channel plane per 8-byte access
 #endif
@@ -336,29 +333,10 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         }
         cf* S2b = a.S2 + (size_t)b * bstride_o;
         const unsigned dst0 = (unsigned)(slot ? rm : r) * (unsigned)a.L2 * NO + (unsigned)(ka * NO + m);
-#if FL_P5_PAIR_STORES
-        // 16-byte stores: lanes 2i, 2i+1 hold channels m, m+1 of the same columns.  For the columns (2j, 2j+1) the even lane
-        // ends up with (its own, its neighbour's) values of column 2j, the odd lane with (its neighbour's, its own) of column
-        // 2j+1 -- four DPP moves (neighbour swap, written to the odd resp. even lanes only) buy one store instruction: 8-byte
-        // stores are bound by their issue rate (60 per unit from four wavefronts), not by bytes
-        const bool odd = m & 1;
-        const unsigned base2 = 8u * dst0 + (odd ? 8u * (unsigned)(A * NO) - 8u : 0u);
-#pragma unroll
-        for (int j = 0; j + 1 < B; j += 2) {
-            const cf e0 = v[j] * t[j], e1 = v[j + 1] * t[j + 1];
-            auto sw = [](float keep, float give, int bank) {
-                return __int_as_float(bank == 0xA ? __builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(give), 0xB1, 0xF, 0xA, false)
-                                                  : __builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(give), 0xB1, 0xF, 0x5, false));
-            };
-            const f2 lo = {sw(e0.x, e1.x, 0xA), sw(e0.y, e1.y, 0xA)};      // even lanes: own column 2j; odd lanes: the neighbour's column 2j+1
-            const f2 hi = {sw(e1.x, e0.x, 0x5), sw(e1.y, e0.y, 0x5)};      // even lanes: the neighbour's column 2j; odd lanes: own column 2j+1
-            st_nt16(S2b, base2 + 8u * (unsigned)(A * j * NO), lo, hi);
-        }
-        if (B & 1) st_nt(S2b, 8u * (dst0 + (unsigned)(A * (B - 1) * NO)), v[B - 1] * t[B - 1]);
-#else
+        // (16-byte stores of channel pairs -- four DPP moves per column pair to buy one store instruction -- measured no faster:
+        // 70.7-71.3 against 69.4-69.8 us in the step; the moves and their hazard slots cost what the stores saved)
 #pragma unroll
         for (int kb = 0; kb < B; ++kb) st_nt(S2b, 8u * (dst0 + (unsigned)(A * kb * NO)), v[kb] * t[kb]);
-#endif
         if (DBG) q_ph[2] += clock64() - q_t0;     // twiddles + stores
     };
 
