@@ -924,10 +924,10 @@ class _SpectralApply(torch.autograd.Function):
             + (None, None, None, None, None)
 
     @staticmethod
-    def _backward(cfg, Hp, Xkept, need_x, need_h, gy, out_scale):
-        """Gradients (gx, gH) for the output gradient gy -- or, with out_scale (a float device scalar c), for c * gy without
-        forming it: the pipeline is linear, so the factor is applied where the results are small (in the walking kernel's
-        epilogue for dL/dH)."""
+    def _backward(cfg, Hp, Xkept, need_x, need_h, gy, out_scale, host_factor=1.0):
+        """Gradients (gx, gH) for the output gradient gy -- or, with out_scale (a device scalar c of gy's dtype) and host_factor
+        (a Python float f), for (c f) * gy without forming it: the pipeline is linear, so the factor is applied where the
+        results are small (f rides in the walking kernel's transform scale, c in its epilogue: no launch of its own)."""
         kept = [Xkept]
         nfft, scale_f, env_f, scale_i, env_i, T, NI, NO, walk = cfg
         g = gy.contiguous()
@@ -939,7 +939,7 @@ class _SpectralApply(torch.autograd.Function):
         gx = gH = None
         if walk:
             if need_h:
-                gH = _spec_gradh_walk(Sg, kept[0], B, NI, NO, nfft, scale_i, None if out_scale is None else out_scale.float())
+                gH = _spec_gradh_walk(Sg, kept[0], B, NI, NO, nfft, scale_i * host_factor, out_scale)      # (walking kernels: float32)
             if need_x:
                 # rfft' : g_x[t] = scale_f e_f(t) Re sum_k g_X[k] exp(+j w_k t), g_X = H^H g_Y
                 if _walk_applies(nfft, B, NO, NI):
@@ -948,19 +948,19 @@ class _SpectralApply(torch.autograd.Function):
                     S3, _ = _spec_mid(Sg, B, NO, NI, nfft, Hp, True, False, True, scale_i, 1, 1)
                 gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f, env_f)
                 if out_scale is not None:
-                    gx = gx * out_scale.to(gx.dtype)
+                    gx = gx * (out_scale * host_factor)
             return gx, gH
         # rfft' : g_x[t] = scale_f e_f(t) Re sum_k g_X[k] exp(+j w_k t), g_X = H^H g_Y -- an inverse transform with halved interior bins
         S3, gYs = _spec_mid(Sg, B, NO, NI if need_x else NO, nfft, Hp if need_x else None, True, need_h, need_x, scale_i, 1, 1)
         if need_x:
             gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f, env_f)
             if out_scale is not None:
-                gx = gx * out_scale.to(gx.dtype)
+                gx = gx * (out_scale * host_factor)
         if need_h:
             Xs = kept[0]
             gH = _gradh_launch(gYs.movedim(-1, 1), Xs.movedim(-1, 1), False).movedim(-1, 0)
             if out_scale is not None:
-                gH = gH * out_scale.to(gH.real.dtype)
+                gH = gH * (out_scale * host_factor)
         return gx, gH
 
 
@@ -993,8 +993,9 @@ class _SpectralMeanSquare(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         y, Hp, *kept = ctx.saved_tensors
-        c = (gloss.to(y.dtype) * (2.0 / y.numel())).reshape(())          # device scalar in the pipeline's precision
-        gx, gH = _SpectralApply._backward(ctx.cfg, Hp, kept[0] if kept else None, ctx.needs_input_grad[0], ctx.needs_input_grad[1], y, c)
+        c = gloss.to(y.dtype).reshape(())          # device scalar in the pipeline's precision (no launch when it already is)
+        gx, gH = _SpectralApply._backward(ctx.cfg, Hp, kept[0] if kept else None, ctx.needs_input_grad[0], ctx.needs_input_grad[1], y, c,
+                                          2.0 / y.numel())
         return gx, gH, None, None
 
 
