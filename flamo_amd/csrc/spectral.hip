@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(256) permute_bins_kernel(const cf* __restrict_
 #ifndef FL_F64
 struct PlanEntry { int nfft, L1, L2, lean; };
 // the tuned lengths: every channel combination and the tuning variants exist for the three BASELINE lengths
-static const PlanEntry kPlans[] = {{96000, 200, 240, 0}, {192000, 300, 320, 0}, {384000, 400, 480, 0},
+static const PlanEntry kPlans[] = {{96000, 200, 240, 0}, {192000, 400, 240, 0}, {384000, 800, 240, 0},
                                    {2048, 32, 32, 1},    {4096, 32, 64, 1},     {8192, 64, 64, 1},     {16384, 64, 128, 1},
                                    {32768, 128, 128, 1}, {65536, 128, 256, 1},  {131072, 256, 256, 1}, {48000, 150, 160, 1},
                                    {144000, 225, 320, 1}};
@@ -671,7 +671,7 @@ static const PlanEntry kPlans[] = {{96000, 200, 240, 0}, {192000, 300, 320, 0}, 
 // (a row length is 2^k B, k <= 5: the row kernel's threads divide evenly over the k_a of its second stage)
 // Preference: the row length nearest to 256 (a row pair of all channels in LDS, 240..256 bin pairs for a workgroup's threads),
 // rows not shorter than columns.  Planned lengths take the equal-channel kernels.
-static const int kColLens[] = {32, 50, 64, 75, 100, 125, 128, 150, 200, 225, 250, 256, 300, 400, 441};
+static const int kColLens[] = {32, 50, 64, 75, 100, 125, 128, 150, 200, 225, 250, 256, 300, 400, 441, 800};
 static const int kRowLens[] = {32, 50, 64, 100, 128, 160, 200, 240, 256, 320, 400, 480};
 static const PlanEntry* plan_of(int nfft) {
     for (const PlanEntry& p : kPlans)
@@ -727,7 +727,17 @@ static size_t g_cols_inv_min_lds = [] { const char* e = getenv("FLAMO_COLS_INV_L
 // up to 8 channels at every plan length (3 % at nfft=96000, 11 % at 192000); with 16 channels a 16-wide tile would be a
 // single column of 128-byte segments and the 32-wide tile with all loads in flight is ahead.
 // (float64: always the 16-wide tile -- its LDS is twice the float32 tile's)
-static int cols_vt(int G) { return sizeof(real_t) == 8 ? 16 : g_spec_vt ? g_spec_vt : (G <= 8 ? 16 : 32); }
+// (the 32-wide tile of a long column pass does not fit the LDS: 32 x 801 values at L1 = 800 -- the 16-wide tile then)
+static int cols_vt(int G, int L1 = 0) {
+    int vt = sizeof(real_t) == 8 ? 16 : g_spec_vt ? g_spec_vt : (G <= 8 ? 16 : 32);
+    while (vt > 8 && ((size_t)vt * (L1 | 1) + L1 + vt * 25) * sizeof(cf) > 150 * 1024) vt >>= 1;      // (8: float64 at L1 = 800)
+    return vt;
+}
+static int cols_vt_of(int nfft, int G) {
+    int l1 = 0, l2 = 0;
+    if (spec_plan(nfft, l1, l2) != FL_OK) l1 = 0;
+    return cols_vt(G, l1);
+}
 static int cols_rg(int vt, int L1) { return sizeof(real_t) == 8 ? 1 : g_spec_rg ? g_spec_rg : (vt == 32 ? 4 : (L1 <= 200 ? 1 : 2)); }
 
 static int cols_setup(ColsArgs& a, int nfft, int Bn, int t_len, int t_lim, int G, const void* W, int vt) {
@@ -761,6 +771,9 @@ static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStrea
     }
     const int vt = a.CT << a.cgs;
     if constexpr (sizeof(real_t) == 8) {      // float64: the 16-wide tile, one load group (its values are four registers each)
+        if constexpr (A * B >= 800) {
+            if (vt == 8) FL_COLS(8, 1) else FL_COLS(16, 1)      // (the longest column pass: a 16-wide tile of doubles exceeds the LDS)
+        } else
         FL_COLS(16, 1)
     } else if constexpr (LEAN) {              // one load-group choice per tile width
         if (vt == 32) FL_COLS(32, 2) else FL_COLS(16, 2)
@@ -794,6 +807,7 @@ static int cols_launch(bool inverse, const ColsArgs& a, int Bn, hipStream_t st) 
         case 125: launch_cols<5, 25, true>(inverse, a, (unsigned)nblk, st); break;
         case 250: launch_cols<10, 25, true>(inverse, a, (unsigned)nblk, st); break;
         case 441: launch_cols<21, 21, true>(inverse, a, (unsigned)nblk, st); break;
+        case 800: launch_cols<32, 25, true>(inverse, a, (unsigned)nblk, st); break;
         default: set_error("spectral cols: unsupported column length %d", a.L1); return FL_ERR_UNSUPPORTED;
     }
     FL_CHECK_LAUNCH(inverse ? "spec_cols_inv" : "spec_cols_fwd");
@@ -917,7 +931,7 @@ using namespace fl::FL_SPEC_NS;
 
 // LDS of the column kernels for G channels: (VT (L1 | 1) + L1 + VT B) complex values, B <= 25
 static size_t cols_lds_need(int L1, int G) {
-    const int vt = cols_vt(G);
+    const int vt = cols_vt(G, L1);
     return ((size_t)vt * (L1 | 1) + L1 + (size_t)vt * 25) * sizeof(cf);
 }
 
@@ -973,7 +987,7 @@ int fl_spec_supports(int nfft, int n_in, int n_out) {
     }
     // a column-pass workgroup owns CT = VT / min(G, VT) columns of all G channels: CT must divide the row length
     for (int G : {n_in, n_out}) {
-        const int vt = cols_vt(G), ct = vt / (G < vt ? G : vt);
+        const int vt = cols_vt(G, l1), ct = vt / (G < vt ? G : vt);
         if (l2 % ct) return 0;
     }
     const int nch = n_in > n_out ? n_in : n_out;
@@ -1004,7 +1018,7 @@ int FL_SPEC_FN(fl_spec_cols_fwd)(const void* x, int Bn, int t_len, int G, void* 
     FL_REQUIRE(reinterpret_cast<uintptr_t>(x) % (2 * RSZ) == 0, "spec_cols_fwd: x must be aligned to two samples");
     if (Bn == 0) return FL_OK;
     ColsArgs a = {};
-    int rc = cols_setup(a, nfft, Bn, t_len, t_len, G, W, cols_vt(G));
+    int rc = cols_setup(a, nfft, Bn, t_len, t_len, G, W, cols_vt_of(nfft, G));
     if (rc) return rc;
     a.x = (const real_t*)x;
     a.S = (cf*)S;
@@ -1027,7 +1041,7 @@ int FL_SPEC_FN(fl_spec_cols_blocks)(int nfft, int Bn, int G) {      // workgroup
     ColsArgs a = {};
     static const real_t dummy = 0;
     if (Bn <= 0) return 0;
-    if (cols_setup(a, nfft, Bn, 0, 0, G, &dummy, cols_vt(G))) return -1;
+    if (cols_setup(a, nfft, Bn, 0, 0, G, &dummy, cols_vt_of(nfft, G))) return -1;
     return Bn * a.nct * a.ngt;
 }
 }  // extern "C"
@@ -1038,7 +1052,7 @@ static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, 
     FL_REQUIRE(t_out >= 0 && t_out <= t_len, "spec_cols_inv: t_out must be in [0, t_len]");
     if (Bn == 0) return FL_OK;
     ColsArgs a = {};
-    int rc = cols_setup(a, nfft, Bn, t_len, t_out, G, W, cols_vt(G));
+    int rc = cols_setup(a, nfft, Bn, t_len, t_out, G, W, cols_vt_of(nfft, G));
     if (rc) return rc;
     a.y = (real_t*)y;
     a.S = (cf*)S2;
