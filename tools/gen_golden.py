@@ -438,7 +438,7 @@ def gen_round2(dsp, system):
     # (a) config-2 miniature at the size SURVEY 8-c4 names (nfft=960, 8x8): float64 AND float32 runs of the reference
     for db in (0.0, 30.0):
         torch.manual_seed(7000 + int(db))
-        N, nfft, B = 8, 960, 1       # (SURVEY 8-c4 names B = 3; one item keeps the fixture a third of the size, the batch axis is covered by config2_db*)
+        N, nfft, B = 8, 960, 3       # (the size SURVEY 8-c4 names)
         W = _f32vals(torch.randn(N, N))
         Gp = _f32vals(torch.empty(12, N, N).uniform_(10 ** (-6 / 20), 10 ** (6 / 20)))
         x = _f32vals(torch.randn(B, nfft, N))
