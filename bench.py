@@ -528,7 +528,7 @@ def main():
     x = torch.randn(BATCH, NFFT, NCH, device=dev, dtype=dtype)   # resident in HBM before timing
 
     def eager_step(sync_grads=True):
-        finish_gradients()
+        del pending[:-1]
         for p in params:
             p.grad = None
         y = model(x)
@@ -546,11 +546,12 @@ def main():
 
     def sync_gradients():
         """Data-parallel gradient sum: < 4 KB through one cached flat buffer and ONE RCCL all-reduce per step, issued
-        asynchronously: the host goes on, and the handle is finished (stream wait + sums back into the gradients) by
-        finish_gradients() in front of the NEXT backward pass -- where an optimiser step would read them -- never after
-        it: a later finish would put the previous step's sums over fresh gradients."""
+        asynchronously with the sums left IN the buffer (dist.all_reduce_grads(in_buffer=True): the handle's `reduced` views
+        are what an optimiser reads, as with DDP's gradient-as-bucket-view).  The replay's own gradient tensors are free as soon
+        as they have been copied into the buffer, so the next replay overlaps the collective; the refill of the buffer is
+        ordered behind the previous collective on the stream.  finish_gradients() (the fences) waits for what is in flight."""
         from flamo_amd import dist as fd
-        pending.append(fd.all_reduce_grads(params, async_op=True))
+        pending.append(fd.all_reduce_grads(params, async_op=True, in_buffer=True))
 
     step = eager_step
     gs = None
@@ -574,7 +575,7 @@ def main():
 
         if gs is not None:
             def step():
-                finish_gradients()          # the previous step's sums are in place before the replay rewrites the gradients
+                del pending[:-1]            # (handles of finished steps: the next all_reduce_grads call orders itself behind the last)
                 loss = gs.replay()
                 if dist_on:
                     sync_gradients()

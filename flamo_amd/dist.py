@@ -151,14 +151,20 @@ def take_local_bins(X: torch.Tensor, group=None) -> torch.Tensor:
 _flat_cache = {}
 
 
-def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op: bool = False):
+def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op: bool = False, in_buffer: bool = False):
     """Sum the gradients of replicated parameters over ranks with ONE flat all-reduce per dtype, through a flat
     buffer that is allocated once per parameter set (no cat / cast / per-parameter temporaries per step): the gradients
     are copied into views of the buffer (one multi-tensor copy), reduced in place, and copied back.
     async_op: returns a callable that waits for the collective and copies the sums back -- call it before the
     gradients are read AND before the next backward pass (or graph replay) rewrites them: a handle that is still
     open when the same parameters are reduced again is waited for and its sums are dropped, with a warning.
-    None otherwise."""
+    None otherwise.
+    in_buffer (with async_op): the sums STAY in the flat buffer -- the handle's ``reduced`` list holds one view per parameter,
+    shaped like its gradient, which is where an optimiser reads them (DistributedDataParallel's gradient-as-bucket-view);
+    nothing is copied back unless the handle is called with ``copy_back=True``.  The parameters' own ``.grad`` tensors are free
+    at once, so the next backward pass (or graph replay) may start while the collective is still in flight: the next call on
+    the same parameters orders its refill of the buffer behind the previous collective on the stream (no host wait, no
+    warning)."""
     ps = [p for p in params if p.grad is not None]
     if not ps:
         return (lambda: None) if async_op else None
@@ -177,6 +183,9 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
                 off += n
             ent = _flat_cache[key] = [flat, views, None]
         flat, views, outstanding = ent
+        if outstanding is not None and getattr(outstanding, "in_buffer", False):
+            outstanding()              # in-buffer handle: its sums were the buffer's business; order the refill behind its collective
+            outstanding = None
         if outstanding is not None:
             # an earlier asynchronous call on this buffer has not been finished: its collective may still be reading and
             # writing the buffer this call is about to refill.  Wait for it -- at most one collective per parameter set is
@@ -200,7 +209,7 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
 
     done = [False]
 
-    def finish(copy_back: bool = True):
+    def finish(copy_back: bool = not in_buffer):
         if done[0]:
             return
         done[0] = True
@@ -224,6 +233,9 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
                 torch._foreach_copy_(dst, src)
 
     if async_op:
+        finish.in_buffer = bool(in_buffer)
+        finish.reduced = [v.view_as(p.grad) for _, views, plist, _ in pending for p, v in zip(plist, views)]
+        finish.params = [p for _, _, plist, _ in pending for p in plist]
         for _, _, _, ent in pending:
             ent[2] = finish
         return finish

@@ -80,6 +80,18 @@ def _worker(rank, world, port, M, results):
             fd.all_reduce_grads([p])
         ok_red = ok_red and torch.allclose(p.grad, torch.full((5,), float(sum(range(1, world + 1))))) and \
             any("never finished" in str(w.message) for w in wlist)
+        # sums left in the flat buffer (DDP's gradient-as-bucket-view): the gradients themselves stay local and free for the next
+        # backward pass; a second reduction orders itself behind the first without a warning
+        p.grad = torch.full((5,), float(rank + 1))
+        h1 = fd.all_reduce_grads([p], async_op=True, in_buffer=True)
+        p.grad = torch.full((5,), 10.0 * (rank + 1))          # the next backward pass, while h1 may still be in flight
+        with warnings.catch_warnings(record=True) as wlist2:
+            warnings.simplefilter("always")
+            h2 = fd.all_reduce_grads([p], async_op=True, in_buffer=True)
+        h2()
+        ok_red = ok_red and not wlist2 and torch.allclose(h2.reduced[0], torch.full((5,), 10.0 * sum(range(1, world + 1)))) and \
+            torch.allclose(p.grad, torch.full((5,), 10.0 * (rank + 1))) and h2.params[0] is p
+        h2(copy_back=True)                                    # (already finished: a no-op)
         results[rank] = bool(ok_fwd and ok_bwd and ok_red and ok_ctx and ok_x and torch.equal(rl, full.real))
     finally:
         dist.destroy_process_group()
