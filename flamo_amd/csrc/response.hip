@@ -810,32 +810,75 @@ __global__ void __launch_bounds__(256, 2) sos_response_bwd_mixed_kernel(
         // q_p = conj(gH) H d^p, shared by all sections: Re(q_p / B_s) = (q_p.x Br + q_p.y Bi) / |B_s|^2
         const cx<float> q0 = gc * h, q1 = q0 * d, q2 = q1 * d;
         unsigned slow = 0;
+        // The range test of a section pair -- |B|^2 |A|^2 a normal number in both halves -- used to cost two v_cmp_class, two
+        // selects of the reciprocal, the flag bits and their hazard slots per pair (a fifth of the loop beside its 33 packed
+        // instructions).  Now the pairs are taken in groups of GP: the group's values are formed with the RAW reciprocals (a
+        // lane with a bad section holds inf / NaN there, nothing is accumulated yet), one packed min and one `nn * 0` sum per
+        // pair watch the range (min >= FLT_MIN: no zero / denormal; 0 * nn == 0: no inf / NaN), and ONE test per group and lane
+        // decides between the plain accumulation and the careful per-section form below (the lanes that need it: rare).
+        constexpr int GP = (SCH / 2) % 3 == 0 ? 3 : (SCH / 2);
 #pragma unroll
-        for (int u = 0; u < SCH / 2; ++u) {
-            const f2 b0 = tb[u], b1 = tb[SCH / 2 + u], b2 = tb[SCH + u];
-            const f2 a0 = tb[3 * SCH / 2 + u], a1 = tb[2 * SCH + u], a2 = tb[5 * SCH / 2 + u];
-            const f2 Br = b0 + b1 * xr + b2 * x2r, Bi = b1 * xi + b2 * x2i;
-            const f2 Ar = a0 + a1 * xr + a2 * x2r, Ai = a1 * xi + a2 * x2i;
-            const f2 nb = Br * Br + Bi * Bi, na = Ar * Ar + Ai * Ai;
-            // one reciprocal per section for both quotients (v_rcp_f32 is a quarter-rate instruction):
-            // 1/|B|^2 = |A|^2 / (|B|^2 |A|^2).  A product that is not a normal number (a norm vanished, or left the float
-            // range) is flagged for the double route
-            const f2 nn = nb * na;
-            const bool ok0 = __builtin_amdgcn_classf(nn.x, 0x100);             // +normal
-            const bool ok1 = __builtin_amdgcn_classf(nn.y, 0x100);
-            slow |= (ok0 ? 0u : (1u << (2 * u))) | (ok1 ? 0u : (2u << (2 * u)));
-            f2 inv;
-            inv.x = ok0 ? __builtin_amdgcn_rcpf(nn.x) : 0.f;
-            inv.y = ok1 ? __builtin_amdgcn_rcpf(nn.y) : 0.f;
-            const f2 ib = inv * na, ia = -(inv * nb);
-            const f2 Brs = Br * ib, Bis = Bi * ib, Ars = Ar * ia, Ais = Ai * ia;
-            // (one fused multiply-add per statement: "acc += x + y" would be a multiply, an fma and an add)
-            acc[0][u] = Brs * q0.x + acc[0][u]; acc[0][u] = Bis * q0.y + acc[0][u];
-            acc[1][u] = Brs * q1.x + acc[1][u]; acc[1][u] = Bis * q1.y + acc[1][u];
-            acc[2][u] = Brs * q2.x + acc[2][u]; acc[2][u] = Bis * q2.y + acc[2][u];
-            acc[3][u] = Ars * q0.x + acc[3][u]; acc[3][u] = Ais * q0.y + acc[3][u];
-            acc[4][u] = Ars * q1.x + acc[4][u]; acc[4][u] = Ais * q1.y + acc[4][u];
-            acc[5][u] = Ars * q2.x + acc[5][u]; acc[5][u] = Ais * q2.y + acc[5][u];
+        for (int g0 = 0; g0 < SCH / 2; g0 += GP) {
+            f2 sBr[GP], sBi[GP], sAr[GP], sAi[GP];
+            f2 mn = {3.0e38f, 3.0e38f}, zz = {0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < GP; ++v) {
+                const int u = g0 + v;
+                const f2 b0 = tb[u], b1 = tb[SCH / 2 + u], b2 = tb[SCH + u];
+                const f2 a0 = tb[3 * SCH / 2 + u], a1 = tb[2 * SCH + u], a2 = tb[5 * SCH / 2 + u];
+                const f2 Br = b0 + b1 * xr + b2 * x2r, Bi = b1 * xi + b2 * x2i;
+                const f2 Ar = a0 + a1 * xr + a2 * x2r, Ai = a1 * xi + a2 * x2i;
+                const f2 nb = Br * Br + Bi * Bi, na = Ar * Ar + Ai * Ai;
+                const f2 nn = nb * na;
+                mn = __builtin_elementwise_min(mn, nn);
+                zz = __builtin_elementwise_fma(nn, (f2)(0.f), zz);
+                f2 inv;
+                inv.x = __builtin_amdgcn_rcpf(nn.x);
+                inv.y = __builtin_amdgcn_rcpf(nn.y);
+                const f2 ib = inv * na, ia = -(inv * nb);
+                sBr[v] = Br * ib; sBi[v] = Bi * ib; sAr[v] = Ar * ia; sAi[v] = Ai * ia;
+            }
+            const bool okg = fminf(mn.x, mn.y) >= 1.17549435e-38f && (zz.x + zz.y) == 0.f;
+            if (__builtin_expect(okg, 1)) {
+#pragma unroll
+                for (int v = 0; v < GP; ++v) {
+                    const int u = g0 + v;
+                    // (one fused multiply-add per statement: "acc += x + y" would be a multiply, an fma and an add)
+                    acc[0][u] = sBr[v] * q0.x + acc[0][u]; acc[0][u] = sBi[v] * q0.y + acc[0][u];
+                    acc[1][u] = sBr[v] * q1.x + acc[1][u]; acc[1][u] = sBi[v] * q1.y + acc[1][u];
+                    acc[2][u] = sBr[v] * q2.x + acc[2][u]; acc[2][u] = sBi[v] * q2.y + acc[2][u];
+                    acc[3][u] = sAr[v] * q0.x + acc[3][u]; acc[3][u] = sAi[v] * q0.y + acc[3][u];
+                    acc[4][u] = sAr[v] * q1.x + acc[4][u]; acc[4][u] = sAi[v] * q1.y + acc[4][u];
+                    acc[5][u] = sAr[v] * q2.x + acc[5][u]; acc[5][u] = sAi[v] * q2.y + acc[5][u];
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < GP; ++v) {
+                    const int u = g0 + v;
+                    const f2 b0 = tb[u], b1 = tb[SCH / 2 + u], b2 = tb[SCH + u];
+                    const f2 a0 = tb[3 * SCH / 2 + u], a1 = tb[2 * SCH + u], a2 = tb[5 * SCH / 2 + u];
+                    const f2 Br = b0 + b1 * xr + b2 * x2r, Bi = b1 * xi + b2 * x2i;
+                    const f2 Ar = a0 + a1 * xr + a2 * x2r, Ai = a1 * xi + a2 * x2i;
+                    const f2 nb = Br * Br + Bi * Bi, na = Ar * Ar + Ai * Ai;
+                    // one reciprocal per section for both quotients: 1/|B|^2 = |A|^2 / (|B|^2 |A|^2).  A product that is not a
+                    // normal number (a norm vanished, or left the float range) is flagged for the double route
+                    const f2 nn = nb * na;
+                    const bool ok0 = __builtin_amdgcn_classf(nn.x, 0x100);             // +normal
+                    const bool ok1 = __builtin_amdgcn_classf(nn.y, 0x100);
+                    slow |= (ok0 ? 0u : (1u << (2 * u))) | (ok1 ? 0u : (2u << (2 * u)));
+                    f2 inv;
+                    inv.x = ok0 ? __builtin_amdgcn_rcpf(nn.x) : 0.f;
+                    inv.y = ok1 ? __builtin_amdgcn_rcpf(nn.y) : 0.f;
+                    const f2 ib = inv * na, ia = -(inv * nb);
+                    const f2 Brs = Br * ib, Bis = Bi * ib, Ars = Ar * ia, Ais = Ai * ia;
+                    acc[0][u] = Brs * q0.x + acc[0][u]; acc[0][u] = Bis * q0.y + acc[0][u];
+                    acc[1][u] = Brs * q1.x + acc[1][u]; acc[1][u] = Bis * q1.y + acc[1][u];
+                    acc[2][u] = Brs * q2.x + acc[2][u]; acc[2][u] = Bis * q2.y + acc[2][u];
+                    acc[3][u] = Ars * q0.x + acc[3][u]; acc[3][u] = Ais * q0.y + acc[3][u];
+                    acc[4][u] = Ars * q1.x + acc[4][u]; acc[4][u] = Ais * q1.y + acc[4][u];
+                    acc[5][u] = Ars * q2.x + acc[5][u]; acc[5][u] = Ais * q2.y + acc[5][u];
+                }
+            }
         }
         if (slow) {   // rare: redo the flagged sections in double
             SosEval e;
