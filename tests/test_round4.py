@@ -171,3 +171,26 @@ def test_walking_kernels_beyond_the_benchmark_shape(gpu, nfft, NI, NO, B):
     check_close(tag + "/y", yw.cpu(), yr.detach(), 1e-5)
     check_close(tag + "/gx", gxw.cpu(), gxr, 1e-5)
     check_close(tag + "/gH", gHw.cpu(), gHr, 1e-5)
+
+
+@pytest.mark.parametrize("nfft,G,B,t_out", [(96000, 8, 3, 96000), (96000, 16, 2, 50000), (32000, 4, 2, 32000), (4096, 2, 5, 4096), (384000, 8, 1, 384000)])
+def test_inverse_column_pass_leaves_the_sum_of_squares(gpu, dt, nfft, G, B, t_out):
+    """fl_spec_cols_inv_sumsq_*: the same y as fl_spec_cols_inv_* (bit for bit) plus per-workgroup partial sums whose total is
+    sum(y^2) over the samples it stored (truncated output, envelope and scale included); fl_mean_square_final_* reduces them."""
+    from flamo_amd import _lib, ops
+    if not ops.spectral_supported(nfft, G, G, dt):
+        pytest.skip("no fused plan at this shape / precision")
+    torch.manual_seed(nfft + G)
+    L = nfft // 2
+    S2 = torch.randn(B * L * G, dtype=CD[dt], device=gpu)
+    y0 = ops._spec_cols_inv(S2, B, nfft, t_out, G, nfft, 1.0 / nfft, ops.env_log2_of(20.0, nfft))
+    y1, parts = ops._spec_cols_inv(S2, B, nfft, t_out, G, nfft, 1.0 / nfft, ops.env_log2_of(20.0, nfft), want_sumsq=True)
+    assert torch.equal(y0, y1)
+    assert parts.dtype == torch.float64 and parts.numel() == int(ops._spec_fn("fl_spec_cols_blocks", dt)(nfft, B, G))
+    want = (y1.double() ** 2).sum()
+    assert abs(parts.sum().item() / want.item() - 1.0) < (1e-12 if dt == F64 else 2e-6)
+    assert y1[:, t_out:].abs().max().item() == 0.0 if t_out < nfft else True
+    loss = torch.empty((), dtype=dt, device=gpu)
+    fn = _lib.lib().fl_mean_square_final_f32 if dt == torch.float32 else _lib.lib().fl_mean_square_final_f64
+    _lib.check(fn(parts.data_ptr(), parts.numel(), 1.0 / y1.numel(), loss.data_ptr(), ops._stream()), "mean_square_final")
+    assert abs(loss.item() / (want.item() / y1.numel()) - 1.0) < (1e-12 if dt == F64 else 2e-6)
