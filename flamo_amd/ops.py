@@ -2185,9 +2185,17 @@ def mean_square(y: torch.Tensor) -> torch.Tensor:
     """(y ** 2).mean() of a real tensor in one streaming pass each way (forward: one read of y;
     backward: one read + one write), in whatever layout y is stored."""
     tag = getattr(y, "_flamo_sa", None)
-    if FUSE_OBJECTIVE and tag is not None and tag.parts is not None and y._version == tag.version and torch.is_grad_enabled() \
-            and (tag.x.requires_grad or tag.Hrm.requires_grad) and (tag.Xs is not None or not tag.Hrm.requires_grad):
-        return _SpectralMeanSquare.apply(tag.x, tag.Hrm, y.detach(), tag)
+    if FUSE_OBJECTIVE and tag is not None and tag.parts is not None and y._version == tag.version:
+        if torch.is_grad_enabled() and (tag.x.requires_grad or tag.Hrm.requires_grad):
+            if tag.Xs is not None or not tag.Hrm.requires_grad:
+                return _SpectralMeanSquare.apply(tag.x, tag.Hrm, y.detach(), tag)
+        elif not (torch.is_grad_enabled() and y.requires_grad):
+            # nothing to differentiate (evaluation under no_grad, validation steps): the value alone, from the partial sums
+            loss = torch.empty((), dtype=y.dtype, device=y.device)
+            fn = _lib.lib().fl_mean_square_final_f32 if y.dtype == torch.float32 else _lib.lib().fl_mean_square_final_f64
+            with kernel_timer.span("mean_square_final"):
+                _lib.check(fn(tag.parts.data_ptr(), tag.parts.numel(), 1.0 / y.numel(), loss.data_ptr(), _stream()), "mean_square_final")
+            return loss
     return _MeanSquare.apply(y)
 
 

@@ -128,6 +128,14 @@ def test_objective_rides_in_the_pipeline(gpu, dt, nfft, N, B):
         assert relerr(l1, l0) < tol, (second_use, relerr(l1, l0))
         for a, b, k in zip(g1, g0, ("gx", "gW", "gG")):
             assert relerr(a, b) < 10 * tol, (second_use, k, relerr(a, b))
+    with torch.no_grad():                                    # validation: the value alone, still without a pass over y
+        yv = model(x)
+        ops.kernel_timer.reset(True)
+        lv = ops.mean_square(yv)
+        torch.cuda.synchronize()
+        used = set(ops.kernel_timer.records)
+        ops.kernel_timer.enabled = False
+        assert used == {"mean_square_final"} and relerr(lv, (yv.double() ** 2).mean()) < (1e-12 if dt == F64 else 1e-6)
     # the objective of a tensor that was modified after the pipeline produced it: the generic passes
     y = model(x)
     y.mul_(2.0)
