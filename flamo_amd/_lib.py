@@ -104,6 +104,10 @@ _SIGNATURES = {
     "fl_geq_sections": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fl_geq_sections_bwd": (_i, [_vp, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp]),
     "fl_geq_sections_bwd_w": (_i, [_vp, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "fl_geq_sections_bwd_w64": (_i, [_vp, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "fl_sos_response_rc_c128": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _d, _vp, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
+    "fl_geq_response_rc_c128": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _d, _vp, _i, _i, _i, _vp, _l, _vp, _l, _vp]),
+    "fl_sos_response_bwd_rc_c128": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _d, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "fl_solve_max_n": (_i, [_i]),
     "fl_solve_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),

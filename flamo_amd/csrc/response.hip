@@ -110,16 +110,17 @@ __global__ void __launch_bounds__(256) sos_response_kernel(const double* __restr
 // cascade-type filter): one thread per (output channel m, bin) walks the Nmid cascades of its row, stores G (the
 // backward pass needs it) and the product -- the composition pass over the response-sized tensors and the real -> complex
 // conversion of W (three tiny launches) never run.  G is rounded to float before the product, as the separate passes do.
-template <int NIW>
+// (T = double: the same operator in complex128 with a float64 constant factor, what the reference's float64 examples run)
+template <int NIW, typename T = float>
 __global__ void __launch_bounds__(256) sos_response_rc_kernel(const double* __restrict__ b, const double* __restrict__ a, int S,
-                                                             int C, int Nmid, const float* __restrict__ Wr, double g,
+                                                             int C, int Nmid, const T* __restrict__ Wr, double g,
                                                              const cx<double>* __restrict__ Wd, int nfft, int bin0, int m_local,
-                                                             cx<float>* __restrict__ G, long g_pitch, cx<float>* __restrict__ H,
+                                                             cx<T>* __restrict__ G, long g_pitch, cx<T>* __restrict__ H,
                                                              long h_pitch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lb = reinterpret_cast<double*>(smem);            // [Nmid][3][S]
     double* la = lb + Nmid * 3 * S;
-    float* lw = reinterpret_cast<float*>(la + Nmid * 3 * S);   // [Nmid][NIW]
+    T* lw = reinterpret_cast<T*>(la + Nmid * 3 * S);   // [Nmid][NIW]
     const int m = blockIdx.y;
     for (int i = threadIdx.x; i < Nmid * 3 * S; i += 256) {
         const int j = i / (3 * S), e = i - j * 3 * S;
@@ -131,9 +132,9 @@ __global__ void __launch_bounds__(256) sos_response_rc_kernel(const double* __re
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= m_local) return;
     const SosEval e = sos_point(Wd, nfft, bin_of(f, bin0, nfft), g);
-    cx<float> acc[NIW];
+    cx<T> acc[NIW];
 #pragma unroll
-    for (int n = 0; n < NIW; ++n) acc[n] = cx<float>(0.f, 0.f);
+    for (int n = 0; n < NIW; ++n) acc[n] = cx<T>((T)0, (T)0);
 #pragma unroll 2
     for (int j = 0; j < Nmid; ++j) {
         const double* tb = lb + j * 3 * S;
@@ -146,12 +147,12 @@ __global__ void __launch_bounds__(256) sos_response_rc_kernel(const double* __re
             Bp = Bp * e.poly(tb, S, s);
             Ap = Ap * e.poly(ta, S, s);
         }
-        const cx<double> h = (Ap.x != 0 || Ap.y != 0) ? cdiv(Bp, Ap) : cx<double>((double)eps_of<float>(), 0);
-        const cx<float> hf((float)h.x, (float)h.y);
+        const cx<double> h = (Ap.x != 0 || Ap.y != 0) ? cdiv(Bp, Ap) : cx<double>((double)eps_of<T>(), 0);
+        const cx<T> hf((T)h.x, (T)h.y);
         G[(size_t)(m * Nmid + j) * g_pitch + f] = hf;
 #pragma unroll
         for (int n = 0; n < NIW; ++n) {
-            const float w = lw[j * NIW + n];
+            const T w = lw[j * NIW + n];
             acc[n].x += w * hf.x;
             acc[n].y += w * hf.y;
         }
@@ -512,26 +513,73 @@ __device__ inline cx<double> cdiv_fast(cx<double> a, cx<double> b) {
 // Hs (or null): the forward output.  With it the cascade product is not re-evaluated per bin (24 polynomial values and 24
 // complex products for a graphic equaliser, per section chunk); the section loop shares q_p = conj(gH) H z_p between the
 // sections and takes ONE reciprocal per section for both quotients, 1/|B|^2 = |A|^2 / (|B|^2 |A|^2), as the mixed kernel does.
-template <typename T, int SCH>
+// NIW > 0: "right constant factor" mode of the all-double kernel (see SosRC below: Hs = G is the cascade's own response, gH
+// holds dL/dH of H = G W, planes m * NIW + n) -- the float64 form of the fused Matrix-then-cascade operator.
+struct SosRCd {
+    int Nmid, nbx;       // nbx: bin blocks (the grid is 1-D in this mode)
+    const double* Wr;    // (Nmid, NIW) row-major
+    double* partW;       // (nbx, C, NIW)
+};
+template <typename T, int SCH, int NIW = 0>
 __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __restrict__ gH, long g_pitch, const cx<T>* __restrict__ Hs,
                                                               long h_pitch, const double* __restrict__ b,
                                                               const double* __restrict__ a, int S, int C, double g,
                                                               const cx<double>* __restrict__ Wd, int nfft, int bin0,
-                                                              int m_local, double* __restrict__ part) {
+                                                              int m_local, double* __restrict__ part, SosRCd rc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* lb = reinterpret_cast<double*>(smem);
     double* la = lb + 3 * S;
-    const int c = blockIdx.y;
+    // block -> (bin block bx, channel pair c); constant-factor mode: the Nmid pairs of one output channel on one XCD, as in
+    // the mixed kernel below (they read the same NIW gradient planes)
+    int bx, c, nbx;
+    if (NIW > 0) {
+        nbx = rc.nbx;
+        const int id = blockIdx.x, xcd = id & 7, t = id >> 3;
+        const int j = t % rc.Nmid, pr = (t / rc.Nmid) * 8 + xcd;        // pr = m * nbx + bx
+        if (pr >= (C / rc.Nmid) * nbx) return;
+        bx = pr % nbx;
+        c = (pr / nbx) * rc.Nmid + j;
+    } else {
+        bx = blockIdx.x;
+        nbx = gridDim.x;
+        c = blockIdx.y;
+    }
     stage_taps(b, a, S, C, c, lb, la);
     const int s0 = blockIdx.z * SCH;
     double acc[6 * SCH];   // [(i*3 + p)*SCH + q]: i = b|a, p = tap, q = section of the chunk
 #pragma unroll
     for (int v = 0; v < 6 * SCH; ++v) acc[v] = 0.0;
     const T eps = eps_of<T>();
+    constexpr int NW = NIW > 0 ? NIW : 1;
+    double wrow[NW], accw[NW];
+    const cx<T>* gbase = gH + (size_t)c * g_pitch;
+    if (NIW > 0) {
+        const int mrow = c / rc.Nmid, j = c - mrow * rc.Nmid;
+        gbase = gH + (size_t)mrow * NIW * g_pitch;
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            wrow[n] = rc.Wr[j * NIW + n];
+            accw[n] = 0.0;
+        }
+    }
 
-    for (int f = blockIdx.x * 256 + threadIdx.x; f < m_local; f += gridDim.x * 256) {
+    for (int f = bx * 256 + threadIdx.x; f < m_local; f += nbx * 256) {
         const SosEval e = sos_point(Wd, nfft, bin_of(f, bin0, nfft), g);
-        const cx<T> gin = gH[(size_t)c * g_pitch + f];
+        cx<T> gin;
+        if (NIW > 0) {
+            // dL/dG = sum_n W[j][n] dL/dH[m][n];  dL/dW[j][n] += Re(conj(G) dL/dH[m][n])
+            const cx<T> hv = Hs[(size_t)c * h_pitch + f];
+            gin = cx<T>((T)0, (T)0);
+#pragma unroll
+            for (int n = 0; n < NW; ++n) {
+                const cx<T> t = gbase[(size_t)n * g_pitch + f];
+                gin.x += (T)wrow[n] * t.x;
+                gin.y += (T)wrow[n] * t.y;
+                if (blockIdx.z == 0) accw[n] += (double)hv.x * (double)t.x + (double)hv.y * (double)t.y;
+            }
+        } else {
+            gin = gbase[f];
+        }
         cx<double> h, Ap(1, 0);
         if (Hs) {
             const cx<T> hv = Hs[(size_t)c * h_pitch + f];
@@ -605,8 +653,22 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
         const int s = s0 + q;
         if (s < S) {
             const double v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-            part[((((size_t)blockIdx.x * 2 + i) * 3 + p) * S + s) * C + c] = v;
+            part[((((size_t)bx * 2 + i) * 3 + p) * S + s) * C + c] = v;
         }
+    }
+    if (NIW > 0 && blockIdx.z == 0) {
+        __shared__ double redw[4][NW];
+#pragma unroll
+        for (int n = 0; n < NW; ++n) {
+            double v = accw[n];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) redw[wave][n] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < NW)
+            rc.partW[((size_t)bx * C + c) * NW + threadIdx.x] =
+                redw[0][threadIdx.x] + redw[1][threadIdx.x] + redw[2][threadIdx.x] + redw[3][threadIdx.x];
     }
 }
 
@@ -1037,16 +1099,26 @@ __global__ void __launch_bounds__(256) geq_sections_bwd_kernel(const void* __res
                                                               const double* __restrict__ ga, long blk_stride, int nblk,
                                                               int nb, int C, const double* __restrict__ k,
                                                               void* __restrict__ ggain, int main_blocks,
-                                                              const float* __restrict__ partW, int wrows, int wn,
-                                                              float* __restrict__ gW) {
+                                                              const void* __restrict__ partW_, int wrows, int wn,
+                                                              void* __restrict__ gW_, int w_f64) {
     if ((int)blockIdx.x >= main_blocks) {
         const int e = ((int)blockIdx.x - main_blocks) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
         if (e >= wn) return;
+        if (w_f64) {
+            const double* partW = reinterpret_cast<const double*>(partW_);
+            double v = 0.0;
+            for (int r = lane; r < wrows; r += 64) v += partW[(size_t)r * wn + e];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) reinterpret_cast<double*>(gW_)[e] = v;
+            return;
+        }
+        const float* partW = reinterpret_cast<const float*>(partW_);
         float v = 0.f;
         for (int r = lane; r < wrows; r += 64) v += partW[(size_t)r * wn + e];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) gW[e] = v;
+        if (lane == 0) reinterpret_cast<float*>(gW_)[e] = v;
         return;
     }
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1192,7 +1264,7 @@ static int sos_impl(const void* b, const void* a, int S, int C, double gamma, co
 template <typename T>
 static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S, int C,
                         double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream,
-                        int rc_ni = 0, SosRC rc = SosRC{0, 0, nullptr, nullptr}) {
+                        int rc_ni = 0, SosRC rc = SosRC{0, 0, nullptr, nullptr}, SosRCd rcd = SosRCd{0, 0, nullptr, nullptr}) {
     FL_REQUIRE((gH || rc.oG) && b && a && part && Wd, "sos_response_bwd: null pointer");
     FL_REQUIRE(g_pitch >= m_local && (!H || h_pitch >= m_local), "sos_response_bwd: g_pitch / h_pitch must be >= m_local");
     FL_REQUIRE(S > 0 && S <= 1024 && C > 0 && C <= 65535 && nfft > 0 && bin_range_ok(bin0, m_local, nfft) && m_local > 0, "sos_response_bwd: bad sizes");
@@ -1228,14 +1300,36 @@ static int sos_bwd_impl(const void* gH, long g_pitch, const void* H, long h_pitc
             return FL_OK;
         }
     }
-    FL_REQUIRE(rc_ni == 0 && !rc.oG, "sos_response_bwd: the constant-factor and outer-product modes need float32 and the saved forward response");
+    FL_REQUIRE(!rc.oG, "sos_response_bwd: the outer-product mode needs float32 and the saved forward response");
+    if (rc_ni > 0) {      // constant-factor mode of the all-double kernel: one section chunk (the NIW gradient planes are read once)
+        if constexpr (sizeof(T) == 8) {
+            FL_REQUIRE(H && rcd.Wr && rcd.partW && rcd.Nmid > 0, "sos_response_bwd: constant-factor mode needs the saved response");
+            rcd.nbx = sos_blocks(m_local, C, S, false);
+            const dim3 grid(cdiv_i((C / rcd.Nmid) * rcd.nbx, 8) * 8 * rcd.Nmid, 1, cdiv_i(S, 6));
+#define FL_SOS_BWD_RC(NIW_)                                                                                              \
+    if (rc_ni == NIW_)                                                                                                   \
+        hipLaunchKernelGGL((sos_response_bwd_kernel<double, 6, NIW_>), grid, dim3(256), (size_t)6 * S * sizeof(double), \
+                           (hipStream_t)stream, (const cx<double>*)gH, g_pitch, (const cx<double>*)H, h_pitch,           \
+                           (const double*)b, (const double*)a, S, C, gamma, (const cx<double>*)Wd, nfft, bin0, m_local,  \
+                           (double*)part, rcd);
+            FL_SOS_BWD_RC(2) else FL_SOS_BWD_RC(4) else FL_SOS_BWD_RC(8) else FL_SOS_BWD_RC(16) else {
+                set_error("sos_response_bwd: no kernel for %d input channels of the constant factor", rc_ni);
+                return FL_ERR_UNSUPPORTED;
+            }
+#undef FL_SOS_BWD_RC
+            FL_CHECK_LAUNCH("sos_response_bwd_rc");
+            return FL_OK;
+        }
+        set_error("sos_response_bwd: the float32 constant-factor mode needs the saved forward response");
+        return FL_ERR_BAD_ARG;
+    }
     const int sch = sos_chunk_of(S, false);
 #define FL_SOS_BWD(SC)                                                                                              \
     {                                                                                                               \
         dim3 grid(sos_blocks(m_local, C, S, false), C, cdiv_i(S, SC));                                              \
         hipLaunchKernelGGL((sos_response_bwd_kernel<T, SC>), grid, dim3(256), (size_t)6 * S * sizeof(double),      \
                            (hipStream_t)stream, (const cx<T>*)gH, g_pitch, (const cx<T>*)H, h_pitch, (const double*)b, (const double*)a, S, C, gamma, \
-                           (const cx<double>*)Wd, nfft, bin0, m_local, (double*)part);                              \
+                           (const cx<double>*)Wd, nfft, bin0, m_local, (double*)part, SosRCd{0, 0, nullptr, nullptr}); \
     }
     if (sch == 12) FL_SOS_BWD(12)
     else if (sch == 6) FL_SOS_BWD(6)
@@ -1313,25 +1407,35 @@ int fl_geq_sections_bwd(const void* gain, int in_kind, const void* gb, const voi
     const int mb = cdiv_i((long)nb * C, 256);
     hipLaunchKernelGGL(geq_sections_bwd_kernel, dim3(mb), dim3(256), 0, (hipStream_t)stream,
                        gain, in_kind, (const double*)gb, (const double*)ga, blk_stride, nblk, nb, C,
-                       (const double*)consts, ggain, mb, (const float*)nullptr, 0, 0, (float*)nullptr);
+                       (const double*)consts, ggain, mb, (const void*)nullptr, 0, 0, (void*)nullptr, 0);
     FL_CHECK_LAUNCH("geq_sections_bwd");
     return FL_OK;
 }
-int fl_geq_sections_bwd_w(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
-                          int C, const void* consts, void* ggain, const void* partW, int wrows, int wn, void* gW, void* stream) {
+static int geq_bwd_w_impl(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
+                          int C, const void* consts, void* ggain, const void* partW, int wrows, int wn, void* gW, int w_f64, void* stream) {
     FL_REQUIRE(gain && gb && ga && consts && ggain && partW && gW, "geq_sections_bwd_w: null pointer");
     FL_REQUIRE(nb >= 4 && C > 0 && nblk > 0 && in_kind >= 0 && in_kind <= 4 && wrows > 0 && wn > 0, "geq_sections_bwd_w: bad sizes");
     const int mb = cdiv_i((long)nb * C, 256);
     hipLaunchKernelGGL(geq_sections_bwd_kernel, dim3(mb + cdiv_i(wn, 4)), dim3(256), 0, (hipStream_t)stream,
                        gain, in_kind, (const double*)gb, (const double*)ga, blk_stride, nblk, nb, C,
-                       (const double*)consts, ggain, mb, (const float*)partW, wrows, wn, (float*)gW);
+                       (const double*)consts, ggain, mb, partW, wrows, wn, gW, w_f64);
     FL_CHECK_LAUNCH("geq_sections_bwd_w");
     return FL_OK;
+}
+int fl_geq_sections_bwd_w(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
+                          int C, const void* consts, void* ggain, const void* partW, int wrows, int wn, void* gW, void* stream) {
+    return geq_bwd_w_impl(gain, in_kind, gb, ga, blk_stride, nblk, nb, C, consts, ggain, partW, wrows, wn, gW, 0, stream);
+}
+int fl_geq_sections_bwd_w64(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
+                            int C, const void* consts, void* ggain, const void* partW, int wrows, int wn, void* gW, void* stream) {
+    return geq_bwd_w_impl(gain, in_kind, gb, ga, blk_stride, nblk, nb, C, consts, ggain, partW, wrows, wn, gW, 1, stream);
 }
 int fl_sos_response_bwd_c64(const void* gH, long g_pitch, const void* H, long h_pitch, const void* b, const void* a, int S,
                             int C, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* part, void* stream) {
     return sos_bwd_impl<float>(gH, g_pitch, H, h_pitch, b, a, S, C, gamma, Wd, nfft, bin0, m_local, part, stream);
 }
+}  // extern "C"
+template <typename T>
 static int rc_impl(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
                    const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
                    int float_eval, void* stream, GeqDesign gd) {
@@ -1341,13 +1445,14 @@ static int rc_impl(const void* b, const void* a, int S, int No, int Nmid, int Ni
                    m_local >= 0, "sos_response_rc: bad sizes");
     if (m_local == 0) return FL_OK;
     dim3 grid(cdiv_i(m_local, 256), No);
-    const size_t lds = (size_t)Nmid * 6 * S * sizeof(double) + (size_t)Nmid * Ni * sizeof(float);
+    const size_t lds = (size_t)Nmid * 6 * S * sizeof(double) + (size_t)Nmid * Ni * sizeof(T);
+    FL_REQUIRE(lds <= 64 * 1024, "sos_response_rc: the coefficient tables of one output row exceed 64 KB of LDS");
     const size_t lds_fast = ((size_t)Nmid * 12 * ((S + 1) & ~1) + (size_t)Nmid * Ni) * sizeof(float);
     // the float kernel's threads take bin PAIRS: half the elements (+ the Nyquist element as a pair of its own in row-major order)
     const int npairs = bin0 >= 0 ? cdiv_i(m_local, 2) : (((nfft / 2 / (-bin0)) + 1) / 2) * (-bin0) + 1;
     const dim3 grid_fast(cdiv_i(npairs, 256), No);
 #define FL_RC_FWD(NIW_)                                                                                                      \
-    if (Ni == NIW_ && g_rc_fast && float_eval) {                                                                             \
+    if constexpr (sizeof(T) == 4) if (Ni == NIW_ && g_rc_fast && float_eval) {                                                                             \
         if (g_rc_fast == 2)                                                                                                  \
             hipLaunchKernelGGL((sos_response_rc_fast_kernel<NIW_, 2>), grid_fast, dim3(256), lds_fast, (hipStream_t)stream,       \
                                (const double*)b, (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma,              \
@@ -1373,9 +1478,9 @@ static int rc_impl(const void* b, const void* a, int S, int No, int Nmid, int Ni
                                gd.in_kind, S, No * Nmid, gd.k, gd.b_out, gd.a_out);                                              \
             FL_CHECK_LAUNCH("geq_sections");                                                                                     \
         }                                                                                                                        \
-        hipLaunchKernelGGL((sos_response_rc_kernel<NIW_>), grid, dim3(256), lds, (hipStream_t)stream, (const double*)b,      \
-                           (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma, (const cx<double>*)Wd, nfft, bin0, \
-                           m_local, (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch);                                         \
+        hipLaunchKernelGGL((sos_response_rc_kernel<NIW_, T>), grid, dim3(256), lds, (hipStream_t)stream, (const double*)b,   \
+                           (const double*)a, S, No * Nmid, Nmid, (const T*)Wr, gamma, (const cx<double>*)Wd, nfft, bin0,     \
+                           m_local, (cx<T>*)G, g_pitch, (cx<T>*)H, h_pitch);                                                 \
         FL_CHECK_LAUNCH("sos_response_rc");                                                                                  \
         return FL_OK;                                                                                                        \
     }
@@ -1384,15 +1489,24 @@ static int rc_impl(const void* b, const void* a, int S, int No, int Nmid, int Ni
     set_error("sos_response_rc: no kernel for %d input channels of the constant factor", Ni);
     return FL_ERR_UNSUPPORTED;
 }
+extern "C" {
 int fl_sos_response_rc_c64(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
                            const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
                            int float_eval, void* stream) {
-    return rc_impl(b, a, S, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, G, g_pitch, H, h_pitch, float_eval, stream,
-                   GeqDesign{nullptr, 0, nullptr, nullptr, nullptr});
+    return rc_impl<float>(b, a, S, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, G, g_pitch, H, h_pitch, float_eval, stream,
+                          GeqDesign{nullptr, 0, nullptr, nullptr, nullptr});
 }
-int fl_geq_response_rc_c64(const void* gain, int in_kind, int nb, const void* consts, void* b, void* a, int No, int Nmid, int Ni,
-                           const void* Wr, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch,
-                           void* H, long h_pitch, int float_eval, void* stream) {
+int fl_sos_response_rc_c128(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
+                            const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
+                            void* stream) {
+    return rc_impl<double>(b, a, S, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, G, g_pitch, H, h_pitch, 0, stream,
+                           GeqDesign{nullptr, 0, nullptr, nullptr, nullptr});
+}
+}  // extern "C"
+template <typename T>
+static int geq_rc_impl(const void* gain, int in_kind, int nb, const void* consts, void* b, void* a, int No, int Nmid, int Ni,
+                       const void* Wr, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch,
+                       void* H, long h_pitch, int float_eval, void* stream) {
     FL_REQUIRE(gain && consts, "geq_response_rc: null pointer");
     FL_REQUIRE(in_kind >= 0 && in_kind <= 4 && nb >= 4, "geq_response_rc: in_kind in [0, 4], at least four bands");
     if (m_local == 0) {      // nothing to evaluate: the sections are still an output
@@ -1401,8 +1515,21 @@ int fl_geq_response_rc_c64(const void* gain, int in_kind, int nb, const void* co
         FL_CHECK_LAUNCH("geq_sections");
         return FL_OK;
     }
-    return rc_impl(b, a, nb, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, G, g_pitch, H, h_pitch, float_eval, stream,
-                   GeqDesign{gain, in_kind, (const double*)consts, (double*)b, (double*)a});
+    return rc_impl<T>(b, a, nb, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, G, g_pitch, H, h_pitch, float_eval, stream,
+                      GeqDesign{gain, in_kind, (const double*)consts, (double*)b, (double*)a});
+}
+extern "C" {
+int fl_geq_response_rc_c64(const void* gain, int in_kind, int nb, const void* consts, void* b, void* a, int No, int Nmid, int Ni,
+                           const void* Wr, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch,
+                           void* H, long h_pitch, int float_eval, void* stream) {
+    return geq_rc_impl<float>(gain, in_kind, nb, consts, b, a, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, G, g_pitch, H,
+                              h_pitch, float_eval, stream);
+}
+int fl_geq_response_rc_c128(const void* gain, int in_kind, int nb, const void* consts, void* b, void* a, int No, int Nmid, int Ni,
+                            const void* Wr, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch,
+                            void* H, long h_pitch, void* stream) {
+    return geq_rc_impl<double>(gain, in_kind, nb, consts, b, a, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, G, g_pitch, H,
+                               h_pitch, 0, stream);
 }
 int fl_sos_response_apply_max_ni(int S) {      // cascades per row whose coefficient tables fit the default 64 KB of dynamic LDS
     const int SP = (S + 1) & ~1;
@@ -1437,6 +1564,14 @@ int fl_sos_response_bwd_rc_c64(const void* gHfull, long g_pitch, const void* G, 
     SosRC rc{Nmid, 0, (const float*)Wr, (float*)partW};
     return sos_bwd_impl<float>(gHfull, g_pitch, G, h_pitch, b, a, S, No * Nmid, gamma, Wd, nfft, bin0, m_local, part, stream,
                                Ni, rc);
+}
+int fl_sos_response_bwd_rc_c128(const void* gHfull, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
+                                int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,
+                                int bin0, int m_local, void* part, void* partW, void* stream) {
+    FL_REQUIRE(G && Wr && partW && No > 0 && Nmid > 0 && Ni > 0, "sos_response_bwd_rc: bad arguments");
+    SosRCd rcd{Nmid, 0, (const double*)Wr, (double*)partW};
+    return sos_bwd_impl<double>(gHfull, g_pitch, G, h_pitch, b, a, S, No * Nmid, gamma, Wd, nfft, bin0, m_local, part, stream,
+                                Ni, SosRC{0, 0, nullptr, nullptr}, rcd);
 }
 int fl_sos_response_bwd_outer_c64(const void* gY, long gy_sb, long gy_sn, const void* X, long x_sb, long x_sn, int B, int No, int Ni,
                                   const void* H, long h_pitch, const void* b, const void* a, int S, double gamma, const void* Wd,

@@ -1963,12 +1963,17 @@ def geq_cascade_apply(x, consts, X, gamma: float, nfft: int, dtype=torch.float32
 
 def cascade_rc_supported(real: torch.dtype, n_in: int, n_mid: int = 1, n_sections: int = 1) -> bool:
     """cascade response (n_mid cascades of n_sections per output row) times a real constant matrix with n_in columns: the
-    fused operator exists -- float32, 2/4/8/16 columns, and fl_sos_response_rc_c64's own limits (n_mid <= 32, <= 64 sections,
-    coefficient tables of one output row within the default 64 KB of dynamic LDS: n_mid * 6 * sections doubles)."""
-    if not (real == torch.float32 and SOS_BWD_MIXED and int(n_in) in (2, 4, 8, 16)):
+    fused operator exists -- 2/4/8/16 columns, and fl_sos_response_rc_c64 / _c128's own limits (n_mid <= 32, <= 64 sections
+    -- 12 in float64 --, coefficient tables of one output row within the default 64 KB of dynamic LDS: n_mid * 6 * sections
+    doubles)."""
+    if int(n_in) not in (2, 4, 8, 16):
         return False
     n_mid, n_sections = int(n_mid), int(n_sections)
     if n_mid < 1 or n_mid > 32 or n_sections < 1 or n_sections > 64:
+        return False
+    if real == torch.float64:      # the all-double kernels: the backward keeps one chunk of at most 12 sections in registers
+        return n_sections <= 12 and n_mid * 6 * n_sections * 8 + n_mid * int(n_in) * 8 <= 64 * 1024
+    if not (real == torch.float32 and SOS_BWD_MIXED):
         return False
     return n_mid * 6 * n_sections * 8 + n_mid * int(n_in) * 4 <= 64 * 1024
 
@@ -1984,12 +1989,22 @@ def _cascade_rc_forward(b, a, Wr, gamma, nfft, real, float_eval, geq=None):
         raise ValueError(f"cascade_rc: the constant factor must be ({Nmid}, N_in), got {tuple(Wr.shape)}")
     Ni = Wr.shape[1]
     bin0, m_local = _bin0_arg(nfft)
-    G = _empty_rows((No, Nmid), m_local, torch.complex64, dev)
-    H = _empty_rows((No, Ni), m_local, torch.complex64, dev)
+    f64 = real == torch.float64
+    G = _empty_rows((No, Nmid), m_local, _cdtype(real), dev)
+    H = _empty_rows((No, Ni), m_local, _cdtype(real), dev)
     Wc = Wr.contiguous()
     P = _pitch(m_local)
     with kernel_timer.span("sos_response_rc"):
-        if geq is not None:
+        if f64 and geq is not None:
+            xc, kind, consts = geq
+            _lib.check(_lib.lib().fl_geq_response_rc_c128(xc.data_ptr(), kind, S, consts.data_ptr(), b.data_ptr(), a.data_ptr(), No, Nmid, Ni,
+                                                          Wc.data_ptr(), float(gamma), twiddles(nfft, torch.float64, dev).data_ptr(), nfft,
+                                                          bin0, m_local, G.data_ptr(), P, H.data_ptr(), P, _stream()), "geq_response_rc")
+        elif f64:
+            _lib.check(_lib.lib().fl_sos_response_rc_c128(b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni, Wc.data_ptr(), float(gamma),
+                                                          twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local,
+                                                          G.data_ptr(), P, H.data_ptr(), P, _stream()), "sos_response_rc")
+        elif geq is not None:
             xc, kind, consts = geq
             _lib.check(_lib.lib().fl_geq_response_rc_c64(xc.data_ptr(), kind, S, consts.data_ptr(), b.data_ptr(), a.data_ptr(), No, Nmid, Ni,
                                                          Wc.data_ptr(), float(gamma), twiddles(nfft, torch.float64, dev).data_ptr(), nfft,
@@ -2004,18 +2019,19 @@ def _cascade_rc_forward(b, a, Wr, gamma, nfft, real, float_eval, geq=None):
 
 
 def _cascade_rc_backward(gH, G, b, a, Wr, cfg):
-    """-> (part: float64 (nblk, 2, 3, S, C), gW: float32 (Nmid, Ni))"""
+    """-> (part: float64 (nblk, 2, 3, S, C), partW: (nblk, No, Nmid, Ni) in the response's real dtype)"""
     gamma, nfft, S, C_, bin0, m_local, real = cfg
     No, Nmid = G.shape[0], G.shape[1]
     Ni = Wr.shape[1]
     g = _h_planar(gH.resolve_conj(), True)
     L = _lib.lib()
-    nblk = L.fl_sos_bwd_blocks(m_local, C_, S, 1)
+    nblk = L.fl_sos_bwd_blocks(m_local, C_, S, 0 if real == torch.float64 else 1)
     part = torch.empty((nblk, 2, 3, S, C_), dtype=torch.float64, device=b.device)
-    partW = torch.empty((nblk, No, Nmid, Ni), dtype=torch.float32, device=b.device)
+    partW = torch.empty((nblk, No, Nmid, Ni), dtype=real, device=b.device)
     Wc = Wr.contiguous()
+    fn = L.fl_sos_response_bwd_rc_c128 if real == torch.float64 else L.fl_sos_response_bwd_rc_c64
     with kernel_timer.span("sos_response_bwd_rc"):
-        _lib.check(L.fl_sos_response_bwd_rc_c64(g.data_ptr(), _lead_pitch(g.movedim(0, -1)), G.data_ptr(), _pitch(m_local),
+        _lib.check(fn(g.data_ptr(), _lead_pitch(g.movedim(0, -1)), G.data_ptr(), _pitch(m_local),
                                                 b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni, Wc.data_ptr(), gamma,
                                                 twiddles(nfft, torch.float64, b.device).data_ptr(), nfft, bin0, m_local,
                                                 part.data_ptr(), partW.data_ptr(), _stream()), "sos_response_bwd_rc")
@@ -2075,21 +2091,22 @@ class _GeqCascadeRC(torch.autograd.Function):
         gW = torch.empty_like(Wr, memory_format=torch.contiguous_format)
         esz = part.element_size()
         # design backward (sums the bin-block partials) + the constant factor's partials, one launch
-        _lib.check(_lib.lib().fl_geq_sections_bwd_w(xc.data_ptr(), _geq_in_kind(xc, True, ctx.sig), part.data_ptr(),
-                                                    part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
-                                                    out.data_ptr(), partW.data_ptr(), partW.shape[0] * partW.shape[1],
-                                                    partW.shape[2] * partW.shape[3], gW.data_ptr(), _stream()), "geq_sections_bwd_w")
+        fn = _lib.lib().fl_geq_sections_bwd_w64 if partW.dtype == torch.float64 else _lib.lib().fl_geq_sections_bwd_w
+        _lib.check(fn(xc.data_ptr(), _geq_in_kind(xc, True, ctx.sig), part.data_ptr(),
+                      part.data_ptr() + 3 * st * esz, 6 * st, nblk, nb, C_, consts.data_ptr(),
+                      out.data_ptr(), partW.data_ptr(), partW.shape[0] * partW.shape[1],
+                      partW.shape[2] * partW.shape[3], gW.data_ptr(), _stream()), "geq_sections_bwd_w")
         return out, None, gW, None, None, None, None
 
 
 def sos_response_rc(b, a, Wr, gamma: float, nfft: int, dtype=torch.float32) -> torch.Tensor:
     """sos_response(b, a) (M, N_out, N_mid) times the real constant matrix Wr (N_mid, N_in) on the right, per bin."""
-    return _SosRC.apply(b.to(torch.float64), a.to(torch.float64), Wr.to(torch.float32), float(gamma), int(nfft), dtype)
+    return _SosRC.apply(b.to(torch.float64), a.to(torch.float64), Wr.to(dtype), float(gamma), int(nfft), dtype)
 
 
 def geq_cascade_rc(x, consts, Wr, gamma: float, nfft: int, dtype=torch.float32, gain_map: str = "abs") -> torch.Tensor:
     """geq_cascade(x, ...) (M, N_out, N_mid) times the real constant matrix Wr (N_mid, N_in) on the right, per bin."""
-    return _GeqCascadeRC.apply(x, consts, Wr.to(torch.float32), float(gamma), int(nfft), dtype, _is_sigmoid(gain_map))
+    return _GeqCascadeRC.apply(x, consts, Wr.to(dtype), float(gamma), int(nfft), dtype, _is_sigmoid(gain_map))
 
 
 def _is_sigmoid(gain_map: str) -> bool:

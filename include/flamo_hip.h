@@ -372,6 +372,20 @@ int fl_geq_response_rc_c64(const void* gain, int in_kind, int nb, const void* co
 int fl_sos_response_bwd_rc_c64(const void* gHfull, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
                                int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,
                                int bin0, int m_local, void* part, void* partW, void* stream);
+/* The three operators above in complex128 with a float64 constant factor (Wr, partW double; G, H, gHfull complex128) --
+ * the same Series(Matrix, <cascade-type filter>) of system.py:299-300 when the model is built with dtype=torch.float64, the
+ * default of the reference's example scripts (examples/e7_biquad.py:237).  Everything is evaluated in double (the kernels
+ * of fl_sos_response_c128 / fl_sos_response_bwd_c128 with the composition folded in); the backward takes cascades of at most
+ * 12 sections (one register-resident chunk, so that the Ni gradient planes are read once). */
+int fl_sos_response_rc_c128(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma,
+                            const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch,
+                            void* stream);
+int fl_geq_response_rc_c128(const void* gain, int in_kind, int nb, const void* consts, void* b, void* a, int No, int Nmid, int Ni,
+                            const void* Wr, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* G, long g_pitch,
+                            void* H, long h_pitch, void* stream);
+int fl_sos_response_bwd_rc_c128(const void* gHfull, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
+                                int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,
+                                int bin0, int m_local, void* part, void* partW, void* stream);
 
 /* Graphic-equaliser design: command gains -> the float32-rounded second-order sections of
  * GEQ / parallelGEQ for all C channel pairs at once (replaces the Python double loop over
@@ -396,6 +410,9 @@ int fl_geq_sections_bwd(const void* gain, int in_kind, const void* gb, const voi
  * blocks * No, wn = Nmid * Ni). */
 int fl_geq_sections_bwd_w(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
                           int C, const void* consts, void* ggain, const void* partW, int wrows, int wn, void* gW, void* stream);
+/* ... with double partW / gW (the partials of fl_sos_response_bwd_rc_c128) */
+int fl_geq_sections_bwd_w64(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
+                            int C, const void* consts, void* ggain, const void* partW, int wrows, int wn, void* gW, void* stream);
 
 /* ------------------------------------------------------------------ closed loop
  * Replace torch.linalg.solve(A, B) in system.Recursion.forward (system.py:420-425).

@@ -202,3 +202,56 @@ def test_inverse_column_pass_leaves_the_sum_of_squares(gpu, dt, nfft, G, B, t_ou
     fn = _lib.lib().fl_mean_square_final_f32 if dt == torch.float32 else _lib.lib().fl_mean_square_final_f64
     _lib.check(fn(parts.data_ptr(), parts.numel(), 1.0 / y1.numel(), loss.data_ptr(), ops._stream()), "mean_square_final")
     assert abs(loss.item() / (want.item() / y1.numel()) - 1.0) < (1e-12 if dt == F64 else 2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,nfft,N", [("geq", 96000, 8), ("biquad", 48000, 4), ("svf", 4800, 2), ("geq", 2048, 16)])
+def test_matrix_cascade_operator_float64(gpu, kind, nfft, N):
+    """Series(Matrix, cascade filter) built with dtype=float64 (examples/e7_biquad.py:237's default): the fused pair
+    operator in complex128 (fl_sos_response_rc_c128 / fl_geq_response_rc_c128 forward, fl_sos_response_bwd_rc_c128
+    backward with the constant factor's partials in double) against the generic composition of the two responses --
+    output and both parameter gradients -- and its response against the float64 oracle's."""
+    from collections import OrderedDict
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    from oracle import hotpath as O
+    torch.manual_seed(7 + N)
+    kw = dict(nfft=nfft, alias_decay_db=0.0, device=gpu, dtype=F64, requires_grad=True)
+    mat = dsp.Matrix(size=(N, N), matrix_type="random", **kw)
+    if kind == "geq":
+        flt = dsp.GEQ(size=(N, N), **kw)
+    elif kind == "biquad":
+        flt = dsp.Biquad(size=(N, N), n_sections=3, filter_type="bandpass", **kw)
+    else:
+        flt = dsp.SVF(size=(N, N), n_sections=2, **kw)
+    shell = system.Shell(system.Series(OrderedDict(mix=mat, flt=flt)), dsp.FFT(nfft, dtype=F64), dsp.iFFT(nfft, dtype=F64))
+    params = [mat.param, flt.param]
+    x = torch.randn(2, nfft, N, device=gpu, dtype=F64)
+
+    def run():
+        ops.kernel_timer.reset(True)
+        y = shell(x)
+        g = torch.autograd.grad(ops.mean_square(y), params)
+        torch.cuda.synchronize()
+        used = set(ops.kernel_timer.records)
+        ops.kernel_timer.enabled = False
+        return y.detach(), g, used
+
+    y1, g1, used1 = run()
+    assert "sos_response_rc" in used1 and "sos_response_bwd_rc" in used1, used1
+    system.FUSE_MATRIX_CASCADE = False
+    try:
+        y2, g2, used2 = run()
+    finally:
+        system.FUSE_MATRIX_CASCADE = True
+    assert "sos_response_bwd_rc" not in used2
+    assert relerr(y1, y2) < 1e-12
+    for a, b in zip(g1, g2):
+        assert a.dtype == F64 and relerr(a, b) < 1e-10, kind
+    if kind == "geq":
+        spec = flt._cascade_spec(flt.param)
+        W = mat.map(mat.param.detach())
+        H = ops.geq_cascade_rc(spec[1], spec[2], W, flt._gamma_f, nfft, dtype=F64)
+        assert H.dtype == torch.complex128
+        Href = O.geq_response(flt.param.detach().cpu().double(), nfft, O.gamma_of(0.0, nfft, F64)) @ W.cpu().to(torch.complex128)
+        assert relerr(H.cpu(), Href) < 1e-12
