@@ -835,7 +835,9 @@ static int g_walk_wgs = 0;        // workgroups of the forward walking kernel (0
 static int g_walk_slices = 0;     // batch slices of the backward walking kernel (0: CUs / row pairs)
 static long long* g_walk_times = nullptr;
 static int g_walk_nsc = 2;        // output-channel groups of the backward kernel (tuning: fl_debug_set_walk mode 14 -> 4)
-static int g_walk_fc = [] { const char* e = getenv("FLAMO_WALK_FC"); return e ? atoi(e) : 38; }();      // cost of entering a row pair, in twentieths of a unit
+static int g_walk_fc = [] { const char* e = getenv("FLAMO_WALK_FC"); return e ? atoi(e) : 38; }();      // cost of a workgroup's first row pair, in twentieths of a unit
+static int g_walk_fc2 = [] { const char* e = getenv("FLAMO_WALK_FC2"); return e ? atoi(e) : 38; }();    // ... of changing to the next one
+static int g_walk_us = [] { const char* e = getenv("FLAMO_WALK_US"); return e ? atoi(e) : 16; }();      // a unit of a self-mirrored row pair
 
 static int device_cus() {       // of the current device, cached per device
     static int cus[kMaxDevices] = {};
@@ -1051,7 +1053,7 @@ int fl_spec_walk_partition(int nfft, int Bn, int n_wg, int* bounds) {
     // round 3: with the earlier 1.55 units per entry the workgroups that enter two row pairs finished 6 % behind the rest).
     // Equal unit COUNTS left the slowest workgroup 13-19 % above the mean.  Costs in twentieths of a unit; the smallest cap for which a greedy sweep needs no more than
     // n_wg ranges (binary search), then the sweep's cuts.
-    const int P = L1 / 2 + 1, U = P * Bn, UC = 20, US = 16, FC = g_walk_fc;
+    const int P = L1 / 2 + 1, U = P * Bn, UC = 20, US = g_walk_us, FC = g_walk_fc, FC2 = g_walk_fc2;
     auto ucost = [&](int u) { const int r = u / Bn; return (r == 0 || 2 * r == L1) ? US : UC; };
     auto sweep = [&](long cap, int* out) {       // number of ranges used; out[i] = first unit of range i
         int n = 0, u = 0;
@@ -1063,7 +1065,7 @@ int fl_spec_walk_partition(int nfft, int Bn, int n_wg, int* bounds) {
             ++u;
             while (u < U) {
                 const int r = u / Bn;
-                const long add = ucost(u) + (r != last_r ? FC : 0);
+                const long add = ucost(u) + (r != last_r ? FC2 : 0);
                 if (c + add > cap) break;
                 c += add;
                 last_r = r;
