@@ -172,6 +172,20 @@ __global__ void __launch_bounds__(256) sos_response_rc_kernel(const double* __re
 // gains (eq.py:57-111, the arithmetic of geq_sections_kernel) instead of being read -- every workgroup needs the 12 sections
 // of its N_mid cascades, one per thread -- and the first bin block of each output channel writes them out for the backward
 // pass: the design launch in front of this one (5 us and a dispatch gap in the config-2 step) is gone.
+// The section polynomial turned by half a sample: with w = exp(-i omega), z = g w,
+//     B(z) conj(w) = b0 conj(w) + g b1 + g^2 b2 w = [S cos(omega) + T] + i [D sin(omega)],   S = b0 + g^2 b2, T = g b1, D = b0 - g^2 b2
+// -- real and imaginary part are ONE multiply-add and ONE multiply (the monomial and the 1 -+ w forms take four), every
+// section of B and of A carries the same unit factor conj(w), so prod B / prod A, |B|^2 and the quotients the backward
+// pass forms are unchanged.  Float-safe as the 1 -+ w form is: about the nearer of omega = 0 / pi,
+//     Re = (S + T) - S x,  x = 1 - cos(omega)   (bins below nfft/4)     |     Re = (T - S) + S x,  x = 1 + cos(omega)
+// with the sums formed in double and x formed in double from the float64 twiddle before rounding.  Table entry of a
+// section: (c0, c1, c2) with Re = c0 + c1 x, Im = c2 sin(omega), `pitch` floats apart.
+__device__ inline void half_turn_tables(double t0, double t1, double t2, double g, float* lo, float* hi, int pitch) {
+    const double S = t0 + g * g * t2, T = g * t1, D = t0 - g * g * t2;
+    lo[0] = (float)(S + T); lo[pitch] = (float)(-S); lo[2 * pitch] = (float)D;
+    hi[0] = (float)(T - S); hi[pitch] = (float)S;    hi[2 * pitch] = (float)D;
+}
+
 struct GeqDesign {
     const void* gain;      // (nb, C) command gains / raw parameters, or null: sections are read from b, a
     int in_kind;
@@ -221,8 +235,7 @@ __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double*
             const double t0 = poly ? ta[0] : tb[0], t1 = poly ? ta[1] : tb[1], t2 = poly ? ta[2] : tb[2];
             float* lo = cf + ((size_t)j * 4 + 0 * 2 + poly) * 3 * SP;
             float* hi = cf + ((size_t)j * 4 + 1 * 2 + poly) * 3 * SP;
-            lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
-            hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+            half_turn_tables(t0, t1, t2, g, lo + sidx, hi + sidx, SP);
         }
     }
     for (int i = threadIdx.x; i < Nmid * NIW; i += 256) lw[i] = Wr[i];
@@ -254,16 +267,14 @@ __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double*
         }
     }
     bool low[2];
-    float xr[2], xi[2], x2r[2], x2i[2];
+    float xr[2], xi[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int k = bin_of(e[q], bin0, nfft);
         const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
-        const cx<double> z1(g * w1.x, g * w1.y);
         low[q] = 4 * (long)k < nfft;
-        const double xrd = low[q] ? 1.0 - z1.x : 1.0 + z1.x, xid = low[q] ? -z1.y : z1.y;
-        xr[q] = (float)xrd; xi[q] = (float)xid;
-        x2r[q] = (float)(xrd * xrd - xid * xid); x2i[q] = (float)(2.0 * xrd * xid);
+        xr[q] = (float)(low[q] ? 1.0 - w1.x : 1.0 + w1.x);      // 1 -+ cos(omega), formed in double
+        xi[q] = (float)(-w1.y);                                  // sin(omega)
     }
     const bool same = low[0] == low[1];
     cx<float> acc[2][NIW];
@@ -277,10 +288,10 @@ __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double*
         for (int q = 0; q < 2; ++q) {
             pbr[q] = (f2)(1.f); pbi[q] = (f2)(0.f); par[q] = (f2)(1.f); pai[q] = (f2)(0.f);
         }
-        // one section pair of bin q: c0 + c1 x + c2 x^2 (x^2 shared by all sections) times the running products
+        // one section pair of bin q: (c0 + c1 x) + i c2 sin(omega) (half_turn_tables) times the running products
         auto step = [&](int q, f2 b0, f2 b1, f2 b2, f2 a0, f2 a1, f2 a2) {
-            const f2 Br = b0 + b1 * xr[q] + b2 * x2r[q], Bi = b1 * xi[q] + b2 * x2i[q];
-            const f2 Ar = a0 + a1 * xr[q] + a2 * x2r[q], Ai = a1 * xi[q] + a2 * x2i[q];
+            const f2 Br = b0 + b1 * xr[q], Bi = b2 * xi[q];
+            const f2 Ar = a0 + a1 * xr[q], Ai = a2 * xi[q];
             const f2 nbr = pbr[q] * Br - pbi[q] * Bi, nbi = pbr[q] * Bi + pbi[q] * Br;
             const f2 nar = par[q] * Ar - pai[q] * Ai, nai = par[q] * Ai + pai[q] * Ar;
             pbr[q] = nbr; pbi[q] = nbi; par[q] = nar; pai[q] = nai;
@@ -675,19 +686,21 @@ __global__ void __launch_bounds__(256) sos_response_bwd_kernel(const cx<T>* __re
 // Mixed-precision backward for float32 storage (H, gH are c64): float arithmetic arranged so that
 // nothing is lost where the monomial form b0 + b1 w + b2 w^2 cancels, and written on section PAIRS so
 // that it compiles to packed-float instructions.
-//  * Section values B_s(k), A_s(k): float, from coefficients re-expanded (in double) about w = +1 for
-//    the lower half of the bins and about w = -1 for the upper half.  Near DC the monomial terms
-//    cancel to ~theta^2 of their size (1e-5 for a 31 Hz band: float would keep 2 digits); the shifted
-//    form's terms are each of the size of the result times the section's Q.  A value that vanishes or
-//    leaves the float range is flagged and redone in double after the loop.
-//  * Quotients conj(gH) H / B_s: float, relative error ~1e-7 per bin.  H is the saved forward output
+//  * Section values B_s(k), A_s(k): float, each polynomial turned by half a sample (half_turn_tables: B conj(w) =
+//    [S cos + T] + i D sin, a multiply-add and a multiply) and its real part expanded (in double) about omega = 0 for
+//    the lower half of the bins and about pi for the upper half.  Near DC the monomial terms cancel to ~theta^2 of their
+//    size (1e-5 for a 31 Hz band: float would keep 2 digits); the expanded form's terms are each of the size of the
+//    result times the section's Q.  A value that vanishes or leaves the float range is flagged and redone in double after
+//    the loop.  (Until round 4 the polynomials were expanded in x = 1 -+ w without the turn: c0 + c1 x + c2 x^2, four
+//    packed operations per section pair and polynomial instead of two.)
+//  * Quotients conj(gH) H / (B_s conj(w)): float, relative error ~1e-7 per bin.  H is the saved forward output
 //    (evaluated in double, rounded once), so the cascade product is not re-evaluated.
-//  * Running sums: float, in the basis {1, d, d^2}, d = 1 - g w, instead of {1, g w, (g w)^2}: at low
-//    frequency the three monomial sums are nearly equal and the parameter maps downstream take
-//    differences of them (factor 1/theta^2 ~ 1e4..1e5), which float sums would not survive, while the
-//    d-basis sums are the well-scaled quantities those differences are made of.  They are converted
-//    back to (b0, b1, b2) gradients in double:
-//      sum Re(t) = G0,   sum Re(t g w) = G0 - G1,   sum Re(t (g w)^2) = G0 - 2 G1 + G2.
+//  * Running sums: float, in the basis {Re t, (1 - cos) Re t, sin Im t} instead of the three monomial sums
+//    {Re(t conj(w)), g Re t, g^2 Re(t w)}: at low frequency those are nearly equal and the parameter maps downstream
+//    take first and second differences of them (factors 1/theta, 1/theta^2 ~ 1e4..1e5), which float sums would not
+//    survive, while the basis sums ARE those differences (second difference = -2 G1, first = 2 G2).  They are
+//    converted back to (b0, b1, b2) gradients in double:
+//      d/db0 = G0 - G1 - G2,   d/db1 = g G0,   d/db2 = g^2 (G0 - G1 + G2).
 // Agreement with the all-double kernel ~1e-6 (tests/test_hip_kernels.py).
 // Rare route of the mixed kernel: a section value that vanishes or leaves the float range (e.g. a
 // band-pass numerator at DC).  All double, product of the other sections as in the kernel above;
@@ -756,20 +769,16 @@ __global__ void __launch_bounds__(256, 2) sos_response_bwd_mixed_kernel(
         c = blockIdx.y;
     }
     stage_taps(b, a, S, C, c, lb, la);
-    // B(w) = b0 + b1 w + b2 w^2 re-expanded about w = +1 (x = 1 - w) and about w = -1 (x = 1 + w):
-    //   B = (b0+b1+b2) - (b1+2 b2) x + b2 x^2      |      B = (b0-b1+b2) + (b1-2 b2) x + b2 x^2
-    // sums formed in double, stored in float (see the kernel comment for why this form is float-safe).  Sections past
-    // the cascade's end are padding, b = a = (1, 0, 0): their sums are computed and never written
+    // the section polynomials turned by half a sample, about omega = 0 for the lower half of the bins and about pi for the
+    // upper half (half_turn_tables: real part one multiply-add, imaginary part one multiply; sums formed in double, stored
+    // in float).  Sections past the cascade's end are padding, b = a = (1, 0, 0): their sums are computed and never written
     const int s0 = blockIdx.z * SCH;
     for (int i = threadIdx.x; i < 2 * SCH; i += blockDim.x) {
         const int poly = i / SCH, q = i - poly * SCH, sidx = s0 + q;
         const double* t = poly ? la : lb;
         const bool real = sidx < S;
         const double t0 = real ? t[sidx] : 1.0, t1 = real ? t[S + sidx] : 0.0, t2 = real ? t[2 * S + sidx] : 0.0;
-        float* lo = cf + (0 * 2 + poly) * 3 * SCH;
-        float* hi = cf + (1 * 2 + poly) * 3 * SCH;
-        lo[q] = (float)(t0 + t1 + t2); lo[SCH + q] = (float)(-(t1 + 2 * t2)); lo[2 * SCH + q] = (float)t2;
-        hi[q] = (float)(t0 - t1 + t2); hi[SCH + q] = (float)(t1 - 2 * t2);    hi[2 * SCH + q] = (float)t2;
+        half_turn_tables(t0, t1, t2, g, cf + (0 * 2 + poly) * 3 * SCH + q, cf + (1 * 2 + poly) * 3 * SCH + q, SCH);
     }
     __syncthreads();
     // running sums of section PAIRS (x: section s0+2u, y: section s0+2u+1): every operation below is a
@@ -861,16 +870,15 @@ __global__ void __launch_bounds__(256, 2) sos_response_bwd_mixed_kernel(
         if (h.x == eps && h.y == 0.f) continue;   // guarded bin (prod A == 0): constant, zero gradient
         const int k = cur.k;
         const cx<double> w1 = cur.w1;
-        const cx<double> z1(g * w1.x, g * w1.y);
-        const cx<float> d((float)(1.0 - z1.x), (float)(-z1.y));
-        const bool low = 4 * (long)k < nfft;      // w nearer to +1 than to -1
-        const double xrd = low ? 1.0 - z1.x : 1.0 + z1.x, xid = low ? -z1.y : z1.y;
-        const float xr = (float)xrd, xi = (float)xid;
-        const float x2r = (float)(xrd * xrd - xid * xid), x2i = (float)(2.0 * xrd * xid);      // the sections share x and x^2: B = c0 + c1 x + c2 x^2
+        const bool low = 4 * (long)k < nfft;      // omega nearer to 0 than to pi
+        const float xr = (float)(low ? 1.0 - w1.x : 1.0 + w1.x), xi = (float)(-w1.y);      // 1 -+ cos(omega) (formed in double), sin(omega)
+        const float uu = (float)(1.0 - w1.x);
         const f2* tb = reinterpret_cast<const f2*>(cf + (low ? 0 : 6 * SCH));      // [b|a][3][SCH / 2] section pairs
         const cx<float> gc(gin.x, -gin.y);
-        // q_p = conj(gH) H d^p, shared by all sections: Re(q_p / B_s) = (q_p.x Br + q_p.y Bi) / |B_s|^2
-        const cx<float> q0 = gc * h, q1 = q0 * d, q2 = q1 * d;
+        // With t = conj(gH) H / (B_s conj(w)) the three tap gradients are sums of Re(t conj(w)), g Re(t), g^2 Re(t w); the
+        // running sums are kept in the basis {Re t, (1 - cos) Re t, sin Im t} -- well-scaled quantities, combined in double at
+        // the end -- through three per-bin vectors shared by all sections:  sum_p += (q_p.x Br + q_p.y Bi) / |B_s|^2
+        const cx<float> q0 = gc * h, q1(uu * q0.x, uu * q0.y), q2(xi * q0.y, -(xi * q0.x));
         unsigned slow = 0;
         // The range test of a section pair -- |B|^2 |A|^2 a normal number in both halves -- used to cost two v_cmp_class, two
         // selects of the reciprocal, the flag bits and their hazard slots per pair (a fifth of the loop beside its 33 packed
@@ -888,8 +896,8 @@ __global__ void __launch_bounds__(256, 2) sos_response_bwd_mixed_kernel(
                 const int u = g0 + v;
                 const f2 b0 = tb[u], b1 = tb[SCH / 2 + u], b2 = tb[SCH + u];
                 const f2 a0 = tb[3 * SCH / 2 + u], a1 = tb[2 * SCH + u], a2 = tb[5 * SCH / 2 + u];
-                const f2 Br = b0 + b1 * xr + b2 * x2r, Bi = b1 * xi + b2 * x2i;
-                const f2 Ar = a0 + a1 * xr + a2 * x2r, Ai = a1 * xi + a2 * x2i;
+                const f2 Br = b0 + b1 * xr, Bi = b2 * xi;
+                const f2 Ar = a0 + a1 * xr, Ai = a2 * xi;
                 const f2 nb = Br * Br + Bi * Bi, na = Ar * Ar + Ai * Ai;
                 const f2 nn = nb * na;
                 mn = __builtin_elementwise_min(mn, nn);
@@ -919,8 +927,8 @@ __global__ void __launch_bounds__(256, 2) sos_response_bwd_mixed_kernel(
                     const int u = g0 + v;
                     const f2 b0 = tb[u], b1 = tb[SCH / 2 + u], b2 = tb[SCH + u];
                     const f2 a0 = tb[3 * SCH / 2 + u], a1 = tb[2 * SCH + u], a2 = tb[5 * SCH / 2 + u];
-                    const f2 Br = b0 + b1 * xr + b2 * x2r, Bi = b1 * xi + b2 * x2i;
-                    const f2 Ar = a0 + a1 * xr + a2 * x2r, Ai = a1 * xi + a2 * x2i;
+                    const f2 Br = b0 + b1 * xr, Bi = b2 * xi;
+                    const f2 Ar = a0 + a1 * xr, Ai = a2 * xi;
                     const f2 nb = Br * Br + Bi * Bi, na = Ar * Ar + Ai * Ai;
                     // one reciprocal per section for both quotients: 1/|B|^2 = |A|^2 / (|B|^2 |A|^2).  A product that is not a
                     // normal number (a norm vanished, or left the float range) is flagged for the double route
@@ -944,9 +952,9 @@ __global__ void __launch_bounds__(256, 2) sos_response_bwd_mixed_kernel(
         }
         if (slow) {   // rare: redo the flagged sections in double
             SosEval e;
-            e.z1 = z1;
-            e.z2 = z1 * z1;
-            const cx<float> d2 = d * d;
+            e.z1 = cx<double>(g * w1.x, g * w1.y);
+            e.z2 = e.z1 * e.z1;
+            const float cwf = (float)w1.x;
 #pragma unroll
             for (int q = 0; q < SCH; ++q) {
                 if (((slow >> q) & 1u) && s0 + q < S) {
@@ -954,8 +962,9 @@ __global__ void __launch_bounds__(256, 2) sos_response_bwd_mixed_kernel(
                     const cx<double> Bs = e.poly(lb, S, s), As = e.poly(la, S, s);
                     cx<float> tb2, ta2;
                     sos_bwd_slow_section(e, lb, la, S, s, gc, Bs, As, tb2, ta2);
-                    const float v[6] = {tb2.x, tb2.x * d.x - tb2.y * d.y, tb2.x * d2.x - tb2.y * d2.y,
-                                        -ta2.x, -(ta2.x * d.x - ta2.y * d.y), -(ta2.x * d2.x - ta2.y * d2.y)};
+                    // the careful route returns conj(gH) H / B_s: times w is the quotient by the turned polynomial
+                    const cx<float> tt(tb2.x * cwf + tb2.y * xi, tb2.y * cwf - tb2.x * xi), ua(ta2.x * cwf + ta2.y * xi, ta2.y * cwf - ta2.x * xi);
+                    const float v[6] = {tt.x, uu * tt.x, xi * tt.y, -ua.x, -(uu * ua.x), -(xi * ua.y)};
 #pragma unroll
                     for (int p = 0; p < 6; ++p) {
                         if (q & 1) acc[p][q / 2].y += v[p];
@@ -994,7 +1003,8 @@ __global__ void __launch_bounds__(256, 2) sos_response_bwd_mixed_kernel(
                 const int j = (i * 3 + p) * SCH + q;
                 G[p] = (double)red[0][j] + (double)red[1][j] + (double)red[2][j] + (double)red[3][j];
             }
-            const double out[3] = {G[0], G[0] - G[1], G[0] - 2.0 * G[1] + G[2]};
+            // Re(t conj(w)) = (1 - u) Re t - sin Im t,   Re(t w) = (1 - u) Re t + sin Im t,   u = 1 - cos
+            const double out[3] = {G[0] - G[1] - G[2], g * G[0], g * g * (G[0] - G[1] + G[2])};
 #pragma unroll
             for (int p = 0; p < 3; ++p) part[((((size_t)bx * 2 + i) * 3 + p) * S + s) * C + c] = out[p];
         }
