@@ -67,6 +67,7 @@ _SIGNATURES = {
     "fl_spec_gradh_walk_scaled_f32": (_i, [_vp, _vp, _vp, _l, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _vp, _vp]),
     "fl_mean_square_final_f32": (_i, [_vp, _i, _d, _vp, _vp]),
     "fl_mean_square_final_f64": (_i, [_vp, _i, _d, _vp, _vp]),
+    "fl_pack_toggle": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "fl_spec_cols_inv_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp]),
     "fl_permute_bins_c64": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp]),
     "fl_permute_bins_c128": (_i, [_vp, _l, _vp, _l, _i, _i, _i, _vp]),

@@ -172,6 +172,37 @@ static int mean_square_bwd_impl(const void* y, const void* gloss, void* gy, long
     return FL_OK;
 }
 
+// ---------------------------------------------------------------- gradient buckets of a replayed step
+// The parameter gradients of a captured training step, packed into ONE of two flat buffers -- alternately, chosen ON THE
+// DEVICE from a counter the kernel itself advances, so that the packing is a node of the captured graph like any other
+// (no host-side copy between two replays: on this runtime an eager launch between two graph launches costs ~10 us of
+// idle device on either side) and the data-parallel all-reduce of step k can still be in flight on bucket k & 1 while
+// replay k + 1 fills the other one (DistributedDataParallel's gradient-as-bucket-view, double-buffered).
+//   table: count entries of three 64-bit words (source address, byte offset in the bucket, bytes; all multiples of 4)
+//   state: [0] packs done so far (its parity chooses the bucket), [1] arrivals of the current launch
+// One workgroup per entry; the last one to arrive -- every workgroup has read the parity before it arrives -- advances the
+// counter and clears the arrivals for the next launch.
+__global__ void __launch_bounds__(256) pack_toggle_kernel(const unsigned long long* __restrict__ table, int count, char* flat0,
+                                                          char* flat1, int* state) {
+    __shared__ int par;
+    if (threadIdx.x == 0) par = __atomic_load_n(&state[0], __ATOMIC_RELAXED) & 1;
+    __syncthreads();
+    const unsigned long long* e = table + 3 * (size_t)blockIdx.x;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(e[0]);
+    uint32_t* dst = reinterpret_cast<uint32_t*>((par ? flat1 : flat0) + e[1]);
+    const size_t n = e[2] / 4;
+    for (size_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&state[1], 1) == count - 1) {
+            __atomic_store_n(&state[1], 0, __ATOMIC_RELAXED);
+            __threadfence();
+            atomicAdd(&state[0], 1);
+        }
+    }
+}
+
 }  // namespace fl
 
 using namespace fl;
@@ -194,6 +225,13 @@ int fl_mean_square_final_f64(const void* parts, int n_parts, double inv_count, v
     FL_REQUIRE(parts && loss && n_parts > 0, "mean_square_final: bad arguments");
     hipLaunchKernelGGL((mean_square_final_kernel<double>), dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)parts, n_parts, inv_count, (double*)loss);
     FL_CHECK_LAUNCH("mean_square_final");
+    return FL_OK;
+}
+int fl_pack_toggle(const void* table, int count, void* flat0, void* flat1, void* state, void* stream) {
+    FL_REQUIRE(table && flat0 && flat1 && state && count > 0 && count <= 65535, "pack_toggle: bad arguments");
+    hipLaunchKernelGGL(pack_toggle_kernel, dim3(count), dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)table, count,
+                       (char*)flat0, (char*)flat1, (int*)state);
+    FL_CHECK_LAUNCH("pack_toggle");
     return FL_OK;
 }
 int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream) {

@@ -151,6 +151,60 @@ def take_local_bins(X: torch.Tensor, group=None) -> torch.Tensor:
 _flat_cache = {}
 
 
+class BucketReducer:
+    """Data-parallel gradient sums of a replayed step without a copy between two replays: the captured graph packs its
+    gradients into two alternating flat buckets (graph.GraphedStep(grad_buckets=True), csrc/reduce.hip fl_pack_toggle), and
+    after each replay ONE asynchronous all-reduce runs on the bucket that replay filled -- in place, the sums stay there
+    (DistributedDataParallel's gradient-as-bucket-view) -- while the next replay already fills the other bucket.
+
+        red = BucketReducer(step)            # step = GraphedStep(..., grad_buckets=True)
+        loss = red.replay()                  # orders itself behind the collective that last used the bucket it will fill
+        sums = red.reduced()                 # waits (on the stream) for this step's collective: one view per parameter
+
+    What is ordered, and where: the collective of step k starts behind replay k (the communicator's stream waits for the
+    launch stream when the collective is issued); replay k + 2 rewrites the bucket collective k worked on, so replay()
+    makes the launch stream wait for that collective first -- it finished a whole step earlier, the wait costs nothing;
+    reduced() waits for the newest collective.  The host never blocks.
+    (Measured with one rank over RCCL on an MI355X, config 2: 0.354-0.357 ms per step, the same as all_reduce_grads(in_buffer=
+    True) behind each replay and 17-20 us above the step without a collective -- the copy this class removes was 5 us of it;
+    the rest is idle device in front of the next graph launch wherever a cross-stream event sits between two replays
+    (tools/dbg/dist_timeline.py).  bench.py therefore stays on all_reduce_grads, the path its two-rank CPU tests cover.)"""
+
+    def __init__(self, step, group=None):
+        if getattr(step, "buckets", None) is None:
+            raise ValueError("BucketReducer: the step was not captured with grad_buckets=True")
+        self.step, self.group = step, group
+        self._work = [None, None]
+
+    def _finish(self, b):
+        w, self._work[b] = self._work[b], None
+        if w is not None:
+            w.wait()
+
+    def replay(self, *inputs) -> torch.Tensor:
+        nxt = self.step.replays & 1                  # the bucket this replay fills
+        self._finish(nxt)
+        loss = self.step(*inputs) if inputs else self.step.replay()
+        flat = self.step.buckets[nxt]
+        if _host_staged(flat, self.group):
+            host = flat.cpu()
+            dist.all_reduce(host, group=self.group)
+            flat.copy_(host)
+        else:
+            self._work[nxt] = dist.all_reduce(flat, group=self.group, async_op=True)
+        return loss
+
+    def reduced(self):
+        """the summed gradients of the last replay: one view of its bucket per parameter (None where there is no gradient)"""
+        b = self.step.bucket
+        self._finish(b)
+        return self.step.bucket_views[b]
+
+    def finish(self):
+        self._finish(0)
+        self._finish(1)
+
+
 def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op: bool = False, in_buffer: bool = False):
     """Sum the gradients of replicated parameters over ranks with ONE flat all-reduce per dtype, through a flat
     buffer that is allocated once per parameter set (no cat / cast / per-parameter temporaries per step): the gradients

@@ -525,6 +525,13 @@ int fl_mean_square_f64(const void* y, long rows, long cols, long pitch, void* lo
 /* loss[0] = inv_count * sum of n_parts partial sums (double), added in a fixed order by one workgroup */
 int fl_mean_square_final_f32(const void* parts, int n_parts, double inv_count, void* loss, void* stream);
 int fl_mean_square_final_f64(const void* parts, int n_parts, double inv_count, void* loss, void* stream);
+/* Gradient buckets of a replayed training step (the data-parallel gradient sum of trainer.py:172-191's loop over several
+ * GPUs; the reference has no counterpart -- it trains on one device): copies `count` tensors into ONE of two flat buffers,
+ * alternating from launch to launch by a counter kept on the device, so that the call can be a node of a captured HIP graph
+ * and the all-reduce of step k may still run on its bucket while replay k + 1 fills the other.
+ *   table: device array of count x 3 uint64 {source address, byte offset inside the bucket, bytes} (multiples of 4),
+ *   state: device int32[2], zero before the first launch: [0] launches done (bucket of launch i is i & 1), [1] internal. */
+int fl_pack_toggle(const void* table, int count, void* flat0, void* flat1, void* state, void* stream);
 int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
 int fl_mean_square_bwd_f64(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
 

@@ -1,5 +1,6 @@
 """Round 4: transform lengths the Stockham kernels do not take (chirp-z route, dsp.py:84-89 hands ANY nfft to torch.fft),
 fused-pipeline plans derived from the factorisation, batch-walking kernels beyond the benchmark's shape."""
+import os
 from collections import OrderedDict
 
 import pytest
@@ -9,6 +10,7 @@ from conftest import check_close, relerr
 
 pytestmark = pytest.mark.gpu
 F64 = torch.float64
+F32 = torch.float32
 TOL = {torch.float64: 1e-10, torch.float32: 1e-5}
 CD = {torch.float64: torch.complex128, torch.float32: torch.complex64}
 
@@ -255,3 +257,92 @@ def test_matrix_cascade_operator_float64(gpu, kind, nfft, N):
         assert H.dtype == torch.complex128
         Href = O.geq_response(flt.param.detach().cpu().double(), nfft, O.gamma_of(0.0, nfft, F64)) @ W.cpu().to(torch.complex128)
         assert relerr(H.cpu(), Href) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [F32, F64])
+def test_graphed_step_gradient_buckets(gpu, dt):
+    """GraphedStep(grad_buckets=True): the captured graph packs its parameter gradients into two flat buckets that alternate
+    from replay to replay (fl_pack_toggle: the bucket is chosen from a counter kept on the device) -- after replay i bucket
+    i & 1 holds that replay's gradients, the other one still the previous replay's; a parameter the step does not use has
+    no view; the bucket index follows the replays however they are issued (replay() / __call__)."""
+    from flamo_amd import ops
+    from flamo_amd.graph import GraphedStep
+    from flamo_amd.processor import dsp, system
+    nfft, N = 4800, 4
+    torch.manual_seed(3)
+    kw = dict(nfft=nfft, alias_decay_db=0.0, device=gpu, dtype=dt, requires_grad=True)
+    mat = dsp.Matrix(size=(N, N), matrix_type="random", **kw)
+    geq = dsp.GEQ(size=(N, N), **kw)
+    model = system.Shell(system.Series(OrderedDict(mix=mat, eq=geq)), dsp.FFT(nfft, dtype=dt), dsp.iFFT(nfft, dtype=dt))
+    unused = torch.nn.Parameter(torch.zeros(5, device=gpu, dtype=dt))
+    params = [mat.param, unused, geq.param]
+    xs = [torch.randn(2, nfft, N, device=gpu, dtype=dt) for _ in range(5)]
+    step = GraphedStep(lambda xx: ops.mean_square(model(xx)), (xs[0],), params, grad_buckets=True)
+    assert [p is unused for p in step.params] == [False, True, False]
+    with pytest.raises(RuntimeError):
+        step.bucket
+    prev = None
+    for i, x in enumerate(xs):
+        loss = step(x) if i % 2 else (step.static_inputs[0].copy_(x), step.replay())[1]
+        torch.cuda.synchronize()
+        want = torch.autograd.grad(ops.mean_square(model(x)), [mat.param, geq.param])
+        b = step.bucket
+        assert b == i & 1
+        v = step.bucket_views[b]
+        assert v[1] is None and v[0].shape == mat.param.shape and v[2].shape == geq.param.shape
+        assert torch.equal(v[0], mat.param.grad) and torch.equal(v[2], geq.param.grad)      # a copy of what the replay left
+        assert relerr(v[0], want[0]) < (1e-10 if dt == F64 else 1e-4) and relerr(v[2], want[1]) < (1e-10 if dt == F64 else 1e-4)
+        assert relerr(loss, ops.mean_square(model(x)).detach()) < 1e-5
+        if prev is not None:
+            o = step.bucket_views[1 - b]
+            assert torch.equal(o[0], prev[0]) and torch.equal(o[2], prev[1])                  # untouched by this replay
+        prev = (v[0].clone(), v[2].clone())
+    with pytest.raises(ValueError):
+        GraphedStep(lambda xx: ops.mean_square(model(xx)), (xs[0],), [], grad_buckets=True)
+
+
+@pytest.mark.gpu
+def test_bucket_reducer_single_rank_over_rccl(gpu):
+    """dist.BucketReducer with backend "nccl" (= RCCL) and one rank on the test box: replay, in-place asynchronous all-reduce of
+    the bucket the replay filled, the next replay ordered behind the collective that last used ITS bucket; the sums of a
+    one-rank job are the gradients themselves (tests/test_dist_rccl.py runs bench.py's multi-rank line through it on >= 2 GPUs)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+import flamo_amd
+import torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+from collections import OrderedDict
+from flamo_amd import dist as fd, ops
+from flamo_amd.graph import GraphedStep
+from flamo_amd.processor import dsp, system
+nfft, N = 4800, 4
+kw = dict(nfft=nfft, alias_decay_db=0.0, device=dev, dtype=torch.float32, requires_grad=True)
+mat = dsp.Matrix(size=(N, N), matrix_type="random", **kw); geq = dsp.GEQ(size=(N, N), **kw)
+model = system.Shell(system.Series(OrderedDict(mix=mat, eq=geq)), dsp.FFT(nfft), dsp.iFFT(nfft))
+params = [mat.param, geq.param]
+xs = [torch.randn(2, nfft, N, device=dev) for _ in range(6)]
+step = GraphedStep(lambda xx: ops.mean_square(model(xx)), (xs[0],), params, grad_buckets=True)
+red = fd.BucketReducer(step)
+for i, x in enumerate(xs):
+    loss = red.replay(x)
+    if i %% 2 == 0:                  # every other step reads its sums; the others leave the collective in flight
+        sums = red.reduced()
+        torch.cuda.synchronize()
+        want = torch.autograd.grad(ops.mean_square(model(x)), params)
+        for s_, w_ in zip(sums, want):
+            assert torch.allclose(s_, w_, rtol=1e-4, atol=1e-9), (i, (s_ - w_).abs().max())
+red.finish()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("BUCKETS-OK")
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert "BUCKETS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
