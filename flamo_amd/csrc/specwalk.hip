@@ -910,7 +910,7 @@ using namespace fl;
 extern "C" {
 
 int fl_debug_set_walk(int mode, int wgs, int slices, void* times) {
-    g_walk_nsc = mode == 14 ? 4 : 2;
+    g_walk_nsc = mode == 14 ? 4 : mode == 15 ? 1 : 2;
     g_walk = mode;
     g_walk_wgs = wgs;
     g_walk_slices = slices;
@@ -944,6 +944,7 @@ int fl_spec_gradh_slices(int nfft, int Bn) {
     const int P = l1 / 2 + 1;
     int ns = device_cus() / (2 * P);
     if (g_walk_nsc == 4) ns = 1;
+    if (g_walk_nsc == 1) ns = device_cus() / P;
     if (ns < 1) ns = 1;
     return ns < Bn ? ns : Bn;
 }
@@ -998,6 +999,7 @@ static int gradh_walk_impl(const void* Sg, const void* Xp, void* dH_parts, long 
 #define FL_GRADH_ROWS(A_, B_)                                                                                                    \
     if (NI == 8 && NO == 8) {                                                                                                    \
         if (A_ == 16 && B_ == 15 && g_walk_nsc == 4) FL_GRADH(16, 15, 8, 8, 4, 4, 1)                                             \
+        else if (A_ == 16 && B_ == 15 && g_walk_nsc == 1) FL_GRADH(16, 15, 8, 8, 1, 2, 1)                                        \
         else if (A_ == 16 && B_ == 15 && g_walk == 17) FL_GRADH(16, 15, 8, 8, 2, 2, 2)                                           \
         else FL_GRADH(A_, B_, 8, 8, 2, 2, 1)                                                                                     \
     }                                                                                                                            \

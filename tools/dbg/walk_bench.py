@@ -138,7 +138,8 @@ for r in (1, 7, 57, 99):
     print(f"pair-major spectrum row pair {r}: k {rel(torch.view_as_real(got), torch.view_as_real(want)):.2e}  L-k {rel(torch.view_as_real(gotm), torch.view_as_real(wantm)):.2e}")
 for ns in [int(v) for v in args.slices.split(",")]:
     # "4": four output-channel groups per row pair; "17": doubled staging regions, transfers issued by the wavefronts without an FFT stage (tuning variant)
-    L.fl_debug_set_walk(14 if ns == 4 else 17 if ns == 17 else 1, 0, 0 if ns in (4, 17) else ns, None)
+    # "15": ALL output channels in one workgroup (every wavefront has an FFT stage in step 2), the batch in two slices
+    L.fl_debug_set_walk(14 if ns == 4 else 17 if ns == 17 else 15 if ns == 15 else 1, 0, 0 if ns in (4, 15, 17) else ns, None)
     nsl = L.fl_spec_gradh_slices(nfft, B)
     parts = torch.full((nsl, N, N, P), float("nan"), dtype=torch.complex64, device=dev)
     out = torch.empty((N, N, P), dtype=torch.complex64, device=dev)
@@ -169,7 +170,8 @@ print(f"spec_mid (spectrum only): median {t[0]:.1f} us; mimo_gradh: median {t2[0
 # phase picture of the backward kernel
 nblk = 8 * ((L1 // 2 + 1 + 7) // 8) * 2 * 4
 bufg = torch.zeros(nblk * 8, dtype=torch.int64, device=dev)
-L.fl_debug_set_walk(1, 0, 0, bufg.data_ptr())
+gmode = int(os.environ.get("WALK_GRADH_MODE", "1"))       # 15: all output channels per workgroup, two batch slices
+L.fl_debug_set_walk(gmode, 0, 0, bufg.data_ptr())
 nsl = L.fl_spec_gradh_slices(nfft, B)
 parts = torch.empty((nsl, N, N, P), dtype=torch.complex64, device=dev)
 _lib.check(L.fl_spec_gradh_walk_f32(Sg.data_ptr(), Xp.data_ptr(), parts.data_ptr(), N * N * P, N * P, P, nsl, W.data_ptr(), nfft, B, N, N, 1.0 / nfft, 1, ops._stream()), "gradh_walk")
