@@ -760,8 +760,11 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
                 }
             }
         } else if (t >= 1 && t <= n_it) {     // P2(t-1): second stage XF[(t-1) & 1] -> Y.  item = (m fastest, ka, slot)
-            // (DEPTH 2: the items sit on the group's last wavefronts, 4 and 5 issue transfers)
-            const int item = (opaque(tid) & 255) - (DEPTH == 2 ? P2_OFF : 0);
+            // The items sit on the group's LAST wavefronts: wavefront w runs on SIMD w % 4, the first stage's items are on
+            // wavefronts 0.. of group 0 -- with 2 x 64 items each (four output channels) that is SIMD 0, 1 for P1 and SIMD 2, 3
+            // for P2; on the group's first wavefronts both stages shared SIMD 0 and 1 while the other two idled through the step
+            // (own work 52 k / 61 k cycles per workgroup against 7 k on wavefront 7).  (DEPTH 2: wavefronts 4 and 5 issue transfers.)
+            const int item = (opaque(tid) & 255) - P2_OFF;
             const int m = item % NOL, ka = (item / NOL) % A, slot = item / (NOL * A);
             if (item >= 0 && item < NI2 && !(slot && selfm)) {
                 cf v[B];
