@@ -545,10 +545,10 @@ __device__ __forceinline__ void wait_vm_le(int n) {
 // Staging is owner-wave (see spec_mid_walk's fetch): a group-0 wavefront transfers the gradient rows its own P1 items
 // read, every wavefront the 4 KB of spectrum its own P3 threads read (with one bin per thread the two groups read
 // different halves of a unit's block) -- each transfer issued right after the owner's reads of the item that used the
-// region and awaited just before its next ones, a full pipeline cycle later (DEPTH 1, the form in use).  DEPTH 2 (tuning
-// mode 17) doubles the staging regions and moves the transfers' issue to the wavefronts that have no FFT stage in step 2;
-// it measured no faster (round 3: 69.5 against 68.7 us, and 66.8 us with the barrier between the two steps removed
-// altogether), i.e. an item's 4000-cycle cycle is neither a transfer round trip nor barrier skew -- see DESIGN 4.9.
+// region and awaited just before its next ones, a full pipeline cycle later (DEPTH 1: every shape but 8 -> 8 channels).
+// DEPTH 2 doubles the staging regions and moves the transfers' issue to the wavefronts that have no FFT stage in step 2
+// (8 -> 8 channels since late round 4: 54.2 against 56.5 us; in round 3, with both FFT stages still on SIMD 0 and 1, it
+// measured no faster -- 69.5 against 68.7 us, and 66.8 us with the barrier between the two steps removed altogether).
 struct GradhArgs {
     const cf* Sg;         // (Bn, L1, L2, NO)
     const cf* Xp;         // pair-major spectrum of the forward kernel
@@ -997,14 +997,16 @@ static int gradh_walk_impl(const void* Sg, const void* Xp, void* dH_parts, long 
         }                                                                                                                        \
     }
     // output channels of a row pair over 2 workgroups (one per CU) -- or one for 2 output channels; tuning: over 4 (two per CU);
-    // (mode 17, tuning: two staging regions per kind, transfers issued by the wavefronts without a stage of their own --
-    // measured 69.5 us against 68.7 us for the owner-wave form at config 2: an item's cycle is not a transfer round trip)
+    // 8 -> 8 channels: two staging regions per kind, transfers issued by the wavefronts without a stage of their own (DEPTH 2).
+    // Round 3 measured that form no faster than owner-wave transfers (69.5 against 68.7 us); since the second stage moved to
+    // SIMD 2 and 3 the first stage is the longest path of the FFT step and the eight transfer issues in front of its
+    // arithmetic count: 54.2 against 56.5 us replayed at config 2.  (Mode 17, tuning: the owner-wave form, DEPTH 1.)
 #define FL_GRADH_ROWS(A_, B_)                                                                                                    \
     if (NI == 8 && NO == 8) {                                                                                                    \
         if (A_ == 16 && B_ == 15 && g_walk_nsc == 4) FL_GRADH(16, 15, 8, 8, 4, 4, 1)                                             \
         else if (A_ == 16 && B_ == 15 && g_walk_nsc == 1) FL_GRADH(16, 15, 8, 8, 1, 2, 1)                                        \
-        else if (A_ == 16 && B_ == 15 && g_walk == 17) FL_GRADH(16, 15, 8, 8, 2, 2, 2)                                           \
-        else FL_GRADH(A_, B_, 8, 8, 2, 2, 1)                                                                                     \
+        else if (A_ == 16 && B_ == 15 && g_walk == 17) FL_GRADH(16, 15, 8, 8, 2, 2, 1)                                           \
+        else FL_GRADH(A_, B_, 8, 8, 2, 2, 2)                                                                                     \
     }                                                                                                                            \
     else if (NI == 4 && NO == 8) FL_GRADH(A_, B_, 4, 8, 2, 2, 1)                                                                 \
     else if (NI == 2 && NO == 8) FL_GRADH(A_, B_, 2, 8, 2, 2, 1)                                                                 \
