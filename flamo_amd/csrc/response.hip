@@ -373,20 +373,15 @@ __global__ void __launch_bounds__(256) sos_response_apply_fast_kernel(const doub
         const bool real = sidx < S;
         const double t0 = real ? t[(size_t)sidx * C + c] : 1.0, t1 = real ? t[(size_t)(S + sidx) * C + c] : 0.0,
                      t2 = real ? t[(size_t)(2 * S + sidx) * C + c] : 0.0;
-        float* lo = cf + ((size_t)j * 4 + 0 * 2 + poly) * 3 * SP;
-        float* hi = cf + ((size_t)j * 4 + 1 * 2 + poly) * 3 * SP;
-        lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
-        hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+        half_turn_tables(t0, t1, t2, g, cf + ((size_t)j * 4 + 0 * 2 + poly) * 3 * SP + sidx, cf + ((size_t)j * 4 + 1 * 2 + poly) * 3 * SP + sidx, SP);
     }
     __syncthreads();
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= m_local) return;
     const int k = bin_of(f, bin0, nfft);
     const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
-    const cx<double> z1(g * w1.x, g * w1.y);
     const bool low = 4 * (long)k < nfft;
-    const double xrd = low ? 1.0 - z1.x : 1.0 + z1.x, xid = low ? -z1.y : z1.y;
-    const float xr = (float)xrd, xi = (float)xid, x2r = (float)(xrd * xrd - xid * xid), x2i = (float)(2.0 * xrd * xid);
+    const float xr = (float)(low ? 1.0 - w1.x : 1.0 + w1.x), xi = (float)(-w1.y);      // 1 -+ cos(omega) (formed in double), sin(omega)
     cx<float> acc[BX];
 #pragma unroll
     for (int n = 0; n < BX; ++n) acc[n] = cx<float>(0.f, 0.f);
@@ -402,8 +397,8 @@ __global__ void __launch_bounds__(256) sos_response_apply_fast_kernel(const doub
                      b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
             const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
                      a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
-            const f2 Br = b0 + b1 * xr + b2 * x2r, Bi = b1 * xi + b2 * x2i;      // c0 + c1 x + c2 x^2, x^2 shared by all sections
-            const f2 Ar = a0 + a1 * xr + a2 * x2r, Ai = a1 * xi + a2 * x2i;
+            const f2 Br = b0 + b1 * xr, Bi = b2 * xi;      // (c0 + c1 x) + i c2 sin(omega): half_turn_tables
+            const f2 Ar = a0 + a1 * xr, Ai = a2 * xi;
             const f2 nbr = pbr * Br - pbi * Bi, nbi = pbr * Bi + pbi * Br;
             const f2 nar = par * Ar - pai * Ai, nai = par * Ai + pai * Ar;
             pbr = nbr; pbi = nbi; par = nar; pai = nai;
@@ -460,10 +455,7 @@ __global__ void __launch_bounds__(256) sos_response_fast_kernel(const double* __
 #pragma unroll
         for (int poly = 0; poly < 2; ++poly) {
             const double t0 = poly ? ta[0] : tb[0], t1 = poly ? ta[1] : tb[1], t2 = poly ? ta[2] : tb[2];
-            float* lo = cf + (0 * 2 + poly) * 3 * SP;
-            float* hi = cf + (1 * 2 + poly) * 3 * SP;
-            lo[sidx] = (float)(t0 + t1 + t2); lo[SP + sidx] = (float)(-(t1 + 2 * t2)); lo[2 * SP + sidx] = (float)t2;
-            hi[sidx] = (float)(t0 - t1 + t2); hi[SP + sidx] = (float)(t1 - 2 * t2);    hi[2 * SP + sidx] = (float)t2;
+            half_turn_tables(t0, t1, t2, g, cf + (0 * 2 + poly) * 3 * SP + sidx, cf + (1 * 2 + poly) * 3 * SP + sidx, SP);
         }
     }
     __syncthreads();
@@ -471,10 +463,8 @@ __global__ void __launch_bounds__(256) sos_response_fast_kernel(const double* __
     for (int f = blockIdx.x * kSosFastBins + threadIdx.x; f < f_end; f += 256) {
         const int k = bin_of(f, bin0, nfft);
         const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
-        const cx<double> z1(g * w1.x, g * w1.y);
         const bool low = 4 * (long)k < nfft;
-        const double xrd = low ? 1.0 - z1.x : 1.0 + z1.x, xid = low ? -z1.y : z1.y;
-    const float xr = (float)xrd, xi = (float)xid, x2r = (float)(xrd * xrd - xid * xid), x2i = (float)(2.0 * xrd * xid);
+        const float xr = (float)(low ? 1.0 - w1.x : 1.0 + w1.x), xi = (float)(-w1.y);      // 1 -+ cos(omega) (formed in double), sin(omega)
         const float* cb = cf + (low ? 0 : 6 * SP);
         const float* ca = cb + 3 * SP;
         f2 pbr = (f2)(1.f), pbi = (f2)(0.f), par = (f2)(1.f), pai = (f2)(0.f);
@@ -483,8 +473,8 @@ __global__ void __launch_bounds__(256) sos_response_fast_kernel(const double* __
                      b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
             const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
                      a2 = *reinterpret_cast<const f2*>(ca + 2 * SP + s);
-            const f2 Br = b0 + b1 * xr + b2 * x2r, Bi = b1 * xi + b2 * x2i;      // c0 + c1 x + c2 x^2, x^2 shared by all sections
-            const f2 Ar = a0 + a1 * xr + a2 * x2r, Ai = a1 * xi + a2 * x2i;
+            const f2 Br = b0 + b1 * xr, Bi = b2 * xi;      // (c0 + c1 x) + i c2 sin(omega): half_turn_tables
+            const f2 Ar = a0 + a1 * xr, Ai = a2 * xi;
             const f2 nbr = pbr * Br - pbi * Bi, nbi = pbr * Bi + pbi * Br;
             const f2 nar = par * Ar - pai * Ai, nai = par * Ai + pai * Ar;
             pbr = nbr; pbi = nbi; par = nar; pai = nai;
