@@ -266,6 +266,7 @@ __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double*
             e[1] = two ? e[0] + L2 : e[0];
         }
     }
+    constexpr int UNR_REST = UNR > 1 ? UNR - 1 : 1;      // pairs per trip behind the first one (which starts the products)
     bool low[2];
     float xr[2], xi[2];
 #pragma unroll
@@ -284,10 +285,6 @@ __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double*
         for (int n = 0; n < NIW; ++n) acc[q][n] = cx<float>(0.f, 0.f);
     for (int j = 0; j < Nmid; ++j) {
         f2 pbr[2], pbi[2], par[2], pai[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            pbr[q] = (f2)(1.f); pbi[q] = (f2)(0.f); par[q] = (f2)(1.f); pai[q] = (f2)(0.f);
-        }
         // one section pair of bin q: (c0 + c1 x) + i c2 sin(omega) (half_turn_tables) times the running products
         auto step = [&](int q, f2 b0, f2 b1, f2 b2, f2 a0, f2 a1, f2 a2) {
             const f2 Br = b0 + b1 * xr[q], Bi = b2 * xi[q];
@@ -299,9 +296,19 @@ __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double*
         if (same) {
             const float* cb = cf + ((size_t)j * 4 + (low[0] ? 0 : 2)) * 3 * SP;
             const float* ca = cb + 3 * SP;
-            // (UNR section pairs per trip: their 6 UNR table reads are issued together -- one LDS latency per trip, not per pair)
-#pragma unroll UNR
-            for (int s = 0; s < SP; s += 2) {
+            {   // the first pair STARTS the running products (what a multiplication of (1, 0) by it gives, bit for bit): sixteen
+                // moves and sixteen packed operations per cascade less
+                const f2 b0 = *reinterpret_cast<const f2*>(cb), b1 = *reinterpret_cast<const f2*>(cb + SP), b2 = *reinterpret_cast<const f2*>(cb + 2 * SP);
+                const f2 a0 = *reinterpret_cast<const f2*>(ca), a1 = *reinterpret_cast<const f2*>(ca + SP), a2 = *reinterpret_cast<const f2*>(ca + 2 * SP);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    pbr[q] = b0 + b1 * xr[q]; pbi[q] = b2 * xi[q];
+                    par[q] = a0 + a1 * xr[q]; pai[q] = a2 * xi[q];
+                }
+            }
+            // (UNR section pairs per trip with the first: their table reads are issued together -- one LDS latency per trip, not per pair)
+#pragma unroll UNR_REST
+            for (int s = 2; s < SP; s += 2) {
                 const f2 b0 = *reinterpret_cast<const f2*>(cb + s), b1 = *reinterpret_cast<const f2*>(cb + SP + s),
                          b2 = *reinterpret_cast<const f2*>(cb + 2 * SP + s);
                 const f2 a0 = *reinterpret_cast<const f2*>(ca + s), a1 = *reinterpret_cast<const f2*>(ca + SP + s),
@@ -311,6 +318,7 @@ __global__ void __launch_bounds__(256) sos_response_rc_fast_kernel(const double*
             }
         } else {
             for (int q = 0; q < 2; ++q) {
+                pbr[q] = (f2)(1.f); pbi[q] = (f2)(0.f); par[q] = (f2)(1.f); pai[q] = (f2)(0.f);
                 const float* cb = cf + ((size_t)j * 4 + (low[q] ? 0 : 2)) * 3 * SP;
                 const float* ca = cb + 3 * SP;
                 for (int s = 0; s < SP; s += 2) {
