@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
     }
     __syncthreads();
     real_t* yb = a.y + (size_t)b * a.t_len * a.G + g0;
+    const real_t scale0 = a.dev_scale ? a.scale * *a.dev_scale : a.scale;
     real_t sq = 0;
     for (int item = threadIdx.x; item < A * VT; item += 256) {
         const int ka = item / VT, vv = item % VT;
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
             // (re_g, im_g) per lane -> even lane (re_g, re_g+1) at sample 2j, odd lane (im_g-1, im_g) at 2j+1
             const real_t got = swap1(par ? v[kb].x : v[kb].y);
             real2 q = par ? make_real2(got, v[kb].y) : make_real2(v[kb].x, got);
-            real_t s = a.scale;
+            real_t s = scale0;
             if (a.env_log2 != 0.0) s *= env_at(a.env_log2, t);
             q.x *= s;
             q.y *= s;
@@ -1027,7 +1028,7 @@ int FL_SPEC_FN(fl_spec_cols_fwd)(const void* x, int Bn, int t_len, int G, void* 
 }
 
 static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
-                         double env_log2, double* sumsq, void* stream);
+                         double env_log2, double* sumsq, void* stream, const real_t* dev_scale = nullptr);
 int FL_SPEC_FN(fl_spec_cols_inv)(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                          double env_log2, void* stream) {
     return cols_inv_impl(S2, y, Bn, t_len, t_out, G, W, nfft, scale, env_log2, nullptr, stream);
@@ -1036,6 +1037,11 @@ int FL_SPEC_FN(fl_spec_cols_inv_sumsq)(const void* S2, void* y, int Bn, int t_le
                                double env_log2, void* sumsq_parts, void* stream) {
     FL_REQUIRE(sumsq_parts, "spec_cols_inv_sumsq: null pointer");
     return cols_inv_impl(S2, y, Bn, t_len, t_out, G, W, nfft, scale, env_log2, (double*)sumsq_parts, stream);
+}
+int FL_SPEC_FN(fl_spec_cols_inv_scaled)(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                                const void* dev_scale, double env_log2, void* stream) {
+    FL_REQUIRE(dev_scale, "spec_cols_inv_scaled: null pointer");
+    return cols_inv_impl(S2, y, Bn, t_len, t_out, G, W, nfft, scale, env_log2, nullptr, stream, (const real_t*)dev_scale);
 }
 int FL_SPEC_FN(fl_spec_cols_blocks)(int nfft, int Bn, int G) {      // workgroups of a column pass = entries of sumsq_parts
     ColsArgs a = {};
@@ -1046,7 +1052,7 @@ int FL_SPEC_FN(fl_spec_cols_blocks)(int nfft, int Bn, int G) {      // workgroup
 }
 }  // extern "C"
 static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
-                         double env_log2, double* sumsq, void* stream) {
+                         double env_log2, double* sumsq, void* stream, const real_t* dev_scale) {
     FL_REQUIRE(S2 && y, "spec_cols_inv: null pointer");
     FL_REQUIRE(reinterpret_cast<uintptr_t>(y) % (2 * RSZ) == 0, "spec_cols_inv: y must be aligned to two samples");
     FL_REQUIRE(t_out >= 0 && t_out <= t_len, "spec_cols_inv: t_out must be in [0, t_len]");
@@ -1059,6 +1065,7 @@ static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, 
     a.scale = (real_t)scale;
     a.env_log2 = env_log2;
     a.sumsq = sumsq;
+    a.dev_scale = dev_scale;
     return cols_launch(true, a, Bn, (hipStream_t)stream);
 }
 extern "C" {

@@ -50,6 +50,8 @@ struct ColsArgs {
     int t_len, t_lim;
     real_t scale;
     double env_log2;
+    const real_t* dev_scale;   // inverse, optional: a DEVICE scalar multiplied into `scale` (the objective's 2 g / N in the gradient
+                          // of the input: ops.mean_square) -- a multiplication pass over the result otherwise
     double* sumsq;        // inverse, optional: sumsq[workgroup] = sum of the squares of the samples this workgroup stored (the
                           // objective's reduction rides in the pass that produces y: ops.mean_square never re-reads it)
 };

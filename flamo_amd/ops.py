@@ -792,8 +792,9 @@ def _spec_mid(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, want_inverse, spec_sca
     return S2, Xs
 
 
-def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2, want_sumsq=False):
-    """-> y (B, t_len, G); with want_sumsq also the per-workgroup partial sums of y^2 (double) the same launch leaves behind"""
+def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2, want_sumsq=False, dev_scale=None):
+    """-> y (B, t_len, G); with want_sumsq also the per-workgroup partial sums of y^2 (double) the same launch leaves behind;
+    dev_scale: a device scalar of the pipeline's real dtype multiplied into `scale` by the kernel"""
     alloc = torch.zeros if t_len > t_out else torch.empty
     real = _rdtype(S2)
     y = alloc((B, t_len, G), dtype=real, device=S2.device)
@@ -805,6 +806,12 @@ def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2, want_sumsq=Fal
             _lib.check(_spec_fn("fl_spec_cols_inv_sumsq", real)(S2.data_ptr(), y.data_ptr(), B, t_len, t_out, G,
                                                                 twiddles(nfft, real, S2.device).data_ptr(), nfft, scale, env_log2,
                                                                 parts.data_ptr(), _stream()), "spec_cols_inv_sumsq")
+        elif dev_scale is not None:
+            if dev_scale.dtype != real or not dev_scale.is_cuda or dev_scale.numel() != 1:
+                raise ValueError("spec_cols_inv: dev_scale must be one device scalar of the signal's dtype")
+            _lib.check(_spec_fn("fl_spec_cols_inv_scaled", real)(S2.data_ptr(), y.data_ptr(), B, t_len, t_out, G,
+                                                                 twiddles(nfft, real, S2.device).data_ptr(), nfft, scale,
+                                                                 dev_scale.data_ptr(), env_log2, _stream()), "spec_cols_inv_scaled")
         else:
             _lib.check(_spec_fn("fl_spec_cols_inv", real)(S2.data_ptr(), y.data_ptr(), B, t_len, t_out, G,
                                                           twiddles(nfft, real, S2.device).data_ptr(), nfft, scale, env_log2,
@@ -946,16 +953,15 @@ class _SpectralApply(torch.autograd.Function):
                     S3, _ = _spec_mid_walk(Sg, B, NO, NI, nfft, Hp, True, False, scale_i, 1, 1)
                 else:
                     S3, _ = _spec_mid(Sg, B, NO, NI, nfft, Hp, True, False, True, scale_i, 1, 1)
-                gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f, env_f)
-                if out_scale is not None:
-                    gx = gx * (out_scale * host_factor)
+                # (the objective's factor: its host part in the pass's scale, its device part multiplied in by the kernel)
+                gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f * (host_factor if out_scale is not None else 1.0), env_f,
+                                    dev_scale=out_scale)
             return gx, gH
         # rfft' : g_x[t] = scale_f e_f(t) Re sum_k g_X[k] exp(+j w_k t), g_X = H^H g_Y -- an inverse transform with halved interior bins
         S3, gYs = _spec_mid(Sg, B, NO, NI if need_x else NO, nfft, Hp if need_x else None, True, need_h, need_x, scale_i, 1, 1)
         if need_x:
-            gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f, env_f)
-            if out_scale is not None:
-                gx = gx * (out_scale * host_factor)
+            gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f * (host_factor if out_scale is not None else 1.0), env_f,
+                                dev_scale=out_scale)
         if need_h:
             Xs = kept[0]
             gH = _gradh_launch(gYs.movedim(-1, 1), Xs.movedim(-1, 1), False).movedim(-1, 0)

@@ -190,6 +190,11 @@ int fl_spec_cols_inv_f32(const void* S2, void* y, int Bn, int t_len, int t_out, 
 int fl_spec_cols_inv_sumsq_f32(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                                double env_log2, void* sumsq_parts, void* stream);
 int fl_spec_cols_blocks_f32(int nfft, int Bn, int G);
+/* K3 with a DEVICE scalar (float; double in the _f64 form) multiplied into `scale`: the gradient of the input under an
+ * objective whose factor lives on the device (trainer.py:177-190: loss.backward() hands 2 g / N down as a tensor) -- a
+ * multiplication pass over the (Bn, t_len, G) result otherwise */
+int fl_spec_cols_inv_scaled_f32(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                                const void* dev_scale, double env_log2, void* stream);
 /* per plane: dst[i] = src[k(i)] (inverse = 0, natural -> row-major bin order) or dst[k(i)] = src[i] (inverse = 1) */
 int fl_permute_bins_c64(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
                         void* stream);
@@ -208,6 +213,8 @@ int fl_spec_cols_inv_f64(const void* S2, void* y, int Bn, int t_len, int t_out, 
 int fl_spec_cols_inv_sumsq_f64(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                                double env_log2, void* sumsq_parts, void* stream);
 int fl_spec_cols_blocks_f64(int nfft, int Bn, int G);
+int fl_spec_cols_inv_scaled_f64(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
+                                const void* dev_scale, double env_log2, void* stream);
 int fl_permute_bins_c128(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
                          void* stream);
 
