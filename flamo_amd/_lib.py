@@ -79,6 +79,8 @@ _SIGNATURES = {
     "fl_mimo_diag_c128": (_i, [_vp, _l, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_mimo_gradh_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _d, _i, _i, _i, _i, _i, _vp]),
     "fl_mimo_gradh_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _d, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradh_scaled_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _d, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fl_mimo_gradh_scaled_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _d, _vp, _i, _i, _i, _i, _i, _vp]),
     "fl_mimo_gradh_diag_c64": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _i, _i, _i, _i, _vp]),
     "fl_mimo_gradh_diag_c128": (_i, [_vp, _l, _l, _l, _vp, _l, _l, _l, _vp, _l, _i, _i, _i, _i, _vp]),
     "fl_mimo_gradw_blocks": (_i, [_i]),

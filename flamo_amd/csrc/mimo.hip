@@ -111,9 +111,10 @@ template <typename T, int MT, int NT>
 __global__ void __launch_bounds__(256) mimo_gradh_kernel(
     const cx<T>* __restrict__ G, long gs_b, long gs_m, long gs_k,
     const cx<T>* __restrict__ X, long xs_b, long xs_n, long xs_k,
-    cx<T>* __restrict__ dH, long dh_pitch, T scale, int B, int M, int No, int Ni, int K) {
+    cx<T>* __restrict__ dH, long dh_pitch, T scale, int B, int M, int No, int Ni, int K, const T* __restrict__ dev_scale) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     if (f >= M) return;
+    if (dev_scale) scale *= *dev_scale;      // a factor that lives on the device (an objective's 2 g / N): no pass over dH for it
     const int m0 = blockIdx.y * MT, n0 = blockIdx.z * NT;
     cx<T> acc[MT][NT];
 #pragma unroll
@@ -614,14 +615,16 @@ static int mimo_diag_impl(const void* h, long hs_f, long hs_n, int conj_h, const
 
 template <typename T>
 static int gradh_impl(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
-                      void* dH, long dh_pitch, double scale, int B, int M, int No, int Ni, int K, void* stream) {
+                      void* dH, long dh_pitch, double scale, int B, int M, int No, int Ni, int K, void* stream,
+                      const void* dev_scale_ = nullptr) {
+    const T* dev_scale = (const T*)dev_scale_;
     FL_REQUIRE(G && X && dH, "mimo_gradh: null pointer");
     FL_REQUIRE(dh_pitch >= M, "mimo_gradh: dh_pitch must be >= M");
     FL_REQUIRE(B >= 0 && M >= 0 && No > 0 && Ni > 0 && K > 0, "mimo_gradh: bad sizes");
     if (M == 0) return FL_OK;
     hipStream_t st = (hipStream_t)stream;
     if constexpr (sizeof(T) == 4) {
-        if (g_mimo_variant == 0 && mfma_applies(No, Ni, B * K)) {
+        if (g_mimo_variant == 0 && !dev_scale && mfma_applies(No, Ni, B * K)) {      // (a device-side factor: the lane kernels)
             MmaArgs a = {};
             a.A = (const cx<float>*)G; a.sa_f = 1; a.sa_i = gs_m; a.sa_t1 = gs_b; a.sa_t2 = gs_k; a.conj_a = 0;
             a.B = (const cx<float>*)X; a.sb_j1 = 0; a.sb_j2 = xs_n; a.sb_t1 = xs_b; a.sb_t2 = xs_k; a.conj_b = 1;
@@ -640,20 +643,20 @@ static int gradh_impl(const void* G, long gs_b, long gs_m, long gs_k, const void
         FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradh: too many channels");
         if (tn == 8)
             hipLaunchKernelGGL((mimo_gradh_kernel<T, 8, 8>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
-                               (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K);
+                               (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K, dev_scale);
         else
             hipLaunchKernelGGL((mimo_gradh_kernel<T, 8, 4>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
-                               (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K);
+                               (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K, dev_scale);
     } else if (No >= 4 && Ni >= 4) {
         dim3 grid(cdiv_i(M, 256), cdiv_i(No, 4), cdiv_i(Ni, 4));
         FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradh: too many channels");
         hipLaunchKernelGGL((mimo_gradh_kernel<T, 4, 4>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
-                           (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K);
+                           (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K, dev_scale);
     } else {
         dim3 grid(cdiv_i(M, 256), No, Ni);
         FL_REQUIRE(grid.y <= 65535 && grid.z <= 65535, "mimo_gradh: too many channels");
         hipLaunchKernelGGL((mimo_gradh_kernel<T, 1, 1>), grid, dim3(256), 0, st, (const cx<T>*)G, gs_b, gs_m, gs_k,
-                           (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K);
+                           (const cx<T>*)X, xs_b, xs_n, xs_k, (cx<T>*)dH, dh_pitch, (T)scale, B, M, No, Ni, K, dev_scale);
     }
     FL_CHECK_LAUNCH("mimo_gradh");
     return FL_OK;
@@ -874,6 +877,16 @@ int fl_mimo_gradh_c64(const void* G, long gs_b, long gs_m, long gs_k, const void
 int fl_mimo_gradh_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
                        void* dH, long dh_pitch, double scale, int B, int M, int No, int Ni, int K, void* stream) {
     return gradh_impl<double>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, dH, dh_pitch, scale, B, M, No, Ni, K, stream);
+}
+int fl_mimo_gradh_scaled_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                             void* dH, long dh_pitch, double scale, const void* dev_scale, int B, int M, int No, int Ni, int K, void* stream) {
+    FL_REQUIRE(dev_scale, "mimo_gradh_scaled: null pointer");
+    return gradh_impl<float>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, dH, dh_pitch, scale, B, M, No, Ni, K, stream, dev_scale);
+}
+int fl_mimo_gradh_scaled_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                              void* dH, long dh_pitch, double scale, const void* dev_scale, int B, int M, int No, int Ni, int K, void* stream) {
+    FL_REQUIRE(dev_scale, "mimo_gradh_scaled: null pointer");
+    return gradh_impl<double>(G, gs_b, gs_m, gs_k, X, xs_b, xs_n, xs_k, dH, dh_pitch, scale, B, M, No, Ni, K, stream, dev_scale);
 }
 int fl_mimo_gradh_diag_c64(const void* G, long gs_b, long gs_n, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
                            void* dh, long dh_pitch, int B, int M, int N, int K, void* stream) {

@@ -964,9 +964,8 @@ class _SpectralApply(torch.autograd.Function):
                                 dev_scale=out_scale)
         if need_h:
             Xs = kept[0]
-            gH = _gradh_launch(gYs.movedim(-1, 1), Xs.movedim(-1, 1), False).movedim(-1, 0)
-            if out_scale is not None:
-                gH = gH * (out_scale * host_factor)
+            gH = _gradh_launch(gYs.movedim(-1, 1), Xs.movedim(-1, 1), False, host_factor if out_scale is not None else 1.0,
+                               out_scale).movedim(-1, 0)
         return gx, gH
 
 
@@ -1065,8 +1064,9 @@ def _mimo_launch(H, per_bin, diag, conj_t, X):
     return Y
 
 
-def _gradh_launch(G, X, diag, scale=1.0):
-    """sum over batch/trailing dims of G x conj(X): planar (No, Ni, M) [full] or (N, M) [diag]."""
+def _gradh_launch(G, X, diag, scale=1.0, dev_scale=None):
+    """sum over batch/trailing dims of G x conj(X): planar (No, Ni, M) [full] or (N, M) [diag].
+    dev_scale (full form): a device scalar of the real dtype multiplied into `scale` by the kernel."""
     real = _rdtype(X)
     B, M, Ni, K, xs_b, xs_n, xs_k = _bnk(X)
     _, _, No, _, gs_b, gs_m, gs_k = _bnk(G)
@@ -1081,8 +1081,15 @@ def _gradh_launch(G, X, diag, scale=1.0):
     dH = _empty_rows((No, Ni), M, X.dtype, X.device)
     fn = L.fl_mimo_gradh_c64 if real == torch.float32 else L.fl_mimo_gradh_c128
     with kernel_timer.span(f"mimo_gradh[cols={B * K},{No}x{Ni}]"):
-        _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dH.data_ptr(), P, float(scale), B, M,
-                      No, Ni, K, _stream()), "mimo_gradh")
+        if dev_scale is not None:
+            if dev_scale.dtype != real or not dev_scale.is_cuda or dev_scale.numel() != 1:
+                raise ValueError("mimo_gradh: dev_scale must be one device scalar of the signal's real dtype")
+            fn = L.fl_mimo_gradh_scaled_c64 if real == torch.float32 else L.fl_mimo_gradh_scaled_c128
+            _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dH.data_ptr(), P, float(scale),
+                          dev_scale.data_ptr(), B, M, No, Ni, K, _stream()), "mimo_gradh_scaled")
+        else:
+            _lib.check(fn(G.data_ptr(), gs_b, gs_m, gs_k, X.data_ptr(), xs_b, xs_n, xs_k, dH.data_ptr(), P, float(scale), B, M,
+                          No, Ni, K, _stream()), "mimo_gradh")
     return dH
 
 

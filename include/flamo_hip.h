@@ -258,6 +258,12 @@ int fl_mimo_gradh_c64(const void* G, long gs_b, long gs_m, long gs_k,
 int fl_mimo_gradh_c128(const void* G, long gs_b, long gs_m, long gs_k,
                        const void* X, long xs_b, long xs_n, long xs_k,
                        void* dH, long dh_pitch, double scale, int B, int M, int No, int Ni, int K, void* stream);
+/* ... with a DEVICE scalar (float / double) multiplied into `scale` by the kernel: the factor an objective hands down as a
+ * tensor (trainer.py:177-190: loss.backward()) -- a multiplication pass over dH otherwise */
+int fl_mimo_gradh_scaled_c64(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                             void* dH, long dh_pitch, double scale, const void* dev_scale, int B, int M, int No, int Ni, int K, void* stream);
+int fl_mimo_gradh_scaled_c128(const void* G, long gs_b, long gs_m, long gs_k, const void* X, long xs_b, long xs_n, long xs_k,
+                              void* dH, long dh_pitch, double scale, const void* dev_scale, int B, int M, int No, int Ni, int K, void* stream);
 /* dh[n,f] = sum_{b,k} G[b,n,k,f] * conj(X[b,n,k,f])   (planar dh: n*dh_pitch + f) */
 int fl_mimo_gradh_diag_c64(const void* G, long gs_b, long gs_n, long gs_k,
                            const void* X, long xs_b, long xs_n, long xs_k,
