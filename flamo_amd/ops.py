@@ -1833,6 +1833,11 @@ class _GeqCascade(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gH):
         xc, consts, b, a, *kept = ctx.saved_tensors
+        nbx = _geq_lanes_blocks(ctx.cfg, 1, 0, 0) if kept else 0
+        if nbx > 0:
+            C_ = ctx.cfg[3]
+            out, _ = _geq_backward_lanes(0, gH, kept[0], b, a, None, ctx.cfg, C_, 1, 0, nbx, xc, consts, ctx.sig)
+            return out, None, None, None, None, None
         part = _sos_backward_launch(gH, kept[0] if kept else None, b, a, ctx.cfg)
         nblk = part.shape[0]
         nb = xc.shape[0]
@@ -2051,6 +2056,44 @@ def _cascade_rc_backward(gH, G, b, a, Wr, cfg):
     return part, partW
 
 
+def _geq_lanes_blocks(cfg, ppr: int, niw: int, mode: int) -> int:
+    """bin blocks of the lanes-per-section backward (csrc/cascade2.hip) for this shape, 0 when it does not take it"""
+    gamma, nfft, S, C_, bin0, m_local, real = cfg
+    if real != torch.float32 or not SOS_BWD_MIXED:
+        return 0
+    return int(_lib.lib().fl_geq_bwd_lanes_blocks(m_local, C_, S, nfft, bin0, int(ppr), int(niw), int(mode)))
+
+
+def _geq_backward_lanes(mode, gH, G, b, a, Wr, cfg, No, Nmid, Ni, nbx, xc, consts, sig):
+    """graphic equaliser, float32: cascade backward with one lane per (pair, section) + the launch that reduces its block
+    partials and runs the design's backward.  -> (dL/dx in x's dtype, dL/dWr or None)"""
+    gamma, nfft, S, C_, bin0, m_local, real = cfg
+    dev = b.device
+    g = _h_planar(gH.resolve_conj(), True)
+    L = _lib.lib()
+    psum = torch.empty((nbx, 4, S * C_), dtype=torch.float32, device=dev)      # every entry is written
+    pq = torch.empty((nbx, C_), dtype=torch.float32, device=dev)
+    # per workgroup (bin block x pair group) ONE (Nmid, Ni) matrix, summed over the group's output channels already
+    wrows = L.fl_geq_bwd_lanes_wrows(m_local, C_, S, nfft, bin0, Nmid, Ni) if mode == 1 else 0
+    partW = torch.empty((wrows, Nmid * Ni), dtype=torch.float32, device=dev) if mode == 1 else None
+    Wc = Wr.contiguous() if mode == 1 else None
+    with kernel_timer.span("sos_response_bwd_rc" if mode == 1 else "sos_response_bwd"):
+        _lib.check(L.fl_geq_response_bwd_lanes_c64(mode, g.data_ptr(), _lead_pitch(g.movedim(0, -1)), G.data_ptr(), _pitch(m_local),
+                                                   b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni,
+                                                   None if Wc is None else Wc.data_ptr(), gamma,
+                                                   twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local,
+                                                   psum.data_ptr(), pq.data_ptr(), None if partW is None else partW.data_ptr(),
+                                                   _stream()), "geq_response_bwd_lanes")
+    out = torch.empty_like(xc)
+    gW = torch.empty_like(Wr, memory_format=torch.contiguous_format) if mode == 1 else None
+    _lib.check(L.fl_geq_sections_bwd_lanes(xc.data_ptr(), _geq_in_kind(xc, True, sig), psum.data_ptr(), pq.data_ptr(), nbx,
+                                           b.data_ptr(), a.data_ptr(), gamma, S, C_, consts.data_ptr(), out.data_ptr(),
+                                           None if partW is None else partW.data_ptr(), wrows,
+                                           Nmid * Ni if mode == 1 else 0, None if gW is None else gW.data_ptr(), _stream()),
+               "geq_sections_bwd_lanes")
+    return out, gW
+
+
 class _SosRC(torch.autograd.Function):
     """sos_response(b, a) @ Wr with the composition's backward folded into the cascade's backward kernel"""
 
@@ -2095,6 +2138,10 @@ class _GeqCascadeRC(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gH):
         xc, consts, b, a, G, Wr = ctx.saved_tensors
+        nbx = _geq_lanes_blocks(ctx.cfg, G.shape[1], Wr.shape[1], 1)
+        if nbx > 0:
+            out, gW = _geq_backward_lanes(1, gH, G, b, a, Wr, ctx.cfg, G.shape[0], G.shape[1], Wr.shape[1], nbx, xc, consts, ctx.sig)
+            return out, None, gW, None, None, None, None
         part, partW = _cascade_rc_backward(gH, G, b, a, Wr, ctx.cfg)
         nblk = part.shape[0]
         nb = xc.shape[0]

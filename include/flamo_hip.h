@@ -427,6 +427,35 @@ int fl_geq_sections_bwd_w(const void* gain, int in_kind, const void* gb, const v
 int fl_geq_sections_bwd_w64(const void* gain, int in_kind, const void* gb, const void* ga, long blk_stride, int nblk, int nb,
                             int C, const void* consts, void* ggain, const void* partW, int wrows, int wn, void* gW, void* stream);
 
+/* Second generation of the graphic equaliser's cascade backward (csrc/cascade2.hip): one lane per (channel pair, section)
+ * walking the bins, instead of one lane per bin walking the sections -- the backward of the cascade tail dsp.py:1520-1526
+ * for GEQ / parallelGEQ sections (dsp.py:2563-2593, eq.py:57-111) under the einsum dsp.py:922-924, with the composition
+ * backward of Series(Matrix, GEQ) (system.py:299-300, dsp.py:466-468) folded in as fl_sos_response_bwd_rc_c64 does.
+ *   mode 0: gH = dL/dG, planes c (No * Nmid channel pairs; Ni, Wr, partW unused);
+ *   mode 1: gH = dL/dH of H = G W, planes (m * Ni + n); Wr float (Nmid, Ni); partW float (fl_geq_bwd_lanes_wrows(...),
+ *           Nmid * Ni) out (per-workgroup partials of sum_m Re(conj(G[m][j]) dL/dH[m][n]), a v_mfma_f32_16x16x4_f32
+ *           contraction over the bins).
+ * G: the saved response (planes c); b, a: the designed taps, double (3, S, No * Nmid).
+ * Outputs: psum float (nbx, 4, S * No * Nmid) -- per block, section and pair the sums of Re(q / B~), Re(q / A~),
+ * sin Im(q / B~), sin Im(q / A~) (q = conj(dL/dG) G, B~ / A~ the section polynomials turned by half a sample) -- and
+ * pq float (nbx, No * Nmid), the sums of Re(q); nbx = fl_geq_bwd_lanes_blocks(...) (0: shape not taken, use the
+ * first-generation entry points).  fl_geq_sections_bwd_lanes reduces them, recovers the third sum from
+ * sum Re(q) = (S + T) G0 - S G1 - D G2, forms the tap gradients and runs the design's backward (as fl_geq_sections_bwd_w). */
+int fl_geq_bwd_lanes_blocks(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw, int mode);
+int fl_geq_bwd_lanes_wrows(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw);
+int fl_geq_response_bwd_lanes_c64(int mode, const void* gH, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
+                                  int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,
+                                  int bin0, int m_local, void* psum, void* pq, void* partW, void* stream);
+int fl_geq_sections_bwd_lanes(const void* gain, int in_kind, const void* psum, const void* pq, int nbx, const void* b, const void* a,
+                              double gamma, int nb, int C, const void* consts, void* ggain, const void* partW, int wrows, int wn,
+                              void* gW, void* stream);
+/* test / tuning hook: on = 0 routes every cascade through the first-generation kernels; blocks_per_cu, tile_bins >= 0 set
+ * the grid's sizing (negative: unchanged).  Returns the previous `on`. */
+int fl_debug_set_cascade_lanes(int on, int blocks_per_cu, int tile_bins);
+/* tuning hook: device buffer of 6 int64 per (workgroup, wavefront) receiving the cycles spent per phase (null: off); skip bit 0 /
+ * bit 1 leave out the lane-per-bin / lane-per-section phase (wrong results: timing only) */
+int fl_debug_set_cascade_stamps(void* device_buffer, int skip);
+
 /* ------------------------------------------------------------------ closed loop
  * Replace torch.linalg.solve(A, B) in system.Recursion.forward (system.py:420-425).
  * Per bin f:  A_f = (one_minus ? I - P[:,:,f] : P[:,:,f]);  if adjoint, A_f := A_f^H;

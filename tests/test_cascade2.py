@@ -1,0 +1,112 @@
+"""Second-generation cascade kernels (csrc/cascade2.hip): one lane per (channel pair, section).
+
+The backward of a graphic equaliser's cascade (dsp.py:2563-2593 over eq.py:57-111, cascade tail dsp.py:1520-1526) is
+compared with the first-generation lane-per-bin kernels (response.hip) and with the all-double kernels on the same inputs:
+same operator, same saved response, a random complex cotangent."""
+import pytest
+import torch
+
+from conftest import check_close, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _lanes(on):
+    from flamo_amd import _lib
+    return _lib.lib().fl_debug_set_cascade_lanes(int(on), -1, -1)
+
+
+def _grads_rc(geq, W, nfft, row_major, seed, f64=False):
+    from flamo_amd import ops
+    import contextlib
+    x = geq.param.detach().clone().requires_grad_(True)
+    Wl = (W.double() if f64 else W).detach().clone().requires_grad_(True)
+    spec = geq._cascade_spec(x)
+    with (ops.row_major_bins(nfft) if row_major else contextlib.nullcontext()):
+        H = ops.geq_cascade_rc(spec[1], spec[2], Wl, geq._gamma_f, nfft, dtype=torch.float64 if f64 else torch.float32)
+        g = torch.Generator(device=H.device).manual_seed(seed)
+        ct = torch.randn(H.shape, generator=g, device=H.device) + 1j * torch.randn(H.shape, generator=g, device=H.device)
+        (H * ct.to(H.dtype).conj()).real.sum().backward()
+    return H.detach(), x.grad.detach(), Wl.grad.detach()
+
+
+@pytest.mark.parametrize("row_major", [True, False])
+@pytest.mark.parametrize("db", [0.0, 30.0])
+@pytest.mark.parametrize("nfft,N", [(96000, 8), (4096, 4), (24000, 2), (96000, 16)])
+def test_lanes_backward_rc_matches_first_generation(gpu, nfft, N, db, row_major):
+    """Matrix-then-GEQ (the pair of BASELINE configs[1]): lanes kernel against the first generation and against the operator in
+    complex128 (the all-double kernels, fl_sos_response_bwd_rc_c128) under the same cotangent"""
+    from flamo_amd import _lib
+    from flamo_amd.processor import dsp
+    L = _lib.lib()
+    if row_major and nfft == 4096:
+        pytest.skip("row-major order is the fused pipeline's (walking shapes)")
+    torch.manual_seed(5)
+    geq = dsp.GEQ(size=(N, N), nfft=nfft, alias_decay_db=db, device=gpu, dtype=torch.float32)
+    W = torch.randn(N, N, device=gpu)
+    M = nfft // 2 + 1
+    if L.fl_geq_bwd_lanes_blocks(M, N * N, 12, nfft, 0, N, N, 1) == 0:
+        pytest.skip("shape not taken by the lanes kernel")
+    prev = _lanes(1)
+    try:
+        H1, gx1, gW1 = _grads_rc(geq, W, nfft, row_major, 3)
+        _lanes(0)
+        H0, gx0, gW0 = _grads_rc(geq, W, nfft, row_major, 3)
+    finally:
+        _lanes(prev)
+    _, gxd, gWd = _grads_rc(geq, W, nfft, row_major, 3, f64=True)
+    assert torch.equal(H1, H0)
+    tag = f"lanes_rc/{nfft}_{N}_{int(db)}_{int(row_major)}"
+    e1, e0 = relerr(gx1, gxd), relerr(gx0, gxd)
+    print(f"\n{tag}: gain gradient vs complex128: lanes {e1:.2e}, first generation {e0:.2e}; dW {relerr(gW1, gWd):.2e} / {relerr(gW0, gWd):.2e}")
+    # (a white complex cotangent; the saved float32 response enters both float32 backward passes)
+    check_close(tag + "/g_gain", gx1, gxd, max(3e-6, 2 * e0))
+    check_close(tag + "/g_W", gW1, gWd, 3e-6)
+
+
+@pytest.mark.parametrize("sig", [False, True])
+@pytest.mark.parametrize("nfft,N,shard", [(192000, 16, None), (192000, 16, (12001, 12000)), (1500, 6, None), (96000, 32, None)])
+def test_lanes_backward_plain_matches_first_generation(gpu, nfft, N, shard, sig):
+    """parallelGEQ (the attenuation filters of the feedback delay networks, e8_fdn.py:97) -- plain mode, contiguous bins, a bin shard"""
+    from flamo_amd import _lib, ops
+    from flamo_amd.processor import dsp
+    torch.manual_seed(7)
+    kw = dict(nfft=nfft, alias_decay_db=30.0, device=gpu, dtype=torch.float32)
+    geq = dsp.parallelGEQ(size=(N,), map=dsp.db_of_sigmoid, **kw) if sig else dsp.parallelGEQ(size=(N,), **kw)
+    if sig:
+        geq.assign_value(torch.randn_like(geq.param) + 2.0)
+
+    def run():
+        x = geq.param.detach().clone().requires_grad_(True)
+        spec = geq._cascade_spec(x)
+        if shard is not None:
+            ops.set_bin_shard(*shard)
+        try:
+            H = ops.geq_cascade(spec[1], spec[2], geq._gamma_f, nfft, gain_map=spec[3] if len(spec) > 3 else "abs")
+            g = torch.Generator(device=H.device).manual_seed(11)
+            ct = torch.randn(H.shape, generator=g, device=H.device) + 1j * torch.randn(H.shape, generator=g, device=H.device)
+            (H * ct.conj()).real.sum().backward()
+        finally:
+            ops.set_bin_shard(0, None)
+        return H.detach(), x.grad.detach()
+
+    M = nfft // 2 + 1 if shard is None else shard[1]
+    if _lib.lib().fl_geq_bwd_lanes_blocks(M, N, 12, nfft, 0 if shard is None else shard[0], 1, 0, 0) == 0:
+        pytest.skip("shape not taken by the lanes kernel")
+    prev = _lanes(1)
+    try:
+        H1, g1 = run()
+        _lanes(0)
+        H0, g0 = run()
+        ops.SOS_BWD_MIXED = False
+        try:
+            _, gd = run()
+        finally:
+            ops.SOS_BWD_MIXED = True
+    finally:
+        _lanes(prev)
+    assert torch.equal(H1, H0)
+    tag = f"lanes_plain/{nfft}_{N}_{'shard' if shard else 'all'}_{int(sig)}"
+    e0 = relerr(g0, gd)
+    print(f"\n{tag}: gain gradient vs all-double: lanes {relerr(g1, gd):.2e}, first generation {e0:.2e}")
+    check_close(tag + "/g_gain", g1, gd, max(3e-6, 2 * e0))
