@@ -44,9 +44,9 @@ struct LanesArgs {
     const cx<float>* G;    // saved response, planes c
     long h_pitch;
     const float* Wr;       // (PPR, NIW) constant factor (rc mode)
-    float* psum;           // (nbx, 2 * NSUM, S * C) partial sums
-    float* pq;             // (nbx, C) partial sums of Re(q)
-    float* partW;          // (nbx * pair groups, PPR * NIW) partial sums of the constant factor's gradient (rc mode)
+    float* psum;           // (S * C, nbx, 4) partial sums (G0 of B, G0 of A, G2 of B, G2 of A)
+    float* pq;             // (C, nbx) partial sums of Re(q)
+    float* partW;          // (PPR * NIW, nbx * pair groups) partial sums of the constant factor's gradient (rc mode)
     // "outer" mode: dL/dG[m][n] = sum_b gY[b][m] conj(X[b][n]) formed from the two signals
     const cx<float>* oG;
     const cx<float>* oX;
@@ -362,14 +362,12 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
     }
 #undef FL_STAMP
 
-    // ---- partial sums of this block: [sum][section * C + pair], coalesced over the pairs
+    // ---- partial sums of this block: [section * C + pair][block][4 sums] -- one 16-byte store per lane, and the reduction
+    // reads an entry's partials as one run
+    (void)acc1;
     if (l_on) {
-        const size_t SC = (size_t)S * C;
-        float* ps = A.psum + (size_t)bx * (2 * NSUM) * SC + (size_t)sl * C + c;
-        ps[0] = acc0.x; ps[SC] = acc0.y; ps[2 * SC] = acc2.x; ps[3 * SC] = acc2.y;
-        if constexpr (NSUM == 3) {
-            ps[4 * SC] = acc1.x; ps[5 * SC] = acc1.y;
-        }
+        static_assert(NSUM == 2, "the partials are one 16-byte record per (entry, block)");
+        reinterpret_cast<f4*>(A.psum)[((size_t)sl * C + c) * A.nbx + bx] = f4{acc0.x, acc0.y, acc2.x, acc2.y};
     }
     {   // sum Re(q) per pair: the items' sums through LDS (the tile buffers are done with), one thread per pair adds its tb items
         float* qred = reinterpret_cast<float*>(smem);      // [items][JPT]
@@ -386,7 +384,7 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
             const int r = t / (JPT * JG), jr = t - r * (JPT * JG), jg = jr / JPT, jj = jr - jg * JPT;
             float tot = 0.f;
             for (int i = 0; i < A.tb; ++i) tot += qred[(size_t)((r * A.tb + i) * JG + jg) * JPT + jj];
-            A.pq[(size_t)bx * C + cg * npb + t] = tot;
+            A.pq[(size_t)(cg * npb + t) * A.nbx + bx] = tot;
         }
     }
     if constexpr (RC) {
@@ -404,78 +402,95 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
             float tot = 0.f;
             const int nit = A.tb * A.rows;      // items of one pair group
             for (int u = 0; u < nit; ++u) tot += wred[(size_t)(jg + JG * u) * (JPT * NIW) + jj * NIW + nn];
-            A.partW[((size_t)bx * gridDim.y + cg) * (PPR * NIW) + t] = tot;
+            A.partW[(size_t)t * (A.nbx * gridDim.y) + (size_t)bx * gridDim.y + cg] = tot;
         }
     }
 }
 
 // ---------------------------------------------------------------- reduction + completion + design backward
-// 32 consecutive (band, pair) entries per workgroup, 32 threads per entry striding over the nbx block partials (double sums,
-// fixed order: deterministic); the entry's first thread recovers G1 from sum Re(t P~) = Q, forms the six tap gradients as the first-generation kernel's epilogue does
+// One wavefront per (band, pair) entry, its lanes striding over the nbx block partials (double sums, fixed butterfly:
+// deterministic); the first lane recovers G1 from sum Re(t P~) = Q, forms the six tap gradients as the first-generation kernel's epilogue does
 // (d/db0 = G0 - G1 - G2, d/db1 = g G0, d/db2 = g^2 (G0 - G1 + G2)) and runs the design's backward (geq_design_bwd).  Band 0
 // is the pure gain: d/db0 = Q / b0.  Tail blocks: gW[e] = sum of the constant factor's partials, as geq_sections_bwd_kernel.
-__global__ void __launch_bounds__(1024) geq_bwd_lanes_kernel(const void* __restrict__ gain, int in_kind,
-                                                             const float* __restrict__ psum, const float* __restrict__ pq, int nbx,
-                                                             const double* __restrict__ b, const double* __restrict__ a, double gam,
-                                                             int nb, int C, const double* __restrict__ k, void* __restrict__ ggain,
-                                                             int main_blocks, const float* __restrict__ partW, int wrows, int wn,
-                                                             float* __restrict__ gW) {
-    __shared__ double red[5][32][33];
-    const int t = threadIdx.x;
+__global__ void __launch_bounds__(256) geq_bwd_lanes_kernel(const void* __restrict__ gain, int in_kind,
+                                                            const float* __restrict__ psum, const float* __restrict__ pq, int nbx,
+                                                            const double* __restrict__ b, const double* __restrict__ a, double gam,
+                                                            int nb, int C, const double* __restrict__ k, void* __restrict__ ggain,
+                                                            int main_blocks, int epb, const float* __restrict__ partW, int wrows,
+                                                            int wn, float* __restrict__ gW) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if ((int)blockIdx.x >= main_blocks) {
-        // gW[e] = sum_r partW[r][e]: 16 entries x 64 row slices per block (coalesced 64-byte pieces, fixed order)
-        float* redf = reinterpret_cast<float*>(&red[0][0][0]);      // [64][17]
-        const int le = t & 15, sl = t >> 4, e = ((int)blockIdx.x - main_blocks) * 16 + le;
+        // gW[e] = sum_r partW[e][r]: one wavefront per entry, the lanes stride over the (contiguous) rows, fixed butterfly
+        const int e = ((int)blockIdx.x - main_blocks) * 4 + wave;
+        if (e >= wn) return;
         float v = 0.f;
-        if (e < wn)
-            for (int r = sl; r < wrows; r += 64) v += partW[(size_t)r * wn + e];
-        redf[sl * 17 + le] = v;
-        __syncthreads();
-        if (t < 16 && e < wn) {
-            float tot = 0.f;
-            for (int s2 = 0; s2 < 64; ++s2) tot += redf[s2 * 17 + t];
-            gW[e] = tot;
-        }
+#pragma unroll 4
+        for (int r = lane; r < wrows; r += 64) v += partW[(size_t)e * wrows + r];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) gW[e] = v;
         return;
     }
-    // 32 consecutive (band, pair) entries x 32 block slices: the partials are read as 128-byte pieces
-    const int li = t & 31, sl = t >> 5;
-    const int idx = blockIdx.x * 32 + li;
+    // W wavefronts per (band, pair) entry (W = 4 / entries per workgroup): the entry's nbx partial records are ONE contiguous run
+    // (the cascade kernel writes them transposed), each wavefront takes a quarter / half / all of it with every load issued
+    // before the first is needed; the entry's own operands (gain, taps) are requested first, so that their round trips run
+    // under the partials' ones
+    __shared__ double red[4][5];
+    const int W = 4 / epb, part = wave % W;
+    const int idx0 = blockIdx.x * epb + wave / W;
     const size_t SC = (size_t)nb * C;
-    const bool on = idx < nb * C;
-    const int band = on ? idx / C : 0, c = on ? idx - band * C : 0;
+    const bool on = idx0 < nb * C;
+    const int idx = on ? idx0 : 0;
+    const int band = idx / C, c = idx - band * C;
+    double raw;
+    const double g = geq_linear_gain(gain, in_kind, idx, &raw);
+    double tap[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        tap[0][p] = b[p * SC + idx];
+        tap[1][p] = a[p * SC + idx];
+    }
     double v[5] = {0, 0, 0, 0, 0};
+    const int per = (nbx + W - 1) / W, b0 = part * per, b1 = min(nbx, b0 + per);
+    const f4* ps4 = reinterpret_cast<const f4*>(psum) + (size_t)idx * nbx;
     if (on) {
-        for (int bx = sl; bx < nbx; bx += 32) {
+#pragma unroll 4
+        for (int bx = b0 + lane; bx < b1; bx += 64) {
             if (band > 0) {
-                const float* p = psum + (size_t)bx * 4 * SC + idx;
-                v[0] += (double)p[0]; v[1] += (double)p[SC]; v[2] += (double)p[2 * SC]; v[3] += (double)p[3 * SC];
+                const f4 r4 = ps4[bx];
+                v[0] += (double)r4.x; v[1] += (double)r4.y; v[2] += (double)r4.z; v[3] += (double)r4.w;
             }
-            v[4] += (double)pq[(size_t)bx * C + c];
+            v[4] += (double)pq[(size_t)c * nbx + bx];
         }
     }
 #pragma unroll
-    for (int p = 0; p < 5; ++p) red[p][sl][li] = v[p];
-    __syncthreads();
-    if (t >= 32 || !on) return;
+    for (int o = 32; o >= 1; o >>= 1)
 #pragma unroll
-    for (int p = 0; p < 5; ++p) v[p] = 0;
-#pragma unroll 1
-    for (int s2 = 0; s2 < 32; ++s2) {
+        for (int p = 0; p < 5; ++p) v[p] += __shfl_xor(v[p], o, 64);
+    if (W > 1) {
+        if (lane == 0) {
 #pragma unroll
-        for (int p = 0; p < 5; ++p) v[p] += red[p][s2][li];
+            for (int p = 0; p < 5; ++p) red[wave][p] = v[p];
+        }
+        __syncthreads();
+        if (part == 0) {
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                double tot = red[wave][p];
+                for (int w2 = 1; w2 < W; ++w2) tot += red[wave + w2][p];
+                v[p] = tot;
+            }
+        }
     }
+    if (lane != 0 || part != 0 || !on) return;
     const double Q = v[4];
-    double raw;
-    const double g = geq_linear_gain(gain, in_kind, idx, &raw);
     double out[2][3] = {{0, 0, 0}, {0, 0, 0}};
     if (band == 0) {
-        out[0][0] = Q / b[idx];
+        out[0][0] = Q / tap[0][0];
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const double* co = i ? a : b;
-            const double t0 = co[idx], t1 = co[SC + idx], t2 = co[2 * SC + idx];
+            const double t0 = tap[i][0], t1 = tap[i][1], t2 = tap[i][2];
             const double Sg = t0 + gam * gam * t2, T = gam * t1, D = t0 - gam * gam * t2;
             const double sgn = i ? -1.0 : 1.0;
             const double G0 = sgn * v[i], G2 = sgn * v[2 + i];
@@ -489,6 +504,198 @@ __global__ void __launch_bounds__(1024) geq_bwd_lanes_kernel(const void* __restr
     geq_store_gain_grad(ggain, in_kind, idx, dg, g, raw);
 }
 
+static int g_lanes = 1;        // 0: the first-generation kernels everywhere (test hook)
+static int g_lanes_fwd = 1;    // ... of the forward kernel alone
+
+// ---------------------------------------------------------------- forward: cascade response times a constant matrix
+// H[m][n] = sum_j G[m][j] W[j][n], G[m][j] = prod_s B_s / prod_s A_s (response.hip: sos_response_rc_fast_kernel is the first
+// generation: two sections per packed instruction, two running products per polynomial, merged at the end).  Here numerator and
+// denominator of ONE section share the packed halves: the running product (prod B, prod A) is one packed complex value, a
+// section costs six packed instructions per bin (value 2, product 4), there is no merge of chains, and -- graphic equaliser --
+// the pure-gain band 0 (eq.py:91-94) is folded into band 1's numerator table: 11 sections per cascade, not 12.  One table
+// entry = two 16-byte reads: (c0B, c0A, c1B, c1A | c2B, c2A, -, -), Re = c0 + c1 x, Im = c2 sin (half_turn_tables).
+template <int NIW>
+__global__ void __launch_bounds__(256) sos_response_rc_ba_kernel(const double* __restrict__ b, const double* __restrict__ a, int S,
+                                                                 int C, int Nmid, const float* __restrict__ Wr, double g,
+                                                                 const cx<double>* __restrict__ Wd, int nfft, int bin0,
+                                                                 int m_local, cx<float>* __restrict__ G, long g_pitch,
+                                                                 cx<float>* __restrict__ H, long h_pitch, GeqDesign gd) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int s_first = gd.gain ? 1 : 0, Seff = S - s_first;
+    f4* tab = reinterpret_cast<f4*>(smem);                                   // [Nmid][basis 2][Seff][2]
+    float* lw = reinterpret_cast<float*>(tab + (size_t)Nmid * 2 * Seff * 2);   // [Nmid][NIW]
+    double* dt = reinterpret_cast<double*>(lw + ((Nmid * NIW + 3) & ~3));    // [Nmid][S][6] taps (b0 b1 b2 a0 a1 a2)
+    const int m = blockIdx.y;
+    for (int i = threadIdx.x; i < Nmid * S; i += 256) {
+        const int j = i / S, sidx = i - j * S;
+        const int c = m * Nmid + j;
+        double tb[3], ta[3];
+        if (gd.gain) {
+            geq_section_of(gd.gain, gd.in_kind, sidx * C + c, sidx, S, gd.k, tb, ta);
+            if (blockIdx.x == 0) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    gd.b_out[(size_t)(q * S + sidx) * C + c] = tb[q];
+                    gd.a_out[(size_t)(q * S + sidx) * C + c] = ta[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                tb[q] = b[(size_t)(q * S + sidx) * C + c];
+                ta[q] = a[(size_t)(q * S + sidx) * C + c];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            dt[(size_t)i * 6 + q] = tb[q];
+            dt[(size_t)i * 6 + 3 + q] = ta[q];
+        }
+    }
+    for (int i = threadIdx.x; i < Nmid * NIW; i += 256) lw[i] = Wr[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < Nmid * Seff; i += 256) {
+        const int j = i / Seff, se = i - j * Seff;
+        const double* t = dt + (size_t)(j * S + s_first + se) * 6;
+        // (graphic equaliser: band 0 is b = (g0, 0, 0), a = (1, 0, 0) -- its factor g0 multiplies band 1's numerator)
+        const double sc = (s_first && se == 0) ? dt[(size_t)(j * S) * 6] : 1.0;
+        const double g2 = g * g;
+        const double SB = sc * (t[0] + g2 * t[2]), TB = sc * g * t[1], DB = sc * (t[0] - g2 * t[2]);
+        const double SA = t[3] + g2 * t[5], TA = g * t[4], DA = t[3] - g2 * t[5];
+        f4* lo = tab + ((size_t)(j * 2 + 0) * Seff + se) * 2;
+        f4* hi = tab + ((size_t)(j * 2 + 1) * Seff + se) * 2;
+        lo[0] = f4{(float)(SB + TB), (float)(SA + TA), (float)(-SB), (float)(-SA)};
+        lo[1] = f4{(float)DB, (float)DA, 0.f, 0.f};
+        hi[0] = f4{(float)(TB - SB), (float)(TA - SA), (float)SB, (float)SA};
+        hi[1] = f4{(float)DB, (float)DA, 0.f, 0.f};
+    }
+    __syncthreads();
+    // a thread takes TWO ADJACENT BINS through the cascades (one set of table reads serves both): natural order elements
+    // 2p, 2p + 1; row-major order (row 2r, column c) and the element one row below (bin + 1); the Nyquist element alone
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    int e[2];
+    bool two;
+    if (bin0 >= 0) {
+        e[0] = 2 * p;
+        if (e[0] >= m_local) return;
+        two = e[0] + 1 < m_local;
+        e[1] = two ? e[0] + 1 : e[0];
+    } else {
+        const int L2 = -bin0, L = nfft >> 1, L1 = L / L2, main = ((L1 + 1) >> 1) * L2;
+        if (p > main) return;
+        if (p == main) {
+            e[0] = e[1] = L;
+            two = false;
+        } else {
+            const int r = p / L2, c2 = p - r * L2;
+            e[0] = 2 * r * L2 + c2;
+            two = 2 * r + 1 < L1;
+            e[1] = two ? e[0] + L2 : e[0];
+        }
+    }
+    bool low[2];
+    float xr[2], xi[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int k = bin_of(e[q], bin0, nfft);
+        const cx<double> w1 = Wd[k < nfft ? k : k - nfft];
+        low[q] = 4 * (long)k < nfft;
+        xr[q] = (float)(low[q] ? 1.0 - w1.x : 1.0 + w1.x);      // 1 -+ cos(omega), formed in double
+        xi[q] = (float)(-w1.y);                                  // sin(omega)
+    }
+    const bool same = low[0] == low[1];
+    f2 acc[2][NIW];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int n = 0; n < NIW; ++n) acc[q][n] = f2{0.f, 0.f};
+    for (int j = 0; j < Nmid; ++j) {
+        f2 Pr[2], Pi[2];      // (prod B, prod A): real and imaginary parts
+        auto first = [&](int q, f4 e0, f4 e1) {
+            Pr[q] = f2{e0.z, e0.w} * xr[q] + f2{e0.x, e0.y};
+            Pi[q] = f2{e1.x, e1.y} * xi[q];
+        };
+        auto step = [&](int q, f4 e0, f4 e1) {
+            const f2 R = f2{e0.z, e0.w} * xr[q] + f2{e0.x, e0.y};
+            const f2 I = f2{e1.x, e1.y} * xi[q];
+            f2 nr = Pi[q] * I;
+            nr = Pr[q] * R - nr;
+            f2 ni = Pr[q] * I;
+            ni = Pi[q] * R + ni;
+            Pr[q] = nr;
+            Pi[q] = ni;
+        };
+        if (same) {
+            const f4* tb = tab + (size_t)(j * 2 + (low[0] ? 0 : 1)) * Seff * 2;
+            first(0, tb[0], tb[1]);
+            first(1, tb[0], tb[1]);
+#pragma unroll 5
+            for (int se = 1; se < Seff; ++se) {
+                const f4 e0 = tb[2 * se], e1 = tb[2 * se + 1];
+                step(0, e0, e1);
+                step(1, e0, e1);
+            }
+        } else {
+            for (int q = 0; q < 2; ++q) {
+                const f4* tb = tab + (size_t)(j * 2 + (low[q] ? 0 : 1)) * Seff * 2;
+                if (q == 0) first(0, tb[0], tb[1]);
+                else first(1, tb[0], tb[1]);
+                for (int se = 1; se < Seff; ++se) {
+                    if (q == 0) step(0, tb[2 * se], tb[2 * se + 1]);
+                    else step(1, tb[2 * se], tb[2 * se + 1]);
+                }
+            }
+        }
+        const f4 w0 = *reinterpret_cast<const f4*>(lw + j * NIW);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float Bx = Pr[q].x, By = Pi[q].x, Ax = Pr[q].y, Ay = Pi[q].y;
+            f2 hf;
+            if (Ax != 0.f || Ay != 0.f) {
+                const float inv = __builtin_amdgcn_rcpf(Ax * Ax + Ay * Ay);      // (1 ulp; an IEEE division is ten instructions per bin and cascade)
+                hf = f2{(Bx * Ax + By * Ay) * inv, (By * Ax - Bx * Ay) * inv};
+            } else {
+                hf = f2{eps_of<float>(), 0.f};
+            }
+            if (q == 0 || two) G[(size_t)(m * Nmid + j) * g_pitch + e[q]] = cx<float>(hf.x, hf.y);
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) {
+                const float w = NIW >= 4 && n < 4 ? w0[n & 3] : lw[j * NIW + n];
+                acc[q][n] = hf * w + acc[q][n];
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (q == 0 || two) {
+#pragma unroll
+            for (int n = 0; n < NIW; ++n) H[(size_t)(m * NIW + n) * h_pitch + e[q]] = cx<float>(acc[q][n].x, acc[q][n].y);
+        }
+}
+
+// host side of the kernel above (called by response.hip: rc_impl); returns FL_ERR_UNSUPPORTED (no error text) when the shape is
+// not taken, so that the caller falls back to the first generation
+int rc_ba_launch(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd,
+                 int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch, void* stream, GeqDesign gd) {
+    if (!g_lanes_fwd || S < 2 || !(Ni == 2 || Ni == 4 || Ni == 8 || Ni == 16)) return FL_ERR_UNSUPPORTED;
+    const int Seff = S - (gd.gain ? 1 : 0);
+    const size_t lds = (size_t)Nmid * 2 * Seff * 32 + (size_t)((Nmid * Ni + 3) & ~3) * 4 + (size_t)Nmid * S * 6 * 8;
+    if (lds > 64 * 1024) return FL_ERR_UNSUPPORTED;
+    const int npairs = bin0 >= 0 ? cdiv_i(m_local, 2) : (((nfft / 2 / (-bin0)) + 1) / 2) * (-bin0) + 1;
+    const dim3 grid(cdiv_i(npairs, 256), No);
+#define FL_BA(NIW_)                                                                                                              \
+    hipLaunchKernelGGL((sos_response_rc_ba_kernel<NIW_>), grid, dim3(256), lds, (hipStream_t)stream, (const double*)b,           \
+                       (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma, (const cx<double>*)Wd, nfft, bin0, m_local, \
+                       (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch, gd)
+    if (Ni == 2) FL_BA(2);
+    else if (Ni == 4) FL_BA(4);
+    else if (Ni == 8) FL_BA(8);
+    else FL_BA(16);
+#undef FL_BA
+    FL_CHECK_LAUNCH("sos_response_rc_ba");
+    return FL_OK;
+}
+
 // ---------------------------------------------------------------- host: geometry
 struct LanesPlan {
     int ok;
@@ -496,8 +703,7 @@ struct LanesPlan {
     size_t lds1;      // one set of tile buffers (the kernel takes two)
 };
 
-static int g_lanes = 1;        // 0: the first-generation kernels everywhere (test hook)
-static int g_lanes_bpc = 1;    // resident workgroups per CU the grid is sized for
+static int g_lanes_bpc = 0;    // resident workgroups per CU the grid is sized for (0: as many as 12 wavefronts per CU allow)
 static int g_lanes_tb = 0;     // > 0: forced tile length
 static long long* g_lanes_stamps = nullptr;
 static int g_lanes_skip = 0;
@@ -552,8 +758,8 @@ static LanesPlan lanes_plan(int m_local, int C, int S, int nfft, int bin0, int p
     const int per_elem = mode == 0 ? P.rows : P.rows * (ppr / jpt);
     const int tb_max = (mode == 0 ? 4 * P.threads : P.threads) / per_elem;
     if (tb_max < 8) return P;
-    int bpc = g_lanes_bpc > 0 ? g_lanes_bpc : 1;
-    if (bpc * nw > 12) bpc = 12 / nw;      // (the kernel is built for three wavefronts per SIMD)
+    int bpc = g_lanes_bpc > 0 ? g_lanes_bpc : 12 / nw;      // (the kernel is built for three wavefronts per SIMD: 12 per CU)
+    if (bpc * nw > 12) bpc = 12 / nw;
     if (bpc < 1) bpc = 1;
     const int slots = lanes_cus() * bpc;
     int nbx_target = slots / P.ng;
@@ -619,7 +825,10 @@ using namespace fl;
 extern "C" {
 int fl_debug_set_cascade_lanes(int on, int blocks_per_cu, int tile_bins) {
     const int prev = g_lanes;
-    if (on >= 0) g_lanes = on;
+    if (on >= 0) {
+        g_lanes = on & 1;
+        g_lanes_fwd = (on & 1) && !(on & 2);      // (on = 3: second-generation backward, first-generation forward)
+    }
     if (blocks_per_cu >= 0) g_lanes_bpc = blocks_per_cu;
     if (tile_bins >= 0) g_lanes_tb = tile_bins;
     return prev;
@@ -692,10 +901,11 @@ int fl_geq_sections_bwd_lanes(const void* gain, int in_kind, const void* psum, c
     FL_REQUIRE(gain && psum && pq && b && a && consts && ggain, "geq_sections_bwd_lanes: null pointer");
     FL_REQUIRE(in_kind >= 0 && in_kind <= 4 && nb >= 4 && C > 0 && nbx > 0, "geq_sections_bwd_lanes: bad sizes");
     FL_REQUIRE(wn == 0 || (partW && gW && wrows > 0), "geq_sections_bwd_lanes: bad constant-factor partials");
-    const int main_blocks = cdiv_i((long)nb * C, 32);
-    hipLaunchKernelGGL(geq_bwd_lanes_kernel, dim3(main_blocks + cdiv_i(wn, 16)), dim3(1024), 0, (hipStream_t)stream, gain, in_kind,
+    const int epb = nbx > 512 ? 1 : nbx > 256 ? 2 : 4;      // entries per workgroup: 4 / 2 / 1 wavefronts per entry
+    const int main_blocks = cdiv_i((long)nb * C, epb);
+    hipLaunchKernelGGL(geq_bwd_lanes_kernel, dim3(main_blocks + cdiv_i(wn, 4)), dim3(256), 0, (hipStream_t)stream, gain, in_kind,
                        (const float*)psum, (const float*)pq, nbx, (const double*)b, (const double*)a, gamma, nb, C,
-                       (const double*)consts, ggain, main_blocks, (const float*)partW, wrows, wn, (float*)gW);
+                       (const double*)consts, ggain, main_blocks, epb, (const float*)partW, wrows, wn, (float*)gW);
     FL_CHECK_LAUNCH("geq_sections_bwd_lanes");
     return FL_OK;
 }

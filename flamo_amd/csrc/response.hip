@@ -1287,6 +1287,12 @@ static int rc_impl(const void* b, const void* a, int S, int No, int Nmid, int Ni
     // the float kernel's threads take bin PAIRS: half the elements (+ the Nyquist element as a pair of its own in row-major order)
     const int npairs = bin0 >= 0 ? cdiv_i(m_local, 2) : (((nfft / 2 / (-bin0)) + 1) / 2) * (-bin0) + 1;
     const dim3 grid_fast(cdiv_i(npairs, 256), No);
+    if constexpr (sizeof(T) == 4) {
+        if (g_rc_fast && float_eval) {      // second generation (cascade2.hip); shapes it does not take fall through
+            const int rc2 = rc_ba_launch(b, a, S, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, G, g_pitch, H, h_pitch, stream, gd);
+            if (rc2 != FL_ERR_UNSUPPORTED) return rc2;
+        }
+    }
 #define FL_RC_FWD(NIW_)                                                                                                      \
     if constexpr (sizeof(T) == 4) if (Ni == NIW_ && g_rc_fast && float_eval) {                                                                             \
         if (g_rc_fast == 2)                                                                                                  \

@@ -186,4 +186,8 @@ struct GeqDesign {
 };
 
 
+// csrc/cascade2.hip: the Matrix-then-cascade forward with (numerator, denominator) in the packed halves
+int rc_ba_launch(const void* b, const void* a, int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd,
+                 int nfft, int bin0, int m_local, void* G, long g_pitch, void* H, long h_pitch, void* stream, GeqDesign gd);
+
 }  // namespace fl

@@ -2071,11 +2071,11 @@ def _geq_backward_lanes(mode, gH, G, b, a, Wr, cfg, No, Nmid, Ni, nbx, xc, const
     dev = b.device
     g = _h_planar(gH.resolve_conj(), True)
     L = _lib.lib()
-    psum = torch.empty((nbx, 4, S * C_), dtype=torch.float32, device=dev)      # every entry is written
-    pq = torch.empty((nbx, C_), dtype=torch.float32, device=dev)
+    psum = torch.empty((S * C_, nbx, 4), dtype=torch.float32, device=dev)      # (band 0's entries stay unwritten and unread: closed form from pq)
+    pq = torch.empty((C_, nbx), dtype=torch.float32, device=dev)
     # per workgroup (bin block x pair group) ONE (Nmid, Ni) matrix, summed over the group's output channels already
     wrows = L.fl_geq_bwd_lanes_wrows(m_local, C_, S, nfft, bin0, Nmid, Ni) if mode == 1 else 0
-    partW = torch.empty((wrows, Nmid * Ni), dtype=torch.float32, device=dev) if mode == 1 else None
+    partW = torch.empty((Nmid * Ni, wrows), dtype=torch.float32, device=dev) if mode == 1 else None
     Wc = Wr.contiguous() if mode == 1 else None
     with kernel_timer.span("sos_response_bwd_rc" if mode == 1 else "sos_response_bwd"):
         _lib.check(L.fl_geq_response_bwd_lanes_c64(mode, g.data_ptr(), _lead_pitch(g.movedim(0, -1)), G.data_ptr(), _pitch(m_local),

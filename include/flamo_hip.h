@@ -432,13 +432,13 @@ int fl_geq_sections_bwd_w64(const void* gain, int in_kind, const void* gb, const
  * for GEQ / parallelGEQ sections (dsp.py:2563-2593, eq.py:57-111) under the einsum dsp.py:922-924, with the composition
  * backward of Series(Matrix, GEQ) (system.py:299-300, dsp.py:466-468) folded in as fl_sos_response_bwd_rc_c64 does.
  *   mode 0: gH = dL/dG, planes c (No * Nmid channel pairs; Ni, Wr, partW unused);
- *   mode 1: gH = dL/dH of H = G W, planes (m * Ni + n); Wr float (Nmid, Ni); partW float (fl_geq_bwd_lanes_wrows(...),
- *           Nmid * Ni) out (per-workgroup partials of sum_m Re(conj(G[m][j]) dL/dH[m][n]), a v_mfma_f32_16x16x4_f32
+ *   mode 1: gH = dL/dH of H = G W, planes (m * Ni + n); Wr float (Nmid, Ni); partW float (Nmid * Ni,
+ *           fl_geq_bwd_lanes_wrows(...)) out (per-workgroup partials of sum_m Re(conj(G[m][j]) dL/dH[m][n]), a v_mfma_f32_16x16x4_f32
  *           contraction over the bins).
  * G: the saved response (planes c); b, a: the designed taps, double (3, S, No * Nmid).
- * Outputs: psum float (nbx, 4, S * No * Nmid) -- per block, section and pair the sums of Re(q / B~), Re(q / A~),
+ * Outputs: psum float (S * No * Nmid, nbx, 4) -- per section, pair and block the sums of Re(q / B~), Re(q / A~),
  * sin Im(q / B~), sin Im(q / A~) (q = conj(dL/dG) G, B~ / A~ the section polynomials turned by half a sample) -- and
- * pq float (nbx, No * Nmid), the sums of Re(q); nbx = fl_geq_bwd_lanes_blocks(...) (0: shape not taken, use the
+ * pq float (No * Nmid, nbx), the sums of Re(q); nbx = fl_geq_bwd_lanes_blocks(...) (0: shape not taken, use the
  * first-generation entry points).  fl_geq_sections_bwd_lanes reduces them, recovers the third sum from
  * sum Re(q) = (S + T) G0 - S G1 - D G2, forms the tap gradients and runs the design's backward (as fl_geq_sections_bwd_w). */
 int fl_geq_bwd_lanes_blocks(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw, int mode);

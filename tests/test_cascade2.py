@@ -54,8 +54,10 @@ def test_lanes_backward_rc_matches_first_generation(gpu, nfft, N, db, row_major)
         H0, gx0, gW0 = _grads_rc(geq, W, nfft, row_major, 3)
     finally:
         _lanes(prev)
-    _, gxd, gWd = _grads_rc(geq, W, nfft, row_major, 3, f64=True)
-    assert torch.equal(H1, H0)
+    Hd, gxd, gWd = _grads_rc(geq, W, nfft, row_major, 3, f64=True)
+    # (the second-generation forward evaluates the same cascade with numerator and denominator packed: same float accuracy)
+    check_close(f"lanes_rc/{nfft}_{N}_{int(db)}_{int(row_major)}/H", H1, Hd, 1e-6)
+    check_close(f"lanes_rc/{nfft}_{N}_{int(db)}_{int(row_major)}/H_gen1", H0, Hd, 1e-6)
     tag = f"lanes_rc/{nfft}_{N}_{int(db)}_{int(row_major)}"
     e1, e0 = relerr(gx1, gxd), relerr(gx0, gxd)
     print(f"\n{tag}: gain gradient vs complex128: lanes {e1:.2e}, first generation {e0:.2e}; dW {relerr(gW1, gWd):.2e} / {relerr(gW0, gWd):.2e}")

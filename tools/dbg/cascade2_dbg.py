@@ -45,6 +45,36 @@ def timed(fn, reps=50):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
+# forward: second generation against the first
+def fwd():
+    with ops.row_major_bins(nfft):
+        return ops._cascade_rc_forward(b, a, W, geq._gamma_f, nfft, torch.float32, True, geq=(xc, ops._geq_in_kind(xc, True, False), consts))
+res = {}
+for on in (3, 1):
+    L.fl_debug_set_cascade_lanes(on, -1, -1)
+    Hq, Gq, _ = fwd()
+    res[on] = (Hq.clone(), Gq[..., :m_local].clone(), timed(lambda: fwd()))
+L.fl_debug_set_rc_fast(0)
+Hd, Gd, _ = fwd()
+L.fl_debug_set_rc_fast(6)
+rel = lambda x, y: ((x - y).norm() / y.norm()).item()
+print(f"forward: first generation {res[3][2]:.1f} us, second {res[1][2]:.1f} us (eager call: host time included); second vs first: H {rel(res[1][0], res[3][0]):.2e} G {rel(res[1][1], res[3][1]):.2e};"
+      f" vs the double evaluation: second H {rel(res[1][0], Hd):.2e} G {rel(res[1][1], Gd[..., :m_local]):.2e}, first H {rel(res[3][0], Hd):.2e} G {rel(res[3][1], Gd[..., :m_local]):.2e}")
+Gp2 = ops._empty_rows((N, N), m_local, torch.complex64, dev)
+Hp2 = ops._empty_rows((N, N), m_local, torch.complex64, dev)
+def fwd_c(on):
+    L.fl_debug_set_cascade_lanes(on, -1, -1)
+    return lambda: _lib.check(L.fl_geq_response_rc_c64(xc.data_ptr(), ops._geq_in_kind(xc, True, False), S, consts.data_ptr(), b.data_ptr(), a.data_ptr(), N, N, N, W.data_ptr(), gamma,
+                                                       Wd.data_ptr(), nfft, bin0, m_local, Gp2.data_ptr(), P, Hp2.data_ptr(), P, 1, st), "f")
+Wd = ops.twiddles(nfft, torch.float64, dev)
+P = ops._pitch(m_local)
+st = ops._stream()
+gamma = float(geq._gamma_f)
+for on in (3, 1):
+    f = fwd_c(on)
+    print(f"forward through the C ABI, lanes={on}: {timed(f):.1f} us")
+L.fl_debug_set_cascade_lanes(1, -1, -1)
+
 # first generation
 nblk = L.fl_sos_bwd_blocks(m_local, C, S, 1)
 part = torch.empty((nblk, 2, 3, S, C), dtype=torch.float64, device=dev)
@@ -81,10 +111,10 @@ for bpc, tb in ((1, 0), (1, 20), (1, 12), (1, 10)):
     nbx = L.fl_geq_bwd_lanes_blocks(m_local, C, S, nfft, bin0, N, N, 1)
     if nbx == 0:
         continue
-    psum = torch.empty((nbx, 4, S * C), dtype=torch.float32, device=dev)
-    pq = torch.empty((nbx, C), dtype=torch.float32, device=dev)
+    psum = torch.zeros((S * C, nbx, 4), dtype=torch.float32, device=dev)
+    pq = torch.empty((C, nbx), dtype=torch.float32, device=dev)
     wrows = L.fl_geq_bwd_lanes_wrows(m_local, C, S, nfft, bin0, N, N)
-    pW = torch.empty((wrows, N * N), dtype=torch.float32, device=dev)
+    pW = torch.empty((N * N, wrows), dtype=torch.float32, device=dev)
     f2 = lambda: _lib.check(L.fl_geq_response_bwd_lanes_c64(1, gH.data_ptr(), P, G.data_ptr(), P, b.data_ptr(), a.data_ptr(), S, N, N, N, W.data_ptr(), gamma,
                                                             Wd.data_ptr(), nfft, bin0, m_local, psum.data_ptr(), pq.data_ptr(), pW.data_ptr(), st), "g2")
     out2 = torch.empty_like(xc)
@@ -108,8 +138,8 @@ for bpc, tb in ((1, 0), (1, 20), (1, 12), (1, 10)):
     print(f"without the section phase {t_no2:.1f} us, without both {t_no12:.1f} us")
     print(f"lanes bpc {bpc} tile {tb:2d} blocks {nbx:4d}: cascade backward {t2:.1f} us, reduce + design {t2d:.1f} us;  gain grad vs gen1 {((out2 - g1).norm() / g1.norm()).item():.2e}  W {((gW2 - gW).norm() / gW.norm()).item():.2e}")
 # tap gradients from the lanes sums (float64 on the host side)
-ps = psum.double().sum(0).view(4, S, C)
-Q = pq.double().sum(0)
+ps = psum.double().sum(1).view(S, C, 4).permute(2, 0, 1)
+Q = pq.double().sum(-1)
 bb, aa = b.view(3, S, C), a.view(3, S, C)
 tot2 = torch.zeros_like(tot1).view(2, 3, S, C)
 for i, (co, sgn) in enumerate(((bb, 1.0), (aa, -1.0))):
