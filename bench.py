@@ -793,6 +793,17 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["input_grad"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             try:
+                # the same step under the objectives a drop-in user writes: the literal (y ** 2).mean() through torch's own
+                # kernels and autograd, and the reference's training criterion (loss.py:66-103) against a random target
+                out["objectives"] = objective_legs(model, params, x, args.steps, products_per_step // world)
+                if world == 1:
+                    out["value_generic_objective"] = out["objectives"]["torch_literal"]["products_per_s"]
+                    out["ms_per_step_generic_objective"] = out["objectives"]["torch_literal"]["ms_per_step"]
+                    out["value_mse_objective"] = out["objectives"]["mse_loss"]["products_per_s"]
+                    out["ms_per_step_mse_objective"] = out["objectives"]["mse_loss"]["ms_per_step"]
+            except Exception as e:  # noqa: BLE001
+                out["objectives"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:
                 out["variants"] = config2_variants(dev, x, args.steps)
             except Exception as e:  # noqa: BLE001
                 out["variants"] = {"error": f"{type(e).__name__}: {e}"[:300]}
@@ -826,6 +837,40 @@ def main():
         except Exception:       # noqa: BLE001
             pass
         print(line, flush=True)
+
+
+def objective_legs(model, params, x, steps, products):
+    """configs[1] under other objectives than the fused ops.mean_square: (i) the literal `(y ** 2).mean()` evaluated and
+    differentiated by torch (what a user's unedited script does: the pipeline's y is materialised, torch's pow / mean and their
+    backward run, g_y is a tensor); (ii) flamo_amd.optimize.mse_loss -- the reference's criterion, flamo/optimize/loss.py:66-103
+    as called by trainer.py:179-189 -- against a random target (ops.mse: one streaming pass each way); (iii) nn.MSELoss on
+    equal shapes through ops.mse (examples/e7_biquad.py:82)."""
+    from flamo_amd import ops
+    from flamo_amd.graph import GraphedStep
+    from flamo_amd.optimize import mse_loss
+    saved = [p.grad for p in params]
+    crit = mse_loss(nfft=NFFT, device=str(x.device))
+    g = torch.Generator(device=x.device).manual_seed(7)
+    t_sum = torch.randn(x.shape[0], NFFT, generator=g, device=x.device, dtype=x.dtype)
+    t_full = torch.randn(x.shape[0], NFFT, NCH, generator=g, device=x.device, dtype=x.dtype)
+    legs = {"torch_literal": lambda xx: (model(xx) ** 2).mean(),
+            "mse_loss": lambda xx: crit(model(xx), t_sum),
+            "mse_equal_shapes": lambda xx: ops.mse(model(xx), t_full)}
+    res = {}
+    for name, fn in legs.items():
+        gs = GraphedStep(fn, (x,), params, warmup=2)
+        settle_device(gs.replay, max_steps=100)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gs.replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        res[name] = {"ms_per_step": round(ms, 4), "products_per_s": products / (ms * 1e-3)}
+        del gs
+    for p, gsv in zip(params, saved):
+        p.grad = gsv
+    return res
 
 
 def input_grad_leg(model, params, x, steps, products):

@@ -141,6 +141,10 @@ _SIGNATURES = {
     "fl_mean_square_f64": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp]),
     "fl_mean_square_bwd_f32": (_i, [_vp, _vp, _vp, _l, _l, _l, _vp]),
     "fl_mean_square_bwd_f64": (_i, [_vp, _vp, _vp, _l, _l, _l, _vp]),
+    "fl_mse_f32": (_i, [_vp, _vp, _l, _i, _vp, _vp, _vp]),
+    "fl_mse_f64": (_i, [_vp, _vp, _l, _i, _vp, _vp, _vp]),
+    "fl_mse_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _vp]),
+    "fl_mse_bwd_f64": (_i, [_vp, _vp, _vp, _vp, _l, _i, _vp]),
     "fl_matrix_exp_stash_elems": (_sz, [_i]),
     "fl_matrix_exp_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "fl_matrix_exp_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),

@@ -172,6 +172,123 @@ static int mean_square_bwd_impl(const void* y, const void* gloss, void* gy, long
     return FL_OK;
 }
 
+// ---------------------------------------------------------------- mean squared error against a target
+// loss = mean_r (sum_{c < ncols} y[r][c] - t[r])^2 over `rows` rows of `ncols` contiguous values: ncols = 1 is
+// nn.MSELoss()(y, t) on equal shapes (examples/e7_biquad.py:82), ncols = N_out the reference's criterion
+// flamo/optimize/loss.py:66-103 (`mse_loss.forward`: the prediction summed over its last axis, then nn.MSELoss against the
+// squeezed target) -- one streaming pass each way (forward reads y and t; backward reads both and writes
+// g_y[r][c] = (2 g / rows) (sum_c y[r][c] - t[r])) instead of torch's sum / sub / pow / mean and their four backward kernels.
+template <typename T, int NC>
+__global__ void __launch_bounds__(256) mse_kernel(const T* __restrict__ y, const T* __restrict__ t, long rows, int ncols,
+                                                  double* __restrict__ partial) {
+    double acc = 0.0;
+    const long stride = (long)gridDim.x * 256;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += stride) {
+        T s = (T)0;
+        if constexpr (NC == 1) {
+            s = y[r];
+        } else if constexpr (NC == 4 || NC == 8 || NC == 16) {
+#pragma unroll
+            for (int q = 0; q < NC / 4; ++q) {
+                const Vec4<T> v = *reinterpret_cast<const Vec4<T>*>(y + r * NC + 4 * q);
+                s += (v.v[0] + v.v[1]) + (v.v[2] + v.v[3]);
+            }
+        } else {
+            for (int c = 0; c < ncols; ++c) s += y[r * ncols + c];
+        }
+        const T d = s - t[r];
+        acc += (double)(d * d);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+template <typename T, int NC>
+__global__ void __launch_bounds__(256) mse_bwd_kernel(const T* __restrict__ y, const T* __restrict__ t, const T* __restrict__ gloss,
+                                                      double two_inv_rows, T* __restrict__ gy, long rows, int ncols) {
+    const T k = (T)(two_inv_rows * (double)gloss[0]);
+    const long stride = (long)gridDim.x * 256;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += stride) {
+        T s = (T)0;
+        if constexpr (NC == 1) {
+            s = y[r];
+        } else if constexpr (NC == 4 || NC == 8 || NC == 16) {
+#pragma unroll
+            for (int q = 0; q < NC / 4; ++q) {
+                const Vec4<T> v = *reinterpret_cast<const Vec4<T>*>(y + r * NC + 4 * q);
+                s += (v.v[0] + v.v[1]) + (v.v[2] + v.v[3]);
+            }
+        } else {
+            for (int c = 0; c < ncols; ++c) s += y[r * ncols + c];
+        }
+        const T d = k * (s - t[r]);
+        if constexpr (NC == 1) {
+            gy[r] = d;
+        } else if constexpr (NC == 4 || NC == 8 || NC == 16) {
+            Vec4<T> o;
+            o.v[0] = o.v[1] = o.v[2] = o.v[3] = d;
+#pragma unroll
+            for (int q = 0; q < NC / 4; ++q) *reinterpret_cast<Vec4<T>*>(gy + r * NC + 4 * q) = o;
+        } else {
+            for (int c = 0; c < ncols; ++c) gy[r * ncols + c] = d;
+        }
+    }
+}
+
+static int mse_blocks(long rows) {
+    long g = (rows + 255) / 256;
+    if (g > 2048) g = 2048;
+    return (int)(g < 1 ? 1 : g);
+}
+
+template <typename T>
+static int mse_impl(const void* y, const void* t, long rows, int ncols, void* loss, void* scratch, void* stream) {
+    FL_REQUIRE(y && t && loss && scratch, "mse: null pointer");
+    FL_REQUIRE(rows > 0 && ncols > 0 && ncols <= 4096, "mse: bad sizes");
+    const int nblk = mse_blocks(rows);
+    double* partial = reinterpret_cast<double*>(scratch);
+    const bool al = (reinterpret_cast<uintptr_t>(y) % (4 * sizeof(T))) == 0;
+#define FL_MSE(NC_)                                                                                                           \
+    hipLaunchKernelGGL((mse_kernel<T, NC_>), dim3(nblk), dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)t, rows, ncols, partial)
+    if (ncols == 1) FL_MSE(1);
+    else if (ncols == 4 && al) FL_MSE(4);
+    else if (ncols == 8 && al) FL_MSE(8);
+    else if (ncols == 16 && al) FL_MSE(16);
+    else FL_MSE(0);
+#undef FL_MSE
+    FL_CHECK_LAUNCH("mse");
+    hipLaunchKernelGGL((mean_square_final_kernel<T>), dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)partial, nblk,
+                       1.0 / (double)rows, (T*)loss);
+    FL_CHECK_LAUNCH("mse_final");
+    return FL_OK;
+}
+
+template <typename T>
+static int mse_bwd_impl(const void* y, const void* t, const void* gloss, void* gy, long rows, int ncols, void* stream) {
+    FL_REQUIRE(y && t && gloss && gy, "mse_bwd: null pointer");
+    FL_REQUIRE(rows > 0 && ncols > 0 && ncols <= 4096, "mse_bwd: bad sizes");
+    long g = (rows + 1023) / 1024;      // four rows per lane
+    if (g < 1) g = 1;
+    if (g > 65535) g = 65535;
+    const bool al = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gy)) % (4 * sizeof(T))) == 0;
+#define FL_MSEB(NC_)                                                                                                          \
+    hipLaunchKernelGGL((mse_bwd_kernel<T, NC_>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const T*)y, (const T*)t,  \
+                       (const T*)gloss, 2.0 / (double)rows, (T*)gy, rows, ncols)
+    if (ncols == 1) FL_MSEB(1);
+    else if (ncols == 4 && al) FL_MSEB(4);
+    else if (ncols == 8 && al) FL_MSEB(8);
+    else if (ncols == 16 && al) FL_MSEB(16);
+    else FL_MSEB(0);
+#undef FL_MSEB
+    FL_CHECK_LAUNCH("mse_bwd");
+    return FL_OK;
+}
+
 // ---------------------------------------------------------------- gradient buckets of a replayed step
 // The parameter gradients of a captured training step, packed into ONE of two flat buffers -- alternately, chosen ON THE
 // DEVICE from a counter the kernel itself advances, so that the packing is a node of the captured graph like any other
@@ -226,6 +343,18 @@ int fl_mean_square_final_f64(const void* parts, int n_parts, double inv_count, v
     hipLaunchKernelGGL((mean_square_final_kernel<double>), dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)parts, n_parts, inv_count, (double*)loss);
     FL_CHECK_LAUNCH("mean_square_final");
     return FL_OK;
+}
+int fl_mse_f32(const void* y, const void* t, long rows, int ncols, void* loss, void* scratch, void* stream) {
+    return mse_impl<float>(y, t, rows, ncols, loss, scratch, stream);
+}
+int fl_mse_f64(const void* y, const void* t, long rows, int ncols, void* loss, void* scratch, void* stream) {
+    return mse_impl<double>(y, t, rows, ncols, loss, scratch, stream);
+}
+int fl_mse_bwd_f32(const void* y, const void* t, const void* gloss, void* gy, long rows, int ncols, void* stream) {
+    return mse_bwd_impl<float>(y, t, gloss, gy, rows, ncols, stream);
+}
+int fl_mse_bwd_f64(const void* y, const void* t, const void* gloss, void* gy, long rows, int ncols, void* stream) {
+    return mse_bwd_impl<double>(y, t, gloss, gy, rows, ncols, stream);
 }
 int fl_pack_toggle(const void* table, int count, void* flat0, void* flat1, void* state, void* stream) {
     FL_REQUIRE(table && flat0 && flat1 && state && count > 0 && count <= 65535, "pack_toggle: bad arguments");

@@ -175,6 +175,7 @@ class BucketReducer:
             raise ValueError("BucketReducer: the step was not captured with grad_buckets=True")
         self.step, self.group = step, group
         self._work = [None, None]
+        self._replays_seen = step.replays
 
     def _finish(self, b):
         w, self._work[b] = self._work[b], None
@@ -182,9 +183,14 @@ class BucketReducer:
             w.wait()
 
     def replay(self, *inputs) -> torch.Tensor:
+        if self.step.replays != self._replays_seen:
+            raise RuntimeError("BucketReducer: the step was replayed outside the reducer (its device-side bucket counter and the "
+                               "reducer's bookkeeping no longer agree, a collective may still own the bucket that replay filled); "
+                               "replay through the reducer only")
         nxt = self.step.replays & 1                  # the bucket this replay fills
         self._finish(nxt)
         loss = self.step(*inputs) if inputs else self.step.replay()
+        self._replays_seen = self.step.replays
         flat = self.step.buckets[nxt]
         if _host_staged(flat, self.group):
             host = flat.cpu()
@@ -219,6 +225,9 @@ def all_reduce_grads(params: Iterable[torch.nn.Parameter], group=None, async_op:
     at once, so the next backward pass (or graph replay) may start while the collective is still in flight: the next call on
     the same parameters orders its refill of the buffer behind the previous collective on the stream (no host wait, no
     warning)."""
+    if in_buffer and not async_op:
+        raise ValueError("all_reduce_grads: in_buffer leaves the sums in the flat buffer, reachable only through the handle that "
+                         "async_op=True returns; a synchronous call would leave every rank's .grad with its local values")
     ps = [p for p in params if p.grad is not None]
     if not ps:
         return (lambda: None) if async_op else None

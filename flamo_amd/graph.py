@@ -13,7 +13,7 @@ come from PyTorch's graph-private pool, so capture needs nothing special from th
     step.grads                    # the parameters' .grad tensors are updated in place by the replay
 
 Data-parallel training: ``GraphedStep(..., grad_buckets=True)`` also packs the gradients, inside the captured graph, into
-one of two flat buffers that alternate from replay to replay (``csrc/reduce.hip: fl_pack_toggle``); ``dist.all_reduce_bucket``
+one of two flat buffers that alternate from replay to replay (``csrc/reduce.hip: fl_pack_toggle``); ``dist.BucketReducer``
 sums the bucket of the last replay over the ranks while the next replay already fills the other one.
 """
 from __future__ import annotations

@@ -687,8 +687,8 @@ def rfft(x: torch.Tensor, nfft: int, norm: str = "backward", alias_decay_db: Opt
     if norm not in _NORM_FWD:
         raise ValueError(f"Invalid normalization mode: {norm}")
     env = 0.0 if not alias_decay_db else env_log2_of(alias_decay_db, nfft)
+    _require_gpu(x)      # (before the plan query: that one loads the library)
     if not fft_plan_ok(int(nfft), _rdtype(x)):
-        _require_gpu(x)
         if x.is_complex():
             raise TypeError("rfft expects a real tensor")
         return _rfft_chirp(x, int(nfft), _NORM_FWD[norm](nfft), env)
@@ -700,8 +700,8 @@ def irfft(X: torch.Tensor, nfft: int, norm: str = "backward", alias_decay_db: Op
     if norm not in _NORM_INV:
         raise ValueError(f"Invalid normalization mode: {norm}")
     env = 0.0 if not alias_decay_db else env_log2_of(alias_decay_db, nfft)
+    _require_gpu(X)
     if not fft_plan_ok(int(nfft), _rdtype(X)):
-        _require_gpu(X)
         if not X.is_complex():
             raise TypeError("irfft expects a complex tensor")
         return _irfft_chirp(X.resolve_conj(), int(nfft), _NORM_INV[norm](nfft), env)
@@ -2258,13 +2258,77 @@ class _MeanSquare(torch.autograd.Function):
         return gy
 
 
+def _is_pipeline_output(y: torch.Tensor) -> bool:
+    """y still IS what _SpectralApply returned to autograd: its grad_fn is that node (a y produced under no_grad has none),
+    no tensor hook, no retain_grad -- otherwise the fused objective would bypass something the caller can observe"""
+    fn = y.grad_fn
+    if fn is None or type(fn).__name__ != "_SpectralApplyBackward":
+        return False
+    if getattr(y, "retains_grad", False) or getattr(y, "_backward_hooks", None):
+        return False
+    return True
+
+
+class _MSE(torch.autograd.Function):
+    """mean((sum_c y[..., c] - t) ** 2) (ncols = 1: plain nn.MSELoss) in one streaming pass each way"""
+
+    @staticmethod
+    def forward(ctx, y, t, ncols):
+        dev = _require_gpu(y, t)
+        yc, tc = y.contiguous(), t.contiguous()
+        rows = yc.numel() // ncols
+        loss = torch.empty((), dtype=y.dtype, device=dev)
+        L = _lib.lib()
+        fn = L.fl_mse_f32 if y.dtype == torch.float32 else L.fl_mse_f64
+        with kernel_timer.span("mse"):
+            _lib.check(fn(yc.data_ptr(), tc.data_ptr(), rows, ncols, loss.data_ptr(), _ms_scratch_for(dev).data_ptr(), _stream()), "mse")
+        ctx.save_for_backward(yc, tc)
+        ctx.cfg = (rows, ncols, tuple(y.shape))
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        yc, tc = ctx.saved_tensors
+        rows, ncols, shape = ctx.cfg
+        gy = torch.empty_like(yc)
+        g = gloss.to(yc.dtype).contiguous()
+        L = _lib.lib()
+        fn = L.fl_mse_bwd_f32 if yc.dtype == torch.float32 else L.fl_mse_bwd_f64
+        with kernel_timer.span("mse_bwd"):
+            _lib.check(fn(yc.data_ptr(), tc.data_ptr(), g.data_ptr(), gy.data_ptr(), rows, ncols, _stream()), "mse_bwd")
+        return gy.view(shape), None, None
+
+
+def mse(y: torch.Tensor, target: torch.Tensor, sum_last: bool = False) -> torch.Tensor:
+    """nn.MSELoss()(y, target) (examples/e7_biquad.py:82) -- or, with sum_last, the reference's criterion
+    flamo/optimize/loss.py:101-102: nn.MSELoss()(y.sum(-1), target.squeeze(-1)) -- as one streaming pass each way.
+    The target takes no gradient (a constant of the data set, trainer.py:172-175)."""
+    if y.dtype not in (torch.float32, torch.float64) or not y.is_cuda:
+        raise TypeError("mse expects a real float32 / float64 tensor on the GPU")
+    if y.numel() == 0:
+        raise ValueError("mse of an empty tensor")
+    t = target.detach()
+    ncols = 1
+    if sum_last:
+        ncols = y.shape[-1]
+        if t.dim() == y.dim() and t.shape[-1] == 1:
+            t = t.squeeze(-1)
+        if tuple(t.shape) != tuple(y.shape[:-1]):
+            raise ValueError(f"mse: the target must be {tuple(y.shape[:-1])} (or with a trailing 1), got {tuple(target.shape)}")
+    elif tuple(t.shape) != tuple(y.shape):
+        raise ValueError(f"mse: prediction {tuple(y.shape)} and target {tuple(target.shape)} differ in shape")
+    return _MSE.apply(y, t.to(dtype=y.dtype, device=y.device), int(ncols))
+
+
 def mean_square(y: torch.Tensor) -> torch.Tensor:
     """(y ** 2).mean() of a real tensor in one streaming pass each way (forward: one read of y;
     backward: one read + one write), in whatever layout y is stored."""
     tag = getattr(y, "_flamo_sa", None)
     if FUSE_OBJECTIVE and tag is not None and tag.parts is not None and y._version == tag.version:
-        if torch.is_grad_enabled() and (tag.x.requires_grad or tag.Hrm.requires_grad):
-            if tag.Xs is not None or not tag.Hrm.requires_grad:
+        if torch.is_grad_enabled() and y.requires_grad and _is_pipeline_output(y):
+            # y is the pipeline's own differentiable output, nobody has hung a hook on it or asked to keep its gradient:
+            # the one-node form is indistinguishable from (y ** 2).mean() through y's node
+            if (tag.x.requires_grad or tag.Hrm.requires_grad) and (tag.Xs is not None or not tag.Hrm.requires_grad):
                 return _SpectralMeanSquare.apply(tag.x, tag.Hrm, y.detach(), tag)
         elif not (torch.is_grad_enabled() and y.requires_grad):
             # nothing to differentiate (evaluation under no_grad, validation steps): the value alone, from the partial sums

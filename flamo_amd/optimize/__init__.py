@@ -1,0 +1,2 @@
+"""The criteria of flamo.optimize.loss that sit directly on the hot path's output, evaluated by the library's kernels."""
+from .loss import mse_loss  # noqa: F401

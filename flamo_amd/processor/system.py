@@ -364,12 +364,11 @@ class Recursion(nn.Module):
         # the fused loop forms; above that one workgroup per bin factors the materialised matrix in LDS (fl_solve_max_n: 138 /
         # 97).  The reference's torch.linalg.solve has no bound; there is deliberately no torch fallback on this path.
         self._register_loop = self.output_channels <= (32 if self.dtype == torch.float64 else 64)
-        limit = 97 if self.dtype == torch.float64 else 138      # MI355X (160 KB of LDS per workgroup); the library is asked
-        try:                                                    # when it is there: a part with less LDS answers less
-            from .. import _lib
-            limit = int(_lib.lib().fl_solve_max_n(int(self.dtype == torch.float64)))
-        except (OSError, AttributeError, RuntimeError):         # host-logic use without the built extension
-            pass
+        # the static bound of the LDS solve on MI355X (160 KB of LDS per workgroup); what THIS device's library answers
+        # (fl_solve_max_n) is asked at the first forward, on the tensor's device -- not here: constructing a module must not
+        # initialise the HIP runtime (fork-based data loaders), and the device current now need not be the module's
+        limit = 97 if self.dtype == torch.float64 else 138
+        self._solve_limit_checked = set()
         assert self.output_channels <= limit, (
             f"Recursion: {self.output_channels} loop channels exceed the HIP solve kernels' limit of {limit} "
             f"({'float64' if self.dtype == torch.float64 else 'float32'}); see INTEGRATION.md")
@@ -389,8 +388,23 @@ class Recursion(nn.Module):
                     ext_fb = param
                 elif "feedforward" in key:
                     ext_ff = param
+        if torch.is_tensor(X) and X.is_cuda:
+            self.__check_solve_limit(X.device)
         with ops.loop_scope():
             return self.__forward_in_loop(X, ext_param, ext_fb, ext_ff)
+
+    def __check_solve_limit(self, dev):
+        """once per device: the loop's channel count against what the library's solve kernels take THERE"""
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key in self._solve_limit_checked:
+            return
+        from .. import _lib
+        with torch.cuda.device(dev):
+            limit = int(_lib.lib().fl_solve_max_n(int(self.dtype == torch.float64)))
+        if self.output_channels > limit:
+            raise ValueError(f"Recursion: {self.output_channels} loop channels exceed the HIP solve kernels' limit of {limit} on "
+                             f"device {key} ({'float64' if self.dtype == torch.float64 else 'float32'}); see INTEGRATION.md")
+        self._solve_limit_checked.add(key)
 
     def __forward_in_loop(self, X, ext_param, ext_fb, ext_ff):
         # (external parameters -- system.py:409-415 -- take the same fused routes: every helper below hands each module its own entry)

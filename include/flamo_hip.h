@@ -576,6 +576,15 @@ int fl_mean_square_final_f64(const void* parts, int n_parts, double inv_count, v
 int fl_pack_toggle(const void* table, int count, void* flat0, void* flat1, void* state, void* stream);
 int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
 int fl_mean_square_bwd_f64(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
+/* Mean squared error against a target, the criterion the reference's training loops use (flamo/optimize/trainer.py:179-189
+ * calling flamo/optimize/loss.py:66-103 `mse_loss`, or nn.MSELoss directly as examples/e7_biquad.py:82-87):
+ *   loss = (1 / rows) sum_r (sum_{c < ncols} y[r][c] - t[r])^2,   y: (rows, ncols) contiguous, t: (rows).
+ * ncols = 1: nn.MSELoss()(y, t) on equal shapes; ncols = N_out: loss.py:101-102 (the prediction summed over its last axis).
+ * One streaming pass each way: g_y[r][c] = (2 gloss / rows) (sum_c y[r][c] - t[r]).  scratch as fl_mean_square. */
+int fl_mse_f32(const void* y, const void* t, long rows, int ncols, void* loss, void* scratch, void* stream);
+int fl_mse_f64(const void* y, const void* t, long rows, int ncols, void* loss, void* scratch, void* stream);
+int fl_mse_bwd_f32(const void* y, const void* t, const void* gloss, void* gy, long rows, int ncols, void* stream);
+int fl_mse_bwd_f64(const void* y, const void* t, const void* gloss, void* gy, long rows, int ncols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Orthogonal parameter map of dsp.Matrix: E = exp(A), A = X (skew = 0) or

@@ -1,0 +1,115 @@
+"""Objectives on the hot path's output: ops.mse / flamo_amd.optimize.mse_loss against torch's own evaluation of the
+reference's lines (flamo/optimize/loss.py:66-103, examples/e7_biquad.py:82), and the fused ops.mean_square's guards."""
+import pytest
+import torch
+
+from conftest import check_close, relerr
+
+
+def test_mse_loss_module_matches_reference_lines_on_host():
+    """host tensors take the reference's own lines (sum over the last axis, nn.MSELoss against the squeezed target)"""
+    from flamo_amd.optimize import mse_loss
+    torch.manual_seed(0)
+    y = torch.randn(3, 50, 4, dtype=torch.float64, requires_grad=True)
+    t = torch.randn(3, 50, 1, dtype=torch.float64)
+    crit = mse_loss(nfft=50)
+    assert crit.name == "MSE" and crit.nfft == 50 and isinstance(crit.mse_loss, torch.nn.MSELoss)
+    ref = torch.nn.functional.mse_loss(y.sum(-1), t.squeeze(-1))
+    assert torch.equal(crit(y, t), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("shape", [(3, 960, 8), (2, 1500, 4), (1, 777, 3), (2, 512, 16), (5, 100, 1)])
+def test_mse_kernels_against_torch(gpu, dtype, shape):
+    from flamo_amd import ops
+    from flamo_amd.optimize import mse_loss
+    torch.manual_seed(3)
+    y = torch.randn(*shape, device=gpu, dtype=dtype)
+    tol = 2e-6 if dtype == torch.float32 else 1e-13
+    for sum_last in (False, True):
+        t = torch.randn(*(shape[:-1] + ((1,) if sum_last else shape[-1:])), device=gpu, dtype=dtype)
+        y1 = y.clone().requires_grad_(True)
+        y0 = y.double().clone().requires_grad_(True)
+        if sum_last:
+            loss = mse_loss(nfft=shape[1], device="cuda")(y1, t)
+            ref = torch.nn.functional.mse_loss(y0.sum(-1), t.double().squeeze(-1))
+        else:
+            loss = ops.mse(y1, t)
+            ref = torch.nn.functional.mse_loss(y0, t.double())
+        (3.0 * loss).backward()
+        (3.0 * ref).backward()
+        tag = f"mse/{'x'.join(map(str, shape))}_{str(dtype)[-2:]}_{int(sum_last)}"
+        check_close(tag + "/loss", loss.detach().double().reshape(1), ref.detach().reshape(1), tol)
+        check_close(tag + "/grad", y1.grad.double(), y0.grad, tol)
+
+
+@pytest.mark.gpu
+def test_mse_on_the_fused_shell_against_oracle(gpu):
+    """config-2 miniature trained against a target with the reference's criterion: loss and every gradient against the
+    float64 oracle graph under torch's mse_loss"""
+    from collections import OrderedDict
+    from flamo_amd.optimize import mse_loss
+    from flamo_amd.processor import dsp, system
+    from oracle import hotpath as O
+    torch.manual_seed(11)
+    nfft, N, B = 24000, 4, 5
+    kw = dict(nfft=nfft, alias_decay_db=0.0, device=gpu, dtype=torch.float32)
+    mat = dsp.Matrix(size=(N, N), requires_grad=True, **kw)
+    geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+    model = system.Shell(system.Series(OrderedDict(mix=mat, eq=geq)), dsp.FFT(nfft), dsp.iFFT(nfft))
+    x = torch.randn(B, nfft, N, device=gpu)
+    t = torch.randn(B, nfft, 1, device=gpu)
+    loss = mse_loss(nfft=nfft, device="cuda")(model(x), t)
+    loss.backward()
+    W, G = (p.detach().cpu().double().requires_grad_(True) for p in (mat.param, geq.param))
+    yo = O.config2_forward(x.cpu().double(), W, G, nfft)
+    ref = torch.nn.functional.mse_loss(yo.sum(-1), t.cpu().double().squeeze(-1))
+    gW, gG = torch.autograd.grad(ref, [W, G])
+    check_close("mse_shell/loss", loss.detach().cpu().double().reshape(1), ref.detach().reshape(1), 1e-5)
+    check_close("mse_shell/g_W", mat.param.grad.cpu().double(), gW, 1e-5)
+    check_close("mse_shell/g_geq", geq.param.grad.cpu().double(), gG, 1e-4)
+
+
+@pytest.mark.gpu
+def test_fused_mean_square_only_for_the_pipelines_own_output(gpu):
+    """ops.mean_square takes its one-node form only for a y that still is the pipeline's differentiable output: a y produced
+    under no_grad gives a loss without a graph (as (y ** 2).mean() would), a y with a hook or retain_grad differentiates
+    through its own node (the hook fires, y.grad is filled)"""
+    from collections import OrderedDict
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp, system
+    torch.manual_seed(2)
+    nfft, N, B = 24000, 4, 4
+    kw = dict(nfft=nfft, alias_decay_db=0.0, device=gpu, dtype=torch.float32)
+    mat = dsp.Matrix(size=(N, N), requires_grad=True, **kw)
+    geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+    model = system.Shell(system.Series(OrderedDict(mix=mat, eq=geq)), dsp.FFT(nfft), dsp.iFFT(nfft))
+    x = torch.randn(B, nfft, N, device=gpu)
+    with torch.no_grad():
+        y0 = model(x)
+    l0 = ops.mean_square(y0)                     # grad mode is on again here
+    assert not l0.requires_grad and l0.grad_fn is None
+    assert relerr(l0.reshape(1), (y0 ** 2).mean().reshape(1)) < 1e-6
+    # reference gradients: the fused node
+    y = model(x)
+    ops.mean_square(y).backward()
+    gref = [p.grad.clone() for p in (mat.param, geq.param)]
+    for p in (mat.param, geq.param):
+        p.grad = None
+    # a hook and retain_grad on y: both must be honoured
+    y = model(x)
+    seen = []
+    y.register_hook(lambda g: seen.append(g.shape))
+    y.retain_grad()
+    loss = ops.mean_square(y)
+    loss.backward()
+    assert seen and y.grad is not None
+    check_close("ms_guard/y_grad", y.grad, 2.0 * y.detach() / y.numel(), 1e-6)
+    for p, g in zip((mat.param, geq.param), gref):
+        assert relerr(p.grad, g) < 1e-5
+    # torch.autograd.grad with respect to y itself works on the unfused form
+    y = model(x)
+    y.retain_grad()
+    (gy,) = torch.autograd.grad(ops.mean_square(y), y)
+    assert relerr(gy, 2.0 * y.detach() / y.numel()) < 1e-6
