@@ -414,7 +414,7 @@ def bin_sharded(dev, model, params, x, steps):
             step()
         dist.barrier()
         torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return t.item() / n * 1e3
 
@@ -514,11 +514,20 @@ def main():
     if world > 1 and torch.cuda.device_count() < world and os.environ.get("BENCH_ALLOW_SHARED_GPU") != "1":
         sys.exit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()}")
     dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"   # the env hook runs the collective path with one rank
+    # test rigs only (tests/test_dist_rccl.py on a one-GPU box): BENCH_ALLOW_SHARED_GPU=1 puts the ranks on the GPUs there are,
+    # BENCH_BACKEND=gloo carries the collectives through host memory (RCCL refuses two ranks on one device); the line says so
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_ALLOW_SHARED_GPU") == "1":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ctl = dev if backend == "nccl" else torch.device("cpu")      # where the few control scalars of the collectives live
     if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
 
     from flamo_amd import ops
@@ -568,7 +577,7 @@ def main():
             args.no_graph = True
             gs = None
         if dist_on:                 # every rank must time the same kind of step
-            flag = torch.tensor([1 if gs is None else 0], device=dev)
+            flag = torch.tensor([1 if gs is None else 0], device=ctl)
             dist.all_reduce(flag)
             if flag.item() > 0:
                 args.no_graph, gs = True, None
@@ -623,10 +632,10 @@ def main():
     elapsed_steady = time.perf_counter() - t0
     ranks_seen = 1
     if dist_on:                     # max over ranks; before rank 0 goes on alone into the roofline leg
-        t = torch.tensor([elapsed, elapsed_steady], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, elapsed_steady], device=ctl, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, elapsed_steady = t.tolist()
-        ones = torch.ones(1, device=dev)
+        ones = torch.ones(1, device=ctl)
         dist.all_reduce(ones)       # how many ranks RCCL actually carried
         ranks_seen = int(ones.item())
 
@@ -769,6 +778,7 @@ def main():
                "ms_per_step_unsettled": {"ms_per_step": ms_unsettled, "what": "rounds 1-2's method: 3 replays + W warm-ups right "
                                          "behind the capture, then K timed (inside the device's clock ramp); local step, rank 0"},
                "rccl_ranks_seen": ranks_seen if dist_on else None,
+               "collective_backend": ("nccl (RCCL)" if backend == "nccl" else f"{backend} (test rig, host-staged)") if dist_on else None,
                "config": {"workload": "BASELINE configs[1]: Shell(FFT -> Series(Matrix 8x8, GEQ 8x8) -> iFFT), nfft=96000, "
                                       "batch 32 per GPU, fwd+bwd of (y**2).mean(), parameter grads",
                           "nfft": NFFT, "channels": NCH, "batch_per_gpu": BATCH, "parallelism": f"dp{world} (batch)",

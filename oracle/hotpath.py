@@ -236,15 +236,31 @@ def eq_freqs(interval: int = 1, start_freq: float = 31.25, end_freq: float = 160
 
 
 def geq_sos(gain_db: torch.Tensor, center_freq: torch.Tensor, shelving_freq: torch.Tensor,
-            fs: int = 48000, R: float = 2.7):
+            fs: int = 48000, R: float = 2.7, exact: bool = False):
     """auxiliary/eq.py:57-111 (geq) vectorised over trailing dims of ``gain_db``.
 
     gain_db: (n_bands, ...) with n_bands = len(center_freq)+3.  Returns (b, a), each
     (3, n_bands, ...) **float32** -- the reference allocates the SOS buffers without a dtype and
     calls geq() without one (dsp.py:2573-2585), so GEQ coefficients are float32 even in
     float64 mode (SURVEY F8).  Band 0: pure gain; band 1: low shelf; last: high shelf;
-    others: peaking with Q = sqrt(R)/(R-1) (functional.py:555-675)."""
-    f32 = torch.float32
+    others: peaking with Q = sqrt(R)/(R-1) (functional.py:555-675).
+
+    ``exact=True`` is NOT the reference's arithmetic in the backward direction: the forward VALUES are the
+    reference's float32 coefficients bit for bit, but the graph behind them is the same formulas kept in
+    the dtype of ``gain_db`` (straight-through rounding: value = exact + (rounded - exact).detach()).  The
+    reference's own gain gradient passes through the float32 section graph, where the cancelling tap
+    contributions lose ~1e-4; this mode is the yardstick tests/ use to show which of (reference, HIP path)
+    is closer to the gradient of the function the reference evaluates."""
+    if exact:
+        with torch.no_grad():
+            b_ref, a_ref = geq_sos(gain_db.detach(), center_freq, shelving_freq, fs, R, exact=False)
+        b_ex, a_ex = _geq_sos_impl(gain_db, center_freq, shelving_freq, fs, R, True)
+        return b_ex + (b_ref.to(b_ex.dtype) - b_ex).detach(), a_ex + (a_ref.to(a_ex.dtype) - a_ex).detach()
+    return _geq_sos_impl(gain_db, center_freq, shelving_freq, fs, R, False)
+
+
+def _geq_sos_impl(gain_db, center_freq, shelving_freq, fs, R, exact):
+    f32 = gain_db.dtype if exact else torch.float32
     nb = gain_db.shape[0]
     assert nb == len(center_freq) + len(shelving_freq) + 1
     # dtype choreography of the reference: the scalar formulas run in the dtype of the mapped
@@ -253,7 +269,8 @@ def geq_sos(gain_db: torch.Tensor, center_freq: torch.Tensor, shelving_freq: tor
     # float32 coefficient buffers; the later whole-vector scalings (g2*b, a*gain) are float32.
     gd = gain_db.dtype
     g = 10 ** (gain_db / 20)
-    Rt = torch.tensor(R, dtype=f32)
+    c32 = torch.float32                                   # the band constants: float32 in both modes
+    Rt = torch.tensor(R, dtype=c32)
     Q = torch.sqrt(Rt) / (Rt - 1)
     bs, as_ = [], []
     for band in range(nb):
@@ -264,9 +281,9 @@ def geq_sos(gain_db: torch.Tensor, center_freq: torch.Tensor, shelving_freq: tor
             a = torch.stack([one, zero, zero])
         elif band in (1, nb - 1):
             fc = shelving_freq[0] if band == 1 else shelving_freq[1]
-            t32 = torch.tan((fc.to(f32) / fs * 2 * torch.pi) / 2)
+            t32 = torch.tan((fc.to(c32) / fs * 2 * torch.pi) / 2)
             t, t2 = t32.to(gd), (t32 ** 2).to(gd)            # t**2 is rounded in float32 first
-            st = (torch.sqrt(torch.tensor(2.0, dtype=f32)) * t32).to(gd)  # sqrt(2)*t: float32 product
+            st = (torch.sqrt(torch.tensor(2.0, dtype=c32)) * t32).to(gd)  # sqrt(2)*t: float32 product
             g2, g4 = gb ** 0.5, gb ** 0.25
             b = torch.stack([g2 * t2 + st * g4 + 1, 2 * g2 * t2 - 2, g2 * t2 - st * g4 + 1]).to(f32)
             a = torch.stack([g2 + st * g4 + t2, 2 * t2 - 2 * g2, g2 - st * g4 + t2]).to(f32)
@@ -274,7 +291,7 @@ def geq_sos(gain_db: torch.Tensor, center_freq: torch.Tensor, shelving_freq: tor
             if band == nb - 1:
                 b, a = a * gb.to(f32), b
         else:
-            wc = (center_freq[band - 2].to(f32) / fs * 2 * torch.pi)
+            wc = (center_freq[band - 2].to(c32) / fs * 2 * torch.pi)
             t = torch.tan(wc / Q / 2).to(gd)
             c = torch.cos(wc).to(gd)
             sg = torch.sqrt(gb)
@@ -286,13 +303,13 @@ def geq_sos(gain_db: torch.Tensor, center_freq: torch.Tensor, shelving_freq: tor
 
 
 def geq_response(param: torch.Tensor, nfft: int, gamma: torch.Tensor, fs: int = 48000,
-                 octave_interval: int = 1, map_fn=None) -> torch.Tensor:
+                 octave_interval: int = 1, map_fn=None, exact: bool = False) -> torch.Tensor:
     """GEQ / parallelGEQ.get_poly_coeff (dsp.py:2563-2593, 2657-2680): default map
     20*log10|x| (dsp.py:2529), float32 SOS, then the shared SOS tail with the module's gamma.
     NB the reference swaps the local names a/b but the result is numerator/denominator-correct."""
     cf, sc = eq_freqs(octave_interval)
     gain_db = (20 * torch.log10(torch.abs(param))) if map_fn is None else map_fn(param)
-    b, a = geq_sos(gain_db, cf, sc, fs)
+    b, a = geq_sos(gain_db, cf, sc, fs, exact=exact)
     return sos_response(b, a, nfft, gamma)
 
 
@@ -325,7 +342,7 @@ def config2_forward(x, W, geq_param, nfft, alias_decay_db=0.0, fs=48000):
 
 
 def fdn_forward(x, in_gain, out_gain, U_param, delays_s, nfft, alias_decay_db, fs=48000, unit=100,
-                attn_param=None, attn_map=None, output="time"):
+                attn_param=None, attn_map=None, output="time", geq_exact=False):
     """e8_fdn-type FDN (reverb.py:117-199, examples/e8_fdn.py:106-123):
     FFT -> Gain(N,1) -> Recursion(fF=parallelDelay(isint), fB=Matrix(orthogonal)[ -> parallelGEQ])
     -> Gain(1,N) -> iFFTAntiAlias | abs."""
@@ -340,7 +357,7 @@ def fdn_forward(x, in_gain, out_gain, U_param, delays_s, nfft, alias_decay_db, f
     M = nfft // 2 + 1
     Bk = U.unsqueeze(0).expand(M, N, N)
     if attn_param is not None:
-        G = geq_response(attn_param, nfft, gamma, fs, map_fn=attn_map).to(cdtype(dt))  # (M, N)
+        G = geq_response(attn_param, nfft, gamma, fs, map_fn=attn_map, exact=geq_exact).to(cdtype(dt))  # (M, N)
         Bk = G.unsqueeze(-1) * Bk
     F = torch.diag_embed(D)
     Y = recursion(F, Bk, X)
@@ -371,11 +388,11 @@ def sos_response_at(b: torch.Tensor, a: torch.Tensor, nfft: int, gamma: torch.Te
 
 
 def geq_response_at(param: torch.Tensor, nfft: int, gamma: torch.Tensor, bins: torch.Tensor, fs: int = 48000,
-                    octave_interval: int = 1, map_fn=None) -> torch.Tensor:
+                    octave_interval: int = 1, map_fn=None, exact: bool = False) -> torch.Tensor:
     """geq_response (dsp.py:2563-2593) at the bins `bins`."""
     cf, sc = eq_freqs(octave_interval)
     gain_db = (20 * torch.log10(torch.abs(param))) if map_fn is None else map_fn(param)
-    b, a = geq_sos(gain_db, cf, sc, fs)
+    b, a = geq_sos(gain_db, cf, sc, fs, exact=exact)
     return sos_response_at(b, a, nfft, gamma, bins)
 
 

@@ -84,6 +84,29 @@ def check_close(name, got, ref, tol, max_tol=None, k=5.0, floor=2e-7):
     return l2
 
 
+def check_closer(name, ours, theirs, truth, tol, **kw):
+    """`ours` within `tol` of `truth` (check_close, recorded under `name`) AND at least as close to it as `theirs` is: used where the
+    reference's own result carries float32 noise (equaliser-gain gradients, dsp.py:2573-2585) and `truth` is the oracle's
+    float64 backward of the same function (oracle.hotpath.geq_sos(exact=True))."""
+    e_ref = relerr(theirs, truth)
+    e = check_close(name, ours, truth, tol, **kw)
+    print(f"[parity] {name}: the reference-arithmetic result is {e_ref:.3e} from the float64 backward, this path {e:.3e}")
+    assert e <= e_ref, (name, f"{e:.3e} from the float64 backward; the reference's arithmetic is closer ({e_ref:.3e})")
+    return e, e_ref
+
+
+_SEQ = {}
+
+
+def cc(label, got, ref, tol, **kw):
+    """check_close under a name derived from the running test (PYTEST_CURRENT_TEST) and `label`; a label that repeats within
+    one test (loops over sizes / dtypes, in a fixed order) gets #2, #3, ... so that every comparison has its own record."""
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::", 1)[-1]
+    key = f"{test}/{label}"
+    n = _SEQ[key] = _SEQ.get(key, 0) + 1
+    return check_close(key if n == 1 else f"{key}#{n}", got, ref, tol, **kw)
+
+
 def pytest_sessionfinish(session, exitstatus):
     path = os.environ.get("FLAMO_RECORD_ERRORS")
     if path and _RECORDED:

@@ -39,16 +39,22 @@ def _need(world):
         pytest.skip(f"needs {world} GPUs, {_n_gpus()} visible")
 
 
-def _worker(rank, world, port, M, results):
+def _worker(rank, world, port, M, results, backend="nccl"):
+    """backend "nccl": one rank per GPU over RCCL.  backend "gloo": the SAME body with every rank on GPU 0 and the collectives
+    staged through host memory by flamo_amd.dist (RCCL refuses two ranks on one device) -- how a one-GPU box executes it."""
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    local = rank if backend == "nccl" else 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from flamo_amd import dist as fd
-        ones = torch.ones(1, device=dev)
+        ones = torch.ones(1, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(ones)
         ok = int(ones.item()) == world                               # RCCL carries every rank
         torch.manual_seed(0)                                         # the same "replicated" tensors on every rank
@@ -109,6 +115,18 @@ def test_collectives_over_rccl(world, M):
     assert dict(results) == {r: True for r in range(world)}
 
 
+@pytest.mark.parametrize("M", [49, 4801, 3])
+def test_collectives_two_ranks_on_one_device(M):
+    """The body of test_collectives_over_rccl, two ranks sharing GPU 0 over gloo (host-staged): runs on a one-GPU box, so the
+    worker's code has been executed on device tensors before a multi-GPU node meets it."""
+    _need(1)
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    results = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), M, results, "gloo"), nprocs=2, join=True)
+    assert dict(results) == {0: True, 1: True}
+
+
 def _torchrun(world, script, *args, timeout=900, env=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script, *args]
@@ -160,6 +178,25 @@ def test_bench_line_over_rccl(world):
     lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
+    _check_bench_line(d, world)
+    assert d["collective_backend"].startswith("nccl")
+
+
+def _check_bench_line(d, world):
     assert d["n_gpus"] == world and d["scaling"] == "weak" and d["rccl_ranks_seen"] == world
     assert d["config"]["batch_per_gpu"] == 32 and d["value"] > 0
     assert "bin_sharded" in d and "error" not in d["bin_sharded"], d.get("bin_sharded")
+
+
+def test_bench_line_two_ranks_on_one_device():
+    """test_bench_line_over_rccl's launch and checks with two ranks on GPU 0 over gloo (BENCH_ALLOW_SHARED_GPU / BENCH_BACKEND,
+    bench.py's test-rig hooks): the multi-rank branch of bench.py -- gradient all-reduce after every replay, max over ranks,
+    the bin-sharded legs -- executed end to end on a one-GPU box.  The figures of such a line mean nothing (shared device)."""
+    _need(1)
+    out = _torchrun(2, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                    timeout=1200, env={"BENCH_ALLOW_SHARED_GPU": "1", "BENCH_BACKEND": "gloo"}).stdout
+    lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    _check_bench_line(d, 2)
+    assert "gloo" in d["collective_backend"]
