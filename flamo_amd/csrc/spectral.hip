@@ -129,7 +129,10 @@ __global__ void __launch_bounds__(256, sizeof(real_t) == 8 ? 2 : 3) spec_cols_fw
 }
 
 // ---------------------------------------------------------------- K3: inverse column pass
-template <int A, int B, int VT, int RG>
+// PLAIN: no envelope and every sample inside the output (t_lim >= n): the guards are not compiled at all -- left to a
+// run-time flag the compiler evaluates the envelope for every output and selects (25 x (int -> double, double multiply, exp,
+// ldexp, four selects) per item, a third of the kernel's instructions, and 112 registers against 9x).
+template <int A, int B, int VT, int RG, bool PLAIN>
 __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LEN = A * B, LENP = LEN | 1;
@@ -197,10 +200,10 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
             const real_t got = swap1(par ? v[kb].x : v[kb].y);
             real2 q = par ? make_real2(got, v[kb].y) : make_real2(v[kb].x, got);
             real_t s = scale0;
-            if (a.env_log2 != 0.0) s *= env_at(a.env_log2, t);
+            if (!PLAIN && a.env_log2 != 0.0) s *= env_at(a.env_log2, t);
             q.x *= s;
             q.y *= s;
-            if (t < a.t_lim) {
+            if (PLAIN || t < a.t_lim) {
                 at(reinterpret_cast<real2*>(yb), RSZ * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par))) = q;
                 sq += q.x * q.x + q.y * q.y;
             }
@@ -765,7 +768,9 @@ static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStrea
     {                                                                                                            \
         size_t lds = ((size_t)VT_ * LENP + LEN + (size_t)VT_ * B) * sizeof(cf);                                  \
         if (inverse && g_cols_inv_min_lds > lds) lds = g_cols_inv_min_lds;                                       \
-        if (inverse) hipLaunchKernelGGL((spec_cols_inv<A, B, VT_, RG_>), dim3(nblk), dim3(256), lds, st, a);     \
+        if (inverse && a.env_log2 == 0.0 && a.t_lim >= a.n)                                                      \
+            hipLaunchKernelGGL((spec_cols_inv<A, B, VT_, RG_, true>), dim3(nblk), dim3(256), lds, st, a);        \
+        else if (inverse) hipLaunchKernelGGL((spec_cols_inv<A, B, VT_, RG_, false>), dim3(nblk), dim3(256), lds, st, a); \
         else if (a.env_log2 == 0.0 && a.t_lim >= a.n)                                                            \
             hipLaunchKernelGGL((spec_cols_fwd<A, B, VT_, RG_, true>), dim3(nblk), dim3(256), lds, st, a);        \
         else hipLaunchKernelGGL((spec_cols_fwd<A, B, VT_, RG_, false>), dim3(nblk), dim3(256), lds, st, a);      \
