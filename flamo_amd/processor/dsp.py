@@ -18,6 +18,7 @@ on a few hundred scalars and autograd differentiates them for free.
 from __future__ import annotations
 
 import warnings
+import weakref
 from typing import Optional
 
 import torch
@@ -728,6 +729,46 @@ def db_of_sigmoid(x):
 
 
 _FOLDED_GAIN_MAPS = {_db_of_magnitude: "abs", db_of_sigmoid: "sigmoid"}
+_MAP_KIND_CACHE = weakref.WeakKeyDictionary()
+
+
+def _gain_map_kind(fn):
+    """"abs" / "sigmoid" when `fn` IS one of the two maps the design kernels fold (fl_geq_sections in_kind 1..4), or -- an
+    anonymous callable, as the reference's examples pass them: `map=lambda x: 20 * torch.log10(torch.sigmoid(x))`,
+    e8_fdn.py:97 -- when it reproduces one of them bit for bit, values AND gradient, on a float64 probe vector (negative,
+    tiny, large arguments; evaluated once per callable, so a map with side effects sees one extra call).  None otherwise:
+    the callable then runs as torch ops in front of the design kernel, whatever it does."""
+    kind = _FOLDED_GAIN_MAPS.get(fn)
+    if kind is not None or fn is None:
+        return kind
+    try:
+        return _MAP_KIND_CACHE[fn]
+    except (KeyError, TypeError):
+        pass
+    kind = None
+    try:
+        probe = torch.tensor([-31.5, -7.25, -2.0, -0.75, -1e-3, 1e-6, 0.0625, 0.5, 0.9990234375, 1.0, 1.4142, 3.0, 12.5, 40.0],
+                             dtype=torch.float64)
+        with torch.enable_grad():
+            x = probe.clone().requires_grad_(True)
+            y = fn(x)
+            ok = torch.is_tensor(y) and y.shape == x.shape and y.dtype == x.dtype and y.requires_grad
+            if ok:
+                (g,) = torch.autograd.grad(y.sum(), [x])
+                for named, k in _FOLDED_GAIN_MAPS.items():
+                    xr = probe.clone().requires_grad_(True)
+                    yr = named(xr)
+                    (gr,) = torch.autograd.grad(yr.sum(), [xr])
+                    if torch.equal(y.detach(), yr.detach()) and torch.equal(g, gr):
+                        kind = k
+                        break
+    except Exception:       # a map that does not take a float64 host vector is simply not one of the two
+        kind = None
+    try:
+        _MAP_KIND_CACHE[fn] = kind
+    except TypeError:       # not weak-referenceable: probed again next time
+        pass
+    return kind
 
 
 class GEQ(_SOSMixin, Filter):
@@ -755,7 +796,7 @@ class GEQ(_SOSMixin, Filter):
 
     def get_freq_response(self):
         def response(param):
-            gm = _FOLDED_GAIN_MAPS.get(self.map)
+            gm = _gain_map_kind(self.map)
             if gm is not None and param.is_cuda and param.dtype in (torch.float32, torch.float64):
                 # default map: 10^(map(x)/20) = |x| (or sigmoid(x)), folded into the design kernel with its backward
                 return ops.geq_cascade(param, self._design.device_consts(param.device), self._gamma_f, self.nfft,
@@ -765,7 +806,7 @@ class GEQ(_SOSMixin, Filter):
         self._own_response = response
 
     def _cascade_spec(self, param):
-        gm = _FOLDED_GAIN_MAPS.get(self.map)
+        gm = _gain_map_kind(self.map)
         if gm is not None and param.is_cuda and param.dtype in (torch.float32, torch.float64):
             return ("geq", param, self._design.device_consts(param.device), gm)
         return ("sos", *self._sos_coeffs(self.map(param.double())))

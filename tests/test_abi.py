@@ -137,3 +137,27 @@ def test_graphed_step_refuses_without_the_graph_packet_switch(monkeypatch):
     monkeypatch.setattr(flamo_amd, "_graph_packets_off", lambda: False)
     with pytest.raises(RuntimeError, match="DEBUG_CLR_GRAPH_PACKET_CAPTURE"):
         GraphedStep(lambda x: x.sum(), (torch.zeros(2),), ())
+
+
+def test_anonymous_gain_maps_are_recognised_by_probe():
+    """The reference's examples hand the equalisers their parameter map as a lambda (examples/e8_fdn.py:97); the design
+    kernels fold exactly two maps.  A callable that reproduces one of them bit for bit -- values and gradient -- on the probe
+    vector is that map; anything else (an offset, a straight-through trick with the same values, another formula) is not."""
+    from flamo_amd.processor import dsp
+    kind = dsp._gain_map_kind
+    assert kind(lambda x: 20 * torch.log10(torch.sigmoid(x))) == "sigmoid"
+    assert kind(lambda x: 20 * torch.log10(torch.abs(x))) == "abs"
+    assert kind(dsp.db_of_sigmoid) == "sigmoid" and kind(dsp._db_of_magnitude) == "abs"
+    assert kind(lambda x: 20 * torch.log10(torch.sigmoid(x)) + 0.5) is None
+    assert kind(lambda x: x + (20 * torch.log10(torch.sigmoid(x)) - x).detach()) is None       # same values, other gradient
+    assert kind(lambda x: 10 * torch.log10(torch.sigmoid(x) ** 2)) is None                      # same function, other rounding
+    assert kind(torch.abs) is None and kind(lambda x: x.reshape(2, -1)) is None and kind(lambda x: 1 / 0) is None
+    calls = []
+
+    def counted(x):
+        calls.append(1)
+        return 20 * torch.log10(torch.sigmoid(x))
+    assert kind(counted) == "sigmoid" and kind(counted) == "sigmoid" and len(calls) == 1         # probed once per callable
+    geq = dsp.parallelGEQ(size=(4,), nfft=64)
+    geq.map = lambda x: 20 * torch.log10(torch.sigmoid(x))                                       # set after construction, as e8_fdn.py does
+    assert dsp._gain_map_kind(geq.map) == "sigmoid"

@@ -349,3 +349,27 @@ print("BUCKETS-OK")
 ''' % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
     assert "BUCKETS-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, F64])
+def test_lambda_gain_map_takes_the_folded_route(gpu, dt):
+    """examples/e8_fdn.py:97 passes `map=lambda x: 20*torch.log10(torch.sigmoid(x))`: recognised by probe (dsp._gain_map_kind), the
+    equaliser then runs the same kernels as with the named map -- bit-identical response and gradient -- and differs from the
+    torch-op route (an unrecognised callable computing the same function) by rounding only."""
+    from flamo_amd.processor import dsp
+    nfft, N = 4800, 6
+    outs = []
+    for m in (dsp.db_of_sigmoid, lambda x: 20 * torch.log10(torch.sigmoid(x)), lambda x: 20 * torch.log10(torch.sigmoid(x)) + 0.0 * x):
+        torch.manual_seed(7)
+        att = dsp.parallelGEQ(size=(N,), nfft=nfft, alias_decay_db=30.0, requires_grad=True, device=gpu, dtype=dt)
+        att.map = m
+        att.assign_value(torch.randn(12, N, device=gpu, dtype=dt) * 0.3 + 2)
+        H = att.freq_response(att.param)
+        w = torch.randn(H.shape, device=gpu, dtype=dt, generator=torch.Generator(device=gpu).manual_seed(3))
+        (g,) = torch.autograd.grad((H.real * w).sum() + (H.imag * w.flip(0)).sum(), [att.param])
+        outs.append((H.detach(), g))
+    assert dsp._gain_map_kind(dsp.db_of_sigmoid) == "sigmoid"
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    tol = 1e-12 if dt == F64 else 2e-6
+    cc("H_torch_route", outs[2][0], outs[0][0], tol)
+    cc("g_torch_route", outs[2][1], outs[0][1], 1e-9 if dt == F64 else 2e-4)
