@@ -347,13 +347,16 @@ def secondary(dev):
     torch.manual_seed(130709)
     model = tc.build(dev, dt, 16, 192000)
     x, target = tc.colorless_batch(1, 192000, dev, dt)
-    tc.train(model, x, target, 3, 1e-3)
+    # (sharded=False: this leg runs on rank 0 ALONE while the other ranks wait at the closing barrier -- left to its default the
+    # tool shards the bins whenever a multi-rank group exists and rank 0 would sit in an all-gather nobody else enters; found by
+    # tests/test_dist_rccl.py::test_bench_line_two_ranks_on_one_device)
+    tc.train(model, x, target, 3, 1e-3, sharded=False)
     clock = {}
 
     def start():
         torch.cuda.synchronize()
         clock["t0"] = time.perf_counter()
-    tc.train(model, x, target, 50, 1e-3, graphed=True, on_ready=start, fused_adam=True)
+    tc.train(model, x, target, 50, 1e-3, graphed=True, on_ready=start, fused_adam=True, sharded=False)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - clock["t0"]) / 50 * 1e3
     out["config4_colorless_training"] = {"ms_per_step": round(ms, 4), "bin_solves_per_s": 96001 / (ms * 1e-3)}

@@ -120,6 +120,10 @@ _SIGNATURES = {
     "fl_debug_set_cascade_lanes": (_i, [_i, _i, _i]),
     "fl_debug_set_cascade_stamps": (_i, [_vp, _i]),
     "fl_solve_max_n": (_i, [_i]),
+    "fl_solve_ws_max_n": (_i, []),
+    "fl_solve_ws_bytes": (_l, [_i, _i, _i]),
+    "fl_solve_ws_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _l, _vp]),
+    "fl_solve_ws_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _l, _vp]),
     "fl_solve_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),
     "fl_solve_scaled_c64": (_i, [_vp, _l, _vp, _l, _i, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp]),

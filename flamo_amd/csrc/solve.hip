@@ -729,19 +729,24 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
 // rank-one update of the trailing block), then the right-hand sides in blocks of CB columns (forward and back substitution
 // with the columns of a block side by side).  A correctness path for sizes the reference's torch.linalg.solve
 // (system.py:425) accepts and feedback delay networks rarely use: ~4 N + 2 N (B K / CB) barriers per bin, not tuned.
-template <typename T>
+// WS (loops beyond what the LDS holds: N > 138 / 97): the same algorithm with the matrix in a caller-owned workspace in global
+// memory -- one N x (N + 1) slot per workgroup, a workgroup walks the bins f = blockIdx.x, + gridDim.x, ... -- and only the
+// right-hand-side block and the pivot list in LDS.  __syncthreads() orders a workgroup's global accesses (workgroup-scope
+// fence; its wavefronts share the CU's vector cache).  torch.linalg.solve (system.py:425) has no size bound: neither has this.
+template <typename T, bool WS>
 __global__ void __launch_bounds__(256) solve_lds_kernel(const cx<T>* __restrict__ P, long p_pitch, int one_minus, int adjoint,
                                                         const cx<T>* __restrict__ R, long rs_b, long rs_n, long rs_k,
                                                         cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
-                                                        int B, int M, int N, int K, int CB) {
+                                                        int B, int M, int N, int K, int CB, cx<T>* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int NP = N + 1;
-    cx<T>* Am = reinterpret_cast<cx<T>*>(smem);             // [N][NP]
-    cx<T>* Y = Am + (size_t)N * NP;                          // [N][CB]
+    cx<T>* Am = WS ? ws + (size_t)blockIdx.x * N * NP : reinterpret_cast<cx<T>*>(smem);             // [N][NP]
+    cx<T>* Y = WS ? reinterpret_cast<cx<T>*>(smem) : Am + (size_t)N * NP;                            // [N][CB]
     int* piv = reinterpret_cast<int*>(Y + (size_t)N * CB);   // [N]
     __shared__ T red_v[256];
     __shared__ int red_i[256];
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+  for (int f = blockIdx.x; f < M; f += gridDim.x) {
     for (int e = tid; e < N * N; e += 256) {
         const int i = e / N, j = e - i * N;
         cx<T> v = adjoint ? conj(P[(size_t)(j * N + i) * p_pitch + f]) : P[(size_t)(i * N + j) * p_pitch + f];
@@ -843,6 +848,7 @@ __global__ void __launch_bounds__(256) solve_lds_kernel(const cx<T>* __restrict_
         }
         __syncthreads();
     }
+  }
 }
 
 // LDS one workgroup of the current device may ask for (160 KB on MI355X), less 4 KB for the kernel's static arrays
@@ -861,9 +867,24 @@ static int solve_lds_max_n() {
     return n;
 }
 
+// the workspace form (N beyond solve_lds_max_n, to kSolveWsMaxN): slots of N x (N + 1) values, one per workgroup; as many
+// workgroups as two per CU, the bins, and 1 GB of workspace allow
+constexpr int kSolveWsMaxN = 1024;
+template <typename T>
+static int solve_ws_slots(int N, int M) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    long slots = 2L * cus;
+    const long cap = (1L << 30) / ((long)N * (N + 1) * (long)sizeof(cx<T>));
+    if (slots > cap) slots = cap;
+    if (slots > M) slots = M;
+    return slots < 1 ? 1 : (int)slots;
+}
+
 template <typename T>
 static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k,
-                      void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+                      void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream, void* ws = nullptr,
+                      size_t ws_bytes = 0) {
     FL_REQUIRE((P || dud.U) && (R || dud.rv) && OUT, "solve: null pointer");
     if (dud.rv || dud.cz) {
         FL_REQUIRE(dud.rv && dud.rs && K == 1 && !P, "solve: the rank-one right-hand side needs its scalar signal, one column per batch item and the factored loop");
@@ -877,9 +898,35 @@ static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_mi
     const int nmax_lim = sizeof(T) == 8 ? 32 : 64;
     if (N > nmax_lim) {
         const int big = solve_lds_max_n<T>();
+        if (P && N > big && N <= kSolveWsMaxN && ws) {
+            if (B == 0 || M == 0) return FL_OK;
+            const int slots = solve_ws_slots<T>(N, M);
+            FL_REQUIRE(ws_bytes >= (size_t)slots * N * (N + 1) * sizeof(cx<T>), "solve: workspace too small (fl_solve_ws_bytes)");
+            const size_t budget = solve_lds_budget();
+            int cb = 16;
+            while (cb > 1 && (size_t)N * cb * sizeof(cx<T>) + (size_t)N * sizeof(int) > budget) cb >>= 1;
+            const size_t lds = (size_t)N * cb * sizeof(cx<T>) + (size_t)N * sizeof(int);
+            static bool attr_ws[64] = {};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+            if (!attr_ws[dev] && lds > 64 * 1024) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(solve_lds_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+                if (e != hipSuccess) {
+                    set_error("solve: %zu bytes of LDS per workgroup are not available on device %d (%s)", budget, dev, hipGetErrorString(e));
+                    return FL_ERR_UNSUPPORTED;
+                }
+                attr_ws[dev] = true;
+            }
+            hipLaunchKernelGGL((solve_lds_kernel<T, true>), dim3(slots), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)P, p_pitch, one_minus,
+                               adjoint, (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K, cb, (cx<T>*)ws);
+            FL_CHECK_LAUNCH("solve_ws");
+            return FL_OK;
+        }
         if (!P || N > big) {
-            set_error("solve: N=%d exceeds %s (%d for this precision)", N, P ? "what one workgroup's LDS holds" : "the register-resident limit of the factored forms",
-                      P ? big : nmax_lim);
+            set_error("solve: N=%d exceeds %s (%d for this precision)", N,
+                      P ? (N > kSolveWsMaxN ? "the workspace form's limit" : "what one workgroup's LDS holds (pass a workspace: fl_solve_ws_*)")
+                        : "the register-resident limit of the factored forms",
+                      P ? (N > kSolveWsMaxN ? kSolveWsMaxN : big) : nmax_lim);
             return FL_ERR_UNSUPPORTED;
         }
         if (B == 0 || M == 0) return FL_OK;
@@ -892,15 +939,15 @@ static int solve_impl(const void* P, long p_pitch, const Dud<T>& dud, int one_mi
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
         if (!attr_set[dev]) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(solve_lds_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(solve_lds_kernel<T, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
             if (e != hipSuccess) {
                 set_error("solve: %zu bytes of LDS per workgroup are not available on device %d (%s)", budget, dev, hipGetErrorString(e));
                 return FL_ERR_UNSUPPORTED;
             }
             attr_set[dev] = true;
         }
-        hipLaunchKernelGGL((solve_lds_kernel<T>), dim3(M), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)P, p_pitch, one_minus, adjoint,
-                           (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K, cb);
+        hipLaunchKernelGGL((solve_lds_kernel<T, false>), dim3(M), dim3(256), lds, (hipStream_t)stream, (const cx<T>*)P, p_pitch, one_minus, adjoint,
+                           (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K, cb, (cx<T>*)nullptr);
         FL_CHECK_LAUNCH("solve_lds");
         return FL_OK;
     }
@@ -1231,6 +1278,24 @@ int fl_debug_set_solve_variant(int variant) {
     }
     g_solve_variant = variant;
     return FL_OK;
+}
+int fl_solve_ws_max_n(void) { return kSolveWsMaxN; }
+long fl_solve_ws_bytes(int N, int M, int f64) {
+    if (N <= (f64 ? solve_lds_max_n<double>() : solve_lds_max_n<float>()) || N > kSolveWsMaxN || M <= 0) return 0;
+    return f64 ? (long)solve_ws_slots<double>(N, M) * N * (N + 1) * (long)sizeof(cx<double>)
+               : (long)solve_ws_slots<float>(N, M) * N * (N + 1) * (long)sizeof(cx<float>);
+}
+int fl_solve_ws_c64(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+                    long os_b, long os_n, long os_k, int B, int M, int N, int K, void* ws, long ws_bytes, void* stream) {
+    Dud<float> none = {};
+    return solve_impl<float>(P, p_pitch, none, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream, ws,
+                             ws_bytes > 0 ? (size_t)ws_bytes : 0);
+}
+int fl_solve_ws_c128(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+                     long os_b, long os_n, long os_k, int B, int M, int N, int K, void* ws, long ws_bytes, void* stream) {
+    Dud<double> none = {};
+    return solve_impl<double>(P, p_pitch, none, one_minus, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream, ws,
+                              ws_bytes > 0 ? (size_t)ws_bytes : 0);
 }
 int fl_solve_c64(const void* P, long p_pitch, int one_minus, int adjoint, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
                  long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {

@@ -1235,6 +1235,15 @@ def _solve_launch(Pp, one_minus, adjoint, R):
     OUT = _empty_planar(R.shape, R.dtype, R.device)
     _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
     L = _lib.lib()
+    nws = int(L.fl_solve_ws_bytes(N, M, int(real == torch.float64)))
+    if nws > 0:
+        # loops beyond what one workgroup's LDS holds (N > 138 / 97): the factorisation's matrices in a workspace this call owns
+        ws = torch.empty(nws, dtype=torch.uint8, device=R.device)
+        fn = L.fl_solve_ws_c64 if real == torch.float32 else L.fl_solve_ws_c128
+        with kernel_timer.span("solve_adj" if adjoint else "solve"):
+            _lib.check(fn(Pp.data_ptr(), _lead_pitch(Pp.movedim(0, -1)), int(one_minus), int(adjoint), R.data_ptr(), rs_b, rs_n,
+                          rs_k, OUT.data_ptr(), os_b, os_n, os_k, B, M, N, K, ws.data_ptr(), nws, _stream()), "solve_ws")
+        return OUT
     fn = L.fl_solve_c64 if real == torch.float32 else L.fl_solve_c128
     with kernel_timer.span("solve_adj" if adjoint else "solve"):
         _lib.check(fn(Pp.data_ptr(), _lead_pitch(Pp.movedim(0, -1)), int(one_minus), int(adjoint), R.data_ptr(), rs_b, rs_n,

@@ -362,16 +362,16 @@ class Recursion(nn.Module):
         self.input_channels, self.output_channels = self.__check_io()
         # The closed-loop solve keeps a loop-matrix row per lane up to 64 (float32) / 32 (float64) channels -- the sizes with
         # the fused loop forms; above that one workgroup per bin factors the materialised matrix in LDS (fl_solve_max_n: 138 /
-        # 97).  The reference's torch.linalg.solve has no bound; there is deliberately no torch fallback on this path.
+        # 97), and above THAT in a global-memory workspace (fl_solve_ws_*, to fl_solve_ws_max_n = 1024 channels).  The
+        # reference's torch.linalg.solve has no bound; there is deliberately no torch fallback on this path.
         self._register_loop = self.output_channels <= (32 if self.dtype == torch.float64 else 64)
-        # the static bound of the LDS solve on MI355X (160 KB of LDS per workgroup); what THIS device's library answers
-        # (fl_solve_max_n) is asked at the first forward, on the tensor's device -- not here: constructing a module must not
-        # initialise the HIP runtime (fork-based data loaders), and the device current now need not be the module's
-        limit = 97 if self.dtype == torch.float64 else 138
+        # the static bound of the workspace solve; what THIS device's library answers is asked at the first forward, on the
+        # tensor's device -- not here: constructing a module must not initialise the HIP runtime (fork-based data loaders),
+        # and the device current now need not be the module's
+        limit = 1024
         self._solve_limit_checked = set()
         assert self.output_channels <= limit, (
-            f"Recursion: {self.output_channels} loop channels exceed the HIP solve kernels' limit of {limit} "
-            f"({'float64' if self.dtype == torch.float64 else 'float32'}); see INTEGRATION.md")
+            f"Recursion: {self.output_channels} loop channels exceed the HIP solve kernels' limit of {limit}; see INTEGRATION.md")
 
     @staticmethod
     def __as_series(path, name):
@@ -400,7 +400,7 @@ class Recursion(nn.Module):
             return
         from .. import _lib
         with torch.cuda.device(dev):
-            limit = int(_lib.lib().fl_solve_max_n(int(self.dtype == torch.float64)))
+            limit = max(int(_lib.lib().fl_solve_max_n(int(self.dtype == torch.float64))), int(_lib.lib().fl_solve_ws_max_n()))
         if self.output_channels > limit:
             raise ValueError(f"Recursion: {self.output_channels} loop channels exceed the HIP solve kernels' limit of {limit} on "
                              f"device {key} ({'float64' if self.dtype == torch.float64 else 'float32'}); see INTEGRATION.md")

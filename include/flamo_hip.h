@@ -474,6 +474,21 @@ int fl_solve_c128(const void* P, long p_pitch, int one_minus, int adjoint,
                   void* OUT, long os_b, long os_n, long os_k,
                   int B, int M, int N, int K, void* stream);
 
+/* The same solve for loops beyond fl_solve_max_n, to fl_solve_ws_max_n() channels (torch.linalg.solve, system.py:425, has no
+ * bound): the matrix of a bin lives in a caller-owned workspace in global memory, fl_solve_ws_bytes(N, M, f64) bytes (0 when
+ * the size needs none and fl_solve_* serves it; at most 1 GB: one N x (N + 1) slot per resident workgroup, which walks its bins).
+ * Any N the plain entry points take is routed as they route it (the workspace is then ignored and may be null). */
+int fl_solve_ws_max_n(void);
+long fl_solve_ws_bytes(int N, int M, int f64);
+int fl_solve_ws_c64(const void* P, long p_pitch, int one_minus, int adjoint,
+                    const void* R, long rs_b, long rs_n, long rs_k,
+                    void* OUT, long os_b, long os_n, long os_k,
+                    int B, int M, int N, int K, void* ws, long ws_bytes, void* stream);
+int fl_solve_ws_c128(const void* P, long p_pitch, int one_minus, int adjoint,
+                     const void* R, long rs_b, long rs_n, long rs_k,
+                     void* OUT, long os_b, long os_n, long os_k,
+                     int B, int M, int N, int K, void* ws, long ws_bytes, void* stream);
+
 /* fl_solve_* (one_minus) with a constant row scale of the materialised matrix: A_f = I - diag(l) P[f], l: N complex values
  * l_sn apart.  For loops whose feedforward path ends in per-channel gains (Series(Delay((N,N)), parallelGain(N)) around a
  * mixing matrix, the active-acoustics structure): P = D[f] U is formed once and the gains never make a pass over the

@@ -194,7 +194,7 @@ def test_bench_line_two_ranks_on_one_device():
     the bin-sharded legs -- executed end to end on a one-GPU box.  The figures of such a line mean nothing (shared device)."""
     _need(1)
     out = _torchrun(2, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                    timeout=1200, env={"BENCH_ALLOW_SHARED_GPU": "1", "BENCH_BACKEND": "gloo"}).stdout
+                    timeout=900, env={"BENCH_ALLOW_SHARED_GPU": "1", "BENCH_BACKEND": "gloo"}).stdout
     lines = [ln for ln in out.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])

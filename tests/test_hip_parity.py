@@ -361,8 +361,9 @@ def test_fdn_golden(gpu, dt, name):
     for got, key in zip(g, keys):
         check_close(f"fdn_golden/{name}/{str(dt)[6:]}/{key}", got.cpu(), a[key], 1e-3 if key == "g_attn_param" else 5 * tol)
         if key == "g_attn_param":
+            # (recorded on MI355X: 8e-14 .. 3e-12 in float64, 3e-7 .. 2e-6 in float32 -- the 1e-4 above is the reference's own noise)
             check_closer(f"fdn_golden/{name}/{str(dt)[6:]}/g_attn_param_vs_float64_backward", got.cpu(), a[key], truth,
-                         1e-8 if full else 1e-3)
+                         1e-10 if full else 1e-5)
     if not full:
         return
     core = model.get_core()

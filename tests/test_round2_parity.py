@@ -87,14 +87,14 @@ def test_parallel_probe_and_peq_coeff_api():
 
 
 def test_recursion_channel_limit_is_checked_at_construction():
+    """beyond the register kernels (64 / 32 channels) and the LDS kernel (138 / 97) the solve runs in a global-memory workspace,
+    to 1024 channels (fl_solve_ws_max_n); the static bound is checked without touching the HIP runtime"""
     from flamo_amd.processor import dsp, system
-    kw = dict(nfft=64, dtype=torch.float32)
-    with pytest.raises(AssertionError, match="limit of 138"):
+    for dt_ in (torch.float32, torch.float64):
+        kw = dict(nfft=64, dtype=dt_)
+        with pytest.raises(AssertionError, match="limit of 1024"):
+            system.Recursion(fF=dsp.parallelGain(size=(1025,), **kw), fB=dsp.Matrix(size=(1025, 1025), **kw))
         system.Recursion(fF=dsp.parallelGain(size=(139,), **kw), fB=dsp.Matrix(size=(139, 139), **kw))
-    system.Recursion(fF=dsp.parallelGain(size=(138,), **kw), fB=dsp.Matrix(size=(138, 138), **kw))
-    kw = dict(nfft=64, dtype=torch.float64)
-    with pytest.raises(AssertionError, match="limit of 97"):
-        system.Recursion(fF=dsp.parallelGain(size=(98,), **kw), fB=dsp.Matrix(size=(98, 98), **kw))
 
 
 def test_fusability_follows_forward_overrides_and_hooks():

@@ -62,7 +62,7 @@ def test_fdn16_with_attenuation_full_size_all_gradients(gpu):
         # error (tests/golden/achieved_errors.json) times five on top of it
         check_close(f"fdn16_attn_full/g_{k}", gi.cpu(), gr, 1e-3 if k == "attn_param" else 1e-5)
         if k == "attn_param":
-            check_closer("fdn16_attn_full/g_attn_param_vs_float64_backward", gi.cpu(), gr, g_attn_true, 1e-3)
+            check_closer("fdn16_attn_full/g_attn_param_vs_float64_backward", gi.cpu(), gr, g_attn_true, 1e-5)
 
 
 @gpu_only
@@ -160,13 +160,15 @@ def test_config5_core_full_size_on_sampled_bins(gpu):
         # equaliser gains: float32 section buffers in the reference (and the oracle); see check_close for the recorded bound
         check_close(f"config5_core_full/{k}", gi.cpu(), gr, 1e-3 if k == "g_geq" else 3e-5)
         if k == "g_geq":
-            check_closer("config5_core_full/g_geq_vs_float64_backward", gi.cpu(), gr, g_geq_true, 1e-3)
+            check_closer("config5_core_full/g_geq_vs_float64_backward", gi.cpu(), gr, g_geq_true, 1e-5)
 
 
 @gpu_only
-@pytest.mark.parametrize("dt,N", [(torch.float32, 80), (torch.float32, 138), (torch.float64, 40), (torch.float64, 97)])
+@pytest.mark.parametrize("dt,N", [(torch.float32, 80), (torch.float32, 138), (torch.float64, 40), (torch.float64, 97),
+                                  (torch.float32, 150), (torch.float64, 110), (torch.float32, 257)])
 def test_recursion_beyond_the_register_resident_sizes(gpu, dt, N):
-    """Loops larger than a wavefront's lanes (64 channels in float32, 32 in float64) go through the LDS solve kernel: output and
+    """Loops larger than a wavefront's lanes (64 channels in float32, 32 in float64) go through the LDS solve kernel, loops larger
+    than the LDS (138 / 97) through the workspace form of the same kernel (fl_solve_ws_*): output and
     gradients of Recursion(parallelDelay * parallelGain, orthogonal Matrix) against torch.linalg.solve in float64 (system.py:397-425)."""
     from flamo_amd.processor import dsp, system
     from oracle import hotpath as O

@@ -258,7 +258,7 @@ def test_matrix_cascade_operator_float64(gpu, kind, nfft, N):
         H = ops.geq_cascade_rc(spec[1], spec[2], W, flt._gamma_f, nfft, dtype=F64)
         assert H.dtype == torch.complex128
         Href = O.geq_response(flt.param.detach().cpu().double(), nfft, O.gamma_of(0.0, nfft, F64)) @ W.cpu().to(torch.complex128)
-        cc("H", H.cpu(), Href, 1e-12)
+        cc("H", H.cpu(), Href, 1e-12, max_tol=1e-10)      # (max-norm: the response peaks at 2 while single bins sit near 1e-3)
 
 
 @pytest.mark.gpu

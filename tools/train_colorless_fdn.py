@@ -68,12 +68,15 @@ def sparsity_criterion(model):
     return -(torch.sum(torch.abs(A)) - N * math.sqrt(N)) / (N * (math.sqrt(N) - 1))
 
 
-def train(model, x, target, steps, lr, group=None, log=None, graphed=False, on_ready=None, fused_adam=False):
+def train(model, x, target, steps, lr, group=None, log=None, graphed=False, on_ready=None, fused_adam=False, sharded=None):
     """`steps` iterations of Trainer.train_step.  With a process group the core runs on this rank's bins.
-    graphed (one GPU): forward + criteria + backward replayed from a HIP graph, the Adam update launched behind it."""
+    graphed (one GPU): forward + criteria + backward replayed from a HIP graph, the Adam update launched behind it.
+    sharded: None = whenever a process group with more than one rank exists; False = this rank alone, whatever groups the
+    process has joined (a leg that ONE rank of a multi-rank job runs on its own must not enter a collective)."""
     import torch.distributed as dist
     from flamo_amd import dist as fd
-    sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    if sharded is None:
+        sharded = group is not None or (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
     rank = dist.get_rank(group) if sharded else 0
     params = [p for p in model.parameters() if p.requires_grad]
     # fused_adam: the same update in one launch for all parameters (torch's foreach default is ~12 launches)
