@@ -117,6 +117,10 @@ _SIGNATURES = {
     "fl_geq_bwd_lanes_wrows": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "fl_geq_response_bwd_lanes_c64": (_i, [_i, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _d, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "fl_geq_sections_bwd_lanes": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "fl_geq_bwd_lanes_blocks_f64": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "fl_geq_bwd_lanes_wrows_f64": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "fl_geq_response_bwd_lanes_c128": (_i, [_i, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _d, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "fl_geq_sections_bwd_lanes_f64": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _d, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "fl_debug_set_cascade_lanes": (_i, [_i, _i, _i]),
     "fl_debug_set_cascade_stamps": (_i, [_vp, _i]),
     "fl_solve_max_n": (_i, [_i]),

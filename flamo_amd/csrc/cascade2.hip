@@ -31,7 +31,22 @@
 namespace fl {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+// the packed pair / quadruple of a scalar type: float pairs are the operands of v_pk_*_f32; double "pairs" are two registers
+// pairs and two v_fma_f64 -- the SAME issue time (a packed float instruction occupies the SIMD for two passes), which is why
+// the float64 kernel below runs at the float one's speed where the lane-per-bin kernel of response.hip takes three times as long
+template <typename T> struct Vec;
+template <> struct Vec<float> { typedef f2 v2; typedef f4 v4; };
+template <> struct Vec<double> { typedef d2 v2; typedef d4 v4; };
+__device__ __forceinline__ float rcp_of(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double rcp_of(double x) {      // hardware estimate + two Newton steps (an IEEE division is ~15 instructions)
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return fma(r, fma(-x, r, 1.0), r);
+}
 
+template <typename T>
 struct LanesArgs {
     const double* b;       // (3, S, C) taps (designed by the forward launch)
     const double* a;
@@ -39,17 +54,17 @@ struct LanesArgs {
     double g;              // anti-aliasing radius (gamma)
     const cx<double>* Wd;  // float64 master twiddles
     int nfft, bin0, m_local;
-    const cx<float>* gH;   // cotangent planes: rc mode (row * NIW + n), plain mode c
+    const cx<T>* gH;       // cotangent planes: rc mode (row * NIW + n), plain mode c
     long g_pitch;
-    const cx<float>* G;    // saved response, planes c
+    const cx<T>* G;        // saved response, planes c
     long h_pitch;
-    const float* Wr;       // (PPR, NIW) constant factor (rc mode)
-    float* psum;           // (S * C, nbx, 4) partial sums (G0 of B, G0 of A, G2 of B, G2 of A)
-    float* pq;             // (C, nbx) partial sums of Re(q)
-    float* partW;          // (PPR * NIW, nbx * pair groups) partial sums of the constant factor's gradient (rc mode)
+    const T* Wr;           // (PPR, NIW) constant factor (rc mode)
+    T* psum;               // (S * C, nbx, 4) partial sums (G0 of B, G0 of A, G2 of B, G2 of A)
+    T* pq;                 // (C, nbx) partial sums of Re(q)
+    T* partW;              // (PPR * NIW, nbx * pair groups) partial sums of the constant factor's gradient (rc mode)
     // "outer" mode: dL/dG[m][n] = sum_b gY[b][m] conj(X[b][n]) formed from the two signals
-    const cx<float>* oG;
-    const cx<float>* oX;
+    const cx<T>* oG;
+    const cx<T>* oX;
     long o_gb, o_gn, o_xb, o_xn;
     int oB;
     // geometry (lanes_plan)
@@ -63,22 +78,22 @@ struct LanesArgs {
 // (a transcendental occupies the SIMD for four passes: ONE reciprocal of |B~|^2 |A~|^2 serves both polynomials).
 // x = (1 -+ cos, sin); qa = (q.x, q.y), qb = (sin q.y, -sin q.x) as the lane-per-bin work left them: every scalar factor is a
 // half of an aligned register pair, i.e. an operand selector
-template <int NSUM>
-__device__ __forceinline__ void lane_bin(f2 C0, f2 C1, f2 C2, f2 x, float uu, f2 qa, f2 qb, f2& t0, f2& t1, f2& t2) {
-    const f2 R = C1 * x.x + C0;
-    const f2 I = C2 * x.y;
-    f2 n = R * R;
+template <int NSUM, typename P2, typename T>
+__device__ __forceinline__ void lane_bin(P2 C0, P2 C1, P2 C2, P2 x, T uu, P2 qa, P2 qb, P2& t0, P2& t1, P2& t2) {
+    const P2 R = C1 * x.x + C0;
+    const P2 I = C2 * x.y;
+    P2 n = R * R;
     n = I * I + n;
-    const float r = __builtin_amdgcn_rcpf(n.x * n.y);
-    const f2 inv = f2{n.y, n.x} * r;                     // (1 / |B~|^2, 1 / |A~|^2)
-    const f2 uR = R * inv, uI = I * inv;                 // P~ / |P~|^2
+    const T r = rcp_of(n.x * n.y);
+    const P2 inv = P2{n.y, n.x} * r;                     // (1 / |B~|^2, 1 / |A~|^2)
+    const P2 uR = R * inv, uI = I * inv;                 // P~ / |P~|^2
     // (one fused multiply-add per statement)
     t0 = uR * qa.x + t0;                                 // Re(q / P~)
     t0 = uI * qa.y + t0;
     t2 = uR * qb.x + t2;                                 // sin Im(q / P~)
     t2 = uI * qb.y + t2;
     if constexpr (NSUM == 3) {
-        const f2 uq = qa * uu;
+        const P2 uq = qa * uu;
         t1 = uR * uq.x + t1;                             // (1 - cos) Re(q / P~)
         t1 = uI * uq.y + t1;
     }
@@ -86,24 +101,27 @@ __device__ __forceinline__ void lane_bin(f2 C0, f2 C1, f2 C2, f2 x, float uu, f2
 
 // NIW > 0: constant-factor mode (rows of PPR pairs share NIW cotangent planes); NIW == 0, !OUTER: plain (PPR = 1);
 // OUTER: rows of PPR pairs (m, n), cotangent formed from gY and X.
-template <int NIW, int PPR, int NSUM, bool OUTER>
-__global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <typename RT, int NIW, int PPR, int NSUM, bool OUTER>
+__global__ void __launch_bounds__(sizeof(RT) == 8 ? 384 : 768, sizeof(RT) == 8 ? 2 : 3) sos_bwd_lanes_kernel(const LanesArgs<RT> A) {
+    typedef typename Vec<RT>::v2 P2;
+    typedef typename Vec<RT>::v4 P4;
+    typedef cx<RT> cT;
+    extern __shared__ __attribute__((aligned(32))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int bx = blockIdx.x, cg = blockIdx.y;
     const int npb = A.npb, tbp = A.tbp, S = A.S, C = A.C;
     // two sets of tile buffers: the lane-per-bin work of tile t + 1 writes one while the lane-per-section work of tile t reads the other
     struct Bufs {
-        f4* qs;             // [npb][tbp]  (q, sin * (-i q)), q = conj(gG) G; zero where nothing is due
-        f2* xs;             // [tbp]       (1 -+ cos, sin)
-        float* us;          // [tbp]       1 - cos      (NSUM == 3)
+        P4* qs;             // [npb][tbp]  (q, sin * (-i q)), q = conj(gG) G; zero where nothing is due
+        P2* xs;             // [tbp]       (1 -+ cos, sin)
+        RT* us;          // [tbp]       1 - cos      (NSUM == 3)
     };
     auto bufs_at = [&](int which) {
         Bufs B;
         char* p = smem + (size_t)which * A.lds1;
-        B.qs = reinterpret_cast<f4*>(p);
-        B.xs = reinterpret_cast<f2*>(B.qs + (size_t)npb * tbp);
-        B.us = reinterpret_cast<float*>(B.xs + tbp);
+        B.qs = reinterpret_cast<P4*>(p);
+        B.xs = reinterpret_cast<P2*>(B.qs + (size_t)npb * tbp);
+        B.us = reinterpret_cast<RT*>(B.xs + tbp);
         return B;
     };
 
@@ -112,21 +130,21 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
     const bool l_on = t < nl;
     const int sl = A.s_first + (l_on ? t / npb : 0), pl = l_on ? t % npb : 0;
     const int c = cg * npb + pl;
-    f2 C0lo = {1.f, 1.f}, C1lo = {0.f, 0.f}, C0hi = {1.f, 1.f}, C2 = {0.f, 0.f};      // (C1hi = -C1lo)
+    P2 C0lo = {(RT)1.0, (RT)1.0}, C1lo = {(RT)0.0, (RT)0.0}, C0hi = {(RT)1.0, (RT)1.0}, C2 = {(RT)0.0, (RT)0.0};      // (C1hi = -C1lo)
     if (l_on) {
         const double g2 = A.g * A.g;
         const double b0 = A.b[(size_t)sl * C + c], b1 = A.b[(size_t)(S + sl) * C + c], b2 = A.b[(size_t)(2 * S + sl) * C + c];
         const double a0 = A.a[(size_t)sl * C + c], a1 = A.a[(size_t)(S + sl) * C + c], a2 = A.a[(size_t)(2 * S + sl) * C + c];
         const double SB = b0 + g2 * b2, TB = A.g * b1, DB = b0 - g2 * b2;
         const double SA = a0 + g2 * a2, TA = A.g * a1, DA = a0 - g2 * a2;
-        C0lo = f2{(float)(SB + TB), (float)(SA + TA)};
-        C1lo = f2{(float)(-SB), (float)(-SA)};
-        C0hi = f2{(float)(TB - SB), (float)(TA - SA)};
-        C2 = f2{(float)DB, (float)DA};
+        C0lo = P2{(RT)(SB + TB), (RT)(SA + TA)};
+        C1lo = P2{(RT)(-SB), (RT)(-SA)};
+        C0hi = P2{(RT)(TB - SB), (RT)(TA - SA)};
+        C2 = P2{(RT)DB, (RT)DA};
     }
     const bool wave_on = wave * 64 < nl;
 
-    f2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+    P2 acc0 = {(RT)0.0, (RT)0.0}, acc1 = {(RT)0.0, (RT)0.0}, acc2 = {(RT)0.0, (RT)0.0};
     // ---- tiles: elements f0 .. f0 + n - 1, one expansion point, bin of element f0 + i = kbase + i * kstep
     struct Tile {
         int f0, n, kbase, kstep;
@@ -161,13 +179,14 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
     // tile ahead (they arrive under the lane-per-section work in between).  Plane bases are wavefront-uniform, the lane's part
     // is ONE 32-bit byte offset per tensor (saddr + voffset loads: a 64-bit address per plane would be 32 more registers)
     constexpr bool RC = NIW > 0 && !OUTER;
-    constexpr int JPT = RC ? (NIW >= 16 ? 1 : (PPR >= 2 ? 2 : PPR)) : (OUTER ? PPR : 1);      // pairs of the row per item
+    // pairs of the row per item (double: one -- two pairs' worth of constant-factor sums and cotangent rows in doubles do not fit the registers)
+    constexpr int JPT = RC ? ((NIW >= 16 || sizeof(RT) == 8) ? 1 : (PPR >= 2 ? 2 : PPR)) : (OUTER ? PPR : 1);
     constexpr int JG = (RC || OUTER) ? PPR / JPT : 1;
     constexpr int NG = OUTER ? 2 : (NIW > 0 ? NIW : 1);        // cotangent values per item
     constexpr int TRIPS = (RC || OUTER) ? 1 : 4;               // items per thread and tile (plain mode: one per pair)
     struct Item {
-        cx<float> gv[NG];
-        cx<float> hv[JPT];
+        cT gv[NG];
+        cT hv[JPT];
         cx<double> w1;
     };
     Item pre[TRIPS];
@@ -186,17 +205,17 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
     // v_mfma_f32_16x16x4_f32 a quarter of a tile, two bins per instruction -- measured: 44 k cycles per workgroup against the
     // ~2 k of these packed multiply-adds.)
     constexpr int NWJ = RC ? JPT : 1, NWN = RC ? NIW : 1;
-    float wrow[NWJ][NWN];
-    f2 aw[NWJ][NWN];
+    RT wrow[NWJ][NWN];
+    P2 aw[NWJ][NWN];
 #pragma unroll
     for (int j = 0; j < NWJ; ++j)
 #pragma unroll
         for (int nn = 0; nn < NWN; ++nn) {
-            wrow[j][nn] = RC ? A.Wr[(it_j[0] + j) * NIW + nn] : 0.f;
-            aw[j][nn] = f2{0.f, 0.f};
+            wrow[j][nn] = RC ? A.Wr[(it_j[0] + j) * NIW + nn] : (RT)0.0;
+            aw[j][nn] = P2{(RT)0.0, (RT)0.0};
         }
-    auto at = [](const cx<float>* base, unsigned byte_off) {
-        return *reinterpret_cast<const cx<float>*>(reinterpret_cast<const char*>(base) + byte_off);
+    auto at = [](const cT* base, unsigned byte_off) {
+        return *reinterpret_cast<const cT*>(reinterpret_cast<const char*>(base) + byte_off);
     };
     auto request = [&](const Tile& T) {
         const int np = (T.n + 1) & ~1;
@@ -211,13 +230,13 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
             if constexpr (OUTER) {
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb)
-                    pre[q].gv[bb] = bb < A.oB ? A.oG[(size_t)bb * A.o_gb + (size_t)row * A.o_gn + f] : cx<float>(0.f, 0.f);
-                const unsigned hoff = (unsigned)(((size_t)(row * PPR) * A.h_pitch + f) * 8);
+                    pre[q].gv[bb] = bb < A.oB ? A.oG[(size_t)bb * A.o_gb + (size_t)row * A.o_gn + f] : cT((RT)0.0, (RT)0.0);
+                const unsigned hoff = (unsigned)(((size_t)(row * PPR) * A.h_pitch + f) * sizeof(cT));
 #pragma unroll
                 for (int j = 0; j < JPT; ++j) pre[q].hv[j] = at(A.G + (size_t)j * A.h_pitch, hoff);
             } else if constexpr (RC) {
-                const unsigned goff = (unsigned)(((size_t)(row * NIW) * A.g_pitch + f) * 8);
-                const unsigned hoff = (unsigned)(((size_t)(row * PPR + it_j[q]) * A.h_pitch + f) * 8);
+                const unsigned goff = (unsigned)(((size_t)(row * NIW) * A.g_pitch + f) * sizeof(cT));
+                const unsigned hoff = (unsigned)(((size_t)(row * PPR + it_j[q]) * A.h_pitch + f) * sizeof(cT));
 #pragma unroll
                 for (int nn = 0; nn < NG; ++nn) pre[q].gv[nn] = at(A.gH + (size_t)nn * A.g_pitch, goff);
 #pragma unroll
@@ -229,11 +248,11 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
         }
     };
     // the items' products into the tile buffers: q (with its quarter-turned, sine-weighted copy), the bins' (x, sin)
-    float qsum[TRIPS][JPT];
+    RT qsum[TRIPS][JPT];
 #pragma unroll
     for (int q = 0; q < TRIPS; ++q)
 #pragma unroll
-        for (int j = 0; j < JPT; ++j) qsum[q][j] = 0.f;
+        for (int j = 0; j < JPT; ++j) qsum[q][j] = (RT)0.0;
     auto bin_work = [&](const Tile& T, const Bufs& B) {
         const int n = T.n, np = (n + 1) & ~1;       // an odd tail is padded with a copy of the last bin and a zero cotangent
 #pragma unroll
@@ -242,46 +261,46 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
             if (r < 0 || i >= np) continue;
             const bool valid = i < n;
             const Item& P = pre[q];
-            const float sn = (float)(-P.w1.y);      // sin(omega)
+            const RT sn = (RT)(-P.w1.y);      // sin(omega)
             if (r == 0 && j0 == 0) {
-                B.xs[i] = f2{(float)(T.low ? 1.0 - P.w1.x : 1.0 + P.w1.x), sn};
-                if constexpr (NSUM == 3) B.us[i] = (float)(1.0 - P.w1.x);
+                B.xs[i] = P2{(RT)(T.low ? 1.0 - P.w1.x : 1.0 + P.w1.x), sn};
+                if constexpr (NSUM == 3) B.us[i] = (RT)(1.0 - P.w1.x);
             }
             if constexpr (RC) {
 #pragma unroll
                 for (int j = 0; j < JPT; ++j) {
-                    f2 gi = {0.f, 0.f};
+                    P2 gi = {(RT)0.0, (RT)0.0};
 #pragma unroll
-                    for (int nn = 0; nn < NIW; ++nn) gi = f2{P.gv[nn].x, P.gv[nn].y} * wrow[j][nn] + gi;
-                    const cx<float> h = valid ? P.hv[j] : cx<float>(0.f, 0.f);
-                    const bool live = valid && !(h.x == eps_of<float>() && h.y == 0.f);
-                    const cx<float> qv(gi.x * h.x + gi.y * h.y, gi.x * h.y - gi.y * h.x);      // conj(gi) h
-                    const cx<float> qz = live ? qv : cx<float>(0.f, 0.f);
-                    B.qs[(size_t)(r * PPR + j0 + j) * tbp + i] = f4{qz.x, qz.y, sn * qz.y, -(sn * qz.x)};
+                    for (int nn = 0; nn < NIW; ++nn) gi = P2{P.gv[nn].x, P.gv[nn].y} * wrow[j][nn] + gi;
+                    const cT h = valid ? P.hv[j] : cT((RT)0.0, (RT)0.0);
+                    const bool live = valid && !(h.x == eps_of<RT>() && h.y == (RT)0.0);
+                    const cT qv(gi.x * h.x + gi.y * h.y, gi.x * h.y - gi.y * h.x);      // conj(gi) h
+                    const cT qz = live ? qv : cT((RT)0.0, (RT)0.0);
+                    B.qs[(size_t)(r * PPR + j0 + j) * tbp + i] = P4{qz.x, qz.y, sn * qz.y, -(sn * qz.x)};
                     qsum[q][j] += qz.x;
 #pragma unroll
-                    for (int nn = 0; nn < NIW; ++nn) aw[j][nn] = f2{h.x, h.y} * f2{P.gv[nn].x, P.gv[nn].y} + aw[j][nn];
+                    for (int nn = 0; nn < NIW; ++nn) aw[j][nn] = P2{h.x, h.y} * P2{P.gv[nn].x, P.gv[nn].y} + aw[j][nn];
                 }
             } else if constexpr (OUTER) {
                 // row = output channel m, the PPR pairs of the row are its input channels n: dL/dG[m][n] = sum_b gY[b][m] conj(X[b][n])
                 const int f = T.f0 + (valid ? i : n - 1);
 #pragma unroll 4
                 for (int j = 0; j < PPR; ++j) {
-                    cx<float> gi(0.f, 0.f);
+                    cT gi((RT)0.0, (RT)0.0);
                     for (int bb = 0; bb < A.oB && bb < 2; ++bb) fma_cxc(gi, P.gv[bb], A.oX[(size_t)bb * A.o_xb + (size_t)j * A.o_xn + f]);
-                    const cx<float> h = P.hv[j];
-                    const bool live = valid && !(h.x == eps_of<float>() && h.y == 0.f);
-                    const cx<float> qv(gi.x * h.x + gi.y * h.y, gi.x * h.y - gi.y * h.x);
-                    const cx<float> qz = live ? qv : cx<float>(0.f, 0.f);
-                    B.qs[(size_t)(r * PPR + j) * tbp + i] = f4{qz.x, qz.y, sn * qz.y, -(sn * qz.x)};
+                    const cT h = P.hv[j];
+                    const bool live = valid && !(h.x == eps_of<RT>() && h.y == (RT)0.0);
+                    const cT qv(gi.x * h.x + gi.y * h.y, gi.x * h.y - gi.y * h.x);
+                    const cT qz = live ? qv : cT((RT)0.0, (RT)0.0);
+                    B.qs[(size_t)(r * PPR + j) * tbp + i] = P4{qz.x, qz.y, sn * qz.y, -(sn * qz.x)};
                     qsum[q][j] += qz.x;
                 }
             } else {
-                const cx<float> gi = P.gv[0], h = P.hv[0];
-                const bool live = valid && !(h.x == eps_of<float>() && h.y == 0.f);
-                const cx<float> qv(gi.x * h.x + gi.y * h.y, gi.x * h.y - gi.y * h.x);
-                const cx<float> qz = live ? qv : cx<float>(0.f, 0.f);
-                B.qs[(size_t)r * tbp + i] = f4{qz.x, qz.y, sn * qz.y, -(sn * qz.x)};
+                const cT gi = P.gv[0], h = P.hv[0];
+                const bool live = valid && !(h.x == eps_of<RT>() && h.y == (RT)0.0);
+                const cT qv(gi.x * h.x + gi.y * h.y, gi.x * h.y - gi.y * h.x);
+                const cT qz = live ? qv : cT((RT)0.0, (RT)0.0);
+                B.qs[(size_t)r * tbp + i] = P4{qz.x, qz.y, sn * qz.y, -(sn * qz.x)};
                 qsum[q][0] += qz.x;
             }
         }
@@ -328,21 +347,27 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
 
         // ---- lane-per-section work
         if (wave_on && !(A.skip & 2)) {
-            const f2 C0 = low ? C0lo : C0hi, C1 = low ? C1lo : -C1lo;
-            f2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
-            const f4* qrow = B.qs + (size_t)pl * tbp;
+            const P2 C0 = low ? C0lo : C0hi, C1 = low ? C1lo : -C1lo;
+            P2 t0 = {(RT)0.0, (RT)0.0}, t1 = {(RT)0.0, (RT)0.0}, t2 = {(RT)0.0, (RT)0.0};
+            const P4* qrow = B.qs + (size_t)pl * tbp;
 #pragma unroll 2
             for (int i = 0; i < np; i += 2) {
-                const f4 x4 = *reinterpret_cast<const f4*>(B.xs + i);
-                const f4 qA = qrow[i], qB = qrow[i + 1];
-                float u0 = 0.f, u1 = 0.f;
+                P4 x4;
+                if constexpr (sizeof(RT) == 4) {
+                    x4 = *reinterpret_cast<const P4*>(B.xs + i);
+                } else {
+                    const P2 xa = B.xs[i], xb = B.xs[i + 1];
+                    x4 = P4{xa.x, xa.y, xb.x, xb.y};
+                }
+                const P4 qA = qrow[i], qB = qrow[i + 1];
+                RT u0 = (RT)0.0, u1 = (RT)0.0;
                 if constexpr (NSUM == 3) {
-                    const f2 u2 = *reinterpret_cast<const f2*>(B.us + i);
+                    const P2 u2 = *reinterpret_cast<const P2*>(B.us + i);
                     u0 = u2.x;
                     u1 = u2.y;
                 }
-                lane_bin<NSUM>(C0, C1, C2, f2{x4.x, x4.y}, u0, f2{qA.x, qA.y}, f2{qA.z, qA.w}, t0, t1, t2);
-                lane_bin<NSUM>(C0, C1, C2, f2{x4.z, x4.w}, u1, f2{qB.x, qB.y}, f2{qB.z, qB.w}, t0, t1, t2);
+                lane_bin<NSUM, P2, RT>(C0, C1, C2, P2{x4.x, x4.y}, u0, P2{qA.x, qA.y}, P2{qA.z, qA.w}, t0, t1, t2);
+                lane_bin<NSUM, P2, RT>(C0, C1, C2, P2{x4.z, x4.w}, u1, P2{qB.x, qB.y}, P2{qB.z, qB.w}, t0, t1, t2);
             }
             // (no range test: an equaliser section has no zero on the sampling circle for finite positive gains -- B(1) = sqrt(g) (2 - 2 cos wc),
             // B(-1) = sqrt(g) (2 + 2 cos wc), the imaginary part g t sin(omega) -- and for a gain of exactly 0 the reference's own
@@ -367,10 +392,10 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
     (void)acc1;
     if (l_on) {
         static_assert(NSUM == 2, "the partials are one 16-byte record per (entry, block)");
-        reinterpret_cast<f4*>(A.psum)[((size_t)sl * C + c) * A.nbx + bx] = f4{acc0.x, acc0.y, acc2.x, acc2.y};
+        reinterpret_cast<P4*>(A.psum)[((size_t)sl * C + c) * A.nbx + bx] = P4{acc0.x, acc0.y, acc2.x, acc2.y};
     }
     {   // sum Re(q) per pair: the items' sums through LDS (the tile buffers are done with), one thread per pair adds its tb items
-        float* qred = reinterpret_cast<float*>(smem);      // [items][JPT]
+        RT* qred = reinterpret_cast<RT*>(smem);      // [items][JPT]
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < TRIPS; ++q)
@@ -382,7 +407,7 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
         __syncthreads();
         if (t < npb) {
             const int r = t / (JPT * JG), jr = t - r * (JPT * JG), jg = jr / JPT, jj = jr - jg * JPT;
-            float tot = 0.f;
+            RT tot = (RT)0.0;
             for (int i = 0; i < A.tb; ++i) tot += qred[(size_t)((r * A.tb + i) * JG + jg) * JPT + jj];
             A.pq[(size_t)(cg * npb + t) * A.nbx + bx] = tot;
         }
@@ -390,16 +415,16 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
     if constexpr (RC) {
         // dL/dW partials: every item thread's JPT x NIW sums through LDS, then one thread per entry adds the items of its pair
         // group in a fixed order: one (PPR, NIW) matrix per workgroup
-        float* wred = reinterpret_cast<float*>(smem);      // [threads][JPT * NIW]  (the tile buffers are done with: reuse)
+        RT* wred = reinterpret_cast<RT*>(smem);      // [threads][JPT * NIW]  (the tile buffers are done with: reuse)
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < JPT; ++j)
 #pragma unroll
-            for (int nn = 0; nn < NIW; ++nn) wred[(size_t)t * (JPT * NIW) + j * NIW + nn] = it_r[0] >= 0 ? aw[j][nn].x + aw[j][nn].y : 0.f;
+            for (int nn = 0; nn < NIW; ++nn) wred[(size_t)t * (JPT * NIW) + j * NIW + nn] = it_r[0] >= 0 ? aw[j][nn].x + aw[j][nn].y : (RT)0.0;
         __syncthreads();
         if (t < PPR * NIW) {
             const int j = t / NIW, nn = t - j * NIW, jg = j / JPT, jj = j - jg * JPT;
-            float tot = 0.f;
+            RT tot = (RT)0.0;
             const int nit = A.tb * A.rows;      // items of one pair group
             for (int u = 0; u < nit; ++u) tot += wred[(size_t)(jg + JG * u) * (JPT * NIW) + jj * NIW + nn];
             A.partW[(size_t)t * (A.nbx * gridDim.y) + (size_t)bx * gridDim.y + cg] = tot;
@@ -412,18 +437,20 @@ __global__ void __launch_bounds__(768, 3) sos_bwd_lanes_kernel(const LanesArgs A
 // deterministic); the first lane recovers G1 from sum Re(t P~) = Q, forms the six tap gradients as the first-generation kernel's epilogue does
 // (d/db0 = G0 - G1 - G2, d/db1 = g G0, d/db2 = g^2 (G0 - G1 + G2)) and runs the design's backward (geq_design_bwd).  Band 0
 // is the pure gain: d/db0 = Q / b0.  Tail blocks: gW[e] = sum of the constant factor's partials, as geq_sections_bwd_kernel.
+template <typename T>
 __global__ void __launch_bounds__(256) geq_bwd_lanes_kernel(const void* __restrict__ gain, int in_kind,
-                                                            const float* __restrict__ psum, const float* __restrict__ pq, int nbx,
+                                                            const T* __restrict__ psum, const T* __restrict__ pq, int nbx,
                                                             const double* __restrict__ b, const double* __restrict__ a, double gam,
                                                             int nb, int C, const double* __restrict__ k, void* __restrict__ ggain,
-                                                            int main_blocks, int epb, const float* __restrict__ partW, int wrows,
-                                                            int wn, float* __restrict__ gW) {
+                                                            int main_blocks, int epb, const T* __restrict__ partW, int wrows,
+                                                            int wn, T* __restrict__ gW) {
+    typedef typename Vec<T>::v4 P4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if ((int)blockIdx.x >= main_blocks) {
         // gW[e] = sum_r partW[e][r]: one wavefront per entry, the lanes stride over the (contiguous) rows, fixed butterfly
         const int e = ((int)blockIdx.x - main_blocks) * 4 + wave;
         if (e >= wn) return;
-        float v = 0.f;
+        T v = (T)0;
 #pragma unroll 4
         for (int r = lane; r < wrows; r += 64) v += partW[(size_t)e * wrows + r];
 #pragma unroll
@@ -452,12 +479,12 @@ __global__ void __launch_bounds__(256) geq_bwd_lanes_kernel(const void* __restri
     }
     double v[5] = {0, 0, 0, 0, 0};
     const int per = (nbx + W - 1) / W, b0 = part * per, b1 = min(nbx, b0 + per);
-    const f4* ps4 = reinterpret_cast<const f4*>(psum) + (size_t)idx * nbx;
+    const P4* ps4 = reinterpret_cast<const P4*>(psum) + (size_t)idx * nbx;
     if (on) {
 #pragma unroll 4
         for (int bx = b0 + lane; bx < b1; bx += 64) {
             if (band > 0) {
-                const f4 r4 = ps4[bx];
+                const P4 r4 = ps4[bx];
                 v[0] += (double)r4.x; v[1] += (double)r4.y; v[2] += (double)r4.z; v[3] += (double)r4.w;
             }
             v[4] += (double)pq[(size_t)c * nbx + bx];
@@ -491,10 +518,10 @@ __global__ void __launch_bounds__(256) geq_bwd_lanes_kernel(const void* __restri
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const double t0 = tap[i][0], t1 = tap[i][1], t2 = tap[i][2];
-            const double Sg = t0 + gam * gam * t2, T = gam * t1, D = t0 - gam * gam * t2;
+            const double Sg = t0 + gam * gam * t2, Tg = gam * t1, D = t0 - gam * gam * t2;
             const double sgn = i ? -1.0 : 1.0;
             const double G0 = sgn * v[i], G2 = sgn * v[2 + i];
-            const double G1 = ((Sg + T) * G0 - D * G2 - sgn * Q) / Sg;
+            const double G1 = ((Sg + Tg) * G0 - D * G2 - sgn * Q) / Sg;
             out[i][0] = G0 - G1 - G2;
             out[i][1] = gam * G0;
             out[i][2] = gam * gam * (G0 - G1 + G2);
@@ -734,17 +761,20 @@ static int lanes_cus() {
 }
 
 // mode: 0 plain (ppr = 1), 1 constant factor (ppr = N_mid, niw columns), 2 outer (ppr = N_in)
-static LanesPlan lanes_plan(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw, int mode) {
+// esz: bytes of the kernels' real type (4: float, 8: double -- half the lanes per workgroup, twice the LDS per value)
+static LanesPlan lanes_plan(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw, int mode, int esz = 4) {
     LanesPlan P{};
+    const int max_threads = esz == 8 ? 384 : 768, sc = esz / 4;
     if (!g_lanes || S < 4 || S > 64 || C < 1 || m_local < 1 || ppr < 1 || C % ppr) return P;
     if (mode == 1 && !((niw == 8 && ppr == 8) || (niw == 4 && ppr == 4) || (niw == 2 && ppr == 2) || (niw == 16 && ppr == 16))) return P;
     if (mode == 2 && !(ppr == 8 || ppr == 16 || ppr == 32)) return P;
+    if (esz == 8 && (mode == 2 || (mode == 1 && niw >= 16))) return P;      // (double: sixteen cotangent rows per item spill)
     if (bin0 < 0 && ((-bin0) % 2 || (nfft / 2) % (-bin0) || m_local != nfft / 2 + 1)) return P;
     P.seff = S - 1;
     P.s_first = 1;
     // pairs per block: whole rows, a divisor of C, as many as 768 lanes take
     int npb = 0;
-    for (int cand = ppr; cand <= C && cand * P.seff <= 768; cand += ppr)
+    for (int cand = ppr; cand <= C && cand * P.seff <= max_threads; cand += ppr)
         if (C % cand == 0) npb = cand;
     if (!npb || npb * P.seff < 48) return P;      // (tiny cascades: a lane per bin serves them better)
     P.npb = npb;
@@ -754,12 +784,15 @@ static LanesPlan lanes_plan(int m_local, int C, int S, int nfft, int bin0, int p
     const int nw = P.threads / 64;
     P.tpw = 1;
     // items of the lane-per-bin work per tile element: rows x groups of pairs -- at most one item per thread (plain mode: four)
-    const int jpt = mode == 1 ? (niw >= 16 ? 1 : (ppr >= 2 ? 2 : ppr)) : ppr;
+    const int jpt = mode == 1 ? ((niw >= 16 || esz == 8) ? 1 : (ppr >= 2 ? 2 : ppr)) : ppr;
     const int per_elem = mode == 0 ? P.rows : P.rows * (ppr / jpt);
     const int tb_max = (mode == 0 ? 4 * P.threads : P.threads) / per_elem;
     if (tb_max < 8) return P;
     int bpc = g_lanes_bpc > 0 ? g_lanes_bpc : 12 / nw;      // (the kernel is built for three wavefronts per SIMD: 12 per CU)
     if (bpc * nw > 12) bpc = 12 / nw;
+    // double: 213 registers with eight cotangent rows, i.e. two wavefronts per SIMD and ONE six-wavefront workgroup per CU (93 us at
+    // config 2 against 131 for the lane-per-bin kernel; built for three per SIMD it spills 53 registers: 213 us)
+    if (esz == 8) bpc = 1;
     if (bpc < 1) bpc = 1;
     const int slots = lanes_cus() * bpc;
     int nbx_target = slots / P.ng;
@@ -800,19 +833,21 @@ static LanesPlan lanes_plan(int m_local, int C, int S, int nfft, int bin0, int p
     P.nbx = P.ntiles < nbx_target ? P.ntiles : nbx_target;
     const int npad = (P.tb + 1) & ~1;
     P.tbp = npad + 1;      // pitch = 16 bytes x odd: the lanes' rows fall on different banks
-    P.lds1 = (size_t)P.npb * P.tbp * 16 + (size_t)(P.tbp + 1) * 8 + (size_t)((P.tbp + 3) & ~3) * 4;
+    P.lds1 = ((size_t)P.npb * P.tbp * 16 + (size_t)(P.tbp + 1) * 8 + (size_t)((P.tbp + 3) & ~3) * 4) * sc;
+    P.lds1 = (P.lds1 + 31) & ~(size_t)31;
     {
         const size_t items = mode == 0 ? (size_t)P.tb * P.rows : (size_t)P.threads;
-        const size_t need = items * (mode == 1 ? jpt * (niw > 1 ? niw : 1) : jpt) * 4;      // (the epilogue's reductions reuse the buffers)
-        if (2 * P.lds1 < need) P.lds1 = (need + 31) / 32 * 16;
+        const size_t need = items * (mode == 1 ? jpt * (niw > 1 ? niw : 1) : jpt) * 4 * sc;      // (the epilogue's reductions reuse the buffers)
+        if (2 * P.lds1 < need) P.lds1 = (need + 63) / 64 * 32;
     }
     if (2 * P.lds1 > lanes_lds_limit()) return P;
-    if ((size_t)C * (size_t)m_local * 8 >= (1ull << 32)) return P;      // (32-bit byte offsets into the response / cotangent planes)
+    if ((size_t)C * (size_t)m_local * 8 * sc >= (1ull << 32)) return P;      // (32-bit byte offsets into the response / cotangent planes)
     P.ok = 1;
     return P;
 }
 
-static void lanes_fill(LanesArgs& A, const LanesPlan& P) {
+template <typename T>
+static void lanes_fill(LanesArgs<T>& A, const LanesPlan& P) {
     A.npb = P.npb; A.rows = P.rows; A.seff = P.seff; A.s_first = P.s_first; A.tb = P.tb; A.tbp = P.tbp; A.ntiles = P.ntiles;
     A.tph = P.tph; A.half = P.half; A.L1 = P.L1; A.nlow = P.nlow; A.tiles_low = P.tiles_low; A.nbx = P.nbx;
     A.lds1 = (int)P.lds1;
@@ -845,31 +880,41 @@ int fl_geq_bwd_lanes_wrows(int m_local, int C, int S, int nfft, int bin0, int pp
     const LanesPlan P = lanes_plan(m_local, C, S, nfft, bin0, ppr, niw, 1);
     return P.ok ? P.nbx * P.ng : 0;
 }
+int fl_geq_bwd_lanes_wrows_f64(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw) {
+    const LanesPlan P = lanes_plan(m_local, C, S, nfft, bin0, ppr, niw, 1, 8);
+    return P.ok ? P.nbx * P.ng : 0;
+}
 
 int fl_geq_bwd_lanes_blocks(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw, int mode) {
     const LanesPlan P = lanes_plan(m_local, C, S, nfft, bin0, ppr, niw, mode);
     return P.ok ? P.nbx : 0;
 }
+int fl_geq_bwd_lanes_blocks_f64(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw, int mode) {
+    const LanesPlan P = lanes_plan(m_local, C, S, nfft, bin0, ppr, niw, mode, 8);
+    return P.ok ? P.nbx : 0;
+}
+}  // extern "C"
 
 // mode 0: gH planes c (C = channel pairs); mode 1: gH planes (m * Ni + n), G planes (m * Nmid + j), Wr (Nmid, Ni), partW out
-int fl_geq_response_bwd_lanes_c64(int mode, const void* gH, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
-                                  int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,
-                                  int bin0, int m_local, void* psum, void* pq, void* partW, void* stream) {
+template <typename T>
+static int lanes_bwd_impl(int mode, const void* gH, long g_pitch, const void* G, long h_pitch, const void* b, const void* a, int S, int No,
+                          int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft, int bin0, int m_local, void* psum,
+                          void* pq, void* partW, void* stream) {
     FL_REQUIRE(mode == 0 || mode == 1, "geq_response_bwd_lanes: mode 0 (plain) or 1 (constant factor)");
     FL_REQUIRE(gH && G && b && a && Wd && psum && pq, "geq_response_bwd_lanes: null pointer");
     FL_REQUIRE(mode == 0 || (Wr && partW), "geq_response_bwd_lanes: the constant-factor mode needs Wr and partW");
     FL_REQUIRE(g_pitch >= m_local && h_pitch >= m_local, "geq_response_bwd_lanes: pitches must be >= m_local");
     const int C = No * Nmid, ppr = mode == 1 ? Nmid : 1;
-    const LanesPlan P = lanes_plan(m_local, C, S, nfft, bin0, ppr, Ni, mode);
+    const LanesPlan P = lanes_plan(m_local, C, S, nfft, bin0, ppr, Ni, mode, (int)sizeof(T));
     if (!P.ok) {
         set_error("geq_response_bwd_lanes: unsupported shape (ask fl_geq_bwd_lanes_blocks first)");
         return FL_ERR_UNSUPPORTED;
     }
-    LanesArgs A{};
+    LanesArgs<T> A{};
     A.b = (const double*)b; A.a = (const double*)a; A.S = S; A.C = C; A.g = gamma; A.Wd = (const cx<double>*)Wd;
-    A.nfft = nfft; A.bin0 = bin0; A.m_local = m_local; A.gH = (const cx<float>*)gH; A.g_pitch = g_pitch;
-    A.G = (const cx<float>*)G; A.h_pitch = h_pitch; A.Wr = (const float*)Wr; A.psum = (float*)psum; A.pq = (float*)pq;
-    A.partW = (float*)partW;
+    A.nfft = nfft; A.bin0 = bin0; A.m_local = m_local; A.gH = (const cx<T>*)gH; A.g_pitch = g_pitch;
+    A.G = (const cx<T>*)G; A.h_pitch = h_pitch; A.Wr = (const T*)Wr; A.psum = (T*)psum; A.pq = (T*)pq;
+    A.partW = (T*)partW;
     A.stamps = g_lanes_stamps;
     A.skip = g_lanes_skip;
     lanes_fill(A, P);
@@ -878,7 +923,7 @@ int fl_geq_response_bwd_lanes_c64(int mode, const void* gH, long g_pitch, const 
 #define FL_LANES(NIW_, PPR_)                                                                                                     \
     {                                                                                                                            \
         static bool done[16] = {};                                                                                               \
-        auto kern = sos_bwd_lanes_kernel<NIW_, PPR_, 2, false>;                                                                  \
+        auto kern = sos_bwd_lanes_kernel<T, NIW_, PPR_, 2, false>;                                                               \
         const int rc_ = lanes_ensure_lds(reinterpret_cast<const void*>(kern), lds, done);                                        \
         if (rc_) return rc_;                                                                                                     \
         hipLaunchKernelGGL(kern, grid, block, lds, (hipStream_t)stream, A);                                                      \
@@ -893,20 +938,43 @@ int fl_geq_response_bwd_lanes_c64(int mode, const void* gH, long g_pitch, const 
     return FL_OK;
 }
 
-// psum / pq as left by fl_geq_response_bwd_lanes_c64 (nbx = fl_geq_bwd_lanes_blocks), b / a the designed taps -> ggain in the
+// psum / pq as left by the kernel above (nbx = fl_geq_bwd_lanes_blocks), b / a the designed taps -> ggain in the
 // parameter's dtype (in_kind); wn > 0: gW[e] = sum_r partW[r * wn + e], r < wrows
-int fl_geq_sections_bwd_lanes(const void* gain, int in_kind, const void* psum, const void* pq, int nbx, const void* b, const void* a,
-                              double gamma, int nb, int C, const void* consts, void* ggain, const void* partW, int wrows, int wn,
-                              void* gW, void* stream) {
+template <typename T>
+static int lanes_sections_bwd_impl(const void* gain, int in_kind, const void* psum, const void* pq, int nbx, const void* b, const void* a,
+                                   double gamma, int nb, int C, const void* consts, void* ggain, const void* partW, int wrows, int wn,
+                                   void* gW, void* stream) {
     FL_REQUIRE(gain && psum && pq && b && a && consts && ggain, "geq_sections_bwd_lanes: null pointer");
     FL_REQUIRE(in_kind >= 0 && in_kind <= 4 && nb >= 4 && C > 0 && nbx > 0, "geq_sections_bwd_lanes: bad sizes");
     FL_REQUIRE(wn == 0 || (partW && gW && wrows > 0), "geq_sections_bwd_lanes: bad constant-factor partials");
     const int epb = nbx > 512 ? 1 : nbx > 256 ? 2 : 4;      // entries per workgroup: 4 / 2 / 1 wavefronts per entry
     const int main_blocks = cdiv_i((long)nb * C, epb);
-    hipLaunchKernelGGL(geq_bwd_lanes_kernel, dim3(main_blocks + cdiv_i(wn, 4)), dim3(256), 0, (hipStream_t)stream, gain, in_kind,
-                       (const float*)psum, (const float*)pq, nbx, (const double*)b, (const double*)a, gamma, nb, C,
-                       (const double*)consts, ggain, main_blocks, epb, (const float*)partW, wrows, wn, (float*)gW);
+    hipLaunchKernelGGL(geq_bwd_lanes_kernel<T>, dim3(main_blocks + cdiv_i(wn, 4)), dim3(256), 0, (hipStream_t)stream, gain, in_kind,
+                       (const T*)psum, (const T*)pq, nbx, (const double*)b, (const double*)a, gamma, nb, C,
+                       (const double*)consts, ggain, main_blocks, epb, (const T*)partW, wrows, wn, (T*)gW);
     FL_CHECK_LAUNCH("geq_sections_bwd_lanes");
     return FL_OK;
+}
+
+extern "C" {
+int fl_geq_response_bwd_lanes_c64(int mode, const void* gH, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
+                                  int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,
+                                  int bin0, int m_local, void* psum, void* pq, void* partW, void* stream) {
+    return lanes_bwd_impl<float>(mode, gH, g_pitch, G, h_pitch, b, a, S, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, psum, pq, partW, stream);
+}
+int fl_geq_response_bwd_lanes_c128(int mode, const void* gH, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
+                                   int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,
+                                   int bin0, int m_local, void* psum, void* pq, void* partW, void* stream) {
+    return lanes_bwd_impl<double>(mode, gH, g_pitch, G, h_pitch, b, a, S, No, Nmid, Ni, Wr, gamma, Wd, nfft, bin0, m_local, psum, pq, partW, stream);
+}
+int fl_geq_sections_bwd_lanes(const void* gain, int in_kind, const void* psum, const void* pq, int nbx, const void* b, const void* a,
+                              double gamma, int nb, int C, const void* consts, void* ggain, const void* partW, int wrows, int wn,
+                              void* gW, void* stream) {
+    return lanes_sections_bwd_impl<float>(gain, in_kind, psum, pq, nbx, b, a, gamma, nb, C, consts, ggain, partW, wrows, wn, gW, stream);
+}
+int fl_geq_sections_bwd_lanes_f64(const void* gain, int in_kind, const void* psum, const void* pq, int nbx, const void* b, const void* a,
+                                  double gamma, int nb, int C, const void* consts, void* ggain, const void* partW, int wrows, int wn,
+                                  void* gW, void* stream) {
+    return lanes_sections_bwd_impl<double>(gain, in_kind, psum, pq, nbx, b, a, gamma, nb, C, consts, ggain, partW, wrows, wn, gW, stream);
 }
 }  // extern "C"

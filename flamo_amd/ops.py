@@ -2068,38 +2068,39 @@ def _cascade_rc_backward(gH, G, b, a, Wr, cfg):
 def _geq_lanes_blocks(cfg, ppr: int, niw: int, mode: int) -> int:
     """bin blocks of the lanes-per-section backward (csrc/cascade2.hip) for this shape, 0 when it does not take it"""
     gamma, nfft, S, C_, bin0, m_local, real = cfg
-    if real != torch.float32 or not SOS_BWD_MIXED:
+    if not SOS_BWD_MIXED:
         return 0
-    return int(_lib.lib().fl_geq_bwd_lanes_blocks(m_local, C_, S, nfft, bin0, int(ppr), int(niw), int(mode)))
+    fn = _lib.lib().fl_geq_bwd_lanes_blocks if real == torch.float32 else _lib.lib().fl_geq_bwd_lanes_blocks_f64
+    return int(fn(m_local, C_, S, nfft, bin0, int(ppr), int(niw), int(mode)))
 
 
 def _geq_backward_lanes(mode, gH, G, b, a, Wr, cfg, No, Nmid, Ni, nbx, xc, consts, sig):
-    """graphic equaliser, float32: cascade backward with one lane per (pair, section) + the launch that reduces its block
+    """graphic equaliser, float32 / float64: cascade backward with one lane per (pair, section) + the launch that reduces its block
     partials and runs the design's backward.  -> (dL/dx in x's dtype, dL/dWr or None)"""
     gamma, nfft, S, C_, bin0, m_local, real = cfg
     dev = b.device
     g = _h_planar(gH.resolve_conj(), True)
     L = _lib.lib()
-    psum = torch.empty((S * C_, nbx, 4), dtype=torch.float32, device=dev)      # (band 0's entries stay unwritten and unread: closed form from pq)
-    pq = torch.empty((C_, nbx), dtype=torch.float32, device=dev)
+    f64 = real == torch.float64
+    psum = torch.empty((S * C_, nbx, 4), dtype=real, device=dev)      # (band 0's entries stay unwritten and unread: closed form from pq)
+    pq = torch.empty((C_, nbx), dtype=real, device=dev)
     # per workgroup (bin block x pair group) ONE (Nmid, Ni) matrix, summed over the group's output channels already
-    wrows = L.fl_geq_bwd_lanes_wrows(m_local, C_, S, nfft, bin0, Nmid, Ni) if mode == 1 else 0
-    partW = torch.empty((Nmid * Ni, wrows), dtype=torch.float32, device=dev) if mode == 1 else None
-    Wc = Wr.contiguous() if mode == 1 else None
+    wrows = (L.fl_geq_bwd_lanes_wrows_f64 if f64 else L.fl_geq_bwd_lanes_wrows)(m_local, C_, S, nfft, bin0, Nmid, Ni) if mode == 1 else 0
+    partW = torch.empty((Nmid * Ni, wrows), dtype=real, device=dev) if mode == 1 else None
+    Wc = Wr.to(real).contiguous() if mode == 1 else None
     with kernel_timer.span("sos_response_bwd_rc" if mode == 1 else "sos_response_bwd"):
-        _lib.check(L.fl_geq_response_bwd_lanes_c64(mode, g.data_ptr(), _lead_pitch(g.movedim(0, -1)), G.data_ptr(), _pitch(m_local),
-                                                   b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni,
-                                                   None if Wc is None else Wc.data_ptr(), gamma,
-                                                   twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local,
-                                                   psum.data_ptr(), pq.data_ptr(), None if partW is None else partW.data_ptr(),
-                                                   _stream()), "geq_response_bwd_lanes")
+        _lib.check((L.fl_geq_response_bwd_lanes_c128 if f64 else L.fl_geq_response_bwd_lanes_c64)(
+            mode, g.data_ptr(), _lead_pitch(g.movedim(0, -1)), G.data_ptr(), _pitch(m_local), b.data_ptr(), a.data_ptr(), S, No, Nmid, Ni,
+            None if Wc is None else Wc.data_ptr(), gamma, twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local,
+            psum.data_ptr(), pq.data_ptr(), None if partW is None else partW.data_ptr(), _stream()), "geq_response_bwd_lanes")
     out = torch.empty_like(xc)
-    gW = torch.empty_like(Wr, memory_format=torch.contiguous_format) if mode == 1 else None
-    _lib.check(L.fl_geq_sections_bwd_lanes(xc.data_ptr(), _geq_in_kind(xc, True, sig), psum.data_ptr(), pq.data_ptr(), nbx,
-                                           b.data_ptr(), a.data_ptr(), gamma, S, C_, consts.data_ptr(), out.data_ptr(),
-                                           None if partW is None else partW.data_ptr(), wrows,
-                                           Nmid * Ni if mode == 1 else 0, None if gW is None else gW.data_ptr(), _stream()),
-               "geq_sections_bwd_lanes")
+    gW = torch.empty(Wr.shape, dtype=real, device=dev) if mode == 1 else None
+    _lib.check((L.fl_geq_sections_bwd_lanes_f64 if f64 else L.fl_geq_sections_bwd_lanes)(
+        xc.data_ptr(), _geq_in_kind(xc, True, sig), psum.data_ptr(), pq.data_ptr(), nbx, b.data_ptr(), a.data_ptr(), gamma, S, C_,
+        consts.data_ptr(), out.data_ptr(), None if partW is None else partW.data_ptr(), wrows, Nmid * Ni if mode == 1 else 0,
+        None if gW is None else gW.data_ptr(), _stream()), "geq_sections_bwd_lanes")
+    if gW is not None and gW.dtype != Wr.dtype:
+        gW = gW.to(Wr.dtype)
     return out, gW
 
 

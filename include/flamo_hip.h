@@ -449,6 +449,18 @@ int fl_geq_response_bwd_lanes_c64(int mode, const void* gH, long g_pitch, const 
 int fl_geq_sections_bwd_lanes(const void* gain, int in_kind, const void* psum, const void* pq, int nbx, const void* b, const void* a,
                               double gamma, int nb, int C, const void* consts, void* ggain, const void* partW, int wrows, int wn,
                               void* gW, void* stream);
+/* The same pair in double precision (round 5; float64 modules, the reference examples' default dtype): gH, G complex128, Wr,
+ * psum, pq, partW, gW double; half the lanes per workgroup.  Two v_fma_f64 per packed float instruction cost the SAME issue
+ * time, so the float64 cascade backward runs at the float32 one's speed (the lane-per-bin double kernel takes 3x as long).
+ * 2 / 4 / 8 constant-factor columns (16 would spill: fl_geq_bwd_lanes_blocks_f64 answers 0 and the first generation serves). */
+int fl_geq_bwd_lanes_blocks_f64(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw, int mode);
+int fl_geq_bwd_lanes_wrows_f64(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw);
+int fl_geq_response_bwd_lanes_c128(int mode, const void* gH, long g_pitch, const void* G, long h_pitch, const void* b, const void* a,
+                                   int S, int No, int Nmid, int Ni, const void* Wr, double gamma, const void* Wd, int nfft,
+                                   int bin0, int m_local, void* psum, void* pq, void* partW, void* stream);
+int fl_geq_sections_bwd_lanes_f64(const void* gain, int in_kind, const void* psum, const void* pq, int nbx, const void* b, const void* a,
+                                  double gamma, int nb, int C, const void* consts, void* ggain, const void* partW, int wrows, int wn,
+                                  void* gW, void* stream);
 /* test / tuning hook: on = 0 routes every cascade through the first-generation kernels; blocks_per_cu, tile_bins >= 0 set
  * the grid's sizing (negative: unchanged).  Returns the previous `on`. */
 int fl_debug_set_cascade_lanes(int on, int blocks_per_cu, int tile_bins);

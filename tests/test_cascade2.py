@@ -54,7 +54,11 @@ def test_lanes_backward_rc_matches_first_generation(gpu, nfft, N, db, row_major)
         H0, gx0, gW0 = _grads_rc(geq, W, nfft, row_major, 3)
     finally:
         _lanes(prev)
-    Hd, gxd, gWd = _grads_rc(geq, W, nfft, row_major, 3, f64=True)
+    prev = _lanes(0)                 # the yardstick: the all-double lane-per-bin kernels (the float64 operator's first generation)
+    try:
+        Hd, gxd, gWd = _grads_rc(geq, W, nfft, row_major, 3, f64=True)
+    finally:
+        _lanes(prev)
     # (the second-generation forward evaluates the same cascade with numerator and denominator packed: same float accuracy)
     check_close(f"lanes_rc/{nfft}_{N}_{int(db)}_{int(row_major)}/H", H1, Hd, 1e-6)
     check_close(f"lanes_rc/{nfft}_{N}_{int(db)}_{int(row_major)}/H_gen1", H0, Hd, 1e-6)
@@ -112,3 +116,71 @@ def test_lanes_backward_plain_matches_first_generation(gpu, nfft, N, shard, sig)
     e0 = relerr(g0, gd)
     print(f"\n{tag}: gain gradient vs all-double: lanes {relerr(g1, gd):.2e}, first generation {e0:.2e}")
     check_close(tag + "/g_gain", g1, gd, max(3e-6, 2 * e0))
+
+
+@pytest.mark.parametrize("row_major", [True, False])
+@pytest.mark.parametrize("nfft,N,db", [(96000, 8, 0.0), (96000, 8, 30.0), (4096, 4, 30.0), (24000, 2, 0.0)])
+def test_lanes_backward_rc_float64_matches_first_generation(gpu, nfft, N, db, row_major):
+    """the same pair in float64 (the reference examples' default dtype): the double lanes kernels (fl_geq_response_bwd_lanes_c128)
+    against the all-double lane-per-bin kernels, same operator, same cotangent -- 1e-10"""
+    from flamo_amd import _lib
+    from flamo_amd.processor import dsp
+    if row_major and nfft == 4096:
+        pytest.skip("row-major order is the fused pipeline's (walking shapes)")
+    torch.manual_seed(5)
+    geq = dsp.GEQ(size=(N, N), nfft=nfft, alias_decay_db=db, device=gpu, dtype=torch.float64)
+    W = torch.randn(N, N, device=gpu, dtype=torch.float64)
+    M = nfft // 2 + 1
+    if _lib.lib().fl_geq_bwd_lanes_blocks_f64(M, N * N, 12, nfft, 0, N, N, 1) == 0:
+        pytest.skip("shape not taken by the double lanes kernel")
+    prev = _lanes(1)
+    try:
+        H1, gx1, gW1 = _grads_rc(geq, W, nfft, row_major, 3, f64=True)
+        _lanes(0)
+        H0, gx0, gW0 = _grads_rc(geq, W, nfft, row_major, 3, f64=True)
+    finally:
+        _lanes(prev)
+    tag = f"lanes_rc_f64/{nfft}_{N}_{int(db)}_{int(row_major)}"
+    check_close(tag + "/H", H1, H0, 1e-12)
+    check_close(tag + "/g_gain", gx1, gx0, 1e-10)
+    check_close(tag + "/g_W", gW1, gW0, 1e-10)
+
+
+@pytest.mark.parametrize("sig", [False, True])
+@pytest.mark.parametrize("nfft,N,shard", [(192000, 16, None), (192000, 16, (12001, 12000)), (1500, 6, None)])
+def test_lanes_backward_plain_float64_matches_first_generation(gpu, nfft, N, shard, sig):
+    """parallelGEQ in float64: plain mode of the double lanes kernel against the all-double lane-per-bin kernel"""
+    from flamo_amd import _lib, ops
+    from flamo_amd.processor import dsp
+    torch.manual_seed(7)
+    kw = dict(nfft=nfft, alias_decay_db=30.0, device=gpu, dtype=torch.float64)
+    geq = dsp.parallelGEQ(size=(N,), map=dsp.db_of_sigmoid, **kw) if sig else dsp.parallelGEQ(size=(N,), **kw)
+    if sig:
+        geq.assign_value(torch.randn_like(geq.param) + 2.0)
+
+    def run():
+        x = geq.param.detach().clone().requires_grad_(True)
+        spec = geq._cascade_spec(x)
+        if shard is not None:
+            ops.set_bin_shard(*shard)
+        try:
+            H = ops.geq_cascade(spec[1], spec[2], geq._gamma_f, nfft, dtype=torch.float64, gain_map=spec[3] if len(spec) > 3 else "abs")
+            g = torch.Generator(device=H.device).manual_seed(11)
+            ct = torch.randn(H.shape, generator=g, device=H.device, dtype=torch.float64) + 1j * torch.randn(H.shape, generator=g, device=H.device, dtype=torch.float64)
+            (H * ct.conj()).real.sum().backward()
+        finally:
+            ops.set_bin_shard(0, None)
+        return H.detach(), x.grad.detach()
+
+    M = nfft // 2 + 1 if shard is None else shard[1]
+    if _lib.lib().fl_geq_bwd_lanes_blocks_f64(M, N, 12, nfft, 0 if shard is None else shard[0], 1, 0, 0) == 0:
+        pytest.skip("shape not taken by the double lanes kernel")
+    prev = _lanes(1)
+    try:
+        H1, g1 = run()
+        _lanes(0)
+        H0, g0 = run()
+    finally:
+        _lanes(prev)
+    assert H1.dtype == torch.complex128 and torch.equal(H1, H0)
+    check_close(f"lanes_plain_f64/{nfft}_{N}_{'shard' if shard else 'all'}_{int(sig)}/g_gain", g1, g0, 1e-10)
