@@ -48,6 +48,10 @@ _SIGNATURES = {
     "fl_debug_set_spec_times": (_i, [_vp]),
     "fl_spec_cols_fwd_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _vp]),
     "fl_spec_cols_fwd_f64": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _d, _vp]),
+    "fl_spec_gradh_loop_supports_f32": (_i, [_i, _i, _i]),
+    "fl_spec_gradh_loop_supports_f64": (_i, [_i, _i, _i]),
+    "fl_spec_gradh_loop_f32": (_i, [_vp, _vp, _l, _l, _vp, _l, _l, _vp, _i, _i, _i, _i, _d, _i, _d, _vp, _vp]),
+    "fl_spec_gradh_loop_f64": (_i, [_vp, _vp, _l, _l, _vp, _l, _l, _vp, _i, _i, _i, _i, _d, _i, _d, _vp, _vp]),
     "fl_spec_mid_f32": (_i, [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "fl_spec_mid_f64": (_i, [_vp, _vp, _vp, _l, _l, _vp, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _i, _vp]),
     "fl_spec_walk_supports": (_i, [_i, _i, _i]),

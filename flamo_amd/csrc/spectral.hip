@@ -629,6 +629,271 @@ __global__ void __launch_bounds__(256 * NTH, ((NTH == 2 && MS == 1) || P3V == 1 
     if (a.dbg_times && tid == 0) a.dbg_times[(size_t)blockIdx.x * 8 + 5] = clock64();
 }
 
+// ---------------------------------------------------------------- backward: dL/dH without the gradient's spectrum in HBM
+// dH[m][n][i] = sum_b gY[b][m][i] conj(X[b][n][i]) for the shapes and precisions the batch-walking kernels of specwalk.hip do not
+// take (float64 -- the reference examples' default dtype --, fewer than four batch items).  The layered form is two launches:
+// spec_mid without a response turns the gradient's scratch rows into its spectrum (one read + one write of the signal), then
+// fl_mimo_gradh reads that spectrum and the kept one (two reads): 4.25 signal passes.  Here a workgroup owns (row pair,
+// output-channel group) and WALKS THE BATCH: per item the row FFTs of its NOL gradient channels (P1, P2 as in spec_mid), the
+// split step in registers, and the outer product with the kept spectrum accumulated in registers -- thread (bin pair p, half
+// ms) holds dH[2 bins][NOL / 2][NI]; 2.25 passes, no atomics, the sum over the batch in a fixed order.
+// Both operands of an item arrive by LDS-DMA (global_load_lds_dwordx4, no register round trip: in double the accumulators are
+// half of the register file and a register prefetch of the rows spilled -- 1.0 ms): the gradient rows of item b+1 are in flight
+// while item b runs its second stage and its products, the kept spectrum of item b+1 while item b+1 runs its two FFT stages.
+// One residue class of a size-R transform, out[k] = X[S k + E], from all R inputs (decimation in frequency by S: S threads share
+// a transform and each keeps R / S values -- a quarter of the registers of the whole transform in one thread, which is what lets
+// the double-precision accumulators below stay in registers)
+template <typename T, int R, int S, int E, typename LD>
+__device__ __forceinline__ void fft_residue(LD ld, cx<T> (&y)[R / S]) {
+    constexpr int Q = R / S;
+    constexpr TwTab<R> tw = TwTab<R>();
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+        cx<T> acc = ld(j);
+#pragma unroll
+        for (int s = 1; s < S; ++s) {
+            const int m = ((s * E) % S) * Q;                    // W_S^(sE) = W_R^(Q s E)
+            const cx<T> x = ld(j + s * Q);
+            if (m == 0) acc = acc + x;
+            else if (2 * m == R) acc = acc - x;
+            else if (4 * m == R) acc = acc + mul_mi(x);
+            else if (4 * m == 3 * R) acc = acc + mul_i(x);
+            else fma_cx(acc, x, cx<T>((T)tw.re[m], (T)tw.im[m]));
+        }
+        const int mj = (j * E) % R;
+        y[j] = mj == 0 ? acc : mul_plain(acc, cx<T>((T)tw.re[mj], (T)tw.im[mj]));
+    }
+    RegFFT<T, Q, false>::run(y);
+}
+
+struct GradLoopArgs {
+    const cf* Sg;         // (Bn, L1, L2, NO): column pass of the output's gradient
+    const cf* Xs;         // kept spectrum, row-major bin order: Xs[b*xs_b + n*xs_n + i]
+    long xs_b, xs_n;
+    cf* dH;               // dH[m*ds_m + n*ds_n + i], row-major bin order
+    long ds_m, ds_n;
+    const cf* W;
+    int n, L, L1, L2, Bn;
+    real_t scale_g;       // scale of the gradient's forward transform
+    int interior2;        // double its interior bins (irfft backward)
+    real_t out_scale;     // host factor on dH
+    const real_t* dev_scale;   // device scalar multiplied into dH, or null
+    long long* dbg;       // tuning: cycle sums per phase (8 per workgroup), or null
+};
+
+template <int A, int B, int NI, int NO, int NSC>
+struct GradLoopShape {
+    static constexpr int LEN = A * B, LENP = LEN | 1, NOL = NO / NSC, NT = 512, NW = NT / 64;
+    static constexpr int PC = 16 / (int)sizeof(cf);                 // complex values per 16-byte piece
+    static constexpr int CP = NOL / PC;                              // pieces per time step of the gradient rows
+    static constexpr int GP = 2 * LEN * CP, XP = 2 * NI * LEN / PC;  // pieces per item: gradient rows, kept spectrum
+    static constexpr int GI = (GP + 63) / 64, XI = (XP + 63) / 64;   // wavefront transfers per item
+    static constexpr int GW = (GI + NW - 1) / NW, XW = (XI + NW - 1) / NW;   // ... per wavefront (the last ones repeated)
+    static constexpr size_t lds_bytes = ((size_t)2 * LEN * NOL + (size_t)2 * NI * LEN + (size_t)2 * NOL * LENP + 2 * LEN) * sizeof(cf);
+    static_assert(NO % NSC == 0 && NOL % 2 == 0 && NOL % PC == 0 && LEN % PC == 0 && LEN <= 256, "tile shape");
+};
+
+template <int A, int B, int NI, int NO, int NSC>
+__global__ void __launch_bounds__(512) spec_gradh_loop(GradLoopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using SH = GradLoopShape<A, B, NI, NO, NSC>;
+    constexpr int LEN = SH::LEN, LENP = SH::LENP, NOL = SH::NOL, MPT = NOL / 2, NT = SH::NT, NW = SH::NW;
+    constexpr int PC = SH::PC, CP = SH::CP, GP = SH::GP, XP = SH::XP, GI = SH::GI, XI = SH::XI, GW = SH::GW, XW = SH::XW;
+    cf* G = reinterpret_cast<cf*>(smem);     // [2][LEN][NOL]   gradient rows of the item, as they lie in HBM
+    cf* X = G + 2 * LEN * NOL;               // [2][NI][LEN]    kept spectrum of the item
+    cf* U = X + 2 * NI * LEN;                // [2][NOL][LENP]  the rows between the stages, then their spectrum
+    cf* tw = U + 2 * NOL * LENP;             // W_LEN^m
+    cf* ws = tw + LEN;                       // W_n^(L1*k2)
+    const int P = a.L1 / 2 + 1;
+    // XCD-aware order: the channel groups of a row pair on one XCD (they read the same block of the kept spectrum)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int r = (q / NSC) * 8 + xcd, mo = (q % NSC) * NOL;
+    if (r >= P) return;
+    const int rm = (a.L1 - r) % a.L1;
+    const bool selfm = rm == r;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const size_t bstride = (size_t)a.L1 * (size_t)a.L2 * NO;
+    for (int j = tid; j < LEN; j += NT) {
+        tw[j] = a.W[a.n + a.L1 + j];
+        ws[j] = a.W[a.n + a.L1 + a.L2 + j];
+    }
+    // ---- the transfers of this wavefront: byte offsets inside an item, LDS bases (a wavefront whose turn lies behind the last
+    // transfer repeats the last one: every wavefront issues the same count, which is what the counter waits below rely on)
+    unsigned goff[GW], xoff[XW], glds[GW], xlds[XW];
+    bool gon[GW], xon[XW];
+#pragma unroll
+    for (int k = 0; k < GW; ++k) {
+        int ins = k * NW + wv;
+        if (ins >= GI) ins = GI - 1;
+        const int g = ins * 64 + lane;
+        gon[k] = g < GP;
+        const int gg = gon[k] ? g : 0;
+        const int cc = gg % CP, t = (gg / CP) % LEN, slot = gg / (CP * LEN);
+        goff[k] = ESZ * (((unsigned)(slot ? rm : r) * LEN + t) * NO + mo + cc * PC);
+        glds[k] = lds_addr_of(G) + 1024u * ins;
+    }
+#pragma unroll
+    for (int k = 0; k < XW; ++k) {
+        int ins = k * NW + wv;
+        if (ins >= XI) ins = XI - 1;
+        const int x = ins * 64 + lane;
+        xon[k] = x < XP;
+        const int xx = xon[k] ? x : 0;
+        const int jc = xx % (LEN / PC), nn = (xx / (LEN / PC)) % NI, slot = xx / (LEN / PC * NI);
+        xoff[k] = ESZ * ((unsigned)nn * (unsigned)a.xs_n + (unsigned)(slot ? rm : r) * LEN + jc * PC);
+        xlds[k] = lds_addr_of(X) + 1024u * ins;
+    }
+    auto issue_g = [&](int b) {
+        const cf* Sb = a.Sg + (size_t)b * bstride;
+#pragma unroll
+        for (int k = 0; k < GW; ++k)
+            if (gon[k]) dma16s(Sb, goff[k], glds[k]);
+    };
+    auto issue_x = [&](int b) {
+        const cf* Xb = a.Xs + (size_t)b * a.xs_b;
+#pragma unroll
+        for (int k = 0; k < XW; ++k)
+            if (xon[k]) dma16s(Xb, xoff[k], xlds[k]);
+    };
+    // the product's thread: bin pair p, output channels [mo + ms MPT, + MPT)
+    const int p = tid & 255, ms = tid >> 8;
+    int slotB = 0, colB = 0;
+    bool dc = false;
+    const bool valid = p < LEN && pair_of(r, selfm, p, LEN, slotB, colB, dc);
+    const unsigned ik = (unsigned)r * LEN + (p < LEN ? p : 0);
+    const unsigned im = dc ? (unsigned)a.L : (unsigned)(slotB ? rm : r) * LEN + colB;
+    const bool two = im != ik;
+    cf acck[MPT][NI], accm[MPT][NI];
+#pragma unroll
+    for (int m = 0; m < MPT; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NI; ++nn) acck[m][nn] = accm[m][nn] = cf(0, 0);
+    __syncthreads();
+    const cf wk = a.W[r] * ws[p < LEN ? p : 0];
+    const cf wm(-wk.x, wk.y);                                   // W_n^(L-k) = -conj(W_n^k)
+    const real_t hs = (real_t)0.5 * a.scale_g * (a.interior2 ? (real_t)2 : (real_t)1);
+    // Both FFT stages are shared by S threads per transform (fft_residue): thread (e = tid / 128, item = tid % 128), e uniform
+    // over a wavefront.  P1 item: (slot, tb, nn), nn fastest; P2 item: (row rl = slot * NOL + nn, ka), rl fastest.
+    constexpr int S1 = 2, S2 = B % 3 == 0 ? 3 : 4;
+    static_assert(2 * B * NOL <= 128 && 2 * NOL * A <= 128 && A % S1 == 0 && B % S2 == 0, "128 items per residue class");
+    const int e12 = __builtin_amdgcn_readfirstlane(tid >> 7), it = tid & 127;
+    const int nn1 = it % NOL, tb1 = (it / NOL) % B, slot1 = it / (NOL * B);
+    const bool have1 = e12 < S1 && it < 2 * B * NOL && !(slot1 && selfm);
+    const int rl = it % (2 * NOL), ka = it / (2 * NOL);
+    const bool act2 = e12 < S2 && it < 2 * NOL * A && !((rl / NOL) && selfm);
+    if (a.Bn > 0) {
+        issue_g(0);
+        issue_x(0);
+        wait_vm<XW>();                       // the rows have landed (this wavefront's share; the spectrum may stay in flight)
+    }
+    lds_barrier();
+    long long ph[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
+#define FL_STAMP(i) if (a.dbg) { const long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - tq; tq = t_; }
+    if (a.dbg) tq = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int b = 0; b < a.Bn; ++b) {
+        const bool more = b + 1 < a.Bn;
+        // ---- P1: first stage of the gradient rows
+        if (have1) {
+            const cf* g = G + ((slot1 * LEN + tb1) * NOL + nn1);
+            auto ld = [&](int ta) { return g[ta * B * NOL]; };
+            cf v1[A / S1];
+            if (e12 == 0) fft_residue<real_t, A, S1, 0>(ld, v1); else fft_residue<real_t, A, S1, 1>(ld, v1);
+            cf* u = U + (slot1 * NOL + nn1) * LENP + tb1;
+#pragma unroll
+            for (int k = 0; k < A / S1; ++k) {
+                const int kk = S1 * k + e12;
+                u[kk * B] = v1[k] * tw[kk * tb1];
+            }
+        }
+        FL_STAMP(0)
+        lds_barrier();
+        FL_STAMP(1)
+        if (more) issue_g(b + 1);            // the next item's rows: in flight through P2 and P3
+        // ---- P2: second stage, natural order in place
+        {
+            cf v[B / S2];
+            cf* urow = U + rl * LENP;
+            if (act2) {
+                auto ld = [&](int tb) { return urow[ka * B + tb]; };
+                if (e12 == 0) fft_residue<real_t, B, S2, 0>(ld, v);
+                else if (e12 == 1) fft_residue<real_t, B, S2, 1>(ld, v);
+                else if (e12 == 2) fft_residue<real_t, B, S2, 2>(ld, v);
+                else fft_residue<real_t, B, S2, S2 - 1>(ld, v);
+            }
+            lds_barrier();
+            if (act2) {
+#pragma unroll
+                for (int k = 0; k < B / S2; ++k) urow[ka + A * (S2 * k + e12)] = v[k];
+            }
+        }
+        FL_STAMP(2)
+        if (more) wait_vm<GW>(); else wait_vm<0>();      // this item's kept spectrum has landed
+        lds_barrier();
+        FL_STAMP(3)
+        // ---- P3: split step of this thread's channels, outer product with the kept spectrum
+        if (valid) {
+            cf gk[MPT], gm[MPT];
+#pragma unroll
+            for (int m2 = 0; m2 < MPT; ++m2) {
+                const int m = ms * MPT + m2;
+                const cf zk = U[m * LENP + p];
+                const cf zm = U[(slotB * NOL + m) * LENP + colB];
+                if (dc) {
+                    gk[m2] = cf(a.scale_g * (zk.x + zk.y), 0);      // gY[0]
+                    gm[m2] = cf(a.scale_g * (zk.x - zk.y), 0);      // gY[L]
+                } else {
+                    const cf pk = zk + conj(zm), dk = zk - conj(zm);
+                    const cf ok = pk + mul_mi(wk * dk);
+                    const cf pm = zm + conj(zk), dm = zm - conj(zk);
+                    const cf om = pm + mul_mi(wm * dm);
+                    gk[m2] = cf(hs * ok.x, hs * ok.y);
+                    gm[m2] = cf(hs * om.x, hs * om.y);
+                }
+            }
+            const cf* xr = X + p;
+            const cf* xq = X + slotB * NI * LEN + colB;
+#pragma unroll
+            for (int nn = 0; nn < NI; ++nn) {
+                const cf xk = xr[nn * LEN];
+                // the Nyquist bin is not part of any row: the one thread that owns it reads it where it lies
+                const cf xm = dc ? a.Xs[(size_t)b * a.xs_b + (size_t)nn * a.xs_n + a.L] : xq[nn * LEN];
+#pragma unroll
+                for (int m2 = 0; m2 < MPT; ++m2) {
+                    fma_cxc(acck[m2][nn], gk[m2], xk);           // += g conj(x)
+                    fma_cxc(accm[m2][nn], gm[m2], xm);
+                }
+            }
+        }
+        FL_STAMP(4)
+        wait_vm<0>();                        // the next item's rows have landed (a second stage and a product in flight)
+        lds_barrier();                       // ... everybody's, and the spectrum's region is free
+        if (more) issue_x(b + 1);            // in flight through the next item's two FFT stages
+        FL_STAMP(5)
+    }
+#undef FL_STAMP
+    if (a.dbg && tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.dbg[(size_t)blockIdx.x * 8 + i] = ph[i];
+    }
+    if (valid) {
+        real_t os = a.out_scale;
+        if (a.dev_scale) os *= *a.dev_scale;
+#pragma unroll
+        for (int m2 = 0; m2 < MPT; ++m2) {
+            const int m = mo + ms * MPT + m2;
+#pragma unroll
+            for (int nn = 0; nn < NI; ++nn) {
+                cf* o = a.dH + (size_t)m * a.ds_m + (size_t)nn * a.ds_n;
+                at(o, ESZ * ik) = cf(os * acck[m2][nn].x, os * acck[m2][nn].y);
+                if (two) at(o, ESZ * im) = cf(os * accm[m2][nn].x, os * accm[m2][nn].y);
+            }
+        }
+    }
+}
+
+
 // ---------------------------------------------------------------- contiguous twiddle copies
 // W[n + j] = W_L1^j (j < L1), W[n + L1 + j] = W_L2^j (j < L2), W[n + L1 + L2 + j] = W_n^(L1 j) (j < L2): what every
 // workgroup of the three kernels stages into LDS -- as contiguous runs instead of L1 + 2 L2 gathers from the master table
@@ -822,6 +1087,14 @@ static int cols_launch(bool inverse, const ColsArgs& a, int Bn, hipStream_t st) 
 
 static int g_mid_bg = 1, g_mid_hfake = 0, g_mid_pfd = 0;
 static long long* g_mid_times = nullptr;
+}  // namespace FL_SPEC_NS
+// tuning: cycle sums per phase of spec_gradh_loop (8 per workgroup), shared by the float32 and float64 builds
+#ifndef FL_F64
+long long* g_gradloop_times = nullptr;
+#else
+extern long long* g_gradloop_times;
+#endif
+namespace FL_SPEC_NS {
 
 template <int A, int B, int NI, int NO, int BG, int MS>
 static void launch_mid_bg(const MidArgs& a, hipStream_t st) {
@@ -961,6 +1234,70 @@ size_t fl_spec_aux_elems(int nfft) {
 
 #endif
 
+// the batch-walking gradient kernel takes 240- and 256-bin rows, equal channel counts of 2 / 4 / 8
+static bool gradh_loop_shape(int l2, int NI, int NO) { return (l2 == 240 || l2 == 256) && NI == NO && (NI == 2 || NI == 4 || NI == 8); }
+
+int FL_SPEC_FN(fl_spec_gradh_loop_supports)(int nfft, int NI, int NO) {
+    int l1, l2;
+    if (spec_plan(nfft, l1, l2) != FL_OK) return 0;
+    return gradh_loop_shape(l2, NI, NO) ? 1 : 0;
+}
+
+extern "C++" {
+template <int A, int B, int N>
+static int launch_gradh_loop(const GradLoopArgs& a, hipStream_t st) {
+    constexpr int NSC = N >= 4 ? 2 : 1;
+    using SH = GradLoopShape<A, B, N, N, NSC>;
+    // more dynamic LDS than the default 64 KB: the attribute is per function and per device, set once each and checked
+    static bool done[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!done[dev]) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spec_gradh_loop<A, B, N, N, NSC>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SH::lds_bytes);
+        if (e != hipSuccess) {
+            set_error("spec_gradh_loop: %zu bytes of LDS per workgroup are not available on device %d (%s)", SH::lds_bytes, dev, hipGetErrorString(e));
+            return FL_ERR_UNSUPPORTED;
+        }
+        done[dev] = true;
+    }
+    const int P = a.L1 / 2 + 1;
+    hipLaunchKernelGGL((spec_gradh_loop<A, B, N, N, NSC>), dim3((unsigned)(cdiv_i(P, 8) * 8 * NSC)), dim3(512), SH::lds_bytes, st, a);
+    return FL_OK;
+}
+}
+
+int FL_SPEC_FN(fl_spec_gradh_loop)(const void* Sg, const void* Xs, long xs_b, long xs_n, void* dH, long ds_m, long ds_n, const void* W,
+                                   int nfft, int Bn, int NI, int NO, double scale_g, int interior2, double out_scale,
+                                   const void* dev_scale, void* stream) {
+    FL_REQUIRE(Sg && Xs && dH && W, "spec_gradh_loop: null pointer");
+    GradLoopArgs a = {};
+    int rc = spec_plan(nfft, a.L1, a.L2);
+    if (rc) return rc;
+    if (!gradh_loop_shape(a.L2, NI, NO)) {
+        set_error("spec_gradh_loop: shape not taken (ask fl_spec_gradh_loop_supports): rows of %d bins, %d -> %d channels", a.L2, NI, NO);
+        return FL_ERR_UNSUPPORTED;
+    }
+    FL_REQUIRE(Bn >= 0 && (size_t)a.L1 * a.L2 * NO * sizeof(cf) * (size_t)(Bn > 0 ? 1 : 0) < (1ull << 32), "spec_gradh_loop: bad sizes");
+    a.Sg = (const cf*)Sg; a.Xs = (const cf*)Xs; a.xs_b = xs_b; a.xs_n = xs_n; a.dH = (cf*)dH; a.ds_m = ds_m; a.ds_n = ds_n;
+    a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn;
+    a.scale_g = (real_t)scale_g; a.interior2 = interior2; a.out_scale = (real_t)out_scale; a.dev_scale = (const real_t*)dev_scale;
+    a.dbg = g_gradloop_times;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.L2 == 240) {
+        if (NI == 8) rc = launch_gradh_loop<16, 15, 8>(a, st);
+        else if (NI == 4) rc = launch_gradh_loop<16, 15, 4>(a, st);
+        else rc = launch_gradh_loop<16, 15, 2>(a, st);
+    } else {
+        if (NI == 8) rc = launch_gradh_loop<16, 16, 8>(a, st);
+        else if (NI == 4) rc = launch_gradh_loop<16, 16, 4>(a, st);
+        else rc = launch_gradh_loop<16, 16, 2>(a, st);
+    }
+    if (rc) return rc;
+    FL_CHECK_LAUNCH("spec_gradh_loop");
+    return FL_OK;
+}
+
 int FL_SPEC_FN(fl_spec_aux_fill)(void* W, int nfft, void* stream) {
     FL_REQUIRE(W, "spec_aux_fill: null pointer");
     int l1, l2;
@@ -1005,6 +1342,7 @@ int fl_spec_supports(int nfft, int n_in, int n_out) {
 #ifndef FL_F64
 int fl_debug_set_spec_times(void* buf) {
     g_mid_times = (long long*)buf;
+    g_gradloop_times = (long long*)buf;
     return FL_OK;
 }
 

@@ -104,6 +104,52 @@ __device__ __forceinline__ bool pair_of(int r, bool selfm, int p, int LEN, int& 
 }
 
 
+// ---------------------------------------------------------------- LDS-DMA, LDS-only barrier, explicit counter waits
+// LDS-DMA of 16 bytes per lane: 64 lanes' pieces land at lds_byte_addr + 16*lane (wave-uniform base in M0), straight from
+// the per-lane global address -- no VGPR round trip.  Written as inline assembly ON PURPOSE: issued through the builtin,
+// the compiler orders every later LDS read of the kernel behind the transfer (it cannot tell the staging buffer from the
+// row buffers: s_waitcnt vmcnt(0) in front of the next ds_read), which is exactly the overlap this kernel exists for.
+// The kernel waits for its transfers itself (vmcnt(0) in front of the barrier that precedes their first read).
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_byte_addr) : "memory");
+}
+// the same with a wavefront-uniform base in an SGPR pair and a 32-bit per-lane byte offset (no 64-bit address arithmetic per piece)
+__device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+// workgroup barrier that orders LDS traffic only (a plain __syncthreads() also drains the vector-memory queue: the
+// prefetch in flight and the previous unit's stores)
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // s_waitcnt vmcnt(0)
+__device__ __forceinline__ void wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }    // s_waitcnt lgkmcnt(0)
+
+// s_waitcnt vmcnt(n) for a wavefront-uniform n (the count of this wavefront's NEWER transfers that may stay in flight); the
+// counter's field is split in the encoding (bits 3:0 and 15:14).  Unknown counts wait for everything: always safe.
+__device__ __forceinline__ void wait_vm_le(int n) {
+    switch (n) {
+        case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+        case 8: __builtin_amdgcn_s_waitcnt(0x0F78); break;
+        case 12: __builtin_amdgcn_s_waitcnt(0x0F7C); break;
+        case 16: __builtin_amdgcn_s_waitcnt(0x4F70); break;
+        case 20: __builtin_amdgcn_s_waitcnt(0x4F74); break;
+        case 24: __builtin_amdgcn_s_waitcnt(0x4F78); break;
+        default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+    }
+}
+// the same for a compile-time count (0 ... 63)
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    __builtin_amdgcn_s_waitcnt((N & 15) | 0x0F70 | ((N >> 4) << 14));
+}
+
 }  // namespace FL_SPEC_NS
 
 // the fused plan of a transform length (spectral.hip, float32 build)

@@ -870,6 +870,30 @@ def _spec_mid_walk(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, spec_scale, inter
     return S2, Xp
 
 
+GRADH_LOOP = True      # False: the layered backward (spec_mid without a response + mimo_gradh); tests compare the two
+# The one-launch form's parallelism is (row pairs x channel groups) -- 202 workgroups at nfft = 96000 -- whatever the batch; the
+# layered form's grows with the batch.  Measured on an MI355X (tools/dbg/gradloop_dbg.py): 29.5 against 36.1 us at two items in
+# float64, 22.6 against 27.8 in float32, 31.6 against 36.0 (4 x 4, eight items), but 62.4 against 56.4 at nfft = 65536 (130
+# workgroups) with eight items and 211 against 206 us at 32 items in float64 (its two FFT stages run on two to six of the
+# workgroup's eight wavefronts and are latency-bound).  Up to this many items it is taken:
+GRADH_LOOP_MAX_BATCH = 4
+
+
+def _spec_gradh_loop(Sg, Xs, B, NI, NO, nfft, scale_g, host_factor, out_scale):
+    """dL/dH (M, NO, NI) view in row-major bin order from the gradient's column pass Sg and the kept spectrum Xs (B, NI, P)"""
+    dev = Sg.device
+    M = nfft // 2 + 1
+    real = _rdtype(Sg)
+    P = _pitch(M)
+    dH = _empty_rows((NO, NI), M, Sg.dtype, dev)
+    with kernel_timer.span("spec_gradh_loop"):
+        _lib.check(_spec_fn("fl_spec_gradh_loop", real)(Sg.data_ptr(), Xs.data_ptr(), NI * P, P, dH.data_ptr(), NI * P, P,
+                                                        twiddles(nfft, real, dev).data_ptr(), nfft, B, NI, NO, float(scale_g), 1,
+                                                        float(host_factor), None if out_scale is None else out_scale.data_ptr(),
+                                                        _stream()), "spec_gradh_loop")
+    return dH.movedim(-1, 0)
+
+
 def _spec_gradh_walk(Sg, Xp, B, NI, NO, nfft, scale_g, out_scale=None):
     """dL/dH (M, NO, NI) view, row-major bin order, from the gradient's scratch rows and the pair-major spectrum;
     out_scale: float32 device scalar multiplied in on the way out"""
@@ -957,6 +981,10 @@ class _SpectralApply(torch.autograd.Function):
                 gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f * (host_factor if out_scale is not None else 1.0), env_f,
                                     dev_scale=out_scale)
             return gx, gH
+        if need_h and not need_x and GRADH_LOOP and B <= GRADH_LOOP_MAX_BATCH and _spec_fn("fl_spec_gradh_loop_supports", _rdtype(Sg))(nfft, NI, NO):
+            # the response's gradient alone (the training step: the data tensor takes no gradient, trainer.py:172-191): one launch
+            # that walks the batch -- the gradient's spectrum is never written and read back (fl_spec_gradh_loop_*)
+            return None, _spec_gradh_loop(Sg, kept[0], B, NI, NO, nfft, scale_i, host_factor if out_scale is not None else 1.0, out_scale)
         # rfft' : g_x[t] = scale_f e_f(t) Re sum_k g_X[k] exp(+j w_k t), g_X = H^H g_Y -- an inverse transform with halved interior bins
         S3, gYs = _spec_mid(Sg, B, NO, NI if need_x else NO, nfft, Hp if need_x else None, True, need_h, need_x, scale_i, 1, 1)
         if need_x:

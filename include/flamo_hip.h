@@ -198,6 +198,23 @@ int fl_spec_cols_inv_scaled_f32(const void* S2, void* y, int Bn, int t_len, int 
 /* per plane: dst[i] = src[k(i)] (inverse = 0, natural -> row-major bin order) or dst[k(i)] = src[i] (inverse = 1) */
 int fl_permute_bins_c64(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
                         void* stream);
+/* Backward of the pipeline, gradient of the response, in ONE launch (round 5) where the batch-walking kernel
+ * fl_spec_gradh_walk_f32 does not apply -- float64, fewer than four batch items:
+ *   dH[m][n][i] = out_scale * (*dev_scale) * sum_b gY[b][m][i] conj(Xs[b][n][i]),
+ * gY = the spectrum of the output's gradient whose column pass is Sg (scale_g, interior bins doubled: the irfft backward of
+ * dsp.py:110-115 under the einsum backward of dsp.py:922-924), Xs the spectrum fl_spec_mid_* kept.  Replaces
+ * fl_spec_mid_*(S2 = null, Xs out) + fl_mimo_gradh_*: the gradient's spectrum is never written.  A workgroup owns (row pair,
+ * output-channel group) and walks the batch; the sum over the batch is in a fixed order (no atomics).  240- / 256-bin rows,
+ * equal channel counts of 2 / 4 / 8 (fl_spec_gradh_loop_supports_*). */
+int fl_spec_gradh_loop_supports_f32(int nfft, int NI, int NO);
+int fl_spec_gradh_loop_supports_f64(int nfft, int NI, int NO);
+int fl_spec_gradh_loop_f32(const void* Sg, const void* Xs, long xs_b, long xs_n, void* dH, long ds_m, long ds_n, const void* W,
+                           int nfft, int Bn, int NI, int NO, double scale_g, int interior2, double out_scale,
+                           const void* dev_scale, void* stream);
+int fl_spec_gradh_loop_f64(const void* Sg, const void* Xs, long xs_b, long xs_n, void* dH, long ds_m, long ds_n, const void* W,
+                           int nfft, int Bn, int NI, int NO, double scale_g, int interior2, double out_scale,
+                           const void* dev_scale, void* stream);
+
 /* The same pipeline in float64 / complex128 (spectral.hip compiled a second time with real_t = double): same arguments, same
  * layouts, W from fl_twiddle_fill_f64 + fl_spec_aux_fill_f64.  One workgroup per (row pair, batch item) at every plan length,
  * equal channel counts only (fl_spec_supports_f64 also accounts for the doubled LDS of the row and column tiles). */

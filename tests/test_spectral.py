@@ -7,7 +7,7 @@ from collections import OrderedDict
 import pytest
 import torch
 
-from conftest import relerr
+from conftest import check_close, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -671,3 +671,62 @@ def test_geq_sigmoid_map_folded_into_the_design_kernel(gpu, parallel):
             (Y.abs() ** 2).sum().backward()
             res.append((Y.detach(), m.param.grad.clone()))
         assert relerr(res[0][0], res[1][0]) < 2e-6 and relerr(res[0][1], res[1][1]) < 5e-5
+
+
+@pytest.mark.parametrize("dt,nfft,N,B", [(torch.float64, 96000, 8, 3), (torch.float64, 96000, 8, 32), (torch.float64, 96000, 4, 2),
+                                         (torch.float64, 24000, 2, 5), (torch.float64, 65536, 8, 3), (torch.float32, 96000, 8, 3),
+                                         (torch.float32, 65536, 4, 2), (torch.float64, 192000, 8, 2)])
+def test_response_gradient_in_one_launch(gpu, dt, nfft, N, B):
+    """The training step's backward (the data takes no gradient, trainer.py:172-191) where the float32 batch-walking kernel does not
+    apply: fl_spec_gradh_loop_* walks the batch per (row pair, channel group) instead of writing the gradient's spectrum and
+    reading it back.  Against the layered form (spec_mid without a response + mimo_gradh) on the same inputs, with a plain
+    cotangent and through the fused objective (device-side factor), and against torch.fft + einsum in float64."""
+    from flamo_amd import ops
+    cd = torch.complex128 if dt == torch.float64 else torch.complex64
+    torch.manual_seed(nfft + N + B)
+    M = nfft // 2 + 1
+    x = torch.randn(B, nfft, N, device=gpu, dtype=dt)
+    H = (torch.randn(M, N, N, device=gpu, dtype=cd) / N ** 0.5).requires_grad_(True)
+    c = torch.randn(B, nfft, N, device=gpu, dtype=dt)
+
+    def run(objective):
+        ops.kernel_timer.reset(True)
+        y = ops.spectral_apply(x, ops.permute_bins(H, nfft), nfft, "backward", "backward", None, 30.0)
+        loss = ops.mean_square(y) if objective else (y * c).sum()
+        (g,) = torch.autograd.grad(loss, [H])
+        torch.cuda.synchronize()
+        used = set(ops.kernel_timer.records)
+        ops.kernel_timer.enabled = False
+        return g, used
+
+    keep = ops.GRADH_LOOP_MAX_BATCH
+    try:
+        for objective in (False, True):
+            ops.GRADH_LOOP_MAX_BATCH = keep
+            _, used = run(objective)
+            walks = dt == torch.float32 and B >= 4
+            assert ("spec_gradh_walk" in used) == walks and ("spec_gradh_loop" in used) == (not walks and B <= keep), used
+            if walks:
+                continue
+            ops.GRADH_LOOP_MAX_BATCH = 1 << 30        # the kernel itself at any batch size
+            g1, used1 = run(objective)
+            assert "spec_gradh_loop" in used1 and not any(k.startswith("mimo_gradh") for k in used1), used1
+            ops.GRADH_LOOP = False
+            try:
+                g0, used0 = run(objective)
+            finally:
+                ops.GRADH_LOOP = True
+            assert "spec_gradh_loop" not in used0 and any(k.startswith("mimo_gradh") for k in used0), used0
+            tag = f"gradh_loop/{str(dt)[6:]}_{nfft}_{N}_{B}_{int(objective)}"
+            check_close(tag + "/vs_layered", g1, g0, 1e-12 if dt == torch.float64 else 2e-6)
+    finally:
+        ops.GRADH_LOOP_MAX_BATCH = keep
+    if B <= 3:
+        xr, Hr = x.cpu().double(), H.detach().cpu().to(torch.complex128).requires_grad_(True)
+        t = torch.arange(nfft, dtype=torch.float64)
+        yr = torch.fft.irfft(torch.einsum("fmn,bfn->bfm", Hr, torch.fft.rfft(xr, n=nfft, dim=1)), n=nfft, dim=1) \
+            * (10.0 ** (30.0 / (20.0 * nfft) * t))[:, None]
+        (gr,) = torch.autograd.grad((yr * c.cpu().double()).sum(), [Hr])
+        g1, used1 = run(False)
+        assert "spec_gradh_loop" in used1
+        check_close(f"gradh_loop/{str(dt)[6:]}_{nfft}_{N}_{B}/vs_torch_fft", g1.cpu(), gr, 1e-10 if dt == torch.float64 else 1e-5)

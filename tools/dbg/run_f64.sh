@@ -1,7 +1,7 @@
-# float64 config-2 step: lanes tests + kernel stats
+# float64 config-2 step: the one-launch response gradient's tests + kernel stats of the float64 step
 cd /root/repo
 mkdir -p gpurun_out/q
-timeout 600 python -m pytest tests/test_cascade2.py -q -m gpu -x -k float64 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_spectral.py -q -m gpu -x -k "one_launch" 2>&1 | tail -15
 ROOT=/root/repo
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/q/stats64 -o r -- python $ROOT/bench.py --dtype f64 --no-cpu-baseline --no-extras > $ROOT/gpurun_out/q/bench64.json 2> $ROOT/gpurun_out/q/bench64.err
