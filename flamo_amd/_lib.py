@@ -158,6 +158,7 @@ _SIGNATURES = {
     "fl_mse_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _l, _i, _vp]),
     "fl_mse_bwd_f64": (_i, [_vp, _vp, _vp, _vp, _l, _i, _vp]),
     "fl_matrix_exp_stash_elems": (_sz, [_i]),
+    "fl_debug_set_expm_mfma": (_i, [_i]),
     "fl_matrix_exp_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "fl_matrix_exp_f64": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "fl_matrix_exp_bwd_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp]),

@@ -217,6 +217,180 @@ __global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE
     }
 }
 
+// ---------------------------------------------------------------- N = 16 on the float64 matrix cores (round 5)
+// The 16-channel mixing matrix of the feedback delay networks (configs 3 and 4): ONE wavefront, every matrix in registers, every
+// product four v_mfma_f64_16x16x4_f64 -- no LDS, no barrier, no shuffle.  A matrix M lives in the instruction's C/D layout
+// (register r of lane l = M[(l >> 4) + 4 r][l & 15]); in that layout register c IS the B operand of K-chunk c
+// (B[k = 4 c + (l >> 4)][j = l & 15]), and the A operand of chunk c (A[i = l & 15][k = 4 c + (l >> 4)]) is register c of the
+// TRANSPOSE in the same layout.  So the kernels carry every matrix together with its transpose -- (P, P^T), (E, E^T), (G, G^T)
+// -- and each step produces both: eight instructions per Horner step or squaring forward, twelve / sixteen backward, all
+// chained through registers.  The schedule and the stash (natural row-major order) are those of the LDS kernels above: either
+// backward reads either forward's stash.  Forward 12.3 -> 6.5 us, backward 18.0 -> 9.6 us at N = 16 (one matrix: latency).
+typedef double d4m __attribute__((ext_vector_type(4)));
+
+// acc += L R, Lt = the LEFT factor's transpose in the C/D layout, R = the right factor in the C/D layout
+__device__ __forceinline__ d4m mm16(const d4m Lt, const d4m R, d4m acc) {
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[0], R[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[1], R[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[2], R[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[3], R[3], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ d4m zero16() { return d4m{0.0, 0.0, 0.0, 0.0}; }
+// a row-major (16, 16) matrix of doubles into the C/D layout, or its transpose
+__device__ __forceinline__ d4m load16(const double* __restrict__ src, int lane, bool transposed) {
+    const int j = lane & 15, i0 = lane >> 4;
+    d4m m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[r] = transposed ? src[j * 16 + i0 + 4 * r] : src[(i0 + 4 * r) * 16 + j];
+    return m;
+}
+__device__ __forceinline__ void store16(double* __restrict__ dst, int lane, const d4m m) {
+    const int j = lane & 15, i0 = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(i0 + 4 * r) * 16 + j] = m[r];
+}
+// alpha M + I
+__device__ __forceinline__ d4m scale_plus_identity16(const d4m m, double alpha, int lane) {
+    const int j = lane & 15, i0 = lane >> 4;
+    d4m o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = fma(m[r], alpha, (i0 + 4 * r == j) ? 1.0 : 0.0);
+    return o;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) expm16_fwd_kernel(const T* __restrict__ X, int skew, T* __restrict__ E, T* __restrict__ Ec,
+                                                       double* __restrict__ stash) {
+    constexpr int N = 16, NN = 256;
+    const int lane = threadIdx.x, j = lane & 15, i0 = lane >> 4;
+    auto entry = [&](int i, int jj) -> double {      // A[i][jj]
+        if (!skew) return (double)X[i * N + jj];
+        const double x = (double)X[jj > i ? i * N + jj : jj * N + i];
+        return jj > i ? x : (jj < i ? -x : 0.0);
+    };
+    d4m A, At;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        A[r] = entry(i0 + 4 * r, j);
+        At[r] = entry(j, i0 + 4 * r);
+    }
+    // |A|_1 = largest column sum: this lane's four rows of column j, the four lane groups, then the sixteen columns
+    double cs = (fabs(A[0]) + fabs(A[1])) + (fabs(A[2]) + fabs(A[3]));
+    cs += __shfl_xor(cs, 16, 64);
+    cs += __shfl_xor(cs, 32, 64);
+    double nrm = cs;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) nrm = fmax(nrm, __shfl_xor(nrm, o, 64));
+    int sq = 0;
+    if (nrm > 0.25) {                            // nrm / 2^sq <= 1/4
+        int e;
+        const double m = frexp(nrm * 4.0, &e);
+        sq = (m == 0.5) ? e - 1 : e;
+    }
+    sq = sq > EXPM_SQ ? EXPM_SQ : sq;
+    sq = __builtin_amdgcn_readfirstlane(sq);
+    if (lane == 0) stash[(size_t)EXPM_SLOTS * NN] = (double)sq;
+    const double scale = ldexp(1.0, -sq);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        A[r] *= scale;
+        At[r] *= scale;
+    }
+    store16(stash, lane, A);                     // A_s
+    d4m P = scale_plus_identity16(zero16(), 0.0, lane), Pt = P;
+#pragma unroll 1
+    for (int k = EXPM_ORDER; k >= 1; --k) {
+        store16(stash + (size_t)k * NN, lane, P);                                        // P_{k+1}
+        const d4m q = mm16(At, P, zero16());                                             // A_s P_{k+1}
+        const d4m qt = mm16(P, At, zero16());                                            // P_{k+1}^T A_s^T
+        P = scale_plus_identity16(q, 1.0 / k, lane);
+        Pt = scale_plus_identity16(qt, 1.0 / k, lane);
+    }
+#pragma unroll 1
+    for (int i = 0; i < sq; ++i) {
+        store16(stash + (size_t)(EXPM_ORDER + 1 + i) * NN, lane, P);                     // E_i
+        const d4m q = mm16(Pt, P, zero16());                                             // E_i E_i
+        const d4m qt = mm16(P, Pt, zero16());                                            // E_i^T E_i^T
+        P = q;
+        Pt = qt;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int idx = (i0 + 4 * r) * N + j;
+        const T v = (T)P[r];
+        if (Ec) {
+            Ec[2 * idx] = v;
+            Ec[2 * idx + 1] = (T)0;
+        }
+        if (E) E[idx] = v;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) expm16_bwd_kernel(const T* __restrict__ gE, const T* __restrict__ gEc, int skew,
+                                                       const double* __restrict__ stash, T* __restrict__ gX) {
+    constexpr int N = 16, NN = 256;
+    __shared__ double dAs[N * (N + 1)];
+    const int lane = threadIdx.x, j = lane & 15, i0 = lane >> 4;
+    auto cot = [&](int idx) { return (gE ? (double)gE[idx] : 0.0) + (gEc ? (double)gEc[2 * idx] : 0.0); };
+    d4m G, Gt, dA = zero16();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        G[r] = cot((i0 + 4 * r) * N + j);
+        Gt[r] = cot(j * N + i0 + 4 * r);
+    }
+    const int SQ = __builtin_amdgcn_readfirstlane((int)stash[(size_t)EXPM_SLOTS * NN]);
+    const d4m As = load16(stash, lane, false);
+    // step t = 0..SQ-1: E_{SQ-1-t};  t = SQ..SQ+ORDER-1: P_{t-SQ+2} -- the stashed matrix of step t + 1 is requested (both
+    // layouts) while step t multiplies: the steps are a dependent chain
+    const int steps = SQ + EXPM_ORDER;
+    auto slot_of = [&](int t) { return t < SQ ? EXPM_ORDER + 1 + (SQ - 1 - t) : t - SQ + 1; };
+    d4m S = load16(stash + (size_t)slot_of(0) * NN, lane, false), St = load16(stash + (size_t)slot_of(0) * NN, lane, true);
+#pragma unroll 1
+    for (int t = 0; t < steps; ++t) {
+        const d4m C = S, Ct = St;
+        if (t + 1 < steps) {
+            S = load16(stash + (size_t)slot_of(t + 1) * NN, lane, false);
+            St = load16(stash + (size_t)slot_of(t + 1) * NN, lane, true);
+        }
+        if (t < SQ) {                                                  // E_{i+1} = E_i^2:  G <- G E^T + E^T G
+            d4m g = mm16(Gt, Ct, zero16());                            //   G E^T      (left G: its transpose; right E^T)
+            g = mm16(C, G, g);                                         // + E^T G      (left E^T: transpose E; right G)
+            d4m gt = mm16(Ct, Gt, zero16());                           //   E G^T
+            gt = mm16(G, C, gt);                                       // + G^T E
+            G = g;
+            Gt = gt;
+        } else {                                                       // P_k = I + A_s P_{k+1} / k
+            const double ik = 1.0 / (double)(t - SQ + 1);
+            const d4m d = mm16(Gt, Ct, zero16());                      // G P_{k+1}^T
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dA[r] = fma(d[r], ik, dA[r]);  // dA_s += G P_{k+1}^T / k
+            const d4m g = mm16(As, G, zero16());                       // A_s^T G      (left A_s^T: transpose A_s)
+            const d4m gt = mm16(G, As, zero16());                      // G^T A_s
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                G[r] = g[r] * ik;
+                Gt[r] = gt[r] * ik;
+            }
+        }
+    }
+    // the skew map needs dA - dA^T: the one transposition of the kernel, through 2 KB of LDS
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dAs[(i0 + 4 * r) * (N + 1) + j] = dA[r];
+    __syncthreads();
+    const double scale = ldexp(1.0, -SQ);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + 4 * r;
+        double v = dA[r];
+        if (skew) v = (j > i) ? (v - dAs[j * (N + 1) + i]) : 0.0;
+        gX[i * N + j] = (T)(v * scale);
+    }
+}
+
+static int g_expm_mfma = 1;      // test hook: 0 = the LDS kernels also at N = 16
+
 static int expm_threads(int N) {
     int t = (N * N + 63) / 64 * 64;
     return t > 1024 ? 1024 : t;
@@ -231,6 +405,11 @@ static int expm_fwd_impl(const void* X, int N, int skew, void* E, void* Ec, void
         int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&expm_fwd_kernel<T, 0>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "matrix_exp LDS size");
         if (rc) return rc;
+    }
+    if (N == 16 && g_expm_mfma) {
+        hipLaunchKernelGGL((expm16_fwd_kernel<T>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const T*)X, skew, (T*)E, (T*)Ec, (double*)stash);
+        FL_CHECK_LAUNCH("matrix_exp");
+        return FL_OK;
     }
 #define FL_EXPM_FWD(NT_)                                                                                                   \
     hipLaunchKernelGGL((expm_fwd_kernel<T, NT_>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)X, N, \
@@ -258,6 +437,12 @@ static int expm_bwd_impl(const void* gE, const void* gEc, int N, int skew, const
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "matrix_exp_bwd LDS size");
         if (rc) return rc;
     }
+    if (N == 16 && g_expm_mfma) {
+        hipLaunchKernelGGL((expm16_bwd_kernel<T>), dim3(1), dim3(64), 0, (hipStream_t)stream, (const T*)gE, (const T*)gEc, skew,
+                           (const double*)stash, (T*)gX);
+        FL_CHECK_LAUNCH("matrix_exp_bwd");
+        return FL_OK;
+    }
 #define FL_EXPM_BWD(NT_)                                                                                                     \
     hipLaunchKernelGGL((expm_bwd_kernel<T, NT_>), dim3(1), dim3(expm_threads(N)), lds, (hipStream_t)stream, (const T*)gE,    \
                        (const T*)gEc, N, skew, (const double*)stash, (T*)gX)
@@ -278,6 +463,11 @@ static int expm_bwd_impl(const void* gE, const void* gEc, int N, int skew, const
 using namespace fl;
 
 extern "C" {
+int fl_debug_set_expm_mfma(int on) {
+    const int prev = g_expm_mfma;
+    if (on >= 0) g_expm_mfma = on ? 1 : 0;
+    return prev;
+}
 size_t fl_matrix_exp_stash_elems(int N) { return (size_t)EXPM_SLOTS * N * N + 1; }
 int fl_matrix_exp_f32(const void* X, int N, int skew, void* E, void* stash, void* stream) {
     return expm_fwd_impl<float>(X, N, skew, E, nullptr, stash, stream);

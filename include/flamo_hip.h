@@ -639,6 +639,9 @@ int fl_mse_bwd_f64(const void* y, const void* t, const void* gloss, void* gy, lo
  * HIP graph.  X, E, gE, gX: (N, N) row major in the parameter type (_f32 / _f64), N <= 64;
  * stash: fl_matrix_exp_stash_elems(N) doubles written by the forward and read by the backward. */
 size_t fl_matrix_exp_stash_elems(int N);
+/* test hook: 0 = the LDS kernels also at N = 16 (default 1: one wavefront on v_mfma_f64_16x16x4_f64, csrc/expm.hip); returns
+ * the previous setting, a negative argument only queries */
+int fl_debug_set_expm_mfma(int on);
 int fl_matrix_exp_f32(const void* X, int N, int skew, void* E, void* stash, void* stream);
 int fl_matrix_exp_f64(const void* X, int N, int skew, void* E, void* stash, void* stream);
 int fl_matrix_exp_bwd_f32(const void* gE, int N, int skew, const void* stash, void* gX, void* stream);

@@ -358,6 +358,39 @@ def test_matrix_exp_kernel_matches_torch(gpu, N):
                 assert (E.detach().cpu().double() @ E.detach().cpu().double().mT - I).abs().max() < tol * 10
 
 
+def test_matrix_exp_16_on_matrix_cores_matches_lds_kernels(gpu):
+    """N = 16 (the feedback delay networks' mixing matrix, e8_fdn.py / e8_colorless_fdn.py) runs as one wavefront on
+    v_mfma_f64_16x16x4_f64 with every matrix and its transpose in registers: against the LDS kernels of the same schedule -- values,
+    gradients, and each backward on the OTHER forward's stash (the layout is shared) -- plain and through the skew map, all three
+    output forms."""
+    from flamo_amd import _lib, ops
+    L = _lib.lib()
+    torch.manual_seed(16)
+    prev = L.fl_debug_set_expm_mfma(-1)
+    try:
+        for dt, tol in ((torch.float64, 1e-13), (torch.float32, 1e-6)):
+            for skew, amp in ((True, 1.0), (False, 0.3), (True, 25.0), (False, 3.0)):
+                X0 = (torch.randn(16, 16, dtype=dt) * amp).to(gpu)
+                Cw = torch.randn(16, 16, dtype=dt, device=gpu)
+                res = {}
+                for fwd_on in (1, 0):
+                    for bwd_on in (1, 0):
+                        X = X0.clone().requires_grad_(True)
+                        L.fl_debug_set_expm_mfma(fwd_on)
+                        E, Ec = ops.matrix_exp_both(X, skew=skew)
+                        L.fl_debug_set_expm_mfma(bwd_on)
+                        (g,) = torch.autograd.grad((E * Cw).sum() + (Ec.real * Cw.mT).sum(), [X])
+                        res[(fwd_on, bwd_on)] = (E.detach(), Ec.detach(), g)
+                E0, Ec0, g0 = res[(0, 0)]
+                assert torch.equal(Ec0.real, E0) and float(Ec0.imag.abs().max()) == 0.0
+                for key, (E, Ec, g) in res.items():
+                    tag = f"expm16/{str(dt)[6:]}_{int(skew)}_{amp}_{key[0]}{key[1]}"
+                    assert relerr(E, E0) < tol and relerr(Ec.real, E0) < tol, (tag, relerr(E, E0))
+                    assert relerr(g, g0) < 20 * tol, (tag, relerr(g, g0))
+    finally:
+        L.fl_debug_set_expm_mfma(prev)
+
+
 def test_response_overlap_is_transparent(gpu):
     """Building the folded response on the side stream (Shell + Series) changes nothing but timing:
     eager outputs and gradients are bit-identical with the overlap on and off, and a captured step

@@ -450,9 +450,12 @@ def test_solve_properties(gpu):
     # above 64 channels the matrix is factored per bin in LDS (round 3), up to what 160 KB holds: 138 in float32
     R65 = torch.randn(1, 4, 65, dtype=torch.complex64, device=gpu)
     cc("ops_solve_torch_zeros_4_65_65_dtype_torc", ops.solve(torch.zeros(4, 65, 65, dtype=torch.complex64, device=gpu), R65), R65, 1e-06)
+    # ... and above that in a global-memory workspace (fl_solve_ws_*, round 5), to 1024 channels
+    R139 = torch.randn(1, 4, 139, dtype=torch.complex64, device=gpu)
+    cc("ops_solve_torch_zeros_4_139_139_workspace", ops.solve(torch.zeros(4, 139, 139, dtype=torch.complex64, device=gpu), R139), R139, 1e-06)
     with pytest.raises(RuntimeError):
-        ops.solve(torch.zeros(4, 139, 139, dtype=torch.complex64, device=gpu),
-                  torch.zeros(1, 4, 139, dtype=torch.complex64, device=gpu))
+        ops.solve(torch.zeros(2, 1025, 1025, dtype=torch.complex64, device=gpu),
+                  torch.zeros(1, 2, 1025, dtype=torch.complex64, device=gpu))
 
 
 def test_config2_full_size(gpu):
