@@ -225,7 +225,9 @@ __global__ void __launch_bounds__(1024) expm_bwd_kernel(const T* __restrict__ gE
 // TRANSPOSE in the same layout.  So the kernels carry every matrix together with its transpose -- (P, P^T), (E, E^T), (G, G^T)
 // -- and each step produces both: eight instructions per Horner step or squaring forward, twelve / sixteen backward, all
 // chained through registers.  The schedule and the stash (natural row-major order) are those of the LDS kernels above: either
-// backward reads either forward's stash.  Forward 12.3 -> 6.5 us, backward 18.0 -> 9.6 us at N = 16 (one matrix: latency).
+// backward reads either forward's stash.  Forward 12.3 -> 8.7 us, backward 18.0 -> 14.3 us at N = 16 inside the FDN step (rocprofv3;
+// one matrix, one wavefront: ~4.5 us of either is the launch, the backward's first three loads are a dependent chain); the
+// replayed FDN step 0.382 -> 0.377 ms, the colorless training step 0.344 -> 0.338 ms.
 typedef double d4m __attribute__((ext_vector_type(4)));
 
 // acc += L R, Lt = the LEFT factor's transpose in the C/D layout, R = the right factor in the C/D layout

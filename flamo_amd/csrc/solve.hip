@@ -359,12 +359,8 @@ __device__ inline void opaque(cx<double>& v) { asm("" : "+v"(v.x), "+v"(v.y)); }
 // group -- a 32-lane group has no one-instruction broadcast -- and every broadcast of a pivot-row element now
 // feeds two row updates; which slot holds the pivot (K / LANES) and which slots still have rows below it are
 // known at compile time, so finished slots drop out of the update loops altogether.
-// PIVL (tuning, fl_debug_set_solve_variant(5)): the pivot row of every elimination step goes through LDS -- its owner lane writes
-// the columns right of the diagonal, every lane of the group reads them back as broadcast reads -- instead of two DPP moves per
-// 32-bit half (four vector-ALU slots per complex column at 8 lanes per bin, beside the four packed multiply-adds they feed).
-// OCC (tuning, variants 6 ... 9): wavefronts per SIMD the register allocation is held to.
-template <typename T, int LANES, int RPL, bool PIVL = false, int OCC = 1>
-__global__ void __launch_bounds__(256, OCC) solve_inplace_kernel(
+template <typename T, int LANES, int RPL>
+__global__ void __launch_bounds__(256) solve_inplace_kernel(
     const cx<T>* __restrict__ P, long p_pitch, Dud<T> dud, int one_minus, int adjoint,
     const cx<T>* __restrict__ R, long rs_b, long rs_n, long rs_k,
     cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
@@ -590,27 +586,12 @@ __global__ void __launch_bounds__(256, OCC) solve_inplace_kernel(
                 l[s].y = (gi > LK) ? l[s].y : (T)0;
             }
         }
-        if constexpr (PIVL) {
-            __shared__ __attribute__((aligned(16))) cx<T> prow[(256 / LANES) * NMAX];
-            cx<T>* pg = prow + (threadIdx.x / LANES) * NMAX;
-            if (gi == LK) {
-#pragma unroll
-                for (int J = KK + 1; J < NMAX; ++J) pg[J] = row[SK][J];
-            }
-            static_for<KK + 1, NMAX>([&](auto jc) {
-                constexpr int J = decltype(jc)::value;
-                const cx<T> pr = pg[J];
-#pragma unroll
-                for (int s = SK; s < RPL; ++s) row[s][J] = cfnma(row[s][J], cmul_of(l[s]), pr);
-            });
-        } else {
         static_for<KK + 1, NMAX>([&](auto jc) {
             constexpr int J = decltype(jc)::value;
             const cx<T> pr = group_bcast<LANES, LK>(row[SK][J]);
 #pragma unroll
             for (int s = SK; s < RPL; ++s) row[s][J] = cfnma(row[s][J], cmul_of(l[s]), pr);
         });
-        }
 #pragma unroll
         for (int s = SK; s < RPL; ++s) {
             if (s == SK) {
@@ -702,22 +683,6 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
             // element feeds two row updates: 86 -> 73 us at N = 16 (c64), 131 -> 108 us (c128), 82 -> 63 us at N = 9
             // (tools/dbg/archive/solve_rpl2_16.py; 4 lanes x 4 rows: 80 us, and it spills).  fl_debug_set_solve_variant(4): the
             // one-row-per-lane kernels.
-#define FL_SOLVE_TUNE(CODE_, PIVL_, OCC_)                                                                                           \
-            if (!P && g_solve_rpl2_16 == CODE_) {                                                                                   \
-                hipLaunchKernelGGL((solve_inplace_kernel<T, 8, 2, PIVL_, OCC_>), dim3(cdiv_i(M, 32)), dim3(256), 0, st, (const cx<T>*)P, \
-                                   p_pitch, dud, one_minus, adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k,        \
-                                   (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);                                                      \
-                FL_CHECK_LAUNCH("solve");                                                                                           \
-                return FL_OK;                                                                                                       \
-            }
-            if constexpr (sizeof(T) == 4) {      // tuning variants 5 ... 9 (float): pivot row through LDS, register budgets
-                FL_SOLVE_TUNE(2, true, 1)
-                FL_SOLVE_TUNE(3, false, 3)
-                FL_SOLVE_TUNE(4, false, 4)
-                FL_SOLVE_TUNE(5, true, 3)
-                FL_SOLVE_TUNE(6, true, 4)
-            }
-#undef FL_SOLVE_TUNE
             if (!P && g_solve_rpl2_16 != 1) {
                 hipLaunchKernelGGL((solve_inplace_kernel<T, 8, 2>), dim3(cdiv_i(M, 32)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
                                    dud, one_minus, adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
@@ -1305,8 +1270,8 @@ int fl_solve_max_n(int f64) { return f64 ? solve_lds_max_n<double>() : solve_lds
 int fl_debug_set_solve_variant(int variant) {
     g_solve_thr = 1;
     g_solve_rpl2_p = variant == 3;
-    g_solve_rpl2_16 = variant == 4 ? 1 : ((variant >= 5 && variant <= 9) ? variant - 3 : 0);
-    if (variant >= 3 && variant <= 9) variant = 0;
+    g_solve_rpl2_16 = variant == 4 ? 1 : 0;
+    if (variant == 3 || variant == 4) variant = 0;
     if (variant >= 10) {          // 10 + t: in-place kernels with pivot threshold 2^-t
         g_solve_thr = variant - 10;
         variant = 0;
