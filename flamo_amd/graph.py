@@ -59,8 +59,13 @@ class GraphedStep:
         self.graph = torch.cuda.CUDAGraph()
         # thread-local capture mode: a communicator's watchdog thread (RCCL) may query events while this
         # thread captures; in the default global mode that would invalidate the capture
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.static_out = self._run_captured()
+        # constants of parameter values taken from the warm-up runs' caches instead of being recorded (ops.capture_scope): kept
+        # alive here, their parameters' version counters checked before every replay
+        self._constants = []
+        from . import ops
+        with ops.capture_scope(self._constants):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.static_out = self._run_captured()
         # the gradients the captured backward produces live in the graph's pool and are rewritten
         # in place by every replay: hand them to the parameters as they are (no copy per step)
         for p, g in zip(self.params, self._static_grads):
@@ -145,8 +150,16 @@ class GraphedStep:
     def grads(self):
         return [p.grad for p in self.params]
 
+    def _check_constants(self):
+        for ref, version, _ in self._constants:
+            p = ref()
+            if p is None or p._version != version:
+                raise RuntimeError("GraphedStep: a parameter whose response the captured graph holds as a constant (an integer delay) "
+                                   "has been assigned a new value since the capture -- capture the step again")
+
     def replay(self) -> torch.Tensor:
         """Replay on the current contents of the static inputs (no host-side copies)."""
+        self._check_constants()
         self.graph.replay()
         self.replays += 1
         return self.static_out
@@ -155,6 +168,7 @@ class GraphedStep:
         for dst, src in zip(self.static_inputs, inputs):
             if src is not dst:
                 dst.copy_(src)
+        self._check_constants()
         self.graph.replay()
         self.replays += 1
         return self.static_out

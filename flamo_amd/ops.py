@@ -310,6 +310,7 @@ class _PerThread(threading.local):
         self.side_streams = {}
         self.loop_depth = 0
         self.step_memo = None
+        self.capture_constants = None
 
 
 _tls = _PerThread()
@@ -350,6 +351,31 @@ class step_scope:
 
 def step_memo():
     return _tls.step_memo
+
+
+class capture_scope:
+    """Opened by flamo_amd.graph.GraphedStep around its capture: constants of the parameter VALUES that the eager warm-up runs
+    left in a cache (the integer-delay response: `round` has a zero gradient) may be taken from it instead of being recorded as
+    launches of every replay.  Each such constant is registered here as (weak reference to the parameter, its version counter,
+    the tensor): the step keeps the tensor alive for the graph's lifetime and refuses to replay once the parameter has been
+    assigned a new value."""
+
+    def __init__(self, sink: list):
+        self.sink = sink
+
+    def __enter__(self):
+        self._prev = _tls.capture_constants
+        _tls.capture_constants = self.sink
+        return self
+
+    def __exit__(self, *exc):
+        _tls.capture_constants = self._prev
+        return False
+
+
+def capture_constants():
+    """the list a capturing GraphedStep collects its constants in, or None"""
+    return _tls.capture_constants
 
 
 def fork_event():

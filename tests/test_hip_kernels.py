@@ -934,3 +934,51 @@ def test_replayed_step_is_stable_under_eager_launches(gpu):
         del junk
         assert torch.equal(out, out0), (i, out.item(), out0.item())
         assert all(torch.equal(p.grad, g) for p, g in zip(params, g0))
+
+
+def test_captured_step_holds_integer_delay_response_as_a_constant(gpu):
+    """A feedback delay network's integer delays never change during training (e8_fdn.py:84-90, e8_colorless_fdn.py: parallelDelay
+    with isint=True, requires_grad=False): a GraphedStep takes their response from the cache its eager warm-up runs left instead of
+    recording the response's launch and the eight small ones in front of it into every replay.  Replays equal the eager step;
+    eager calls with another bin order in between do not disturb them (the step keeps the tensor alive); once the delays are
+    assigned a new value the step refuses to replay."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import train_colorless_fdn as T
+    from flamo_amd import ops
+    from flamo_amd.graph import GraphedStep
+    torch.manual_seed(3)
+    nfft, N = 24000, 8
+    model = T.build(gpu, torch.float32, N, nfft)
+    x, target = T.colorless_batch(1, nfft, gpu, torch.float32)
+    params = [p for p in model.parameters() if p.requires_grad]
+    delays = model.get_core().feedback_loop.feedforward
+
+    def criteria(xx):
+        return T.mse_criterion(model(xx), target) + 0.2 * T.sparsity_criterion(model)
+
+    for p in params:
+        p.grad = None
+    with ops.step_scope():
+        criteria(x).backward()
+    want = [p.grad.clone() for p in params]
+    step = GraphedStep(criteria, (x,), params, warmup=2)
+    assert len(step._constants) >= 1 and all(c[0]() is delays.param for c in step._constants)
+    loss0 = step.replay().clone()
+    for p, w in zip(params, want):
+        assert relerr(p.grad, w) < 1e-6
+    # an eager evaluation of the same module under another key replaces the module's cache entry: the graph's constant survives
+    with torch.no_grad():
+        ops.set_bin_shard(100, 50)
+        try:
+            delays.freq_response(delays.param)
+        finally:
+            ops.set_bin_shard(0, None)
+    junk = [torch.randn(1 << 18, device=gpu) for _ in range(8)]
+    del junk
+    assert torch.equal(step.replay(), loss0)
+    with torch.no_grad():
+        delays.assign_value(delays.param.detach().clone() * 1.5)
+    with pytest.raises(RuntimeError):
+        step.replay()

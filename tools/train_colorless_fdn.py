@@ -55,9 +55,19 @@ def colorless_batch(B, nfft, dev, dtype):
     return x, torch.ones(B, M, 1, device=dev, dtype=dtype)
 
 
+_MSE = {}
+
+
 def mse_criterion(est, target):
-    """mse_loss.forward (optimize/loss.py:102-103): channels summed, then the mean squared error."""
-    return torch.mean((est.sum(dim=-1) - target.squeeze(-1)) ** 2)
+    """mse_loss.forward (optimize/loss.py:102-103): channels summed, then the mean squared error -- the drop-in class
+    flamo_amd.optimize.mse_loss, as examples/e8_colorless_fdn.py:137 instantiates the reference's (one pass each way on device
+    tensors instead of torch's sum / sub / pow / mean kernels and their backward; FLAMO_TORCH_CRITERIA=1: the torch lines)."""
+    if os.environ.get("FLAMO_TORCH_CRITERIA", "0") == "1":
+        return torch.mean((est.sum(dim=-1) - target.squeeze(-1)) ** 2)
+    if "fn" not in _MSE:
+        from flamo_amd.optimize import mse_loss
+        _MSE["fn"] = mse_loss()
+    return _MSE["fn"](est, target)
 
 
 def sparsity_criterion(model):
