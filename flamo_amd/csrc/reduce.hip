@@ -320,6 +320,64 @@ __global__ void __launch_bounds__(256) pack_toggle_kernel(const unsigned long lo
     }
 }
 
+// ---------------------------------------------------------------- sparsity criterion of a mixing matrix
+// loss = mean_c (sum_ij |A_c[i][j]| - N sqrt(N)) / (N (1 - sqrt(N)))  over C matrices of (N, N) -- flamo/optimize/loss.py:12-63
+// (`sparsity_loss`: the second criterion of the colorless-FDN training, examples/e8_colorless_fdn.py:138) in ONE launch each way
+// instead of torch's abs / sum / sub / div / neg kernels and their backward: the matrix is 16 x 16, every one of those launches
+// is pure latency inside a captured training step.  One workgroup; the sums are taken in a fixed order.
+template <typename T>
+__global__ void __launch_bounds__(256) sparsity_kernel(const T* __restrict__ A, int C, int N, T* __restrict__ loss) {
+    __shared__ double red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double sn = sqrt((double)N), k = 1.0 / ((double)N * (1.0 - sn));
+    double total = 0.0;
+    for (int c = 0; c < C; ++c) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < N * N; i += 256) s += fabs((double)A[(size_t)c * N * N + i]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[wave] = s;
+        __syncthreads();
+        total += ((red[0] + red[1]) + (red[2] + red[3]) - (double)N * sn) * k;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (T)(total / (double)C);
+}
+
+// g_A = gloss sign(A) / (C N (1 - sqrt(N)))   (sign(0) = 0, as torch.sign)
+template <typename T>
+__global__ void __launch_bounds__(256) sparsity_bwd_kernel(const T* __restrict__ A, const T* __restrict__ gloss, int C, int N,
+                                                           T* __restrict__ gA) {
+    const double sn = sqrt((double)N);
+    const T k = (T)((double)gloss[0] / ((double)C * (double)N * (1.0 - sn)));
+    const size_t n = (size_t)C * N * N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const T a = A[i];
+        gA[i] = a > (T)0 ? k : (a < (T)0 ? -k : (a == (T)0 ? (T)0 : a * k));      // (a NaN entry stays NaN)
+    }
+}
+
+template <typename T>
+static int sparsity_impl(const void* A, int C, int N, void* loss, void* stream) {
+    FL_REQUIRE(A && loss, "sparsity: null pointer");
+    FL_REQUIRE(C >= 1 && N >= 2, "sparsity: at least one matrix of at least 2 x 2");
+    hipLaunchKernelGGL((sparsity_kernel<T>), dim3(1), dim3(256), 0, (hipStream_t)stream, (const T*)A, C, N, (T*)loss);
+    FL_CHECK_LAUNCH("sparsity");
+    return FL_OK;
+}
+template <typename T>
+static int sparsity_bwd_impl(const void* A, const void* gloss, int C, int N, void* gA, void* stream) {
+    FL_REQUIRE(A && gloss && gA, "sparsity_bwd: null pointer");
+    FL_REQUIRE(C >= 1 && N >= 2, "sparsity_bwd: at least one matrix of at least 2 x 2");
+    const size_t n = (size_t)C * N * N;
+    size_t g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL((sparsity_bwd_kernel<T>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const T*)A, (const T*)gloss, C, N,
+                       (T*)gA);
+    FL_CHECK_LAUNCH("sparsity_bwd");
+    return FL_OK;
+}
+
 }  // namespace fl
 
 using namespace fl;
@@ -368,5 +426,13 @@ int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows
 }
 int fl_mean_square_bwd_f64(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream) {
     return mean_square_bwd_impl<double>(y, gloss, gy, rows, cols, pitch, stream);
+}
+int fl_sparsity_f32(const void* A, int C, int N, void* loss, void* stream) { return sparsity_impl<float>(A, C, N, loss, stream); }
+int fl_sparsity_f64(const void* A, int C, int N, void* loss, void* stream) { return sparsity_impl<double>(A, C, N, loss, stream); }
+int fl_sparsity_bwd_f32(const void* A, const void* gloss, int C, int N, void* gA, void* stream) {
+    return sparsity_bwd_impl<float>(A, gloss, C, N, gA, stream);
+}
+int fl_sparsity_bwd_f64(const void* A, const void* gloss, int C, int N, void* gA, void* stream) {
+    return sparsity_bwd_impl<double>(A, gloss, C, N, gA, stream);
 }
 }

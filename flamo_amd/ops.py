@@ -2333,6 +2333,42 @@ def _is_pipeline_output(y: torch.Tensor) -> bool:
     return True
 
 
+class _Sparsity(torch.autograd.Function):
+    """mean_c (sum |A_c| - N sqrt N) / (N (1 - sqrt N)) of (C, N, N) real matrices, one launch each way"""
+
+    @staticmethod
+    def forward(ctx, A):
+        dev = _require_gpu(A)
+        Ac = A.contiguous()
+        C, N = (1 if Ac.dim() == 2 else Ac.shape[0]), Ac.shape[-1]
+        loss = torch.empty((), dtype=A.dtype, device=dev)
+        L = _lib.lib()
+        fn = L.fl_sparsity_f32 if A.dtype == torch.float32 else L.fl_sparsity_f64
+        _lib.check(fn(Ac.data_ptr(), C, N, loss.data_ptr(), _stream()), "sparsity")
+        ctx.save_for_backward(Ac)
+        ctx.cn = (C, N)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (Ac,) = ctx.saved_tensors
+        C, N = ctx.cn
+        gA = torch.empty_like(Ac)
+        g = gloss.to(Ac.dtype).contiguous()
+        L = _lib.lib()
+        fn = L.fl_sparsity_bwd_f32 if Ac.dtype == torch.float32 else L.fl_sparsity_bwd_f64
+        _lib.check(fn(Ac.data_ptr(), g.data_ptr(), C, N, gA.data_ptr(), _stream()), "sparsity_bwd")
+        return gA
+
+
+def sparsity(A: torch.Tensor) -> torch.Tensor:
+    """The reference's sparsity criterion on a mixing matrix A (N, N) or a stack (C, N, N) -- flamo/optimize/loss.py:52-63:
+    -(sum|A| - N sqrt N) / (N (sqrt N - 1)), the mean over C of the same expression for a stack."""
+    if A.dim() not in (2, 3) or A.shape[-1] != A.shape[-2] or A.shape[-1] < 2 or A.dtype not in (torch.float32, torch.float64):
+        raise ValueError("sparsity: a real (N, N) or (C, N, N) matrix with N >= 2")
+    return _Sparsity.apply(A)
+
+
 class _MSE(torch.autograd.Function):
     """mean((sum_c y[..., c] - t) ** 2) (ncols = 1: plain nn.MSELoss) in one streaming pass each way"""
 

@@ -620,6 +620,15 @@ int fl_mean_square_final_f64(const void* parts, int n_parts, double inv_count, v
 int fl_pack_toggle(const void* table, int count, void* flat0, void* flat1, void* state, void* stream);
 int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
 int fl_mean_square_bwd_f64(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
+/* Sparsity criterion of a mixing matrix, the second criterion of the colorless-FDN training (flamo/optimize/loss.py:12-63
+ * `sparsity_loss`, examples/e8_colorless_fdn.py:138):
+ *   loss = mean_c (sum_ij |A_c[i][j]| - N sqrt(N)) / (N (1 - sqrt(N))),   A: (C, N, N) contiguous (C = 1: the plain matrix),
+ *   g_A = gloss sign(A) / (C N (1 - sqrt(N)))  (gloss a device scalar; sign(0) = 0 as torch.sign).
+ * One launch each way instead of torch's abs / sum / sub / div / neg launches and their backward. */
+int fl_sparsity_f32(const void* A, int C, int N, void* loss, void* stream);
+int fl_sparsity_f64(const void* A, int C, int N, void* loss, void* stream);
+int fl_sparsity_bwd_f32(const void* A, const void* gloss, int C, int N, void* gA, void* stream);
+int fl_sparsity_bwd_f64(const void* A, const void* gloss, int C, int N, void* gA, void* stream);
 /* Mean squared error against a target, the criterion the reference's training loops use (flamo/optimize/trainer.py:179-189
  * calling flamo/optimize/loss.py:66-103 `mse_loss`, or nn.MSELoss directly as examples/e7_biquad.py:82-87):
  *   loss = (1 / rows) sum_r (sum_{c < ncols} y[r][c] - t[r])^2,   y: (rows, ncols) contiguous, t: (rows).

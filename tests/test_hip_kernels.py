@@ -982,3 +982,42 @@ def test_captured_step_holds_integer_delay_response_as_a_constant(gpu):
         delays.assign_value(delays.param.detach().clone() * 1.5)
     with pytest.raises(RuntimeError):
         step.replay()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_sparsity_criterion_matches_the_reference_lines(gpu, dt):
+    """ops.sparsity / flamo_amd.optimize.sparsity_loss (flamo/optimize/loss.py:12-63) against the reference's torch lines: a
+    plain (N, N) matrix, a (C, N, N) stack, values and gradients (sign(0) = 0), and the class on an FDN model."""
+    import math
+    import sys
+    import os
+    from flamo_amd import ops
+    from flamo_amd.optimize import sparsity_loss
+    torch.manual_seed(9)
+    tol = 1e-6 if dt == torch.float32 else 1e-14
+    for shape in ((16, 16), (3, 8, 8), (1, 4, 4), (2, 2)):
+        A0 = torch.randn(*shape, dtype=dt, device=gpu)
+        A0.view(-1)[1] = 0.0
+        N = shape[-1]
+        Ar = A0.clone().requires_grad_(True)
+        if len(shape) == 3:
+            ref = torch.mean((torch.sum(torch.abs(Ar), dim=(-2, -1)) - N * math.sqrt(N)) / (N * (1 - math.sqrt(N))))
+        else:
+            ref = -(torch.sum(torch.abs(Ar)) - N * math.sqrt(N)) / (N * (math.sqrt(N) - 1))
+        (gr,) = torch.autograd.grad(ref * 1.7, [Ar])
+        Ah = A0.clone().requires_grad_(True)
+        out = ops.sparsity(Ah)
+        (gh,) = torch.autograd.grad(out * 1.7, [Ah])
+        assert abs(out.item() - ref.item()) <= tol * max(1.0, abs(ref.item())), (shape, out.item(), ref.item())
+        assert relerr(gh, gr) < tol and float(gh.view(-1)[1]) == 0.0
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import train_colorless_fdn as T
+    model = T.build(gpu, dt, 8, 4800)
+    mix = model.get_core().feedback_loop.feedback
+    got = sparsity_loss()(None, None, model)
+    A = mix.map(mix.param)
+    want = -(torch.sum(torch.abs(A)) - 8 * math.sqrt(8)) / (8 * (math.sqrt(8) - 1))
+    assert abs(got.item() - want.item()) <= 10 * tol
+    (g1,) = torch.autograd.grad(got, [mix.param])
+    (g2,) = torch.autograd.grad(want, [mix.param])
+    assert relerr(g1, g2) < 20 * tol

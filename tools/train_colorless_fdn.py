@@ -71,7 +71,13 @@ def mse_criterion(est, target):
 
 
 def sparsity_criterion(model):
-    """sparsity_loss.forward for a plain mixing matrix (optimize/loss.py:36-63)."""
+    """sparsity_loss.forward for a plain mixing matrix (optimize/loss.py:36-63): the drop-in class flamo_amd.optimize.sparsity_loss,
+    as examples/e8_colorless_fdn.py:138 instantiates the reference's (FLAMO_TORCH_CRITERIA=1: the torch lines)."""
+    if os.environ.get("FLAMO_TORCH_CRITERIA", "0") != "1":
+        if "sp" not in _MSE:
+            from flamo_amd.optimize import sparsity_loss
+            _MSE["sp"] = sparsity_loss()
+        return _MSE["sp"](None, None, model)
     mix = model.get_core().feedback_loop.feedback
     A = mix.map(mix.param)
     N = A.shape[-1]
