@@ -480,10 +480,11 @@ __global__ void __launch_bounds__(256) fft_cols_fast(FftArgs<T> a) {
 // (W_n^(L-j) = -conj(W_n^j)), and the eight rows ta B + tb it holds for column c are, reversed, the eight rows
 // (A-1-ta) B + (B-1-tb) of item (B-1-tb) of column L2-c: a complete input of that column's first-stage FFT.
 // Columns 0 and L2/2 are their own partners (within the column, other rows): they are processed as plain columns.
-template <typename T, int A, int B>
+// CD = 4 (CT = 8): few signals -- see launch_fft: the tiles shrink until the launch has enough workgroups.
+template <typename T, int A, int B, int CD = 16>
 __global__ void __launch_bounds__(256) fft_cols_ipair(FftArgs<T> a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int CT = 32, CD = 16, LEN = A * B, LENP = LEN | 1;
+    constexpr int CT = 2 * CD, LEN = A * B, LENP = LEN | 1;
     cx<T>* U = reinterpret_cast<cx<T>*>(smem);   // [CT][LENP]: local columns 0..15 = c, 16..31 = partner of column lc-16
     cx<T>* tw = U + CT * LENP;                    // W_LEN^m
     cx<T>* t2 = tw + LEN;                         // [CT][B]: W_L^(col * A * kb)
@@ -737,7 +738,14 @@ static const FastSplit* fast_split(int len) {
 
 template <typename T, int A, int B>
 static void launch_cols_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, size_t lds, hipStream_t st) {
-    if (a.CT == 32) {
+    if (a.CT == 4) {        // few signals (launch_fft): four columns per workgroup
+        if (inverse)
+            hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_IRFFT_PRE, true, 4>), dim3(nblk), dim3(256), lds, st, a);
+        else if (a.pack_fast)
+            hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_PACK_FAST, false, 4>), dim3(nblk), dim3(256), lds, st, a);
+        else
+            hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_PACK, false, 4>), dim3(nblk), dim3(256), lds, st, a);
+    } else if (a.CT == 32) {
         if (inverse)
             hipLaunchKernelGGL((fft_cols_fast<T, A, B, LOAD_IRFFT_PRE, true, 32>), dim3(nblk), dim3(256), lds, st, a);
         else
@@ -753,7 +761,8 @@ static void launch_cols_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, s
 }
 template <typename T, int A, int B>
 static void launch_cols_ipair(const FftArgs<T>& a, unsigned nblk, size_t lds, hipStream_t st) {
-    hipLaunchKernelGGL((fft_cols_ipair<T, A, B>), dim3(nblk), dim3(256), lds, st, a);
+    if (a.CT == 8) hipLaunchKernelGGL((fft_cols_ipair<T, A, B, 4>), dim3(nblk), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((fft_cols_ipair<T, A, B, 16>), dim3(nblk), dim3(256), lds, st, a);
 }
 template <typename T, int A, int B>
 static void launch_rows_fast(bool inverse, const FftArgs<T>& a, unsigned nblk, size_t lds, int nthreads, hipStream_t st) {
@@ -979,7 +988,17 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
             // 32-column tiles pay off for the inverse (its mirror reads straddle lines), not forward
             const bool pair = inverse && sizeof(T) == 4 && g_fast_pair && g_fast_ct == 0 && a.ci_n == 0;
             a.CT = (sizeof(T) == 4 && (g_fast_ct == 32 || (g_fast_ct == 0 && inverse))) ? 32 : 16;
-            a.ntiles = pair ? cdiv_i(p.L2 / 2 + 1, 16) : cdiv_i(p.L2, a.CT);
+            // Few signals (a batch-1 feedback delay network transforms ONE, config 3: six such launches per step): with
+            // 16-column tiles the pass is 20 workgroups, each moving its 77 KB at the ~10 B/cycle a single CU sustains --
+            // 3 us of an 11 us launch.  Four columns per workgroup (32-byte pieces: irrelevant at 1.5 MB) spread it over four
+            // times as many CUs.  (round 5; the row pass below shrinks its tiles the same way)
+            const bool few = g_fast_ct == 0 && a.ci_n == 0 && (long)cdiv_i(p.L2, 16) * nsig < 64;
+            int cd = 16;
+            if (few) {
+                cd = 4;
+                a.CT = pair ? 8 : 4;
+            }
+            a.ntiles = pair ? cdiv_i(p.L2 / 2 + 1, cd) : cdiv_i(p.L2, a.CT);
             const size_t lds = (size_t)(a.CT * a.L1P + p.L1 + a.CT * f1->B + (inverse ? p.L1 + a.CT : 0)) * esz;
             const size_t nblk = cols_grid(a, nsig);
             FL_REQUIRE(nblk < (1ull << 31), "grid too large");
@@ -1017,6 +1036,11 @@ static int launch_fft(bool inverse, FftArgs<T> a, const Plan& p, int nsig, hipSt
         if (rt > lds_rows) rt = lds_rows;
         if (rt > 16) rt = 16;
         if (g_fast_rt > 0 && g_fast_rt < rt) rt = g_fast_rt;
+        if (g_fast_rt == 0) {      // few signals: tiles of at least two rows, as many workgroups as the part has CUs (0.346 -> 0.334 ms per FDN step)
+            int want = (int)(((long)P * nsig + 255) / 256);
+            if (want < 2) want = 2;
+            if (want < rt) rt = want;
+        }
         if (rt > P) rt = P;
         FL_REQUIRE(rt >= 1, "row pass does not fit (L2=%d)", p.L2);
         const int nthreads = (per * rt * fs->A > 256) ? 512 : 256;
