@@ -153,6 +153,10 @@ _SIGNATURES = {
     "fl_mean_square_f64": (_i, [_vp, _l, _l, _l, _vp, _vp, _vp]),
     "fl_mean_square_bwd_f32": (_i, [_vp, _vp, _vp, _l, _l, _l, _vp]),
     "fl_mean_square_bwd_f64": (_i, [_vp, _vp, _vp, _l, _l, _l, _vp]),
+    "fl_cabs_c64": (_i, [_vp, _vp, _l, _l, _l, _l, _vp]),
+    "fl_cabs_c128": (_i, [_vp, _vp, _l, _l, _l, _l, _vp]),
+    "fl_cabs_bwd_c64": (_i, [_vp, _vp, _vp, _l, _l, _l, _l, _vp]),
+    "fl_cabs_bwd_c128": (_i, [_vp, _vp, _vp, _l, _l, _l, _l, _vp]),
     "fl_sparsity_f32": (_i, [_vp, _i, _i, _vp, _vp]),
     "fl_sparsity_f64": (_i, [_vp, _i, _i, _vp, _vp]),
     "fl_sparsity_bwd_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),

@@ -378,6 +378,57 @@ static int sparsity_bwd_impl(const void* A, const void* gloss, int C, int N, voi
     return FL_OK;
 }
 
+// ---------------------------------------------------------------- magnitude of a spectrum
+// out = |z| and its backward g_z = g z / |z| (0 where z = 0: torch's sgn) over rows of `cols` contiguous complex values `pitch`
+// apart -- the output layer of the reference's magnitude-domain examples, dsp.Transform(lambda x: torch.abs(x))
+// (examples/e7_biquad.py:76, e8_colorless_fdn.py:102), one launch each way where torch runs abs, then sgn and a complex multiply.
+template <typename T>
+__global__ void __launch_bounds__(256) cabs_kernel(const cx<T>* __restrict__ z, T* __restrict__ out, long rows, long cols, long pitch,
+                                                   long opitch) {
+    for (long r = blockIdx.y; r < rows; r += gridDim.y)
+        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < cols; c += (long)gridDim.x * 256) {
+            const cx<T> v = z[r * pitch + c];
+            out[r * opitch + c] = (T)hypot(v.x, v.y);
+        }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) cabs_bwd_kernel(const cx<T>* __restrict__ z, const T* __restrict__ g, cx<T>* __restrict__ gz,
+                                                       long rows, long cols, long pitch, long gpitch) {
+    for (long r = blockIdx.y; r < rows; r += gridDim.y)
+        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < cols; c += (long)gridDim.x * 256) {
+            const cx<T> v = z[r * pitch + c];
+            const T m = (T)hypot(v.x, v.y), gg = g[r * gpitch + c];
+            gz[r * pitch + c] = m > (T)0 ? cx<T>(gg * (v.x / m), gg * (v.y / m)) : cx<T>((T)0 * gg, (T)0 * gg);
+        }
+}
+static dim3 cabs_grid(long rows, long cols) {
+    long gx = (cols + 1023) / 1024;      // four values per lane
+    if (gx < 1) gx = 1;
+    if (gx > 4096) gx = 4096;
+    long gy = rows;
+    if (gy > 65535) gy = 65535;
+    if (gy < 1) gy = 1;
+    return dim3((unsigned)gx, (unsigned)gy);
+}
+template <typename T>
+static int cabs_impl(const void* z, void* out, long rows, long cols, long pitch, long opitch, void* stream) {
+    FL_REQUIRE(z && out, "cabs: null pointer");
+    FL_REQUIRE(rows > 0 && cols > 0 && pitch >= cols && opitch >= cols, "cabs: bad sizes");
+    hipLaunchKernelGGL((cabs_kernel<T>), cabs_grid(rows, cols), dim3(256), 0, (hipStream_t)stream, (const cx<T>*)z, (T*)out, rows, cols,
+                       pitch, opitch);
+    FL_CHECK_LAUNCH("cabs");
+    return FL_OK;
+}
+template <typename T>
+static int cabs_bwd_impl(const void* z, const void* g, void* gz, long rows, long cols, long pitch, long gpitch, void* stream) {
+    FL_REQUIRE(z && g && gz, "cabs_bwd: null pointer");
+    FL_REQUIRE(rows > 0 && cols > 0 && pitch >= cols && gpitch >= cols, "cabs_bwd: bad sizes");
+    hipLaunchKernelGGL((cabs_bwd_kernel<T>), cabs_grid(rows, cols), dim3(256), 0, (hipStream_t)stream, (const cx<T>*)z, (const T*)g,
+                       (cx<T>*)gz, rows, cols, pitch, gpitch);
+    FL_CHECK_LAUNCH("cabs_bwd");
+    return FL_OK;
+}
+
 }  // namespace fl
 
 using namespace fl;
@@ -434,5 +485,17 @@ int fl_sparsity_bwd_f32(const void* A, const void* gloss, int C, int N, void* gA
 }
 int fl_sparsity_bwd_f64(const void* A, const void* gloss, int C, int N, void* gA, void* stream) {
     return sparsity_bwd_impl<double>(A, gloss, C, N, gA, stream);
+}
+int fl_cabs_c64(const void* z, void* out, long rows, long cols, long pitch, long opitch, void* stream) {
+    return cabs_impl<float>(z, out, rows, cols, pitch, opitch, stream);
+}
+int fl_cabs_c128(const void* z, void* out, long rows, long cols, long pitch, long opitch, void* stream) {
+    return cabs_impl<double>(z, out, rows, cols, pitch, opitch, stream);
+}
+int fl_cabs_bwd_c64(const void* z, const void* g, void* gz, long rows, long cols, long pitch, long gpitch, void* stream) {
+    return cabs_bwd_impl<float>(z, g, gz, rows, cols, pitch, gpitch, stream);
+}
+int fl_cabs_bwd_c128(const void* z, const void* g, void* gz, long rows, long cols, long pitch, long gpitch, void* stream) {
+    return cabs_bwd_impl<double>(z, g, gz, rows, cols, pitch, gpitch, stream);
 }
 }

@@ -2333,6 +2333,58 @@ def _is_pipeline_output(y: torch.Tensor) -> bool:
     return True
 
 
+class _CAbs(torch.autograd.Function):
+    """|z| of a complex tensor in one launch each way; the result has z's memory order (a bin-planar view stays one)"""
+
+    @staticmethod
+    def forward(ctx, z):
+        dev = _require_gpu(z)
+        zm, rows, cols, pitch = _rows_of(z)
+        real = _rdtype(zm)
+        if zm.is_contiguous():
+            out = torch.empty(zm.shape, dtype=real, device=dev)
+        else:
+            mem = zm.movedim(1, -1)
+            out = torch.empty_strided(mem.shape, mem.stride(), dtype=real, device=dev).movedim(-1, 1)
+        L = _lib.lib()
+        fn = L.fl_cabs_c64 if real == torch.float32 else L.fl_cabs_c128
+        _lib.check(fn(zm.data_ptr(), out.data_ptr(), rows, cols, pitch, pitch, _stream()), "cabs")
+        ctx.save_for_backward(zm)
+        ctx.layout = (rows, cols, pitch)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (zm,) = ctx.saved_tensors
+        rows, cols, pitch = ctx.layout
+        # the cotangent in the output's own memory order (same strides: rows `pitch` apart), else through a copy of that shape
+        if zm.is_contiguous():
+            gm = g.contiguous()
+            gpitch = pitch
+        else:
+            mem = zm.movedim(1, -1)
+            gv = g.movedim(1, -1)
+            if tuple(gv.stride()) == tuple(mem.stride()):
+                gm = g
+            else:
+                gm = torch.empty_strided(mem.shape, mem.stride(), dtype=g.dtype, device=g.device).movedim(-1, 1)
+                gm.copy_(g)
+            gpitch = pitch
+        gz = torch.empty_strided(zm.shape, zm.stride(), dtype=zm.dtype, device=zm.device)
+        L = _lib.lib()
+        fn = L.fl_cabs_bwd_c64 if zm.dtype == torch.complex64 else L.fl_cabs_bwd_c128
+        _lib.check(fn(zm.data_ptr(), gm.data_ptr(), gz.data_ptr(), rows, cols, pitch, gpitch, _stream()), "cabs_bwd")
+        return gz
+
+
+def cabs(z: torch.Tensor) -> torch.Tensor:
+    """torch.abs of a complex device tensor (the magnitude output layer, dsp.py:27-66 wrapping `lambda x: torch.abs(x)`) in one
+    launch each way."""
+    if not z.is_complex() or z.dtype not in (torch.complex64, torch.complex128) or z.numel() == 0:
+        raise ValueError("cabs: a non-empty complex64 / complex128 tensor")
+    return _CAbs.apply(z)
+
+
 class _Sparsity(torch.autograd.Function):
     """mean_c (sum |A_c| - N sqrt N) / (N (1 - sqrt N)) of (C, N, N) real matrices, one launch each way"""
 

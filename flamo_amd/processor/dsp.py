@@ -38,6 +38,50 @@ def _gamma(alias_decay_db, nfft, device=None, dtype=torch.float32) -> torch.Tens
 
 
 # ============================================================================ transforms
+MAGNITUDE_LAYER = True      # False: a recognised `torch.abs` output layer still runs as the callable (tests compare the two)
+_MAGNITUDE_CACHE = None
+
+
+def _is_magnitude_map(fn) -> bool:
+    """True when `fn` IS torch.abs or reproduces it bit for bit -- values AND gradient -- on a complex128 probe vector (zeros, both
+    signs, tiny and large parts): the examples' output layer `lambda x: torch.abs(x)` (e7_biquad.py:76, e8_colorless_fdn.py:102).
+    Evaluated once per callable (a map with side effects sees one extra call); anything else runs as it is."""
+    global _MAGNITUDE_CACHE
+    if fn is torch.abs:
+        return True
+    if fn is None or fn is _identity:
+        return False
+    import weakref
+    if _MAGNITUDE_CACHE is None:
+        _MAGNITUDE_CACHE = weakref.WeakKeyDictionary()
+    try:
+        return _MAGNITUDE_CACHE[fn]
+    except (KeyError, TypeError):
+        pass
+    ok = False
+    try:
+        re = torch.tensor([0.0, 1.0, -1.0, 0.0, 3.0, -0.5, 1e-12, 2.5e7, -7.25, 0.0], dtype=torch.float64)
+        im = torch.tensor([0.0, 0.0, 0.0, -2.0, 4.0, 0.125, -3e-13, 1.5e6, -7.25, 1e-300], dtype=torch.float64)
+        probe = torch.complex(re, im)
+        w = torch.linspace(0.5, 1.5, probe.numel(), dtype=torch.float64)
+        with torch.enable_grad():
+            x = probe.clone().requires_grad_(True)
+            y = fn(x)
+            if torch.is_tensor(y) and y.shape == x.shape and y.dtype == torch.float64 and y.requires_grad:
+                (g,) = torch.autograd.grad((y * w).sum(), [x])
+                xr = probe.clone().requires_grad_(True)
+                yr = torch.abs(xr)
+                (gr,) = torch.autograd.grad((yr * w).sum(), [xr])
+                ok = bool(torch.equal(y.detach(), yr.detach()) and torch.equal(torch.view_as_real(g), torch.view_as_real(gr)))
+    except Exception:       # a callable that does not take a complex128 host vector is simply not the magnitude
+        ok = False
+    try:
+        _MAGNITUDE_CACHE[fn] = ok
+    except TypeError:       # not weak-referenceable: probed again next time
+        pass
+    return ok
+
+
 class Transform(nn.Module):
     """Wraps a callable as a layer (dsp.py:27-66)."""
 
@@ -49,6 +93,9 @@ class Transform(nn.Module):
         self.dtype = dtype
 
     def forward(self, x: torch.Tensor):
+        if (torch.is_tensor(x) and x.is_cuda and x.dtype in (torch.complex64, torch.complex128) and x.numel() > 0
+                and MAGNITUDE_LAYER and _is_magnitude_map(self.transform)):
+            return ops.cabs(x)
         return self.transform(x)
 
     def probe(self, z: torch.Tensor):

@@ -620,6 +620,15 @@ int fl_mean_square_final_f64(const void* parts, int n_parts, double inv_count, v
 int fl_pack_toggle(const void* table, int count, void* flat0, void* flat1, void* state, void* stream);
 int fl_mean_square_bwd_f32(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
 int fl_mean_square_bwd_f64(const void* y, const void* gloss, void* gy, long rows, long cols, long pitch, void* stream);
+/* Magnitude of a spectrum, the output layer of the reference's magnitude-domain examples -- dsp.Transform(lambda x: torch.abs(x)),
+ * examples/e7_biquad.py:76, e8_colorless_fdn.py:102 (flamo/processor/dsp.py:27-66 wraps the callable):
+ *   out[r][c] = |z[r][c]|,   g_z[r][c] = g[r][c] z[r][c] / |z[r][c]|  (0 where z = 0, as torch's sgn),
+ * rows of `cols` contiguous values, `pitch` (complex) / `opitch`, `gpitch` (real) apart: contiguous tensors (rows = 1) and the
+ * bin-planar views of this library alike.  One launch each way (torch: abs; sgn and a complex multiply). */
+int fl_cabs_c64(const void* z, void* out, long rows, long cols, long pitch, long opitch, void* stream);
+int fl_cabs_c128(const void* z, void* out, long rows, long cols, long pitch, long opitch, void* stream);
+int fl_cabs_bwd_c64(const void* z, const void* g, void* gz, long rows, long cols, long pitch, long gpitch, void* stream);
+int fl_cabs_bwd_c128(const void* z, const void* g, void* gz, long rows, long cols, long pitch, long gpitch, void* stream);
 /* Sparsity criterion of a mixing matrix, the second criterion of the colorless-FDN training (flamo/optimize/loss.py:12-63
  * `sparsity_loss`, examples/e8_colorless_fdn.py:138):
  *   loss = mean_c (sum_ij |A_c[i][j]| - N sqrt(N)) / (N (1 - sqrt(N))),   A: (C, N, N) contiguous (C = 1: the plain matrix),

@@ -1021,3 +1021,42 @@ def test_sparsity_criterion_matches_the_reference_lines(gpu, dt):
     (g1,) = torch.autograd.grad(got, [mix.param])
     (g2,) = torch.autograd.grad(want, [mix.param])
     assert relerr(g1, g2) < 20 * tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_magnitude_output_layer_in_one_launch(gpu, dt):
+    """dsp.Transform(lambda x: torch.abs(x)) -- the output layer of examples/e7_biquad.py:76 and e8_colorless_fdn.py:102 -- is
+    recognised by probe (values and gradient of the callable bit for bit torch.abs's) and runs as ops.cabs: against the callable
+    itself on a contiguous spectrum and on a bin-planar view (a core's output), zeros included; other callables are left alone."""
+    from flamo_amd import ops
+    from flamo_amd.processor import dsp
+    cd = torch.complex64 if dt == torch.float32 else torch.complex128
+    tol = 1e-6 if dt == torch.float32 else 1e-14
+    torch.manual_seed(4)
+    layer = dsp.Transform(lambda x: torch.abs(x), device=gpu, dtype=dt)
+    other = dsp.Transform(lambda x: torch.abs(x) * 1.0000001, device=gpu, dtype=dt)
+    assert dsp._is_magnitude_map(layer.transform) and dsp._is_magnitude_map(torch.abs) and not dsp._is_magnitude_map(other.transform)
+    B, M, N = 2, 4801, 3
+    zc = torch.randn(B, M, N, dtype=cd, device=gpu)
+    zc[0, 5, 1] = 0
+    planar = ops._empty_planar((B, M, N), cd, gpu)
+    planar.copy_(zc)
+    assert not planar.is_contiguous()
+    w = torch.randn(B, M, N, dtype=dt, device=gpu)
+    for z0 in (zc, planar):
+        res = []
+        for on in (True, False):
+            dsp.MAGNITUDE_LAYER = on
+            try:
+                z = z0.detach().clone() if z0.is_contiguous() else z0.detach()
+                z = z.requires_grad_(True)
+                y = layer(z)
+                (g,) = torch.autograd.grad((y * w).sum(), [z])
+                res.append((y.detach(), g))
+            finally:
+                dsp.MAGNITUDE_LAYER = True
+        assert res[0][0].dtype == dt and res[0][0].shape == (B, M, N)
+        assert relerr(res[0][0], res[1][0]) < tol and relerr(res[0][1], res[1][1]) < tol
+        assert float(res[0][0][0, 5, 1]) == 0.0 and complex(res[0][1][0, 5, 1]) == 0
+    y2 = other(zc)
+    assert relerr(y2, torch.abs(zc) * 1.0000001) < tol

@@ -1,19 +1,17 @@
-# config 5 with the N = 32 solve variants (0: shuffle kernel for a materialised loop matrix, 3: two rows per lane with DPP broadcasts)
 cd /root/repo
-for v in 0 3 0 3; do
-python - $v <<'PY'
+timeout 1200 python -m pytest tests/test_hip_kernels.py tests/test_round3_parity.py tests/test_hip_parity.py tests/test_objectives.py -q -m gpu -x -k "magnitude or e7 or colorless or constant or objectives or mse" 2>&1 | tail -4
+python tools/train_colorless_fdn.py --steps 300 --graph --fused-adam 2>/dev/null | tail -1 | python -c "import sys, json; d = json.loads(sys.stdin.read()); print('colorless:', round(d['ms_per_step'], 4), 'ms per step; losses', d['loss_last'])"
+python - <<'PY'
+from flamo_amd.processor import dsp
+dsp.MAGNITUDE_LAYER = False
 import runpy, sys, io, contextlib, json
-v = int(sys.argv[1])
-from flamo_amd import _lib
-_lib.lib().fl_debug_set_solve_variant(v)
-sys.argv = ["tools/bench_fdn.py", "--workload", "config5", "--dtype", "f32", "--steps", "8"]
+sys.argv = ["tools/train_colorless_fdn.py", "--steps", "300", "--graph", "--fused-adam"]
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
     try:
-        runpy.run_path("tools/bench_fdn.py", run_name="__main__")
+        runpy.run_path("tools/train_colorless_fdn.py", run_name="__main__")
     except SystemExit:
         pass
 d = json.loads(buf.getvalue().strip().splitlines()[-1])
-print(f"solve variant {v}: {d['f32']['ms_per_step']:.3f} ms eager, {d['f32'].get('graph_ms_per_step', 0):.3f} ms replayed; grad relerr {d['f32'].get('graph_vs_eager_grad_relerr')}")
+print("colorless, magnitude layer as the callable:", round(d["ms_per_step"], 4), "ms per step; losses", d["loss_last"])
 PY
-done
