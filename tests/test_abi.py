@@ -161,3 +161,53 @@ def test_anonymous_gain_maps_are_recognised_by_probe():
     geq = dsp.parallelGEQ(size=(4,), nfft=64)
     geq.map = lambda x: 20 * torch.log10(torch.sigmoid(x))                                       # set after construction, as e8_fdn.py does
     assert dsp._gain_map_kind(geq.map) == "sigmoid"
+
+
+def test_criteria_and_magnitude_layer_host_logic():
+    """Host-side logic of the round-5 drop-ins, no GPU: the magnitude-layer probe takes exactly the callables that are torch.abs
+    (values and gradient bit for bit) and nothing else; flamo_amd.optimize.mse_loss / sparsity_loss on host tensors run the
+    reference's own lines (flamo/optimize/loss.py:12-103) -- constructors, attributes and values."""
+    import math
+    from flamo_amd.optimize import mse_loss, sparsity_loss
+    from flamo_amd.processor import dsp
+    assert dsp._is_magnitude_map(torch.abs)
+    assert dsp._is_magnitude_map(lambda x: torch.abs(x))
+    assert dsp._is_magnitude_map(lambda z: z.abs())
+    assert dsp._is_magnitude_map(lambda x: torch.abs(x) + 0.0 * x.real)          # the same function written differently: taken
+    assert not dsp._is_magnitude_map(lambda x: torch.abs(x) + 1e-30)
+    assert not dsp._is_magnitude_map(lambda x: torch.abs(x) ** 2)
+    assert not dsp._is_magnitude_map(lambda x: x)
+    assert not dsp._is_magnitude_map(lambda x: torch.abs(x).float())
+    assert not dsp._is_magnitude_map(lambda x: 1 / 0)
+    layer = dsp.Transform(lambda x: torch.abs(x))
+    z = torch.randn(2, 5, 3, dtype=torch.complex128)
+    assert torch.equal(layer(z), torch.abs(z))          # host tensors: the callable itself
+    crit = mse_loss(nfft=1024, device="cpu")
+    assert crit.name == "MSE" and crit.nfft == 1024 and isinstance(crit.mse_loss, torch.nn.MSELoss)
+    yp, yt = torch.randn(2, 7, 3, dtype=torch.float64, requires_grad=True), torch.randn(2, 7, 1, dtype=torch.float64)
+    want = torch.nn.MSELoss()(yp.sum(-1), yt.squeeze(-1))
+    assert torch.equal(crit(yp, yt), want)
+
+    class _Mix:
+        def __init__(self, A):
+            self.param = A
+            self.map = lambda x: x
+
+    class _Model:
+        def __init__(self, A):
+            core = type("C", (), {})()
+            core.feedback_loop = type("L", (), {})()
+            core.feedback_loop.feedback = _Mix(A)
+            self._core = core
+
+        def get_core(self):
+            return self._core
+
+    for A in (torch.randn(6, 6, dtype=torch.float64), torch.randn(3, 4, 4, dtype=torch.float64)):
+        N = A.shape[-1]
+        got = sparsity_loss()(None, None, _Model(A))
+        if A.dim() == 3:
+            ref = torch.mean((torch.sum(torch.abs(A), dim=(-2, -1)) - N * math.sqrt(N)) / (N * (1 - math.sqrt(N))))
+        else:
+            ref = -(torch.sum(torch.abs(A)) - N * math.sqrt(N)) / (N * (math.sqrt(N) - 1))
+        assert abs(float(got) - float(ref)) < 1e-14
