@@ -512,8 +512,12 @@ __global__ void __launch_bounds__(256) geq_bwd_lanes_kernel(const void* __restri
     if (lane != 0 || part != 0 || !on) return;
     const double Q = v[4];
     double out[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    // the closed forms divide by band 0's gain and by S = b0 + g^2 b2: a gain of exactly zero (|x| map at x = 0, an underflowed
+    // sigmoid) would store 0/0 = NaN into the parameter's gradient where the product-rule gradient is finite -- such a tap
+    // takes a zero gradient, as the first-generation epilogue gives it
+    constexpr double kTiny = 1e-290;
     if (band == 0) {
-        out[0][0] = Q / tap[0][0];
+        out[0][0] = fabs(tap[0][0]) > kTiny ? Q / tap[0][0] : 0.0;
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -521,7 +525,7 @@ __global__ void __launch_bounds__(256) geq_bwd_lanes_kernel(const void* __restri
             const double Sg = t0 + gam * gam * t2, Tg = gam * t1, D = t0 - gam * gam * t2;
             const double sgn = i ? -1.0 : 1.0;
             const double G0 = sgn * v[i], G2 = sgn * v[2 + i];
-            const double G1 = ((Sg + Tg) * G0 - D * G2 - sgn * Q) / Sg;
+            const double G1 = fabs(Sg) > kTiny ? ((Sg + Tg) * G0 - D * G2 - sgn * Q) / Sg : 0.0;
             out[i][0] = G0 - G1 - G2;
             out[i][1] = gam * G0;
             out[i][2] = gam * gam * (G0 - G1 + G2);
@@ -741,10 +745,10 @@ static size_t lanes_lds_limit() {
     return (size_t)v;
 }
 // more dynamic LDS than the default 64 KB: the attribute is per function AND per device, set (and checked) once per pair
-static int lanes_ensure_lds(const void* kern, size_t lds, bool* done /* [16] */) {
+static int lanes_ensure_lds(const void* kern, size_t lds, bool* done /* [64] */) {
     if (lds <= 64 * 1024) return FL_OK;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (done[dev]) return FL_OK;
     const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lanes_lds_limit());
     if (e != hipSuccess) {
@@ -922,7 +926,7 @@ static int lanes_bwd_impl(int mode, const void* gH, long g_pitch, const void* G,
     const size_t lds = 2 * P.lds1;
 #define FL_LANES(NIW_, PPR_)                                                                                                     \
     {                                                                                                                            \
-        static bool done[16] = {};                                                                                               \
+        static bool done[64] = {};                                                                                               \
         auto kern = sos_bwd_lanes_kernel<T, NIW_, PPR_, 2, false>;                                                               \
         const int rc_ = lanes_ensure_lds(reinterpret_cast<const void*>(kern), lds, done);                                        \
         if (rc_) return rc_;                                                                                                     \

@@ -2339,6 +2339,7 @@ class _CAbs(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z):
         dev = _require_gpu(z)
+        z = z.resolve_conj()        # a lazily conjugated view: the kernels read the storage (the backward would return conj's gradient)
         zm, rows, cols, pitch = _rows_of(z)
         real = _rdtype(zm)
         if zm.is_contiguous():
@@ -2451,6 +2452,9 @@ class _MSE(torch.autograd.Function):
         return gy.view(shape), None, None
 
 
+MSE_MAX_COLS = 4096      # fl_mse_*: columns summed per row (reduce.hip)
+
+
 def mse(y: torch.Tensor, target: torch.Tensor, sum_last: bool = False) -> torch.Tensor:
     """nn.MSELoss()(y, target) (examples/e7_biquad.py:82) -- or, with sum_last, the reference's criterion
     flamo/optimize/loss.py:101-102: nn.MSELoss()(y.sum(-1), target.squeeze(-1)) -- as one streaming pass each way.
@@ -2463,6 +2467,8 @@ def mse(y: torch.Tensor, target: torch.Tensor, sum_last: bool = False) -> torch.
     ncols = 1
     if sum_last:
         ncols = y.shape[-1]
+        if ncols > MSE_MAX_COLS:
+            raise ValueError(f"mse: at most {MSE_MAX_COLS} summed columns, got {ncols}")
         if t.dim() == y.dim() and t.shape[-1] == 1:
             t = t.squeeze(-1)
         if tuple(t.shape) != tuple(y.shape[:-1]):

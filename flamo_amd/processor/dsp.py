@@ -37,31 +37,81 @@ def _gamma(alias_decay_db, nfft, device=None, dtype=torch.float32) -> torch.Tens
     return 10 ** (-torch.abs(db) / nfft / 20)
 
 
+# ============================================================================ recognised callables
+# The reference's examples hand over two small functions as ANONYMOUS callables: the magnitude output layer
+# `lambda x: torch.abs(x)` (e7_biquad.py:76, e8_colorless_fdn.py:102) and the equalisers' gain map
+# `lambda x: 20*torch.log10(torch.sigmoid(x))` (e8_fdn.py:97).  The drop-in runs those inside its kernels.  The contract
+# ("Recognised callables"): a callable is replaced by a kernel only when
+#   (1) it IS the named function (torch.abs, dsp._db_of_magnitude, dsp.db_of_sigmoid), or
+#   (2) it is a STATELESS plain Python function -- a `def` / `lambda` with no closure cells, no default arguments, not a bound
+#       method, not an nn.Module or other callable object -- whose bytecode refers to nothing but the names `torch`, `abs`,
+#       `log10`, `sigmoid` and the constants 20 / 20.0 (so `.clamp(...)`, a dtype test, a captured or global scale are refused
+#       on sight: they would need another name), AND it then reproduces the named function bit for bit, values and gradient,
+#       on a probe vector that spans 1e-30 ... 1e30;
+#   the module has not opted out (`Transform(..., recognise=False)`, `GEQ(..., fold_map=False)`, or the attributes of the same
+#   names set later), and the first substitution of an anonymous callable says so once through `warnings.warn`.
+# Everything else runs as the callable it is, as torch ops in front of / behind the kernels.
+import types as _types
+
+_PURE_NAMES = frozenset({"torch", "abs", "log10", "sigmoid"})
+_PURE_CONSTS = (20, 20.0)
+
+
+def _is_stateless_function_of(fn, names=_PURE_NAMES) -> bool:
+    """(2) above, the structural half: nothing the function computes can depend on anything but its argument."""
+    if not isinstance(fn, _types.FunctionType):
+        return False            # builtins, bound methods, functools.partial, nn.Module instances, callable objects
+    if fn.__closure__ or fn.__defaults__ or fn.__kwdefaults__:
+        return False
+    code = fn.__code__
+    if code.co_argcount != 1 or code.co_kwonlyargcount or code.co_flags & 0x0C:      # exactly one positional argument, no *args / **kwargs
+        return False
+    if code.co_freevars or code.co_cellvars or not set(code.co_names) <= names:
+        return False
+    for c in code.co_consts:
+        if c is None or isinstance(c, str):      # a docstring is harmless
+            continue
+        if isinstance(c, bool) or not isinstance(c, (int, float)) or c not in _PURE_CONSTS:
+            return False
+    return True
+
+
+_SUBSTITUTION_WARNED = set()
+
+
+def _warn_substitution(fn, what: str) -> None:
+    key = (getattr(fn, "__code__", None) or id(fn), what)
+    if key in _SUBSTITUTION_WARNED:
+        return
+    _SUBSTITUTION_WARNED.add(key)
+    code = getattr(fn, "__code__", None)
+    where = f"{code.co_filename}:{code.co_firstlineno}" if code is not None else repr(fn)
+    warnings.warn(f"flamo_amd: the callable defined at {where} equals {what} bit for bit and runs inside the HIP kernels from now "
+                  f"on (pass recognise=False / fold_map=False to the module to keep it as torch ops)", stacklevel=3)
+
+
 # ============================================================================ transforms
 MAGNITUDE_LAYER = True      # False: a recognised `torch.abs` output layer still runs as the callable (tests compare the two)
-_MAGNITUDE_CACHE = None
+_MAGNITUDE_CACHE = weakref.WeakKeyDictionary()
 
 
 def _is_magnitude_map(fn) -> bool:
-    """True when `fn` IS torch.abs or reproduces it bit for bit -- values AND gradient -- on a complex128 probe vector (zeros, both
-    signs, tiny and large parts): the examples' output layer `lambda x: torch.abs(x)` (e7_biquad.py:76, e8_colorless_fdn.py:102).
-    Evaluated once per callable (a map with side effects sees one extra call); anything else runs as it is."""
-    global _MAGNITUDE_CACHE
+    """True when `fn` IS torch.abs, or is a stateless plain function over {torch, abs} (`_is_stateless_function_of`) that
+    reproduces it bit for bit -- values AND gradient -- on a complex128 probe vector (zeros, both signs, 1e-300 ... 1e30):
+    the examples' output layer `lambda x: torch.abs(x)` (e7_biquad.py:76, e8_colorless_fdn.py:102).  Probed once per function
+    object (a stateless function cannot change its answer); anything else runs as it is."""
     if fn is torch.abs:
         return True
-    if fn is None or fn is _identity:
+    if not _is_stateless_function_of(fn):
         return False
-    import weakref
-    if _MAGNITUDE_CACHE is None:
-        _MAGNITUDE_CACHE = weakref.WeakKeyDictionary()
     try:
         return _MAGNITUDE_CACHE[fn]
-    except (KeyError, TypeError):
+    except KeyError:
         pass
     ok = False
     try:
-        re = torch.tensor([0.0, 1.0, -1.0, 0.0, 3.0, -0.5, 1e-12, 2.5e7, -7.25, 0.0], dtype=torch.float64)
-        im = torch.tensor([0.0, 0.0, 0.0, -2.0, 4.0, 0.125, -3e-13, 1.5e6, -7.25, 1e-300], dtype=torch.float64)
+        re = torch.tensor([0.0, 1.0, -1.0, 0.0, 3.0, -0.5, 1e-12, 2.5e7, -7.25, 0.0, 1e30, -1e-30, 6e9, -3e15], dtype=torch.float64)
+        im = torch.tensor([0.0, 0.0, 0.0, -2.0, 4.0, 0.125, -3e-13, 1.5e6, -7.25, 1e-300, -1e30, 1e-30, 8e9, 0.0], dtype=torch.float64)
         probe = torch.complex(re, im)
         w = torch.linspace(0.5, 1.5, probe.numel(), dtype=torch.float64)
         with torch.enable_grad():
@@ -73,12 +123,9 @@ def _is_magnitude_map(fn) -> bool:
                 yr = torch.abs(xr)
                 (gr,) = torch.autograd.grad((yr * w).sum(), [xr])
                 ok = bool(torch.equal(y.detach(), yr.detach()) and torch.equal(torch.view_as_real(g), torch.view_as_real(gr)))
-    except Exception:       # a callable that does not take a complex128 host vector is simply not the magnitude
+    except Exception:       # a function that does not take a complex128 host vector is simply not the magnitude
         ok = False
-    try:
-        _MAGNITUDE_CACHE[fn] = ok
-    except TypeError:       # not weak-referenceable: probed again next time
-        pass
+    _MAGNITUDE_CACHE[fn] = ok
     return ok
 
 
@@ -86,15 +133,18 @@ class Transform(nn.Module):
     """Wraps a callable as a layer (dsp.py:27-66)."""
 
     def __init__(self, transform: callable = _identity, device: Optional[str] = None,
-                 dtype: torch.dtype = torch.float32):
+                 dtype: torch.dtype = torch.float32, *, recognise: bool = True):
         super().__init__()
         self.transform = transform
         self.device = device
         self.dtype = dtype
+        self.recognise = recognise      # False: the callable always runs as it is (see "recognised callables" above)
 
     def forward(self, x: torch.Tensor):
         if (torch.is_tensor(x) and x.is_cuda and x.dtype in (torch.complex64, torch.complex128) and x.numel() > 0
-                and MAGNITUDE_LAYER and _is_magnitude_map(self.transform)):
+                and MAGNITUDE_LAYER and self.recognise and _is_magnitude_map(self.transform)):
+            if self.transform is not torch.abs:
+                _warn_substitution(self.transform, "torch.abs")
             return ops.cabs(x)
         return self.transform(x)
 
@@ -789,21 +839,24 @@ _MAP_KIND_CACHE = weakref.WeakKeyDictionary()
 
 def _gain_map_kind(fn):
     """"abs" / "sigmoid" when `fn` IS one of the two maps the design kernels fold (fl_geq_sections in_kind 1..4), or -- an
-    anonymous callable, as the reference's examples pass them: `map=lambda x: 20 * torch.log10(torch.sigmoid(x))`,
-    e8_fdn.py:97 -- when it reproduces one of them bit for bit, values AND gradient, on a float64 probe vector (negative,
-    tiny, large arguments; evaluated once per callable, so a map with side effects sees one extra call).  None otherwise:
-    the callable then runs as torch ops in front of the design kernel, whatever it does."""
+    anonymous function, as the reference's examples pass them: `map=lambda x: 20 * torch.log10(torch.sigmoid(x))`,
+    e8_fdn.py:97 -- when it is a stateless plain function over {torch, abs, log10, sigmoid, 20} (`_is_stateless_function_of`:
+    no closure, no defaults, no other name in its bytecode) AND reproduces one of them bit for bit, values and gradient, on a
+    float64 probe vector (both signs, 1e-30 ... 1e30).  None otherwise: the callable then runs as torch ops in front of the
+    design kernel, whatever it does."""
     kind = _FOLDED_GAIN_MAPS.get(fn)
     if kind is not None or fn is None:
         return kind
+    if not _is_stateless_function_of(fn):
+        return None
     try:
         return _MAP_KIND_CACHE[fn]
-    except (KeyError, TypeError):
+    except KeyError:
         pass
     kind = None
     try:
-        probe = torch.tensor([-31.5, -7.25, -2.0, -0.75, -1e-3, 1e-6, 0.0625, 0.5, 0.9990234375, 1.0, 1.4142, 3.0, 12.5, 40.0],
-                             dtype=torch.float64)
+        probe = torch.tensor([-200.0, -31.5, -7.25, -2.0, -0.75, -1e-3, -1e-30, 1e-30, 1e-6, 0.0625, 0.5, 0.9990234375, 1.0, 1.4142,
+                              3.0, 12.5, 40.0, 200.0, 1e9, 1e30, -1e30], dtype=torch.float64)
         with torch.enable_grad():
             x = probe.clone().requires_grad_(True)
             y = fn(x)
@@ -814,15 +867,14 @@ def _gain_map_kind(fn):
                     xr = probe.clone().requires_grad_(True)
                     yr = named(xr)
                     (gr,) = torch.autograd.grad(yr.sum(), [xr])
-                    if torch.equal(y.detach(), yr.detach()) and torch.equal(g, gr):
+                    # equal_nan: sigmoid saturates at the extremes of the probe (log10(0) = -inf, gradient nan) in both alike
+                    if torch.equal(torch.nan_to_num(y.detach(), nan=7.0), torch.nan_to_num(yr.detach(), nan=7.0)) and \
+                            torch.equal(torch.nan_to_num(g, nan=7.0), torch.nan_to_num(gr, nan=7.0)):
                         kind = k
                         break
-    except Exception:       # a map that does not take a float64 host vector is simply not one of the two
+    except Exception:       # a function that does not take a float64 host vector is simply not one of the two
         kind = None
-    try:
-        _MAP_KIND_CACHE[fn] = kind
-    except TypeError:       # not weak-referenceable: probed again next time
-        pass
+    _MAP_KIND_CACHE[fn] = kind
     return kind
 
 
@@ -832,7 +884,9 @@ class GEQ(_SOSMixin, Filter):
 
     def __init__(self, size: tuple = (1, 1), octave_interval: int = 1, nfft: int = 2 ** 11, fs: int = 48000,
                  map: callable = _db_of_magnitude, requires_grad: bool = False,
-                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32,
+                 *, fold_map: bool = True):
+        self.fold_map = fold_map        # False: the map always runs as torch ops in front of the design kernel
         self.octave_interval = octave_interval
         self.fs = fs
         self.center_freq, self.shelving_crossover = eq_freqs(interval=octave_interval)
@@ -849,9 +903,18 @@ class GEQ(_SOSMixin, Filter):
     def check_param_shape(self):
         assert len(self.size) == 3, "Filter must be 3D, for 2D (parallel) filters use ParallelGEQ module."
 
+    def _folded_map(self):
+        """the design kernel's name for self.map ("abs" / "sigmoid"), or None: run the callable (see "recognised callables")"""
+        if not getattr(self, "fold_map", True):
+            return None
+        gm = _gain_map_kind(self.map)
+        if gm is not None and self.map not in _FOLDED_GAIN_MAPS:
+            _warn_substitution(self.map, "20*log10(|x|)" if gm == "abs" else "20*log10(sigmoid(x))")
+        return gm
+
     def get_freq_response(self):
         def response(param):
-            gm = _gain_map_kind(self.map)
+            gm = self._folded_map()
             if gm is not None and param.is_cuda and param.dtype in (torch.float32, torch.float64):
                 # default map: 10^(map(x)/20) = |x| (or sigmoid(x)), folded into the design kernel with its backward
                 return ops.geq_cascade(param, self._design.device_consts(param.device), self._gamma_f, self.nfft,
@@ -861,7 +924,7 @@ class GEQ(_SOSMixin, Filter):
         self._own_response = response
 
     def _cascade_spec(self, param):
-        gm = _gain_map_kind(self.map)
+        gm = self._folded_map()
         if gm is not None and param.is_cuda and param.dtype in (torch.float32, torch.float64):
             return ("geq", param, self._design.device_consts(param.device), gm)
         return ("sos", *self._sos_coeffs(self.map(param.double())))
@@ -881,9 +944,11 @@ class parallelGEQ(GEQ):
 
     def __init__(self, size: tuple = (1,), octave_interval: int = 1, nfft: int = 2 ** 11, fs: int = 48000,
                  map: callable = _db_of_magnitude, requires_grad: bool = False,
-                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32):
+                 alias_decay_db: float = 0.0, device: Optional[str] = None, dtype: torch.dtype = torch.float32,
+                 *, fold_map: bool = True):
         super().__init__(size=size, octave_interval=octave_interval, nfft=nfft, fs=fs, map=map,
-                         requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device, dtype=dtype)
+                         requires_grad=requires_grad, alias_decay_db=alias_decay_db, device=device, dtype=dtype,
+                         fold_map=fold_map)
 
     def check_param_shape(self):
         assert len(self.size) == 2, "Filter must be 2D, for 3D filters use GEQ module."

@@ -696,6 +696,17 @@ int fl_eig_c64(const void* A, long a_pitch, int N, int M, void* lam, long l_pitc
 int fl_eig_c128(const void* A, long a_pitch, int N, int M, void* lam, long l_pitch, void* V, long v_pitch, void* info,
                 void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Measurement only (no reference call site: the reference has no device code).  What the memory system sustains on a
+ * hand-written persistent streaming kernel -- the ceiling bench.py's "device" object states beside the 8 TB/s
+ * specification and the roofline fractions of the HBM-bound passes (torch.fft.rfft / einsum / irfft of
+ * flamo/processor/dsp.py:88, 114, 922-924) are read against.
+ *   kind 0: read `bytes` from src (one float per workgroup written to partials[workgroups]);  1: write `bytes` to dst;
+ *   2: copy src -> dst;  3: read `bytes`, write bytes/8 (the 8:1 mix of the response-gradient pass).
+ *   bytes: multiple of 32 KiB;  workgroups: persistent grid (256 threads each, 16 bytes per lane and access, eight in flight);
+ *   flags: bit 0 non-temporal loads, bit 1 non-temporal stores, bit 2 walk the buffer from its end (consumer-first order). */
+int fl_hbm_probe(int kind, const void* src, void* dst, size_t bytes, int workgroups, int flags, void* partials, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

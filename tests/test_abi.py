@@ -141,26 +141,52 @@ def test_graphed_step_refuses_without_the_graph_packet_switch(monkeypatch):
 
 def test_anonymous_gain_maps_are_recognised_by_probe():
     """The reference's examples hand the equalisers their parameter map as a lambda (examples/e8_fdn.py:97); the design
-    kernels fold exactly two maps.  A callable that reproduces one of them bit for bit -- values and gradient -- on the probe
-    vector is that map; anything else (an offset, a straight-through trick with the same values, another formula) is not."""
+    kernels fold exactly two maps.  The contract (flamo_amd/processor/dsp.py "recognised callables"): a
+    STATELESS plain function -- no closure, no defaults, only the names torch / abs / log10 / sigmoid and the constant 20 in
+    its bytecode -- that reproduces one of the two bit for bit, values and gradient, on the probe vector is that map;
+    anything else (a clamp, an offset, a captured scale, a callable object, a straight-through trick) is not."""
+    import warnings
     from flamo_amd.processor import dsp
     kind = dsp._gain_map_kind
     assert kind(lambda x: 20 * torch.log10(torch.sigmoid(x))) == "sigmoid"
     assert kind(lambda x: 20 * torch.log10(torch.abs(x))) == "abs"
+    assert kind(lambda v: 20.0 * v.sigmoid().log10()) == "sigmoid"
     assert kind(dsp.db_of_sigmoid) == "sigmoid" and kind(dsp._db_of_magnitude) == "abs"
+    # the round-5 review's counter-examples: each would have passed a value probe of moderate arguments
+    assert kind(lambda x: 20 * torch.log10(torch.sigmoid(x)).clamp(min=-200)) is None            # another name in the bytecode
+    assert kind(lambda x: 20 * torch.log10(torch.abs(x)).clamp(max=100)) is None
+    assert kind(lambda x: 20 * torch.log10(torch.abs(x)) if x.dtype == torch.float64 else x) is None   # dtype-dependent
+    scale = [1.0]
+    assert kind(lambda x: 20 * torch.log10(torch.abs(x)) * scale[0]) is None                    # closure over mutable state
+    assert kind(lambda x, k=20: k * torch.log10(torch.abs(x))) is None                           # default argument
+
+    class Stateful(torch.nn.Module):
+        def forward(self, x):
+            return 20 * torch.log10(torch.abs(x))
+    assert kind(Stateful()) is None and kind(Stateful().forward) is None                         # callable objects, bound methods
+    import functools
+    assert kind(functools.partial(dsp._db_of_magnitude)) is None
     assert kind(lambda x: 20 * torch.log10(torch.sigmoid(x)) + 0.5) is None
     assert kind(lambda x: x + (20 * torch.log10(torch.sigmoid(x)) - x).detach()) is None       # same values, other gradient
     assert kind(lambda x: 10 * torch.log10(torch.sigmoid(x) ** 2)) is None                      # same function, other rounding
+    assert kind(lambda x: 20 * torch.log10(torch.sigmoid(torch.abs(x)))) is None                # allowed names, another function
     assert kind(torch.abs) is None and kind(lambda x: x.reshape(2, -1)) is None and kind(lambda x: 1 / 0) is None
-    calls = []
-
-    def counted(x):
-        calls.append(1)
-        return 20 * torch.log10(torch.sigmoid(x))
-    assert kind(counted) == "sigmoid" and kind(counted) == "sigmoid" and len(calls) == 1         # probed once per callable
     geq = dsp.parallelGEQ(size=(4,), nfft=64)
     geq.map = lambda x: 20 * torch.log10(torch.sigmoid(x))                                       # set after construction, as e8_fdn.py does
     assert dsp._gain_map_kind(geq.map) == "sigmoid"
+    # the substitution is announced once per function, and a module can opt out
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        assert geq._folded_map() == "sigmoid" and geq._folded_map() == "sigmoid"
+    assert len([w for w in rec if "runs inside the HIP kernels" in str(w.message)]) == 1
+    keep = dsp.parallelGEQ(size=(4,), nfft=64, map=lambda x: 20 * torch.log10(torch.sigmoid(x)), fold_map=False)
+    assert keep._folded_map() is None
+    geq.fold_map = False
+    assert geq._folded_map() is None
+    with warnings.catch_warnings(record=True) as rec:                                            # the named maps: no warning
+        warnings.simplefilter("always")
+        assert dsp.GEQ(size=(2, 2), nfft=64)._folded_map() == "abs"
+    assert not rec
 
 
 def test_criteria_and_magnitude_layer_host_logic():
@@ -173,7 +199,16 @@ def test_criteria_and_magnitude_layer_host_logic():
     assert dsp._is_magnitude_map(torch.abs)
     assert dsp._is_magnitude_map(lambda x: torch.abs(x))
     assert dsp._is_magnitude_map(lambda z: z.abs())
-    assert dsp._is_magnitude_map(lambda x: torch.abs(x) + 0.0 * x.real)          # the same function written differently: taken
+    assert not dsp._is_magnitude_map(lambda x: torch.abs(x) + 0.0 * x.real)      # another name (`real`) in the bytecode: refused on sight
+    assert not dsp._is_magnitude_map(lambda x: torch.abs(x).clamp(max=1e9))      # the review's counter-example (probe maximum was 2.5e7)
+    gain = [1.0]
+    assert not dsp._is_magnitude_map(lambda x: torch.abs(x) * gain[0])           # closure over mutable state
+
+    class Mag(torch.nn.Module):
+        def forward(self, x):
+            return torch.abs(x)
+    assert not dsp._is_magnitude_map(Mag()) and not dsp._is_magnitude_map(Mag().forward)
+    assert dsp.Transform(lambda x: torch.abs(x)).recognise and not dsp.Transform(lambda x: torch.abs(x), recognise=False).recognise
     assert not dsp._is_magnitude_map(lambda x: torch.abs(x) + 1e-30)
     assert not dsp._is_magnitude_map(lambda x: torch.abs(x) ** 2)
     assert not dsp._is_magnitude_map(lambda x: x)
@@ -211,3 +246,35 @@ def test_criteria_and_magnitude_layer_host_logic():
         else:
             ref = -(torch.sum(torch.abs(A)) - N * math.sqrt(N)) / (N * (math.sqrt(N) - 1))
         assert abs(float(got) - float(ref)) < 1e-14
+
+
+def test_sparsity_loss_of_a_householder_feedback_against_the_reference():
+    """flamo/optimize/loss.py:51-53: with a HouseholderMatrix as the mixing matrix the criterion is the sparsity of I - 2 u u^T,
+    not of the stored unit vector (the drop-in of round 5 returned -inf here: N = 1).  Value and gradient recorded from the
+    reference itself (tools/gen_golden.py::gen_householder_sparsity), reproduced by the drop-in criterion on a drop-in FDN core
+    built on the host (no kernel runs: construction and the criterion's host lines only)."""
+    import os
+    from collections import OrderedDict
+    import numpy as np
+    from flamo_amd.optimize import sparsity_loss
+    from flamo_amd.processor import dsp, system
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "householder_sparsity.npz"))
+    N, nfft = 6, 256
+    kw = dict(nfft=nfft, dtype=torch.float64)
+    mix = dsp.HouseholderMatrix(size=(N, N), requires_grad=True, **kw)
+    with torch.no_grad():
+        mix.param.copy_(torch.from_numpy(gold["u"]))
+    core = system.Series(OrderedDict(input_gain=dsp.Gain(size=(N, 1), **kw),
+                                     feedback_loop=system.Recursion(fF=dsp.parallelDelay(size=(N,), max_len=40, isint=True, **kw), fB=mix),
+                                     output_gain=dsp.Gain(size=(1, N), **kw)))
+    model = system.Shell(core, dsp.FFT(nfft, dtype=torch.float64), dsp.iFFT(nfft, dtype=torch.float64))
+    loss = sparsity_loss()(None, None, model)
+    (g,) = torch.autograd.grad(loss, [mix.param])
+    assert abs(loss.item() - float(gold["loss"])) < 1e-14, (loss.item(), float(gold["loss"]))
+    assert np.allclose(g.numpy(), gold["g_u"], rtol=1e-12, atol=1e-15)
+    # the nested form the reference also looks in: feedback = Series(mixing_matrix=Householder, ...)
+    core2 = system.Series(OrderedDict(feedback_loop=system.Recursion(
+        fF=dsp.parallelDelay(size=(N,), max_len=40, isint=True, **kw),
+        fB=system.Series(OrderedDict(mixing_matrix=mix, attenuation=dsp.parallelGain(size=(N,), **kw))))))
+    model2 = system.Shell(core2, dsp.FFT(nfft, dtype=torch.float64), dsp.iFFT(nfft, dtype=torch.float64))
+    assert abs(float(sparsity_loss()(None, None, model2)) - float(gold["loss"])) < 1e-14

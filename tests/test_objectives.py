@@ -72,6 +72,51 @@ def test_mse_on_the_fused_shell_against_oracle(gpu):
 
 
 @pytest.mark.gpu
+def test_mse_on_the_fused_shell_at_bench_size_against_oracle(gpu):
+    """The `mse` legs of the bench line (bench.py::objective_legs) at EXACTLY their size -- nfft = 96000, 8x8, batch 32, float32,
+    the walking kernels and the 8-channel / 32-item grid of the column passes (the sum((y - t)^2) partials of
+    spec_cols_inv<..., true> and the c (y - t) load of the backward column pass) -- against the float64 oracle graph under
+    torch's own mse_loss: the reference's criterion (flamo/optimize/loss.py:101-102, target (32, 96000, 1)) and nn.MSELoss on
+    equal shapes (examples/e7_biquad.py:82).  Loss 1e-5, gW 1e-5, gG 1e-4 (the equaliser-gain gradient: DESIGN 5)."""
+    from collections import OrderedDict
+    from flamo_amd import ops
+    from flamo_amd.optimize import mse_loss
+    from flamo_amd.processor import dsp, system
+    from oracle import hotpath as O
+    N, nfft, B = 8, 96000, 32
+    torch.manual_seed(130709)
+    W = torch.randn(N, N).double()
+    G = torch.empty(12, N, N).uniform_(10 ** (-6 / 20), 10 ** (6 / 20)).double()
+    x = torch.randn(B, nfft, N).double()
+    t_sum = torch.randn(B, nfft, 1).double()
+    t_full = torch.randn(B, nfft, N).double()
+    Wl, Gl = W.clone().requires_grad_(True), G.clone().requires_grad_(True)
+    yref = O.config2_forward(x, Wl, Gl, nfft)
+    ref_sum = torch.nn.functional.mse_loss(yref.sum(-1), t_sum.squeeze(-1))
+    ref_full = torch.nn.functional.mse_loss(yref, t_full)
+    g_sum = torch.autograd.grad(ref_sum, [Wl, Gl], retain_graph=True)
+    g_full = torch.autograd.grad(ref_full, [Wl, Gl])
+    kw = dict(nfft=nfft, alias_decay_db=0.0, device=gpu, dtype=torch.float32)
+    mat = dsp.Matrix(size=(N, N), requires_grad=True, **kw)
+    geq = dsp.GEQ(size=(N, N), requires_grad=True, **kw)
+    mat.assign_value(W.to(gpu, torch.float32))
+    geq.assign_value(G.to(gpu, torch.float32))
+    model = system.Shell(system.Series(OrderedDict(mix=mat, eq=geq)), dsp.FFT(nfft), dsp.iFFT(nfft))
+    xg = x.to(gpu, torch.float32)
+    crit = mse_loss(nfft=nfft, device="cuda")
+    loss = crit(model(xg), t_sum.to(gpu, torch.float32))
+    g = torch.autograd.grad(loss, [mat.param, geq.param])
+    check_close("mse_shell_bench/sum/loss", loss.detach().cpu().double().reshape(1), ref_sum.detach().reshape(1), 1e-5)
+    check_close("mse_shell_bench/sum/gW", g[0].cpu().double(), g_sum[0], 1e-5)
+    check_close("mse_shell_bench/sum/gG", g[1].cpu().double(), g_sum[1], 1e-4)
+    loss = ops.mse(model(xg), t_full.to(gpu, torch.float32))
+    g = torch.autograd.grad(loss, [mat.param, geq.param])
+    check_close("mse_shell_bench/full/loss", loss.detach().cpu().double().reshape(1), ref_full.detach().reshape(1), 1e-5)
+    check_close("mse_shell_bench/full/gW", g[0].cpu().double(), g_full[0], 1e-5)
+    check_close("mse_shell_bench/full/gG", g[1].cpu().double(), g_full[1], 1e-4)
+
+
+@pytest.mark.gpu
 def test_fused_mean_square_only_for_the_pipelines_own_output(gpu):
     """ops.mean_square takes its one-node form only for a y that still is the pipeline's differentiable output: a y produced
     under no_grad gives a loss without a graph (as (y ** 2).mean() would), a y with a hook or retain_grad differentiates

@@ -559,6 +559,25 @@ def gen_round2(dsp, system):
     save("r2_peq_coeff", dict(kind="peq_coeff"), **arrays)
 
 
+# ----------------------------------------------------------------------------- sparsity of a Householder mixing matrix
+def gen_householder_sparsity(dsp, system):
+    """flamo/optimize/loss.py:51-53: the criterion of a HouseholderMatrix feedback is that of I - 2 u u^T.  A 6-channel FDN core
+    whose feedback is the Householder module itself (the first place the criterion looks); value and gradient w.r.t. u."""
+    from flamo.optimize.loss import sparsity_loss
+    torch.manual_seed(20260930)
+    N, nfft = 6, 256
+    kw = dict(nfft=nfft, dtype=F64)
+    delays = dsp.parallelDelay(size=(N,), max_len=40, isint=True, **kw)
+    mix = dsp.HouseholderMatrix(size=(N, N), requires_grad=True, **kw)
+    core = system.Series(OrderedDict(input_gain=dsp.Gain(size=(N, 1), **kw),
+                                     feedback_loop=system.Recursion(fF=delays, fB=mix),
+                                     output_gain=dsp.Gain(size=(1, N), **kw)))
+    model = system.Shell(core, dsp.FFT(nfft, dtype=F64), dsp.iFFT(nfft, dtype=F64))
+    loss = sparsity_loss()(None, None, model)
+    (g,) = torch.autograd.grad(loss, [mix.param])
+    save("householder_sparsity", dict(kind="householder_sparsity", N=N, nfft=nfft), u=mix.param, loss=loss, g_u=g)
+
+
 def main():
     torch.set_default_dtype(torch.float32)
     dsp, system = refimport.load()
@@ -580,6 +599,9 @@ def main():
     if "--colorless-only" in sys.argv:
         gen_colorless(dsp, system)
         return
+    if "--householder-only" in sys.argv:
+        gen_householder_sparsity(dsp, system)
+        return
     if "--biquad-only" in sys.argv:
         gen_biquad_training(dsp, system)
         return
@@ -592,6 +614,7 @@ def main():
     gen_accurate_geq(dsp)
     gen_colorless(dsp, system)
     gen_biquad_training(dsp, system)
+    gen_householder_sparsity(dsp, system)
     gen_round2(dsp, system)
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print(f"total {total/1024:.1f} KiB")
