@@ -111,7 +111,42 @@ def device_info(dev):
     e1.record()
     torch.cuda.synchronize()
     info["hbm_copy_probe_GBs"] = round(10 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    info["hbm_probe"] = hbm_probe(dev)
     return info
+
+
+def hbm_probe(dev):
+    """What the memory system sustains on the library's own hand-written streaming kernels (fl_hbm_probe, csrc/probe.hip:
+    persistent grid of 8 x 256 workgroups, 16 bytes per lane and access, eight in flight) -- the ceiling the HBM-bound passes are
+    read against, per access mix (read only / write only / copy / 8 bytes read per byte written: spec_gradh_walk's mix) and per
+    buffer size (98 MB: the pipeline's scratch, resident in the 256 MiB Infinity Cache when launches repeat; 1 GiB: HBM), the
+    better of the default and the non-temporal policy, GB/s of moved bytes over 10 back-to-back launches."""
+    from flamo_amd import _lib
+    L = _lib.lib()
+    GiB = 1 << 30
+    sizes = {"98MB": 98304000 // 32768 * 32768, "1GiB": GiB}
+    src = torch.empty(GiB // 4, device=dev).normal_()
+    dst = torch.empty(GiB // 4, device=dev)
+    part = torch.empty(4096, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    moved = {0: lambda n: n, 1: lambda n: n, 2: lambda n: 2 * n, 3: lambda n: n + n // 8}
+    out = {}
+    for kind, name in ((0, "read"), (1, "write"), (2, "copy"), (3, "read8_write1")):
+        for label, nbytes in sizes.items():
+            best = 0.0
+            for flags in (0, 3):
+                for _ in range(2):
+                    _lib.check(L.fl_hbm_probe(kind, src.data_ptr(), dst.data_ptr(), nbytes, 2048, flags, part.data_ptr(), st), "hbm_probe")
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    _lib.check(L.fl_hbm_probe(kind, src.data_ptr(), dst.data_ptr(), nbytes, 2048, flags, part.data_ptr(), st), "hbm_probe")
+                e1.record()
+                torch.cuda.synchronize()
+                best = max(best, 10 * moved[kind](nbytes) / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+            out[f"{name}_{label}_GBs"] = round(best, 1)
+    del src, dst
+    return out
 
 
 # ----------------------------------------------------------------------------- CPU baseline

@@ -181,6 +181,7 @@ _SIGNATURES = {
     "fl_matrix_exp_bwd_both_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "fl_eig_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
     "fl_eig_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
+    "fl_set_stream_policy": (_i, [C.c_uint, _i]),
     "fl_hbm_probe": (_i, [_i, _vp, _vp, _sz, _i, _i, _vp, _vp]),
 }
 

@@ -72,6 +72,7 @@ struct LanesArgs {
     int lds1;              // bytes of ONE set of tile buffers (the kernel takes two)
     long long* stamps;     // tuning: per (block, wavefront) cycles spent in {lane-per-bin phase, first barrier, MFMA, lane-per-section phase, second barrier, whole kernel}
     int skip;              // tuning: 1 skips the lane-per-bin phase's work, 2 the lane-per-section phase's
+    unsigned pol;          // cache policy of the operand loads (common.h: POL_LANES_*)
 };
 
 // one (lane, bin): (B, A) of the lane's section in the halves of the packed values.  11 packed + 1 multiply + 1 reciprocal
@@ -217,6 +218,11 @@ __global__ void __launch_bounds__(sizeof(RT) == 8 ? 384 : 768, sizeof(RT) == 8 ?
     auto at = [](const cT* base, unsigned byte_off) {
         return *reinterpret_cast<const cT*>(reinterpret_cast<const char*>(base) + byte_off);
     };
+    auto at_nt = [](const cT* base, unsigned byte_off) {
+        typedef RT rv2 __attribute__((ext_vector_type(2)));
+        const rv2 v = __builtin_nontemporal_load(reinterpret_cast<const rv2*>(reinterpret_cast<const char*>(base) + byte_off));
+        return cT(v.x, v.y);
+    };
     auto request = [&](const Tile& T) {
         const int np = (T.n + 1) & ~1;
 #pragma unroll
@@ -237,10 +243,20 @@ __global__ void __launch_bounds__(sizeof(RT) == 8 ? 384 : 768, sizeof(RT) == 8 ?
             } else if constexpr (RC) {
                 const unsigned goff = (unsigned)(((size_t)(row * NIW) * A.g_pitch + f) * sizeof(cT));
                 const unsigned hoff = (unsigned)(((size_t)(row * PPR + it_j[q]) * A.h_pitch + f) * sizeof(cT));
+                if (A.pol & POL_LANES_GH_NT) {
 #pragma unroll
-                for (int nn = 0; nn < NG; ++nn) pre[q].gv[nn] = at(A.gH + (size_t)nn * A.g_pitch, goff);
+                    for (int nn = 0; nn < NG; ++nn) pre[q].gv[nn] = at_nt(A.gH + (size_t)nn * A.g_pitch, goff);
+                } else {
 #pragma unroll
-                for (int j = 0; j < JPT; ++j) pre[q].hv[j] = at(A.G + (size_t)j * A.h_pitch, hoff);
+                    for (int nn = 0; nn < NG; ++nn) pre[q].gv[nn] = at(A.gH + (size_t)nn * A.g_pitch, goff);
+                }
+                if (A.pol & POL_LANES_G_NT) {
+#pragma unroll
+                    for (int j = 0; j < JPT; ++j) pre[q].hv[j] = at_nt(A.G + (size_t)j * A.h_pitch, hoff);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < JPT; ++j) pre[q].hv[j] = at(A.G + (size_t)j * A.h_pitch, hoff);
+                }
             } else {
                 pre[q].gv[0] = A.gH[(size_t)row * A.g_pitch + f];
                 pre[q].hv[0] = A.G[(size_t)row * A.h_pitch + f];
@@ -550,7 +566,7 @@ __global__ void __launch_bounds__(256) sos_response_rc_ba_kernel(const double* _
                                                                  int C, int Nmid, const float* __restrict__ Wr, double g,
                                                                  const cx<double>* __restrict__ Wd, int nfft, int bin0,
                                                                  int m_local, cx<float>* __restrict__ G, long g_pitch,
-                                                                 cx<float>* __restrict__ H, long h_pitch, GeqDesign gd) {
+                                                                 cx<float>* __restrict__ H, long h_pitch, GeqDesign gd, unsigned pol) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int s_first = gd.gain ? 1 : 0, Seff = S - s_first;
     f4* tab = reinterpret_cast<f4*>(smem);                                   // [Nmid][basis 2][Seff][2]
@@ -688,7 +704,12 @@ __global__ void __launch_bounds__(256) sos_response_rc_ba_kernel(const double* _
             } else {
                 hf = f2{eps_of<float>(), 0.f};
             }
-            if (q == 0 || two) G[(size_t)(m * Nmid + j) * g_pitch + e[q]] = cx<float>(hf.x, hf.y);
+            if (q == 0 || two) {
+                // G is read again by the backward pass only, a pipeline later: optionally past the caches (POL_RC_ST_NT)
+                f2* gp = reinterpret_cast<f2*>(G + (size_t)(m * Nmid + j) * g_pitch + e[q]);
+                if (pol & POL_RC_ST_NT) __builtin_nontemporal_store(hf, gp);
+                else *gp = hf;
+            }
 #pragma unroll
             for (int n = 0; n < NIW; ++n) {
                 const float w = NIW >= 4 && n < 4 ? w0[n & 3] : lw[j * NIW + n];
@@ -717,7 +738,7 @@ int rc_ba_launch(const void* b, const void* a, int S, int No, int Nmid, int Ni, 
 #define FL_BA(NIW_)                                                                                                              \
     hipLaunchKernelGGL((sos_response_rc_ba_kernel<NIW_>), grid, dim3(256), lds, (hipStream_t)stream, (const double*)b,           \
                        (const double*)a, S, No * Nmid, Nmid, (const float*)Wr, gamma, (const cx<double>*)Wd, nfft, bin0, m_local, \
-                       (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch, gd)
+                       (cx<float>*)G, g_pitch, (cx<float>*)H, h_pitch, gd, stream_policy())
     if (Ni == 2) FL_BA(2);
     else if (Ni == 4) FL_BA(4);
     else if (Ni == 8) FL_BA(8);
@@ -921,6 +942,7 @@ static int lanes_bwd_impl(int mode, const void* gH, long g_pitch, const void* G,
     A.partW = (T*)partW;
     A.stamps = g_lanes_stamps;
     A.skip = g_lanes_skip;
+    A.pol = stream_policy();
     lanes_fill(A, P);
     const dim3 grid(P.nbx, P.ng), block(P.threads);
     const size_t lds = 2 * P.lds1;

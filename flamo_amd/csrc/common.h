@@ -243,4 +243,29 @@ int check_hip(hipError_t e, const char* what);
 
 static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---------------------------------------------------------------- cache policy of the pipeline's data streams (host)
+// Each stream of the fused Shell pipeline (spectral.hip, specwalk.hip) and of the cascade kernels is loaded / stored either with
+// the default policy or non-temporally; which is right depends on who touched the data last and who reads it next (DESIGN 4.10:
+// a plain read of data that left the Infinity Cache runs at half the rate of a non-temporal one behind a writing pass).  One bit
+// per stream; `site` 1 selects the second set of column-pass bits (the gradient's transform: its input was written by the
+// previous launch, the forward transform's was not).  fl_set_stream_policy (flamo_hip.h) sets both.
+enum StreamPolicy : unsigned {
+    POL_COLS_LD_NT = 1u << 0,    // spec_cols_fwd: loads of the time-domain input
+    POL_COLS_ST_NT = 1u << 1,    // spec_cols_fwd: stores of the scratch rows
+    POL_INV_LD_NT = 1u << 2,     // spec_cols_inv: loads of the scratch rows
+    POL_INV_ST_NT = 1u << 3,     // spec_cols_inv: stores of the time-domain output
+    POL_WALK_S_NT = 1u << 4,     // spec_mid_walk: LDS-DMA of the scratch rows
+    POL_WALK_S2_PLAIN = 1u << 5, // spec_mid_walk: scratch rows out with the default policy (non-temporal otherwise)
+    POL_WALK_XP_PLAIN = 1u << 6, // spec_mid_walk: kept spectrum out with the default policy (non-temporal otherwise)
+    POL_GRADH_SG_NT = 1u << 7,   // spec_gradh_walk: LDS-DMA of the gradient's scratch rows
+    POL_GRADH_XP_NT = 1u << 8,   // spec_gradh_walk: LDS-DMA of the kept spectrum
+    POL_GRADH_DH_NT = 1u << 9,   // spec_gradh_walk: stores of dL/dH
+    POL_LANES_G_NT = 1u << 10,   // sos_bwd_lanes: loads of the cascade response G (written a forward pass ago)
+    POL_LANES_GH_NT = 1u << 11,  // sos_bwd_lanes: loads of dL/dH (written by the previous launch)
+    POL_RC_ST_NT = 1u << 12,     // sos_response_rc_ba: stores of G (read again only by the backward pass)
+    POL_SITE1_SHIFT = 16,        // bits 16, 17: POL_COLS_LD_NT / POL_COLS_ST_NT of site 1
+};
+unsigned stream_policy();        // the current mask
+int stream_site();               // 0 / 1
+
 }  // namespace fl

@@ -47,7 +47,9 @@ __global__ void __launch_bounds__(256, sizeof(real_t) == 8 ? 2 : 3) spec_cols_fw
     constexpr int NIT = B * VT, NR = (NIT + 255) / 256;
     const real_t* xb = a.x + (size_t)b * a.t_len * a.G + g0;
     cf v[RG][A];
-    auto load_group = [&](int r0) {
+    const bool ld_nt_pol = a.pol & 1u, st_nt_pol = a.pol & 2u;      // workgroup-uniform: one branch around each group of accesses
+    auto load_group_p = [&](int r0, auto nt_tag) {
+        constexpr bool NT = decltype(nt_tag)::value;
 #pragma unroll
         for (int rr = 0; rr < RG; ++rr) {
             const int item = threadIdx.x + (r0 + rr) * 256;
@@ -59,12 +61,16 @@ __global__ void __launch_bounds__(256, sizeof(real_t) == 8 ? 2 : 3) spec_cols_fw
                 for (int ta = 0; ta < A; ++ta) {
                     const int j = c0 + cl + a.L2 * (ta * B + tb);
                     const int t = 2 * j + par;
-                    real2 q = make_real2(0, 0);
-                    if (PLAIN || t < a.t_lim) q = at(reinterpret_cast<const real2*>(xb), RSZ * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par)));
+                    v2f q = {0, 0};
+                    if (PLAIN || t < a.t_lim) q = ldv<NT>(xb, RSZ * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par)));
                     v[rr][ta] = cf(q.x, q.y);
                 }
             }
         }
+    };
+    auto load_group = [&](int r0) {
+        if (ld_nt_pol) load_group_p(r0, std::true_type{});
+        else load_group_p(r0, std::false_type{});
     };
     // the first group's samples are requested BEFORE the twiddle tables are fetched: the tables' latency (a dependent
     // global round trip in front of the barrier) then overlaps the data's instead of preceding it
@@ -120,11 +126,17 @@ __global__ void __launch_bounds__(256, sizeof(real_t) == 8 ? 2 : 3) spec_cols_fw
         RegFFT<real_t, B, false>::run(v);
         const cf w1 = a.W[2 * c * ka];
         const cf* w2 = t2 + cl * B;
+        auto store_all = [&](auto nt_tag) {
+            constexpr bool NT = decltype(nt_tag)::value;
 #pragma unroll
-        for (int kb = 0; kb < B; ++kb) {
-            const int k1 = ka + A * kb;
-            at(out, ESZ * (((unsigned)k1 * (unsigned)a.L2 + (unsigned)c) * (unsigned)a.G + (unsigned)gl)) = v[kb] * (w1 * w2[kb]);
-        }
+            for (int kb = 0; kb < B; ++kb) {
+                const int k1 = ka + A * kb;
+                const cf r = v[kb] * (w1 * w2[kb]);
+                stv<NT>(out, ESZ * (((unsigned)k1 * (unsigned)a.L2 + (unsigned)c) * (unsigned)a.G + (unsigned)gl), v2f{r.x, r.y});
+            }
+        };
+        if (st_nt_pol) store_all(std::true_type{});
+        else store_all(std::false_type{});
     }
 }
 
@@ -147,7 +159,9 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
     constexpr int NIT = B * VT, NR = (NIT + 255) / 256;
     const cf* in = a.S + (size_t)b * a.L1 * a.L2 * a.G + g0;
     cf v[RG][A];
-    auto load_group = [&](int r0) {
+    const bool ld_nt_pol = a.pol & 1u, st_nt_pol = a.pol & 2u;      // workgroup-uniform: one branch around each group of accesses
+    auto load_group_p = [&](int r0, auto nt_tag) {
+        constexpr bool NT = decltype(nt_tag)::value;
 #pragma unroll
         for (int rr = 0; rr < RG; ++rr) {
             const int item = threadIdx.x + (r0 + rr) * 256;
@@ -155,10 +169,16 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
                 const int tb = item / VT, vv = item % VT;
                 const int cl = vv >> a.cgs, gl = vv & (CG - 1);
 #pragma unroll
-                for (int ta = 0; ta < A; ++ta)
-                    v[rr][ta] = at(in, ESZ * (((unsigned)(ta * B + tb) * (unsigned)a.L2 + (unsigned)(c0 + cl)) * (unsigned)a.G + (unsigned)gl));
+                for (int ta = 0; ta < A; ++ta) {
+                    const v2f q = ldv<NT>(in, ESZ * (((unsigned)(ta * B + tb) * (unsigned)a.L2 + (unsigned)(c0 + cl)) * (unsigned)a.G + (unsigned)gl));
+                    v[rr][ta] = cf(q.x, q.y);
+                }
             }
         }
+    };
+    auto load_group = [&](int r0) {
+        if (ld_nt_pol) load_group_p(r0, std::true_type{});
+        else load_group_p(r0, std::false_type{});
     };
     load_group(0);                                 // data first, tables behind it (see the forward pass)
     for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[a.n + j];
@@ -204,7 +224,9 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
             q.x *= s;
             q.y *= s;
             if (PLAIN || t < a.t_lim) {
-                at(reinterpret_cast<real2*>(yb), RSZ * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par))) = q;
+                const unsigned yo = RSZ * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par));
+                if (st_nt_pol) stv<true>(yb, yo, v2f{q.x, q.y});
+                else stv<false>(yb, yo, v2f{q.x, q.y});
                 sq += q.x * q.x + q.y * q.y;
             }
         }
@@ -1367,6 +1389,7 @@ int FL_SPEC_FN(fl_spec_cols_fwd)(const void* x, int Bn, int t_len, int G, void* 
     a.x = (const real_t*)x;
     a.S = (cf*)S;
     a.env_log2 = env_log2;
+    a.pol = (stream_policy() >> (stream_site() ? POL_SITE1_SHIFT : 0)) & 3u;
     return cols_launch(false, a, Bn, (hipStream_t)stream);
 }
 
@@ -1409,6 +1432,7 @@ static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, 
     a.env_log2 = env_log2;
     a.sumsq = sumsq;
     a.dev_scale = dev_scale;
+    a.pol = (stream_policy() >> 2) & 3u;      // POL_INV_LD_NT, POL_INV_ST_NT
     return cols_launch(true, a, Bn, (hipStream_t)stream);
 }
 extern "C" {

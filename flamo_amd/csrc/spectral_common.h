@@ -54,6 +54,7 @@ struct ColsArgs {
                           // of the input: ops.mean_square) -- a multiplication pass over the result otherwise
     double* sumsq;        // inverse, optional: sumsq[workgroup] = sum of the squares of the samples this workgroup stored (the
                           // objective's reduction rides in the pass that produces y: ops.mean_square never re-reads it)
+    unsigned pol;         // cache policy of this launch's streams: bit 0 non-temporal loads, bit 1 non-temporal stores (common.h: StreamPolicy)
 };
 
 // Global accesses as (workgroup-uniform base pointer) + (32-bit byte offset per lane): the address then costs one
@@ -76,6 +77,21 @@ __device__ __forceinline__ void st_nt(cf* base, unsigned byte_off, cf v) {
     q.x = v.x;
     q.y = v.y;
     __builtin_nontemporal_store(q, reinterpret_cast<v2f*>(reinterpret_cast<char*>(base) + byte_off));
+}
+
+// the same accesses with the policy as a template parameter (the kernels branch ONCE, workgroup-uniformly, around a whole group
+// of accesses: see ColsArgs::pol)
+template <bool NT>
+__device__ __forceinline__ v2f ldv(const void* base, unsigned byte_off) {
+    const v2f* p = reinterpret_cast<const v2f*>(reinterpret_cast<const char*>(base) + byte_off);
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void stv(void* base, unsigned byte_off, v2f q) {
+    v2f* p = reinterpret_cast<v2f*>(reinterpret_cast<char*>(base) + byte_off);
+    if constexpr (NT) __builtin_nontemporal_store(q, p);
+    else *p = q;
 }
 
 #ifdef FL_F64
@@ -116,6 +132,17 @@ __device__ __forceinline__ void dma16(const void* g, unsigned lds_byte_addr) {
 // the same with a wavefront-uniform base in an SGPR pair and a 32-bit per-lane byte offset (no 64-bit address arithmetic per piece)
 __device__ __forceinline__ void dma16s(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
     asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+// ... and with the non-temporal policy (streamed once by this CU, not wanted in L2 / the Infinity Cache afterwards)
+template <bool NT>
+__device__ __forceinline__ void dma16p(const void* g, unsigned lds_byte_addr) {
+    if constexpr (NT) asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(g), "s"(lds_byte_addr) : "memory");
+    else asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_byte_addr) : "memory");
+}
+template <bool NT>
+__device__ __forceinline__ void dma16sp(const void* sbase, unsigned voff, unsigned lds_byte_addr) {
+    if constexpr (NT) asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+    else asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;

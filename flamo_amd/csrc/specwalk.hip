@@ -41,6 +41,7 @@ struct WalkArgs {
     const int* bounds;    // work partition: workgroup w takes units [bounds[w], bounds[w+1]) (fl_spec_walk_partition), or null: equal counts
     cf* Xp;               // spectrum out, pair-major: Xp[(u*2 + e)*NI*LEN + ((n/2)*LEN + p)*2 + n%2], u = r*Bn + b, e = 0: bin k, 1: bin L-k; or null
     long long* dbg_times; // tuning: per-workgroup cycle stamps, or null
+    unsigned pol;         // cache policy of the streams (common.h: POL_WALK_*)
 };
 
 // a copy of a per-lane value the optimiser cannot see through: what is derived from it is recomputed where it is used
@@ -77,6 +78,11 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_nt16(cf* base, unsigned byte_off, f2 lo, f2 hi) {
     const f4 q = {lo.x, lo.y, hi.x, hi.y};
     __builtin_nontemporal_store(q, reinterpret_cast<f4*>(reinterpret_cast<char*>(base) + byte_off));
+}
+
+__device__ __forceinline__ void st_pl16(cf* base, unsigned byte_off, f2 lo, f2 hi) {
+    const f4 q = {lo.x, lo.y, hi.x, hi.y};
+    *reinterpret_cast<f4*>(reinterpret_cast<char*>(base) + byte_off) = q;
 }
 
 // ---------------------------------------------------------------- packed complex pieces (two floats per lane and instruction)
@@ -223,9 +229,15 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         }
         const char* base = reinterpret_cast<const char*>(a.S + (size_t)f_b * bstride_i);
         const int wv = wave & 3;
+        if (a.pol & POL_WALK_S_NT) {
 #pragma unroll
-        for (int q = 0; q < A / 2; ++q)
-            dma16s(base + (size_t)q * (2 * B * NI * 8), fetch_voff, stage_lds + (unsigned)(((wv * A + 2 * q) * 64) * 8));
+            for (int q = 0; q < A / 2; ++q)
+                dma16sp<true>(base + (size_t)q * (2 * B * NI * 8), fetch_voff, stage_lds + (unsigned)(((wv * A + 2 * q) * 64) * 8));
+        } else {
+#pragma unroll
+            for (int q = 0; q < A / 2; ++q)
+                dma16sp<false>(base + (size_t)q * (2 * B * NI * 8), fetch_voff, stage_lds + (unsigned)(((wv * A + 2 * q) * 64) * 8));
+        }
         if (++f_b == a.Bn) {             // the next fetch is for the next row pair
             f_b = 0;
             ++f_r;
@@ -311,8 +323,13 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
         const unsigned dst0 = (unsigned)(slot ? rm : r) * (unsigned)a.L2 * NO + (unsigned)(ka * NO + m);
         // (16-byte stores of channel pairs -- four DPP moves per column pair to buy one store instruction -- measured no faster:
         // 70.7-71.3 against 69.4-69.8 us in the step; the moves and their hazard slots cost what the stores saved)
+        if (a.pol & POL_WALK_S2_PLAIN) {
 #pragma unroll
-        for (int kb = 0; kb < B; ++kb) st_nt(S2b, 8u * (dst0 + (unsigned)(A * kb * NO)), v[kb] * t[kb]);
+            for (int kb = 0; kb < B; ++kb) at(S2b, 8u * (dst0 + (unsigned)(A * kb * NO))) = v[kb] * t[kb];
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < B; ++kb) st_nt(S2b, 8u * (dst0 + (unsigned)(A * kb * NO)), v[kb] * t[kb]);
+        }
         if (DBG) q_ph[2] += clock64() - q_t0;     // twiddles + stores
     };
 
@@ -421,7 +438,15 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
                     // from its staging buffer as one ds_read_b128
 #if FL_XP_PAIRS
                     cf* xo = a.Xp + ((size_t)u * 2 + grp) * (NI * LEN) + 2 * p;
-                    if (grp) {
+                    if (a.pol & POL_WALK_XP_PLAIN) {
+                        if (grp) {
+#pragma unroll
+                            for (int j = 0; j < NI / 2; ++j) st_pl16(xo, 16u * (unsigned)(j * LEN), xm[2 * j], xm[2 * j + 1]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NI / 2; ++j) st_pl16(xo, 16u * (unsigned)(j * LEN), xk[2 * j], xk[2 * j + 1]);
+                        }
+                    } else if (grp) {
 #pragma unroll
                         for (int j = 0; j < NI / 2; ++j) st_nt16(xo, 16u * (unsigned)(j * LEN), xm[2 * j], xm[2 * j + 1]);
                     } else {
@@ -522,6 +547,7 @@ struct GradhArgs {
     const float* out_scale;   // device scalar multiplied into dH on the way out, or null (the objective's 2 g / N: see ops.mean_square)
     int interior2_g;      // double its interior bins (irfft backward)
     long long* dbg_times; // tuning: 8 int64 per workgroup (begin, end, cycles in step 1, in step 2, per wavefront 0 / 1 / 4 / 7 of step 2)
+    unsigned pol;         // cache policy of the streams (common.h: POL_GRADH_*)
 };
 
 template <int A, int B, int NI, int NO, int NSC, int OCC, int DEPTH, bool DBG = false>
@@ -570,8 +596,13 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
         if (item0 >= NI1 || (item0 >= B * NOL && selfm)) item0 = 0;
         const int m0 = item0 % NOL, tb = (item0 / NOL) % B, slot = item0 / (NOL * B);
         const cf* src = a.Sg + (size_t)b * bstride_g + (size_t)(slot ? rm : r) * (a.L2 * NO) + ((hi * B + tb) * NO + mo + m0);
+        if (a.pol & POL_GRADH_SG_NT) {
 #pragma unroll
-        for (int q = 0; q < A / 2; ++q) dma16(src + q * (2 * B * NO), sg_buf + (unsigned)(((cw * A + 2 * q) * 64) * 8));
+            for (int q = 0; q < A / 2; ++q) dma16p<true>(src + q * (2 * B * NO), sg_buf + (unsigned)(((cw * A + 2 * q) * 64) * 8));
+        } else {
+#pragma unroll
+            for (int q = 0; q < A / 2; ++q) dma16p<false>(src + q * (2 * B * NO), sg_buf + (unsigned)(((cw * A + 2 * q) * 64) * 8));
+        }
     };
     auto fetch_x = [&](int i, int cw) {  // X[n][the 64 pairs of wavefront cw] of its side of the unit's block
         const int b = b_lo + i;
@@ -585,8 +616,13 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
         if (pp > LEN - 2) pp = LEN - 2;
         const cf* src = a.Xp + (((size_t)r * a.Bn + b) * 2 + (cw >> 2)) * (NI * LEN) + (lane >> 5) * LEN + pp;
 #endif
+        if (a.pol & POL_GRADH_XP_NT) {
 #pragma unroll
-        for (int q = 0; q < NI / 2; ++q) dma16(src + q * (2 * LEN), sx_buf + (unsigned)(((cw * NI + 2 * q) * 64) * 8));
+            for (int q = 0; q < NI / 2; ++q) dma16p<true>(src + q * (2 * LEN), sx_buf + (unsigned)(((cw * NI + 2 * q) * 64) * 8));
+        } else {
+#pragma unroll
+            for (int q = 0; q < NI / 2; ++q) dma16p<false>(src + q * (2 * LEN), sx_buf + (unsigned)(((cw * NI + 2 * q) * 64) * 8));
+        }
     };
 
     // the product's thread
@@ -772,10 +808,18 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
             for (int m = 0; m < NOL; ++m) {
                 unsigned o = 8u * ((unsigned)(mo + m) * (unsigned)a.ds_m + bin);
                 const unsigned step = 8u * (unsigned)a.ds_n;
+                if (a.pol & POL_GRADH_DH_NT) {
 #pragma unroll
-                for (int nn = 0; nn < NI; ++nn) {
-                    at(out, o) = c2(acc[m][nn]);
-                    o += step;
+                    for (int nn = 0; nn < NI; ++nn) {
+                        st_nt(out, o, c2(acc[m][nn]));
+                        o += step;
+                    }
+                } else {
+#pragma unroll
+                    for (int nn = 0; nn < NI; ++nn) {
+                        at(out, o) = c2(acc[m][nn]);
+                        o += step;
+                    }
                 }
             }
         }
@@ -937,6 +981,7 @@ static int gradh_walk_impl(const void* Sg, const void* Xp, void* dH_parts, long 
     a.Sg = (const cf*)Sg; a.Xp = (const cf*)Xp; a.dH = (cf*)dH_parts; a.ds_s = ds_s; a.ds_m = ds_m; a.ds_n = ds_n;
     a.W = (const cf*)W; a.n = nfft; a.L = nfft / 2; a.Bn = Bn; a.NS = n_slices;
     a.scale_g = (float)scale_g; a.interior2_g = interior2_g; a.dbg_times = g_walk_times; a.out_scale = out_scale;
+    a.pol = stream_policy();
     FL_REQUIRE((size_t)NO * (size_t)ds_m * 8ull < (1ull << 32), "spec_gradh_walk: a partial plane set exceeds 32-bit offsets");
     const int P = a.L1 / 2 + 1;
     hipStream_t st = (hipStream_t)stream;
@@ -1073,6 +1118,7 @@ int fl_spec_mid_walk_f32(const void* S, void* S2, void* Xp, const void* H, long 
     a.spec_scale = (float)spec_scale; a.spec_interior2 = spec_interior2; a.pre_half = pre_half; a.dbg_times = g_walk_times;
     a.Xp = (cf*)Xp;
     a.bounds = (const int*)bounds;
+    a.pol = stream_policy();
     FL_REQUIRE((size_t)a.L1 * a.L2 * (NI > NO ? NI : NO) * 8ull < (1ull << 32), "spec_mid_walk: a batch item exceeds 32-bit offsets");
     FL_REQUIRE(reinterpret_cast<uintptr_t>(S) % 16 == 0, "spec_mid_walk: S must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;

@@ -781,14 +781,22 @@ def permute_bins(H: torch.Tensor, nfft: int, inverse: bool = False) -> torch.Ten
     return _PermuteBins.apply(H, int(nfft), bool(inverse))
 
 
-def _spec_cols_fwd(x, nfft, env_log2):
-    """x: contiguous real (B, T, G) -> scratch (B*L*G,) complex"""
+def _spec_cols_fwd(x, nfft, env_log2, site=0):
+    """x: contiguous real (B, T, G) -> scratch (B*L*G,) complex.  site 1: the gradient's transform (its input was written by the
+    launch in front of it: another cache policy than for the forward transform's input, fl_set_stream_policy)"""
     B, T, G = x.shape
     S = torch.empty(B * (nfft // 2) * G, dtype=_cdtype(x.dtype), device=x.device)
-    with kernel_timer.span("spec_cols_fwd"):
-        _lib.check(_spec_fn("fl_spec_cols_fwd", x.dtype)(x.data_ptr(), B, T, G, S.data_ptr(),
-                                                         twiddles(nfft, x.dtype, x.device).data_ptr(), nfft, env_log2, _stream()),
-                   "spec_cols_fwd")
+    L = _lib.lib()
+    if site:
+        L.fl_set_stream_policy(0xFFFFFFFF, site)
+    try:
+        with kernel_timer.span("spec_cols_fwd"):
+            _lib.check(_spec_fn("fl_spec_cols_fwd", x.dtype)(x.data_ptr(), B, T, G, S.data_ptr(),
+                                                             twiddles(nfft, x.dtype, x.device).data_ptr(), nfft, env_log2, _stream()),
+                       "spec_cols_fwd")
+    finally:
+        if site:
+            L.fl_set_stream_policy(0xFFFFFFFF, 0)
     return S
 
 
@@ -992,7 +1000,7 @@ class _SpectralApply(torch.autograd.Function):
             g = g.clone()
         B = g.shape[0]
         # irfft' : g_Y[k] = w_k scale_i sum_t g_y[t] e_i(t) exp(-j w_k t) -- a forward transform with doubled interior bins
-        Sg = _spec_cols_fwd(g, nfft, env_i)
+        Sg = _spec_cols_fwd(g, nfft, env_i, site=1)
         gx = gH = None
         if walk:
             if need_h:

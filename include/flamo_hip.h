@@ -696,6 +696,13 @@ int fl_eig_c64(const void* A, long a_pitch, int N, int M, void* lam, long l_pitc
 int fl_eig_c128(const void* A, long a_pitch, int N, int M, void* lam, long l_pitch, void* V, long v_pitch, void* info,
                 void* stream);
 
+/* Cache policy of the pipeline's data streams (process-wide mask; csrc/common.h: enum StreamPolicy names the bits -- one per
+ * stream of the fused Shell pipeline: default or non-temporal loads / stores) and the launch SITE of the calling thread's next
+ * column passes (0: the forward transform of the input, 1: the gradient's transform, whose input the previous launch wrote).
+ * mask 0xFFFFFFFF / site < 0 leave the respective setting; returns the mask in force.  A tuning knob of the measurement
+ * (tools/dbg/policy_sweep.py), no reference call site; the library's default is the measured best. */
+int fl_set_stream_policy(unsigned mask, int site);
+
 /* ------------------------------------------------------------------------------------------------
  * Measurement only (no reference call site: the reference has no device code).  What the memory system sustains on a
  * hand-written persistent streaming kernel -- the ceiling bench.py's "device" object states beside the 8 TB/s
