@@ -181,6 +181,10 @@ _SIGNATURES = {
     "fl_matrix_exp_bwd_both_f64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "fl_eig_c64": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
     "fl_eig_c128": (_i, [_vp, _l, _i, _i, _vp, _l, _vp, _l, _vp, _vp]),
+    "fl_launch_pair_begin": (_i, []),
+    "fl_launch_pair_pending": (_i, []),
+    "fl_debug_launch_pair_count": (_l, []),
+    "fl_launch_pair_flush": (_i, [_vp]),
     "fl_set_stream_policy": (_i, [C.c_uint, _i]),
     "fl_hbm_probe": (_i, [_i, _vp, _vp, _sz, _i, _i, _vp, _vp]),
 }
@@ -199,9 +203,20 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
-def lib() -> C.CDLL:
-    """The loaded library.  Raises (never falls back) when it has not been built."""
+# A launch pair is open on this thread (ops.paired_launch): a recorded response launch must go out before ANY other library
+# call than the column pass that carries it -- every call site fetches the handle through lib(), which is where that is enforced.
+_pair = threading.local()
+
+
+def lib(pair_ok: bool = False) -> C.CDLL:
+    """The loaded library.  Raises (never falls back) when it has not been built.  ``pair_ok``: the caller is the launch that
+    carries a recorded one (see ops.paired_launch); every other call flushes it first."""
     global _lib
+    if not pair_ok and getattr(_pair, "stream_of", None) is not None and _lib is not None and _lib.fl_launch_pair_pending():
+        rc = _lib.fl_launch_pair_flush(_pair.stream_of())
+        _lib.fl_launch_pair_begin()
+        if rc != 0:
+            raise RuntimeError(f"libflamo_hip launch pair flush failed (code {rc}): " + _lib.fl_last_error().decode("utf-8", "replace"))
     if _lib is None:
         with _lock:
             if _lib is None:

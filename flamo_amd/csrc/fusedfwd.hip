@@ -1,0 +1,90 @@
+// The input's column pass and the cascade response in ONE grid (see fusedfwd.h).  gfx950 only.
+//
+// Workgroup i of T = n_cols + n_rc takes the response role when floor((i + 1) n_rc / T) > floor(i n_rc / T) -- the response's
+// workgroups are spread evenly through the grid, so that every CU holds both kinds for the whole launch: the response's packed
+// multiply-adds issue while the column pass's wavefronts wait for HBM.  Both bodies are the device functions the plain kernels
+// run (spec_cols_body.h, rc_ba_body.h): same arithmetic, same results bit for bit.
+#include "spectral_common.h"
+#include "spec_cols_body.h"
+#include "fusedfwd.h"
+
+namespace fl {
+using namespace sp32;
+
+template <int A, int B, int VT, int RG, bool PLAIN, int NIW>
+__global__ void __launch_bounds__(256, 5) cols_fwd_rc_kernel(ColsArgs a, RcBaArgs r, int n_cols, int n_rc, int rc_gx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long T = (long)n_cols + n_rc;
+    const int i = blockIdx.x;
+    const int before = (int)(((long)i * n_rc) / T), after = (int)(((long)(i + 1) * n_rc) / T);
+    if (after > before) rc_ba_body<NIW>(r, before % rc_gx, before / rc_gx, smem);
+    else spec_cols_fwd_body<A, B, VT, RG, PLAIN>(a, i - before, smem);
+}
+
+static thread_local bool t_pair_mode = false, t_have = false;
+static thread_local PendingRc t_pending;
+static long g_pair_launches = 0;      // grids issued with both roles (tests check that the path under test is this one)
+static int g_pair_enabled = [] { const char* e = getenv("FLAMO_LAUNCH_PAIR"); return e ? atoi(e) : 1; }();
+
+bool pair_mode() { return t_pair_mode && g_pair_enabled; }
+void pending_rc_put(const PendingRc& p) {
+    t_pending = p;
+    t_have = true;
+}
+bool pending_rc_take(PendingRc& out) {
+    if (!t_have) return false;
+    out = t_pending;
+    t_have = false;
+    return true;
+}
+
+int fused_cols_rc_launch(const ColsArgs& a, unsigned n_cols, const PendingRc& rc, hipStream_t st) {
+    // the metric's shapes: 200-point columns (nfft = 96000), the 16-wide tile with one load group, 4 or 8 channels on the factor
+    const int vt = a.CT << a.cgs;
+    if (a.L1 != 200 || vt != 16 || !(rc.niw == 8 || rc.niw == 4)) return FL_ERR_UNSUPPORTED;
+    constexpr int A = 8, B = 25, LEN = A * B, LENP = LEN | 1;
+    size_t lds = ((size_t)16 * LENP + LEN + (size_t)16 * B) * sizeof(cf);
+    if (rc.lds > lds) lds = rc.lds;
+    const long n_rc = (long)rc.gx * rc.gy, total = (long)n_cols + n_rc;
+    if (total >= (1l << 31)) return FL_ERR_UNSUPPORTED;
+    const bool plain = a.env_log2 == 0.0 && a.t_lim >= a.n;
+#define FL_PAIR(PLAIN_, NIW_)                                                                                          \
+    hipLaunchKernelGGL((cols_fwd_rc_kernel<A, B, 16, 1, PLAIN_, NIW_>), dim3((unsigned)total), dim3(256), lds, st, a, rc.args, \
+                       (int)n_cols, (int)n_rc, rc.gx)
+    if (plain) {
+        if (rc.niw == 8) FL_PAIR(true, 8);
+        else FL_PAIR(true, 4);
+    } else {
+        if (rc.niw == 8) FL_PAIR(false, 8);
+        else FL_PAIR(false, 4);
+    }
+#undef FL_PAIR
+    FL_CHECK_LAUNCH("cols_fwd_rc");
+    ++g_pair_launches;
+    return FL_OK;
+}
+
+}  // namespace fl
+
+using namespace fl;
+
+extern "C" {
+
+int fl_launch_pair_begin(void) {
+    t_pair_mode = true;
+    t_have = false;
+    return FL_OK;
+}
+
+int fl_launch_pair_pending(void) { return t_have ? 1 : 0; }
+
+long fl_debug_launch_pair_count(void) { return g_pair_launches; }
+
+int fl_launch_pair_flush(void* stream) {
+    t_pair_mode = false;
+    PendingRc p;
+    if (pending_rc_take(p)) return rc_ba_launch_now(p, (hipStream_t)stream);
+    return FL_OK;
+}
+
+}  // extern "C"

@@ -781,19 +781,56 @@ def permute_bins(H: torch.Tensor, nfft: int, inverse: bool = False) -> torch.Ten
     return _PermuteBins.apply(H, int(nfft), bool(inverse))
 
 
+LAUNCH_PAIRS = True       # the cascade response's launch rides in the input's column pass (csrc/fusedfwd.hip); False: two launches
+
+
+class paired_launch:
+    """Between enter and exit a Matrix-then-cascade response launch of this thread (fl_geq_response_rc_c64 /
+    fl_sos_response_rc_c64, second-generation kernel) is RECORDED by the library and issued by the next float32 forward column
+    pass in the same grid (csrc/fusedfwd.h): the response's packed arithmetic runs beside the column pass's HBM traffic instead of
+    in front of it.  Any other library call in between issues the recorded launch first (flamo_amd/_lib.py: lib()), exit issues
+    one that is still recorded; torch operations that READ the response in between must be preceded by ``flush()`` -- the
+    only user, Shell's fused forward (processor/system.py), does that."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled and LAUNCH_PAIRS)
+
+    def __enter__(self):
+        if self.enabled:
+            if getattr(_lib._pair, "stream_of", None) is not None:      # nested: the outer region owns the mode
+                self.enabled = False
+            else:
+                _lib.lib().fl_launch_pair_begin()
+                _lib._pair.stream_of = _stream
+        return self
+
+    def flush(self):
+        if self.enabled and getattr(_lib._pair, "stream_of", None) is not None:
+            L = _lib.lib(pair_ok=True)
+            if L.fl_launch_pair_pending():
+                _lib.check(L.fl_launch_pair_flush(_stream()), "launch pair flush")
+                L.fl_launch_pair_begin()
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            _lib._pair.stream_of = None
+            _lib.check(_lib.lib().fl_launch_pair_flush(_stream()), "launch pair flush")
+        return False
+
+
 def _spec_cols_fwd(x, nfft, env_log2, site=0):
     """x: contiguous real (B, T, G) -> scratch (B*L*G,) complex.  site 1: the gradient's transform (its input was written by the
     launch in front of it: another cache policy than for the forward transform's input, fl_set_stream_policy)"""
     B, T, G = x.shape
     S = torch.empty(B * (nfft // 2) * G, dtype=_cdtype(x.dtype), device=x.device)
-    L = _lib.lib()
+    W = twiddles(nfft, x.dtype, x.device)
+    L = _lib.lib(pair_ok=not site)        # the forward transform's pass carries a recorded response launch (paired_launch)
     if site:
         L.fl_set_stream_policy(0xFFFFFFFF, site)
     try:
         with kernel_timer.span("spec_cols_fwd"):
-            _lib.check(_spec_fn("fl_spec_cols_fwd", x.dtype)(x.data_ptr(), B, T, G, S.data_ptr(),
-                                                             twiddles(nfft, x.dtype, x.device).data_ptr(), nfft, env_log2, _stream()),
-                       "spec_cols_fwd")
+            fn = L.fl_spec_cols_fwd_f32 if x.dtype == torch.float32 else L.fl_spec_cols_fwd_f64
+            _lib.check(fn(x.data_ptr(), B, T, G, S.data_ptr(), W.data_ptr(), nfft, env_log2, _stream()), "spec_cols_fwd")
     finally:
         if site:
             L.fl_set_stream_policy(0xFFFFFFFF, 0)

@@ -747,17 +747,21 @@ class Shell(nn.Module):
         nfft, M = self.nfft, self.nfft // 2 + 1
         if isinstance(fin, FFTAntiAlias):
             fin._check(x)
-        with ops.row_major_bins(nfft):      # the responses come out in the pipeline's bin order (no reordering pass)
-            H, diag = Series._run_response(run, [x.shape[0], M, n_in], ext_param, x.device)
-        if diag:
-            H = torch.diag_embed(H)
-        if H.dim() == 2:
-            H = H.unsqueeze(0).expand(M, *H.shape)
-        cdt = torch.complex64 if x.dtype == torch.float32 else torch.complex128
-        if H.dtype != cdt:
-            H = H.to(cdt)
-        return ops.spectral_apply(x, H, nfft, fin.norm, fout.norm, getattr(fin, "_alias_db", None),
-                                  getattr(fout, "_alias_db", None))
+        # (a Matrix-then-cascade response's launch is recorded and rides in the input's column pass: ops.paired_launch)
+        with ops.paired_launch(x.dtype == torch.float32) as pair:
+            with ops.row_major_bins(nfft):      # the responses come out in the pipeline's bin order (no reordering pass)
+                H, diag = Series._run_response(run, [x.shape[0], M, n_in], ext_param, x.device)
+            cdt = torch.complex64 if x.dtype == torch.float32 else torch.complex128
+            if diag or H.dim() == 2 or H.dtype != cdt:
+                pair.flush()                    # torch operations read the response below
+            if diag:
+                H = torch.diag_embed(H)
+            if H.dim() == 2:
+                H = H.unsqueeze(0).expand(M, *H.shape)
+            if H.dtype != cdt:
+                H = H.to(cdt)
+            return ops.spectral_apply(x, H, nfft, fin.norm, fout.norm, getattr(fin, "_alias_db", None),
+                                      getattr(fout, "_alias_db", None))
 
     # ---- accessors
     def get_inputLayer(self):

@@ -696,6 +696,18 @@ int fl_eig_c64(const void* A, long a_pitch, int N, int M, void* lam, long l_pitc
 int fl_eig_c128(const void* A, long a_pitch, int N, int M, void* lam, long l_pitch, void* V, long v_pitch, void* info,
                 void* stream);
 
+/* Launch pairs: two independent kernels of the forward pass in ONE grid -- the cascade-times-matrix response
+ * (fl_geq_response_rc_c64 / fl_sos_response_rc_c64: parameters only; the reference's get_freq_response of flamo/processor/dsp.py:
+ * 2563-2593 behind dsp.Matrix's map, dsp.py:649) beside the column pass of the input's transform (fl_spec_cols_fwd_f32: the first
+ * half of torch.fft.rfft, dsp.py:88).  Between begin and flush on the calling thread the response launch is RECORDED; the next
+ * fl_spec_cols_fwd_f32 issues both (shapes it does not take: the recorded launch first, alone); flush issues a launch that is
+ * still recorded and ends the mode.  The caller guarantees that nothing reads the response's outputs in between.
+ * fl_launch_pair_pending: 1 while a launch is recorded.  FLAMO_LAUNCH_PAIR=0 turns recording off. */
+int fl_launch_pair_begin(void);
+int fl_launch_pair_pending(void);
+long fl_debug_launch_pair_count(void);      /* grids issued with both roles so far (process-wide) */
+int fl_launch_pair_flush(void* stream);
+
 /* Cache policy of the pipeline's data streams (process-wide mask; csrc/common.h: enum StreamPolicy names the bits -- one per
  * stream of the fused Shell pipeline: default or non-temporal loads / stores) and the launch SITE of the calling thread's next
  * column passes (0: the forward transform of the input, 1: the gradient's transform, whose input the previous launch wrote).

@@ -277,4 +277,4 @@ def test_sparsity_loss_of_a_householder_feedback_against_the_reference():
         fF=dsp.parallelDelay(size=(N,), max_len=40, isint=True, **kw),
         fB=system.Series(OrderedDict(mixing_matrix=mix, attenuation=dsp.parallelGain(size=(N,), **kw))))))
     model2 = system.Shell(core2, dsp.FFT(nfft, dtype=torch.float64), dsp.iFFT(nfft, dtype=torch.float64))
-    assert abs(float(sparsity_loss()(None, None, model2)) - float(gold["loss"])) < 1e-14
+    assert abs(sparsity_loss()(None, None, model2).item() - float(gold["loss"])) < 1e-14

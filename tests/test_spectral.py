@@ -730,3 +730,51 @@ def test_response_gradient_in_one_launch(gpu, dt, nfft, N, B):
         g1, used1 = run(False)
         assert "spec_gradh_loop" in used1
         check_close(f"gradh_loop/{str(dt)[6:]}_{nfft}_{N}_{B}/vs_torch_fft", g1.cpu(), gr, 1e-10 if dt == torch.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("kind,N,db", [("geq", 8, 0.0), ("geq", 8, 30.0), ("geq", 4, 0.0), ("biquad", 8, 0.0), ("geq-then-gain", 8, 0.0),
+                                       ("geq", 16, 0.0)])
+def test_launch_pair_response_beside_column_pass(gpu, kind, N, db):
+    """csrc/fusedfwd.hip: the Matrix-then-cascade response's launch rides in the input's column pass (one grid, either role per
+    workgroup).  Same device functions as the two plain kernels: output and gradients EQUAL the two-launch form bit for bit; the
+    grid with both roles is issued exactly where the shape has one (float32, 200-point columns, 4 / 8 channels) and the recorded
+    launch goes out alone everywhere else (16 channels; another module behind the pair reads the response first)."""
+    from flamo_amd import _lib, ops
+    from flamo_amd.processor import dsp, system
+    nfft, B = 96000, 3
+    torch.manual_seed(21)
+    kw = dict(nfft=nfft, alias_decay_db=db, device=gpu, dtype=torch.float32, requires_grad=True)
+    mat = dsp.Matrix(size=(N, N), matrix_type="random", **kw)
+    if kind == "biquad":       # raw sections WITHOUT a gradient are evaluated by the float kernel (with one: in double, no pair)
+        flt = dsp.Biquad(size=(N, N), n_sections=3, filter_type="bandpass", **{**kw, "requires_grad": False})
+    else:
+        flt = dsp.GEQ(size=(N, N), **kw)
+    mods = OrderedDict(mix=mat, flt=flt)
+    if kind == "geq-then-gain":
+        mods["tail"] = dsp.parallelGain(size=(N,), **kw)
+    fin = dsp.FFTAntiAlias(nfft, alias_decay_db=db, device=gpu) if db else dsp.FFT(nfft)
+    fout = dsp.iFFTAntiAlias(nfft, alias_decay_db=db, device=gpu) if db else dsp.iFFT(nfft)
+    shell = system.Shell(system.Series(mods), fin, fout)
+    params = [m.param for m in mods.values() if m.param.requires_grad]
+    x = torch.randn(B, nfft, N, device=gpu)
+    L = _lib.lib()
+
+    def run():
+        y = shell(x)
+        g = torch.autograd.grad(ops.mean_square(y), params)
+        return [y.detach()] + [t.detach() for t in g]
+
+    n0 = L.fl_debug_launch_pair_count()
+    paired = run()
+    n1 = L.fl_debug_launch_pair_count()
+    assert not L.fl_launch_pair_pending()
+    takes = kind in ("geq", "biquad") and N in (4, 8)
+    assert n1 - n0 == (1 if takes else 0), (kind, N, n1 - n0)
+    ops.LAUNCH_PAIRS = False
+    try:
+        plain = run()
+    finally:
+        ops.LAUNCH_PAIRS = True
+    assert L.fl_debug_launch_pair_count() == n1
+    for a, b in zip(paired, plain):
+        assert torch.equal(a, b), kind
