@@ -11,12 +11,19 @@
 namespace fl {
 using namespace sp32;
 
+// n_mix: the response's workgroups are spread evenly over the FIRST n_mix workgroups of the grid (n_rc <= n_mix <= n_cols +
+// n_rc); the rest are column-pass workgroups.  n_mix = n_cols + n_rc is the even spread; a smaller value puts more of the
+// response's wavefronts on every SIMD while they last (one response workgroup per CU is one wavefront per SIMD: its dependent
+// packed chains then issue at a fraction of the rate).
 template <int A, int B, int VT, int RG, bool PLAIN, int NIW>
-__global__ void __launch_bounds__(256, 5) cols_fwd_rc_kernel(ColsArgs a, RcBaArgs r, int n_cols, int n_rc, int rc_gx) {
+__global__ void __launch_bounds__(256, 5) cols_fwd_rc_kernel(ColsArgs a, RcBaArgs r, int n_mix, int n_rc, int rc_gx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const long T = (long)n_cols + n_rc;
     const int i = blockIdx.x;
-    const int before = (int)(((long)i * n_rc) / T), after = (int)(((long)(i + 1) * n_rc) / T);
+    if (i >= n_mix) {
+        spec_cols_fwd_body<A, B, VT, RG, PLAIN>(a, i - n_rc, smem);
+        return;
+    }
+    const int before = (int)(((long)i * n_rc) / n_mix), after = (int)(((long)(i + 1) * n_rc) / n_mix);
     if (after > before) rc_ba_body<NIW>(r, before % rc_gx, before / rc_gx, smem);
     else spec_cols_fwd_body<A, B, VT, RG, PLAIN>(a, i - before, smem);
 }
@@ -24,6 +31,8 @@ __global__ void __launch_bounds__(256, 5) cols_fwd_rc_kernel(ColsArgs a, RcBaArg
 static thread_local bool t_pair_mode = false, t_have = false;
 static thread_local PendingRc t_pending;
 static long g_pair_launches = 0;      // grids issued with both roles (tests check that the path under test is this one)
+// response workgroups per column-pass workgroup in the mixed part of the grid, in percent of the even spread's ratio (100)
+static int g_pair_density = [] { const char* e = getenv("FLAMO_PAIR_DENSITY"); return e ? atoi(e) : 100; }();
 static int g_pair_enabled = [] { const char* e = getenv("FLAMO_LAUNCH_PAIR"); return e ? atoi(e) : 1; }();
 
 bool pair_mode() { return t_pair_mode && g_pair_enabled; }
@@ -48,9 +57,12 @@ int fused_cols_rc_launch(const ColsArgs& a, unsigned n_cols, const PendingRc& rc
     const long n_rc = (long)rc.gx * rc.gy, total = (long)n_cols + n_rc;
     if (total >= (1l << 31)) return FL_ERR_UNSUPPORTED;
     const bool plain = a.env_log2 == 0.0 && a.t_lim >= a.n;
+    long n_mix = n_rc + (long)n_cols * 100 / (g_pair_density > 0 ? g_pair_density : 100);
+    if (n_mix > total) n_mix = total;
+    if (n_mix < n_rc) n_mix = n_rc;
 #define FL_PAIR(PLAIN_, NIW_)                                                                                          \
     hipLaunchKernelGGL((cols_fwd_rc_kernel<A, B, 16, 1, PLAIN_, NIW_>), dim3((unsigned)total), dim3(256), lds, st, a, rc.args, \
-                       (int)n_cols, (int)n_rc, rc.gx)
+                       (int)n_mix, (int)n_rc, rc.gx)
     if (plain) {
         if (rc.niw == 8) FL_PAIR(true, 8);
         else FL_PAIR(true, 4);
