@@ -602,10 +602,18 @@ def main():
 
     step = eager_step
     gs = None
+    walk_stamps = None
     if not args.no_graph:
         # forward + backward are captured once (torch.cuda.CUDAGraph) and replayed; the tiny RCCL gradient all-reduce
         # stays eager after each replay
         from flamo_amd.graph import GraphedStep
+        from flamo_amd import _lib as _fl
+        # the dominant kernel's launches INSIDE the replayed graph stamp the device's constant-rate clock per workgroup (two
+        # 8-byte stores each): its duration in the timed region itself, where HIP events cannot be recorded (roofline leg below)
+        if rank == 0 and dtype == torch.float32 and ops._walk_applies(NFFT, BATCH, NCH, NCH):
+            walk_stamps = torch.zeros(2 * 1024 + 1, dtype=torch.int64, device=dev)
+            walk_wgs_n = _fl.lib().fl_spec_walk_workgroups(NFFT, BATCH)
+            _fl.lib().fl_debug_set_walk_stamps(walk_stamps.data_ptr())
         try:
             gs = GraphedStep(lambda xx: ops.mean_square(model(xx)), (x,), params, warmup=2)
         except Exception as e:      # capture refused (e.g. by another thread's activity): time eager steps instead
@@ -614,6 +622,8 @@ def main():
             torch.cuda.synchronize()
             args.no_graph = True
             gs = None
+        if walk_stamps is not None:
+            _fl.lib().fl_debug_set_walk_stamps(None)      # captured launches keep the buffer; eager ones from here on do not stamp
         if dist_on:                 # every rank must time the same kind of step
             flag = torch.tensor([1 if gs is None else 0], device=ctl)
             dist.all_reduce(flag)
@@ -668,6 +678,24 @@ def main():
         step()
     fence()
     elapsed_steady = time.perf_counter() - t0
+    # the dominant kernel's launch duration inside the replayed step, from the stamps its workgroups leave: max(end) - min(start)
+    # of the launch of each of 30 more replays of the SAME graph (a synchronisation and a 4 KB read-back behind each; the kernel
+    # itself runs behind its real predecessor inside the graph, exactly as in the timed replays)
+    walk_clock = None
+    if gs is not None and walk_stamps is not None:
+        khz = _fl.lib().fl_wall_clock_khz()
+        durs, active = [], []
+        for _ in range(30):
+            gs.replay()
+            torch.cuda.synchronize()
+            raw = walk_stamps.cpu()
+            st = raw[:2 * walk_wgs_n].view(-1, 2)
+            t0s = int(st[:, 0].min())
+            durs.append((int(raw[2048]) - t0s) / khz)                 # ms: start of this kernel -> start of the next one
+            active.append((int(st[:, 1].max()) - t0s) / khz)         # ms: first workgroup's start -> last workgroup's last store
+        durs.sort()
+        walk_clock = {"launch_ms": sum(durs) / len(durs), "median_ms": durs[len(durs) // 2], "min_ms": durs[0], "max_ms": durs[-1],
+                      "active_ms": sum(active) / len(active), "launches": len(durs), "clock_khz": khz}
     ranks_seen = 1
     if dist_on:                     # max over ranks; before rank 0 goes on alone into the roofline leg
         t = torch.tensor([elapsed, elapsed_steady], device=ctl, dtype=torch.float64)
@@ -785,6 +813,24 @@ def main():
             # the same kernel inside the REPLAYED step, from the committed rocprofv3 --kernel-trace --stats run of this command
             # (events cannot be recorded inside a captured graph on ROCm; the eager leg above starts every launch behind
             # cache-flushing copies and reads ~10 % longer)
+            if walk and walk_clock:
+                # `frac` / `achieved` / `launch_ms`: the launches of the TIMED graph's replays themselves, by the device's constant-rate
+                # clock: every workgroup of this kernel stamps s_memrealtime at its start, the first workgroup of the NEXT kernel of
+                # the graph (the inverse column pass) at its own start; launch_ms = start of the next kernel - start of this one,
+                # the kernel's whole slot in the step (launch, run, drain of its stores, the gap to its successor), mean of 30
+                # replays -- the committed rocprofv3 average of the same command must agree.  `active_ms` (first workgroup's start
+                # to the last workgroup's last acknowledged store) and the event figure of the eager in-step leg (an event pair
+                # costs ~3 us of the ~70 it brackets) stay beside it.
+                roof["events_in_step"] = {"launch_ms": mean_ms, "frac": achieved / HBM_PEAK_GBS, "launches": n, "what": roof.pop("events")}
+                dm = walk_clock["launch_ms"]
+                roof.update(achieved=alg[key] / (dm * 1e-3) / 1e9, frac=alg[key] / (dm * 1e-3) / 1e9 / HBM_PEAK_GBS, launch_ms=dm,
+                            launches=walk_clock["launches"],
+                            active_ms=walk_clock["active_ms"], active_frac=alg[key] / (walk_clock["active_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            measured=("device clock (s_memrealtime, %d kHz) inside the replayed graph: start of the next kernel minus "
+                                      "start of this one, in each of %d replays of the timed graph (median %.4f, min %.4f, max %.4f ms)"
+                                      % (walk_clock["clock_khz"], walk_clock["launches"], walk_clock["median_ms"],
+                                         walk_clock["min_ms"], walk_clock["max_ms"])),
+                            layered_route_equivalent_GBs=layered / (dm * 1e-3) / 1e9)
             if key in timers_cold:
                 nc, msc = timers_cold[key]
                 roof["cold_leg"] = {"launch_ms": msc, "frac": alg[key] / (msc * 1e-3) / 1e9 / HBM_PEAK_GBS, "launches": nc,

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "fl_spec_gradh_walk_f32": (_i, [_vp, _vp, _vp, _l, _l, _l, _i, _vp, _i, _i, _i, _i, _d, _i, _vp]),
     "fl_sum_parts_c64": (_i, [_vp, _l, _i, _vp, _l, _vp]),
     "fl_debug_set_walk": (_i, [_i, _i, _i, _vp]),
+    "fl_debug_set_walk_stamps": (_i, [_vp]),
+    "fl_wall_clock_khz": (_i, []),
     "fl_spec_cols_inv_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp]),
     "fl_spec_cols_inv_sumsq_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp, _vp]),
     "fl_spec_cols_inv_sumsq_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp, _vp]),

@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
     const int c0 = ct * a.CT, g0 = gt * CG;
     constexpr int NIT = B * VT, NR = (NIT + 255) / 256;
     const cf* in = a.S + (size_t)b * a.L1 * a.L2 * a.G + g0;
+    if (a.stamp && blockIdx.x == 0 && threadIdx.x == 0) *a.stamp = (long long)__builtin_amdgcn_s_memrealtime();
     cf v[RG][A];
     const bool ld_nt_pol = a.pol & 1u, st_nt_pol = a.pol & 2u;      // workgroup-uniform: one branch around each group of accesses
     auto load_group_p = [&](int r0, auto nt_tag) {
@@ -1340,6 +1341,7 @@ static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, 
     a.sumsq = sumsq;
     a.dev_scale = dev_scale;
     a.pol = (stream_policy() >> 2) & 3u;      // POL_INV_LD_NT, POL_INV_ST_NT
+    a.stamp = walk_successor_stamp();
     return cols_launch(true, a, Bn, (hipStream_t)stream);
 }
 extern "C" {

@@ -55,6 +55,8 @@ struct ColsArgs {
     double* sumsq;        // inverse, optional: sumsq[workgroup] = sum of the squares of the samples this workgroup stored (the
                           // objective's reduction rides in the pass that produces y: ops.mean_square never re-reads it)
     unsigned pol;         // cache policy of this launch's streams: bit 0 non-temporal loads, bit 1 non-temporal stores (common.h: StreamPolicy)
+    long long* stamp;     // measurement, or null: the inverse pass's workgroup 0 leaves the device clock here when it starts
+                          // (with spec_mid_walk's own stamps: that kernel's whole slot in a replayed step; fl_debug_set_walk_stamps)
 };
 
 // Global accesses as (workgroup-uniform base pointer) + (32-bit byte offset per lane): the address then costs one
@@ -178,6 +180,9 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 }  // namespace FL_SPEC_NS
+
+// specwalk.hip: where the launch behind spec_mid_walk stamps its start (null: measurement off)
+long long* walk_successor_stamp();
 
 // the fused plan of a transform length (spectral.hip, float32 build)
 int spec_plan(int nfft, int& L1, int& L2);

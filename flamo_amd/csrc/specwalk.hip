@@ -42,6 +42,8 @@ struct WalkArgs {
     cf* Xp;               // spectrum out, pair-major: Xp[(u*2 + e)*NI*LEN + ((n/2)*LEN + p)*2 + n%2], u = r*Bn + b, e = 0: bin k, 1: bin L-k; or null
     long long* dbg_times; // tuning: per-workgroup cycle stamps, or null
     unsigned pol;         // cache policy of the streams (common.h: POL_WALK_*)
+    long long* stamps;    // measurement, or null: stamps[2 w], stamps[2 w + 1] = s_memrealtime when workgroup w started / finished --
+                          // the launch's duration INSIDE a replayed graph (events cannot be recorded there), bench.py's roofline
 };
 
 // a copy of a per-lane value the optimiser cannot see through: what is derived from it is recomputed where it is used
@@ -198,6 +200,7 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
     const int w = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     int u = a.bounds ? a.bounds[w] : (int)((long)Utot * w / G);
     const int u_hi = a.bounds ? a.bounds[w + 1] : (int)((long)Utot * (w + 1) / G);
+    if (a.stamps && tid == 0) a.stamps[2 * blockIdx.x] = a.stamps[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     if (u >= u_hi) return;
     const size_t bstride_i = (size_t)a.L1 * a.L2 * NI, bstride_o = (size_t)a.L1 * a.L2 * NO;
     const unsigned stage_lds = lds_addr_of(stage);
@@ -505,6 +508,10 @@ __global__ void __launch_bounds__(512, OCC) spec_mid_walk(WalkArgs a) {
             lds_barrier();
             FL_STAMP(3)
         }
+    }
+    if (a.stamps && tid == 0) {      // (behind this wavefront's last stores: the kernel's end as the memory system sees it)
+        wait_vm0();
+        a.stamps[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     }
     if (DBG && a.dbg_times && tid == 0) {
         long long* o = a.dbg_times + (size_t)blockIdx.x * 8;
@@ -839,14 +846,18 @@ __global__ void __launch_bounds__(256) sum_parts_kernel(const float4* __restrict
 }
 
 constexpr int kMaxDevices = 64;
+constexpr int kMaxWalkWgs = 1024;     // stamps buffer: [2 * kMaxWalkWgs] per-workgroup (start, end) + [1] start of the next launch
 static int g_walk = 1;            // 0: off (spec_mid only); 1: on for the shapes below
 static int g_walk_wgs = 0;        // workgroups of the forward walking kernel (0: one per CU)
 static int g_walk_slices = 0;     // batch slices of the backward walking kernel (0: CUs / row pairs)
 static long long* g_walk_times = nullptr;
+static long long* g_walk_stamps = nullptr;      // fl_debug_set_walk_stamps
 static int g_walk_nsc = 2;        // output-channel groups of the backward kernel (tuning: fl_debug_set_walk mode 14 -> 4)
 static int g_walk_fc = [] { const char* e = getenv("FLAMO_WALK_FC"); return e ? atoi(e) : 38; }();      // cost of a workgroup's first row pair, in twentieths of a unit
 static int g_walk_fc2 = [] { const char* e = getenv("FLAMO_WALK_FC2"); return e ? atoi(e) : 38; }();    // ... of changing to the next one
 static int g_walk_us = [] { const char* e = getenv("FLAMO_WALK_US"); return e ? atoi(e) : 16; }();      // a unit of a self-mirrored row pair
+
+long long* walk_successor_stamp() { return g_walk_stamps ? g_walk_stamps + 2 * kMaxWalkWgs : nullptr; }
 
 static int device_cus() {       // of the current device, cached per device
     static int cus[kMaxDevices] = {};
@@ -917,6 +928,17 @@ static int launch_walk(const WalkArgs& a, hipStream_t st) {
 using namespace fl;
 
 extern "C" {
+
+int fl_debug_set_walk_stamps(void* buf) {
+    g_walk_stamps = (long long*)buf;
+    return FL_OK;
+}
+
+int fl_wall_clock_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    return khz;
+}
 
 int fl_debug_set_walk(int mode, int wgs, int slices, void* times) {
     g_walk_nsc = mode == 14 ? 4 : mode == 15 ? 1 : 2;
@@ -1119,6 +1141,7 @@ int fl_spec_mid_walk_f32(const void* S, void* S2, void* Xp, const void* H, long 
     a.Xp = (cf*)Xp;
     a.bounds = (const int*)bounds;
     a.pol = stream_policy();
+    a.stamps = walk_wgs(a.L1, Bn) <= kMaxWalkWgs ? g_walk_stamps : nullptr;
     FL_REQUIRE((size_t)a.L1 * a.L2 * (NI > NO ? NI : NO) * 8ull < (1ull << 32), "spec_mid_walk: a batch item exceeds 32-bit offsets");
     FL_REQUIRE(reinterpret_cast<uintptr_t>(S) % 16 == 0, "spec_mid_walk: S must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;

@@ -181,6 +181,13 @@ int fl_sum_parts_c64(const void* parts, long part_stride, int n_parts, void* out
 /* tuning hook: mode 0 switches the walking kernels off (fl_spec_walk_supports -> 0); wgs / slices override the forward
  * kernel's workgroup count and the backward kernel's slice count (0 = per device); times: 8 int64 per workgroup or null */
 int fl_debug_set_walk(int mode, int wgs, int slices, void* times);
+/* Measurement: with a device buffer of 2 x 1024 + 1 int64 set, every launch of fl_spec_mid_walk_f32 issued (or captured)
+ * afterwards stamps the constant-rate device clock (s_memrealtime, fl_wall_clock_khz) when each workgroup w starts and ends
+ * (buf[2 w], buf[2 w + 1]), and the inverse column pass behind it (fl_spec_cols_inv_*) leaves its own start in buf[2048]:
+ * buf[2048] - min(start) is the kernel's whole slot inside a replayed graph (its launch, its run, the drain of its stores), where
+ * events cannot be recorded; max(end) - min(start) its active time.  NULL: off. */
+int fl_debug_set_walk_stamps(void* buf);
+int fl_wall_clock_khz(void);
 /* K3: y[b][t][g] = scale * e(t) * (unnormalised inverse transform of S2), t < t_out <= t_len; y: real (Bn, t_len, G) */
 int fl_spec_cols_inv_f32(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                          double env_log2, void* stream);
