@@ -754,6 +754,7 @@ def main():
         hb = esz * M * NCH * NCH
         alg = {   # algorithmic HBM bytes per launch
             "spec_cols_fwd": 2 * sig,                                        # x in, scratch out (twice per step: fwd + bwd)
+            "spec_cols_fwd+response": 2 * sig + 2 * hb,                      # launch pair (csrc/fusedfwd.hip): + the response's G and H out
             f"spec_mid[{NCH}->{NCH},H,inv,spec]": 3 * sig + hb,               # scratch in; spectrum (kept for backward), scratch out; H
             f"spec_mid[{NCH}->{NCH},spec]": 2 * sig,                          # backward: scratch in, dL/dY out
             "spec_cols_inv": 2 * sig,

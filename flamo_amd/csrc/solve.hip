@@ -20,6 +20,10 @@
 
 namespace fl {
 
+// kept factors, tiled by the BPB bins of a workgroup: element (s, k) of bin f; pivot row s of bin f
+__host__ __device__ inline long kept_lu_index(int f, int s, int k, int N, int BPB) { return (((long)(f / BPB) * N + s) * BPB + f % BPB) * N + k; }
+__host__ __device__ inline long kept_piv_index(int f, int s, int N, int BPB) { return ((long)(f / BPB) * N + s) * BPB + f % BPB; }
+
 template <typename T>
 __device__ inline cx<T> shfl_cx(cx<T> v, int src, int width) {
     return cx<T>(__shfl(v.x, src, width), __shfl(v.y, src, width));
@@ -54,6 +58,17 @@ struct Dud {
     cx<T>* cz;
     long cz_sb;
     int rv_real, cw_real;
+    // Kept factors (fl_solve_scaled_keep_*: the shuffle kernel only): the LU factors as they stand in the lanes' registers after
+    // the elimination (L below the diagonal, unit diagonal implied, U on and above it) in pivot order, and piv = the row of A that
+    // became each pivot row, TILED by the workgroup's bins: element (s, k) of bin f at kept_lu_index = [f / BPB][s][f % BPB][k], a
+    // workgroup's BPB = 256 / NMAX bins form one contiguous N^2 BPB block.  The forward kernel's lane stores ITS ROW as one
+    // contiguous run (8 N bytes: whole cache lines, 16-byte stores); the adjoint kernel's group of N lanes reads N consecutive
+    // values per stored row s -- the transposition the adjoint needs is this choice of the innermost index.  (A planar layout
+    // left a workgroup 8 N^2 separate 64-byte pieces: measured 2.2 TB/s on the stores, 1.2 TB/s on the adjoint's loads.)  The backward pass's adjoint system then costs a substitution over N^2 stored values
+    // per bin (fl_solve_kept_adjoint_*) instead of a second factorisation: at N = 32 the elimination is 90 % of the solve,
+    // and the part has 288 GB to keep 8 N^2 bytes per bin in.
+    cx<T>* lu_out;
+    int* piv_out;
 };
 
 
@@ -141,15 +156,25 @@ __global__ void __launch_bounds__(256) solve_kernel(
     // ---- load (or build) this lane's row of A
     cx<T> row[NMAX];
     if (P) {
+        // every load unconditional, all in flight together: lanes and columns beyond N read a valid element and discard it (a
+        // guard per element made every load a branch with its own wait: N serial round trips per wavefront in front of the
+        // elimination -- a quarter of this kernel's time at N = 32, M = 192001)
+        const int gr = gi < N ? gi : N - 1;
+        const cx<T>* p0 = adjoint ? P + (long)gr * p_pitch + f : P + (long)gr * N * p_pitch + f;
+        const long step = adjoint ? (long)N * p_pitch : p_pitch;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) row[j] = p0[(long)(j < N ? j : 0) * step];
+        // (uniform) constant row scale of the materialised matrix, A = I - diag(l) P: the lane's own entry, or -- adjoint: the
+        // row of P is the column j -- a wavefront-uniform (scalar) load per column
+        cx<T> lrow(1, 0);
+        if (dud.l && !adjoint) lrow = dud.l[(long)gr * dud.l_sn];
 #pragma unroll
         for (int j = 0; j < NMAX; ++j) {
-            cx<T> v(0, 0);
-            if (gi < N && j < N) {
-                v = adjoint ? conj(P[((long)j * N + gi) * p_pitch + f]) : P[((long)gi * N + j) * p_pitch + f];
-                // constant row scale of the materialised matrix: A = I - diag(l) P (the row of P is j for the adjoint)
-                if (dud.l) v = v * (adjoint ? conj(dud.l[(long)j * dud.l_sn]) : dud.l[(long)gi * dud.l_sn]);
-                if (one_minus) v = cx<T>(-v.x, -v.y);
-            }
+            cx<T> v = adjoint ? conj(row[j]) : row[j];
+            if (dud.l) v = v * (adjoint ? conj(dud.l[(long)(j < N ? j : 0) * dud.l_sn]) : lrow);
+            if (one_minus) v = cx<T>(-v.x, -v.y);
+            const bool keep = gi < N && j < N;
+            v = cx<T>(keep ? v.x : (T)0, keep ? v.y : (T)0);
             if (one_minus ? (j == gi) : (j == gi && gi >= N)) v.x += (T)1;
             row[j] = v;
         }
@@ -215,6 +240,28 @@ __global__ void __launch_bounds__(256) solve_kernel(
         }
     }
 
+    if (dud.lu_out && gi < N) {      // (uniform) the factors and the pivot order are kept for the adjoint system (see Dud)
+        cx<T>* lo = dud.lu_out + kept_lu_index(f, my_step, 0, N, BPB);
+        if ((N & 1) == 0 || sizeof(T) == 8) {      // (uniform) 16-byte stores: two float values / one double value each
+            typedef T v4 __attribute__((ext_vector_type(16 / sizeof(T))));
+            constexpr int PER = 16 / sizeof(cx<T>);
+#pragma unroll
+            for (int k = 0; k < NMAX; k += PER) {
+                if (k < N) {
+                    v4 q;
+                    if constexpr (PER == 2) q = v4{row[k].x, row[k].y, row[k + 1].x, row[k + 1].y};
+                    else q = v4{row[k].x, row[k].y};
+                    *reinterpret_cast<v4*>(lo + k) = q;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NMAX; ++k)
+                if (k < N) lo[k] = row[k];
+        }
+        dud.piv_out[kept_piv_index(f, my_step, N, BPB)] = gi;
+    }
+
     // ---- apply to every right-hand side
     const int ncols = B * K;
     for (int col = 0; col < ncols; ++col) {
@@ -249,6 +296,75 @@ __global__ void __launch_bounds__(256) solve_kernel(
             }
         }
         if (gi < N) OUT[(long)b * os_b + (long)my_step * os_n + (long)kk * os_k + f] = y;
+    }
+}
+
+// ---------------------------------------------------------------- adjoint system from kept factors
+// P A = L U as solve_kernel left it (rows in pivot order: Dud::lu_out, piv[s] = the row of A that is pivot row s).  A^H x = b is
+// U^H L^H (P x) = b: lane j of a bin's group holds COLUMN j of the stored factors -- the planar layout makes the transposition a
+// choice of plane at load time -- i.e. row j of U^H (lower triangular) and of L^H (unit upper triangular), and both
+// substitutions are the outer-product form of the forward kernel: the lane that finishes an unknown broadcasts it, the others
+// subtract their stored entry times it.  x[piv[s]] = v[s] on the way out.  HBM-bound: 8 N^2 bytes per bin, once.
+template <typename T, int NMAX>
+__global__ void __launch_bounds__(256) solve_kept_adjoint_kernel(const cx<T>* __restrict__ LU, const int* __restrict__ piv,
+                                                                 const cx<T>* __restrict__ R, long rs_b, long rs_n,
+                                                                 long rs_k, cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
+                                                                 int B, int M, int N, int K) {
+    constexpr int BPB = 256 / NMAX;
+    const int gi = threadIdx.x % NMAX;
+    const int f = blockIdx.x * BPB + threadIdx.x / NMAX;
+    if (f >= M) return;      // whole lane group leaves together
+    const bool on = gi < N;
+    cx<T> col[NMAX];         // col[s] = conj(factor[s][gi]): entry (gi, s) of U^H (s <= gi) / L^H (s > gi)
+    {   // every load unconditional and in flight together (lanes / rows beyond N read a valid element and discard it: a guard per
+        // load made each one a branch with its own wait -- 32 serial round trips per wavefront, 1.06 ms at N = 32, M = 192001)
+        const cx<T>* base = LU + kept_lu_index(f, 0, on ? gi : 0, N, BPB);
+        const long sstride = (long)BPB * N;
+#pragma unroll
+        for (int s = 0; s < NMAX; ++s) col[s] = base[(s < N ? s : 0) * sstride];
+#pragma unroll
+        for (int s = 0; s < NMAX; ++s) {
+            const bool keep = on && s < N;
+            col[s] = cx<T>(keep ? col[s].x : (T)0, keep ? -col[s].y : (T)0);
+        }
+    }
+    const int dst = on ? piv[kept_piv_index(f, gi, N, BPB)] : 0;
+    cx<T> dinv(0, 0);
+#pragma unroll
+    for (int s = 0; s < NMAX; ++s) {      // the lane's own diagonal of U^H (a select chain: the register index is the lane)
+        dinv.x = (gi == s) ? col[s].x : dinv.x;
+        dinv.y = (gi == s) ? col[s].y : dinv.y;
+    }
+    dinv = on ? crecip(dinv) : cx<T>(0, 0);
+    const int ncols = B * K;
+    for (int c = 0; c < ncols; ++c) {
+        const int b = c / K, kk = c - b * K;
+        cx<T> y(0, 0);
+        if (on) y = R[(long)b * rs_b + (long)gi * rs_n + (long)kk * rs_k + f];
+        // U^H z = b: z_s = b_s / conj(U[s][s]) in lane s; lanes j > s subtract conj(U[s][j]) z_s
+#pragma unroll
+        for (int s = 0; s < NMAX; ++s) {
+            if (s < N) {
+                const cx<T> yd = y * dinv;
+                y.x = (gi == s) ? yd.x : y.x;
+                y.y = (gi == s) ? yd.y : y.y;
+                const cx<T> zs = shfl_cx(y, s, NMAX);
+                const cx<T> t = col[s] * zs;
+                y.x -= (gi > s) ? t.x : (T)0;
+                y.y -= (gi > s) ? t.y : (T)0;
+            }
+        }
+        // L^H v = z (unit diagonal): v_s = z_s in lane s; lanes j < s subtract conj(L[s][j]) v_s
+#pragma unroll
+        for (int s = NMAX - 1; s >= 1; --s) {
+            if (s < N) {
+                const cx<T> vs = shfl_cx(y, s, NMAX);
+                const cx<T> t = col[s] * vs;
+                y.x -= (gi < s) ? t.x : (T)0;
+                y.y -= (gi < s) ? t.y : (T)0;
+            }
+        }
+        if (on) OUT[(long)b * os_b + (long)dst * os_n + (long)kk * os_k + f] = y;
     }
 }
 
@@ -354,6 +470,14 @@ __device__ inline void opaque(cx<float>& v) {
 }
 __device__ inline void opaque(cx<double>& v) { asm("" : "+v"(v.x), "+v"(v.y)); }
 
+// the constant 1 in device memory: what an absent diagonal factor is read as (one load path, no branch per factor)
+__device__ double kOneRe[2] = {1.0, 0.0};
+__device__ float kOneRef[2] = {1.f, 0.f};
+template <typename T> __device__ inline const cx<T>* one_ptr() {
+    if constexpr (sizeof(T) == 8) return reinterpret_cast<const cx<T>*>(kOneRe);
+    else return reinterpret_cast<const cx<T>*>(kOneRef);
+}
+
 // LANES lanes per bin, RPL rows per lane: row s*LANES + g of A lives in slot s of lane g, NMAX = LANES * RPL.
 // RPL = 1 is the layout described above (N <= 16).  RPL = 2 (16 < N <= 32, float) keeps the 16-lane DPP row as the
 // group -- a 32-lane group has no one-instruction broadcast -- and every broadcast of a pivot-row element now
@@ -366,13 +490,46 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
     cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
     int B, int M, int N, int K) {
     constexpr int NMAX = LANES * RPL, BPB = 256 / LANES;
-    const int thr_steps = adjoint >> 8;     // tuning: exponent steps of the pivot threshold (host passes >= 1)
+    const int thr_steps = (adjoint >> 8) & 0xFF;     // tuning: exponent steps of the pivot threshold (host passes >= 1)
+    const bool no_prefetch = (adjoint >> 16) & 1;    // tuning (fl_debug_set_solve_variant(5)): the right-hand side is fetched behind the elimination
     adjoint &= 1;
     const int gi = threadIdx.x % LANES;
     const int f = blockIdx.x * BPB + threadIdx.x / LANES;
     // the frequency-independent mixing matrix, zero-padded to NMAX x NMAX (and transposed for the adjoint
     // system), staged once per workgroup: the row build below reads it with compile-time offsets, no guards
     __shared__ cx<T> Us[NMAX * NMAX];
+    // ---- factored loop: EVERYTHING this lane reads from global memory is requested here, unconditionally and together -- the two
+    // diagonal factors of its rows, the first right-hand side, the output-gain entries -- in front of the mixing matrix's staging
+    // barrier.  Lanes beyond M and rows beyond N read a valid element and discard it; the right-hand side is fetched for the row
+    // the slot holds BEFORE pivoting (threshold pivoting keeps the diagonal for every damped loop: a wavefront in which a row did
+    // move fetches again, below).  With a guard per element every load was a branch with its own wait: ~11 serial round trips
+    // per wavefront against ~4 us of arithmetic, two wavefronts per SIMD to hide them.
+    cx<T> pre_l[RPL], pre_l2[RPL], pre_r[RPL], pre_y[RPL], pre_cw[RPL];
+    if (!P) {
+        const cx<T>* one = one_ptr<T>();
+        const int fc = f < M ? f : M - 1;
+        const cx<T>* lp = dud.l ? dud.l : one;
+        const long l_sn = dud.l ? dud.l_sn : 0, l_sf = dud.l ? dud.l_sf : 0;
+        const cx<T>* l2p = dud.l2 ? dud.l2 : one;
+        const long l2_sn = dud.l2 ? dud.l2_sn : 0, l2_sf = dud.l2 ? dud.l2_sf : 0;
+        const cx<T>* rp = dud.r ? dud.r : one;
+        const long r_sn = dud.r ? dud.r_sn : 0, r_sf = dud.r ? dud.r_sf : 0;
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int ri = s * LANES + gi, rc = ri < N ? ri : N - 1;
+            pre_l[s] = lp[(long)rc * l_sn + (long)fc * l_sf];
+            pre_l2[s] = l2p[(long)rc * l2_sn + (long)fc * l2_sf];
+            pre_r[s] = rp[(long)rc * r_sn + (long)fc * r_sf];
+            if (dud.rv) {        // (uniform) rank-one right-hand side: the gain entry; the scalar signal's value is lane-independent
+                pre_y[s] = gain_at<T>(dud.rv, dud.rv_real, rc);
+            } else {
+                pre_y[s] = R[(long)rc * rs_n + fc];                      // column 0: b = 0, kk = 0
+            }
+            pre_cw[s] = dud.cz ? gain_at<T>(dud.cw, dud.cw_real, rc) : cx<T>(0, 0);
+        }
+    }
+    cx<T> pre_rs(0, 0);
+    if (!P && dud.rv) pre_rs = dud.rs[f < M ? f : M - 1];                // b = 0
     if (!P) {
         for (int e = threadIdx.x; e < NMAX * NMAX; e += 256) {
             const int i = e / NMAX, j = e % NMAX;
@@ -459,17 +616,13 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
       }
     } else {
         // A[i][j] = delta_ij - l_i U_ij r_j ;  A^H[i][j] = delta_ij - conj(r_i) conj(U_ji) conj(l_j)
-        const cx<T> one(1, 0);
         cx<T> own[RPL], oth[RPL];
 #pragma unroll
         for (int s = 0; s < RPL; ++s) {
-            const int ri = s * LANES + gi;
-            cx<T> lv = one, rv = one;
-            if (ri < N) {
-                if (dud.l) lv = dud.l[(long)ri * dud.l_sn + (long)f * dud.l_sf];
-                if (dud.l2) lv = lv * dud.l2[(long)ri * dud.l2_sn + (long)f * dud.l2_sf];
-                if (dud.r) rv = dud.r[(long)ri * dud.r_sn + (long)f * dud.r_sf];
-            }
+            const bool real_row = s * LANES + gi < N;
+            cx<T> lv = pre_l[s] * pre_l2[s], rv = pre_r[s];        // (absent factors were read as ones)
+            lv = cx<T>(real_row ? lv.x : (T)1, real_row ? lv.y : (T)0);
+            rv = cx<T>(real_row ? rv.x : (T)1, real_row ? rv.y : (T)0);
             own[s] = adjoint ? conj(rv) : lv;
             oth[s] = adjoint ? conj(lv) : rv;
         }
@@ -607,20 +760,42 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
 
     // ---- apply to every right-hand side: slot s of lane g ends up with x_{s*LANES+g}
     const int ncols = B * K;
+    // did any row of this wavefront change its slot?  (uniform; almost never: the first column's right-hand side is then the
+    // one requested at the top of the kernel)
+    bool moved = false;
+#pragma unroll
+    for (int s = 0; s < RPL; ++s) moved |= orig[s] != s * LANES + gi;
+    const bool refetch = P != nullptr || no_prefetch || __any(moved);
     for (int col = 0; col < ncols; ++col) {
         const int b = col / K, kk = col - b * K;
         cx<T> y[RPL];
+        if (col == 0 && !refetch) {
 #pragma unroll
-        for (int s = 0; s < RPL; ++s) {
-            y[s] = cx<T>(0, 0);
-            if (s * LANES + gi < N) {
-                if (dud.rv) {           // rank-one right-hand side (K == 1): gain vector entry times the scalar signal
-                    const cx<T> gv = gain_at<T>(dud.rv, dud.rv_real, orig[s]);
-                    y[s] = (adjoint ? conj(gv) : gv) * dud.rs[(long)b * dud.rs_sb + f];
-                } else {
-                    y[s] = R[(long)b * rs_b + (long)orig[s] * rs_n + (long)kk * rs_k + f];
-                }
-                if (dud.rhs_l2 && !(adjoint & 1)) y[s] = y[s] * dud.l2[(long)orig[s] * dud.l2_sn + (long)f * dud.l2_sf];
+            for (int s = 0; s < RPL; ++s) {
+                cx<T> v = pre_y[s];
+                if (dud.rv) v = (adjoint ? conj(v) : v) * pre_rs;
+                if (dud.rhs_l2 && !(adjoint & 1)) v = v * pre_l2[s];
+                const bool real_row = s * LANES + gi < N;
+                y[s] = cx<T>(real_row ? v.x : (T)0, real_row ? v.y : (T)0);
+            }
+        } else {
+            // all of the column's loads together, unconditionally (rows beyond N read row N - 1 and discard it)
+            cx<T> raw[RPL], l2v[RPL], rsv(0, 0);
+            if (dud.rv) rsv = dud.rs[(long)b * dud.rs_sb + f];
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) {
+                const int oc = orig[s] < N ? orig[s] : N - 1;
+                if (dud.rv) raw[s] = gain_at<T>(dud.rv, dud.rv_real, oc);      // rank-one right-hand side (K == 1)
+                else raw[s] = R[(long)b * rs_b + (long)oc * rs_n + (long)kk * rs_k + f];
+                l2v[s] = (dud.rhs_l2 && !(adjoint & 1)) ? dud.l2[(long)oc * dud.l2_sn + (long)f * dud.l2_sf] : cx<T>(1, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) {
+                cx<T> v = raw[s];
+                if (dud.rv) v = (adjoint ? conj(v) : v) * rsv;
+                if (dud.rhs_l2 && !(adjoint & 1)) v = v * l2v[s];
+                const bool real_row = s * LANES + gi < N;
+                y[s] = cx<T>(real_row ? v.x : (T)0, real_row ? v.y : (T)0);
             }
         }
         static_for<0, NMAX - 1>([&](auto kc) {          // forward: y_i -= L[i][k] y_k, i > k
@@ -656,7 +831,7 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
             const int ri = s * LANES + gi;
             if (ri < N) {
                 OUT[(long)b * os_b + (long)ri * os_n + (long)kk * os_k + f] = y[s];
-                if (dud.cz) fma_cx(z, gain_at<T>(dud.cw, dud.cw_real, ri), y[s]);
+                if (dud.cz) fma_cx(z, P ? gain_at<T>(dud.cw, dud.cw_real, ri) : pre_cw[s], y[s]);
             }
         }
         if (dud.cz && !adjoint) {      // uniform: the output-gain row applied in the wavefront
@@ -670,6 +845,7 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
 static int g_solve_rpl2_16 = 0;   // factored loop, N in (4, 16]: 0 = two rows per lane (default), 1 = one row per lane (variant 4)
 static int g_solve_rpl2_p = 0;    // tuning: variant 3 = two-rows-per-lane kernel also for a materialised P
 static int g_solve_thr = 1;       // pivot threshold 2^-thr (tuning: variant 10 + thr)
+static int g_solve_noprefetch = 0;   // tuning: variant 5 = the in-place kernels fetch the right-hand side behind the elimination
 static int g_solve_variant = 0;   // tuning hook: 1 forces the shuffle kernel for every N
 
 template <typename T, int NMAX>
@@ -685,7 +861,7 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
             // one-row-per-lane kernels.
             if (!P && g_solve_rpl2_16 != 1) {
                 hipLaunchKernelGGL((solve_inplace_kernel<T, 8, 2>), dim3(cdiv_i(M, 32)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
-                                   dud, one_minus, adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
+                                   dud, one_minus, adjoint | (g_solve_thr << 8) | (g_solve_noprefetch << 16), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
                                    os_b, os_n, os_k, B, M, N, K);
                 FL_CHECK_LAUNCH("solve");
                 return FL_OK;
@@ -694,7 +870,7 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
         if constexpr (NMAX == 8) {
             if (!P && g_solve_rpl2_16 != 1) {      // N in (4, 8] on 4 lanes x 2 rows (16 bins per wavefront): 29 -> 23 us at N = 8
                 hipLaunchKernelGGL((solve_inplace_kernel<T, 4, 2>), dim3(cdiv_i(M, 64)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
-                                   dud, one_minus, adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
+                                   dud, one_minus, adjoint | (g_solve_thr << 8) | (g_solve_noprefetch << 16), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
                                    os_b, os_n, os_k, B, M, N, K);
                 FL_CHECK_LAUNCH("solve");
                 return FL_OK;
@@ -702,14 +878,14 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
         }
         if constexpr (NMAX <= 16) {
             hipLaunchKernelGGL((solve_inplace_kernel<T, NMAX, 1>), grid, dim3(256), 0, st, (const cx<T>*)P, p_pitch, dud, one_minus,
-                               adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);
+                               adjoint | (g_solve_thr << 8) | (g_solve_noprefetch << 16), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);
             FL_CHECK_LAUNCH("solve");
             return FL_OK;
         } else if constexpr (NMAX == 32 && sizeof(T) == 4) {    // two rows per lane, 16 lanes per bin
             // (a materialised P keeps the shuffle kernel for now: its row-per-lane loads are 32-byte pieces here)
             if (!P || g_solve_rpl2_p) {
                 hipLaunchKernelGGL((solve_inplace_kernel<T, 16, 2>), dim3(cdiv_i(M, 16)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
-                                   dud, one_minus, adjoint | (g_solve_thr << 8), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b,
+                                   dud, one_minus, adjoint | (g_solve_thr << 8) | (g_solve_noprefetch << 16), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b,
                                    os_n, os_k, B, M, N, K);
                 FL_CHECK_LAUNCH("solve");
                 return FL_OK;
@@ -991,12 +1167,6 @@ struct DudSide {
 };
 // 1 + 0i in memory, deliberately not const: a constant the compiler can see through turns the loads of an absent factor
 // back into a branch
-__device__ double kOneRe[2] = {1.0, 0.0};
-__device__ float kOneRef[2] = {1.f, 0.f};
-template <typename T> __device__ inline const cx<T>* one_ptr() {
-    if constexpr (sizeof(T) == 8) return reinterpret_cast<const cx<T>*>(kOneRe);
-    else return reinterpret_cast<const cx<T>*>(kOneRef);
-}
 
 template <typename T, int NP, bool WR>
 __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud_grads_kernel(Dud<T> d, const cx<T>* __restrict__ gR, const cx<T>* __restrict__ OUT, long s_b,
@@ -1264,6 +1434,55 @@ static int dud_grads_impl(const Dud<T>& d, const void* gR, const void* OUT, long
 
 using namespace fl;
 
+// forward system of the scaled loop with its factors kept (shuffle kernel: N <= 64 / 32), and the adjoint system from them
+template <typename T>
+static int solve_scaled_keep_impl(const void* P, long p_pitch, const void* l, long l_sn, const void* R, long rs_b, long rs_n, long rs_k,
+                                  void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* LU, void* piv, void* stream) {
+    FL_REQUIRE(P && l && R && OUT && LU && piv, "solve_scaled_keep: null pointer");
+    FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0 && p_pitch >= M, "solve_scaled_keep: bad sizes (p_pitch >= M)");
+    FL_REQUIRE(N <= (sizeof(T) == 8 ? 32 : 64), "solve_scaled_keep: N exceeds the register-resident kernels (%d)", sizeof(T) == 8 ? 32 : 64);
+    if (B == 0 || M == 0) return FL_OK;
+    Dud<T> d = {(const cx<T>*)l, l_sn, 0, nullptr, nullptr, 0, 0};
+    d.lu_out = (cx<T>*)LU; d.piv_out = (int*)piv;
+    hipStream_t st = (hipStream_t)stream;
+#define FL_KEEP(NM)                                                                                                                  \
+    {                                                                                                                                \
+        hipLaunchKernelGGL((solve_kernel<T, NM>), dim3(cdiv_i(M, 256 / NM)), dim3(256), 0, st, (const cx<T>*)P, p_pitch, d, 1, 0,    \
+                           (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);                            \
+        FL_CHECK_LAUNCH("solve_scaled_keep");                                                                                        \
+        return FL_OK;                                                                                                                \
+    }
+    if (N <= 4) FL_KEEP(4)
+    if (N <= 8) FL_KEEP(8)
+    if (N <= 16) FL_KEEP(16)
+    if (N <= 32) FL_KEEP(32)
+    if constexpr (sizeof(T) == 4) FL_KEEP(64)
+#undef FL_KEEP
+    return FL_ERR_UNSUPPORTED;
+}
+template <typename T>
+static int solve_kept_adjoint_impl(const void* LU, const void* piv, const void* R, long rs_b, long rs_n,
+                                   long rs_k, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+    FL_REQUIRE(LU && piv && R && OUT, "solve_kept_adjoint: null pointer");
+    FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0, "solve_kept_adjoint: bad sizes");
+    FL_REQUIRE(N <= (sizeof(T) == 8 ? 32 : 64), "solve_kept_adjoint: N exceeds the register-resident kernels (%d)", sizeof(T) == 8 ? 32 : 64);
+    if (B == 0 || M == 0) return FL_OK;
+    hipStream_t st = (hipStream_t)stream;
+#define FL_KEPT(NM)                                                                                                                  \
+    {                                                                                                                                \
+        hipLaunchKernelGGL((solve_kept_adjoint_kernel<T, NM>), dim3(cdiv_i(M, 256 / NM)), dim3(256), 0, st, (const cx<T>*)LU,       \
+                           (const int*)piv, (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);          \
+        FL_CHECK_LAUNCH("solve_kept_adjoint");                                                                                       \
+        return FL_OK;                                                                                                                \
+    }
+    if (N <= 4) FL_KEPT(4)
+    if (N <= 8) FL_KEPT(8)
+    if (N <= 16) FL_KEPT(16)
+    if (N <= 32) FL_KEPT(32)
+    if constexpr (sizeof(T) == 4) FL_KEPT(64)
+#undef FL_KEPT
+    return FL_ERR_UNSUPPORTED;
+}
 extern "C" {
 int fl_solve_max_n(int f64) { return f64 ? solve_lds_max_n<double>() : solve_lds_max_n<float>(); }
 
@@ -1271,7 +1490,8 @@ int fl_debug_set_solve_variant(int variant) {
     g_solve_thr = 1;
     g_solve_rpl2_p = variant == 3;
     g_solve_rpl2_16 = variant == 4 ? 1 : 0;
-    if (variant == 3 || variant == 4) variant = 0;
+    g_solve_noprefetch = variant == 5 ? 1 : 0;
+    if (variant == 3 || variant == 4 || variant == 5) variant = 0;
     if (variant >= 10) {          // 10 + t: in-place kernels with pivot threshold 2^-t
         g_solve_thr = variant - 10;
         variant = 0;
@@ -1312,6 +1532,34 @@ int fl_solve_scaled_c64(const void* P, long p_pitch, const void* l, long l_sn, i
     FL_REQUIRE(P && l, "solve_scaled: null pointer");
     Dud<float> d = {(const cx<float>*)l, l_sn, 0, nullptr, nullptr, 0, 0};
     return solve_impl<float>(P, p_pitch, d, 1, adjoint, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+// elements of the kept-factor arrays for N channels and M bins (both tiled by the workgroup's bins: see Dud)
+static int kept_bpb(int N, bool f64) { return 256 / (N <= 4 ? 4 : N <= 8 ? 8 : N <= 16 ? 16 : N <= 32 ? 32 : 64); }
+size_t fl_solve_kept_lu_elems(int N, int M, int f64) {
+    if (N <= 0 || M <= 0 || N > (f64 ? 32 : 64)) return 0;
+    const int bpb = kept_bpb(N, f64);
+    return (size_t)cdiv_i(M, bpb) * N * N * bpb;
+}
+size_t fl_solve_kept_piv_elems(int N, int M, int f64) {
+    if (N <= 0 || M <= 0 || N > (f64 ? 32 : 64)) return 0;
+    const int bpb = kept_bpb(N, f64);
+    return (size_t)cdiv_i(M, bpb) * N * bpb;
+}
+int fl_solve_scaled_keep_c64(const void* P, long p_pitch, const void* l, long l_sn, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+                             long os_b, long os_n, long os_k, int B, int M, int N, int K, void* LU, void* piv, void* stream) {
+    return solve_scaled_keep_impl<float>(P, p_pitch, l, l_sn, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, LU, piv, stream);
+}
+int fl_solve_scaled_keep_c128(const void* P, long p_pitch, const void* l, long l_sn, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
+                              long os_b, long os_n, long os_k, int B, int M, int N, int K, void* LU, void* piv, void* stream) {
+    return solve_scaled_keep_impl<double>(P, p_pitch, l, l_sn, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, LU, piv, stream);
+}
+int fl_solve_kept_adjoint_c64(const void* LU, const void* piv, const void* R, long rs_b, long rs_n, long rs_k,
+                              void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+    return solve_kept_adjoint_impl<float>(LU, piv, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
+}
+int fl_solve_kept_adjoint_c128(const void* LU, const void* piv, const void* R, long rs_b, long rs_n, long rs_k,
+                               void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
+    return solve_kept_adjoint_impl<double>(LU, piv, R, rs_b, rs_n, rs_k, OUT, os_b, os_n, os_k, B, M, N, K, stream);
 }
 int fl_solve_scaled_c128(const void* P, long p_pitch, const void* l, long l_sn, int adjoint, const void* R, long rs_b, long rs_n,
                          long rs_k, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {

@@ -280,6 +280,13 @@ class KernelTimer:
 
         return _Span()
 
+    def drop_last(self, name):
+        """forget the newest span of this name (its launch was recorded for a launch pair, not issued: see paired_launch)"""
+        if self.enabled and self.records.get(name):
+            self.records[name].pop()
+            if not self.records[name]:
+                del self.records[name]
+
     def summary(self):
         """name -> (launches, mean milliseconds); call after torch.cuda.synchronize()."""
         out = {}
@@ -828,7 +835,8 @@ def _spec_cols_fwd(x, nfft, env_log2, site=0):
     if site:
         L.fl_set_stream_policy(0xFFFFFFFF, site)
     try:
-        with kernel_timer.span("spec_cols_fwd"):
+        with kernel_timer.span("spec_cols_fwd+response" if (not site and kernel_timer.enabled and L.fl_launch_pair_pending())
+                               else "spec_cols_fwd"):
             fn = L.fl_spec_cols_fwd_f32 if x.dtype == torch.float32 else L.fl_spec_cols_fwd_f64
             _lib.check(fn(x.data_ptr(), B, T, G, S.data_ptr(), W.data_ptr(), nfft, env_log2, _stream()), "spec_cols_fwd")
     finally:
@@ -1717,6 +1725,43 @@ def _solve_scaled_launch(DU, g, adjoint, R):
     return OUT
 
 
+# The scaled loop's forward solve keeps its LU factors for the backward pass's adjoint system when the elimination dominates the
+# solve (N > KEEP_LU_MIN_N) and the factors fit the budget: 8 N^2 bytes per bin in HBM (1.6 GB at the 32 x 32 chain of nfft =
+# 384000) against a second (2/3) N^3 elimination per bin.  False / a smaller budget: the adjoint system is factored again.
+KEEP_LU = True
+KEEP_LU_MIN_N = 16
+KEEP_LU_MAX_BYTES = 16 << 30
+
+
+def _solve_scaled_keep_launch(DU, g, R):
+    real = _rdtype(R)
+    B, M, N, K, rs_b, rs_n, rs_k = _bnk(R)
+    OUT = _empty_planar(R.shape, R.dtype, R.device)
+    _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
+    L = _lib.lib()
+    f64 = int(real == torch.float64)
+    LU = torch.empty(L.fl_solve_kept_lu_elems(N, M, f64), dtype=R.dtype, device=R.device)
+    piv = torch.empty(L.fl_solve_kept_piv_elems(N, M, f64), dtype=torch.int32, device=R.device)
+    fn = L.fl_solve_scaled_keep_c64 if real == torch.float32 else L.fl_solve_scaled_keep_c128
+    with kernel_timer.span("solve"):
+        _lib.check(fn(DU.data_ptr(), _lead_pitch(DU.movedim(0, -1)), g.data_ptr(), g.stride(0), R.data_ptr(), rs_b, rs_n, rs_k,
+                      OUT.data_ptr(), os_b, os_n, os_k, B, M, N, K, LU.data_ptr(), piv.data_ptr(), _stream()), "solve_scaled_keep")
+    return OUT, LU, piv
+
+
+def _solve_kept_adjoint_launch(LU, piv, R):
+    real = _rdtype(R)
+    B, M, N, K, rs_b, rs_n, rs_k = _bnk(R)
+    OUT = _empty_planar(R.shape, R.dtype, R.device)
+    _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
+    L = _lib.lib()
+    fn = L.fl_solve_kept_adjoint_c64 if real == torch.float32 else L.fl_solve_kept_adjoint_c128
+    with kernel_timer.span("solve_adj"):
+        _lib.check(fn(LU.data_ptr(), piv.data_ptr(), R.data_ptr(), rs_b, rs_n, rs_k, OUT.data_ptr(), os_b,
+                      os_n, os_k, B, M, N, K, _stream()), "solve_kept_adjoint")
+    return OUT
+
+
 class _SolveScaledLoop(torch.autograd.Function):
     """OUT = (I - diag(g) D[f] U)^-1 R per bin; D: per-bin (M, N, N) WITHOUT gradient, g: (N,), U: (N, N) constants.
     P' = D U is formed once; the gains scale its rows inside the solve.  Backward without the (M, N, N) gradient of the
@@ -1736,14 +1781,24 @@ class _SolveScaledLoop(torch.autograd.Function):
         # P'[f] = D[f] U: rows of D as batch items of a signal, U^T as the constant matrix (planar memory of the result IS
         # the per-bin matrix (M, N, N))
         DU = _mimo_launch(Uc.transpose(-1, -2), False, False, False, to_planar(Dp.permute(1, 0, 2))).permute(1, 0, 2)
-        OUT = _solve_scaled_launch(DU, gc, False, Rp)
-        ctx.save_for_backward(gc, Dp, Uc, DU, OUT)
+        M = Rp.shape[1]
+        keep = (KEEP_LU and any(ctx.needs_input_grad) and KEEP_LU_MIN_N < N <= (64 if _rdtype(Rp) == torch.float32 else 32)
+                and N * N * (M + 64) * Rp.element_size() <= KEEP_LU_MAX_BYTES)
+        if keep:
+            OUT, LU, piv = _solve_scaled_keep_launch(DU, gc, Rp)
+            ctx.save_for_backward(gc, Dp, Uc, DU, OUT, LU, piv)
+        else:
+            OUT = _solve_scaled_launch(DU, gc, False, Rp)
+            ctx.save_for_backward(gc, Dp, Uc, DU, OUT)
         return OUT
 
     @staticmethod
     def backward(ctx, gOUT):
-        gc, Dp, Uc, DU, OUT = ctx.saved_tensors
-        gR = _solve_scaled_launch(DU, gc, True, to_planar(gOUT.resolve_conj()))        # A^-H g
+        gc, Dp, Uc, DU, OUT, *kept = ctx.saved_tensors
+        if kept:      # A^-H g from the forward solve's factors: a substitution, no second elimination
+            gR = _solve_kept_adjoint_launch(kept[0], kept[1], to_planar(gOUT.resolve_conj()))
+        else:
+            gR = _solve_scaled_launch(DU, gc, True, to_planar(gOUT.resolve_conj()))    # A^-H g
         g_g = g_U = None
         if ctx.needs_input_grad[0]:
             v = _mimo_launch(DU, True, False, False, OUT)                             # P' out
@@ -2141,6 +2196,8 @@ def _cascade_rc_forward(b, a, Wr, gamma, nfft, real, float_eval, geq=None):
                                                          twiddles(nfft, torch.float64, dev).data_ptr(), nfft, bin0, m_local,
                                                          G.data_ptr(), P, H.data_ptr(), P, int(bool(float_eval and FLOAT_CASCADE_EVAL)),
                                                          _stream()), "sos_response_rc")
+    if kernel_timer.enabled and _lib.lib(pair_ok=True).fl_launch_pair_pending():
+        kernel_timer.drop_last("sos_response_rc")       # recorded, not issued: it rides in the input's column pass
     return H.movedim(-1, 0), G, (float(gamma), nfft, S, No * Nmid, bin0, m_local, real)
 
 

@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from conftest import relerr
+from conftest import check_close, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -1060,3 +1060,48 @@ def test_magnitude_output_layer_in_one_launch(gpu, dt):
         assert float(res[0][0][0, 5, 1]) == 0.0 and complex(res[0][1][0, 5, 1]) == 0
     y2 = other(zc)
     assert relerr(y2, torch.abs(zc) * 1.0000001) < tol
+
+
+@pytest.mark.parametrize("N,K", [(20, 1), (32, 1), (32, 3), (48, 1)])
+def test_scaled_loop_adjoint_from_kept_factors(gpu, N, K):
+    """fl_solve_scaled_keep_* + fl_solve_kept_adjoint_*: the backward pass's adjoint system A^H x = g from the LU factors the
+    forward solve left (no second elimination) against LAPACK autograd in float64 on the materialised loop
+    (flamo/processor/system.py:420-425: torch.linalg.solve and its backward), vector and matrix right-hand sides, and against
+    the re-factoring route it replaces (ops.KEEP_LU = False)."""
+    from flamo_amd import ops
+    torch.manual_seed(100 + N)
+    M, B = 193, 2
+    for cd, tol in ((torch.complex128, 1e-11), (torch.complex64, 3e-5)):
+        if cd == torch.complex128 and N > 32:
+            continue
+        D64 = torch.exp(2j * torch.pi * torch.rand(M, N, N, dtype=torch.float64))
+        U64 = torch.linalg.qr(torch.randn(N, N, dtype=torch.float64))[0].to(torch.complex128)
+        g64 = ((0.2 + 0.5 * torch.rand(N, dtype=torch.float64)) / N ** 0.5).to(torch.complex128)
+        shape = (B, M, N) if K == 1 else (B, M, N, K)
+        R64 = torch.randn(*shape, dtype=torch.complex128)
+        C64 = torch.randn(*shape, dtype=torch.complex128)
+        gr, Ur, Rr = (t.clone().requires_grad_(True) for t in (g64, U64, R64))
+        A = torch.eye(N, dtype=torch.complex128) - gr.unsqueeze(-1) * (D64 @ Ur)
+        Yr = torch.linalg.solve(A.unsqueeze(0), Rr.unsqueeze(-1) if K == 1 else Rr)
+        Yr = Yr.squeeze(-1) if K == 1 else Yr
+        want = torch.autograd.grad(torch.sum(torch.real(Yr * torch.conj(C64))), [gr, Ur, Rr])
+        res = {}
+        for keep in (True, False):
+            ops.KEEP_LU = keep
+            try:
+                gd, Ud, Rd = (t.detach().to(gpu, cd).requires_grad_(True) for t in (g64, U64, R64))
+                ops.kernel_timer.reset(True)
+                Y = ops.solve_scaled_loop(gd, D64.to(gpu, cd), Ud, Rd)
+                got = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C64.to(gpu, cd)))), [gd, Ud, Rd])
+                torch.cuda.synchronize()
+            finally:
+                ops.KEEP_LU = True
+                ops.kernel_timer.enabled = False
+            res[keep] = (Y.detach(), *got)
+        tag = f"kept_lu/N{N}_K{K}_{str(cd)[-3:]}"
+        check_close(tag + "/Y", res[True][0].cpu().to(torch.complex128), Yr.detach(), tol)
+        for name, a, b in zip(("g_g", "g_U", "g_R"), res[True][1:], want):
+            check_close(f"{tag}/{name}", a.cpu().to(torch.complex128), b, tol)
+        assert torch.equal(res[True][0], res[False][0])                 # the same forward kernel, with and without the stores
+        for a, b in zip(res[True][1:], res[False][1:]):                 # the two adjoint routes: rounding apart
+            assert relerr(a, b) < (1e-11 if cd == torch.complex128 else 3e-5)
