@@ -266,16 +266,22 @@ __global__ void __launch_bounds__(64) expm16_fwd_kernel(const T* __restrict__ X,
                                                        double* __restrict__ stash) {
     constexpr int N = 16, NN = 256;
     const int lane = threadIdx.x, j = lane & 15, i0 = lane >> 4;
-    auto entry = [&](int i, int jj) -> double {      // A[i][jj]
-        if (!skew) return (double)X[i * N + jj];
-        const double x = (double)X[jj > i ? i * N + jj : jj * N + i];
-        return jj > i ? x : (jj < i ? -x : 0.0);
-    };
+    // A[i][jj] and its transpose: the lane's eight loads are requested together, unconditionally (the skew form reads the upper
+    // triangle's element for both halves and signs it afterwards: with the load inside the case distinction every one of them
+    // was a branch with its own wait -- eight serial round trips in a kernel of 4 us of arithmetic)
+    auto index = [&](int i, int jj) { return skew ? (jj > i ? i * N + jj : jj * N + i) : i * N + jj; };
+    auto signed_entry = [&](double x, int i, int jj) { return skew ? (jj > i ? x : (jj < i ? -x : 0.0)) : x; };
+    T raw[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        raw[r] = X[index(i0 + 4 * r, j)];
+        raw[4 + r] = X[index(j, i0 + 4 * r)];
+    }
     d4m A, At;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        A[r] = entry(i0 + 4 * r, j);
-        At[r] = entry(j, i0 + 4 * r);
+        A[r] = signed_entry((double)raw[r], i0 + 4 * r, j);
+        At[r] = signed_entry((double)raw[4 + r], j, i0 + 4 * r);
     }
     // |A|_1 = largest column sum: this lane's four rows of column j, the four lane groups, then the sixteen columns
     double cs = (fabs(A[0]) + fabs(A[1])) + (fabs(A[2]) + fabs(A[3]));
@@ -335,12 +341,26 @@ __global__ void __launch_bounds__(64) expm16_bwd_kernel(const T* __restrict__ gE
     constexpr int N = 16, NN = 256;
     __shared__ double dAs[N * (N + 1)];
     const int lane = threadIdx.x, j = lane & 15, i0 = lane >> 4;
-    auto cot = [&](int idx) { return (gE ? (double)gE[idx] : 0.0) + (gEc ? (double)gEc[2 * idx] : 0.0); };
+    // the cotangent (real form + real part of the complex form, either may be absent): all sixteen loads requested together --
+    // an absent form reads the first element of the other with weight zero (no branch, no wait per load)
+    const T* ge = gE ? gE : gEc;
+    const T* gc = gEc ? gEc : gE;
+    const int ge_s = gE ? 1 : 0, gc_s = gEc ? 2 : 0;
+    const double ge_w = gE ? 1.0 : 0.0, gc_w = gEc ? 1.0 : 0.0;
+    T rawe[8], rawc[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int a = (i0 + 4 * r) * N + j, b = j * N + i0 + 4 * r;
+        rawe[r] = ge[a * ge_s];
+        rawc[r] = gc[a * gc_s];
+        rawe[4 + r] = ge[b * ge_s];
+        rawc[4 + r] = gc[b * gc_s];
+    }
     d4m G, Gt, dA = zero16();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        G[r] = cot((i0 + 4 * r) * N + j);
-        Gt[r] = cot(j * N + i0 + 4 * r);
+        G[r] = ge_w * (double)rawe[r] + gc_w * (double)rawc[r];
+        Gt[r] = ge_w * (double)rawe[4 + r] + gc_w * (double)rawc[4 + r];
     }
     const int SQ = __builtin_amdgcn_readfirstlane((int)stash[(size_t)EXPM_SLOTS * NN]);
     const d4m As = load16(stash, lane, false);
