@@ -504,6 +504,9 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
     // the slot holds BEFORE pivoting (threshold pivoting keeps the diagonal for every damped loop: a wavefront in which a row did
     // move fetches again, below).  With a guard per element every load was a branch with its own wait: ~11 serial round trips
     // per wavefront against ~4 us of arithmetic, two wavefronts per SIMD to hide them.
+    // (double: the right-hand side and the output gains stay behind the elimination -- their registers would take the kernel from
+    // two wavefronts per SIMD to one: 0.41 -> 0.49 ms on the float64 FDN step)
+    constexpr bool kPrefetchRhs = sizeof(T) == 4;
     cx<T> pre_l[RPL], pre_l2[RPL], pre_r[RPL], pre_y[RPL], pre_cw[RPL];
     if (!P) {
         const cx<T>* one = one_ptr<T>();
@@ -520,16 +523,18 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
             pre_l[s] = lp[(long)rc * l_sn + (long)fc * l_sf];
             pre_l2[s] = l2p[(long)rc * l2_sn + (long)fc * l2_sf];
             pre_r[s] = rp[(long)rc * r_sn + (long)fc * r_sf];
-            if (dud.rv) {        // (uniform) rank-one right-hand side: the gain entry; the scalar signal's value is lane-independent
-                pre_y[s] = gain_at<T>(dud.rv, dud.rv_real, rc);
-            } else {
-                pre_y[s] = R[(long)rc * rs_n + fc];                      // column 0: b = 0, kk = 0
+            if constexpr (kPrefetchRhs) {
+                if (dud.rv) {        // (uniform) rank-one right-hand side: the gain entry; the scalar signal's value is lane-independent
+                    pre_y[s] = gain_at<T>(dud.rv, dud.rv_real, rc);
+                } else {
+                    pre_y[s] = R[(long)rc * rs_n + fc];                      // column 0: b = 0, kk = 0
+                }
+                pre_cw[s] = dud.cz ? gain_at<T>(dud.cw, dud.cw_real, rc) : cx<T>(0, 0);
             }
-            pre_cw[s] = dud.cz ? gain_at<T>(dud.cw, dud.cw_real, rc) : cx<T>(0, 0);
         }
     }
     cx<T> pre_rs(0, 0);
-    if (!P && dud.rv) pre_rs = dud.rs[f < M ? f : M - 1];                // b = 0
+    if (kPrefetchRhs && !P && dud.rv) pre_rs = dud.rs[f < M ? f : M - 1];                // b = 0
     if (!P) {
         for (int e = threadIdx.x; e < NMAX * NMAX; e += 256) {
             const int i = e / NMAX, j = e % NMAX;
@@ -765,7 +770,7 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
     bool moved = false;
 #pragma unroll
     for (int s = 0; s < RPL; ++s) moved |= orig[s] != s * LANES + gi;
-    const bool refetch = P != nullptr || no_prefetch || __any(moved);
+    const bool refetch = !kPrefetchRhs || P != nullptr || no_prefetch || __any(moved);
     for (int col = 0; col < ncols; ++col) {
         const int b = col / K, kk = col - b * K;
         cx<T> y[RPL];
@@ -831,7 +836,7 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
             const int ri = s * LANES + gi;
             if (ri < N) {
                 OUT[(long)b * os_b + (long)ri * os_n + (long)kk * os_k + f] = y[s];
-                if (dud.cz) fma_cx(z, P ? gain_at<T>(dud.cw, dud.cw_real, ri) : pre_cw[s], y[s]);
+                if (dud.cz) fma_cx(z, (P || !kPrefetchRhs) ? gain_at<T>(dud.cw, dud.cw_real, ri) : pre_cw[s], y[s]);
             }
         }
         if (dud.cz && !adjoint) {      // uniform: the output-gain row applied in the wavefront
