@@ -68,6 +68,46 @@ __global__ void __launch_bounds__(PROBE_THREADS) hbm_probe_kernel(const pf4* __r
     }
 }
 
+
+// the same streams with 8 bytes per lane and access (the column passes' width: a lane owns one complex value / one channel pair
+// of one sample): what the access width alone costs
+typedef float pf2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__global__ void __launch_bounds__(PROBE_THREADS) hbm_probe8_kernel(const pf2* __restrict__ src, pf2* __restrict__ dst, size_t n2,
+                                                                   float* __restrict__ partial) {
+    constexpr int U = 2 * PROBE_UNROLL;                       // the same bytes in flight per lane
+    const size_t chunk = (size_t)PROBE_THREADS * U, chunks = n2 / chunk;
+    pf2 acc = {0.f, 0.f};
+    for (size_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+        const size_t base = c * chunk + threadIdx.x;
+        pf2 v[U];
+        if constexpr (KIND != 1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = src[base + (size_t)u * PROBE_THREADS];
+        }
+        if constexpr (KIND == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += v[u];
+        } else if constexpr (KIND == 1) {
+            const pf2 k = {1.f, (float)c};
+#pragma unroll
+            for (int u = 0; u < U; ++u) dst[base + (size_t)u * PROBE_THREADS] = k;
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) dst[base + (size_t)u * PROBE_THREADS] = v[u];
+        }
+    }
+    if constexpr (KIND == 0) {
+        float s = acc.x + acc.y;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        __shared__ float red[PROBE_THREADS / 64];
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    }
+}
+
 template <int KIND>
 static int probe_launch(const void* src, void* dst, size_t n4, int wgs, int flags, float* partial, hipStream_t st) {
     const int rev = (flags >> 2) & 1;
@@ -93,6 +133,16 @@ extern "C" int fl_hbm_probe(int kind, const void* src, void* dst, size_t bytes, 
     FL_REQUIRE((kind == 1 || src) && (kind == 0 || dst) && (kind != 0 || partials), "fl_hbm_probe: null buffer");
     const size_t n4 = bytes / 16;
     hipStream_t st = (hipStream_t)stream;
+    if (flags & 8) {      // 8 bytes per lane and access (kinds 0 / 1 / 2, default policy)
+        FL_REQUIRE(kind <= 2, "fl_hbm_probe: the 8-byte form has kinds 0, 1, 2");
+        const pf2* s2 = (const pf2*)src;
+        pf2* d2 = (pf2*)dst;
+        if (kind == 0) hipLaunchKernelGGL((hbm_probe8_kernel<0>), dim3(workgroups), dim3(PROBE_THREADS), 0, st, s2, d2, bytes / 8, (float*)partials);
+        else if (kind == 1) hipLaunchKernelGGL((hbm_probe8_kernel<1>), dim3(workgroups), dim3(PROBE_THREADS), 0, st, s2, d2, bytes / 8, (float*)partials);
+        else hipLaunchKernelGGL((hbm_probe8_kernel<2>), dim3(workgroups), dim3(PROBE_THREADS), 0, st, s2, d2, bytes / 8, (float*)partials);
+        FL_CHECK_LAUNCH("fl_hbm_probe");
+        return FL_OK;
+    }
     switch (kind) {
         case 0: probe_launch<0>(src, dst, n4, workgroups, flags, (float*)partials, st); break;
         case 1: probe_launch<1>(src, dst, n4, workgroups, flags, (float*)partials, st); break;

@@ -747,7 +747,8 @@ int fl_set_stream_policy(unsigned mask, int site);
  *   kind 0: read `bytes` from src (one float per workgroup written to partials[workgroups]);  1: write `bytes` to dst;
  *   2: copy src -> dst;  3: read `bytes`, write bytes/8 (the 8:1 mix of the response-gradient pass).
  *   bytes: multiple of 32 KiB;  workgroups: persistent grid (256 threads each, 16 bytes per lane and access, eight in flight);
- *   flags: bit 0 non-temporal loads, bit 1 non-temporal stores, bit 2 walk the buffer from its end (consumer-first order). */
+ *   flags: bit 0 non-temporal loads, bit 1 non-temporal stores, bit 2 walk the buffer from its end (consumer-first order),
+ *          bit 3 eight bytes per lane and access instead of sixteen (kinds 0 - 2, default policy). */
 int fl_hbm_probe(int kind, const void* src, void* dst, size_t bytes, int workgroups, int flags, void* partials, void* stream);
 
 #ifdef __cplusplus
