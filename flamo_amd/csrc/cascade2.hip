@@ -498,13 +498,28 @@ __global__ void __launch_bounds__(256) geq_bwd_lanes_kernel(const void* __restri
     const int per = (nbx + W - 1) / W, b0 = part * per, b1 = min(nbx, b0 + per);
     const P4* ps4 = reinterpret_cast<const P4*>(psum) + (size_t)idx * nbx;
     if (on) {
-#pragma unroll 4
-        for (int bx = b0 + lane; bx < b1; bx += 64) {
-            if (band > 0) {
-                const P4 r4 = ps4[bx];
-                v[0] += (double)r4.x; v[1] += (double)r4.y; v[2] += (double)r4.z; v[3] += (double)r4.w;
+        // four records per lane and trip, all eight loads requested before the first is added (a record beyond the range reads
+        // the range's first one and is masked: with the guard around the load every trip was a round trip of its own -- four in
+        // a row in a kernel that is nothing but latency)
+        const T* pqc = pq + (size_t)c * nbx;
+        for (int base = b0; base < b1; base += 256) {
+            P4 r4[4];
+            T q1[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bx = base + lane + 64 * u;
+                ok[u] = bx < b1;
+                const int bc = ok[u] ? bx : b0;
+                r4[u] = ps4[bc];
+                q1[u] = pqc[bc];
             }
-            v[4] += (double)pq[(size_t)c * nbx + bx];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double m = ok[u] ? 1.0 : 0.0, mb = (ok[u] && band > 0) ? 1.0 : 0.0;
+                v[0] += mb * (double)r4[u].x; v[1] += mb * (double)r4[u].y; v[2] += mb * (double)r4[u].z; v[3] += mb * (double)r4[u].w;
+                v[4] += m * (double)q1[u];
+            }
         }
     }
 #pragma unroll
@@ -635,7 +650,8 @@ static int lanes_cus() {
 // esz: bytes of the kernels' real type (4: float, 8: double -- half the lanes per workgroup, twice the LDS per value)
 static LanesPlan lanes_plan(int m_local, int C, int S, int nfft, int bin0, int ppr, int niw, int mode, int esz = 4) {
     LanesPlan P{};
-    const int max_threads = esz == 8 ? 384 : 768, sc = esz / 4;
+    static const int env_maxt = [] { const char* e = getenv("FLAMO_LANES_MAXT"); return e ? atoi(e) : 0; }();      // tuning: lanes per workgroup
+    const int max_threads = esz == 8 ? 384 : (env_maxt >= 64 && env_maxt <= 768 ? env_maxt : 768), sc = esz / 4;
     if (!g_lanes || S < 4 || S > 64 || C < 1 || m_local < 1 || ppr < 1 || C % ppr) return P;
     if (mode == 1 && !((niw == 8 && ppr == 8) || (niw == 4 && ppr == 4) || (niw == 2 && ppr == 2) || (niw == 16 && ppr == 16))) return P;
     if (mode == 2 && !(ppr == 8 || ppr == 16 || ppr == 32)) return P;
