@@ -29,3 +29,6 @@ python tools/bench_fdn.py --batch 8 2>/dev/null | tail -1 > $OUT/fdn_b8.json
 rm -f $OUT/*/r_kernel_trace.csv.bak
 ls -la $OUT $OUT/stats | head -30
 cut -c1-400 $OUT/bench.json
+# round 6: the memory system's ceilings on the library's own streaming kernels, and the cache-policy A/B of the step
+python tools/dbg/hbm_probe.py --json $OUT/hbm_probe.json > $OUT/hbm_probe.txt 2>&1
+python tools/dbg/policy_ab.py 0x0,0x30,0x34,0x1030,0x100 3 2>/dev/null | grep mask > $OUT/policy_ab.txt
