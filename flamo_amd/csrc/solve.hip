@@ -306,10 +306,14 @@ __global__ void __launch_bounds__(256) solve_kernel(
 // substitutions are the outer-product form of the forward kernel: the lane that finishes an unknown broadcasts it, the others
 // subtract their stored entry times it.  x[piv[s]] = v[s] on the way out.  HBM-bound: 8 N^2 bytes per bin, once.
 template <typename T, int NMAX>
-__global__ void __launch_bounds__(256) solve_kept_adjoint_kernel(const cx<T>* __restrict__ LU, const int* __restrict__ piv,
+__global__ void __launch_bounds__(256) solve_kept_adjoint_kernel(const cx<T>* __restrict__ LU, const int* __restrict__ piv, int TB,
                                                                  const cx<T>* __restrict__ R, long rs_b, long rs_n,
-                                                                 long rs_k, cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
+                                                                 long rs_k, const void* __restrict__ rv, int rv_real,
+                                                                 const cx<T>* __restrict__ rsig, long rsig_sb,
+                                                                 cx<T>* __restrict__ OUT, long os_b, long os_n, long os_k,
                                                                  int B, int M, int N, int K) {
+    // TB: bins per tile of the kernel that stored the factors (its workgroup's bins: kept_lu_index)
+    // rv / rsig: rank-one right-hand side conj(rv[j]) rsig[b][f] (the output-gain row times the output's gradient: ops.fdn_core), or R
     constexpr int BPB = 256 / NMAX;
     const int gi = threadIdx.x % NMAX;
     const int f = blockIdx.x * BPB + threadIdx.x / NMAX;
@@ -318,8 +322,8 @@ __global__ void __launch_bounds__(256) solve_kept_adjoint_kernel(const cx<T>* __
     cx<T> col[NMAX];         // col[s] = conj(factor[s][gi]): entry (gi, s) of U^H (s <= gi) / L^H (s > gi)
     {   // every load unconditional and in flight together (lanes / rows beyond N read a valid element and discard it: a guard per
         // load made each one a branch with its own wait -- 32 serial round trips per wavefront, 1.06 ms at N = 32, M = 192001)
-        const cx<T>* base = LU + kept_lu_index(f, 0, on ? gi : 0, N, BPB);
-        const long sstride = (long)BPB * N;
+        const cx<T>* base = LU + kept_lu_index(f, 0, on ? gi : 0, N, TB);
+        const long sstride = (long)TB * N;
 #pragma unroll
         for (int s = 0; s < NMAX; ++s) col[s] = base[(s < N ? s : 0) * sstride];
 #pragma unroll
@@ -328,7 +332,9 @@ __global__ void __launch_bounds__(256) solve_kept_adjoint_kernel(const cx<T>* __
             col[s] = cx<T>(keep ? col[s].x : (T)0, keep ? -col[s].y : (T)0);
         }
     }
-    const int dst = on ? piv[kept_piv_index(f, gi, N, BPB)] : 0;
+    const int dst = on ? piv[kept_piv_index(f, gi, N, TB)] : 0;
+    cx<T> gvc(0, 0);
+    if (rv) gvc = conj(gain_at<T>(rv, rv_real, on ? gi : 0));
     cx<T> dinv(0, 0);
 #pragma unroll
     for (int s = 0; s < NMAX; ++s) {      // the lane's own diagonal of U^H (a select chain: the register index is the lane)
@@ -340,7 +346,9 @@ __global__ void __launch_bounds__(256) solve_kept_adjoint_kernel(const cx<T>* __
     for (int c = 0; c < ncols; ++c) {
         const int b = c / K, kk = c - b * K;
         cx<T> y(0, 0);
-        if (on) y = R[(long)b * rs_b + (long)gi * rs_n + (long)kk * rs_k + f];
+        if (rv) y = gvc * rsig[(long)b * rsig_sb + f];
+        else y = R[(long)b * rs_b + (long)(on ? gi : 0) * rs_n + (long)kk * rs_k + f];
+        y = cx<T>(on ? y.x : (T)0, on ? y.y : (T)0);
         // U^H z = b: z_s = b_s / conj(U[s][s]) in lane s; lanes j > s subtract conj(U[s][j]) z_s
 #pragma unroll
         for (int s = 0; s < NMAX; ++s) {
@@ -762,6 +770,34 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
         dinv[SK].x = (gi == LK) ? inv.x : dinv[SK].x;
         dinv[SK].y = (gi == LK) ? inv.y : dinv[SK].y;
     });
+
+    if (dud.lu_out) {      // (uniform) the factors and the pivot order are kept for the adjoint system (see Dud): rows are in pivot order already
+#pragma unroll
+        for (int s = 0; s < RPL; ++s) {
+            const int pr = s * LANES + gi;
+            if (pr < N) {
+                cx<T>* lo = dud.lu_out + kept_lu_index(f, pr, 0, N, BPB);
+                if ((N & 1) == 0 || sizeof(T) == 8) {
+                    typedef T v4 __attribute__((ext_vector_type(16 / sizeof(T))));
+                    constexpr int PER = 16 / sizeof(cx<T>);
+#pragma unroll
+                    for (int k = 0; k < NMAX; k += PER) {
+                        if (k < N) {
+                            v4 q;
+                            if constexpr (PER == 2) q = v4{row[s][k].x, row[s][k].y, row[s][k + 1].x, row[s][k + 1].y};
+                            else q = v4{row[s][k].x, row[s][k].y};
+                            *reinterpret_cast<v4*>(lo + k) = q;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NMAX; ++k)
+                        if (k < N) lo[k] = row[s][k];
+                }
+                dud.piv_out[kept_piv_index(f, pr, N, BPB)] = orig[s];
+            }
+        }
+    }
 
     // ---- apply to every right-hand side: slot s of lane g ends up with x_{s*LANES+g}
     const int ncols = B * K;
@@ -1467,16 +1503,20 @@ static int solve_scaled_keep_impl(const void* P, long p_pitch, const void* l, lo
 }
 template <typename T>
 static int solve_kept_adjoint_impl(const void* LU, const void* piv, const void* R, long rs_b, long rs_n,
-                                   long rs_k, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream) {
-    FL_REQUIRE(LU && piv && R && OUT, "solve_kept_adjoint: null pointer");
+                                   long rs_k, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream,
+                                   int tile_bins = 0, const void* rv = nullptr, int rv_real = 0, const void* rsig = nullptr,
+                                   long rsig_sb = 0) {
+    FL_REQUIRE(LU && piv && (R || (rv && rsig)) && OUT, "solve_kept_adjoint: null pointer");
     FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0, "solve_kept_adjoint: bad sizes");
+    FL_REQUIRE(!rv || K == 1, "solve_kept_adjoint: the rank-one right-hand side has one column per batch item");
     FL_REQUIRE(N <= (sizeof(T) == 8 ? 32 : 64), "solve_kept_adjoint: N exceeds the register-resident kernels (%d)", sizeof(T) == 8 ? 32 : 64);
     if (B == 0 || M == 0) return FL_OK;
     hipStream_t st = (hipStream_t)stream;
 #define FL_KEPT(NM)                                                                                                                  \
     {                                                                                                                                \
         hipLaunchKernelGGL((solve_kept_adjoint_kernel<T, NM>), dim3(cdiv_i(M, 256 / NM)), dim3(256), 0, st, (const cx<T>*)LU,       \
-                           (const int*)piv, (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);          \
+                           (const int*)piv, tile_bins > 0 ? tile_bins : 256 / NM, (const cx<T>*)R, rs_b, rs_n, rs_k, rv, rv_real,    \
+                           (const cx<T>*)rsig, rsig_sb, (cx<T>*)OUT, os_b, os_n, os_k, B, M, N, K);                                  \
         FL_CHECK_LAUNCH("solve_kept_adjoint");                                                                                       \
         return FL_OK;                                                                                                                \
     }
@@ -1549,6 +1589,44 @@ size_t fl_solve_kept_piv_elems(int N, int M, int f64) {
     if (N <= 0 || M <= 0 || N > (f64 ? 32 : 64)) return 0;
     const int bpb = kept_bpb(N, f64);
     return (size_t)cdiv_i(M, bpb) * N * bpb;
+}
+// the FDN form (fl_solve_fdn_*) with kept factors: 8 < N <= 16 on the two-rows-per-lane kernel (its workgroup's 32 bins are a tile)
+int fl_solve_fdn_keep_tile(int N, int f64) {
+    (void)f64;
+    return (N > 8 && N <= 16 && g_solve_variant == 0 && g_solve_rpl2_16 != 1) ? 32 : 0;
+}
+int fl_solve_fdn_keep_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                          long r_sn, long r_sf, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw, int cw_real,
+                          void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* LU, void* piv,
+                          void* stream) {
+    FL_REQUIRE(U && l2 && rv && rs && (!cz || cw) && LU && piv, "solve_fdn_keep: null pointer");
+    FL_REQUIRE(fl_solve_fdn_keep_tile(N, 0) > 0, "solve_fdn_keep: 8 < N <= 16 on the default kernels (fl_solve_fdn_keep_tile)");
+    Dud<float> d = {(const cx<float>*)l, l_sn, l_sf, (const cx<float>*)U, (const cx<float>*)r, r_sn, r_sf,
+                    (const cx<float>*)l2, l2_sn, l2_sf, 1, rv, (const cx<float>*)rs, rs_sb, cw, (cx<float>*)cz, cz_sb, rv_real, cw_real};
+    d.lu_out = (cx<float>*)LU; d.piv_out = (int*)piv;
+    return solve_impl<float>(nullptr, 0, d, 1, 0, nullptr, 0, 0, 0, OUT, os_b, os_n, os_k, B, M, N, 1, stream);
+}
+int fl_solve_fdn_keep_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                           long r_sn, long r_sf, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw, int cw_real,
+                           void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* LU, void* piv,
+                           void* stream) {
+    FL_REQUIRE(U && l2 && rv && rs && (!cz || cw) && LU && piv, "solve_fdn_keep: null pointer");
+    FL_REQUIRE(fl_solve_fdn_keep_tile(N, 1) > 0, "solve_fdn_keep: 8 < N <= 16 on the default kernels (fl_solve_fdn_keep_tile)");
+    Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf,
+                     (const cx<double>*)l2, l2_sn, l2_sf, 1, rv, (const cx<double>*)rs, rs_sb, cw, (cx<double>*)cz, cz_sb, rv_real, cw_real};
+    d.lu_out = (cx<double>*)LU; d.piv_out = (int*)piv;
+    return solve_impl<double>(nullptr, 0, d, 1, 0, nullptr, 0, 0, 0, OUT, os_b, os_n, os_k, B, M, N, 1, stream);
+}
+// A^-H (conj(rv) . rs) from factors kept by fl_solve_fdn_keep_* (tile_bins = fl_solve_fdn_keep_tile)
+int fl_solve_kept_adjoint_rank1_c64(const void* LU, const void* piv, int tile_bins, const void* rv, int rv_real, const void* rs, long rs_sb,
+                                    void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* stream) {
+    FL_REQUIRE(rv && rs && tile_bins > 0, "solve_kept_adjoint_rank1: null pointer / tile");
+    return solve_kept_adjoint_impl<float>(LU, piv, nullptr, 0, 0, 0, OUT, os_b, os_n, os_k, B, M, N, 1, stream, tile_bins, rv, rv_real, rs, rs_sb);
+}
+int fl_solve_kept_adjoint_rank1_c128(const void* LU, const void* piv, int tile_bins, const void* rv, int rv_real, const void* rs, long rs_sb,
+                                     void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* stream) {
+    FL_REQUIRE(rv && rs && tile_bins > 0, "solve_kept_adjoint_rank1: null pointer / tile");
+    return solve_kept_adjoint_impl<double>(LU, piv, nullptr, 0, 0, 0, OUT, os_b, os_n, os_k, B, M, N, 1, stream, tile_bins, rv, rv_real, rs, rs_sb);
 }
 int fl_solve_scaled_keep_c64(const void* P, long p_pitch, const void* l, long l_sn, const void* R, long rs_b, long rs_n, long rs_k, void* OUT,
                              long os_b, long os_n, long os_k, int B, int M, int N, int K, void* LU, void* piv, void* stream) {

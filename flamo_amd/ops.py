@@ -1559,9 +1559,18 @@ def _fdn_in_solve(real, N) -> bool:
     return FDN_GAINS_IN_SOLVE and N <= (32 if real == torch.float32 else 16)
 
 
-def _solve_fdn_launch(l, l2, U, r, adjoint, gain, sig, cw):
+# The FDN's forward solve CAN keep its LU factors (8 N^2 bytes per bin: 197 MB at 16 channels, nfft = 192000) for the backward
+# pass's adjoint system (fl_solve_fdn_keep_* / fl_solve_kept_adjoint_rank1_*; 8 < N <= 16) -- measured and left OFF: at N = 16 the
+# two passes over the factors (stores + 39 us on the forward kernel, 43.5 us for the substitution, both at HBM rate) cost more
+# than the elimination they replace (66 us): 0.339 against 0.311 ms on the replayed FDN step.  The elimination grows with N^3, the
+# factors with N^2: the scaled loop keeps them above 16 channels (KEEP_LU), where it wins 1.8 ms at N = 32.  Tests run both.
+KEEP_LU_FDN = False
+
+
+def _solve_fdn_launch(l, l2, U, r, adjoint, gain, sig, cw, keep=False):
     """OUT = A^-1 (l2 . (gain sig)) [forward] or A^-H (conj(gain) sig) [adjoint]; with cw (forward) also z = cw . OUT.
-    gain, cw: contiguous N-vectors, real or complex; sig: planar one-channel signal (B, M, 1).  -> (OUT, z | None)"""
+    gain, cw: contiguous N-vectors, real or complex; sig: planar one-channel signal (B, M, 1).  -> (OUT, z | None), or with
+    keep (forward): (OUT, z, (LU, piv, tile)) -- the factors for _solve_fdn_kept_adjoint_launch."""
     real = _rdtype(sig)
     B, M, _, K, ss_b, _, _ = _bnk(sig)
     assert K == 1
@@ -1571,16 +1580,43 @@ def _solve_fdn_launch(l, l2, U, r, adjoint, gain, sig, cw):
     z = _empty_planar((B, M, 1), sig.dtype, sig.device) if cw is not None else None
     zs_b = _bnk(z)[4] if z is not None else 0
     L = _lib.lib()
-    fn = L.fl_solve_fdn_c64 if real == torch.float32 else L.fl_solve_fdn_c128
     lp, l_sn, l_sf = _diag_args(l)
     l2p, l2_sn, l2_sf = _diag_args(l2)
     rp, r_sn, r_sf = _diag_args(r)
+    if keep:
+        assert not adjoint
+        tile = L.fl_solve_fdn_keep_tile(N, int(real == torch.float64))
+        nt = (M + tile - 1) // tile
+        LU = torch.empty(nt * tile * N * N, dtype=sig.dtype, device=sig.device)
+        piv = torch.empty(nt * tile * N, dtype=torch.int32, device=sig.device)
+        fn = L.fl_solve_fdn_keep_c64 if real == torch.float32 else L.fl_solve_fdn_keep_c128
+        with kernel_timer.span("solve_dud"):
+            _lib.check(fn(lp, l_sn, l_sf, l2p, l2_sn, l2_sf, U.data_ptr(), rp, r_sn, r_sf, gain.data_ptr(),
+                          int(not gain.is_complex()), sig.data_ptr(), ss_b, None if cw is None else cw.data_ptr(),
+                          int(cw is not None and not cw.is_complex()), None if z is None else z.data_ptr(), zs_b, OUT.data_ptr(), os_b,
+                          os_n, os_k, B, M, N, LU.data_ptr(), piv.data_ptr(), _stream()), "solve_fdn_keep")
+        return OUT, z, (LU, piv, tile)
+    fn = L.fl_solve_fdn_c64 if real == torch.float32 else L.fl_solve_fdn_c128
     with kernel_timer.span("solve_dud_adj" if adjoint else "solve_dud"):
         _lib.check(fn(lp, l_sn, l_sf, l2p, l2_sn, l2_sf, U.data_ptr(), rp, r_sn, r_sf, int(adjoint), gain.data_ptr(),
                       int(not gain.is_complex()), sig.data_ptr(), ss_b, None if cw is None else cw.data_ptr(),
                       int(cw is not None and not cw.is_complex()), None if z is None else z.data_ptr(), zs_b, OUT.data_ptr(), os_b,
                       os_n, os_k, B, M, N, _stream()), "solve_fdn")
     return OUT, z
+
+
+def _solve_fdn_kept_adjoint_launch(LU, piv, tile, gain, sig, N):
+    """A^-H (conj(gain) sig) from the factors the forward solve kept"""
+    real = _rdtype(sig)
+    B, M, _, K, ss_b, _, _ = _bnk(sig)
+    OUT = _empty_planar((B, M, N), sig.dtype, sig.device)
+    _, _, _, _, os_b, os_n, os_k = _bnk(OUT)
+    L = _lib.lib()
+    fn = L.fl_solve_kept_adjoint_rank1_c64 if real == torch.float32 else L.fl_solve_kept_adjoint_rank1_c128
+    with kernel_timer.span("solve_dud_adj"):
+        _lib.check(fn(LU.data_ptr(), piv.data_ptr(), int(tile), gain.data_ptr(), int(not gain.is_complex()), sig.data_ptr(), ss_b,
+                      OUT.data_ptr(), os_b, os_n, os_k, B, M, N, _stream()), "solve_kept_adjoint_rank1")
+    return OUT
 
 
 class _FdnCore(torch.autograd.Function):
@@ -1602,14 +1638,19 @@ class _FdnCore(torch.autograd.Function):
         lp, l2p, rp = pl(l), pl(l2), pl(r)
         bc, cc = b.resolve_conj().contiguous(), c.resolve_conj().contiguous()
         ctx.in_solve = _fdn_in_solve(_rdtype(Xp), N)
-        if ctx.in_solve:
+        kept = None
+        if ctx.in_solve and KEEP_LU_FDN and any(ctx.needs_input_grad) and \
+                _lib.lib().fl_solve_fdn_keep_tile(N, int(_rdtype(Xp) == torch.float64)) > 0:
+            OUT, y, kept = _solve_fdn_launch(lp, l2p, Uc, rp, False, bc, Xp, cc, keep=True)
+        elif ctx.in_solve:
             OUT, y = _solve_fdn_launch(lp, l2p, Uc, rp, False, bc, Xp, cc)
         else:
             R0 = _apply_const(bc, False, Xp)
             OUT = _solve_dud2_launch(lp, l2p, True, Uc, rp, False, R0)
             y = _apply_const(cc, False, OUT)
         ctx.have = (l is not None, r is not None)
-        ctx.save_for_backward(*([t for t in (lp, rp) if t is not None] + [l2p, Uc, OUT, Xp, bc, cc]))
+        ctx.kept_tile = kept[2] if kept is not None else 0
+        ctx.save_for_backward(*([t for t in (lp, rp) if t is not None] + [l2p, Uc, OUT, Xp, bc, cc] + (list(kept[:2]) if kept is not None else [])))
         return y
 
     @staticmethod
@@ -1617,9 +1658,11 @@ class _FdnCore(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         lp = saved.pop(0) if ctx.have[0] else None
         rp = saved.pop(0) if ctx.have[1] else None
-        l2p, Uc, OUT, Xp, bc, cc = saved
+        l2p, Uc, OUT, Xp, bc, cc, *kept = saved
         gyp = to_planar(gy.resolve_conj())
-        if ctx.in_solve:
+        if kept:          # A^-H c^H gy from the forward solve's factors: a substitution, no second elimination
+            gR = _solve_fdn_kept_adjoint_launch(kept[0], kept[1], ctx.kept_tile, cc, gyp, Uc.shape[0])
+        elif ctx.in_solve:
             gR, _ = _solve_fdn_launch(lp, l2p, Uc, rp, True, cc, gyp, None)                           # A^-H c^H gy
         else:
             gR = _solve_dud2_launch(lp, l2p, False, Uc, rp, True, _apply_const(cc, True, gyp))

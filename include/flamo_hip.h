@@ -550,6 +550,24 @@ int fl_solve_kept_adjoint_c64(const void* LU, const void* piv, const void* R, lo
                               void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream);
 int fl_solve_kept_adjoint_c128(const void* LU, const void* piv, const void* R, long rs_b, long rs_n, long rs_k,
                                void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, int K, void* stream);
+/* The same for the feedback delay network between its gains (fl_solve_fdn_*, forward system; reverb.py:117-199 / e8_fdn.py:60-100
+ * through system.py:420-425): 8 < N <= 16.  fl_solve_fdn_keep_tile: bins per tile of the kept arrays for this size (0: this size
+ * keeps nothing -- call fl_solve_fdn_* both ways); LU: ceil(M / tile) * tile * N^2 complex values, piv: ceil(M / tile) * tile * N
+ * int32.  fl_solve_kept_adjoint_rank1_*: OUT = A^-H (conj(rv) . rs), the backward's adjoint system with the output-gain row rv
+ * (N values, real or complex) times the output's gradient rs (B, M) as its right-hand side. */
+int fl_solve_fdn_keep_tile(int N, int f64);
+int fl_solve_fdn_keep_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                          long r_sn, long r_sf, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw, int cw_real,
+                          void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* LU, void* piv,
+                          void* stream);
+int fl_solve_fdn_keep_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                           long r_sn, long r_sf, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw, int cw_real,
+                           void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* LU, void* piv,
+                           void* stream);
+int fl_solve_kept_adjoint_rank1_c64(const void* LU, const void* piv, int tile_bins, const void* rv, int rv_real, const void* rs, long rs_sb,
+                                    void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* stream);
+int fl_solve_kept_adjoint_rank1_c128(const void* LU, const void* piv, int tile_bins, const void* rv, int rv_real, const void* rs, long rs_sb,
+                                     void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* stream);
 
 /* Same solve with the loop matrix given in the factored form every feedback delay network has
  * (reverb.py:117-199, e8_fdn.py:60-100: delays and attenuation filters are diagonal, only the

@@ -1105,3 +1105,64 @@ def test_scaled_loop_adjoint_from_kept_factors(gpu, N, K):
         assert torch.equal(res[True][0], res[False][0])                 # the same forward kernel, with and without the stores
         for a, b in zip(res[True][1:], res[False][1:]):                 # the two adjoint routes: rounding apart
             cc("a", a, b, (1e-11 if cd == torch.complex128 else 3e-5), max_tol=float("inf"))
+
+
+@pytest.mark.parametrize("N", [9, 12, 13, 16])
+@pytest.mark.parametrize("kind", ["damped", "exchanges"])
+def test_fdn_adjoint_from_kept_factors(gpu, N, kind):
+    """fl_solve_fdn_keep_* + fl_solve_kept_adjoint_rank1_* (8 < N <= 16): ops.fdn_core's backward solves A^H x = conj(c) g from
+    the LU factors its forward solve left instead of a second elimination -- output and every gradient against LAPACK autograd
+    in float64 on the materialised system (flamo/processor/system.py:420-425 between the two gains), for damped loops (no row
+    moves) and loops that exchange rows at every step (the pivot order travels with the factors), odd and even N, batch 1 and
+    3, and against the re-factoring route it replaces (ops.KEEP_LU_FDN = False)."""
+    from flamo_amd import _lib, ops
+    torch.manual_seed(7 * N + (kind == "exchanges"))
+    M = 391
+    assert _lib.lib().fl_solve_fdn_keep_tile(N, 0) == 32      # (ops.KEEP_LU_FDN is off by default: measured slower at these sizes)
+    for cd, tol in ((torch.complex128, 1e-11), (torch.complex64, 3e-5)):
+        rd = torch.float64 if cd == torch.complex128 else torch.float32
+        if kind == "damped":
+            U64 = torch.linalg.qr(torch.randn(N, N, dtype=torch.float64))[0]
+            l64 = 0.97 * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64))
+            scale = 1.0
+        else:
+            perm = torch.roll(torch.arange(N), 1)
+            U64 = 3.0 * torch.eye(N, dtype=torch.float64)[perm] + 0.05 * torch.randn(N, N, dtype=torch.float64)
+            l64 = torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64))
+            scale = 30.0
+        l2_64 = 0.9 * torch.exp(2j * torch.pi * torch.rand(M, N, dtype=torch.float64))
+        r64 = (0.8 + 0.2 * torch.rand(M, N, dtype=torch.float64)).to(torch.complex128)
+        b64, c64 = torch.randn(N, 1, dtype=torch.float64), torch.randn(1, N, dtype=torch.float64)
+        for B in (1, 3):
+            X64 = torch.randn(B, M, 1, dtype=torch.complex128)
+            C64 = torch.randn(B, M, 1, dtype=torch.complex128)
+            ref_in = [t.clone().requires_grad_(True) for t in (b64, c64, l64, U64, r64, X64)]
+            bR, cR, lR, UR, rR, XR = ref_in
+            A = torch.eye(N, dtype=torch.complex128) - (lR * l2_64).unsqueeze(-1) * UR.to(torch.complex128) * rR.unsqueeze(-2)
+            rhs = l2_64.unsqueeze(0) * (bR.to(torch.complex128).squeeze(-1) * XR)              # (B, M, N)
+            out = torch.linalg.solve(A.unsqueeze(0), rhs.unsqueeze(-1)).squeeze(-1)
+            Yr = (out * cR.to(torch.complex128).squeeze(0)).sum(-1, keepdim=True)
+            want = torch.autograd.grad(torch.sum(torch.real(Yr * torch.conj(C64))), ref_in)
+            res = {}
+            for keep in (True, False):
+                ops.KEEP_LU_FDN = keep
+                try:
+                    dev_in = [b64.to(gpu, rd), c64.to(gpu, rd), l64.to(gpu, cd), U64.to(gpu, cd), r64.to(gpu, cd), X64.to(gpu, cd)]
+                    dev_in = [t.requires_grad_(True) for t in dev_in]
+                    ops.kernel_timer.reset(True)
+                    Y = ops.fdn_core(dev_in[0], dev_in[1], dev_in[2], l2_64.to(gpu, cd), dev_in[3], dev_in[4], dev_in[5])
+                    got = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C64.to(gpu, cd)))), dev_in)
+                    torch.cuda.synchronize()
+                finally:
+                    ops.KEEP_LU_FDN = True
+                    ops.kernel_timer.enabled = False
+                res[keep] = [Y.detach()] + list(got)
+            tag = f"fdn_kept/{kind}_N{N}_B{B}_{str(cd)[-3:]}"
+            names = ("Y", "g_b", "g_c", "g_l", "g_U", "g_r", "g_X")
+            wants = [Yr.detach()] + [w if w.is_complex() or i in (0, 1) else w for i, w in enumerate(want)]
+            for name, a, w in zip(names, res[True], wants):
+                w = w.real if (not a.is_complex() and w.is_complex()) else w
+                check_close(f"{tag}/{name}", a.cpu().to(w.dtype), w, tol * scale, max_tol=float("inf"))
+            assert torch.equal(res[True][0], res[False][0])              # the same forward kernel, with and without the stores
+            for a, b in zip(res[True][1:], res[False][1:]):               # the two adjoint routes: rounding apart
+                assert relerr(a, b) < tol * scale

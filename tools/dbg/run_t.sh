@@ -1,3 +1,3 @@
 cd /root/repo
-python tools/dbg/soak.py 2>&1 | tail -8
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+timeout 2400 python -m pytest tests/test_hip_kernels.py tests/test_hip_parity.py tests/test_round2_parity.py tests/test_round3_parity.py tests/test_round4.py tests/test_objectives.py -q -m gpu 2>&1 | grep -E "passed|failed|^FAILED|^E  " | head -20
+bash tools/dbg/run_fdn.sh 2>&1 | tail -22
