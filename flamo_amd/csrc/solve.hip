@@ -69,6 +69,13 @@ struct Dud {
     // and the part has 288 GB to keep 8 N^2 bytes per bin in.
     cx<T>* lu_out;
     int* piv_out;
+    // The adjoint system's solution for the output-gain row, w[f] = A[f]^-H cw^H, from the FORWARD launch's factors (float32,
+    // 4 < N <= 16: fl_solve_fdn_wadj_c64): the backward pass of a network with ONE output channel has the right-hand side
+    // cw^H gy[b][f] -- the same vector times a scalar per (batch item, bin) -- so its solution is w[f] gy[b][f] and the backward
+    // needs no solve at all.  The transposed substitutions run as dot products over the lanes (row p of the factors sits in
+    // the lane it was eliminated in: column access is a reduction over the group).  Element (n, f) at wadj[n*wadj_sn + f].
+    cx<T>* wadj;
+    long wadj_sn;
 };
 
 
@@ -537,7 +544,7 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
                 } else {
                     pre_y[s] = R[(long)rc * rs_n + fc];                      // column 0: b = 0, kk = 0
                 }
-                pre_cw[s] = dud.cz ? gain_at<T>(dud.cw, dud.cw_real, rc) : cx<T>(0, 0);
+                pre_cw[s] = (dud.cz || dud.wadj) ? gain_at<T>(dud.cw, dud.cw_real, rc) : cx<T>(0, 0);
             }
         }
     }
@@ -796,6 +803,52 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
                 }
                 dud.piv_out[kept_piv_index(f, pr, N, BPB)] = orig[s];
             }
+        }
+    }
+
+    // ---- w = A^-H cw^H from the factors just formed (see Dud::wadj).  P A = L U with the rows in pivot order: A^H = U^H L^H P, so
+    // U^H z = cw^H, L^H u = z, w[orig[p]] = u[p].  Lane (slot s, lane g) holds row p = s LANES + g of the factors, i.e. COLUMN p of
+    // U^H and L^H: unknown k is a dot product over the lanes -- sum_p conj(row_p[k]) z_p, the not-yet-known entries still zero, so
+    // no masks -- one DPP reduction per unknown.
+    constexpr bool kWadj = sizeof(T) == 4 && (LANES == 8 || LANES == 4) && RPL == 2;      // 4 < N <= 16
+    if constexpr (kWadj) {
+        if (dud.wadj) {       // (uniform)
+            cx<T> v[RPL], z[RPL], u[RPL];
+#pragma unroll
+            for (int s = 0; s < RPL; ++s) {
+                const bool real_row = s * LANES + gi < N;
+                v[s] = real_row ? conj(pre_cw[s]) : cx<T>(0, 0);
+                z[s] = u[s] = cx<T>(0, 0);
+            }
+            static_for<0, NMAX>([&](auto kc) {          // U^H z = cw^H, ascending
+                constexpr int KK = decltype(kc)::value;
+                constexpr int SK = KK / LANES, LK = KK % LANES;
+                if (KK >= N) return;
+                cx<T> part(0, 0);
+#pragma unroll
+                for (int s = 0; s <= SK; ++s) fma_cxc(part, z[s], row[s][KK]);       // z_p conj(U[p][k]); rows of later slots are below the diagonal
+                part.x = group_sum<LANES>(part.x);
+                part.y = group_sum<LANES>(part.y);
+                const cx<T> zk = (v[SK] - part) * conj(dinv[SK]);
+                z[SK].x = (gi == LK) ? zk.x : z[SK].x;
+                z[SK].y = (gi == LK) ? zk.y : z[SK].y;
+            });
+            static_for<0, NMAX>([&](auto kc) {          // L^H u = z (unit diagonal), descending
+                constexpr int KK = NMAX - 1 - decltype(kc)::value;
+                constexpr int SK = KK / LANES, LK = KK % LANES;
+                if (KK >= N) return;
+                cx<T> part(0, 0);
+#pragma unroll
+                for (int s = SK; s < RPL; ++s) fma_cxc(part, u[s], row[s][KK]);      // u_p conj(L[p][k]), p > k
+                part.x = group_sum<LANES>(part.x);
+                part.y = group_sum<LANES>(part.y);
+                const cx<T> uk = z[SK] - part;
+                u[SK].x = (gi == LK) ? uk.x : u[SK].x;
+                u[SK].y = (gi == LK) ? uk.y : u[SK].y;
+            });
+#pragma unroll
+            for (int s = 0; s < RPL; ++s)
+                if (s * LANES + gi < N) dud.wadj[(long)orig[s] * dud.wadj_sn + f] = u[s];
         }
     }
 
@@ -1589,6 +1642,19 @@ size_t fl_solve_kept_piv_elems(int N, int M, int f64) {
     if (N <= 0 || M <= 0 || N > (f64 ? 32 : 64)) return 0;
     const int bpb = kept_bpb(N, f64);
     return (size_t)cdiv_i(M, bpb) * N * bpb;
+}
+// the FDN form, forward system, with w = A^-H cw^H beside OUT and cz (Dud::wadj): float32, 4 < N <= 16
+int fl_solve_fdn_wadj_supported(int N) { return (N > 4 && N <= 16 && g_solve_variant == 0 && g_solve_rpl2_16 != 1) ? 1 : 0; }
+int fl_solve_fdn_wadj_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                          long r_sn, long r_sf, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw, int cw_real,
+                          void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* wadj, long wadj_sn,
+                          void* stream) {
+    FL_REQUIRE(U && l2 && rv && rs && cw && wadj, "solve_fdn_wadj: null pointer");
+    FL_REQUIRE(fl_solve_fdn_wadj_supported(N), "solve_fdn_wadj: 4 < N <= 16 on the default kernels (fl_solve_fdn_wadj_supported)");
+    Dud<float> d = {(const cx<float>*)l, l_sn, l_sf, (const cx<float>*)U, (const cx<float>*)r, r_sn, r_sf,
+                    (const cx<float>*)l2, l2_sn, l2_sf, 1, rv, (const cx<float>*)rs, rs_sb, cw, (cx<float>*)cz, cz_sb, rv_real, cw_real};
+    d.wadj = (cx<float>*)wadj; d.wadj_sn = wadj_sn;
+    return solve_impl<float>(nullptr, 0, d, 1, 0, nullptr, 0, 0, 0, OUT, os_b, os_n, os_k, B, M, N, 1, stream);
 }
 // the FDN form (fl_solve_fdn_*) with kept factors: 8 < N <= 16 on the two-rows-per-lane kernel (its workgroup's 32 bins are a tile)
 int fl_solve_fdn_keep_tile(int N, int f64) {

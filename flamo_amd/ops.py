@@ -1567,7 +1567,13 @@ def _fdn_in_solve(real, N) -> bool:
 KEEP_LU_FDN = False
 
 
-def _solve_fdn_launch(l, l2, U, r, adjoint, gain, sig, cw, keep=False):
+# A one-output FDN's backward right-hand side is the output-gain row times a scalar per (batch item, bin): its adjoint solution is
+# w[f] gy[b][f] with w = A^-H c^H formed by the FORWARD launch from its own factors (fl_solve_fdn_wadj_c64; float32, 4 < N <= 16) --
+# the backward pass then runs no solve.  False: the adjoint system is factored and solved by a launch of its own.
+FDN_ADJOINT_IN_FORWARD = True
+
+
+def _solve_fdn_launch(l, l2, U, r, adjoint, gain, sig, cw, keep=False, wadj=False):
     """OUT = A^-1 (l2 . (gain sig)) [forward] or A^-H (conj(gain) sig) [adjoint]; with cw (forward) also z = cw . OUT.
     gain, cw: contiguous N-vectors, real or complex; sig: planar one-channel signal (B, M, 1).  -> (OUT, z | None), or with
     keep (forward): (OUT, z, (LU, piv, tile)) -- the factors for _solve_fdn_kept_adjoint_launch."""
@@ -1583,6 +1589,16 @@ def _solve_fdn_launch(l, l2, U, r, adjoint, gain, sig, cw, keep=False):
     lp, l_sn, l_sf = _diag_args(l)
     l2p, l2_sn, l2_sf = _diag_args(l2)
     rp, r_sn, r_sf = _diag_args(r)
+    if wadj:        # forward, float32: (OUT, z, W) with W (1, M, N) planar = A^-H cw^H
+        assert not adjoint and cw is not None and real == torch.float32
+        W = _empty_planar((1, M, N), sig.dtype, sig.device)
+        _, _, _, _, _, ws_n, _ = _bnk(W)
+        with kernel_timer.span("solve_dud"):
+            _lib.check(L.fl_solve_fdn_wadj_c64(lp, l_sn, l_sf, l2p, l2_sn, l2_sf, U.data_ptr(), rp, r_sn, r_sf, gain.data_ptr(),
+                                               int(not gain.is_complex()), sig.data_ptr(), ss_b, cw.data_ptr(), int(not cw.is_complex()),
+                                               z.data_ptr(), zs_b, OUT.data_ptr(), os_b, os_n, os_k, B, M, N, W.data_ptr(), ws_n,
+                                               _stream()), "solve_fdn_wadj")
+        return OUT, z, W
     if keep:
         assert not adjoint
         tile = L.fl_solve_fdn_keep_tile(N, int(real == torch.float64))
@@ -1639,7 +1655,11 @@ class _FdnCore(torch.autograd.Function):
         bc, cc = b.resolve_conj().contiguous(), c.resolve_conj().contiguous()
         ctx.in_solve = _fdn_in_solve(_rdtype(Xp), N)
         kept = None
-        if ctx.in_solve and KEEP_LU_FDN and any(ctx.needs_input_grad) and \
+        Wadj = None
+        if ctx.in_solve and FDN_ADJOINT_IN_FORWARD and any(ctx.needs_input_grad) and _rdtype(Xp) == torch.float32 and \
+                _lib.lib().fl_solve_fdn_wadj_supported(N):
+            OUT, y, Wadj = _solve_fdn_launch(lp, l2p, Uc, rp, False, bc, Xp, cc, wadj=True)
+        elif ctx.in_solve and KEEP_LU_FDN and any(ctx.needs_input_grad) and \
                 _lib.lib().fl_solve_fdn_keep_tile(N, int(_rdtype(Xp) == torch.float64)) > 0:
             OUT, y, kept = _solve_fdn_launch(lp, l2p, Uc, rp, False, bc, Xp, cc, keep=True)
         elif ctx.in_solve:
@@ -1650,7 +1670,9 @@ class _FdnCore(torch.autograd.Function):
             y = _apply_const(cc, False, OUT)
         ctx.have = (l is not None, r is not None)
         ctx.kept_tile = kept[2] if kept is not None else 0
-        ctx.save_for_backward(*([t for t in (lp, rp) if t is not None] + [l2p, Uc, OUT, Xp, bc, cc] + (list(kept[:2]) if kept is not None else [])))
+        ctx.has_wadj = Wadj is not None
+        ctx.save_for_backward(*([t for t in (lp, rp) if t is not None] + [l2p, Uc, OUT, Xp, bc, cc] +
+                                (list(kept[:2]) if kept is not None else []) + ([Wadj] if Wadj is not None else [])))
         return y
 
     @staticmethod
@@ -1660,7 +1682,9 @@ class _FdnCore(torch.autograd.Function):
         rp = saved.pop(0) if ctx.have[1] else None
         l2p, Uc, OUT, Xp, bc, cc, *kept = saved
         gyp = to_planar(gy.resolve_conj())
-        if kept:          # A^-H c^H gy from the forward solve's factors: a substitution, no second elimination
+        if ctx.has_wadj:  # A^-H c^H gy = w gy with w from the forward launch: a per-bin scaling, no solve (W read as an (M, N, 1) response)
+            gR = _mimo_launch(kept[-1][0].unsqueeze(-1), True, False, False, gyp)
+        elif kept:        # A^-H c^H gy from the forward solve's factors: a substitution, no second elimination
             gR = _solve_fdn_kept_adjoint_launch(kept[0], kept[1], ctx.kept_tile, cc, gyp, Uc.shape[0])
         elif ctx.in_solve:
             gR, _ = _solve_fdn_launch(lp, l2p, Uc, rp, True, cc, gyp, None)                           # A^-H c^H gy

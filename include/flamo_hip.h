@@ -556,6 +556,16 @@ int fl_solve_kept_adjoint_c128(const void* LU, const void* piv, const void* R, l
  * int32.  fl_solve_kept_adjoint_rank1_*: OUT = A^-H (conj(rv) . rs), the backward's adjoint system with the output-gain row rv
  * (N values, real or complex) times the output's gradient rs (B, M) as its right-hand side. */
 int fl_solve_fdn_keep_tile(int N, int f64);
+/* The forward FDN solve with the adjoint system's solution for the output-gain row beside it: wadj[n*wadj_sn + f] =
+ * (A[f]^-H cw^H)[n], from the factors of the same launch.  A network with one output channel has the backward right-hand side
+ * cw^H gy[b][f] -- the same vector times a scalar -- so A^-H (cw^H gy) = wadj . gy and Recursion's backward
+ * (system.py:420-425 under autograd, between the two gains of reverb.py:117-199 / e8_fdn.py:60-100) needs no solve.
+ * float32, 4 < N <= 16 (fl_solve_fdn_wadj_supported); everything else as fl_solve_fdn_c64 with adjoint = 0. */
+int fl_solve_fdn_wadj_supported(int N);
+int fl_solve_fdn_wadj_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                          long r_sn, long r_sf, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw, int cw_real,
+                          void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* wadj, long wadj_sn,
+                          void* stream);
 int fl_solve_fdn_keep_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
                           long r_sn, long r_sf, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw, int cw_real,
                           void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* LU, void* piv,

@@ -1107,18 +1107,21 @@ def test_scaled_loop_adjoint_from_kept_factors(gpu, N, K):
             cc("a", a, b, (1e-11 if cd == torch.complex128 else 3e-5), max_tol=float("inf"))
 
 
-@pytest.mark.parametrize("N", [9, 12, 13, 16])
+@pytest.mark.parametrize("N", [5, 6, 8, 9, 12, 13, 16])
 @pytest.mark.parametrize("kind", ["damped", "exchanges"])
 def test_fdn_adjoint_from_kept_factors(gpu, N, kind):
-    """fl_solve_fdn_keep_* + fl_solve_kept_adjoint_rank1_* (8 < N <= 16): ops.fdn_core's backward solves A^H x = conj(c) g from
-    the LU factors its forward solve left instead of a second elimination -- output and every gradient against LAPACK autograd
+    """ops.fdn_core's backward system A^H x = c^H g (8 < N <= 16) three ways: x = w g with w = A^-H c^H computed by the FORWARD
+    launch from its own factors (fl_solve_fdn_wadj_c64: float32 default, no solve in the backward pass), a substitution over
+    factors the forward solve kept (fl_solve_fdn_keep_* + fl_solve_kept_adjoint_rank1_*), and a second elimination
+    (fl_solve_fdn_* adjoint) -- output and every gradient against LAPACK autograd
     in float64 on the materialised system (flamo/processor/system.py:420-425 between the two gains), for damped loops (no row
     moves) and loops that exchange rows at every step (the pivot order travels with the factors), odd and even N, batch 1 and
     3, and against the re-factoring route it replaces (ops.KEEP_LU_FDN = False)."""
     from flamo_amd import _lib, ops
     torch.manual_seed(7 * N + (kind == "exchanges"))
     M = 391
-    assert _lib.lib().fl_solve_fdn_keep_tile(N, 0) == 32      # (ops.KEEP_LU_FDN is off by default: measured slower at these sizes)
+    assert _lib.lib().fl_solve_fdn_keep_tile(N, 0) == (32 if N > 8 else 0)      # (ops.KEEP_LU_FDN is off by default: measured slower)
+    assert _lib.lib().fl_solve_fdn_wadj_supported(N) == 1
     for cd, tol in ((torch.complex128, 1e-11), (torch.complex64, 3e-5)):
         rd = torch.float64 if cd == torch.complex128 else torch.float32
         if kind == "damped":
@@ -1144,8 +1147,13 @@ def test_fdn_adjoint_from_kept_factors(gpu, N, kind):
             Yr = (out * cR.to(torch.complex128).squeeze(0)).sum(-1, keepdim=True)
             want = torch.autograd.grad(torch.sum(torch.real(Yr * torch.conj(C64))), ref_in)
             res = {}
-            for keep in (True, False):
-                ops.KEEP_LU_FDN = keep
+            # three routes to A^-H c^H gy: w gy with w from the forward launch (float32 default) / a substitution over kept factors /
+            # a second elimination
+            routes = (("forward", (True, False)), ("kept", (False, True)), ("refactor", (False, False)))
+            if N <= 8:
+                routes = (routes[0], routes[2])          # (factors are kept above 8 channels only)
+            for route, (in_fwd, keep) in routes:
+                ops.FDN_ADJOINT_IN_FORWARD, ops.KEEP_LU_FDN = in_fwd, keep
                 try:
                     dev_in = [b64.to(gpu, rd), c64.to(gpu, rd), l64.to(gpu, cd), U64.to(gpu, cd), r64.to(gpu, cd), X64.to(gpu, cd)]
                     dev_in = [t.requires_grad_(True) for t in dev_in]
@@ -1153,16 +1161,20 @@ def test_fdn_adjoint_from_kept_factors(gpu, N, kind):
                     Y = ops.fdn_core(dev_in[0], dev_in[1], dev_in[2], l2_64.to(gpu, cd), dev_in[3], dev_in[4], dev_in[5])
                     got = torch.autograd.grad(torch.sum(torch.real(Y * torch.conj(C64.to(gpu, cd)))), dev_in)
                     torch.cuda.synchronize()
+                    used = set(ops.kernel_timer.summary())
                 finally:
-                    ops.KEEP_LU_FDN = True
+                    ops.FDN_ADJOINT_IN_FORWARD, ops.KEEP_LU_FDN = True, False
                     ops.kernel_timer.enabled = False
-                res[keep] = [Y.detach()] + list(got)
+                res[route] = [Y.detach()] + list(got)
+                # the forward route runs no adjoint solve at all (float32; float64 keeps the launch)
+                assert ("solve_dud_adj" in used) == (route != "forward" or cd == torch.complex128), (route, used)
             tag = f"fdn_kept/{kind}_N{N}_B{B}_{str(cd)[-3:]}"
             names = ("Y", "g_b", "g_c", "g_l", "g_U", "g_r", "g_X")
-            wants = [Yr.detach()] + [w if w.is_complex() or i in (0, 1) else w for i, w in enumerate(want)]
-            for name, a, w in zip(names, res[True], wants):
-                w = w.real if (not a.is_complex() and w.is_complex()) else w
-                check_close(f"{tag}/{name}", a.cpu().to(w.dtype), w, tol * scale, max_tol=float("inf"))
-            assert torch.equal(res[True][0], res[False][0])              # the same forward kernel, with and without the stores
-            for a, b in zip(res[True][1:], res[False][1:]):               # the two adjoint routes: rounding apart
-                assert relerr(a, b) < tol * scale
+            for route in [r for r in ("forward", "kept") if r in res]:
+                for name, a, w in zip(names, res[route], [Yr.detach()] + list(want)):
+                    w = w.real if (not a.is_complex() and w.is_complex()) else w
+                    check_close(f"{tag}/{route}/{name}", a.cpu().to(w.dtype), w, tol * scale, max_tol=float("inf"))
+            for route in [r for r in ("forward", "kept") if r in res]:
+                assert torch.equal(res[route][0], res["refactor"][0])        # the same forward arithmetic with and without the extras
+                for a, b in zip(res[route][1:], res["refactor"][1:]):         # the adjoint routes: rounding apart
+                    assert relerr(a, b) < tol * scale
