@@ -76,6 +76,10 @@ struct Dud {
     // the lane it was eliminated in: column access is a reduction over the group).  Element (n, f) at wadj[n*wadj_sn + f].
     cx<T>* wadj;
     long wadj_sn;
+    // ... and as an INPUT of the gradient kernel (fl_solve_dud2_grads_w_*): gR[b][n][f] = wadj[n][f] wgy[b][f] is formed where it
+    // is consumed -- the adjoint solution never exists in memory.
+    const cx<T>* wgy;
+    long wgy_sb;
 };
 
 
@@ -1294,7 +1298,14 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
     // s_waitcnt vmcnt(0) at the join, which would serialise every round on the memory latency.
     const int ic = min(i, N - 1), span = f_end - f_begin - 1;
     const long lane_off = (long)ic * s_n + f_begin;
-    const cx<T>* gRp = gR + lane_off;
+    // the adjoint solution: gR[b][i][f] as a tensor, or W[i][f] gy[b][f] formed here (Dud::wgy) -- ONE load path for both (base and
+    // strides selected once; the tensor form multiplies by a constant 1): a branch around the loads would put a wait at its join
+    const bool wmode = d.wadj != nullptr;
+    const cx<T>* gRp = wmode ? d.wadj + (long)ic * d.wadj_sn + f_begin : gR + lane_off;
+    const long g_sb = wmode ? 0 : s_b, g_sk = wmode ? 0 : s_k;
+    const cx<T>* one_g = one_ptr<T>();
+    const cx<T>* gyp = wmode ? d.wgy + f_begin : one_g;
+    const long gy_sb = wmode ? d.wgy_sb : 0, gy_sf = wmode ? 1 : 0;
     const cx<T>* OUTp = OUT + lane_off;
     const cx<T>* one = one_ptr<T>();
     const long l_sf = d.l ? d.l_sf : 0, r_sf = d.r ? d.r_sf : 0;
@@ -1309,7 +1320,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 && NP <= 16) ? 3 : 1) dud
         Ops x;
         const int fl = min(fit * BPI + bl, span);
         const long off = (long)fb * s_b + (long)fk * s_k + fl;
-        x.g = gRp[off];
+        x.g = gRp[(long)fb * g_sb + (long)fk * g_sk + fl] * gyp[(long)fb * gy_sb + (long)fl * gy_sf];
         x.o = OUTp[off];
         x.l = lp[(long)fl * l_sf];
         x.r = rp[(long)fl * r_sf];
@@ -1478,7 +1489,8 @@ template <typename T>
 static int dud_grads_impl(const Dud<T>& d, const void* gR, const void* OUT, long s_b, long s_n, long s_k, int B, int M, int N, int K,
                           void* gl, long gl_sn, void* gr, long gr_sn, void* partU, void* gU, void* stream, void* gR0 = nullptr,
                           DudSide<T> side = DudSide<T>{nullptr, nullptr, 0, 0, 0, nullptr}) {
-    FL_REQUIRE(d.U && gR && OUT, "solve_dud_grads: null pointer");
+    FL_REQUIRE(d.U && (gR || (d.wadj && d.wgy)) && OUT, "solve_dud_grads: null pointer");
+    FL_REQUIRE(!d.wadj || K == 1, "solve_dud_grads: the rank-one adjoint solution has one column per batch item");
     FL_REQUIRE(B >= 0 && M >= 0 && N > 0 && K > 0, "solve_dud_grads: bad sizes");
     FL_REQUIRE((partU == nullptr) == (gU == nullptr), "solve_dud_grads: partU and gU go together");
     FL_REQUIRE((!gl || (d.l && d.l_sf)) && (!gr || (d.r && d.r_sf)), "solve_dud_grads: gl / gr are per-bin gradients of per-bin factors");
@@ -1781,6 +1793,20 @@ int fl_solve_dud2_grads_c128(const void* l, long l_sn, long l_sf, const void* l2
                      (const cx<double>*)l2, l2_sn, l2_sf, 0};
     DudSide<double> side = {(const cx<double>*)sx, (const cx<double>*)sy, sx_b, sy_b, sx ? 1 : 0, (double*)g_side_real};
     return dud_grads_impl<double>(d, gR, OUT, s_b, s_n, s_k, B, M, N, K, gl, gl_sn, gr, gr_sn, partU, gU, stream, gR0, side);
+}
+// the same with the adjoint solution given as gR[b][n][f] = W[n][f] gy[b][f] (W from fl_solve_fdn_wadj_c64), formed in the kernel
+int fl_solve_dud2_grads_w_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                              long r_sn, long r_sf, const void* W, long w_sn, const void* gy, long gy_sb, const void* OUT, long s_b,
+                              long s_n, long s_k, int B, int M, int N, void* gl, long gl_sn, void* gr, long gr_sn, void* partU,
+                              void* gU, void* gR0, const void* sx, long sx_b, const void* sy, long sy_b, void* g_side_real,
+                              void* stream) {
+    FL_REQUIRE(l2 && W && gy, "solve_dud2_grads_w: null pointer");
+    FL_REQUIRE((sx == nullptr) == (sy == nullptr) && (!sx || (partU && gU)), "solve_dud2_grads_w: side reductions need sx, sy and the partial buffers");
+    Dud<float> d = {(const cx<float>*)l, l_sn, l_sf, (const cx<float>*)U, (const cx<float>*)r, r_sn, r_sf,
+                    (const cx<float>*)l2, l2_sn, l2_sf, 0};
+    d.wadj = (cx<float>*)const_cast<void*>(W); d.wadj_sn = w_sn; d.wgy = (const cx<float>*)gy; d.wgy_sb = gy_sb;
+    DudSide<float> side = {(const cx<float>*)sx, (const cx<float>*)sy, sx_b, sy_b, sx ? 1 : 0, (float*)g_side_real};
+    return dud_grads_impl<float>(d, nullptr, OUT, s_b, s_n, s_k, B, M, N, 1, gl, gl_sn, gr, gr_sn, partU, gU, stream, gR0, side);
 }
 /* fl_solve_dud2 with the right-hand side built in the kernel, R_i = rv_i rs (rv conjugated for the adjoint system; scaled by
  * l2 for the forward one), and -- forward system, cz non-NULL -- the contracted output z = sum_i cw_i OUT_i beside OUT */

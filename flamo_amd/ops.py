@@ -1682,8 +1682,9 @@ class _FdnCore(torch.autograd.Function):
         rp = saved.pop(0) if ctx.have[1] else None
         l2p, Uc, OUT, Xp, bc, cc, *kept = saved
         gyp = to_planar(gy.resolve_conj())
-        if ctx.has_wadj:  # A^-H c^H gy = w gy with w from the forward launch: a per-bin scaling, no solve (W read as an (M, N, 1) response)
-            gR = _mimo_launch(kept[-1][0].unsqueeze(-1), True, False, False, gyp)
+        Wadj = kept[-1] if ctx.has_wadj else None
+        if Wadj is not None:   # A^-H c^H gy = w gy with w from the forward launch: formed inside the gradient kernel, no solve, no tensor
+            gR = None
         elif kept:        # A^-H c^H gy from the forward solve's factors: a substitution, no second elimination
             gR = _solve_fdn_kept_adjoint_launch(kept[0], kept[1], ctx.kept_tile, cc, gyp, Uc.shape[0])
         elif ctx.in_solve:
@@ -1719,10 +1720,18 @@ class _FdnCore(torch.autograd.Function):
             fn = L.fl_solve_dud2_grads_c64 if real == torch.float32 else L.fl_solve_dud2_grads_c128
             ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
             with kernel_timer.span("solve_dud_grads"):
-                _lib.check(fn(lptr, l_sn, l_sf, l2ptr, l2_sn, l2_sf, Uc.data_ptr(), rptr, r_sn, r_sf, gR.data_ptr(), OUT.data_ptr(),
-                              s_b, s_n, s_k, B, M, N, K, ptr(gl), _pitch(M), ptr(gr), _pitch(M), ptr(part), ptr(gUS), ptr(gR0),
-                              Xp.data_ptr() if side else None, xs_b, gyp.data_ptr() if side else None, gs_b, ptr(side_real),
-                              _stream()), "solve_dud2_grads")
+                if Wadj is not None:
+                    _, _, _, _, _, w_sn, _ = _bnk(Wadj)
+                    _lib.check(L.fl_solve_dud2_grads_w_c64(lptr, l_sn, l_sf, l2ptr, l2_sn, l2_sf, Uc.data_ptr(), rptr, r_sn, r_sf,
+                                                           Wadj.data_ptr(), w_sn, gyp.data_ptr(), gs_b, OUT.data_ptr(), s_b, s_n, s_k, B, M, N,
+                                                           ptr(gl), _pitch(M), ptr(gr), _pitch(M), ptr(part), ptr(gUS), ptr(gR0),
+                                                           Xp.data_ptr() if side else None, xs_b, gyp.data_ptr() if side else None, gs_b,
+                                                           ptr(side_real), _stream()), "solve_dud2_grads_w")
+                else:
+                    _lib.check(fn(lptr, l_sn, l_sf, l2ptr, l2_sn, l2_sf, Uc.data_ptr(), rptr, r_sn, r_sf, gR.data_ptr(), OUT.data_ptr(),
+                                  s_b, s_n, s_k, B, M, N, K, ptr(gl), _pitch(M), ptr(gr), _pitch(M), ptr(part), ptr(gUS), ptr(gR0),
+                                  Xp.data_ptr() if side else None, xs_b, gyp.data_ptr() if side else None, gs_b, ptr(side_real),
+                                  _stream()), "solve_dud2_grads")
             if need_U:
                 gU = gUS[:N * N].view(N, N)
             if side:
