@@ -148,7 +148,10 @@ _SIGNATURES = {
     "fl_solve_fdn_wadj_supported": (_i, [_i]),
     "fl_solve_dud2_grads_w_c64": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _vp, _l, _vp, _l, _l, _l, _i, _i, _i, _vp, _l, _vp, _l,
                                        _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp]),
+    "fl_solve_dud2_grads_w_c128": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _l, _vp, _l, _vp, _l, _l, _l, _i, _i, _i, _vp, _l, _vp, _l,
+                                       _vp, _vp, _vp, _vp, _l, _vp, _l, _vp, _vp]),
     "fl_solve_fdn_wadj_c64": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _l, _l, _i, _i, _i, _vp, _l, _vp]),
+    "fl_solve_fdn_wadj_c128": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _l, _l, _i, _i, _i, _vp, _l, _vp]),
     "fl_solve_fdn_keep_c64": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _l, _l, _i, _i, _i, _vp, _vp, _vp]),
     "fl_solve_fdn_keep_c128": (_i, [_vp, _l, _l, _vp, _l, _l, _vp, _vp, _l, _l, _vp, _i, _vp, _l, _vp, _i, _vp, _l, _vp, _l, _l, _l, _i, _i, _i, _vp, _vp, _vp]),
     "fl_solve_kept_adjoint_rank1_c64": (_i, [_vp, _vp, _i, _vp, _i, _vp, _l, _vp, _l, _l, _l, _i, _i, _i, _vp]),

@@ -502,7 +502,7 @@ template <typename T> __device__ inline const cx<T>* one_ptr() {
 // group -- a 32-lane group has no one-instruction broadcast -- and every broadcast of a pivot-row element now
 // feeds two row updates; which slot holds the pivot (K / LANES) and which slots still have rows below it are
 // known at compile time, so finished slots drop out of the update loops altogether.
-template <typename T, int LANES, int RPL>
+template <typename T, int LANES, int RPL, bool WADJ = false>
 __global__ void __launch_bounds__(256) solve_inplace_kernel(
     const cx<T>* __restrict__ P, long p_pitch, Dud<T> dud, int one_minus, int adjoint,
     const cx<T>* __restrict__ R, long rs_b, long rs_n, long rs_k,
@@ -814,14 +814,17 @@ __global__ void __launch_bounds__(256) solve_inplace_kernel(
     // U^H z = cw^H, L^H u = z, w[orig[p]] = u[p].  Lane (slot s, lane g) holds row p = s LANES + g of the factors, i.e. COLUMN p of
     // U^H and L^H: unknown k is a dot product over the lanes -- sum_p conj(row_p[k]) z_p, the not-yet-known entries still zero, so
     // no masks -- one DPP reduction per unknown.
-    constexpr bool kWadj = sizeof(T) == 4 && (LANES == 8 || LANES == 4) && RPL == 2;      // 4 < N <= 16
+    // (an instantiation of its own, WADJ: its extra registers take the float64 kernel from two wavefronts per SIMD to one, which the
+    // launches that do not ask for w must not pay)
+    constexpr bool kWadj = WADJ && (LANES == 8 || LANES == 4) && RPL == 2;      // 4 < N <= 16
     if constexpr (kWadj) {
         if (dud.wadj) {       // (uniform)
             cx<T> v[RPL], z[RPL], u[RPL];
 #pragma unroll
             for (int s = 0; s < RPL; ++s) {
                 const bool real_row = s * LANES + gi < N;
-                v[s] = real_row ? conj(pre_cw[s]) : cx<T>(0, 0);
+                const cx<T> cwv = kPrefetchRhs ? pre_cw[s] : gain_at<T>(dud.cw, dud.cw_real, real_row ? s * LANES + gi : 0);
+                v[s] = real_row ? conj(cwv) : cx<T>(0, 0);
                 z[s] = u[s] = cx<T>(0, 0);
             }
             static_for<0, NMAX>([&](auto kc) {          // U^H z = cw^H, ascending
@@ -957,6 +960,13 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
             // element feeds two row updates: 86 -> 73 us at N = 16 (c64), 131 -> 108 us (c128), 82 -> 63 us at N = 9
             // (tools/dbg/archive/solve_rpl2_16.py; 4 lanes x 4 rows: 80 us, and it spills).  fl_debug_set_solve_variant(4): the
             // one-row-per-lane kernels.
+            if (!P && g_solve_rpl2_16 != 1 && dud.wadj) {
+                hipLaunchKernelGGL((solve_inplace_kernel<T, 8, 2, true>), dim3(cdiv_i(M, 32)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
+                                   dud, one_minus, adjoint | (g_solve_thr << 8) | (g_solve_noprefetch << 16), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
+                                   os_b, os_n, os_k, B, M, N, K);
+                FL_CHECK_LAUNCH("solve");
+                return FL_OK;
+            }
             if (!P && g_solve_rpl2_16 != 1) {
                 hipLaunchKernelGGL((solve_inplace_kernel<T, 8, 2>), dim3(cdiv_i(M, 32)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
                                    dud, one_minus, adjoint | (g_solve_thr << 8) | (g_solve_noprefetch << 16), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
@@ -966,6 +976,13 @@ static int launch_solve(const void* P, long p_pitch, const Dud<T>& dud, int one_
             }
         }
         if constexpr (NMAX == 8) {
+            if (!P && g_solve_rpl2_16 != 1 && dud.wadj) {
+                hipLaunchKernelGGL((solve_inplace_kernel<T, 4, 2, true>), dim3(cdiv_i(M, 64)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
+                                   dud, one_minus, adjoint | (g_solve_thr << 8) | (g_solve_noprefetch << 16), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
+                                   os_b, os_n, os_k, B, M, N, K);
+                FL_CHECK_LAUNCH("solve");
+                return FL_OK;
+            }
             if (!P && g_solve_rpl2_16 != 1) {      // N in (4, 8] on 4 lanes x 2 rows (16 bins per wavefront): 29 -> 23 us at N = 8
                 hipLaunchKernelGGL((solve_inplace_kernel<T, 4, 2>), dim3(cdiv_i(M, 64)), dim3(256), 0, st, (const cx<T>*)P, p_pitch,
                                    dud, one_minus, adjoint | (g_solve_thr << 8) | (g_solve_noprefetch << 16), (const cx<T>*)R, rs_b, rs_n, rs_k, (cx<T>*)OUT,
@@ -1667,6 +1684,30 @@ int fl_solve_fdn_wadj_c64(const void* l, long l_sn, long l_sf, const void* l2, l
                     (const cx<float>*)l2, l2_sn, l2_sf, 1, rv, (const cx<float>*)rs, rs_sb, cw, (cx<float>*)cz, cz_sb, rv_real, cw_real};
     d.wadj = (cx<float>*)wadj; d.wadj_sn = wadj_sn;
     return solve_impl<float>(nullptr, 0, d, 1, 0, nullptr, 0, 0, 0, OUT, os_b, os_n, os_k, B, M, N, 1, stream);
+}
+int fl_solve_fdn_wadj_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                           long r_sn, long r_sf, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw, int cw_real,
+                           void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* wadj, long wadj_sn,
+                           void* stream) {
+    FL_REQUIRE(U && l2 && rv && rs && cw && wadj, "solve_fdn_wadj: null pointer");
+    FL_REQUIRE(fl_solve_fdn_wadj_supported(N), "solve_fdn_wadj: 4 < N <= 16 on the default kernels (fl_solve_fdn_wadj_supported)");
+    Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf,
+                     (const cx<double>*)l2, l2_sn, l2_sf, 1, rv, (const cx<double>*)rs, rs_sb, cw, (cx<double>*)cz, cz_sb, rv_real, cw_real};
+    d.wadj = (cx<double>*)wadj; d.wadj_sn = wadj_sn;
+    return solve_impl<double>(nullptr, 0, d, 1, 0, nullptr, 0, 0, 0, OUT, os_b, os_n, os_k, B, M, N, 1, stream);
+}
+int fl_solve_dud2_grads_w_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                               long r_sn, long r_sf, const void* W, long w_sn, const void* gy, long gy_sb, const void* OUT, long s_b,
+                               long s_n, long s_k, int B, int M, int N, void* gl, long gl_sn, void* gr, long gr_sn, void* partU,
+                               void* gU, void* gR0, const void* sx, long sx_b, const void* sy, long sy_b, void* g_side_real,
+                               void* stream) {
+    FL_REQUIRE(l2 && W && gy, "solve_dud2_grads_w: null pointer");
+    FL_REQUIRE((sx == nullptr) == (sy == nullptr) && (!sx || (partU && gU)), "solve_dud2_grads_w: side reductions need sx, sy and the partial buffers");
+    Dud<double> d = {(const cx<double>*)l, l_sn, l_sf, (const cx<double>*)U, (const cx<double>*)r, r_sn, r_sf,
+                     (const cx<double>*)l2, l2_sn, l2_sf, 0};
+    d.wadj = (cx<double>*)const_cast<void*>(W); d.wadj_sn = w_sn; d.wgy = (const cx<double>*)gy; d.wgy_sb = gy_sb;
+    DudSide<double> side = {(const cx<double>*)sx, (const cx<double>*)sy, sx_b, sy_b, sx ? 1 : 0, (double*)g_side_real};
+    return dud_grads_impl<double>(d, nullptr, OUT, s_b, s_n, s_k, B, M, N, 1, gl, gl_sn, gr, gr_sn, partU, gU, stream, gR0, side);
 }
 // the FDN form (fl_solve_fdn_*) with kept factors: 8 < N <= 16 on the two-rows-per-lane kernel (its workgroup's 32 bins are a tile)
 int fl_solve_fdn_keep_tile(int N, int f64) {

@@ -1571,6 +1571,7 @@ KEEP_LU_FDN = False
 # w[f] gy[b][f] with w = A^-H c^H formed by the FORWARD launch from its own factors (fl_solve_fdn_wadj_c64; float32, 4 < N <= 16) --
 # the backward pass then runs no solve.  False: the adjoint system is factored and solved by a launch of its own.
 FDN_ADJOINT_IN_FORWARD = True
+FDN_ADJOINT_IN_FORWARD_F64 = True      # (float64: the forward kernel with w runs at one wavefront per SIMD -- still ahead of a second solve)
 
 
 def _solve_fdn_launch(l, l2, U, r, adjoint, gain, sig, cw, keep=False, wadj=False):
@@ -1589,15 +1590,16 @@ def _solve_fdn_launch(l, l2, U, r, adjoint, gain, sig, cw, keep=False, wadj=Fals
     lp, l_sn, l_sf = _diag_args(l)
     l2p, l2_sn, l2_sf = _diag_args(l2)
     rp, r_sn, r_sf = _diag_args(r)
-    if wadj:        # forward, float32: (OUT, z, W) with W (1, M, N) planar = A^-H cw^H
-        assert not adjoint and cw is not None and real == torch.float32
+    if wadj:        # forward: (OUT, z, W) with W (1, M, N) planar = A^-H cw^H
+        assert not adjoint and cw is not None
         W = _empty_planar((1, M, N), sig.dtype, sig.device)
         _, _, _, _, _, ws_n, _ = _bnk(W)
+        fnw = L.fl_solve_fdn_wadj_c64 if real == torch.float32 else L.fl_solve_fdn_wadj_c128
         with kernel_timer.span("solve_dud"):
-            _lib.check(L.fl_solve_fdn_wadj_c64(lp, l_sn, l_sf, l2p, l2_sn, l2_sf, U.data_ptr(), rp, r_sn, r_sf, gain.data_ptr(),
-                                               int(not gain.is_complex()), sig.data_ptr(), ss_b, cw.data_ptr(), int(not cw.is_complex()),
-                                               z.data_ptr(), zs_b, OUT.data_ptr(), os_b, os_n, os_k, B, M, N, W.data_ptr(), ws_n,
-                                               _stream()), "solve_fdn_wadj")
+            _lib.check(fnw(lp, l_sn, l_sf, l2p, l2_sn, l2_sf, U.data_ptr(), rp, r_sn, r_sf, gain.data_ptr(),
+                           int(not gain.is_complex()), sig.data_ptr(), ss_b, cw.data_ptr(), int(not cw.is_complex()),
+                           z.data_ptr(), zs_b, OUT.data_ptr(), os_b, os_n, os_k, B, M, N, W.data_ptr(), ws_n,
+                           _stream()), "solve_fdn_wadj")
         return OUT, z, W
     if keep:
         assert not adjoint
@@ -1656,8 +1658,8 @@ class _FdnCore(torch.autograd.Function):
         ctx.in_solve = _fdn_in_solve(_rdtype(Xp), N)
         kept = None
         Wadj = None
-        if ctx.in_solve and FDN_ADJOINT_IN_FORWARD and any(ctx.needs_input_grad) and _rdtype(Xp) == torch.float32 and \
-                _lib.lib().fl_solve_fdn_wadj_supported(N):
+        if ctx.in_solve and FDN_ADJOINT_IN_FORWARD and any(ctx.needs_input_grad) and \
+                (_rdtype(Xp) == torch.float32 or FDN_ADJOINT_IN_FORWARD_F64) and _lib.lib().fl_solve_fdn_wadj_supported(N):
             OUT, y, Wadj = _solve_fdn_launch(lp, l2p, Uc, rp, False, bc, Xp, cc, wadj=True)
         elif ctx.in_solve and KEEP_LU_FDN and any(ctx.needs_input_grad) and \
                 _lib.lib().fl_solve_fdn_keep_tile(N, int(_rdtype(Xp) == torch.float64)) > 0:
@@ -1722,11 +1724,12 @@ class _FdnCore(torch.autograd.Function):
             with kernel_timer.span("solve_dud_grads"):
                 if Wadj is not None:
                     _, _, _, _, _, w_sn, _ = _bnk(Wadj)
-                    _lib.check(L.fl_solve_dud2_grads_w_c64(lptr, l_sn, l_sf, l2ptr, l2_sn, l2_sf, Uc.data_ptr(), rptr, r_sn, r_sf,
-                                                           Wadj.data_ptr(), w_sn, gyp.data_ptr(), gs_b, OUT.data_ptr(), s_b, s_n, s_k, B, M, N,
-                                                           ptr(gl), _pitch(M), ptr(gr), _pitch(M), ptr(part), ptr(gUS), ptr(gR0),
-                                                           Xp.data_ptr() if side else None, xs_b, gyp.data_ptr() if side else None, gs_b,
-                                                           ptr(side_real), _stream()), "solve_dud2_grads_w")
+                    fnw = L.fl_solve_dud2_grads_w_c64 if real == torch.float32 else L.fl_solve_dud2_grads_w_c128
+                    _lib.check(fnw(lptr, l_sn, l_sf, l2ptr, l2_sn, l2_sf, Uc.data_ptr(), rptr, r_sn, r_sf,
+                                   Wadj.data_ptr(), w_sn, gyp.data_ptr(), gs_b, OUT.data_ptr(), s_b, s_n, s_k, B, M, N,
+                                   ptr(gl), _pitch(M), ptr(gr), _pitch(M), ptr(part), ptr(gUS), ptr(gR0),
+                                   Xp.data_ptr() if side else None, xs_b, gyp.data_ptr() if side else None, gs_b,
+                                   ptr(side_real), _stream()), "solve_dud2_grads_w")
                 else:
                     _lib.check(fn(lptr, l_sn, l_sf, l2ptr, l2_sn, l2_sf, Uc.data_ptr(), rptr, r_sn, r_sf, gR.data_ptr(), OUT.data_ptr(),
                                   s_b, s_n, s_k, B, M, N, K, ptr(gl), _pitch(M), ptr(gr), _pitch(M), ptr(part), ptr(gUS), ptr(gR0),

@@ -560,7 +560,7 @@ int fl_solve_fdn_keep_tile(int N, int f64);
  * (A[f]^-H cw^H)[n], from the factors of the same launch.  A network with one output channel has the backward right-hand side
  * cw^H gy[b][f] -- the same vector times a scalar -- so A^-H (cw^H gy) = wadj . gy and Recursion's backward
  * (system.py:420-425 under autograd, between the two gains of reverb.py:117-199 / e8_fdn.py:60-100) needs no solve.
- * float32, 4 < N <= 16 (fl_solve_fdn_wadj_supported); everything else as fl_solve_fdn_c64 with adjoint = 0. */
+ * 4 < N <= 16 (fl_solve_fdn_wadj_supported); everything else as fl_solve_fdn_* with adjoint = 0. */
 int fl_solve_fdn_wadj_supported(int N);
 /* fl_solve_dud2_grads_c64 with the adjoint solution given in that form: gR[b][n][f] = W[n*w_sn + f] gy[b*gy_sb + f], formed where
  * the kernel consumes it (one column per batch item). */
@@ -569,7 +569,16 @@ int fl_solve_dud2_grads_w_c64(const void* l, long l_sn, long l_sf, const void* l
                               long s_n, long s_k, int B, int M, int N, void* gl, long gl_sn, void* gr, long gr_sn, void* partU,
                               void* gU, void* gR0, const void* sx, long sx_b, const void* sy, long sy_b, void* g_side_real,
                               void* stream);
+int fl_solve_dud2_grads_w_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                              long r_sn, long r_sf, const void* W, long w_sn, const void* gy, long gy_sb, const void* OUT, long s_b,
+                              long s_n, long s_k, int B, int M, int N, void* gl, long gl_sn, void* gr, long gr_sn, void* partU,
+                              void* gU, void* gR0, const void* sx, long sx_b, const void* sy, long sy_b, void* g_side_real,
+                              void* stream);
 int fl_solve_fdn_wadj_c64(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
+                          long r_sn, long r_sf, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw, int cw_real,
+                          void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* wadj, long wadj_sn,
+                          void* stream);
+int fl_solve_fdn_wadj_c128(const void* l, long l_sn, long l_sf, const void* l2, long l2_sn, long l2_sf, const void* U, const void* r,
                           long r_sn, long r_sf, const void* rv, int rv_real, const void* rs, long rs_sb, const void* cw, int cw_real,
                           void* cz, long cz_sb, void* OUT, long os_b, long os_n, long os_k, int B, int M, int N, void* wadj, long wadj_sn,
                           void* stream);

@@ -1166,8 +1166,8 @@ def test_fdn_adjoint_from_kept_factors(gpu, N, kind):
                     ops.FDN_ADJOINT_IN_FORWARD, ops.KEEP_LU_FDN = True, False
                     ops.kernel_timer.enabled = False
                 res[route] = [Y.detach()] + list(got)
-                # the forward route runs no adjoint solve at all (float32; float64 keeps the launch)
-                assert ("solve_dud_adj" in used) == (route != "forward" or cd == torch.complex128), (route, used)
+                # the forward route runs no adjoint solve at all
+                assert ("solve_dud_adj" in used) == (route != "forward"), (route, used)
             tag = f"fdn_kept/{kind}_N{N}_B{B}_{str(cd)[-3:]}"
             names = ("Y", "g_b", "g_c", "g_l", "g_U", "g_r", "g_X")
             for route in [r for r in ("forward", "kept") if r in res]:
@@ -1175,6 +1175,8 @@ def test_fdn_adjoint_from_kept_factors(gpu, N, kind):
                     w = w.real if (not a.is_complex() and w.is_complex()) else w
                     check_close(f"{tag}/{route}/{name}", a.cpu().to(w.dtype), w, tol * scale, max_tol=float("inf"))
             for route in [r for r in ("forward", "kept") if r in res]:
-                assert torch.equal(res[route][0], res["refactor"][0])        # the same forward arithmetic with and without the extras
-                for a, b in zip(res[route][1:], res["refactor"][1:]):         # the adjoint routes: rounding apart
+                # ("kept": the same forward kernel with the factor stores -- identical; "forward": an instantiation of its own)
+                if route == "kept":
+                    assert torch.equal(res[route][0], res["refactor"][0])
+                for a, b in zip(res[route], res["refactor"]):                # rounding apart
                     assert relerr(a, b) < tol * scale

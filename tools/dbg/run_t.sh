@@ -1,3 +1,2 @@
 cd /root/repo
-timeout 1800 python -m pytest tests/test_hip_kernels.py -q -m gpu -x -k "kept_factors or fdn" 2>&1 | grep -E "passed|failed|^FAILED|^E  " | head
-bash tools/dbg/run_fdn.sh 2>&1 | grep -E "passed|failed|colorless|workload|solve|dud|mimo_full" | head -12
+timeout 1800 python -m pytest tests/test_hip_kernels.py tests/test_hip_parity.py tests/test_round2_parity.py tests/test_round3_parity.py -q -m gpu 2>&1 | grep -E "passed|failed|^FAILED|^E  " | head
