@@ -204,6 +204,7 @@ _SIGNATURES = {
     "fl_launch_pair_begin": (_i, []),
     "fl_launch_pair_pending": (_i, []),
     "fl_debug_launch_pair_count": (_l, []),
+    "fl_debug_set_pair_stamps": (_i, [_vp]),
     "fl_launch_pair_flush": (_i, [_vp]),
     "fl_set_stream_policy": (_i, [C.c_uint, _i]),
     "fl_hbm_probe": (_i, [_i, _vp, _vp, _sz, _i, _i, _vp, _vp]),

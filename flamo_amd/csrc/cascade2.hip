@@ -574,12 +574,17 @@ static int g_lanes_fwd = 1;    // ... of the forward kernel alone
 template <int NIW>
 __global__ void __launch_bounds__(256) sos_response_rc_ba_kernel(RcBaArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long* dbg = A.dbg ? A.dbg + 8 * ((size_t)blockIdx.y * 4096 + blockIdx.x) : nullptr;      // (tuning: start / end of the workgroup)
+    if (dbg && threadIdx.x == 0) dbg[4] = (long long)__builtin_amdgcn_s_memrealtime();
     rc_ba_body<NIW>(A, (int)blockIdx.x, (int)blockIdx.y, smem);
+    if (dbg && threadIdx.x == 0) dbg[5] = (long long)__builtin_amdgcn_s_memrealtime();
 }
 
 // host side of the kernel above (called by response.hip: rc_impl); returns FL_ERR_UNSUPPORTED (no error text) when the shape is
 // not taken, so that the caller falls back to the first generation
-int rc_ba_launch_now(const PendingRc& p, hipStream_t st) {
+int rc_ba_launch_now(const PendingRc& p0, hipStream_t st) {
+    PendingRc p = p0;
+    p.args.dbg = pair_dbg() && p.gx <= 4096 ? pair_dbg() + 4 * 8192 : nullptr;
     const dim3 grid(p.gx, p.gy);
     if (p.niw == 2) hipLaunchKernelGGL((sos_response_rc_ba_kernel<2>), grid, dim3(256), p.lds, st, p.args);
     else if (p.niw == 4) hipLaunchKernelGGL((sos_response_rc_ba_kernel<4>), grid, dim3(256), p.lds, st, p.args);

@@ -20,6 +20,7 @@ struct PendingRc {
     size_t lds;
 };
 
+long long* pair_dbg();                              // fl_debug_set_pair_stamps' buffer, or null
 bool pair_mode();                                   // this thread is between begin and flush
 void pending_rc_put(const PendingRc& p);
 bool pending_rc_take(PendingRc& out);               // true (and the slot is cleared) when a launch was recorded

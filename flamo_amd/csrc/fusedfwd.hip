@@ -16,25 +16,38 @@ using namespace sp32;
 // response's wavefronts on every SIMD while they last (one response workgroup per CU is one wavefront per SIMD: its dependent
 // packed chains then issue at a fraction of the rate).
 template <int A, int B, int VT, int RG, bool PLAIN, int NIW>
-__global__ void __launch_bounds__(256, 5) cols_fwd_rc_kernel(ColsArgs a, RcBaArgs r, int n_mix, int n_rc, int rc_gx) {
+__global__ void __launch_bounds__(256, 5) cols_fwd_rc_kernel(ColsArgs a, RcBaArgs r, int n_mix, int n_rc, int rc_gx, long long* dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int i = blockIdx.x;
+    int role = 0;
+    if (dbg && threadIdx.x == 0) dbg[4 * (size_t)i] = (long long)__builtin_amdgcn_s_memrealtime();
     if (i >= n_mix) {
         spec_cols_fwd_body<A, B, VT, RG, PLAIN>(a, i - n_rc, smem);
-        return;
+    } else {
+        const int before = (int)(((long)i * n_rc) / n_mix), after = (int)(((long)(i + 1) * n_rc) / n_mix);
+        if (after > before) {
+            role = 1;
+            rc_ba_body<NIW>(r, before % rc_gx, before / rc_gx, smem);
+        } else {
+            spec_cols_fwd_body<A, B, VT, RG, PLAIN>(a, i - before, smem);
+        }
     }
-    const int before = (int)(((long)i * n_rc) / n_mix), after = (int)(((long)(i + 1) * n_rc) / n_mix);
-    if (after > before) rc_ba_body<NIW>(r, before % rc_gx, before / rc_gx, smem);
-    else spec_cols_fwd_body<A, B, VT, RG, PLAIN>(a, i - before, smem);
+    if (dbg && threadIdx.x == 0) {      // (tuning, fl_debug_set_pair_stamps: start, end, role, HW_ID | XCC_ID << 32 of every workgroup)
+        dbg[4 * (size_t)i + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+        dbg[4 * (size_t)i + 2] = role;
+        dbg[4 * (size_t)i + 3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
 }
 
 static thread_local bool t_pair_mode = false, t_have = false;
 static thread_local PendingRc t_pending;
+static long long* g_pair_dbg = nullptr;      // fl_debug_set_pair_stamps
 static long g_pair_launches = 0;      // grids issued with both roles (tests check that the path under test is this one)
 // response workgroups per column-pass workgroup in the mixed part of the grid, in percent of the even spread's ratio (100)
 static int g_pair_density = [] { const char* e = getenv("FLAMO_PAIR_DENSITY"); return e ? atoi(e) : 100; }();
 static int g_pair_enabled = [] { const char* e = getenv("FLAMO_LAUNCH_PAIR"); return e ? atoi(e) : 1; }();
 
+long long* pair_dbg() { return g_pair_dbg; }
 bool pair_mode() { return t_pair_mode && g_pair_enabled; }
 void pending_rc_put(const PendingRc& p) {
     t_pending = p;
@@ -60,9 +73,11 @@ int fused_cols_rc_launch(const ColsArgs& a, unsigned n_cols, const PendingRc& rc
     long n_mix = n_rc + (long)n_cols * 100 / (g_pair_density > 0 ? g_pair_density : 100);
     if (n_mix > total) n_mix = total;
     if (n_mix < n_rc) n_mix = n_rc;
+    RcBaArgs rargs = rc.args;
+    rargs.dbg = g_pair_dbg ? g_pair_dbg + 4 * 8192 : nullptr;      // (phase stamps of the response role behind the per-workgroup records)
 #define FL_PAIR(PLAIN_, NIW_)                                                                                          \
-    hipLaunchKernelGGL((cols_fwd_rc_kernel<A, B, 16, 1, PLAIN_, NIW_>), dim3((unsigned)total), dim3(256), lds, st, a, rc.args, \
-                       (int)n_mix, (int)n_rc, rc.gx)
+    hipLaunchKernelGGL((cols_fwd_rc_kernel<A, B, 16, 1, PLAIN_, NIW_>), dim3((unsigned)total), dim3(256), lds, st, a, rargs, \
+                       (int)n_mix, (int)n_rc, rc.gx, g_pair_dbg)
     if (plain) {
         if (rc.niw == 8) FL_PAIR(true, 8);
         else FL_PAIR(true, 4);
@@ -91,6 +106,11 @@ int fl_launch_pair_begin(void) {
 int fl_launch_pair_pending(void) { return t_have ? 1 : 0; }
 
 long fl_debug_launch_pair_count(void) { return g_pair_launches; }
+
+int fl_debug_set_pair_stamps(void* buf) {
+    g_pair_dbg = (long long*)buf;
+    return FL_OK;
+}
 
 int fl_launch_pair_flush(void* stream) {
     t_pair_mode = false;

@@ -93,18 +93,39 @@ __device__ inline double geq_linear_gain(const void* gain, int in_kind, int idx,
     return fabs(v);
 }
 
-// one section of the equaliser: band `band` of channel pair idx - band * C (idx = band * C + c), taps into bb[3], aa[3]
-__device__ inline void geq_section_of(const void* __restrict__ gain, int in_kind, int idx, int band, int nb,
-                                      const double* __restrict__ k, double* bb, double* aa) {
-    double raw;
-    const double g = geq_linear_gain(gain, in_kind, idx, &raw);
+// raw command value of (band, channel pair) idx, as stored (in_kind as above) -- the load alone, so that a kernel can request it
+// together with its other operands
+__device__ inline double geq_raw_gain(const void* gain, int in_kind, int idx) {
+    return (in_kind == 2 || in_kind == 4) ? (double)reinterpret_cast<const float*>(gain)[idx]
+                                          : reinterpret_cast<const double*>(gain)[idx];
+}
+// ... and the linear gain from it (geq_linear_gain's arithmetic)
+__device__ inline double geq_gain_of_raw(double v, int in_kind) {
+    if (in_kind == 0) return pow(10.0, v / 20.0);
+    if (in_kind >= 3) return 1.0 / (1.0 + exp(-v));
+    return fabs(v);
+}
+// the two band constants a section's design reads: shelves (t2, st q), peaking bands (t, c); band 0: none (a valid element)
+__device__ inline void geq_band_const_idx(int band, int nb, int* ia, int* ib) {
+    if (band == 1 || band == nb - 1) {
+        const int i = (band == 1) ? 0 : 1;
+        *ia = 2 + i; *ib = 4 + i;
+    } else if (band == 0) {
+        *ia = 0; *ib = 1;
+    } else {
+        *ia = 6 + band - 2; *ib = 6 + (nb - 3) + band - 2;
+    }
+}
+// one section of the equaliser from its linear gain g and its two band constants (ka, kb), taps into bb[3], aa[3]
+__device__ inline void geq_section_vals(double g, int band, int nb, double ka, double kb, double* bb, double* aa) {
     double b0, b1, b2, a0, a1, a2;
     if (band == 0) {
         b0 = f32r(g); b1 = 0; b2 = 0; a0 = 1; a1 = 0; a2 = 0;
     } else if (band == 1 || band == nb - 1) {
-        const int i = (band == 1) ? 0 : 1;
-        const double t2 = k[2 + i], stq = k[4 + i];
-        const double u = sqrt(g), q = pow(g, 0.25);
+        const double t2 = ka, stq = kb;
+        // (g^(1/4) as the root of the root: two correctly rounded square roots, 0.75 ulp -- ocml's pow is ~500 float64
+        // instructions, which inside the launch pair were a third of a response workgroup's life)
+        const double u = sqrt(g), q = sqrt(u);
         const double p0 = f32r(u * t2 + stq * q + 1), p1 = f32r(2 * u * t2 - 2), p2 = f32r(u * t2 - stq * q + 1);
         const double d0 = f32r(u + stq * q + t2), d1 = f32r(2 * t2 - 2 * u), d2 = f32r(u - stq * q + t2);
         const float uf = (float)u, gf = (float)g;
@@ -115,14 +136,22 @@ __device__ inline void geq_section_of(const void* __restrict__ gain, int in_kind
             b0 = (float)d0 * gf; b1 = (float)d1 * gf; b2 = (float)d2 * gf; a0 = s0; a1 = s1; a2 = s2;
         }
     } else {
-        const int np = nb - 3;
-        const double t = k[6 + band - 2], c = k[6 + np + band - 2];
+        const double t = ka, c = kb;
         const double sg = sqrt(g);
         b0 = f32r(sg + g * t); b1 = f32r(-2 * sg * c); b2 = f32r(sg - g * t);
         a0 = f32r(sg + t); a1 = b1; a2 = f32r(sg - t);
     }
     bb[0] = b0; bb[1] = b1; bb[2] = b2;
     aa[0] = a0; aa[1] = a1; aa[2] = a2;
+}
+// one section of the equaliser: band `band` of channel pair idx - band * C (idx = band * C + c), taps into bb[3], aa[3]
+__device__ inline void geq_section_of(const void* __restrict__ gain, int in_kind, int idx, int band, int nb,
+                                      const double* __restrict__ k, double* bb, double* aa) {
+    double raw;
+    const double g = geq_linear_gain(gain, in_kind, idx, &raw);
+    int ia, ib;
+    geq_band_const_idx(band, nb, &ia, &ib);
+    geq_section_vals(g, band, nb, k[ia], k[ib], bb, aa);
 }
 
 
@@ -134,7 +163,7 @@ __device__ inline double geq_design_bwd(int band, int nb, double g, const double
     if (band == 1 || band == nb - 1) {
         const int i = (band == 1) ? 0 : 1;
         const double t2 = k[2 + i], stq = k[4 + i];
-        const double u = sqrt(g), q = pow(g, 0.25);
+        const double u = sqrt(g), q = sqrt(u);
         const double du = 0.5 / u, dq = 0.25 * q / g;
         const double p0 = u * t2 + stq * q + 1, p1 = 2 * u * t2 - 2, p2 = u * t2 - stq * q + 1;
         const double d0 = u + stq * q + t2, d1 = 2 * t2 - 2 * u, d2 = u - stq * q + t2;

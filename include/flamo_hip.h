@@ -774,6 +774,11 @@ int fl_eig_c128(const void* A, long a_pitch, int N, int M, void* lam, long l_pit
 int fl_launch_pair_begin(void);
 int fl_launch_pair_pending(void);
 long fl_debug_launch_pair_count(void);      /* grids issued with both roles so far (process-wide) */
+/* tuning: every workgroup w of the next grids with both roles leaves (start, end by the device's constant-rate clock, role
+ * 0 = column pass / 1 = response, HW_ID | XCC_ID << 32) in buf[4 w .. 4 w + 3] (int64; w < 8192), and response block (bx, m) its
+ * phase stamps (after the design, the tables, the cascades, when its operands arrived; the plain launch: start, end) in
+ * buf[32768 + 8 (4096 m + bx) ..] -- 32768 + 8 * 8 * 4096 entries for eight output rows.  NULL: off. */
+int fl_debug_set_pair_stamps(void* buf);
 int fl_launch_pair_flush(void* stream);
 
 /* Cache policy of the pipeline's data streams (process-wide mask; csrc/common.h: enum StreamPolicy names the bits -- one per
