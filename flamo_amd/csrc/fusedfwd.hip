@@ -44,7 +44,7 @@ static thread_local PendingRc t_pending;
 static long long* g_pair_dbg = nullptr;      // fl_debug_set_pair_stamps
 static long g_pair_launches = 0;      // grids issued with both roles (tests check that the path under test is this one)
 // response workgroups per column-pass workgroup in the mixed part of the grid, in percent of the even spread's ratio (100)
-static int g_pair_density = [] { const char* e = getenv("FLAMO_PAIR_DENSITY"); return e ? atoi(e) : 100; }();
+static int g_pair_density = [] { const char* e = getenv("FLAMO_PAIR_DENSITY"); return e ? atoi(e) : 140; }();
 static int g_pair_enabled = [] { const char* e = getenv("FLAMO_LAUNCH_PAIR"); return e ? atoi(e) : 1; }();
 
 long long* pair_dbg() { return g_pair_dbg; }

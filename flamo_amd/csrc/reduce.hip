@@ -66,10 +66,23 @@ __global__ void __launch_bounds__(256) mean_square_kernel(const T* __restrict__ 
 template <typename T>
 __global__ void __launch_bounds__(256) mean_square_final_kernel(const double* __restrict__ partial, int nblocks,
                                                                double inv_count, T* __restrict__ loss) {
-    // eight loads in flight per lane (a few thousand partials behind one workgroup: the round trips, not the adds, are the time);
-    // the order of the additions is fixed
+    // a few thousand partials behind one workgroup: the round trips, not the adds, are the time -- up to sixteen loads per lane
+    // requested together and unconditionally (an index beyond the range reads partial[0] and adds zero: with the guard around the
+    // load the 1792 partials behind the first 2048 of the metric's 3840 were seven round trips in a row); the order of the
+    // additions is fixed
     double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int i = threadIdx.x;
+    {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int k = i + u * 256;
+            v[u] = partial[k < nblocks ? k : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) q[u & 7] += (i + u * 256 < nblocks) ? v[u] : 0.0;
+        i += 16 * 256;
+    }
     for (; i + 7 * 256 < nblocks; i += 8 * 256) {
         double v[8];
 #pragma unroll
