@@ -38,12 +38,19 @@ __global__ void __launch_bounds__(256, sizeof(real_t) == 8 ? 2 : 3) spec_cols_fw
 // PLAIN: no envelope and every sample inside the output (t_lim >= n): the guards are not compiled at all -- left to a
 // run-time flag the compiler evaluates the envelope for every output and selects (25 x (int -> double, double multiply, exp,
 // ldexp, four selects) per item, a third of the kernel's instructions, and 112 registers against 9x).
-template <int A, int B, int VT, int RG, bool PLAIN>
+// FUSE (PLAIN only): the launch also leaves a.Sg = the forward column pass of the tile it stores (fl_spec_cols_fwd of y, the first
+// pass of the gradient's transform when the objective's g_y is a multiple of y: ops.mean_square).  A workgroup's inverse
+// column transforms produce exactly the samples its forward column transforms consume -- the tile goes back through the row
+// buffer and the two forward stages of spec_cols_body.h with the same operations in the same order (the stored float32 sample
+// IS the register value): the pass that re-reads y (a sixth of the step's streaming bytes) and its launch are not run.
+template <int A, int B, int VT, int RG, bool PLAIN, bool FUSE = false>
 __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
+    static_assert(!FUSE || PLAIN, "the fused gradient pass exists for the plain shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int LEN = A * B, LENP = LEN | 1;
     cf* U = reinterpret_cast<cf*>(smem);   // [VT][LENP]
     cf* tw = U + VT * LENP;                 // W_LEN^m
+    cf* t2 = tw + LEN;                      // [CT][B]: W_L^(c * A * kb)   (FUSE)
     int blk = blockIdx.x;
     const int ct = blk % a.nct; blk /= a.nct;
     const int gt = blk % a.ngt;
@@ -77,6 +84,12 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
     };
     load_group(0);                                 // data first, tables behind it (see the forward pass)
     for (int j = threadIdx.x; j < LEN; j += 256) tw[j] = a.W[a.n + j];
+    if constexpr (FUSE) {
+        for (int j = threadIdx.x; j < a.CT * B; j += 256) {
+            const int cl = j / B, kb = j - cl * B;
+            t2[j] = a.W[2 * (c0 + cl) * A * kb];
+        }
+    }
     __syncthreads();
 #pragma unroll 1
     for (int r0 = 0; r0 < NR; r0 += RG) {
@@ -98,15 +111,13 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
     real_t* yb = a.y + (size_t)b * a.t_len * a.G + g0;
     const real_t scale0 = a.dev_scale ? a.scale * *a.dev_scale : a.scale;
     real_t sq = 0;
-    for (int item = threadIdx.x; item < A * VT; item += 256) {
-        const int ka = item / VT, vv = item % VT;
+    static_assert(!FUSE || A * VT <= 256, "fused gradient pass: one second-stage item per thread");
+    auto second_stage = [&](int ka, int vv, cf (&v)[B], auto fused_tag) {
+        constexpr bool FU = decltype(fused_tag)::value;
         const int cl = vv >> a.cgs, gl = vv & (CG - 1);
         const int par = gl & 1;
-        cf v[B];
-        const cf* u = U + vv * LENP + ka * B;
-#pragma unroll
-        for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
         RegFFT<real_t, B, true, false>::run(v);
+        cf* zu = U + vv * LENP + ka;      // FU: the scaled tile value z[t1 = ka + A kb] (per channel: (y[2j], y[2j+1])) goes back to the row buffer
 #pragma unroll
         for (int kb = 0; kb < B; ++kb) {
             const int t1 = ka + A * kb;
@@ -118,11 +129,70 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
             if (!PLAIN && a.env_log2 != 0.0) s *= env_at(a.env_log2, t);
             q.x *= s;
             q.y *= s;
+            if constexpr (FU) zu[A * kb] = cf(v[kb].x * s, v[kb].y * s);      // (the values the forward pass would load and un-swap)
             if (PLAIN || t < a.t_lim) {
                 const unsigned yo = RSZ * ((unsigned)t * (unsigned)a.G + (unsigned)(gl - par));
                 if (st_nt_pol) stv<true>(yb, yo, v2f{q.x, q.y});
                 else stv<false>(yb, yo, v2f{q.x, q.y});
                 sq += q.x * q.x + q.y * q.y;
+            }
+        }
+    };
+    if constexpr (!FUSE) {
+        for (int item = threadIdx.x; item < A * VT; item += 256) {
+            const int ka = item / VT, vv = item % VT;
+            cf v[B];
+            const cf* u = U + vv * LENP + ka * B;
+#pragma unroll
+            for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
+            second_stage(ka, vv, v, std::false_type{});
+        }
+    } else {
+        const bool act = threadIdx.x < A * VT;
+        const int ka = threadIdx.x / VT, vv = threadIdx.x % VT;
+        cf v[B];
+        if (act) {
+            const cf* u = U + vv * LENP + ka * B;
+#pragma unroll
+            for (int tb = 0; tb < B; ++tb) v[tb] = u[tb];
+        }
+        __syncthreads();                           // every second-stage read of the row buffer is done: the tile goes back into it
+        if (act) second_stage(ka, vv, v, std::true_type{});
+        // ---- the forward column pass of the same tile (spec_cols_body.h, its loads replaced by the row buffer)
+        __syncthreads();
+#pragma unroll 1
+        for (int r0 = 0; r0 < NR; ++r0) {
+            const int item = threadIdx.x + r0 * 256;
+            if (item < NIT) {
+                const int tb = item / VT, vv = item % VT;
+                cf w[A];
+                cf* u = U + vv * LENP + tb;
+#pragma unroll
+                for (int ta = 0; ta < A; ++ta) w[ta] = u[ta * B];
+                RegFFT<real_t, A, false>::run(w);
+                u[0] = w[0];                       // (in place: the item's own A slots)
+#pragma unroll
+                for (int ka = 1; ka < A; ++ka) u[ka * B] = w[ka] * tw[ka * tb];
+            }
+        }
+        __syncthreads();
+        cf* out = a.Sg + (size_t)b * a.L1 * a.L2 * a.G + g0;
+        if (threadIdx.x < A * VT) {
+            const int ka = threadIdx.x / VT, vv = threadIdx.x % VT;
+            const int cl = vv >> a.cgs, gl = vv & (CG - 1);
+            const int c = c0 + cl;
+            cf w[B];
+            const cf* u = U + vv * LENP + ka * B;
+#pragma unroll
+            for (int tb = 0; tb < B; ++tb) w[tb] = u[tb];
+            RegFFT<real_t, B, false>::run(w);
+            const cf w1 = a.W[2 * c * ka];
+            const cf* w2 = t2 + cl * B;
+#pragma unroll
+            for (int kb = 0; kb < B; ++kb) {
+                const int k1 = ka + A * kb;
+                const cf r = w[kb] * (w1 * w2[kb]);
+                stv<false>(out, ESZ * (((unsigned)k1 * (unsigned)a.L2 + (unsigned)c) * (unsigned)a.G + (unsigned)gl), v2f{r.x, r.y});
             }
         }
     }
@@ -950,6 +1020,12 @@ static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStrea
     {                                                                                                            \
         size_t lds = ((size_t)VT_ * LENP + LEN + (size_t)VT_ * B) * sizeof(cf);                                  \
         if (inverse && g_cols_inv_min_lds > lds) lds = g_cols_inv_min_lds;                                       \
+        if constexpr (sizeof(real_t) == 4 && !LEAN && A * VT_ <= 256) {                                          \
+            if (inverse && a.Sg) {                                                                               \
+                hipLaunchKernelGGL((spec_cols_inv<A, B, VT_, RG_, true, true>), dim3(nblk), dim3(256), lds, st, a); \
+                return;                                                                                          \
+            }                                                                                                    \
+        }                                                                                                        \
         if (inverse && a.env_log2 == 0.0 && a.t_lim >= a.n)                                                      \
             hipLaunchKernelGGL((spec_cols_inv<A, B, VT_, RG_, true>), dim3(nblk), dim3(256), lds, st, a);        \
         else if (inverse) hipLaunchKernelGGL((spec_cols_inv<A, B, VT_, RG_, false>), dim3(nblk), dim3(256), lds, st, a); \
@@ -1302,7 +1378,16 @@ int FL_SPEC_FN(fl_spec_cols_fwd)(const void* x, int Bn, int t_len, int G, void* 
 }
 
 static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
-                         double env_log2, double* sumsq, void* stream, const real_t* dev_scale = nullptr);
+                         double env_log2, double* sumsq, void* stream, const real_t* dev_scale = nullptr, void* Sg = nullptr);
+// the fused gradient pass (spec_cols_inv<..., FUSE>) exists for float32, the 200 / 300 / 400-point column plans and a tile of at
+// most 256 second-stage items
+static bool cols_inv_grad_ok(int nfft, int G) {
+    if (sizeof(real_t) != 4) return false;
+    int l1 = 0, l2 = 0;
+    if (G < 2 || (G & 1) || spec_plan(nfft, l1, l2) != FL_OK) return false;
+    const int a_len = l1 == 200 ? 8 : l1 == 300 ? 12 : l1 == 400 ? 16 : 0;
+    return a_len && a_len * cols_vt(G, l1) <= 256;
+}
 int FL_SPEC_FN(fl_spec_cols_inv)(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                          double env_log2, void* stream) {
     return cols_inv_impl(S2, y, Bn, t_len, t_out, G, W, nfft, scale, env_log2, nullptr, stream);
@@ -1311,6 +1396,13 @@ int FL_SPEC_FN(fl_spec_cols_inv_sumsq)(const void* S2, void* y, int Bn, int t_le
                                double env_log2, void* sumsq_parts, void* stream) {
     FL_REQUIRE(sumsq_parts, "spec_cols_inv_sumsq: null pointer");
     return cols_inv_impl(S2, y, Bn, t_len, t_out, G, W, nfft, scale, env_log2, (double*)sumsq_parts, stream);
+}
+int FL_SPEC_FN(fl_spec_cols_inv_grad_supported)(int nfft, int G) { return cols_inv_grad_ok(nfft, G) ? 1 : 0; }
+int FL_SPEC_FN(fl_spec_cols_inv_sumsq_grad)(const void* S2, void* y, void* Sg, int Bn, int G, const void* W, int nfft, double scale,
+                                    void* sumsq_parts, void* stream) {
+    FL_REQUIRE(sumsq_parts && Sg, "spec_cols_inv_sumsq_grad: null pointer");
+    FL_REQUIRE(cols_inv_grad_ok(nfft, G), "spec_cols_inv_sumsq_grad: shape not taken (fl_spec_cols_inv_grad_supported)");
+    return cols_inv_impl(S2, y, Bn, nfft, nfft, G, W, nfft, scale, 0.0, (double*)sumsq_parts, stream, nullptr, Sg);
 }
 int FL_SPEC_FN(fl_spec_cols_inv_scaled)(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                                 const void* dev_scale, double env_log2, void* stream) {
@@ -1326,7 +1418,7 @@ int FL_SPEC_FN(fl_spec_cols_blocks)(int nfft, int Bn, int G) {      // workgroup
 }
 }  // extern "C"
 static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
-                         double env_log2, double* sumsq, void* stream, const real_t* dev_scale) {
+                         double env_log2, double* sumsq, void* stream, const real_t* dev_scale, void* Sg) {
     FL_REQUIRE(S2 && y, "spec_cols_inv: null pointer");
     FL_REQUIRE(reinterpret_cast<uintptr_t>(y) % (2 * RSZ) == 0, "spec_cols_inv: y must be aligned to two samples");
     FL_REQUIRE(t_out >= 0 && t_out <= t_len, "spec_cols_inv: t_out must be in [0, t_len]");
@@ -1340,6 +1432,7 @@ static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, 
     a.env_log2 = env_log2;
     a.sumsq = sumsq;
     a.dev_scale = dev_scale;
+    a.Sg = (cf*)Sg;
     a.pol = (stream_policy() >> 2) & 3u;      // POL_INV_LD_NT, POL_INV_ST_NT
     a.stamp = walk_successor_stamp();
     return cols_launch(true, a, Bn, (hipStream_t)stream);

@@ -54,6 +54,9 @@ struct ColsArgs {
                           // of the input: ops.mean_square) -- a multiplication pass over the result otherwise
     double* sumsq;        // inverse, optional: sumsq[workgroup] = sum of the squares of the samples this workgroup stored (the
                           // objective's reduction rides in the pass that produces y: ops.mean_square never re-reads it)
+    cf* Sg;               // inverse, optional: (Bn, L1, L2, G) -- the FORWARD column pass of the samples this launch stores (what
+                          // fl_spec_cols_fwd of y leaves: the first pass of the gradient's transform when g_y is a multiple of y),
+                          // formed from the tile in registers: y is not read back (spec_cols_inv<..., FUSE>)
     unsigned pol;         // cache policy of this launch's streams: bit 0 non-temporal loads, bit 1 non-temporal stores (common.h: StreamPolicy)
     long long* stamp;     // measurement, or null: the inverse pass's workgroup 0 leaves the device clock here when it starts
                           // (with spec_mid_walk's own stamps: that kernel's whole slot in a replayed step; fl_debug_set_walk_stamps)

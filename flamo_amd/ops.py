@@ -871,13 +871,28 @@ def _spec_mid(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, want_inverse, spec_sca
     return S2, Xs
 
 
-def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2, want_sumsq=False, dev_scale=None):
+def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2, want_sumsq=False, dev_scale=None, grad_cols=False, sg_buf=None):
     """-> y (B, t_len, G); with want_sumsq also the per-workgroup partial sums of y^2 (double) the same launch leaves behind;
-    dev_scale: a device scalar of the pipeline's real dtype multiplied into `scale` by the kernel"""
+    dev_scale: a device scalar of the pipeline's real dtype multiplied into `scale` by the kernel; grad_cols (with want_sumsq, plain
+    shape): also Sg = _spec_cols_fwd(y), formed by the same launch from its tiles (-> y, parts, Sg)"""
     alloc = torch.zeros if t_len > t_out else torch.empty
     real = _rdtype(S2)
     y = alloc((B, t_len, G), dtype=real, device=S2.device)
     parts = None
+    if grad_cols:
+        assert want_sumsq and t_len == t_out == nfft and env_log2 == 0.0
+        nblk = int(_spec_fn("fl_spec_cols_blocks", real)(nfft, B, G))
+        parts = torch.empty(max(nblk, 1), dtype=torch.float64, device=S2.device)
+        # (sg_buf: a dead scratch array of the same size -- the forward transform's column pass, consumed by the row kernel --
+        # so that the step's streaming arrays stay four, as without the fused pass)
+        n_sg = B * (nfft // 2) * G
+        Sg = sg_buf if sg_buf is not None and sg_buf.numel() == n_sg and sg_buf.dtype == S2.dtype and sg_buf.data_ptr() != S2.data_ptr() \
+            else torch.empty(n_sg, dtype=S2.dtype, device=S2.device)
+        with kernel_timer.span("spec_cols_inv+grad_cols"):
+            _lib.check(_spec_fn("fl_spec_cols_inv_sumsq_grad", real)(S2.data_ptr(), y.data_ptr(), Sg.data_ptr(), B, G,
+                                                                     twiddles(nfft, real, S2.device).data_ptr(), nfft, scale,
+                                                                     parts.data_ptr(), _stream()), "spec_cols_inv_sumsq_grad")
+        return y, parts, Sg
     with kernel_timer.span("spec_cols_inv"):
         if want_sumsq:
             nblk = int(_spec_fn("fl_spec_cols_blocks", real)(nfft, B, G))
@@ -1019,12 +1034,20 @@ class _SpectralApply(torch.autograd.Function):
             S2, Xs = _spec_mid_walk(S, B, NI, NO, nfft, Hp, False, ctx.needs_input_grad[1], scale_f, 0, 0)
         else:
             S2, Xs = _spec_mid(S, B, NI, NO, nfft, Hp, False, ctx.needs_input_grad[1], True, scale_f, 0, 0)
-        y, parts = _spec_cols_inv(S2, B, nfft, nfft, NO, nfft, scale_i, env_i, want_sumsq=True)
+        # (the gradient's first pass rides in the inverse pass when this operator's output went into mean_square the last time
+        # it ran with this shape -- _grad_cols_key / GRAD_COLS_IN_FORWARD)
+        key = _grad_cols_key(x, nfft, NI, NO)
+        Sg = None
+        if GRAD_COLS_IN_FORWARD and key in _GRAD_COLS_SEEN and env_i == 0.0 and any(ctx.needs_input_grad[:2]) and \
+                _spec_fn("fl_spec_cols_inv_grad_supported", x.dtype)(nfft, NO):
+            y, parts, Sg = _spec_cols_inv(S2, B, nfft, nfft, NO, nfft, scale_i, env_i, want_sumsq=True, grad_cols=True, sg_buf=S)
+        else:
+            y, parts = _spec_cols_inv(S2, B, nfft, nfft, NO, nfft, scale_i, env_i, want_sumsq=True)
         ctx.save_for_backward(Hp, *([Xs] if Xs is not None else []))
         ctx.cfg = (nfft, scale_f, env_f, scale_i, env_i, T, NI, NO, walk)
         # what an objective computed from y alone can reuse (mean_square): the partial sums the inverse pass left behind, and
         # everything the backward pass needs -- see _SpectralMeanSquare
-        y._flamo_sa = _SpectralTag(x, Hrm, Hp, Xs, ctx.cfg, parts, y._version)
+        y._flamo_sa = _SpectralTag(x, Hrm, Hp, Xs, ctx.cfg, parts, y._version, Sg, key)
         return y
 
     @staticmethod
@@ -1034,7 +1057,7 @@ class _SpectralApply(torch.autograd.Function):
             + (None, None, None, None, None)
 
     @staticmethod
-    def _backward(cfg, Hp, Xkept, need_x, need_h, gy, out_scale, host_factor=1.0):
+    def _backward(cfg, Hp, Xkept, need_x, need_h, gy, out_scale, host_factor=1.0, Sg=None):
         """Gradients (gx, gH) for the output gradient gy -- or, with out_scale (a device scalar c of gy's dtype) and host_factor
         (a Python float f), for (c f) * gy without forming it: the pipeline is linear, so the factor is applied where the
         results are small (f rides in the walking kernel's transform scale, c in its epilogue: no launch of its own)."""
@@ -1045,7 +1068,10 @@ class _SpectralApply(torch.autograd.Function):
             g = g.clone()
         B = g.shape[0]
         # irfft' : g_Y[k] = w_k scale_i sum_t g_y[t] e_i(t) exp(-j w_k t) -- a forward transform with doubled interior bins
-        Sg = _spec_cols_fwd(g, nfft, env_i, site=1)
+        # (Sg given: its column pass was formed by the forward pass's inverse launch from the tiles of y -- _SpectralMeanSquare)
+        kept_sg = Sg is not None      # (a tensor the autograd node keeps: spec_mid works in place when NI == NO -- it gets a copy)
+        if Sg is None:
+            Sg = _spec_cols_fwd(g, nfft, env_i, site=1)
         gx = gH = None
         if walk:
             if need_h:
@@ -1055,7 +1081,7 @@ class _SpectralApply(torch.autograd.Function):
                 if _walk_applies(nfft, B, NO, NI):
                     S3, _ = _spec_mid_walk(Sg, B, NO, NI, nfft, Hp, True, False, scale_i, 1, 1)
                 else:
-                    S3, _ = _spec_mid(Sg, B, NO, NI, nfft, Hp, True, False, True, scale_i, 1, 1)
+                    S3, _ = _spec_mid(Sg.clone() if kept_sg else Sg, B, NO, NI, nfft, Hp, True, False, True, scale_i, 1, 1)
                 # (the objective's factor: its host part in the pass's scale, its device part multiplied in by the kernel)
                 gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f * (host_factor if out_scale is not None else 1.0), env_f,
                                     dev_scale=out_scale)
@@ -1065,7 +1091,8 @@ class _SpectralApply(torch.autograd.Function):
             # that walks the batch -- the gradient's spectrum is never written and read back (fl_spec_gradh_loop_*)
             return None, _spec_gradh_loop(Sg, kept[0], B, NI, NO, nfft, scale_i, host_factor if out_scale is not None else 1.0, out_scale)
         # rfft' : g_x[t] = scale_f e_f(t) Re sum_k g_X[k] exp(+j w_k t), g_X = H^H g_Y -- an inverse transform with halved interior bins
-        S3, gYs = _spec_mid(Sg, B, NO, NI if need_x else NO, nfft, Hp if need_x else None, True, need_h, need_x, scale_i, 1, 1)
+        S3, gYs = _spec_mid(Sg.clone() if kept_sg and need_x else Sg, B, NO, NI if need_x else NO, nfft, Hp if need_x else None, True, need_h,
+                            need_x, scale_i, 1, 1)
         if need_x:
             gx = _spec_cols_inv(S3, B, T, min(T, nfft), NI, nfft, scale_f * (host_factor if out_scale is not None else 1.0), env_f,
                                 dev_scale=out_scale)
@@ -1078,10 +1105,23 @@ class _SpectralApply(torch.autograd.Function):
 
 class _SpectralTag:
     """Rides on the tensor _SpectralApply returns (attribute ``_flamo_sa``): the inputs and kept arrays of that evaluation."""
-    __slots__ = ("x", "Hrm", "Hp", "Xs", "cfg", "parts", "version")
+    __slots__ = ("x", "Hrm", "Hp", "Xs", "cfg", "parts", "version", "Sg", "key")
 
-    def __init__(self, x, Hrm, Hp, Xs, cfg, parts, version):
+    def __init__(self, x, Hrm, Hp, Xs, cfg, parts, version, Sg=None, key=None):
         self.x, self.Hrm, self.Hp, self.Xs, self.cfg, self.parts, self.version = x, Hrm, Hp, Xs, cfg, parts, version
+        self.Sg, self.key = Sg, key
+
+
+# The first pass of the gradient's transform inside the forward pass's inverse launch (fl_spec_cols_inv_sumsq_grad_*): worth a
+# 98 MB store at BASELINE configs[1] only when the backward pass of mean_square(y) follows -- which the operator cannot know when
+# it runs.  It goes by what happened the last time: a shape whose output went into mean_square AND was differentiated is
+# remembered (_SpectralMeanSquare.backward) and takes the fused launch from then on; a miss costs that store, never a result.
+GRAD_COLS_IN_FORWARD = True
+_GRAD_COLS_SEEN = set()
+
+
+def _grad_cols_key(x, nfft, NI, NO):
+    return (int(nfft), int(x.shape[0]), int(NI), int(NO), x.dtype, x.device.index)
 
 
 class _SpectralMeanSquare(torch.autograd.Function):
@@ -1098,16 +1138,22 @@ class _SpectralMeanSquare(torch.autograd.Function):
         fn = _lib.lib().fl_mean_square_final_f32 if real == torch.float32 else _lib.lib().fl_mean_square_final_f64
         with kernel_timer.span("mean_square_final"):
             _lib.check(fn(tag.parts.data_ptr(), tag.parts.numel(), 1.0 / y.numel(), loss.data_ptr(), _stream()), "mean_square_final")
-        ctx.save_for_backward(y, tag.Hp, *([tag.Xs] if tag.Xs is not None else []))
+        ctx.has_xs, ctx.has_sg = tag.Xs is not None, tag.Sg is not None
+        ctx.save_for_backward(y, tag.Hp, *([tag.Xs] if ctx.has_xs else []), *([tag.Sg] if ctx.has_sg else []))
         ctx.cfg = tag.cfg
+        ctx.key = tag.key
         return loss
 
     @staticmethod
     def backward(ctx, gloss):
         y, Hp, *kept = ctx.saved_tensors
+        Xs = kept.pop(0) if ctx.has_xs else None
+        Sg = kept.pop(0) if ctx.has_sg else None
+        if ctx.key is not None:
+            _GRAD_COLS_SEEN.add(ctx.key)           # the next forward pass of this shape forms the gradient's column pass itself
         c = gloss.to(y.dtype).reshape(())          # device scalar in the pipeline's precision (no launch when it already is)
-        gx, gH = _SpectralApply._backward(ctx.cfg, Hp, kept[0] if kept else None, ctx.needs_input_grad[0], ctx.needs_input_grad[1], y, c,
-                                          2.0 / y.numel())
+        gx, gH = _SpectralApply._backward(ctx.cfg, Hp, Xs, ctx.needs_input_grad[0], ctx.needs_input_grad[1], y, c,
+                                          2.0 / y.numel(), Sg=Sg)
         return gx, gH, None, None
 
 

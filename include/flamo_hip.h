@@ -197,6 +197,14 @@ int fl_spec_cols_inv_f32(const void* S2, void* y, int Bn, int t_len, int t_out, 
 int fl_spec_cols_inv_sumsq_f32(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                                double env_log2, void* sumsq_parts, void* stream);
 int fl_spec_cols_blocks_f32(int nfft, int Bn, int G);
+/* K3 (plain shape: every sample stored, no envelope) that also leaves Sg = what fl_spec_cols_fwd_f32 of the y it stores would
+ * leave -- the first pass of the GRADIENT's transform when the objective's g_y is a multiple of y (trainer.py:177-190 with a
+ * squared-error criterion: loss.backward() starts with rfft(g_y), dsp.py:114 under autograd) -- formed from the tile in
+ * registers: the backward pass does not re-read y.  fl_spec_cols_inv_grad_supported_*: 1 where the fused form exists
+ * (float32; 200 / 300 / 400-point column plans), else the caller runs fl_spec_cols_fwd on y. */
+int fl_spec_cols_inv_grad_supported_f32(int nfft, int G);
+int fl_spec_cols_inv_sumsq_grad_f32(const void* S2, void* y, void* Sg, int Bn, int G, const void* W, int nfft, double scale,
+                                    void* sumsq_parts, void* stream);
 /* K3 with a DEVICE scalar (float; double in the _f64 form) multiplied into `scale`: the gradient of the input under an
  * objective whose factor lives on the device (trainer.py:177-190: loss.backward() hands 2 g / N down as a tensor) -- a
  * multiplication pass over the (Bn, t_len, G) result otherwise */
@@ -239,6 +247,9 @@ int fl_spec_cols_inv_sumsq_f64(const void* S2, void* y, int Bn, int t_len, int t
 int fl_spec_cols_blocks_f64(int nfft, int Bn, int G);
 int fl_spec_cols_inv_scaled_f64(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                                 const void* dev_scale, double env_log2, void* stream);
+int fl_spec_cols_inv_grad_supported_f64(int nfft, int G);      /* 0: no fused form in float64 */
+int fl_spec_cols_inv_sumsq_grad_f64(const void* S2, void* y, void* Sg, int Bn, int G, const void* W, int nfft, double scale,
+                                    void* sumsq_parts, void* stream);
 int fl_permute_bins_c128(const void* src, long src_pitch, void* dst, long dst_pitch, int nplanes, int nfft, int inverse,
                          void* stream);
 

@@ -158,3 +158,62 @@ def test_fused_mean_square_only_for_the_pipelines_own_output(gpu):
     y.retain_grad()
     (gy,) = torch.autograd.grad(ops.mean_square(y), y)
     cc("gy", gy, 2.0 * y.detach() / y.numel(), 1e-06)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nfft,N,B,with_x", [(96000, 8, 5, False), (96000, 8, 3, True), (96000, 4, 2, False), (192000, 8, 2, False),
+                                             (144000, 4, 2, True), (96000, 16, 2, False)])
+def test_gradient_column_pass_inside_the_forward_pass(gpu, nfft, N, B, with_x):
+    """fl_spec_cols_inv_sumsq_grad_f32: once the output of an operator of some shape has gone into ops.mean_square and been
+    differentiated, the next forward pass of that shape leaves the gradient's first column pass (fl_spec_cols_fwd of y) from the
+    tiles of its inverse column pass -- y is not read back.  Same operations on the same float32 values: output, loss and gradients
+    EQUAL the two-pass form's, the backward pass runs no column pass of its own (only the input gradient's inverse one), a second
+    backward over the same graph is as good as the first (16 channels: the 32-wide tile and the in-place row kernel), and a plan
+    that is not taken (225-point columns) keeps the separate pass."""
+    from flamo_amd import _lib, ops
+    torch.manual_seed(nfft % 977 + N)
+    M = nfft // 2 + 1
+    H0 = ops.permute_bins(torch.randn(M, N, N, device=gpu, dtype=torch.complex64) / N ** 0.5, nfft)
+    x0 = torch.randn(B, nfft, N, device=gpu)
+    taken = bool(_lib.lib().fl_spec_cols_inv_grad_supported_f32(nfft, N))
+    assert taken == (nfft in (96000, 192000))      # (200- and 400-point column plans; 144000 has 225-point columns: not taken)
+
+    def run(twice=False):
+        H = H0.clone().requires_grad_(True)
+        x = x0.clone().requires_grad_(with_x)
+        ops.kernel_timer.reset(True)
+        y = ops.spectral_apply(x, H, nfft)
+        loss = ops.mean_square(y)
+        g = torch.autograd.grad(3.0 * loss, [H] + ([x] if with_x else []), retain_graph=twice)
+        if twice:
+            g2 = torch.autograd.grad(3.0 * loss, [H] + ([x] if with_x else []))
+            for a, b in zip(g, g2):
+                assert torch.equal(a, b)
+        torch.cuda.synchronize()
+        used = [k for k, v in ops.kernel_timer.records.items() for _ in v]      # one entry per launch
+        ops.kernel_timer.enabled = False
+        return [y.detach(), loss.detach()] + [t.detach() for t in g], used
+
+    ops._GRAD_COLS_SEEN.clear()
+    try:
+        ops.GRAD_COLS_IN_FORWARD = False
+        plain, used0 = run()
+        assert "spec_cols_inv+grad_cols" not in used0
+        ops._GRAD_COLS_SEEN.clear()
+        ops.GRAD_COLS_IN_FORWARD = True
+        first, used1 = run()                      # nothing remembered yet: the two-pass form, and the shape is remembered
+        assert "spec_cols_inv+grad_cols" not in used1
+        fused, used2 = run(twice=True)
+        assert ("spec_cols_inv+grad_cols" in used2) == taken, used2
+        if taken:
+            assert "spec_cols_fwd" in used0 and used2.count("spec_cols_fwd") == used0.count("spec_cols_fwd") - 1, (used0, used2)
+        for a, b, c in zip(plain, first, fused):
+            assert torch.equal(a, b)
+            assert torch.equal(a, c), float((a - c).abs().max())
+        # evaluation without a backward pass afterwards: the value is right whichever launch ran
+        with torch.no_grad():
+            y = ops.spectral_apply(x0, H0, nfft)
+            assert torch.equal(y, plain[0]) and torch.equal(ops.mean_square(y), plain[1])
+    finally:
+        ops.GRAD_COLS_IN_FORWARD = True
+        ops._GRAD_COLS_SEEN.clear()
