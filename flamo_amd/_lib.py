@@ -70,6 +70,8 @@ _SIGNATURES = {
     "fl_spec_cols_inv_sumsq_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _d, _d, _vp, _vp]),
     "fl_spec_cols_blocks_f32": (_i, [_i, _i, _i]),
     "fl_spec_cols_blocks_f64": (_i, [_i, _i, _i]),
+    "fl_spec_cols_inv_inplace_ok_f32": (_i, [_i, _i]),
+    "fl_spec_cols_inv_inplace_ok_f64": (_i, [_i, _i]),
     "fl_spec_cols_inv_grad_supported_f32": (_i, [_i, _i]),
     "fl_spec_cols_inv_grad_supported_f64": (_i, [_i, _i]),
     "fl_spec_cols_inv_sumsq_grad_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _d, _vp, _vp]),

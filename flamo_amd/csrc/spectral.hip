@@ -1397,6 +1397,14 @@ int FL_SPEC_FN(fl_spec_cols_inv_sumsq)(const void* S2, void* y, int Bn, int t_le
     FL_REQUIRE(sumsq_parts, "spec_cols_inv_sumsq: null pointer");
     return cols_inv_impl(S2, y, Bn, t_len, t_out, G, W, nfft, scale, env_log2, (double*)sumsq_parts, stream);
 }
+/* 1: the inverse column pass may write y over its own input (y = S2's storage read as real (Bn, nfft, G)): a workgroup's tile of
+ * samples occupies the bytes of the tile of column values it has read in full before its first store -- when one tile carries
+ * all G channels (G <= the tile width) and every sample is stored (t_len = t_out = nfft) */
+int FL_SPEC_FN(fl_spec_cols_inv_inplace_ok)(int nfft, int G) {
+    int l1 = 0, l2 = 0;
+    if (G < 2 || (G & 1) || spec_plan(nfft, l1, l2) != FL_OK) return 0;
+    return G <= cols_vt(G, l1) ? 1 : 0;
+}
 int FL_SPEC_FN(fl_spec_cols_inv_grad_supported)(int nfft, int G) { return cols_inv_grad_ok(nfft, G) ? 1 : 0; }
 int FL_SPEC_FN(fl_spec_cols_inv_sumsq_grad)(const void* S2, void* y, void* Sg, int Bn, int G, const void* W, int nfft, double scale,
                                     void* sumsq_parts, void* stream) {

@@ -877,7 +877,15 @@ def _spec_cols_inv(S2, B, t_len, t_out, G, nfft, scale, env_log2, want_sumsq=Fal
     shape): also Sg = _spec_cols_fwd(y), formed by the same launch from its tiles (-> y, parts, Sg)"""
     alloc = torch.zeros if t_len > t_out else torch.empty
     real = _rdtype(S2)
-    y = alloc((B, t_len, G), dtype=real, device=S2.device)
+    if INVERSE_IN_PLACE and t_len == t_out == nfft and S2.numel() == B * (nfft // 2) * G and S2.is_contiguous() and \
+            _spec_fn("fl_spec_cols_inv_inplace_ok", real)(nfft, G):
+        # y over the scratch it is transformed from (a workgroup's tile of samples is the bytes of the tile of column values it
+        # has read before its first store): one streaming array less in the step -- the arrays' total, not only the passes'
+        # bytes, is what the memory-side cache sees
+        # (a tensor of its own over the same storage, not a view of S2: the caller hands it out as a Function's output)
+        y = torch.empty(0, dtype=real, device=S2.device).set_(S2.untyped_storage(), 2 * S2.storage_offset(), (B, t_len, G))
+    else:
+        y = alloc((B, t_len, G), dtype=real, device=S2.device)
     parts = None
     if grad_cols:
         assert want_sumsq and t_len == t_out == nfft and env_log2 == 0.0
@@ -964,6 +972,7 @@ def _spec_mid_walk(S, B, NI, NO, nfft, Hrm, conj_t, want_spec, spec_scale, inter
     return S2, Xp
 
 
+INVERSE_IN_PLACE = True      # False: the inverse column pass writes a fresh (B, nfft, G) array (see _spec_cols_inv)
 GRADH_LOOP = True      # False: the layered backward (spec_mid without a response + mimo_gradh); tests compare the two
 # The one-launch form's parallelism is (row pairs x channel groups) -- 202 workgroups at nfft = 96000 -- whatever the batch; the
 # layered form's grows with the batch.  Measured on an MI355X (tools/dbg/gradloop_dbg.py): 29.5 against 36.1 us at two items in

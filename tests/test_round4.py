@@ -194,8 +194,9 @@ def test_inverse_column_pass_leaves_the_sum_of_squares(gpu, dt, nfft, G, B, t_ou
     torch.manual_seed(nfft + G)
     L = nfft // 2
     S2 = torch.randn(B * L * G, dtype=CD[dt], device=gpu)
-    y0 = ops._spec_cols_inv(S2, B, nfft, t_out, G, nfft, 1.0 / nfft, ops.env_log2_of(20.0, nfft))
-    y1, parts = ops._spec_cols_inv(S2, B, nfft, t_out, G, nfft, 1.0 / nfft, ops.env_log2_of(20.0, nfft), want_sumsq=True)
+    # (a full-length output is written over the scratch it is transformed from: ops.INVERSE_IN_PLACE -- each call gets its own)
+    y0 = ops._spec_cols_inv(S2.clone(), B, nfft, t_out, G, nfft, 1.0 / nfft, ops.env_log2_of(20.0, nfft))
+    y1, parts = ops._spec_cols_inv(S2.clone(), B, nfft, t_out, G, nfft, 1.0 / nfft, ops.env_log2_of(20.0, nfft), want_sumsq=True)
     assert torch.equal(y0, y1)
     assert parts.dtype == torch.float64 and parts.numel() == int(ops._spec_fn("fl_spec_cols_blocks", dt)(nfft, B, G))
     want = (y1.double() ** 2).sum()
