@@ -758,6 +758,7 @@ def main():
             f"spec_mid[{NCH}->{NCH},H,inv,spec]": 3 * sig + hb,               # scratch in; spectrum (kept for backward), scratch out; H
             f"spec_mid[{NCH}->{NCH},spec]": 2 * sig,                          # backward: scratch in, dL/dY out
             "spec_cols_inv": 2 * sig,
+            "spec_cols_inv+grad_cols": 3 * sig,                              # scratch in; y out, the gradient's column pass out (ops.GRAD_COLS_IN_FORWARD)
             f"spec_mid_walk[{NCH}->{NCH},spec]": 3 * sig + hb,                # scratch in; scratch out, spectrum kept for backward; H
             f"spec_mid_walk[{NCH}->{NCH}]": 2 * sig + hb,
             "spec_gradh_walk": 2 * sig + hb,                                 # gradient scratch in, kept spectrum in, dL/dH out
