@@ -192,7 +192,9 @@ __global__ void __launch_bounds__(256) spec_cols_inv(ColsArgs a) {
             for (int kb = 0; kb < B; ++kb) {
                 const int k1 = ka + A * kb;
                 const cf r = w[kb] * (w1 * w2[kb]);
-                stv<false>(out, ESZ * (((unsigned)k1 * (unsigned)a.L2 + (unsigned)c) * (unsigned)a.G + (unsigned)gl), v2f{r.x, r.y});
+                const unsigned so = ESZ * (((unsigned)k1 * (unsigned)a.L2 + (unsigned)c) * (unsigned)a.G + (unsigned)gl);
+                if (a.pol & 4u) stv<true>(out, so, v2f{r.x, r.y});
+                else stv<false>(out, so, v2f{r.x, r.y});
             }
         }
     }
@@ -1441,7 +1443,7 @@ static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, 
     a.sumsq = sumsq;
     a.dev_scale = dev_scale;
     a.Sg = (cf*)Sg;
-    a.pol = (stream_policy() >> 2) & 3u;      // POL_INV_LD_NT, POL_INV_ST_NT
+    a.pol = ((stream_policy() >> 2) & 3u) | ((stream_policy() & POL_INV_SG_NT) ? 4u : 0u);      // POL_INV_LD_NT, POL_INV_ST_NT, POL_INV_SG_NT
     a.stamp = walk_successor_stamp();
     return cols_launch(true, a, Bn, (hipStream_t)stream);
 }

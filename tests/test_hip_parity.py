@@ -756,7 +756,9 @@ def test_bench_contract_line(gpu):
     sr = d["step_roofline"]
     assert abs(sr["unfused_bytes_per_step"] - 1.057e9) < 2e6 and 0 < sr["frac_of_unfused_floor"] < 1
     assert sr["pipeline_bytes_per_step"] > sr["unfused_bytes_per_step"]
-    for k in ("spec_cols_fwd", "spec_cols_inv", "spec_mid_walk[8->8,spec]", "spec_gradh_walk"):
+    # (the step's streaming launches: the column pass with the response's workgroups, the row kernel, the inverse column pass
+    # that also leaves the gradient's column pass, the gradient's row kernel)
+    for k in ("spec_cols_fwd+response", "spec_cols_inv+grad_cols", "spec_mid_walk[8->8,spec]", "spec_gradh_walk"):
         assert 0.1 < d["kernels"][k]["frac_hbm_peak"] < 1.0, k
     assert "spec_mid_walk" in r["kernel"] and d["params"].startswith("tests/golden/bench_params.npz")
     assert d["input_grad"]["ms_per_step"] > d["ms_per_step"]
