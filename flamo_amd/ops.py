@@ -1054,6 +1054,7 @@ class _SpectralApply(torch.autograd.Function):
             y, parts = _spec_cols_inv(S2, B, nfft, nfft, NO, nfft, scale_i, env_i, want_sumsq=True)
         ctx.save_for_backward(Hp, *([Xs] if Xs is not None else []))
         ctx.cfg = (nfft, scale_f, env_f, scale_i, env_i, T, NI, NO, walk)
+        ctx.speculated = key if Sg is not None else None
         # what an objective computed from y alone can reuse (mean_square): the partial sums the inverse pass left behind, and
         # everything the backward pass needs -- see _SpectralMeanSquare
         y._flamo_sa = _SpectralTag(x, Hrm, Hp, Xs, ctx.cfg, parts, y._version, Sg, key)
@@ -1062,6 +1063,8 @@ class _SpectralApply(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         Hp, *kept = ctx.saved_tensors
+        if ctx.speculated is not None:
+            _GRAD_COLS_SEEN.discard(ctx.speculated)      # another criterion came: this shape stops forming the column pass ahead
         return _SpectralApply._backward(ctx.cfg, Hp, kept[0] if kept else None, ctx.needs_input_grad[0], ctx.needs_input_grad[1], gy, None) \
             + (None, None, None, None, None)
 
@@ -1124,7 +1127,8 @@ class _SpectralTag:
 # The first pass of the gradient's transform inside the forward pass's inverse launch (fl_spec_cols_inv_sumsq_grad_*): worth a
 # 98 MB store at BASELINE configs[1] only when the backward pass of mean_square(y) follows -- which the operator cannot know when
 # it runs.  It goes by what happened the last time: a shape whose output went into mean_square AND was differentiated is
-# remembered (_SpectralMeanSquare.backward) and takes the fused launch from then on; a miss costs that store, never a result.
+# remembered (_SpectralMeanSquare.backward) and takes the fused launch from then on; a miss costs that store, never a result,
+# and a gradient that arrives through the operator's own node instead (another criterion) makes the shape forget.
 GRAD_COLS_IN_FORWARD = True
 _GRAD_COLS_SEEN = set()
 

@@ -214,6 +214,18 @@ def test_gradient_column_pass_inside_the_forward_pass(gpu, nfft, N, B, with_x):
         with torch.no_grad():
             y = ops.spectral_apply(x0, H0, nfft)
             assert torch.equal(y, plain[0]) and torch.equal(ops.mean_square(y), plain[1])
+        if taken:
+            # another criterion on the same shape: its gradient arrives through the operator's own node, with the right value
+            # (the column pass formed ahead is simply not used), and the shape stops forming it
+            key = next(iter(ops._GRAD_COLS_SEEN))
+            H = H0.clone().requires_grad_(True)
+            ops.kernel_timer.reset(True)
+            y = ops.spectral_apply(x0, H, nfft)
+            (gH,) = torch.autograd.grad((y ** 2).mean() * 3.0, [H])
+            torch.cuda.synchronize()
+            assert "spec_cols_inv+grad_cols" in ops.kernel_timer.records and key not in ops._GRAD_COLS_SEEN
+            ops.kernel_timer.enabled = False
+            check_close(f"grad_cols/{nfft}_{N}_{B}/other_criterion", gH, plain[2], 2e-6, max_tol=float("inf"))
     finally:
         ops.GRAD_COLS_IN_FORWARD = True
         ops._GRAD_COLS_SEEN.clear()
