@@ -1022,7 +1022,7 @@ static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStrea
     {                                                                                                            \
         size_t lds = ((size_t)VT_ * LENP + LEN + (size_t)VT_ * B) * sizeof(cf);                                  \
         if (inverse && g_cols_inv_min_lds > lds) lds = g_cols_inv_min_lds;                                       \
-        if constexpr (sizeof(real_t) == 4 && !LEAN && A * VT_ <= 256) {                                          \
+        if constexpr (!LEAN && A * VT_ <= 256) {                                                                 \
             if (inverse && a.Sg) {                                                                               \
                 hipLaunchKernelGGL((spec_cols_inv<A, B, VT_, RG_, true, true>), dim3(nblk), dim3(256), lds, st, a); \
                 return;                                                                                          \
@@ -1381,10 +1381,9 @@ int FL_SPEC_FN(fl_spec_cols_fwd)(const void* x, int Bn, int t_len, int G, void* 
 
 static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                          double env_log2, double* sumsq, void* stream, const real_t* dev_scale = nullptr, void* Sg = nullptr);
-// the fused gradient pass (spec_cols_inv<..., FUSE>) exists for float32, the 200 / 300 / 400-point column plans and a tile of at
-// most 256 second-stage items
+// the fused gradient pass (spec_cols_inv<..., FUSE>) exists for the 200 / 300 / 400-point column plans and a tile of at most 256
+// second-stage items
 static bool cols_inv_grad_ok(int nfft, int G) {
-    if (sizeof(real_t) != 4) return false;
     int l1 = 0, l2 = 0;
     if (G < 2 || (G & 1) || spec_plan(nfft, l1, l2) != FL_OK) return false;
     const int a_len = l1 == 200 ? 8 : l1 == 300 ? 12 : l1 == 400 ? 16 : 0;

@@ -201,7 +201,7 @@ int fl_spec_cols_blocks_f32(int nfft, int Bn, int G);
  * leave -- the first pass of the GRADIENT's transform when the objective's g_y is a multiple of y (trainer.py:177-190 with a
  * squared-error criterion: loss.backward() starts with rfft(g_y), dsp.py:114 under autograd) -- formed from the tile in
  * registers: the backward pass does not re-read y.  fl_spec_cols_inv_grad_supported_*: 1 where the fused form exists
- * (float32; 200 / 300 / 400-point column plans), else the caller runs fl_spec_cols_fwd on y. */
+ * (200 / 300 / 400-point column plans, both precisions), else the caller runs fl_spec_cols_fwd on y. */
 int fl_spec_cols_inv_grad_supported_f32(int nfft, int G);
 /* 1: fl_spec_cols_inv_* may be given y = S2 (the real (Bn, nfft, G) output over the scratch it is transformed from; t_len = t_out
  * = nfft): a workgroup reads its whole tile before its first store and the two tiles are the same bytes when one tile carries all
@@ -251,7 +251,7 @@ int fl_spec_cols_inv_sumsq_f64(const void* S2, void* y, int Bn, int t_len, int t
 int fl_spec_cols_blocks_f64(int nfft, int Bn, int G);
 int fl_spec_cols_inv_scaled_f64(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                                 const void* dev_scale, double env_log2, void* stream);
-int fl_spec_cols_inv_grad_supported_f64(int nfft, int G);      /* 0: no fused form in float64 */
+int fl_spec_cols_inv_grad_supported_f64(int nfft, int G);
 int fl_spec_cols_inv_inplace_ok_f64(int nfft, int G);
 int fl_spec_cols_inv_sumsq_grad_f64(const void* S2, void* y, void* Sg, int Bn, int G, const void* W, int nfft, double scale,
                                     void* sumsq_parts, void* stream);

@@ -80,7 +80,7 @@ def main():
         return c[0] if c else None
     tags = {"spec_mid_walk[8->8,spec]": "spec_mid_walk<16, 15, 8, 8", "spec_gradh_walk": "spec_gradh_walk<16, 15, 8, 8",
             "spec_mid[8->8,H,inv,spec]": "spec_mid<16, 15, 8, 8, true, true", "spec_mid[8->8,spec]": "spec_mid<16, 15, 8, 8, false, false",
-            "spec_cols_fwd": "spec_cols_fwd<", "spec_cols_fwd+response": "cols_fwd_rc_kernel<", "spec_cols_inv": "spec_cols_inv<", "mimo_gradh[cols=32,8x8]": "mimo_gradh_kernel<float, 4, 4>",
+            "spec_cols_fwd": "spec_cols_fwd<", "spec_cols_fwd+response": "cols_fwd_rc_kernel<", "spec_cols_inv": "spec_cols_inv<", "spec_cols_inv+grad_cols": "spec_cols_inv<8, 25, 16, 1, true, true>", "mimo_gradh[cols=32,8x8]": "mimo_gradh_kernel<float, 4, 4>",
             "sos_response_rc": "sos_response_rc_ba_kernel", "sos_response_bwd_rc": "sos_bwd_lanes_kernel<float, 8, 8", "mimo_full": "mimo_full_kernel<float, 8, 4, 1, false>"}
     traffic = {"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 3`, FETCH_SIZE doubled per "
                          f"MI355X_MICROARCH.md; profiles/{tag}_pmc_hbm_traffic.csv"}
