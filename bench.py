@@ -386,6 +386,9 @@ def secondary(dev):
     # tool shards the bins whenever a multi-rank group exists and rank 0 would sit in an all-gather nobody else enters; found by
     # tests/test_dist_rccl.py::test_bench_line_two_ranks_on_one_device)
     tc.train(model, x, target, 3, 1e-3, sharded=False)
+    # (the timed call's own route once, untimed: the first launch of torch's fused Adam loads its code object -- 0.4 s on a box
+    # whose page cache is cold, which a 50-step region once reported as 8 ms per step)
+    tc.train(model, x, target, 5, 1e-3, graphed=True, fused_adam=True, sharded=False)
     clock = {}
 
     def start():

@@ -1022,7 +1022,7 @@ static void launch_cols(bool inverse, const ColsArgs& a, unsigned nblk, hipStrea
     {                                                                                                            \
         size_t lds = ((size_t)VT_ * LENP + LEN + (size_t)VT_ * B) * sizeof(cf);                                  \
         if (inverse && g_cols_inv_min_lds > lds) lds = g_cols_inv_min_lds;                                       \
-        if constexpr (!LEAN && A * VT_ <= 256) {                                                                 \
+        if constexpr (A * VT_ <= 256) {                                                                          \
             if (inverse && a.Sg) {                                                                               \
                 hipLaunchKernelGGL((spec_cols_inv<A, B, VT_, RG_, true, true>), dim3(nblk), dim3(256), lds, st, a); \
                 return;                                                                                          \
@@ -1381,13 +1381,21 @@ int FL_SPEC_FN(fl_spec_cols_fwd)(const void* x, int Bn, int t_len, int G, void* 
 
 static int cols_inv_impl(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                          double env_log2, double* sumsq, void* stream, const real_t* dev_scale = nullptr, void* Sg = nullptr);
-// the fused gradient pass (spec_cols_inv<..., FUSE>) exists for the 200 / 300 / 400-point column plans and a tile of at most 256
-// second-stage items
+// the fused gradient pass (spec_cols_inv<..., FUSE>) exists where one thread takes one second-stage item of the tile (first radix
+// of the column plan x tile width <= 256: every plan but the 441- and 800-point columns and the 32-wide tile of 16-point radices)
+static int cols_first_radix(int l1) {      // A of launch_cols<A, B> (cols_launch)
+    switch (l1) {
+        case 200: return 8; case 300: return 12; case 400: return 16; case 32: return 8; case 64: return 8; case 128: return 16;
+        case 150: return 10; case 225: return 15; case 256: return 16; case 50: return 2; case 75: return 5; case 100: return 4;
+        case 125: return 5; case 250: return 10; case 441: return 21; case 800: return 32;
+        default: return 0;
+    }
+}
 static bool cols_inv_grad_ok(int nfft, int G) {
     int l1 = 0, l2 = 0;
     if (G < 2 || (G & 1) || spec_plan(nfft, l1, l2) != FL_OK) return false;
-    const int a_len = l1 == 200 ? 8 : l1 == 300 ? 12 : l1 == 400 ? 16 : 0;
-    return a_len && a_len * cols_vt(G, l1) <= 256;
+    const int a_len = cols_first_radix(l1);
+    return a_len && a_len * cols_vt(G, l1) <= 256;      // (cols_vt: the tile width cols_launch takes)
 }
 int FL_SPEC_FN(fl_spec_cols_inv)(const void* S2, void* y, int Bn, int t_len, int t_out, int G, const void* W, int nfft, double scale,
                          double env_log2, void* stream) {

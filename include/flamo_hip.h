@@ -201,7 +201,8 @@ int fl_spec_cols_blocks_f32(int nfft, int Bn, int G);
  * leave -- the first pass of the GRADIENT's transform when the objective's g_y is a multiple of y (trainer.py:177-190 with a
  * squared-error criterion: loss.backward() starts with rfft(g_y), dsp.py:114 under autograd) -- formed from the tile in
  * registers: the backward pass does not re-read y.  fl_spec_cols_inv_grad_supported_*: 1 where the fused form exists
- * (200 / 300 / 400-point column plans, both precisions), else the caller runs fl_spec_cols_fwd on y. */
+ * (every column plan whose first radix times the tile width is at most 256 -- all but the 441- and 800-point columns and 16
+ * channels on 16-point radices -- both precisions), else the caller runs fl_spec_cols_fwd on y. */
 int fl_spec_cols_inv_grad_supported_f32(int nfft, int G);
 /* 1: fl_spec_cols_inv_* may be given y = S2 (the real (Bn, nfft, G) output over the scratch it is transformed from; t_len = t_out
  * = nfft): a workgroup reads its whole tile before its first store and the two tiles are the same bytes when one tile carries all

@@ -164,14 +164,16 @@ def test_fused_mean_square_only_for_the_pipelines_own_output(gpu):
 @pytest.mark.parametrize("nfft,N,B,with_x,dt", [(96000, 8, 5, False, torch.float32), (96000, 8, 3, True, torch.float32),
                                                 (96000, 4, 2, False, torch.float32), (192000, 8, 2, False, torch.float32),
                                                 (144000, 4, 2, True, torch.float32), (96000, 16, 2, False, torch.float32),
-                                                (96000, 8, 5, False, torch.float64), (96000, 8, 2, True, torch.float64)])
+                                                (96000, 8, 5, False, torch.float64), (96000, 8, 2, True, torch.float64),
+                                                (4096, 2, 3, True, torch.float32), (65536, 8, 5, False, torch.float32),
+                                                (32000, 4, 2, True, torch.float64), (88200, 4, 2, False, torch.float32)])
 def test_gradient_column_pass_inside_the_forward_pass(gpu, nfft, N, B, with_x, dt):
     """fl_spec_cols_inv_sumsq_grad_f32: once the output of an operator of some shape has gone into ops.mean_square and been
     differentiated, the next forward pass of that shape leaves the gradient's first column pass (fl_spec_cols_fwd of y) from the
     tiles of its inverse column pass -- y is not read back.  Same operations on the same values: output, loss and gradients EQUAL
     the two-pass form's in float32 (1e-13 in float64), the backward pass runs no column pass of its own (only the input gradient's inverse one), a second
-    backward over the same graph is as good as the first (16 channels: the 32-wide tile and the in-place row kernel), and a plan
-    that is not taken (225-point columns) keeps the separate pass."""
+    backward over the same graph is as good as the first (16 channels: the 32-wide tile and the in-place row kernel), small and
+    odd-factor plans, and a plan that is not taken (441-point columns) keeps the separate pass."""
     from flamo_amd import _lib, ops
     torch.manual_seed(nfft % 977 + N)
     M = nfft // 2 + 1
@@ -179,7 +181,7 @@ def test_gradient_column_pass_inside_the_forward_pass(gpu, nfft, N, B, with_x, d
     H0 = ops.permute_bins(torch.randn(M, N, N, device=gpu, dtype=cdt) / N ** 0.5, nfft)
     x0 = torch.randn(B, nfft, N, device=gpu, dtype=dt)
     taken = bool(ops._spec_fn("fl_spec_cols_inv_grad_supported", dt)(nfft, N))
-    assert taken == (nfft in (96000, 192000))      # (200- and 400-point column plans; 144000 has 225-point columns: not taken)
+    assert taken or nfft == 88200      # (every plan but the 441- / 800-point columns: 88200 = 2 x 441 x 100)
 
     def run(twice=False):
         H = H0.clone().requires_grad_(True)
