@@ -72,7 +72,7 @@ struct LanesArgs {
     int npb, rows, seff, s_first, tb, tbp, ntiles, tph, half, L1, nlow, tiles_low, nbx;
     int lds1;              // bytes of ONE set of tile buffers (the kernel takes two)
     long long* stamps;     // tuning: per (block, wavefront) cycles spent in {lane-per-bin phase, first barrier, MFMA, lane-per-section phase, second barrier, whole kernel}
-    int skip;              // tuning: 1 skips the lane-per-bin phase's work, 2 the lane-per-section phase's
+    int skip;              // tuning: 1 skips the lane-per-bin phase's work, 2 the lane-per-section phase's, 4: one order of the two in every wavefront
     unsigned pol;          // cache policy of the operand loads (common.h: POL_LANES_*)
 };
 
@@ -349,21 +349,12 @@ __global__ void __launch_bounds__(sizeof(RT) == 8 ? 384 : 768, sizeof(RT) == 8 ?
         const Bufs B = bufs_at((tile - t_begin) & 1);
         const int np = (T.n + 1) & ~1;
         const bool low = T.low;
-        // ---- the NEXT tile's lane-per-bin work (its operands were requested a tile ago), then the request for the tile after it
-        if (tile + 1 < t_end && !(A.skip & 1)) {
-            bin_work(Tn, bufs_at((tile + 1 - t_begin) & 1));
-        }
-        T = Tn;
-        if (tile + 2 < t_end) {
-            Tn = tile_of(tile + 2);
-            request(Tn);
-        }
-        FL_STAMP(0, tp)
-
-        FL_STAMP(2, tp)
-
-        // ---- lane-per-section work
-        if (wave_on && !(A.skip & 2)) {
+        // The two halves of a trip are independent (the bin work fills the OTHER set of buffers): the wavefronts of a SIMD take
+        // them in opposite orders -- wavefronts 4..7 the sections first -- so that one wavefront's packed arithmetic issues while
+        // its neighbour on the SIMD waits for the bin work's operands and LDS stores (in one order everywhere the whole SIMD
+        // stalls together behind the barrier).
+        auto section_work = [&]() {
+            if (!(wave_on && !(A.skip & 2))) return;
             const P2 C0 = low ? C0lo : C0hi, C1 = low ? C1lo : -C1lo;
             P2 t0 = {(RT)0.0, (RT)0.0}, t1 = {(RT)0.0, (RT)0.0}, t2 = {(RT)0.0, (RT)0.0};
             const P4* qrow = B.qs + (size_t)pl * tbp;
@@ -392,7 +383,24 @@ __global__ void __launch_bounds__(sizeof(RT) == 8 ? 384 : 768, sizeof(RT) == 8 ?
             acc0 += t0;
             acc2 += t2;
             if constexpr (NSUM == 3) acc1 += t1;
+        };
+        const bool sections_first = !(A.skip & 4) && ((wave >> 2) & 1);
+        if (sections_first) section_work();
+        // ---- the NEXT tile's lane-per-bin work (its operands were requested a tile ago), then the request for the tile after it
+        if (tile + 1 < t_end && !(A.skip & 1)) {
+            bin_work(Tn, bufs_at((tile + 1 - t_begin) & 1));
         }
+        T = Tn;
+        if (tile + 2 < t_end) {
+            Tn = tile_of(tile + 2);
+            request(Tn);
+        }
+        FL_STAMP(0, tp)
+
+        FL_STAMP(2, tp)
+
+        // ---- lane-per-section work
+        if (!sections_first) section_work();
         FL_STAMP(3, tp)
         __syncthreads();
         FL_STAMP(1, tp)

@@ -132,6 +132,9 @@ for bpc, tb in ((1, 0), (1, 20), (1, 12), (1, 10)):
     sm = stamps.double().mean(0)
     print("   cycles per wavefront [bin work, barrier, mfma, section work, lifetime x10ns, kernel cycles]: waves 0/3/7/10:", [[int(v) for v in sm[w]] for w in (0, 3, 7, 10)],
           " max kernel", int(stamps[:, :, 5].max()), " core clock MHz", float((stamps[:, :, 5].double() / stamps[:, :, 4].double().clamp_min(1)).mean() * 100))
+    L.fl_debug_set_cascade_stamps(None, 4); t_one_order = timed(f2)
+    L.fl_debug_set_cascade_stamps(None, 0); t_alt = timed(f2)
+    print(f"one order of the two phases in every wavefront {t_one_order:.1f} us, alternating by wavefront group {t_alt:.1f} us")
     L.fl_debug_set_cascade_stamps(None, 2); t_no2 = timed(f2)
     L.fl_debug_set_cascade_stamps(None, 3); t_no12 = timed(f2)
     L.fl_debug_set_cascade_stamps(None, 0)
