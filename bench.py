@@ -281,24 +281,26 @@ def config2_variants(dev, x, steps):
 
 
 # ----------------------------------------------------------------------------- secondary workloads (one GPU)
-def settle_device(local_step, max_steps=300):
-    """Set-up in front of a timed region: repeat ``local_step`` in blocks of ten until two consecutive blocks agree within 1 %
-    (at least 30, at most ``max_steps`` repeats).  Right after a capture -- host work, GPU idle -- the first ~50 replays of a
-    sub-millisecond step run 10-18 % slower than the rest (tools/dbg/archive/replay_transient.py: the device's clock ramp)."""
+def settle_device(local_step, max_steps=400):
+    """Set-up in front of a timed region: repeat ``local_step`` in blocks of twenty until two consecutive blocks agree within
+    0.5 % (at least 100, at most ``max_steps`` repeats).  Right after a capture -- host work, GPU idle -- the first ~100 replays
+    of a sub-millisecond step run up to 10-18 % slower than the rest (tools/dbg/clock_ramp.py: blocks of a hundred replays read
+    308.8, 293.7, 293.8, 293.9 ... us and stay there; the same after two idle seconds): the device's clock ramp.  Round 5's
+    criterion (blocks of ten within 1 %, from 30 repeats on) stopped at 50 and left the ramp's tail in the timed steps (1-2 %)."""
     rep = {"steps": 0, "ms_first_block": None, "ms_last_block": None}
     prev = None
     while rep["steps"] < max_steps:
         torch.cuda.synchronize()
         tb = time.perf_counter()
-        for _ in range(10):
+        for _ in range(20):
             local_step()
         torch.cuda.synchronize()
-        cur = (time.perf_counter() - tb) / 10 * 1e3
-        rep["steps"] += 10
+        cur = (time.perf_counter() - tb) / 20 * 1e3
+        rep["steps"] += 20
         if rep["ms_first_block"] is None:
             rep["ms_first_block"] = round(cur, 4)
         rep["ms_last_block"] = round(cur, 4)
-        if prev is not None and rep["steps"] >= 30 and abs(cur - prev) <= 0.01 * prev:
+        if prev is not None and rep["steps"] >= 100 and abs(cur - prev) <= 0.005 * prev:
             break
         prev = cur
     return rep
@@ -333,7 +335,7 @@ def sustained_walk_launch_ms(dev, reps=40):
 def _graph_ms(fn, inputs, params, steps):
     from flamo_amd.graph import GraphedStep
     gs = GraphedStep(fn, inputs, params)
-    settle_device(gs.replay, max_steps=100)
+    settle_device(gs.replay, max_steps=160)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -858,9 +860,9 @@ def main():
                "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
                "timed_region": ("eager steps" if args.no_graph else
                                 "HIP-graph replays of forward+backward (torch.cuda.CUDAGraph), one replay per step"),
-               "setup_before_warmup": {"what": "after the capture the local step is repeated in blocks of ten until two consecutive "
-                                               "blocks agree within 1 % (the device's clock ramp: the first ~50 replays run 10-18 % "
-                                               "slower); then the W warm-up steps, then the K timed steps",
+               "setup_before_warmup": {"what": "after the capture the local step is repeated in blocks of twenty (at least 100 times) until "
+                                               "two consecutive blocks agree within 0.5 % (the device's clock ramp: the first ~100 "
+                                               "replays run up to 10-18 % slower); then the W warm-up steps, then the K timed steps",
                                        **settle},
                "ms_per_step_steady": {"ms_per_step": elapsed_steady / n_steady * 1e3, "steps": n_steady,
                                       "what": "the same step over this many more iterations right after the timed region"},
@@ -958,7 +960,7 @@ def objective_legs(model, params, x, steps, products):
     res = {}
     for name, fn in legs.items():
         gs = GraphedStep(fn, (x,), params, warmup=2)
-        settle_device(gs.replay, max_steps=100)
+        settle_device(gs.replay, max_steps=160)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -980,7 +982,7 @@ def input_grad_leg(model, params, x, steps, products):
     saved = [p.grad for p in params]
     from flamo_amd.graph import GraphedStep      # differentiates with respect to `params`: the input joins them
     gs = GraphedStep(lambda xx: ops.mean_square(model(xg)), (x,), list(params) + [xg], warmup=2)
-    settle_device(gs.replay, max_steps=100)
+    settle_device(gs.replay, max_steps=160)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):

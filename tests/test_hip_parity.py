@@ -744,7 +744,7 @@ def test_bench_contract_line(gpu):
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "products/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"]
     su = d["setup_before_warmup"]       # the sustained-state set-up is part of the line: how many repeats, first and last block
-    assert 30 <= su["steps"] <= 300 and su["steps"] % 10 == 0 and su["ms_first_block"] > 0 and su["ms_last_block"] > 0
+    assert 100 <= su["steps"] <= 400 and su["steps"] % 20 == 0 and su["ms_first_block"] > 0 and su["ms_last_block"] > 0
     M = 96000 // 2 + 1
     assert abs(d["value"] - 2 * 32 * M * 8 * 8 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
     r = d["roofline"]
