@@ -264,6 +264,8 @@ enum StreamPolicy : unsigned {
     POL_LANES_GH_NT = 1u << 11,  // sos_bwd_lanes: loads of dL/dH (written by the previous launch)
     POL_RC_ST_NT = 1u << 12,     // sos_response_rc_ba: stores of G (read again only by the backward pass)
     POL_INV_SG_NT = 1u << 13,    // spec_cols_inv<..., FUSE>: stores of the gradient's column pass (read by the next launch but one)
+    POL_GRADH_FORWARD = 1u << 14, // spec_gradh_walk: the batch items of a slice first to last (default: last to first -- the inverse column
+                                  // pass wrote the last items' rows last: 285.3 against 286.7 us per replayed step, eight interleaved rounds)
     POL_SITE1_SHIFT = 16,        // bits 16, 17: POL_COLS_LD_NT / POL_COLS_ST_NT of site 1
 };
 unsigned stream_policy();        // the current mask

@@ -596,7 +596,7 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
 
     // cw: the CONSUMER wavefront whose staging region is filled (the wavefront itself when it transfers for itself)
     auto fetch_g = [&](int i, int cw) {  // the A x 64 first-stage inputs of group-0 wavefront cw's own items, item i of the slice
-        const int b = b_lo + i;
+        const int b = b_lo + ((a.pol & POL_GRADH_FORWARD) ? i : n_it - 1 - i);      // (last to first: common.h)
         const unsigned sg_buf = sg_lds + (unsigned)((i % DEPTH) * SBG * 8);
         const int hi = lane >> 5;
         int item0 = 64 * cw + 2 * (lane & 31);
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(512, OCC) spec_gradh_walk(GradhArgs a) {
         }
     };
     auto fetch_x = [&](int i, int cw) {  // X[n][the 64 pairs of wavefront cw] of its side of the unit's block
-        const int b = b_lo + i;
+        const int b = b_lo + ((a.pol & POL_GRADH_FORWARD) ? i : n_it - 1 - i);      // (last to first: common.h)
         const unsigned sx_buf = sx_lds + (unsigned)((i % DEPTH) * SBX * 8);
 #if FL_XP_PAIRS
         int pp = 64 * (cw & 3) + lane;           // a lane's 16 bytes: channels (2q, 2q + 1) of one bin pair
